@@ -1,0 +1,373 @@
+"""Generate the golden fixtures in this directory from the REFERENCE's own code.
+
+Run in the build container only (needs /root/reference; the GPU box never runs
+this):   python tests/golden/make_golden.py
+
+It imports the reference modules SOBER/_settings.py, _utils.py, _weights.py,
+_rchq.py (no stubs) and _gp.py, _kernel.py (import-time stubs for gpytorch /
+botorch, which are not installed) under a dummy ``SOBER`` package, feeds them
+seeded inputs through a duck-typed GP model, and stores inputs + outputs +
+per-level traces as ``.npz``.  gpytorch is absent, so the model's
+``covar_module.forward`` is the oracle's restated base kernel
+(oracle/sober_oracle.py:base_kernel) -- that boundary is parity-unpinned; all
+code above it (predictive_covariance, Kernel, recombination, CAR, make_cov_psd,
+KMeans, cleansing_weights, batch_tanimoto_sim) is the reference's own.
+
+Nothing from /root/reference is copied: fixtures are data (inputs, outputs).
+"""
+import contextlib
+import importlib.util
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/SOBER"
+
+from oracle import sober_oracle as O  # noqa: E402
+from tests.golden.synth import synth, build_spec, checksum, calc_obj_fn, SEED_CALL  # noqa: E402
+
+
+# --------------------------------------------------------------------------- #
+# reference loader
+# --------------------------------------------------------------------------- #
+def _install_stubs():
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+    g = mod("gpytorch")
+    for sub in ("models", "means", "likelihoods", "constraints", "mlls", "distributions",
+                "settings", "priors", "kernels"):
+        setattr(g, sub, mod("gpytorch." + sub))
+    g.models.ExactGP = object
+    g.means.ZeroMean = object
+    g.likelihoods.GaussianLikelihood = object
+    g.constraints.Interval = object
+    g.mlls.ExactMarginalLogLikelihood = object
+    g.distributions.MultivariateNormal = object
+    tp = mod("gpytorch.priors.torch_priors")
+    tp.GammaPrior = object
+    g.priors.torch_priors = tp
+    g.settings.fast_pred_var = contextlib.nullcontext
+    g.settings.fast_computations = contextlib.nullcontext
+    g.settings.cholesky_jitter = lambda **kw: contextlib.nullcontext()
+    b = mod("botorch")
+    b.fit = mod("botorch.fit")
+    b.fit.fit_gpytorch_mll = lambda *a, **k: None
+
+
+def load_reference():
+    _install_stubs()
+    pkg = types.ModuleType("SOBER")
+    pkg.__path__ = [REF]
+    sys.modules["SOBER"] = pkg
+    out = {}
+    for name in ("_settings", "_utils", "_weights", "_rchq", "_gp", "_kernel"):
+        spec = importlib.util.spec_from_file_location(f"SOBER.{name}", f"{REF}/{name}.py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f"SOBER.{name}"] = m
+        spec.loader.exec_module(m)
+        out[name] = m
+    out["_settings"].setting_parameters(device=torch.device("cpu"), dtype=torch.double)
+    return out
+
+
+class _Pred:
+    def __init__(self, mean, variance):
+        self.mean, self.variance = mean, variance
+
+
+class _Lik:
+    def __init__(self, noise):
+        self.noise = torch.tensor([noise], dtype=torch.double)
+
+    def eval(self):
+        return self
+
+    def __call__(self, pred):
+        return _Pred(pred.mean, pred.variance + self.noise)
+
+
+class DuckModel:
+    """The attributes the reference path touches: covar_module.forward,
+    train_inputs, likelihood.noise, prediction_strategy.covar_cache, eval(), __call__."""
+
+    def __init__(self, spec: O.GPSpec):
+        self.spec = spec
+        self.train_inputs = (spec.X_obs,)
+        self.likelihood = _Lik(spec.noise)
+        self.covar_module = types.SimpleNamespace(forward=lambda x, y: O.base_kernel(spec, x, y))
+        self.prediction_strategy = types.SimpleNamespace(covar_cache=spec.S_cache)
+
+    def eval(self):
+        return self
+
+    def __call__(self, x):
+        mean = O.predict_mean(x, self.spec)
+        return _Pred(mean, torch.zeros_like(mean))
+
+
+CASES = [
+    dict(name="cfg1_rbf_ard", kind=O.RBF, mode="predictive_covariance", N=2000, M=100, d=2, b=10,
+         n_obs=30, ard=True, seed=0),
+    dict(name="rbf_noleft", kind=O.RBF, mode="predictive_covariance", N=2560, M=64, d=3, b=10,
+         n_obs=20, seed=1),
+    dict(name="rbf_b30", kind=O.RBF, mode="predictive_covariance", N=3000, M=120, d=5, b=30,
+         n_obs=50, seed=2, outputscale=1.7),
+    dict(name="matern_b20", kind=O.MATERN52, mode="predictive_covariance", N=3000, M=100, d=6, b=20,
+         n_obs=40, seed=3, ard=True),
+    dict(name="tanimoto_weighted", kind=O.TANIMOTO, mode="weighted_predictive_covariance", N=1500,
+         M=64, d=128, b=10, n_obs=25, seed=4, mean_const=0.3),
+    dict(name="rbf_weighted", kind=O.RBF, mode="weighted_predictive_covariance", N=2000, M=80, d=4,
+         b=10, n_obs=30, seed=5, mean_const=1.0),
+    dict(name="rbf_zero_weights", kind=O.RBF, mode="predictive_covariance", N=2500, M=64, d=3, b=10,
+         n_obs=20, seed=6, zero_frac=0.3),
+    dict(name="rbf_basekernel", kind=O.RBF, mode="kernel", N=1200, M=50, d=3, b=8, n_obs=10, seed=7),
+    dict(name="rbf_calc_obj", kind=O.RBF, mode="predictive_covariance", N=2000, M=64, d=3, b=10,
+         n_obs=20, seed=8, calc_obj=True),
+    dict(name="rbf_tiny_direct", kind=O.RBF, mode="predictive_covariance", N=18, M=12, d=2, b=10,
+         n_obs=6, seed=9),      # n+1 < N <= 2b: straight to the final direct level
+    dict(name="rbf_medium", kind=O.RBF, mode="predictive_covariance", N=20000, M=200, d=6, b=50,
+         n_obs=100, seed=10, store_inputs=False),
+    dict(name="matern_medium", kind=O.MATERN52, mode="predictive_covariance", N=12000, M=200, d=6,
+         b=100, n_obs=100, seed=11, store_inputs=False),
+    dict(name="cfg2_rbf", kind=O.RBF, mode="predictive_covariance", N=100000, M=500, d=10, b=100,
+         n_obs=200, seed=0, store_inputs=False, slim=True),
+]
+
+def run_reference(ref, case, inp, threads=None):
+    spec = build_spec(case, inp)
+    model = DuckModel(spec)
+    kernel = ref["_kernel"].Kernel(model, mode=case["mode"])
+    rchq = ref["_rchq"]
+    rec = dict(levels=[], U=None, gram_in=None, gram_out=None)
+
+    orig_car, orig_sparsify = rchq.Tchernychova_Lyons_CAR, rchq.ker_svd_sparsify
+    tm_cls = ref["_utils"].SafeTensorOperator
+    orig_psd = tm_cls.make_cov_psd
+
+    def car_wrap(X, mu, tm, DEBUG=False):
+        Xc, muc = X.clone(), mu.clone()
+        out = orig_car(X, mu, tm, DEBUG)
+        rec["levels"].append(dict(X_tmp=Xc, tot_weights=muc, w_star=out[0].clone(),
+                                  idx_star=out[1].clone()))
+        return out
+
+    def sparsify_wrap(pt, s, kernel, tm):
+        S, U = orig_sparsify(pt, s, kernel, tm)
+        rec["U"] = U.clone()
+        return S, U
+
+    def psd_wrap(self, cov):
+        rec["gram_in"] = cov.clone()
+        out = orig_psd(self, cov)
+        rec["gram_out"] = out.clone()
+        return out
+
+    rchq.Tchernychova_Lyons_CAR = car_wrap
+    rchq.ker_svd_sparsify = sparsify_wrap
+    tm_cls.make_cov_psd = psd_wrap
+    old_threads = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    try:
+        X_cand = torch.from_numpy(inp["X_cand"].copy())
+        X_nys = torch.from_numpy(inp["X_nys"].copy())
+        mu = torch.from_numpy(inp["mu0"].copy())
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx, w = rchq.recombination(
+                X_cand, X_nys, case["b"], kernel, torch.device("cpu"), torch.double,
+                init_weights=mu, calc_obj=calc_obj_fn if case.get("calc_obj") else None)
+    finally:
+        rchq.Tchernychova_Lyons_CAR = orig_car
+        rchq.ker_svd_sparsify = orig_sparsify
+        tm_cls.make_cov_psd = orig_psd
+        torch.set_num_threads(old_threads)
+    rec.update(idx=idx.clone(), w=w.clone(), mu_after=mu.clone(), spec=spec)
+    return rec
+
+
+def gen_recombination(ref):
+    for case in CASES:
+        inp = synth(case)
+        rec = run_reference(ref, case, inp)
+        rec1 = run_reference(ref, case, inp, threads=1)
+        same_idx = bool(torch.equal(rec["idx"], rec1["idx"]))
+        dw = float(((rec["w"] - rec1["w"]).abs() / rec["w"].abs()).max()) if same_idx else float("nan")
+        spec = rec["spec"]
+        W = spec.S_cache @ spec.S_cache.T
+        condW = float(torch.linalg.cond(W))
+        slim = case.get("slim", False)
+        out = dict(
+            kind=case["kind"], mode=case["mode"], b=case["b"], seed=case["seed"], seed_call=SEED_CALL,
+            N=case["N"], M=case["M"], d=case["d"], n_obs=case["n_obs"],
+            ard=case.get("ard", False), bit_p=case.get("bit_p", 0.1), zero_frac=case.get("zero_frac", 0.0),
+            calc_obj=bool(case.get("calc_obj", False)),
+            outputscale=spec.outputscale, noise=spec.noise, mean_const=spec.mean_const,
+            lengthscale=spec.lengthscale.numpy(),
+            idx=rec["idx"].numpy(), w=rec["w"].numpy(),
+            mu_after_idx=torch.nonzero(rec["mu_after"]).flatten().numpy(),
+            mu_after_val=rec["mu_after"][rec["mu_after"] != 0].numpy(),
+            n_levels=len(rec["levels"]),
+            self_threads_same_idx=same_idx, self_threads_dw=dw, condW=condW,
+            cks_X_cand=checksum(inp["X_cand"]), cks_mu0=checksum(inp["mu0"]),
+            cks_X_nys=checksum(inp["X_nys"]), cks_S_cache=checksum(spec.S_cache.numpy()),
+        )
+        if case.get("store_inputs", True):
+            out.update(X_cand=inp["X_cand"], X_nys=inp["X_nys"], mu0=inp["mu0"], X_obs=inp["X_obs"],
+                       y_obs=inp["y_obs"], S_cache=spec.S_cache.numpy(),
+                       alpha=spec.alpha.numpy())
+        if not slim:
+            out.update(U=rec["U"].numpy(), gram_in=rec["gram_in"].numpy(),
+                       gram_out=rec["gram_out"].numpy())
+        else:
+            out.update(cks_U=checksum(rec["U"].numpy()))
+        for i, lv in enumerate(rec["levels"]):
+            out[f"L{i}_tot_weights"] = lv["tot_weights"].numpy()
+            out[f"L{i}_idx_star"] = lv["idx_star"].numpy()
+            out[f"L{i}_w_star"] = lv["w_star"].numpy()
+            if slim:
+                out[f"L{i}_cks_X_tmp"] = checksum(lv["X_tmp"].numpy())
+                out[f"L{i}_shape_X_tmp"] = np.array(lv["X_tmp"].shape)
+            else:
+                out[f"L{i}_X_tmp"] = lv["X_tmp"].numpy()
+        path = os.path.join(HERE, f"recomb_{case['name']}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{case['name']:22s} levels={len(rec['levels']):2d} |idx|={len(rec['idx']):3d} "
+              f"threads1-vs-8: same_idx={same_idx} dw={dw:.2e} cond(W)={condW:.2e} "
+              f"{os.path.getsize(path) / 1024:.0f} KB")
+
+
+def gen_kmeans(ref):
+    KMeans = ref["_weights"].KMeans
+    rng = np.random.default_rng(100)
+    out = {}
+    x = rng.random((3000, 4))
+    cl, c = KMeans(torch.from_numpy(x.copy()), K=50)
+    out.update(a_x=x, a_K=50, a_cl=cl.numpy(), a_c=c.numpy())
+    # duplicate rows in the first K -> an empty cluster -> NaN centroid
+    x2 = rng.random((500, 3))
+    x2[3] = x2[1]
+    cl2, c2 = KMeans(torch.from_numpy(x2.copy()), K=8)
+    out.update(b_x=x2, b_K=8, b_cl=cl2.numpy(), b_c=c2.numpy())
+    x3 = rng.random((20000, 6))
+    cl3, c3 = KMeans(torch.from_numpy(x3.copy()), K=200)
+    out.update(c_seed=100, c_N=20000, c_d=6, c_K=200, c_cks_x=checksum(x3), c_c=c3.numpy(),
+               c_cl=cl3.numpy().astype(np.int32))
+    np.savez_compressed(os.path.join(HERE, "kmeans.npz"), **out)
+    print("kmeans: NaN centroids in case b:", int(np.isnan(c2.numpy()).any(axis=1).sum()))
+
+
+def gen_weights(ref):
+    WS = ref["_weights"].WeightsStabiliser
+    ws = WS()
+    rng = np.random.default_rng(200)
+    w = rng.random(1000)
+    w[::7] = 1e-9
+    w[5] = np.inf
+    w[11] = np.nan
+    w[13] = -1.0
+    out = dict(eps=ws.eps_weights, a_in=w.copy())
+    out["a_out"] = ws.cleansing_weights(torch.from_numpy(w.copy())).numpy()
+    z = np.zeros(16)
+    out["b_in"] = z.copy()
+    out["b_out"] = ws.cleansing_weights(torch.from_numpy(z.copy())).numpy()
+    w3 = rng.random(500) + 0.01
+    torch.manual_seed(7)
+    out["c_in"] = w3.copy()
+    out["c_idx_deweighted"] = ws.deweighted_resampling(torch.from_numpy(w3.copy()), 40).numpy()
+    torch.manual_seed(8)
+    out["c_idx_weighted"] = ws.weighted_resampling(torch.from_numpy(w3 / w3.sum()), 40).numpy()
+    out["check_true"] = ws.check_weights(torch.from_numpy(w3))
+    out["check_false"] = ws.check_weights(torch.from_numpy(np.r_[np.ones(10), np.zeros(5)]))
+    np.savez_compressed(os.path.join(HERE, "weights.npz"), **out)
+
+
+def gen_psd(ref):
+    tm = ref["_utils"].SafeTensorOperator()
+    rng = np.random.default_rng(300)
+    out = {}
+    A = rng.standard_normal((40, 40))
+    spd = A @ A.T + 40 * np.eye(40)
+    spd = 0.5 * (spd + spd.T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out["a_in"] = spd
+        out["a_out"] = tm.make_cov_psd(torch.from_numpy(spd.copy())).numpy()
+        t = np.linspace(0, 1, 40)               # numerically singular RBF Gram with entries > 0:
+        low = np.exp(-0.5 * (t[:, None] - t[None, :]) ** 2 / 0.5 ** 2)   # Cholesky fails -> jitter ladder
+        out["b_in"] = low
+        out["b_out"] = tm.make_cov_psd(torch.from_numpy(low.copy())).numpy()
+        ns = spd + 1e-13 * rng.standard_normal((40, 40))   # PD but not exactly symmetric
+        out["c_in"] = ns
+        out["c_out"] = tm.make_cov_psd(torch.from_numpy(ns.copy())).numpy()
+        neg = -spd                              # |.| repairs it (Q2)
+        out["d_in"] = neg
+        out["d_out"] = tm.make_cov_psd(torch.from_numpy(neg.copy())).numpy()
+        r5 = A[:, :5] @ A[:, :5].T              # rank 5 with mixed signs: ends on the diagonal fallback
+        r5 = 0.5 * (r5 + r5.T)
+        out["e_in"] = r5
+        out["e_out"] = tm.make_cov_psd(torch.from_numpy(r5.copy())).numpy()
+    np.savez_compressed(os.path.join(HERE, "psd.npz"), **out)
+
+
+def gen_tanimoto():
+    src = open("/root/reference/SOBER/_drug_modelling.py").read()
+    start = src.index("def batch_tanimoto_sim")
+    end = src.index("class BitDistance")
+    ns = {"torch": torch}
+    exec(src[start:end], ns)            # the function is plain torch
+    f = ns["batch_tanimoto_sim"]
+    rng = np.random.default_rng(400)
+    x1 = (rng.random((20, 96)) < 0.2).astype(np.float64)
+    x2 = (rng.random((35, 96)) < 0.2).astype(np.float64)
+    x3 = (rng.random((4, 9, 96)) < 0.2).astype(np.float64)
+    x2[0] = 0.0
+    x1[0] = 0.0
+    out = dict(x1=x1, x2=x2, x3=x3,
+               k12=f(torch.from_numpy(x1), torch.from_numpy(x2)).numpy(),
+               k13=f(torch.from_numpy(x1), torch.from_numpy(x3)).numpy())
+    np.savez_compressed(os.path.join(HERE, "tanimoto.npz"), **out)
+
+
+def gen_kernel_calls(ref):
+    """Kernel.__call__ in all three modes with 2-D and 3-D second argument."""
+    out = {}
+    for kind in (O.RBF, O.MATERN52, O.TANIMOTO):
+        case = dict(kind=kind, N=60, M=12, d=16 if kind == O.TANIMOTO else 3, n_obs=9, seed=500,
+                    ard=True, mean_const=0.5, outputscale=1.3)
+        inp = synth(case)
+        spec = build_spec(case, inp)
+        model = DuckModel(spec)
+        x = torch.from_numpy(inp["X_nys"])
+        y2 = torch.from_numpy(inp["X_cand"][:40])
+        y3 = torch.from_numpy(inp["X_cand"][:40]).reshape(5, 8, -1)
+        out.update({f"{kind}_X_obs": inp["X_obs"], f"{kind}_S_cache": spec.S_cache.numpy(),
+                    f"{kind}_alpha": spec.alpha.numpy(), f"{kind}_ls": spec.lengthscale.numpy(),
+                    f"{kind}_x": x.numpy(), f"{kind}_y2": y2.numpy()})
+        for mode in O.Kernel.MODES:
+            k = ref["_kernel"].Kernel(model, mode=mode)
+            out[f"{kind}_{mode}_2d"] = k(x, y2).numpy()
+            out[f"{kind}_{mode}_3d"] = k(x, y3).numpy()
+    np.savez_compressed(os.path.join(HERE, "kernel_calls.npz"), **out)
+
+
+if __name__ == "__main__":
+    ref = load_reference()
+    gen_tanimoto()
+    gen_kernel_calls(ref)
+    gen_psd(ref)
+    gen_weights(ref)
+    gen_kmeans(ref)
+    gen_recombination(ref)
+    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
+    print(f"total fixture size {tot / 1e6:.2f} MB")

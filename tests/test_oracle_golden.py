@@ -1,0 +1,159 @@
+"""The CPU oracle (oracle/sober_oracle.py) against the golden fixtures that
+tests/golden/make_golden.py captured from the reference's own code.  This is
+what pins the oracle; the GPU parity tests then compare the HIP path with it."""
+import glob
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sober_oracle as O
+from tests.golden.synth import SEED_CALL, calc_obj_fn, load_case
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SMALL = sorted(p for p in glob.glob(os.path.join(GOLD, "recomb_*.npz"))
+               if "cfg2" not in p and "medium" not in p)
+MEDIUM = sorted(glob.glob(os.path.join(GOLD, "recomb_*medium.npz")))
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _run_oracle(path):
+    case, inp, spec, z = load_case(path)
+    kernel = O.Kernel(spec, case["mode"])
+    mu = _t(inp["mu0"].copy())
+    trace = {}
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx, w = O.recombination(_t(inp["X_cand"]), _t(inp["X_nys"]), case["b"], kernel,
+                                 init_weights=mu, calc_obj=calc_obj_fn if case["calc_obj"] else None,
+                                 trace=trace)
+    return z, idx, w, mu, trace
+
+
+@pytest.mark.parametrize("path", SMALL + MEDIUM, ids=lambda p: os.path.basename(p)[7:-4])
+def test_recombination_matches_reference(path):
+    z, idx, w, mu, trace = _run_oracle(path)
+    # same torch ops in the same order in the same process family: bit-for-bit
+    assert np.array_equal(idx.numpy(), z["idx"])
+    assert np.array_equal(w.numpy(), z["w"])
+    nz = torch.nonzero(mu).flatten().numpy()
+    assert np.array_equal(nz, z["mu_after_idx"])                       # Q3: mutated in place
+    assert np.array_equal(mu.numpy()[nz], z["mu_after_val"])
+    assert len(trace["levels"]) == int(z["n_levels"])
+    assert np.array_equal(trace["U"].numpy(), z["U"])
+    for i, lv in enumerate(trace["levels"]):
+        assert np.array_equal(lv["tot_weights"].numpy(), z[f"L{i}_tot_weights"])
+        assert np.array_equal(lv["X_tmp"].numpy(), z[f"L{i}_X_tmp"])
+        assert np.array_equal(lv["idx_star"].numpy(), z[f"L{i}_idx_star"])
+        assert np.array_equal(lv["w_star"].numpy(), z[f"L{i}_w_star"])
+
+
+def test_golden_cases_are_self_consistent():
+    """Only cases whose reference run agrees with itself across MKL thread counts
+    may gate parity."""
+    for p in glob.glob(os.path.join(GOLD, "recomb_*.npz")):
+        z = np.load(p)
+        assert bool(z["self_threads_same_idx"]), p
+        assert float(z["self_threads_dw"]) <= 1e-6, p
+        assert float(z["condW"]) < 1e6, p
+
+
+def test_invariants_without_leftovers():
+    """Sum of weights preserved, positive weights, <= b points; with r == 0 at every
+    level the Nystrom moments are matched exactly."""
+    path = os.path.join(GOLD, "recomb_rbf_noleft.npz")
+    case, inp, spec, z = load_case(path)
+    z, idx, w, mu, trace = _run_oracle(path)
+    assert all(lv.get("r", 0) == 0 for lv in trace["levels"])
+    assert len(idx) <= case["b"] and (w > 0).all()
+    assert abs(float(w.sum()) - float(inp["mu0"].sum())) < 1e-12
+    kernel = O.Kernel(spec, case["mode"])
+    C = kernel(_t(inp["X_nys"]), _t(inp["X_cand"]))
+    lhs = trace["U"] @ (C @ _t(inp["mu0"]))
+    rhs = trace["U"] @ (C[:, idx] @ w)
+    assert float((lhs - rhs).norm() / lhs.norm()) < 1e-10
+
+
+def test_car_matches_reference():
+    z = np.load(os.path.join(GOLD, "recomb_rbf_b30.npz"))
+    for i in range(int(z["n_levels"])):
+        w, idx = O.tchernychova_lyons_car(_t(z[f"L{i}_X_tmp"]), _t(z[f"L{i}_tot_weights"].copy()))
+        assert np.array_equal(idx.numpy(), z[f"L{i}_idx_star"])
+        assert np.array_equal(w.numpy(), z[f"L{i}_w_star"])
+
+
+def test_make_cov_psd_matches_reference():
+    z = np.load(os.path.join(GOLD, "psd.npz"))
+    expect = dict(a="psd", b="jitter", c="abs", d="abs", e="diag")
+    for k, branch in expect.items():
+        tr = {}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = O.make_cov_psd(_t(z[f"{k}_in"].copy()), trace=tr)
+        assert np.array_equal(out.numpy(), z[f"{k}_out"], equal_nan=True), k
+        assert tr["branch"] == branch, (k, tr)
+
+
+def test_gram_psd_branch_recorded():
+    """The reference's Gram is never bit-symmetric (A W A^T rounding), so the
+    predictive-covariance cases all take the |cov| (+ jitter) route."""
+    for p in SMALL:
+        z = np.load(p)
+        if str(z["mode"]) == "kernel":
+            continue
+        gi, go = z["gram_in"], z["gram_out"]
+        assert not np.array_equal(gi, gi.T)
+        assert np.array_equal(go, go.T)
+
+
+def test_kernel_calls_match_reference():
+    z = np.load(os.path.join(GOLD, "kernel_calls.npz"))
+    for kind in (O.RBF, O.MATERN52, O.TANIMOTO):
+        spec = O.GPSpec(kind, _t(z[f"{kind}_ls"]), 1.3, _t(z[f"{kind}_X_obs"]), _t(z[f"{kind}_S_cache"]),
+                        1e-2, 0.5, _t(z[f"{kind}_alpha"]))
+        x, y2 = _t(z[f"{kind}_x"]), _t(z[f"{kind}_y2"])
+        y3 = y2.reshape(5, 8, -1)
+        for mode in O.Kernel.MODES:
+            k = O.Kernel(spec, mode)
+            assert np.array_equal(k(x, y2).numpy(), z[f"{kind}_{mode}_2d"]), (kind, mode)
+            assert np.array_equal(k(x, y3).numpy(), z[f"{kind}_{mode}_3d"]), (kind, mode)
+            assert k(x, y3).shape == (5, x.shape[0], 8)
+    with pytest.raises(ValueError):
+        O.Kernel(spec, "nope")(x, y2)
+
+
+def test_tanimoto_matches_reference():
+    z = np.load(os.path.join(GOLD, "tanimoto.npz"))
+    assert np.array_equal(O.batch_tanimoto_sim(_t(z["x1"]), _t(z["x2"])).numpy(), z["k12"])
+    assert np.array_equal(O.batch_tanimoto_sim(_t(z["x1"]), _t(z["x3"])).numpy(), z["k13"])
+
+
+def test_kmeans_matches_reference():
+    z = np.load(os.path.join(GOLD, "kmeans.npz"))
+    cl, c = O.kmeans(_t(z["a_x"].copy()), K=int(z["a_K"]))
+    assert np.array_equal(cl.numpy(), z["a_cl"]) and np.array_equal(c.numpy(), z["a_c"])
+    cl, c = O.kmeans(_t(z["b_x"].copy()), K=int(z["b_K"]))
+    assert np.array_equal(c.numpy(), z["b_c"], equal_nan=True)
+    assert np.isnan(c.numpy()).any()                      # empty cluster -> NaN centroid
+    cl2, c2 = O.kmeans_chunked(_t(z["a_x"].copy()), K=int(z["a_K"]), chunk=700)
+    assert np.array_equal(cl2.numpy(), z["a_cl"]) and np.array_equal(c2.numpy(), z["a_c"])
+
+
+def test_weights_match_reference():
+    z = np.load(os.path.join(GOLD, "weights.npz"))
+    assert float(z["eps"]) == O.EPS_WEIGHTS                # Q5: FP32 eps even in FP64
+    assert np.array_equal(O.cleansing_weights(_t(z["a_in"].copy())).numpy(), z["a_out"])
+    assert np.array_equal(O.cleansing_weights(_t(z["b_in"].copy())).numpy(), z["b_out"])
+    torch.manual_seed(7)
+    assert np.array_equal(O.deweighted_resampling(_t(z["c_in"].copy()), 40).numpy(), z["c_idx_deweighted"])
+    torch.manual_seed(8)
+    w = z["c_in"] / z["c_in"].sum()
+    assert np.array_equal(O.weighted_resampling(_t(w), 40).numpy(), z["c_idx_weighted"])
+    assert O.check_weights(_t(z["c_in"])) == bool(z["check_true"])
+    assert O.check_weights(_t(np.r_[np.ones(10), np.zeros(5)])) == bool(z["check_false"])
