@@ -1,0 +1,158 @@
+/*
+ * sober_hip.h -- C ABI of libsober_hip.so, the MI355X (gfx950) implementation of
+ * SOBER's kernel-recombination hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless its name
+ *     starts with h_; the library never allocates or frees caller data
+ *     (workspaces are passed in, their sizes come from the *_ws_bytes queries);
+ *   - work is enqueued on the caller's stream (`stream` is a hipStream_t passed as
+ *     void*; NULL = the default stream); no entry point synchronises;
+ *   - return value: 0 = ok, < 0 = argument error (SOBER_E_*), > 0 = hipError_t;
+ *   - FP64 everywhere (the reference runs torch.double, SOBER/_settings.py:8);
+ *     candidate / position indices are int32 on the device (N < 2^31);
+ *   - "scaled points" are rows of DT doubles: x[j] / lengthscale[j] for j < d, zero
+ *     padding for d <= j < DT (DT = sober_padded_dim(d)); for the Tanimoto kernel a
+ *     point is DT/... see sober_pack_bits.
+ *
+ * Each entry cites the reference code it replaces (paths relative to the
+ * reference checkout, ma921/SOBER v2.0.2).
+ */
+#ifndef SOBER_HIP_H
+#define SOBER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOBER_ABI_VERSION 1
+
+/* kernel families: model.covar_module.forward behind SOBER/_gp.py:292-294 */
+#define SOBER_KIND_RBF       0   /* outputscale * exp(-0.5 * |x/l - y/l|^2)                      */
+#define SOBER_KIND_MATERN52  1   /* outputscale * (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)          */
+#define SOBER_KIND_TANIMOTO  2   /* outputscale * (x.y + 1e-6) / (1e-6 + |x|^2 + |y|^2 - x.y),
+                                    SOBER/_drug_modelling.py:15-25,37 (bit-packed 0/1 inputs)    */
+
+#define SOBER_E_ARG      -1      /* null pointer / non-positive size / bad enum                  */
+#define SOBER_E_DIM      -2      /* dimension not supported by the compiled tile set             */
+#define SOBER_E_WS       -3      /* workspace too small                                           */
+
+int sober_abi_version(void);
+
+/* DT for a d-dimensional continuous kernel (multiple of 4, >= d), or -2 if d > SOBER max.       */
+int sober_padded_dim(int d);
+/* number of 64-bit words per point for a d-bit Tanimoto fingerprint.                             */
+int sober_bit_words(int d);
+
+/* x[i, 0:d] / lengthscale -> out[i, 0:dt] (zero padded).  ls_len is 1 (isotropic) or d (ARD).
+ * Replaces the `x1.div(lengthscale)` prologue of gpytorch's RBF/Matern forward that
+ * SOBER/_gp.py:292-294 calls on every kernel evaluation.                                         */
+int sober_scale_points(const double* X, int64_t n, int d, int64_t ldx,
+                       const double* lengthscale, int ls_len,
+                       double* out, int dt, void* stream);
+
+/* 0/1 FP64 fingerprints -> bit-packed words (nwords per row, little-endian bit j of word j/64) and
+ * per-row popcount (|x|^2) as double.  *bad_flag (device int32, zero it first) is set to 1 when an
+ * input is neither 0.0 nor 1.0.  Replaces the FP64 storage consumed by
+ * SOBER/_drug_modelling.py:20-22.                                                                */
+int sober_pack_bits(const double* X, int64_t n, int d, int64_t ldx,
+                    uint64_t* words, int nwords, double* norms, int32_t* bad_flag, void* stream);
+
+/* out[i*ldo + j] = k(a_i, b_{idx ? idx[j] : j}),  i < m, j < n.
+ * a / b are scaled points (continuous kinds; dt doubles per row) or packed words (Tanimoto; dt =
+ * words per row, a_norm / b_norm = popcounts).  The materialised kernel matrix of
+ * `model.covar_module.forward(x, y)`, SOBER/_gp.py:292-294 and SOBER/_kernel.py:28.              */
+int sober_pairwise(int kind, const void* a, const double* a_norm, int64_t m,
+                   const void* b, const double* b_norm, const int32_t* idx, int64_t n,
+                   int dt, double outputscale, double* out, int64_t ldo, void* stream);
+
+/* out[j] = c0 + sum_i k(a_i, b_j) * v[i]   (posterior mean over a pool, j < n): the
+ * `predict_mean` of SOBER/_gp.py:240-253 needed by weighted_covariance, SOBER/_kernel.py:40-41.  */
+int sober_kernel_matvec(int kind, const void* a, const double* a_norm, const double* v, int64_t m,
+                        const void* b, const double* b_norm, int64_t n,
+                        int dt, double outputscale, double c0, double* out, void* stream);
+
+/* The hot kernel (K1-K3 of SURVEY.md 2.1): fused "kernel evaluation x weight -> set sums".
+ * For GLOBAL list positions p in [pos0, pos0 + count) (candidate c = idx[p - pos0], set s = p mod S,
+ * element p div S; pos0 = 0 on one GPU, the start of this rank's contiguous position range when the
+ * list is sharded):
+ *     partG  [chunk][row][col0 + s] += k(rows[row], cand[c]) * mu[c] * (wmul ? wmul[c] : 1)
+ *     partTot[chunk][col0 + s]      += mu[c]                    for p < tot_limit only
+ * with the element range split into n_chunks chunks (deterministic partial sums, no atomics).
+ * Never materialises the (E, M, S) tensor of SOBER/_rchq.py:122-126; running it over ALL live
+ * positions (count = R) reproduces the leftover double count of :128-136 (quirk Q1), and
+ * tot_limit = E*S keeps `tot_weights` (:152) free of it.  A second call with S = 1 over the
+ * leftover positions yields the column added to the last set at :153-164.
+ *   rows     n_rows scaled points (X_nys stacked on X_obs: the posterior correction of
+ *            SOBER/_gp.py:295 is applied after the sum, it is linear)
+ *   partG    n_chunks * n_rows * ldg doubles, partTot n_chunks * ldg doubles (may be NULL)     */
+int sober_level_reduce(int kind, const void* rows, const double* rows_norm, int n_rows,
+                       const void* cand, const double* cand_norm, int dt,
+                       const int32_t* idx, int64_t pos0, int64_t count, int S,
+                       const double* mu, const double* wmul, double outputscale,
+                       int n_chunks, double* partG, int ldg, int col0,
+                       double* partTot, int64_t tot_limit, void* stream);
+/* chunk count the library would pick for a level of `count` positions in S sets.                 */
+int sober_level_chunks(int n_rows, int64_t pos0, int64_t count, int S);
+
+/* G[row*ldo + s] = sum_chunk partG[chunk][row][s]  (s < S).  When extraG != NULL the leftover
+ * partials extraG[xchunk][row][0:n_xcols] (and extraTot[xchunk][0:n_xcols]) -- a level_reduce run
+ * over the leftover positions alone -- are summed and folded into set S-1
+ * (SOBER/_rchq.py:160-164).                                                                       */
+int sober_sum_partials(const double* partG, const double* partTot, int n_chunks, int n_rows,
+                       int ldg, int S, const double* extraG, const double* extraTot,
+                       int n_xchunks, int n_xcols, double* G, int ldo, double* tot, void* stream);
+
+/* Row-major FP64 GEMM on the matrix cores (v_mfma_f64_16x16x4_f64):
+ * C[m,n] = alpha * op(A)[m,k] * op(B)[k,n] + beta * C.  Used for W = S S^T (SOBER/_gp.py:277),
+ * T = KxX W and the posterior correction (SOBER/_gp.py:295), U @ X_for_nys (SOBER/_rchq.py:148). */
+int sober_dgemm(int transa, int transb, int m, int n, int k, double alpha,
+                const double* A, int lda, const double* B, int ldb,
+                double beta, double* C, int ldc, void* stream);
+
+/* X_tmp[s*n + i] = Xtr[i*ldx + s] / tot[s]   (SOBER/_rchq.py:151,166); tot may be NULL (no
+ * division: the final direct level, :78).                                                        */
+int sober_barycentres(const double* Xtr, int ldx, int n, int S, const double* tot,
+                      double* X_tmp, void* stream);
+
+/* K7 (SOBER/_rchq.py:198-221): rescale the kept sets' weights, zero the cancelled ones and write
+ * the compacted survivor list (element-major, kept sets in ascending order, leftovers appended iff
+ * the last set survived).  keep_rank[s] = rank of set s in idx_star or -1.  New global length =
+ * E * n_keep + (keep_rank[S-1] >= 0 ? R - E*S : 0).  idx_cur holds the `count` positions starting at
+ * global position pos0; survivors are written to idx_new[new_global_position - new_pos0].         */
+int sober_level_update(const int32_t* idx_cur, int64_t pos0, int64_t count, int S, int64_t E,
+                       const int32_t* keep_rank, const double* w_star, const double* tot,
+                       int n_keep, double* mu, int32_t* idx_new, int64_t new_pos0, void* stream);
+
+/* Final direct level write-back (SOBER/_rchq.py:108-110): mu[:] = 0 is the caller's memset; this
+ * scatters mu[idx_cur[sel[k]]] = w[k] and writes out_idx[k] = idx_cur[sel[k]] (int64).           */
+int sober_scatter_weights(const int32_t* idx_cur, const int32_t* sel, const double* w, int n_sel,
+                          double* mu, int64_t* out_idx, void* stream);
+
+/* idx[p] = p-th index with mu != 0 is the caller's job (torch.nonzero); helper: int64 -> int32.   */
+int sober_i64_to_i32(const int64_t* in, int64_t n, int32_t* out, void* stream);
+
+/* HOST function (h_ pointers are host memory): the pivot loop of Tchernychova_Lyons_CAR,
+ * SOBER/_rchq.py:237-266.  h_Phi is the null-space basis, N x m row-major (ld = m), destroyed;
+ * h_mu (N) is updated in place.  Same IEEE operation order as the reference's tensor expressions
+ * (no FMA contraction).  Returns the number of pivots performed (< m when quirk Q6 fires).        */
+int sober_car_pivot_host(double* h_Phi, int N, int m, double* h_mu);
+
+/* KMeans of SOBER/_weights.py:100-126: Lloyd, centroids initialised to the first K rows, exactly
+ * `iters` iterations, first-index argmin (a NaN distance wins like torch.argmin), empty cluster ->
+ * NaN centroid.  X is (N, d) row-major raw points.  labels: N int32.  ws: sober_kmeans_ws_bytes.  */
+int64_t sober_kmeans_ws_bytes(int64_t N, int d, int K);
+int sober_kmeans_lloyd(const double* X, int64_t N, int d, int K, int iters,
+                       double* centroids, int32_t* labels, void* ws, int64_t ws_bytes, void* stream);
+
+/* cleansing_weights of SOBER/_weights.py:21-38, in place: w < eps -> 0, inf/nan -> eps, then
+ * normalise by the sum (or 1/n everywhere when the sum is 0).  ws: sober_reduce_ws_bytes(n).     */
+int64_t sober_reduce_ws_bytes(int64_t n);
+int sober_cleansing_weights(double* w, int64_t n, double eps, void* ws, int64_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOBER_HIP_H */

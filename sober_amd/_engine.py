@@ -1,0 +1,256 @@
+"""Host logic of one kernel-recombination step (SOBER/_rchq.py:34-270), device agnostic.
+
+The engine owns every *decision* of the reference's algorithm -- the halving loop, the grouping
+of live positions into 2b sets, quirks Q1-Q6, the Caratheodory pivots -- and
+delegates every *bulk computation* to an `ops` backend.  The product has exactly one backend,
+`HipOps` (hand-written HIP kernels behind the C ABI); there is no CPU path.
+
+Parity-critical pieces stay on the host's LAPACK, exactly where the reference has them
+(SURVEY.md App. C): the PSD repair + randomised SVD of the Nystrom Gram (the `randn` draw comes
+from the CPU generator, so `torch.manual_seed` before the call reproduces the reference's U),
+and the null space of each Caratheodory step (`torch.linalg.svd`).  The device produces their
+inputs (Gram, barycentres) and consumes their outputs (U, kept sets and weights).
+
+Multi-GPU: the live position list is sharded in contiguous ranges, one per rank;
+each level needs ONE all-reduce of the projected partial set sums (n x S doubles) and set masses
+(S doubles); the survivor compaction is closed-form, so no candidate row ever moves.
+"""
+from __future__ import annotations
+
+import time
+import warnings
+from typing import Optional
+
+import torch
+
+from . import _native as nat
+from ._utils import SafeTensorOperator
+
+
+# --------------------------------------------------------------------------- #
+# communicators
+# --------------------------------------------------------------------------- #
+class SoloComm:
+    rank, world = 0, 1
+
+    def allreduce_sum(self, *tensors):
+        return
+
+    def allgather_counts(self, n: int):
+        return [n]
+
+    def allgather_rows(self, t: torch.Tensor, counts):
+        return t
+
+    def broadcast0(self, t: torch.Tensor):
+        return t
+
+
+class DistComm:
+    """torch.distributed group (backend 'nccl' = RCCL over xGMI on the MI355X node; 'gloo' in the
+    CPU tests).  Only small tensors travel: (n*S + S) doubles per level."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allreduce_sum(self, *tensors):
+        if len(tensors) == 1:
+            self.dist.all_reduce(tensors[0], group=self.group)
+            return
+        flat = torch.cat([t.reshape(-1) for t in tensors])        # one message per level
+        self.dist.all_reduce(flat, group=self.group)
+        o = 0
+        for t in tensors:
+            t.copy_(flat[o:o + t.numel()].view_as(t))
+            o += t.numel()
+
+    def allgather_counts(self, n: int):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, int(n), group=self.group)
+        return out
+
+    def broadcast0(self, t: torch.Tensor):
+        """Rank 0's tensor to everyone (the Nystrom basis: its randn draw must be shared)."""
+        self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, 0) if self.group else 0,
+                            group=self.group)
+        return t
+
+    def allgather_rows(self, t: torch.Tensor, counts):
+        """Concatenate per-rank row blocks (rank r contributes counts[r] rows) in rank order."""
+        mx = max(counts)
+        shape = (mx,) + tuple(t.shape[1:])
+        pad = torch.zeros(shape, dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        bufs = [torch.empty_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(bufs, pad, group=self.group)
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+
+
+# --------------------------------------------------------------------------- #
+# host pieces of the algorithm
+# --------------------------------------------------------------------------- #
+def ker_svd_sparsify_host(gram_host: torch.Tensor, s: int, tm: Optional[SafeTensorOperator] = None):
+    """SOBER/_rchq.py:34-39 from `mat = kernel(pt, pt)` on: PSD repair, torch.svd_lowrank (its
+    randn(M, s) comes from the global CPU generator), U = -_U.T."""
+    tm = tm or SafeTensorOperator()
+    mat = tm.make_cov_psd(gram_host)
+    _U, S, _ = torch.svd_lowrank(mat, q=s)
+    return S, -1 * _U.T
+
+
+def car_host(X: torch.Tensor, mu: torch.Tensor):
+    """Tchernychova_Lyons_CAR, SOBER/_rchq.py:224-270, on host tensors: X (N', n'), mu (N',)
+    (modified in place).  Null space from LAPACK's full SVD exactly like :231-234; the pivot loop
+    is the C++ routine of csrc/car_host.cpp.  Returns (w_star, idx_star)."""
+    dt = X.dtype
+    X1 = torch.cat([torch.ones(X.size(0), 1, dtype=dt), X], dim=1)
+    N, n = X1.shape
+    _, _, V = torch.linalg.svd(X1.T)
+    Phi = V[-(N - n):, :].T.contiguous()
+    nat.car_pivot_host(Phi, mu)
+    keep = mu > 0
+    return mu[keep], torch.arange(N)[keep]
+
+
+def survivors_before(p: int, S: int, E: int, kept_prefix, n_keep: int, last_kept: bool) -> int:
+    """Number of surviving list positions strictly below global position p after a level that kept
+    the sets with kept_prefix[s] = #kept sets < s (closed-form compaction)."""
+    ES = E * S
+    if p <= ES:
+        return (p // S) * n_keep + kept_prefix[p % S]
+    return E * n_keep + ((p - ES) if last_kept else 0)
+
+
+# --------------------------------------------------------------------------- #
+# the engine
+# --------------------------------------------------------------------------- #
+class RecombinationEngine:
+    def __init__(self, ops, comm=None, row_offset: int = 0):
+        self.ops = ops
+        self.comm = comm or SoloComm()
+        self.row_offset = int(row_offset)      # global index of local candidate 0 (sharded pools)
+        self.tm = SafeTensorOperator()
+        self.trace = None                      # set to a dict to record per-level data (tests)
+        self.timers = {}                       # phase -> seconds (host wall clock, accumulated)
+
+    def _tick(self, name, t0):
+        t1 = time.perf_counter()
+        self.timers[name] = self.timers.get(name, 0.0) + (t1 - t0)
+        return t1
+
+    # -- Nystrom basis --------------------------------------------------------
+    def nystrom_basis(self, plan, s: int):
+        t0 = time.perf_counter()
+        gram = self.ops.gram(plan)
+        (gram_h,) = self.ops.to_host(gram)
+        t0 = self._tick("gram_device", t0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("default")
+            _, U = ker_svd_sparsify_host(gram_h, s, self.tm)
+        self._tick("nystrom_host", t0)
+        if self.trace is not None:
+            self.trace.update(gram=gram_h.clone(), U=U.clone())
+        return U
+
+    # -- the halving loop -------------------------------------------------------
+    def run(self, plan, mu: torch.Tensor, num_pts: int):
+        """Mod_Tchernychova_Lyons, SOBER/_rchq.py:51-221.  `mu` (local weights, device, float64)
+        is modified in place (Q3).  Returns (idx_star int64 global indices, w_star) on the device,
+        identical on every rank."""
+        ops, comm = self.ops, self.comm
+        n = num_pts - 1
+        S = 2 * (n + 1)
+        U = self.nystrom_basis(plan, n)
+        if comm.world > 1:
+            U = comm.broadcast0(ops.from_host(U.contiguous())).cpu() if ops.device.type != "cpu" \
+                else comm.broadcast0(U.contiguous())
+        ops.set_projection(plan, U)
+
+        idx_cur, count = ops.nonzero_i32(mu)               # idx_story = arange(N)[mu != 0]  (:63-65)
+        counts = comm.allgather_counts(count)
+        pos0 = sum(counts[:comm.rank])
+        R = sum(counts)
+        idx_new = ops.empty_i32(count)
+        levels = [] if self.trace is not None else None
+
+        if self.trace is not None:
+            self.trace["levels"] = levels
+        while True:
+            if R <= n + 1:                                  # :72-75
+                return self._finish_small(mu)
+            if R <= S:                                      # :77-114
+                return self._finish_direct(plan, idx_cur, count, R, mu, levels)
+
+            E = R // S
+            r = R - E * S
+            t0 = time.perf_counter()
+            Xtr, tot = ops.level_moments(plan, idx_cur, pos0, count, S, E, mu)
+            comm.allreduce_sum(Xtr, tot)
+            X_tmp = ops.barycentres(Xtr, tot)               # :151,166
+            X_h, tot_h = ops.to_host(X_tmp, tot)
+            t0 = self._tick("levels_device", t0)
+            w_star, idx_star = car_host(X_h, tot_h.clone())  # :173-175
+            t0 = self._tick("car_host", t0)
+            if levels is not None:
+                levels.append(dict(kind="level", R=R, E=E, r=r, X_tmp=X_h.clone(), tot_weights=tot_h.clone(),
+                                   idx_star=idx_star.clone(), w_star=w_star.clone()))
+
+            n_keep = int(idx_star.numel())
+            keep_rank = torch.full((S,), -1, dtype=torch.int32)
+            keep_rank[idx_star] = torch.arange(n_keep, dtype=torch.int32)
+            last_kept = bool(keep_rank[S - 1] >= 0)
+            kept_prefix = torch.zeros(S + 1, dtype=torch.int64)
+            kept_prefix[1:] = torch.cumsum((keep_rank >= 0).to(torch.int64), 0)
+            kept_prefix = kept_prefix.tolist()
+            R_new = E * n_keep + (r if last_kept else 0)
+            if R_new >= R:
+                raise RuntimeError(
+                    "recombination made no progress (the Caratheodory step cancelled nothing, "
+                    "SOBER/_rchq.py:241-242); the reference would loop forever here")
+            new_pos0 = survivors_before(pos0, S, E, kept_prefix, n_keep, last_kept)
+            new_end = survivors_before(pos0 + count, S, E, kept_prefix, n_keep, last_kept)
+            if count > 0:
+                ops.level_update(idx_cur, pos0, count, S, E, ops.from_host(keep_rank),
+                                 ops.from_host(w_star), tot, n_keep, mu, idx_new, new_pos0)   # :198-221
+            idx_cur, idx_new = idx_new, idx_cur
+            pos0, count, R = new_pos0, new_end - new_pos0, R_new
+
+    # -- terminal branches ------------------------------------------------------
+    def _gather_result(self, idx_local, w_local):
+        comm = self.comm
+        idx_glob = idx_local.to(torch.int64) + self.row_offset
+        if comm.world == 1:
+            return idx_glob, w_local
+        counts = comm.allgather_counts(int(idx_glob.numel()))
+        return comm.allgather_rows(idx_glob, counts), comm.allgather_rows(w_local, counts)
+
+    def _finish_small(self, mu):
+        idx_star = torch.nonzero(mu > 0).flatten()          # arange(len(mu))[mu > 0]  (:73)
+        return self._gather_result(idx_star, mu[idx_star])
+
+    def _finish_direct(self, plan, idx_cur, count, R, mu, levels):
+        ops, comm = self.ops, self.comm
+        n = plan.n
+        if count > 0:
+            X_loc = ops.direct_columns(plan, idx_cur, count)           # rows of (U @ K).T  (:78)
+            mu_loc = mu[idx_cur[:count].long()]
+        else:
+            X_loc = torch.zeros(0, n, dtype=torch.float64, device=ops.device)
+            mu_loc = torch.zeros(0, dtype=torch.float64, device=ops.device)
+        counts = comm.allgather_counts(count)
+        X_all = comm.allgather_rows(X_loc, counts)
+        mu_all = comm.allgather_rows(mu_loc, counts)
+        X_h, mu_h = ops.to_host(X_all, mu_all)
+        w_star, idx_star = car_host(X_h, mu_h.clone())                 # :84-85
+        if levels is not None:
+            levels.append(dict(kind="final", R=R, X_tmp=X_h.clone(), tot_weights=mu_h.clone(),
+                               idx_star=idx_star.clone(), w_star=w_star.clone()))
+        lo = sum(counts[:comm.rank])
+        mine = (idx_star >= lo) & (idx_star < lo + count)
+        sel = (idx_star[mine] - lo).to(torch.int32)
+        mu.zero_()                                                     # mu[:] = 0  (:109)
+        w_mine = ops.from_host(w_star[mine])
+        out_idx = ops.scatter_weights(idx_cur, ops.from_host(sel), w_mine, mu)   # mu[idx_story] = w_star
+        return self._gather_result(out_idx, w_mine)

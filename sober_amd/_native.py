@@ -1,0 +1,230 @@
+"""ctypes binding of libsober_hip.so (the C ABI declared in include/sober_hip.h).
+
+The product path has NO fallback: if the shared library is missing or an entry
+point fails, an exception is raised.  torch is used only for device memory and
+the current HIP stream (`tensor.data_ptr()`, `torch.cuda.current_stream()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsober_hip.so")
+ABI_VERSION = 1
+
+KIND_RBF, KIND_MATERN52, KIND_TANIMOTO = 0, 1, 2
+KIND_BY_NAME = {"rbf": KIND_RBF, "matern52": KIND_MATERN52, "tanimoto": KIND_TANIMOTO}
+
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
+
+# name -> (restype, argtypes); mirrors include/sober_hip.h one to one
+SIGNATURES = {
+    "sober_abi_version": (_i32, []),
+    "sober_padded_dim": (_i32, [_i32]),
+    "sober_bit_words": (_i32, [_i32]),
+    "sober_scale_points": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "sober_pack_bits": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "sober_pairwise": (_i32, [_i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _f64, _vp, _i64, _vp]),
+    "sober_kernel_matvec": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _f64, _vp, _vp]),
+    "sober_level_reduce": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp,
+                                  _f64, _i32, _vp, _i32, _i32, _vp, _i64, _vp]),
+    "sober_level_chunks": (_i32, [_i32, _i64, _i64, _i32]),
+    "sober_sum_partials": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "sober_dgemm": (_i32, [_i32, _i32, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _i32, _f64, _vp, _i32, _vp]),
+    "sober_barycentres": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "sober_level_update": (_i32, [_vp, _i64, _i64, _i32, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp]),
+    "sober_scatter_weights": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "sober_i64_to_i32": (_i32, [_vp, _i64, _vp, _vp]),
+    "sober_car_pivot_host": (_i32, [_vp, _i32, _i32, _vp]),
+    "sober_kmeans_ws_bytes": (_i64, [_i64, _i32, _i32]),
+    "sober_kmeans_lloyd": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "sober_reduce_ws_bytes": (_i64, [_i64]),
+    "sober_cleansing_weights": (_i32, [_vp, _i64, _f64, _vp, _i64, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class SoberHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libsober_hip.so (built by sober_amd/csrc/Makefile or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SoberHipError(
+            f"{LIB_PATH} not found: build it with `make -C sober_amd/csrc` "
+            "(python -c 'import __graft_entry__ as g; g.build()').  sober_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    got = lib.sober_abi_version()
+    if got != ABI_VERSION:
+        raise SoberHipError(f"libsober_hip ABI {got} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc < 0:
+        msg = {-1: "bad argument", -2: "dimension not supported by the compiled tile set",
+               -3: "workspace too small"}.get(rc, "error")
+        raise SoberHipError(f"{what}: {msg} (code {rc})")
+    raise SoberHipError(f"{what}: hipError_t {rc}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor) -> Optional[int]:
+    if not t.is_cuda:
+        raise SoberHipError("sober_amd runs on the MI355X only: tensor is not on a HIP device")
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_contiguous():
+        raise SoberHipError(f"{name}: need contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+# --------------------------------------------------------------------------- #
+# thin typed wrappers (torch tensors in, nothing allocated inside the library)
+# --------------------------------------------------------------------------- #
+def padded_dim(d: int) -> int:
+    r = load().sober_padded_dim(d)
+    _check(min(r, 0), f"padded_dim({d})")
+    return r
+
+
+def bit_words(d: int) -> int:
+    r = load().sober_bit_words(d)
+    _check(min(r, 0), f"bit_words({d})")
+    return r
+
+
+def scale_points(X, lengthscale, out):
+    n, d = X.shape
+    _req(X, torch.float64, "X"); _req(lengthscale, torch.float64, "lengthscale"); _req(out, torch.float64, "out")
+    _check(load().sober_scale_points(X.data_ptr(), n, d, X.stride(0), lengthscale.data_ptr(),
+                                     lengthscale.numel(), out.data_ptr(), out.shape[1], _stream(X)),
+           "sober_scale_points")
+
+
+def pack_bits(X, words, norms, bad_flag):
+    n, d = X.shape
+    _req(X, torch.float64, "X"); _req(words, torch.int64, "words"); _req(norms, torch.float64, "norms")
+    _req(bad_flag, torch.int32, "bad_flag")
+    _check(load().sober_pack_bits(X.data_ptr(), n, d, X.stride(0), words.data_ptr(), words.shape[1],
+                                  norms.data_ptr(), bad_flag.data_ptr(), _stream(X)), "sober_pack_bits")
+
+
+def pairwise(kind, a, a_norm, b, b_norm, idx, n, dt, outputscale, out):
+    _check(load().sober_pairwise(kind, a.data_ptr(), _ptr(a_norm), a.shape[0], b.data_ptr(), _ptr(b_norm),
+                                 _ptr(idx), n, dt, float(outputscale), out.data_ptr(), out.stride(0),
+                                 _stream(out)), "sober_pairwise")
+
+
+def kernel_matvec(kind, a, a_norm, v, b, b_norm, dt, outputscale, c0, out):
+    _check(load().sober_kernel_matvec(kind, a.data_ptr(), _ptr(a_norm), v.data_ptr(), a.shape[0],
+                                      b.data_ptr(), _ptr(b_norm), b.shape[0], dt, float(outputscale),
+                                      float(c0), out.data_ptr(), _stream(out)), "sober_kernel_matvec")
+
+
+def level_chunks(n_rows, pos0, count, S) -> int:
+    r = load().sober_level_chunks(n_rows, pos0, count, S)
+    _check(min(r, 0), "sober_level_chunks")
+    return r
+
+
+def level_reduce(kind, rows, rows_norm, cand, cand_norm, dt, idx, idx_off, pos0, count, S, mu, wmul,
+                 outputscale, n_chunks, partG, ldg, col0, partTot, tot_limit):
+    _req(idx, torch.int32, "idx"); _req(mu, torch.float64, "mu")
+    _check(load().sober_level_reduce(kind, rows.data_ptr(), _ptr(rows_norm), rows.shape[0], cand.data_ptr(),
+                                     _ptr(cand_norm), dt, idx.data_ptr() + 4 * idx_off, pos0, count, S,
+                                     mu.data_ptr(), _ptr(wmul), float(outputscale), n_chunks,
+                                     partG.data_ptr(), ldg, col0, _ptr(partTot), tot_limit, _stream(mu)),
+           "sober_level_reduce")
+
+
+def sum_partials(partG, partTot, n_chunks, n_rows, ldg, S, extraG, extraTot, n_xchunks, n_xcols, G, tot):
+    _check(load().sober_sum_partials(partG.data_ptr(), _ptr(partTot), n_chunks, n_rows, ldg, S,
+                                     _ptr(extraG), _ptr(extraTot), n_xchunks, n_xcols, G.data_ptr(),
+                                     G.stride(0), _ptr(tot), _stream(G)), "sober_sum_partials")
+
+
+def dgemm(A, B, C_, transa=False, transb=False, alpha=1.0, beta=0.0):
+    """C_[m,n] = alpha * op(A) @ op(B) + beta * C_ ; row-major 2-D tensors (unit inner stride)."""
+    m, n = C_.shape
+    k = A.shape[0] if transa else A.shape[1]
+    for t, nm in ((A, "A"), (B, "B"), (C_, "C")):
+        if t.dtype != torch.float64 or t.stride(1) != 1:
+            raise SoberHipError(f"dgemm {nm}: need float64 with unit inner stride")
+    ka = B.shape[1] if transb else B.shape[0]
+    ma = A.shape[1] if transa else A.shape[0]
+    na = B.shape[0] if transb else B.shape[1]
+    if (ma, na, ka) != (m, n, k):
+        raise SoberHipError(f"dgemm shape mismatch {A.shape} {B.shape} -> {C_.shape}")
+    _check(load().sober_dgemm(int(transa), int(transb), m, n, k, float(alpha), A.data_ptr(), A.stride(0),
+                              B.data_ptr(), B.stride(0), float(beta), C_.data_ptr(), C_.stride(0),
+                              _stream(C_)), "sober_dgemm")
+
+
+def barycentres(Xtr, n, S, tot, X_tmp):
+    _check(load().sober_barycentres(Xtr.data_ptr(), Xtr.stride(0), n, S, _ptr(tot), X_tmp.data_ptr(),
+                                    _stream(X_tmp)), "sober_barycentres")
+
+
+def level_update(idx_cur, idx_off, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0):
+    _check(load().sober_level_update(idx_cur.data_ptr() + 4 * idx_off, pos0, count, S, E,
+                                     keep_rank.data_ptr(), w_star.data_ptr(), tot.data_ptr(), n_keep,
+                                     mu.data_ptr(), idx_new.data_ptr(), new_pos0, _stream(mu)),
+           "sober_level_update")
+
+
+def scatter_weights(idx_cur, sel, w, n_sel, mu, out_idx):
+    _check(load().sober_scatter_weights(idx_cur.data_ptr(), sel.data_ptr(), w.data_ptr(), n_sel,
+                                        mu.data_ptr(), out_idx.data_ptr(), _stream(mu)),
+           "sober_scatter_weights")
+
+
+def i64_to_i32(src, dst):
+    _check(load().sober_i64_to_i32(src.data_ptr(), src.numel(), dst.data_ptr(), _stream(src)),
+           "sober_i64_to_i32")
+
+
+def car_pivot_host(Phi: torch.Tensor, mu: torch.Tensor) -> int:
+    """Host tensors (CPU, float64, contiguous).  Phi (N, m) is destroyed, mu updated in place."""
+    if Phi.is_cuda or mu.is_cuda:
+        raise SoberHipError("car_pivot_host takes host tensors")
+    _req(Phi, torch.float64, "Phi"); _req(mu, torch.float64, "mu")
+    N, m = Phi.shape
+    r = load().sober_car_pivot_host(Phi.data_ptr(), N, m, mu.data_ptr())
+    _check(min(r, 0), "sober_car_pivot_host")
+    return r
+
+
+def kmeans_lloyd(X, K, iters, centroids, labels):
+    N, d = X.shape
+    _req(X, torch.float64, "X"); _req(centroids, torch.float64, "centroids"); _req(labels, torch.int32, "labels")
+    _check(load().sober_kmeans_lloyd(X.data_ptr(), N, d, K, iters, centroids.data_ptr(), labels.data_ptr(),
+                                     None, 0, _stream(X)), "sober_kmeans_lloyd")
+
+
+def cleansing_weights(w, eps):
+    _req(w, torch.float64, "weights")
+    nbytes = load().sober_reduce_ws_bytes(w.numel())
+    ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=w.device)
+    _check(load().sober_cleansing_weights(w.data_ptr(), w.numel(), float(eps), ws.data_ptr(), nbytes,
+                                          _stream(w)), "sober_cleansing_weights")

@@ -1,0 +1,206 @@
+"""Device operations of the recombination engine on the HIP library (the only product backend).
+
+`HipOps` owns no algorithmic decision: it allocates workspaces with torch and enqueues the C-ABI
+kernels on the current stream.  The level logic lives in `_engine.py`."""
+from __future__ import annotations
+
+import torch
+
+from . import _native as nat
+from ._kernel import KernelSpec, PointSet, posterior_mean, prepare_points, woodbury
+
+
+class Plan:
+    """Per-step device state shared by all levels."""
+    pass
+
+
+class HipOps:
+    name = "hip"
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise nat.SoberHipError("sober_amd needs a HIP device (torch device 'cuda'); got "
+                                    f"{self.device}.  There is no CPU fallback.")
+        nat.load()
+        self._pin = {}
+        self.prof = None        # list -> (start_event, end_event, kernel entries) per level_reduce launch
+
+    # ------------------------------------------------------------------ plan
+    def build_plan(self, spec: KernelSpec, mode: str, X_nys, X_cand) -> Plan:
+        p = Plan()
+        p.spec, p.mode = spec, mode
+        p.kind = nat.KIND_BY_NAME[spec.kind]
+        p.M = X_nys.shape[0]
+        dev = self.device
+        corrected = mode != "kernel"
+        p.n_obs = spec.X_obs.shape[0] if corrected else 0
+        stacked = torch.cat([X_nys.to(torch.float64), spec.X_obs], 0) if corrected else X_nys
+        p.rows = prepare_points(spec, stacked)                    # [X_nys; X_obs]
+        p.cand = prepare_points(spec, X_cand)
+        p.Mtot = len(p.rows)
+        p.weighted = mode == "weighted_predictive_covariance"
+        p.mean_nys = p.wmul = None
+        if p.weighted:
+            p.mean_nys = posterior_mean(spec, p.rows.rows(0, p.M))
+            p.wmul = posterior_mean(spec, p.cand)                 # mu_y of SOBER/_kernel.py:41
+        p.T = None
+        if corrected:
+            # T = KxX @ W with KxX = k(X_nys, X_obs) (SOBER/_gp.py:293,295)
+            Kall = torch.empty(p.Mtot, p.M, dtype=torch.float64, device=dev)
+            nys = p.rows.rows(0, p.M)
+            nat.pairwise(p.kind, p.rows.data, p.rows.norm, nys.data, nys.norm, None, p.M, p.rows.dt,
+                         spec.outputscale, Kall)
+            p.Kall = Kall
+            W = woodbury(spec)
+            p.T = torch.empty(p.M, p.n_obs, dtype=torch.float64, device=dev)
+            nat.dgemm(Kall[p.M:], W, p.T, transa=True)            # K_Xn^T W == KxX W (k symmetric)
+        p.P = None
+        p.ws = {}
+        return p
+
+    def gram(self, p: Plan):
+        """kernel(pt, pt) of SOBER/_rchq.py:35 for the plan's mode."""
+        dev = self.device
+        if p.T is None:
+            nys = p.rows
+            G = torch.empty(p.M, p.M, dtype=torch.float64, device=dev)
+            nat.pairwise(p.kind, nys.data, nys.norm, nys.data, nys.norm, None, p.M, nys.dt,
+                         p.spec.outputscale, G)
+            return G
+        G = p.Kall[:p.M].clone()
+        nat.dgemm(p.T, p.Kall[p.M:], G, alpha=-1.0, beta=1.0)     # Kxy - (KxX W) KXy
+        if p.weighted:
+            G = p.mean_nys.unsqueeze(1) * G * p.mean_nys.unsqueeze(0)
+        return G
+
+    def set_projection(self, p: Plan, U):
+        """P = [U diag(mean), -(U diag(mean)) T]: phi(x) = P k([X_nys; X_obs], x) is the vector of
+        Nystrom test functions U @ C(X_nys, x) (SOBER/_rchq.py:78,148,156) with the posterior
+        correction of SOBER/_gp.py:295 folded in (it is linear)."""
+        U = U.to(self.device, torch.float64).contiguous()
+        p.n = U.shape[0]
+        P1 = U * p.mean_nys.unsqueeze(0) if p.weighted else U
+        if p.T is None:
+            p.P = P1.contiguous()
+            return
+        P = torch.empty(p.n, p.Mtot, dtype=torch.float64, device=self.device)
+        P[:, :p.M] = P1
+        nat.dgemm(P1.contiguous(), p.T, P[:, p.M:], alpha=-1.0)
+        p.P = P
+
+    # ------------------------------------------------------------------ levels
+    def _prof_begin(self):
+        if self.prof is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.device))      # the stream the kernel is launched on
+        return ev
+
+    def _prof_end(self, ev, entries):
+        if ev is None:
+            return
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(torch.cuda.current_stream(self.device))
+        self.prof.append((ev, ev1, int(entries)))
+
+    def _buf(self, p, name, numel):
+        t = p.ws.get(name)
+        if t is None or t.numel() < numel:
+            t = torch.empty(numel, dtype=torch.float64, device=self.device)
+            p.ws[name] = t
+        return t
+
+    def level_moments(self, p: Plan, idx, pos0, count, S, E, mu):
+        """Partial (n, S) projected set sums and (S,) set masses over the local list positions
+        [pos0, pos0+count) of a level with E full elements (SOBER/_rchq.py:116-164 minus the
+        division).  Q1: leftovers (p >= E*S) are summed into set p mod S AND into set S-1; only
+        the latter reaches `tot`."""
+        dev = self.device
+        ES = E * S
+        n_chunks = nat.level_chunks(p.Mtot, pos0, count, S)
+        partG = self._buf(p, "partG", n_chunks * p.Mtot * S)
+        partTot = self._buf(p, "partTot", n_chunks * S)
+        ev = self._prof_begin()
+        nat.level_reduce(p.kind, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, p.rows.dt, idx, 0,
+                         pos0, count, S, mu, p.wmul, p.spec.outputscale, n_chunks, partG, S, 0, partTot, ES)
+        self._prof_end(ev, count * p.Mtot)
+        extraG = extraTot = None
+        n_xchunks, XS = 0, 16
+        lo = max(pos0, ES)                                   # first local leftover position
+        n_left = pos0 + count - lo
+        if n_left > 0:
+            # second placement of the leftovers (:153-164): the same kernel over the leftover
+            # positions alone, spread over XS pseudo-sets that sum_partials folds into set S-1
+            n_xchunks = nat.level_chunks(p.Mtot, 0, n_left, XS)
+            extraG = self._buf(p, "extraG", n_xchunks * p.Mtot * XS)
+            extraTot = self._buf(p, "extraTot", n_xchunks * XS)
+            ev = self._prof_begin()
+            nat.level_reduce(p.kind, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, p.rows.dt, idx,
+                             lo - pos0, 0, n_left, XS, mu, p.wmul, p.spec.outputscale, n_xchunks, extraG,
+                             XS, 0, extraTot, n_left)
+            self._prof_end(ev, n_left * p.Mtot)
+        G = self._buf(p, "G", p.Mtot * S).view(p.Mtot, S)
+        tot = torch.empty(S, dtype=torch.float64, device=dev)
+        nat.sum_partials(partG, partTot, n_chunks, p.Mtot, S, S, extraG, extraTot, n_xchunks, XS, G, tot)
+        Xtr = torch.empty(p.n, S, dtype=torch.float64, device=dev)
+        nat.dgemm(p.P, G, Xtr)
+        return Xtr, tot
+
+    def direct_columns(self, p: Plan, idx, count):
+        """(count, n) rows U @ kernel(pt_nys, samp[idx]) of the final direct level
+        (SOBER/_rchq.py:78)."""
+        dev = self.device
+        K = torch.empty(p.Mtot, count, dtype=torch.float64, device=dev)
+        nat.pairwise(p.kind, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, idx, count, p.rows.dt,
+                     p.spec.outputscale, K)
+        if p.weighted:
+            K = K * p.wmul[idx[:count].long()].unsqueeze(0)
+        Xtr = torch.empty(p.n, count, dtype=torch.float64, device=dev)
+        nat.dgemm(p.P, K, Xtr)
+        out = torch.empty(count, p.n, dtype=torch.float64, device=dev)
+        nat.barycentres(Xtr, p.n, count, None, out)
+        return out
+
+    def barycentres(self, Xtr, tot):
+        n, S = Xtr.shape
+        out = torch.empty(S, n, dtype=torch.float64, device=self.device)
+        nat.barycentres(Xtr, n, S, tot, out)
+        return out
+
+    def level_update(self, idx_cur, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0):
+        nat.level_update(idx_cur, 0, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0)
+
+    def scatter_weights(self, idx_cur, sel, w, mu):
+        out = torch.empty(sel.numel(), dtype=torch.int64, device=self.device)
+        if sel.numel():
+            nat.scatter_weights(idx_cur, sel, w, sel.numel(), mu, out)
+        return out
+
+    # ------------------------------------------------------------------ plumbing
+    def nonzero_i32(self, mu):
+        nz = torch.nonzero(mu != 0).flatten()
+        out = torch.empty(max(nz.numel(), 1), dtype=torch.int32, device=self.device)
+        if nz.numel():
+            nat.i64_to_i32(nz, out)
+        return out, int(nz.numel())
+
+    def empty_i32(self, n):
+        return torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+
+    def to_host(self, *tensors):
+        outs = []
+        for i, t in enumerate(tensors):
+            key = (i, t.dtype, tuple(t.shape))
+            buf = self._pin.get(key)
+            if buf is None:
+                buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                self._pin[key] = buf
+            buf.copy_(t, non_blocking=True)
+            outs.append(buf)
+        torch.cuda.current_stream(self.device).synchronize()
+        return [o.clone() for o in outs]
+
+    def from_host(self, t, dtype=None):
+        return t.to(self.device, dtype=dtype, non_blocking=False)

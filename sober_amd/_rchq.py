@@ -1,0 +1,80 @@
+"""`recombination` with the reference's signature (SOBER/_rchq.py:5-31) on the MI355X.
+
+    idx_star, w_star = recombination(pts_rec, pts_nys, num_pts, kernel, device, dtype,
+                                     init_weights=None, calc_obj=None)
+
+`kernel` is a `sober_amd.Kernel` (RBF / Matern-5/2 / Tanimoto posterior covariance, weighted or
+raw): the whole step then runs on the fused HIP path -- the (E, M, S) kernel tensor of
+SOBER/_rchq.py:124 is never materialised.  As in the reference, `device`/`dtype` are accepted and
+ignored (the reference builds a SafeTensorOperator from the module globals, :30), `init_weights`
+is modified in place (Q3), and the result depends on the global CPU RNG state through
+`torch.svd_lowrank` (seed it before the call for repeatability).
+"""
+from __future__ import annotations
+
+import torch
+
+from ._engine import DistComm, RecombinationEngine, SoloComm
+from ._kernel import MODES, Kernel
+from ._settings import setting_parameters
+
+
+def _device_of(t, fallback):
+    return t.device if t.is_cuda else fallback
+
+
+def recombination(pts_rec, pts_nys, num_pts, kernel, device=None, dtype=None, init_weights=None,
+                  calc_obj=None, *, group=None, row_offset=0, _ops=None, _trace=None, _timers=None):
+    """Kernel recombination of the weighted empirical measure (pts_rec, init_weights) down to at
+    most `num_pts` points with positive weights that preserve the integrals of num_pts-1 Nystrom
+    test functions built on `pts_nys`.  Returns (idx_star int64, w_star float64).
+
+    Keyword-only extensions (not in the reference):
+      group       a torch.distributed group: `pts_rec`/`init_weights` are then this rank's ROW SHARD
+                  of the pool (global row index = row_offset + local index) and every rank returns
+                  the same global (idx_star, w_star); one small all-reduce per level.
+    """
+    if calc_obj is not None:
+        raise NotImplementedError("the acquisition-guided branch (calc_obj, SOBER/_rchq.py:67-69) "
+                                  "is not on the MI355X path yet")
+    if not isinstance(kernel, Kernel):
+        raise TypeError("sober_amd.recombination needs a sober_amd.Kernel (the fused HIP path reads the "
+                        f"kernel's hyper-parameters); got {type(kernel).__name__}")
+    if kernel.mode not in MODES:
+        raise ValueError('mode should be from ["predictive_covariance", '
+                         '"weighted_predictive_covariance", "kernel"]')
+    if _ops is None:
+        from ._ops_hip import HipOps
+        glob_dev, _ = setting_parameters()
+        dev = _device_of(pts_rec, glob_dev)
+        _ops = HipOps(dev)                       # raises when there is no HIP device / library
+    dev = _ops.device
+
+    N = pts_rec.shape[0]
+    X_cand = pts_rec.detach().to(dev, torch.float64)
+    X_nys = pts_nys.detach().to(dev, torch.float64)
+    caller_mu = init_weights
+    if init_weights is None:
+        mu = torch.ones(N, dtype=torch.float64, device=dev) / N          # :60-61
+    elif init_weights.device == dev and init_weights.dtype == torch.float64 and init_weights.is_contiguous():
+        mu = init_weights                                                 # mutated in place (Q3)
+    else:
+        mu = init_weights.detach().to(dev, torch.float64).contiguous()
+
+    comm = DistComm(group) if group is not None else SoloComm()
+    eng = RecombinationEngine(_ops, comm, row_offset=row_offset)
+    eng.trace = _trace
+    plan = _ops.build_plan(kernel.spec(dev), kernel.mode, X_nys, X_cand)
+    idx_star, w_star = eng.run(plan, mu, int(num_pts))
+    if _timers is not None:
+        for k, v in eng.timers.items():
+            _timers[k] = _timers.get(k, 0.0) + v
+
+    if caller_mu is not None and mu is not caller_mu:
+        caller_mu.copy_(mu.to(caller_mu.device, caller_mu.dtype))         # keep Q3 for foreign tensors
+    return idx_star, w_star
+
+
+def rc_kernel_svd(samp, pt, s, kernel, tm=None, mu=None, calc_obj=None):
+    """SOBER/_rchq.py:42-48."""
+    return recombination(samp, pt, s, kernel, init_weights=mu, calc_obj=calc_obj)

@@ -1,0 +1,403 @@
+// Small kernels around the hot path: point preparation, materialised kernel matrices, posterior
+// mean over a pool, partial-sum reduction, barycentres, the K7 weight/list update, weight scrubbing.
+#include "common.hpp"
+
+namespace sober {
+
+// ------------------------------------------------------------------ point preparation
+__global__ void k_scale_points(const double* __restrict__ X, int64_t n, int d, int64_t ldx,
+                               const double* __restrict__ ls, int ls_len, double* __restrict__ out,
+                               int dt) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * dt) return;
+    const int64_t i = t / dt;
+    const int j = (int)(t % dt);
+    double v = 0.0;
+    if (j < d) v = X[i * ldx + j] / ls[ls_len == 1 ? 0 : j];
+    out[t] = v;
+}
+
+// one wave per row: ballot packs 64 bits at a time
+__global__ void k_pack_bits(const double* __restrict__ X, int64_t n, int d, int64_t ldx,
+                            uint64_t* __restrict__ words, int nwords, double* __restrict__ norms,
+                            int32_t* __restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    int pop = 0;
+    for (int w = 0; w < nwords; ++w) {
+        const int j = w * 64 + lane;
+        double v = (j < d) ? X[row * ldx + j] : 0.0;
+        if (v != 0.0 && v != 1.0) atomicExch(bad, 1);
+        const unsigned long long m = __ballot(v != 0.0);
+        if (lane == 0) words[row * nwords + w] = m;
+        pop += __popcll(m);
+    }
+    if (lane == 0) norms[row] = (double)pop;
+}
+
+// ------------------------------------------------------------------ materialised kernel matrix
+template <int KIND>
+__global__ void k_pairwise(const double* __restrict__ a, const double* __restrict__ an, int64_t m,
+                           const double* __restrict__ b, const double* __restrict__ bn,
+                           const int32_t* __restrict__ idx, int64_t n, int dt, double os,
+                           double* __restrict__ out, int64_t ldo) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= n) return;
+    const int64_t c = idx ? (int64_t)idx[j] : j;
+    double nx = 0.0, ny = 0.0;
+    if constexpr (KIND == SOBER_KIND_TANIMOTO) { nx = an[i]; ny = bn[c]; }
+    out[i * ldo + j] = kern_eval_rt<KIND>(a + i * dt, nx, b + c * dt, ny, dt, os);
+}
+
+// out[j] = c0 + sum_i k(a_i, b_j) v_i : lanes <-> pool points, a tiles broadcast from LDS
+template <int KIND, int DT>
+__global__ __launch_bounds__(256) void k_kernel_matvec(
+    const double* __restrict__ a, const double* __restrict__ an, const double* __restrict__ v,
+    int64_t m, const double* __restrict__ b, const double* __restrict__ bn, int64_t n, double os,
+    double c0, double* __restrict__ out) {
+    constexpr int TA = 64;
+    __shared__ double s_a[TA][DT];
+    __shared__ double s_v[TA];
+    __shared__ double s_n[TA];
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double y[DT];
+    double ny = 0.0;
+    if (j < n) {
+#pragma unroll
+        for (int q = 0; q < DT; ++q) y[q] = b[j * DT + q];
+        if constexpr (KIND == SOBER_KIND_TANIMOTO) ny = bn[j];
+    } else {
+#pragma unroll
+        for (int q = 0; q < DT; ++q) y[q] = 0.0;
+    }
+    double acc = 0.0;
+    for (int64_t i0 = 0; i0 < m; i0 += TA) {
+        const int cnt = (int)min((int64_t)TA, m - i0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt * DT; t += blockDim.x) s_a[t / DT][t % DT] = a[i0 * DT + t];
+        if (threadIdx.x < cnt) {
+            s_v[threadIdx.x] = v[i0 + threadIdx.x];
+            s_n[threadIdx.x] = (KIND == SOBER_KIND_TANIMOTO) ? an[i0 + threadIdx.x] : 0.0;
+        }
+        __syncthreads();
+        for (int i = 0; i < cnt; ++i) {
+            double xa[DT];
+#pragma unroll
+            for (int q = 0; q < DT; ++q) xa[q] = s_a[i][q];
+            acc = fma(kern_eval<KIND, DT>(xa, s_n[i], y, ny, os), s_v[i], acc);
+        }
+    }
+    if (j < n) out[j] = c0 + acc;
+}
+
+// ------------------------------------------------------------------ level plumbing
+__global__ void k_sum_partials(const double* __restrict__ partG, const double* __restrict__ partTot,
+                               int n_chunks, int n_rows, int ldg, int S,
+                               const double* __restrict__ extraG, const double* __restrict__ extraTot,
+                               int n_xchunks, int n_xcols,
+                               double* __restrict__ G, int ldo, double* __restrict__ tot) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;            // row == n_rows -> the tot vector
+    if (s >= S) return;
+    const bool fold = (extraG != nullptr) && (s == S - 1);
+    if (row < n_rows) {
+        double acc = 0.0;
+        for (int c = 0; c < n_chunks; ++c) acc += partG[((size_t)c * n_rows + row) * ldg + s];
+        if (fold) {
+            double ex = 0.0;
+            for (int c = 0; c < n_xchunks; ++c)
+                for (int q = 0; q < n_xcols; ++q) ex += extraG[((size_t)c * n_rows + row) * n_xcols + q];
+            acc += ex;
+        }
+        G[(size_t)row * ldo + s] = acc;
+    } else if (tot != nullptr && partTot != nullptr) {
+        double acc = 0.0;
+        for (int c = 0; c < n_chunks; ++c) acc += partTot[(size_t)c * ldg + s];
+        if (fold && extraTot != nullptr) {
+            double ex = 0.0;
+            for (int c = 0; c < n_xchunks; ++c)
+                for (int q = 0; q < n_xcols; ++q) ex += extraTot[(size_t)c * n_xcols + q];
+            acc += ex;
+        }
+        tot[s] = acc;
+    }
+}
+
+__global__ void k_barycentres(const double* __restrict__ Xtr, int ldx, int n, int S,
+                              const double* __restrict__ tot, double* __restrict__ X_tmp) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * S) return;
+    const int s = t / n, i = t % n;
+    double v = Xtr[(size_t)i * ldx + s];
+    if (tot) v = v / tot[s];
+    X_tmp[t] = v;
+}
+
+__global__ void k_level_update(const int32_t* __restrict__ idx_cur, int64_t pos0, int64_t count, int S,
+                               int64_t E, const int32_t* __restrict__ keep_rank,
+                               const double* __restrict__ w_star, const double* __restrict__ tot,
+                               int n_keep, double* __restrict__ mu, int32_t* __restrict__ idx_new,
+                               int64_t new_pos0) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int64_t p = pos0 + t;               // global list position
+    const int64_t ES = E * S;
+    const int c = idx_cur[t];
+    int s;
+    int64_t dst;
+    if (p < ES) {
+        s = (int)(p % S);
+        const int k = keep_rank[s];
+        dst = (k >= 0) ? (p / S) * n_keep + k : -1;
+    } else {                                   // leftovers ride on the last set (:208-218)
+        s = S - 1;
+        dst = (keep_rank[s] >= 0) ? E * n_keep + (p - ES) : -1;
+    }
+    if (dst >= 0) {
+        const int k = keep_rank[s];
+        mu[c] = (mu[c] * w_star[k]) / tot[s];   // multiply, then divide (:204-205, :212-213)
+        idx_new[dst - new_pos0] = c;
+    } else {
+        mu[c] = 0.0;
+    }
+}
+
+__global__ void k_scatter_weights(const int32_t* __restrict__ idx_cur, const int32_t* __restrict__ sel,
+                                  const double* __restrict__ w, int n_sel, double* __restrict__ mu,
+                                  int64_t* __restrict__ out_idx) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_sel) return;
+    const int c = idx_cur[sel[k]];
+    mu[c] = w[k];
+    out_idx[k] = c;
+}
+
+__global__ void k_i64_to_i32(const int64_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = (int32_t)in[t];
+}
+
+// ------------------------------------------------------------------ cleansing_weights
+constexpr int CW_BLOCKS = 256, CW_THREADS = 256;
+
+__global__ __launch_bounds__(CW_THREADS) void k_clean_partial(double* __restrict__ w, int64_t n,
+                                                              double eps, double* __restrict__ part) {
+    __shared__ double s[CW_THREADS];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CW_THREADS + threadIdx.x; i < n;
+         i += (int64_t)CW_BLOCKS * CW_THREADS) {
+        double v = w[i];
+        if (v < eps) v = 0.0;          // NaN compares false, -inf -> 0  (_weights.py:31)
+        if (isinf(v)) v = eps;         // :32
+        if (isnan(v)) v = eps;         // :33
+        w[i] = v;
+        acc += v;
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = CW_THREADS / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(CW_BLOCKS) void k_clean_total(double* __restrict__ part) {
+    __shared__ double s[CW_BLOCKS];
+    s[threadIdx.x] = part[threadIdx.x];
+    __syncthreads();
+    for (int o = CW_BLOCKS / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[CW_BLOCKS] = s[0];
+}
+
+__global__ void k_clean_scale(double* __restrict__ w, int64_t n, const double* __restrict__ part) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double tot = part[CW_BLOCKS];
+    w[i] = (tot != 0.0) ? w[i] / tot : 1.0 / (double)n;     // :34-37
+}
+
+}  // namespace sober
+
+using namespace sober;
+
+static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+extern "C" int sober_abi_version(void) { return SOBER_ABI_VERSION; }
+
+extern "C" int sober_padded_dim(int d) {
+    if (d <= 0) return SOBER_E_ARG;
+    const int dts[] = {4, 8, 12, 16, 20, 24, 32};
+    for (int v : dts)
+        if (d <= v) return v;
+    return SOBER_E_DIM;
+}
+
+extern "C" int sober_bit_words(int d) {
+    if (d <= 0) return SOBER_E_ARG;
+    const int w = (d + 63) / 64;
+    const int ws[] = {1, 2, 4, 8, 16, 32};
+    for (int v : ws)
+        if (w <= v) return v;
+    return SOBER_E_DIM;
+}
+
+extern "C" int sober_scale_points(const double* X, int64_t n, int d, int64_t ldx,
+                                  const double* lengthscale, int ls_len, double* out, int dt,
+                                  void* stream) {
+    if (!X || !lengthscale || !out || n <= 0 || d <= 0 || dt < d || ldx < d) return SOBER_E_ARG;
+    if (ls_len != 1 && ls_len != d) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_scale_points, dim3(nblk(n * dt, 256)), dim3(256), 0, (hipStream_t)stream, X,
+                       n, d, ldx, lengthscale, ls_len, out, dt);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_pack_bits(const double* X, int64_t n, int d, int64_t ldx, uint64_t* words,
+                               int nwords, double* norms, int32_t* bad_flag, void* stream) {
+    if (!X || !words || !norms || !bad_flag || n <= 0 || d <= 0 || nwords * 64 < d || ldx < d)
+        return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_pack_bits, dim3(nblk(n, 4)), dim3(256), 0, (hipStream_t)stream, X, n, d, ldx,
+                       words, nwords, norms, bad_flag);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_pairwise(int kind, const void* a, const double* a_norm, int64_t m, const void* b,
+                              const double* b_norm, const int32_t* idx, int64_t n, int dt,
+                              double outputscale, double* out, int64_t ldo, void* stream) {
+    if (!a || !b || !out || m <= 0 || n <= 0 || dt <= 0 || ldo < n || m > 65535) return SOBER_E_ARG;
+    if (kind == SOBER_KIND_TANIMOTO && (!a_norm || !b_norm)) return SOBER_E_ARG;
+    dim3 grid(nblk(n, 256), (unsigned)m);
+    hipStream_t st = (hipStream_t)stream;
+    const double* A = (const double*)a;
+    const double* B = (const double*)b;
+    switch (kind) {
+        case SOBER_KIND_RBF:
+            hipLaunchKernelGGL(k_pairwise<SOBER_KIND_RBF>, grid, dim3(256), 0, st, A, a_norm, m, B,
+                               b_norm, idx, n, dt, outputscale, out, ldo);
+            break;
+        case SOBER_KIND_MATERN52:
+            hipLaunchKernelGGL(k_pairwise<SOBER_KIND_MATERN52>, grid, dim3(256), 0, st, A, a_norm, m, B,
+                               b_norm, idx, n, dt, outputscale, out, ldo);
+            break;
+        case SOBER_KIND_TANIMOTO:
+            hipLaunchKernelGGL(k_pairwise<SOBER_KIND_TANIMOTO>, grid, dim3(256), 0, st, A, a_norm, m, B,
+                               b_norm, idx, n, dt, outputscale, out, ldo);
+            break;
+        default: return SOBER_E_ARG;
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <int KIND, int DT>
+static int launch_mv(const void* a, const double* an, const double* v, int64_t m, const void* b,
+                     const double* bn, int64_t n, double os, double c0, double* out, hipStream_t st) {
+    hipLaunchKernelGGL((k_kernel_matvec<KIND, DT>), dim3(nblk(n, 256)), dim3(256), 0, st,
+                       (const double*)a, an, v, m, (const double*)b, bn, n, os, c0, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_kernel_matvec(int kind, const void* a, const double* a_norm, const double* v,
+                                   int64_t m, const void* b, const double* b_norm, int64_t n, int dt,
+                                   double outputscale, double c0, double* out, void* stream) {
+    if (!a || !v || !b || !out || m <= 0 || n <= 0) return SOBER_E_ARG;
+    if (kind == SOBER_KIND_TANIMOTO && (!a_norm || !b_norm)) return SOBER_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+#define MV_CASE(K, D) \
+    case D: return launch_mv<K, D>(a, a_norm, v, m, b, b_norm, n, outputscale, c0, out, st);
+    switch (kind) {
+        case SOBER_KIND_RBF:
+            switch (dt) { MV_CASE(SOBER_KIND_RBF, 4) MV_CASE(SOBER_KIND_RBF, 8) MV_CASE(SOBER_KIND_RBF, 12)
+                          MV_CASE(SOBER_KIND_RBF, 16) MV_CASE(SOBER_KIND_RBF, 20)
+                          MV_CASE(SOBER_KIND_RBF, 24) MV_CASE(SOBER_KIND_RBF, 32)
+                          default: return SOBER_E_DIM; }
+        case SOBER_KIND_MATERN52:
+            switch (dt) { MV_CASE(SOBER_KIND_MATERN52, 4) MV_CASE(SOBER_KIND_MATERN52, 8)
+                          MV_CASE(SOBER_KIND_MATERN52, 12) MV_CASE(SOBER_KIND_MATERN52, 16)
+                          MV_CASE(SOBER_KIND_MATERN52, 20) MV_CASE(SOBER_KIND_MATERN52, 24)
+                          MV_CASE(SOBER_KIND_MATERN52, 32) default: return SOBER_E_DIM; }
+        case SOBER_KIND_TANIMOTO:
+            switch (dt) { MV_CASE(SOBER_KIND_TANIMOTO, 1) MV_CASE(SOBER_KIND_TANIMOTO, 2)
+                          MV_CASE(SOBER_KIND_TANIMOTO, 4) MV_CASE(SOBER_KIND_TANIMOTO, 8)
+                          MV_CASE(SOBER_KIND_TANIMOTO, 16) MV_CASE(SOBER_KIND_TANIMOTO, 32)
+                          default: return SOBER_E_DIM; }
+        default: return SOBER_E_ARG;
+    }
+#undef MV_CASE
+}
+
+extern "C" int sober_sum_partials(const double* partG, const double* partTot, int n_chunks,
+                                  int n_rows, int ldg, int S, const double* extraG,
+                                  const double* extraTot, int n_xchunks, int n_xcols, double* G,
+                                  int ldo, double* tot, void* stream) {
+    if (!partG || !G || n_chunks <= 0 || n_rows <= 0 || S <= 0 || ldg < S || ldo < S) return SOBER_E_ARG;
+    if (extraG && (n_xchunks <= 0 || n_xcols <= 0)) return SOBER_E_ARG;
+    dim3 grid(nblk(S, 64), (unsigned)(n_rows + 1));
+    hipLaunchKernelGGL(k_sum_partials, grid, dim3(64), 0, (hipStream_t)stream, partG, partTot, n_chunks,
+                       n_rows, ldg, S, extraG, extraTot, n_xchunks, n_xcols, G, ldo, tot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_barycentres(const double* Xtr, int ldx, int n, int S, const double* tot,
+                                 double* X_tmp, void* stream) {
+    if (!Xtr || !X_tmp || n <= 0 || S <= 0 || ldx < S) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_barycentres, dim3(nblk((int64_t)n * S, 256)), dim3(256), 0,
+                       (hipStream_t)stream, Xtr, ldx, n, S, tot, X_tmp);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_level_update(const int32_t* idx_cur, int64_t pos0, int64_t count, int S, int64_t E,
+                                  const int32_t* keep_rank, const double* w_star, const double* tot,
+                                  int n_keep, double* mu, int32_t* idx_new, int64_t new_pos0,
+                                  void* stream) {
+    if (!idx_cur || !keep_rank || !w_star || !tot || !mu || !idx_new) return SOBER_E_ARG;
+    if (pos0 < 0 || count <= 0 || S <= 0 || E <= 0 || n_keep < 0 || n_keep > S || new_pos0 < 0)
+        return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_level_update, dim3(nblk(count, 256)), dim3(256), 0, (hipStream_t)stream,
+                       idx_cur, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_scatter_weights(const int32_t* idx_cur, const int32_t* sel, const double* w,
+                                     int n_sel, double* mu, int64_t* out_idx, void* stream) {
+    if (!idx_cur || !sel || !w || !mu || !out_idx || n_sel <= 0) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_scatter_weights, dim3(nblk(n_sel, 256)), dim3(256), 0, (hipStream_t)stream,
+                       idx_cur, sel, w, n_sel, mu, out_idx);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_i64_to_i32(const int64_t* in, int64_t n, int32_t* out, void* stream) {
+    if (!in || !out || n <= 0) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_i64_to_i32, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, in, n, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t sober_reduce_ws_bytes(int64_t n) { (void)n; return (CW_BLOCKS + 1) * sizeof(double); }
+
+extern "C" int sober_cleansing_weights(double* w, int64_t n, double eps, void* ws, int64_t ws_bytes,
+                                       void* stream) {
+    if (!w || !ws || n <= 0) return SOBER_E_ARG;
+    if (ws_bytes < sober_reduce_ws_bytes(n)) return SOBER_E_WS;
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)ws;
+    hipLaunchKernelGGL(k_clean_partial, dim3(CW_BLOCKS), dim3(CW_THREADS), 0, st, w, n, eps, part);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_clean_total, dim3(1), dim3(CW_BLOCKS), 0, st, part);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_clean_scale, dim3(nblk(n, 256)), dim3(256), 0, st, w, n, part);
+    LAUNCH_CHECK();
+    return 0;
+}

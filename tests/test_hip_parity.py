@@ -1,0 +1,303 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs and against the committed golden fixtures.
+
+Bars: indices identical; weights rtol 1e-4 (BASELINE.json north_star) -- we assert 1e-7, two
+orders above what is observed; integer/index work bit-exact."""
+import glob
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import sober_amd
+from oracle import sober_oracle as O
+from tests._oracle_ops import OracleOps
+from tests.golden.synth import SEED_CALL, load_case
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SMALL = sorted(p for p in glob.glob(os.path.join(GOLD, "recomb_*.npz")) if "calc_obj" not in p and "cfg2" not in p)
+W_RTOL = 1e-7
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the -m gpu tests need the MI355X"
+    from sober_amd import _native
+    _native.load()
+    return torch.device("cuda:0")
+
+
+def kspec(spec):
+    return sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs, spec.S_cache,
+                                spec.noise, spec.mean_const, spec.alpha)
+
+
+def run_hip(path, dev, trace=None):
+    case, inp, spec, z = load_case(path)
+    mu = _t(inp["mu0"].copy()).to(dev)
+    kernel = sober_amd.Kernel(kspec(spec), case["mode"])
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                         kernel, dev, torch.double, init_weights=mu, _trace=trace)
+    return case, inp, z, idx, w, mu
+
+
+# --------------------------------------------------------------------------- #
+# end to end
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("path", SMALL, ids=lambda p: os.path.basename(p)[7:-4])
+def test_recombination_vs_golden(path, dev):
+    trace = {}
+    case, inp, z, idx, w, mu = run_hip(path, dev, trace)
+    assert idx.is_cuda and w.is_cuda and idx.dtype == torch.int64
+    assert np.array_equal(idx.cpu().numpy(), z["idx"])
+    np.testing.assert_allclose(w.cpu().numpy(), z["w"], rtol=W_RTOL, atol=0)
+    mu_h = mu.cpu()
+    nz = torch.nonzero(mu_h).flatten().numpy()
+    assert np.array_equal(nz, z["mu_after_idx"])                               # Q3
+    np.testing.assert_allclose(mu_h.numpy()[nz], z["mu_after_val"], rtol=W_RTOL)
+    assert len(trace["levels"]) == int(z["n_levels"])
+    np.testing.assert_allclose(trace["gram"].numpy(), z["gram_in"], rtol=1e-9, atol=1e-13)
+    for i, lv in enumerate(trace["levels"]):
+        assert np.array_equal(lv["idx_star"].numpy(), z[f"L{i}_idx_star"]), i
+        np.testing.assert_allclose(lv["tot_weights"].numpy(), z[f"L{i}_tot_weights"], rtol=1e-9)
+        np.testing.assert_allclose(lv["X_tmp"].numpy(), z[f"L{i}_X_tmp"], rtol=1e-6, atol=1e-10)
+
+
+def test_recombination_vs_oracle_same_inputs(dev):
+    """Fresh seeded inputs (not a fixture): the oracle runs beside the HIP path."""
+    rng = np.random.default_rng(77)
+    N, M, d, b, n_obs = 6000, 150, 7, 25, 60
+    X = rng.random((N, d)); Xo = rng.random((n_obs, d)); mu0 = rng.random(N); mu0 /= mu0.sum()
+    Xn = X[rng.permutation(N)[:M]].copy()
+    spec = O.make_spec(O.RBF, _t(Xo), _t(0.3 * np.sqrt(d) * (1 + np.arange(d) / d)), outputscale=2.0,
+                       noise=1e-2, y_obs=_t(rng.standard_normal(n_obs)))
+    mu_ref = _t(mu0.copy())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(5)
+        idx_ref, w_ref = O.recombination(_t(X), _t(Xn), b, O.Kernel(spec), init_weights=mu_ref)
+        mu = _t(mu0.copy()).to(dev)
+        torch.manual_seed(5)
+        idx, w = sober_amd.recombination(_t(X).to(dev), _t(Xn).to(dev), b, sober_amd.Kernel(kspec(spec)),
+                                         init_weights=mu)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref.numpy())
+    np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=W_RTOL)
+    np.testing.assert_allclose(mu.cpu().numpy(), mu_ref.numpy(), rtol=W_RTOL, atol=0)
+
+
+def test_cfg2_full_size_vs_golden(dev):
+    """BASELINE.json config 2 (N=100k, M=500, d=10, b=100): the reference's own output."""
+    path = os.path.join(GOLD, "recomb_cfg2_rbf.npz")
+    trace = {}
+    case, inp, z, idx, w, mu = run_hip(path, dev, trace)
+    assert np.array_equal(idx.cpu().numpy(), z["idx"])
+    np.testing.assert_allclose(w.cpu().numpy(), z["w"], rtol=W_RTOL)
+    assert len(trace["levels"]) == int(z["n_levels"])
+    for i, lv in enumerate(trace["levels"]):
+        assert np.array_equal(lv["idx_star"].numpy(), z[f"L{i}_idx_star"]), i
+        np.testing.assert_allclose(lv["tot_weights"].numpy(), z[f"L{i}_tot_weights"], rtol=1e-9)
+    # size-independent properties
+    wc = w.cpu()
+    assert (wc > 0).all() and len(wc) <= case["b"]
+    assert abs(float(wc.sum()) - float(inp["mu0"].sum())) < 1e-12
+    assert int((mu != 0).sum()) == len(wc)
+
+
+def test_bit_reproducible(dev):
+    path = os.path.join(GOLD, "recomb_rbf_medium.npz")
+    _, _, _, idx1, w1, mu1 = run_hip(path, dev)
+    _, _, _, idx2, w2, mu2 = run_hip(path, dev)
+    assert torch.equal(idx1, idx2) and torch.equal(w1, w2) and torch.equal(mu1, mu2)
+
+
+def test_moment_identity_without_leftovers(dev):
+    path = os.path.join(GOLD, "recomb_rbf_noleft.npz")
+    trace = {}
+    case, inp, z, idx, w, mu = run_hip(path, dev, trace)
+    _, _, spec, _ = load_case(path)
+    C = O.Kernel(spec, case["mode"])(_t(inp["X_nys"]), _t(inp["X_cand"]))
+    lhs = trace["U"] @ (C @ _t(inp["mu0"]))
+    rhs = trace["U"] @ (C[:, idx.cpu()] @ w.cpu())
+    assert float((lhs - rhs).norm() / lhs.norm()) < 1e-9
+
+
+def test_foreign_weight_tensor_is_still_mutated(dev):
+    """Q3 holds for a caller tensor that is not device/float64 (copied back)."""
+    path = os.path.join(GOLD, "recomb_rbf_noleft.npz")
+    case, inp, spec, z = load_case(path)
+    mu = _t(inp["mu0"].copy())                      # CPU tensor
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                         sober_amd.Kernel(kspec(spec)), init_weights=mu)
+    assert np.array_equal(torch.nonzero(mu).flatten().numpy(), z["mu_after_idx"])
+
+
+def test_sampler_funnel(dev):
+    path = os.path.join(GOLD, "recomb_cfg1_rbf_ard.npz")
+    case, inp, spec, z = load_case(path)
+    sober_amd.setting_parameters(device=dev, dtype=torch.double)
+    rs = sober_amd.RecombinationSampler(sober_amd.Kernel(kspec(spec)))
+    mu = _t(inp["mu0"].copy()).to(dev)
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx, w = rs.sampling_recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), mu, case["b"])
+    assert np.array_equal(idx.cpu().numpy(), z["idx"])
+    np.testing.assert_allclose(w.cpu().numpy(), z["w"], rtol=W_RTOL)
+
+
+# --------------------------------------------------------------------------- #
+# stage level
+# --------------------------------------------------------------------------- #
+def test_kernel_call_matches_reference(dev):
+    z = np.load(os.path.join(GOLD, "kernel_calls.npz"))
+    for kind in (O.RBF, O.MATERN52, O.TANIMOTO):
+        ks = sober_amd.KernelSpec(kind, _t(z[f"{kind}_ls"]), 1.3, _t(z[f"{kind}_X_obs"]),
+                                  _t(z[f"{kind}_S_cache"]), 1e-2, 0.5, _t(z[f"{kind}_alpha"]))
+        x, y2 = _t(z[f"{kind}_x"]).to(dev), _t(z[f"{kind}_y2"]).to(dev)
+        y3 = y2.reshape(5, 8, -1)
+        for mode in ("predictive_covariance", "weighted_predictive_covariance", "kernel"):
+            k = sober_amd.Kernel(ks, mode)
+            np.testing.assert_allclose(k(x, y2).cpu().numpy(), z[f"{kind}_{mode}_2d"], rtol=1e-10, atol=1e-13)
+            out3 = k(x, y3)
+            assert out3.shape == (5, x.shape[0], 8)
+            np.testing.assert_allclose(out3.cpu().numpy(), z[f"{kind}_{mode}_3d"], rtol=1e-10, atol=1e-13)
+    with pytest.raises(ValueError):
+        sober_amd.Kernel(ks, "nope")(x, y2)
+
+
+def test_tanimoto_rejects_non_binary(dev):
+    ks = sober_amd.KernelSpec("tanimoto", torch.ones(1, dtype=torch.double), 1.0,
+                              torch.zeros(3, 8, dtype=torch.double), torch.eye(3, dtype=torch.double))
+    x = torch.rand(4, 8, dtype=torch.double, device=dev)
+    with pytest.raises(ValueError):
+        sober_amd.Kernel(ks, "kernel")(x, x)
+
+
+def test_dgemm_mfma_f64(dev):
+    from sober_amd import _native as nat
+    rng = np.random.default_rng(3)
+    for (m, n, k, ta, tb) in [(99, 200, 700, 0, 0), (500, 200, 500, 1, 0), (200, 200, 200, 0, 1),
+                              (17, 33, 5, 1, 1), (1, 1, 1, 0, 0), (64, 64, 64, 0, 0)]:
+        A = rng.standard_normal((k, m) if ta else (m, k))
+        B = rng.standard_normal((n, k) if tb else (k, n))
+        C0 = rng.standard_normal((m, n))
+        Cd = _t(C0.copy()).to(dev)
+        nat.dgemm(_t(A).to(dev), _t(B).to(dev), Cd, transa=bool(ta), transb=bool(tb), alpha=-0.5, beta=2.0)
+        ref = -0.5 * ((A.T if ta else A) @ (B.T if tb else B)) + 2.0 * C0
+        np.testing.assert_allclose(Cd.cpu().numpy(), ref, rtol=1e-12, atol=1e-12)
+    # exact-integer asymmetric operands catch a transposed C/D fragment map
+    A = np.arange(32 * 8, dtype=np.float64).reshape(32, 8)
+    B = (np.arange(8 * 48, dtype=np.float64).reshape(8, 48) % 7) - 3
+    Cd = torch.zeros(32, 48, dtype=torch.double, device=dev)
+    nat.dgemm(_t(A).to(dev), _t(B).to(dev), Cd)
+    assert np.array_equal(Cd.cpu().numpy(), A @ B)
+
+
+@pytest.mark.parametrize("kind,d", [(O.RBF, 10), (O.MATERN52, 6), (O.TANIMOTO, 200), (O.RBF, 20), (O.RBF, 2)])
+def test_level_moments_vs_test_double(kind, d, dev):
+    """One level (with leftovers and a sharded position range) of the fused kernel against the CPU
+    restatement of the same sums."""
+    from sober_amd._ops_hip import HipOps
+    rng = np.random.default_rng(11)
+    N, M, n_obs, b = 5000, 96, 40, 12
+    S = 2 * b
+    if kind == O.TANIMOTO:
+        X = (rng.random((N, d)) < 0.1).astype(np.float64); Xo = (rng.random((n_obs, d)) < 0.1).astype(np.float64)
+        ls = np.ones(1)
+    else:
+        X = rng.random((N, d)); Xo = rng.random((n_obs, d)); ls = 0.25 * np.sqrt(d) * (1 + np.arange(d) / d)
+    Xn = X[:M].copy()
+    mu0 = rng.random(N)
+    spec = O.make_spec(kind, _t(Xo), _t(ls), outputscale=1.5, y_obs=_t(rng.standard_normal(n_obs)), mean_const=0.2)
+    U = _t(rng.standard_normal((b - 1, M)))
+    live = np.sort(rng.choice(N, size=4321, replace=False)).astype(np.int32)
+    for mode in ("predictive_covariance", "weighted_predictive_covariance", "kernel"):
+        cpu, hip = OracleOps(), HipOps(dev)
+        pc = cpu.build_plan(kspec(spec), mode, _t(Xn), _t(X)); cpu.set_projection(pc, U)
+        ph = hip.build_plan(kspec(spec).to(dev), mode, _t(Xn).to(dev), _t(X).to(dev)); hip.set_projection(ph, U)
+        np.testing.assert_allclose(hip.gram(ph).cpu().numpy(), cpu.gram(pc).numpy(), rtol=1e-10, atol=1e-13)
+        R = len(live); E = R // S
+        for (pos0, count) in [(0, R), (1000, 2000), (E * S - 5, R - (E * S - 5)), (E * S + 3, R - E * S - 3)]:
+            sl = live[pos0:pos0 + count]
+            Xc, tc = cpu.level_moments(pc, _t(sl), pos0, count, S, E, _t(mu0))
+            Xh, th = hip.level_moments(ph, _t(sl).to(dev), pos0, count, S, E, _t(mu0).to(dev))
+            np.testing.assert_allclose(th.cpu().numpy(), tc.numpy(), rtol=1e-12, atol=1e-15)
+            scale = float(Xc.abs().max())
+            np.testing.assert_allclose(Xh.cpu().numpy(), Xc.numpy(), rtol=1e-9, atol=1e-11 * scale)
+        dc = cpu.direct_columns(pc, _t(live[:S - 3]), S - 3)
+        dh = hip.direct_columns(ph, _t(live[:S - 3]).to(dev), S - 3)
+        np.testing.assert_allclose(dh.cpu().numpy(), dc.numpy(), rtol=1e-9, atol=1e-11 * float(dc.abs().max()))
+
+
+def test_level_update_vs_test_double(dev):
+    from sober_amd._ops_hip import HipOps
+    rng = np.random.default_rng(5)
+    S, E, r, N = 20, 7, 6, 1000
+    R = E * S + r
+    live = np.sort(rng.choice(N, size=R, replace=False)).astype(np.int32)
+    for last in (True, False):
+        keep = np.zeros(S, bool); keep[rng.choice(S - 1, 9, replace=False)] = True; keep[S - 1] = last
+        rank = np.full(S, -1, np.int32); rank[keep] = np.arange(keep.sum())
+        n_keep = int(keep.sum())
+        w_star = rng.random(n_keep); tot = rng.random(S) + 0.1
+        for (pos0, count) in [(0, R), (33, 70), (E * S - 2, r + 2)]:
+            prefix = np.r_[0, np.cumsum(keep)].tolist()
+            from sober_amd._engine import survivors_before
+            np0 = survivors_before(pos0, S, E, prefix, n_keep, last)
+            mu_c = _t(rng.random(N)); mu_h = mu_c.clone().to(dev)
+            new_c = torch.full((R,), -7, dtype=torch.int32); new_h = new_c.clone().to(dev)
+            sl = _t(live[pos0:pos0 + count])
+            OracleOps().level_update(sl, pos0, count, S, E, _t(rank), _t(w_star), _t(tot), n_keep, mu_c, new_c, np0)
+            HipOps(dev).level_update(sl.to(dev), pos0, count, S, E, _t(rank).to(dev), _t(w_star).to(dev),
+                                     _t(tot).to(dev), n_keep, mu_h, new_h, np0)
+            assert torch.equal(new_h.cpu(), new_c)                       # index work: bit-exact
+            assert torch.equal(mu_h.cpu(), mu_c)                         # one multiply, one divide
+
+
+# --------------------------------------------------------------------------- #
+# Nystrom subsample + weights
+# --------------------------------------------------------------------------- #
+def test_kmeans_vs_golden(dev):
+    z = np.load(os.path.join(GOLD, "kmeans.npz"))
+    cl, c = sober_amd.KMeans(_t(z["a_x"]).to(dev), K=int(z["a_K"]))
+    assert np.array_equal(cl.cpu().numpy(), z["a_cl"])
+    np.testing.assert_allclose(c.cpu().numpy(), z["a_c"], rtol=1e-12)
+    cl, c = sober_amd.KMeans(_t(z["b_x"]).to(dev), K=int(z["b_K"]))     # empty cluster -> NaN spreads
+    assert np.array_equal(np.isnan(c.cpu().numpy()), np.isnan(z["b_c"]))
+    np.testing.assert_allclose(c.cpu().numpy(), z["b_c"], rtol=1e-12, equal_nan=True)
+    x = np.random.default_rng(int(z["c_seed"]))
+    x.random((3000, 4)); x.random((500, 3))                            # replay the generator's stream
+    x3 = x.random((int(z["c_N"]), int(z["c_d"])))
+    ws = sober_amd.WeightsStabiliser()
+    c3 = ws.kmeans_resampling(_t(x3).to(dev), int(z["c_K"]))
+    np.testing.assert_allclose(c3.cpu().numpy(), z["c_c"], rtol=1e-11)
+
+
+def test_cleansing_weights_vs_golden(dev):
+    z = np.load(os.path.join(GOLD, "weights.npz"))
+    ws = sober_amd.WeightsStabiliser()
+    assert ws.eps_weights == float(z["eps"])
+    w = _t(z["a_in"].copy()).to(dev)
+    out = ws.cleansing_weights(w)
+    np.testing.assert_allclose(out.cpu().numpy(), z["a_out"], rtol=1e-13)
+    assert out.data_ptr() == w.data_ptr()                               # in place
+    assert np.array_equal((out == 0).cpu().numpy(), z["a_out"] == 0)
+    out = ws.cleansing_weights(_t(z["b_in"].copy()).to(dev))
+    assert np.array_equal(out.cpu().numpy(), z["b_out"])                # all-zero -> uniform
+    torch.manual_seed(7)
+    idx = ws.deweighted_resampling(_t(z["c_in"].copy()).to(dev), 40)
+    assert idx.shape == (40,) and len(idx.unique()) == 40
