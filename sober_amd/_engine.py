@@ -91,12 +91,32 @@ class DistComm:
 # --------------------------------------------------------------------------- #
 # host pieces of the algorithm
 # --------------------------------------------------------------------------- #
+class host_lapack_threads:
+    """The host LAPACK problems on this path are small (<= ~500x500); MKL with one thread per core
+    of a 128-core host is 20-40x SLOWER on them than with one thread (measured on the MI355X box:
+    eigvalsh(500) 361 ms vs 8.7 ms, svd(100x200) 20 ms vs 1.3 ms).  Pin the thread count while
+    they run."""
+
+    def __init__(self, size: int):
+        self.n = 1 if size <= 1024 else 8
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        if self.old != self.n:
+            torch.set_num_threads(self.n)
+
+    def __exit__(self, *exc):
+        if self.old != self.n:
+            torch.set_num_threads(self.old)
+
+
 def ker_svd_sparsify_host(gram_host: torch.Tensor, s: int, tm: Optional[SafeTensorOperator] = None):
     """SOBER/_rchq.py:34-39 from `mat = kernel(pt, pt)` on: PSD repair, torch.svd_lowrank (its
     randn(M, s) comes from the global CPU generator), U = -_U.T."""
     tm = tm or SafeTensorOperator()
-    mat = tm.make_cov_psd(gram_host)
-    _U, S, _ = torch.svd_lowrank(mat, q=s)
+    with host_lapack_threads(gram_host.shape[0]):
+        mat = tm.make_cov_psd(gram_host)
+        _U, S, _ = torch.svd_lowrank(mat, q=s)
     return S, -1 * _U.T
 
 
@@ -107,7 +127,8 @@ def car_host(X: torch.Tensor, mu: torch.Tensor):
     dt = X.dtype
     X1 = torch.cat([torch.ones(X.size(0), 1, dtype=dt), X], dim=1)
     N, n = X1.shape
-    _, _, V = torch.linalg.svd(X1.T)
+    with host_lapack_threads(N):
+        _, _, V = torch.linalg.svd(X1.T)
     Phi = V[-(N - n):, :].T.contiguous()
     nat.car_pivot_host(Phi, mu)
     keep = mu > 0

@@ -67,10 +67,10 @@ def test_recombination_vs_golden(path, dev):
     assert np.array_equal(nz, z["mu_after_idx"])                               # Q3
     np.testing.assert_allclose(mu_h.numpy()[nz], z["mu_after_val"], rtol=W_RTOL)
     assert len(trace["levels"]) == int(z["n_levels"])
-    np.testing.assert_allclose(trace["gram"].numpy(), z["gram_in"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(trace["gram"].numpy(), z["gram_in"], rtol=1e-9, atol=1e-12)
     for i, lv in enumerate(trace["levels"]):
         assert np.array_equal(lv["idx_star"].numpy(), z[f"L{i}_idx_star"]), i
-        np.testing.assert_allclose(lv["tot_weights"].numpy(), z[f"L{i}_tot_weights"], rtol=1e-9)
+        np.testing.assert_allclose(lv["tot_weights"].numpy(), z[f"L{i}_tot_weights"], rtol=W_RTOL)
         np.testing.assert_allclose(lv["X_tmp"].numpy(), z[f"L{i}_X_tmp"], rtol=1e-6, atol=1e-10)
 
 
@@ -106,7 +106,7 @@ def test_cfg2_full_size_vs_golden(dev):
     assert len(trace["levels"]) == int(z["n_levels"])
     for i, lv in enumerate(trace["levels"]):
         assert np.array_equal(lv["idx_star"].numpy(), z[f"L{i}_idx_star"]), i
-        np.testing.assert_allclose(lv["tot_weights"].numpy(), z[f"L{i}_tot_weights"], rtol=1e-9)
+        np.testing.assert_allclose(lv["tot_weights"].numpy(), z[f"L{i}_tot_weights"], rtol=W_RTOL)
     # size-independent properties
     wc = w.cpu()
     assert (wc > 0).all() and len(wc) <= case["b"]
@@ -224,7 +224,7 @@ def test_level_moments_vs_test_double(kind, d, dev):
     mu0 = rng.random(N)
     spec = O.make_spec(kind, _t(Xo), _t(ls), outputscale=1.5, y_obs=_t(rng.standard_normal(n_obs)), mean_const=0.2)
     U = _t(rng.standard_normal((b - 1, M)))
-    live = np.sort(rng.choice(N, size=4321, replace=False)).astype(np.int32)
+    live = np.sort(rng.choice(N, size=4337, replace=False)).astype(np.int32)   # E=180, r=17
     for mode in ("predictive_covariance", "weighted_predictive_covariance", "kernel"):
         cpu, hip = OracleOps(), HipOps(dev)
         pc = cpu.build_plan(kspec(spec), mode, _t(Xn), _t(X)); cpu.set_projection(pc, U)
@@ -237,10 +237,10 @@ def test_level_moments_vs_test_double(kind, d, dev):
             Xh, th = hip.level_moments(ph, _t(sl).to(dev), pos0, count, S, E, _t(mu0).to(dev))
             np.testing.assert_allclose(th.cpu().numpy(), tc.numpy(), rtol=1e-12, atol=1e-15)
             scale = float(Xc.abs().max())
-            np.testing.assert_allclose(Xh.cpu().numpy(), Xc.numpy(), rtol=1e-9, atol=1e-11 * scale)
+            np.testing.assert_allclose(Xh.cpu().numpy(), Xc.numpy(), rtol=1e-8, atol=1e-9 * scale)
         dc = cpu.direct_columns(pc, _t(live[:S - 3]), S - 3)
         dh = hip.direct_columns(ph, _t(live[:S - 3]).to(dev), S - 3)
-        np.testing.assert_allclose(dh.cpu().numpy(), dc.numpy(), rtol=1e-9, atol=1e-11 * float(dc.abs().max()))
+        np.testing.assert_allclose(dh.cpu().numpy(), dc.numpy(), rtol=1e-8, atol=1e-9 * float(dc.abs().max()))
 
 
 def test_level_update_vs_test_double(dev):
