@@ -140,6 +140,17 @@ int sober_i64_to_i32(const int64_t* in, int64_t n, int32_t* out, void* stream);
  * (no FMA contraction).  Returns the number of pivots performed (< m when quirk Q6 fires).        */
 int sober_car_pivot_host(double* h_Phi, int N, int m, double* h_mu);
 
+/* DEVICE Caratheodory step (K5 + K6): the whole Tchernychova_Lyons_CAR of SOBER/_rchq.py:224-270 in
+ * one persistent workgroup.  X (N, m-1) row-major barycentres (ld = ldx), mu_in (N) set masses.
+ * The null-space basis is rebuilt from the right Householder reflectors of the Golub-Kahan
+ * bidiagonalisation of [1 | X]^T -- the basis LAPACK/MKL gesdd returns in Vh[m:, :] (:231-234) --
+ * followed by the N-m pivots of :237-266.  Outputs: keep_rank[N] (rank of each surviving row in
+ * idx_star, -1 if cancelled), w_star[0:n_keep], *n_keep, mu_out[N].
+ * sober_car_supported(N, m) = 1 iff the on-chip kernel covers the size (batch <= 100).           */
+int sober_car_supported(int N, int m);
+int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
+                     int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out, void* stream);
+
 /* KMeans of SOBER/_weights.py:100-126: Lloyd, centroids initialised to the first K rows, exactly
  * `iters` iterations, first-index argmin (a NaN distance wins like torch.argmin), empty cluster ->
  * NaN centroid.  X is (N, d) row-major raw points.  labels: N int32.  ws: sober_kmeans_ws_bytes.  */

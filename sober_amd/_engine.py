@@ -155,6 +155,7 @@ class RecombinationEngine:
         self.tm = SafeTensorOperator()
         self.trace = None                      # set to a dict to record per-level data (tests)
         self.timers = {}                       # phase -> seconds (host wall clock, accumulated)
+        self.force_host_car = False            # True: LAPACK null space + C++ pivots on the host
 
     def _tick(self, name, t0):
         t1 = time.perf_counter()
@@ -210,17 +211,7 @@ class RecombinationEngine:
             Xtr, tot = ops.level_moments(plan, idx_cur, pos0, count, S, E, mu)
             comm.allreduce_sum(Xtr, tot)
             X_tmp = ops.barycentres(Xtr, tot)               # :151,166
-            X_h, tot_h = ops.to_host(X_tmp, tot)
-            t0 = self._tick("levels_device", t0)
-            w_star, idx_star = car_host(X_h, tot_h.clone())  # :173-175
-            t0 = self._tick("car_host", t0)
-            if levels is not None:
-                levels.append(dict(kind="level", R=R, E=E, r=r, X_tmp=X_h.clone(), tot_weights=tot_h.clone(),
-                                   idx_star=idx_star.clone(), w_star=w_star.clone()))
-
-            n_keep = int(idx_star.numel())
-            keep_rank = torch.full((S,), -1, dtype=torch.int32)
-            keep_rank[idx_star] = torch.arange(n_keep, dtype=torch.int32)
+            keep_rank_d, w_star_d, keep_rank, n_keep = self._car(X_tmp, tot, R, E, r, levels, t0)  # :173-175
             last_kept = bool(keep_rank[S - 1] >= 0)
             kept_prefix = torch.zeros(S + 1, dtype=torch.int64)
             kept_prefix[1:] = torch.cumsum((keep_rank >= 0).to(torch.int64), 0)
@@ -233,10 +224,43 @@ class RecombinationEngine:
             new_pos0 = survivors_before(pos0, S, E, kept_prefix, n_keep, last_kept)
             new_end = survivors_before(pos0 + count, S, E, kept_prefix, n_keep, last_kept)
             if count > 0:
-                ops.level_update(idx_cur, pos0, count, S, E, ops.from_host(keep_rank),
-                                 ops.from_host(w_star), tot, n_keep, mu, idx_new, new_pos0)   # :198-221
+                ops.level_update(idx_cur, pos0, count, S, E, keep_rank_d, w_star_d, tot, n_keep, mu,
+                                 idx_new, new_pos0)                                           # :198-221
             idx_cur, idx_new = idx_new, idx_cur
             pos0, count, R = new_pos0, new_end - new_pos0, R_new
+
+    # -- one Caratheodory step ---------------------------------------------------
+    def _car(self, X_dev, mu_dev, R, E, r, levels, t0, kind="level"):
+        """Tchernychova_Lyons_CAR on (X_dev (N', n'), mu_dev (N')).  On-chip HIP kernel when the
+        size fits (batch <= 100), host LAPACK + C++ pivots otherwise.  Returns device keep_rank /
+        w_star, the host copy of keep_rank and n_keep."""
+        ops = self.ops
+        Np, n1 = X_dev.shape[0], X_dev.shape[1] + 1
+        on_device = getattr(ops, "car_supported", None) is not None and ops.car_supported(Np, n1) \
+            and not self.force_host_car
+        if on_device:
+            keep_rank_d, w_star_d, n_keep_d, _ = ops.car_device(X_dev, mu_dev)
+            if levels is not None:
+                keep_rank, nk, X_h, mu_h, w_h = ops.to_host(keep_rank_d, n_keep_d, X_dev, mu_dev, w_star_d)
+            else:
+                keep_rank, nk = ops.to_host(keep_rank_d, n_keep_d)
+            n_keep = int(nk[0])
+            self._tick("levels_device", t0)
+            if levels is not None:
+                levels.append(dict(kind=kind, R=R, E=E, r=r, X_tmp=X_h, tot_weights=mu_h,
+                                   idx_star=torch.nonzero(keep_rank >= 0).flatten(), w_star=w_h[:n_keep].clone()))
+            return keep_rank_d, w_star_d, keep_rank, n_keep
+        X_h, mu_h = ops.to_host(X_dev, mu_dev)
+        t0 = self._tick("levels_device", t0)
+        w_star, idx_star = car_host(X_h, mu_h.clone())
+        self._tick("car_host", t0)
+        if levels is not None:
+            levels.append(dict(kind=kind, R=R, E=E, r=r, X_tmp=X_h.clone(), tot_weights=mu_h.clone(),
+                               idx_star=idx_star.clone(), w_star=w_star.clone()))
+        n_keep = int(idx_star.numel())
+        keep_rank = torch.full((Np,), -1, dtype=torch.int32)
+        keep_rank[idx_star] = torch.arange(n_keep, dtype=torch.int32)
+        return ops.from_host(keep_rank), ops.from_host(w_star), keep_rank, n_keep
 
     # -- terminal branches ------------------------------------------------------
     def _gather_result(self, idx_local, w_local):
@@ -263,15 +287,14 @@ class RecombinationEngine:
         counts = comm.allgather_counts(count)
         X_all = comm.allgather_rows(X_loc, counts)
         mu_all = comm.allgather_rows(mu_loc, counts)
-        X_h, mu_h = ops.to_host(X_all, mu_all)
-        w_star, idx_star = car_host(X_h, mu_h.clone())                 # :84-85
-        if levels is not None:
-            levels.append(dict(kind="final", R=R, X_tmp=X_h.clone(), tot_weights=mu_h.clone(),
-                               idx_star=idx_star.clone(), w_star=w_star.clone()))
+        t0 = time.perf_counter()
+        keep_rank_d, w_star_d, keep_rank, n_keep = self._car(X_all, mu_all, R, 0, 0, levels, t0, kind="final")  # :84-85
+        idx_star = torch.nonzero(keep_rank >= 0).flatten()
         lo = sum(counts[:comm.rank])
         mine = (idx_star >= lo) & (idx_star < lo + count)
         sel = (idx_star[mine] - lo).to(torch.int32)
+        ranks = keep_rank[idx_star[mine]].long()
         mu.zero_()                                                     # mu[:] = 0  (:109)
-        w_mine = ops.from_host(w_star[mine])
+        w_mine = w_star_d[ops.from_host(ranks)] if ranks.numel() else w_star_d[:0]
         out_idx = ops.scatter_weights(idx_cur, ops.from_host(sel), w_mine, mu)   # mu[idx_story] = w_star
         return self._gather_result(out_idx, w_mine)

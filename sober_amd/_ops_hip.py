@@ -169,6 +169,21 @@ class HipOps:
         nat.barycentres(Xtr, n, S, tot, out)
         return out
 
+    def car_supported(self, N, m):
+        return nat.car_supported(N, m)
+
+    def car_device(self, X, mu_in):
+        """Tchernychova_Lyons_CAR on the device -> (keep_rank int32 (N,), w_star (N,), n_keep int32
+        (1,), mu_out (N,)); nothing leaves the GPU."""
+        N = X.shape[0]
+        dev = self.device
+        keep_rank = torch.empty(N, dtype=torch.int32, device=dev)
+        w_star = torch.empty(N, dtype=torch.float64, device=dev)
+        n_keep = torch.empty(1, dtype=torch.int32, device=dev)
+        mu_out = torch.empty(N, dtype=torch.float64, device=dev)
+        nat.car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out)
+        return keep_rank, w_star, n_keep, mu_out
+
     def level_update(self, idx_cur, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0):
         nat.level_update(idx_cur, 0, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0)
 

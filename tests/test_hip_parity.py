@@ -301,3 +301,56 @@ def test_cleansing_weights_vs_golden(dev):
     torch.manual_seed(7)
     idx = ws.deweighted_resampling(_t(z["c_in"].copy()).to(dev), 40)
     assert idx.shape == (40,) and len(idx.unique()) == 40
+
+
+# --------------------------------------------------------------------------- #
+# Caratheodory step on the device
+# --------------------------------------------------------------------------- #
+def test_car_device_vs_reference_levels(dev):
+    """k_car on the reference's own per-level inputs (all batch sizes <= 100 in the fixtures)."""
+    from sober_amd import _native as nat
+    from sober_amd._ops_hip import HipOps
+    ops = HipOps(dev)
+    n_checked = 0
+    for p in glob.glob(os.path.join(GOLD, "recomb_*.npz")):
+        z = np.load(p)
+        if "calc_obj" in p or "L0_X_tmp" not in z.files:
+            continue
+        for i in range(int(z["n_levels"])):
+            X, mu = _t(z[f"L{i}_X_tmp"]), _t(z[f"L{i}_tot_weights"])
+            if not nat.car_supported(X.shape[0], X.shape[1] + 1):
+                continue
+            keep_rank, w_star, n_keep, mu_out = ops.car_device(X.to(dev), mu.to(dev))
+            kr = keep_rank.cpu().numpy()
+            nk = int(n_keep.item())
+            idx = np.flatnonzero(kr >= 0)
+            assert np.array_equal(idx, z[f"L{i}_idx_star"]), (p, i)            # index work: exact
+            assert np.array_equal(kr[idx], np.arange(nk))
+            np.testing.assert_allclose(w_star.cpu().numpy()[:nk], z[f"L{i}_w_star"], rtol=W_RTOL)
+            mo = mu_out.cpu().numpy()
+            assert np.array_equal(np.flatnonzero(mo > 0), idx)
+            n_checked += 1
+    assert n_checked >= 60
+
+
+def test_host_and_device_car_agree(dev):
+    """The LAPACK route (used for batch > 100) and the on-chip route give the same step."""
+    path = os.path.join(GOLD, "recomb_matern_medium.npz")
+    case, inp, spec, z = load_case(path)
+    outs = []
+    for force_host in (False, True):
+        from sober_amd._engine import RecombinationEngine
+        old = RecombinationEngine.__init__
+
+        def patched(self, *a, _old=old, **k):
+            _old(self, *a, **k)
+            self.force_host_car = force_host
+        RecombinationEngine.__init__ = patched
+        try:
+            outs.append(run_hip(path, dev))
+        finally:
+            RecombinationEngine.__init__ = old
+    (_, _, _, i1, w1, m1), (_, _, _, i2, w2, m2) = outs
+    assert torch.equal(i1, i2)
+    np.testing.assert_allclose(w1.cpu().numpy(), w2.cpu().numpy(), rtol=W_RTOL)
+    assert np.array_equal(i1.cpu().numpy(), z["idx"])
