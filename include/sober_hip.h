@@ -145,11 +145,13 @@ int sober_car_pivot_host(double* h_Phi, int N, int m, double* h_mu);
  * The null-space basis is rebuilt from the right Householder reflectors of the Golub-Kahan
  * bidiagonalisation of [1 | X]^T -- the basis LAPACK/MKL gesdd returns in Vh[m:, :] (:231-234) --
  * followed by the N-m pivots of :237-266.  Outputs: keep_rank[N] (rank of each surviving row in
- * idx_star, -1 if cancelled), w_star[0:n_keep], *n_keep, mu_out[N].
+ * idx_star, -1 if cancelled), w_star[0:n_keep], *n_keep, mu_out[N]; phi_out (N x (N-m), may be NULL)
+ * receives the null-space basis before the pivots (test hook).
  * sober_car_supported(N, m) = 1 iff the on-chip kernel covers the size (batch <= 100).           */
 int sober_car_supported(int N, int m);
 int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
-                     int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out, void* stream);
+                     int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
+                     double* phi_out, void* stream);
 
 /* KMeans of SOBER/_weights.py:100-126: Lloyd, centroids initialised to the first K rows, exactly
  * `iters` iterations, first-index argmin (a NaN distance wins like torch.argmin), empty cluster ->

@@ -91,16 +91,35 @@ class DistComm:
 # --------------------------------------------------------------------------- #
 # host pieces of the algorithm
 # --------------------------------------------------------------------------- #
+HOST_THREAD_CAP = 8      # process-wide torch CPU thread cap applied on first use (None = leave alone)
+
+
+def _cap_host_threads_once():
+    """One-time, process-wide: torch's default of one CPU thread per core is pathological for the
+    small host LAPACK problems on this path on a many-core GPU host (MI355X box, 128 threads:
+    eigvalsh(500x500) 361 ms vs 8.7 ms with one thread, svd(100x200) 20 ms vs 1.3 ms), and bouncing
+    between 128 and 1 threads per call costs ~15 ms of pool wake-ups per step.  Cap the pool once
+    (module attribute HOST_THREAD_CAP, None disables), then flip 8 <-> 1 around each LAPACK section,
+    which is free."""
+    global _capped
+    if _capped:
+        return
+    _capped = True
+    if HOST_THREAD_CAP is not None and torch.get_num_threads() > HOST_THREAD_CAP:
+        torch.set_num_threads(HOST_THREAD_CAP)
+
+
+_capped = False
+
+
 class host_lapack_threads:
-    """The host LAPACK problems on this path are small (<= ~500x500); MKL with one thread per core
-    of a 128-core host is 20-40x SLOWER on them than with one thread (measured on the MI355X box:
-    eigvalsh(500) 361 ms vs 8.7 ms, svd(100x200) 20 ms vs 1.3 ms).  Pin the thread count while
-    they run."""
+    """Run a host LAPACK section with the thread count that is fastest for its size."""
 
     def __init__(self, size: int):
-        self.n = 1 if size <= 1024 else 8
+        self.n = 1 if size <= 1024 else HOST_THREAD_CAP or 8
 
     def __enter__(self):
+        _cap_host_threads_once()
         self.old = torch.get_num_threads()
         if self.old != self.n:
             torch.set_num_threads(self.n)

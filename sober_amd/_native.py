@@ -41,7 +41,7 @@ SIGNATURES = {
     "sober_i64_to_i32": (_i32, [_vp, _i64, _vp, _vp]),
     "sober_car_pivot_host": (_i32, [_vp, _i32, _i32, _vp]),
     "sober_car_supported": (_i32, [_i32, _i32]),
-    "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sober_kmeans_ws_bytes": (_i64, [_i64, _i32, _i32]),
     "sober_kmeans_lloyd": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "sober_reduce_ws_bytes": (_i64, [_i64]),
@@ -221,12 +221,12 @@ def car_supported(N: int, m: int) -> bool:
     return bool(load().sober_car_supported(N, m))
 
 
-def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out):
+def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None):
     """X (N, m-1) float64 device (unit inner stride), mu_in (N)."""
     N, n = X.shape
     _check(load().sober_car_device(X.data_ptr(), X.stride(0), N, n + 1, mu_in.data_ptr(), keep_rank.data_ptr(),
-                                   w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _stream(X)),
-           "sober_car_device")
+                                   w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
+                                   _stream(X)), "sober_car_device")
 
 
 def kmeans_lloyd(X, K, iters, centroids, labels):

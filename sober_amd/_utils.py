@@ -64,26 +64,57 @@ class SafeTensorOperator(TensorManager):
     @staticmethod
     def is_psd(mat) -> bool:
         """SOBER/_utils.py:117-129: Cholesky succeeds AND exactly symmetric AND no negative
-        eigenvalue.  The reference asks the NON-symmetric solver (`linalg.eig`, 0.2 s at
-        500x500) for the last test; by then `mat` is exactly symmetric, so the symmetric
-        solver gives the same verdict whenever the verdict is well defined (|lambda_min| above
-        rounding, which the 1e-5 jitter ladder guarantees)."""
+        eigenvalue.  Same verdict, cheaper order: the symmetry test first (an asymmetric matrix is
+        rejected whatever Cholesky says), and the symmetric eigen-solver instead of the reference's
+        non-symmetric `linalg.eig` (0.2 s at 500x500) -- by then `mat` is exactly symmetric, so both
+        solvers agree whenever the verdict is well defined (|lambda_min| above rounding)."""
+        if not bool((mat == mat.T).all()):
+            return False
         try:
             torch.linalg.cholesky(mat)
         except Exception:
             return False
-        if not bool((mat == mat.T).all()):
-            return False
         return bool((torch.linalg.eigvalsh(mat) >= 0).all())
 
     def make_cov_psd(self, cov):
-        """SOBER/_utils.py:131-157 on a HOST tensor (quirk Q2: sqrt(cov*cov.T) = |cov|;
-        jitter 1e-5*2^k; diagonal fallback after more than max_iter rounds)."""
+        """SOBER/_utils.py:131-157 on a HOST tensor (quirk Q2: sqrt(cov*cov.T) = |cov|; jitter
+        1e-5*2^k added to the diagonal until PSD; diagonal fallback after more than max_iter
+        rounds).
+
+        The reference probes each rung of the jitter ladder with a Cholesky + eig (up to 12 of
+        each).  Adding t to the diagonal shifts every eigenvalue by t, so ONE symmetric
+        eigen-decomposition of |cov| tells which rung is the first PSD one; the rungs are then
+        applied with the reference's own sequence of diagonal additions.  If lambda_min + t lands
+        within 1e-9 of zero for the deciding rungs the literal ladder runs instead."""
         if self.is_psd(cov):
             return cov
         warnings.warn("Estimated covariance matrix was not positive semi-definite. Conveting...")
         cov = torch.nan_to_num(cov)
         cov = torch.sqrt(cov * cov.T)
+        n_dim = cov.size(0)
+        k_first = None
+        try:
+            lam_min = float(torch.linalg.eigvalsh(cov)[0])
+            shifts = [1e-5 * (2 ** k - 1) for k in range(self.max_iter + 1)]     # after k additions
+            psd = [lam_min + t > 0 for t in shifts]
+            clear = all(abs(lam_min + t) > 1e-9 * max(1.0, abs(lam_min)) for t in shifts)
+            if clear and lam_min == lam_min:
+                k_first = psd.index(True) if any(psd) else self.max_iter + 1
+        except Exception:
+            k_first = None
+        if k_first is None:
+            return self._make_cov_psd_ladder(cov)
+        jitter = torch.ones(n_dim, dtype=cov.dtype, device=cov.device) * 1e-5
+        diag = cov.diagonal()
+        for _ in range(k_first):                      # the reference's additions, one rung at a time
+            diag += jitter
+            jitter *= 2
+        if k_first > self.max_iter:
+            cov = cov.diag().diag()
+        return cov
+
+    def _make_cov_psd_ladder(self, cov):
+        """The literal loop of SOBER/_utils.py:145-156 (borderline spectra only)."""
         if not self.is_psd(cov):
             n_dim = cov.size(0)
             jitter = torch.ones(n_dim, dtype=cov.dtype, device=cov.device) * 1e-5

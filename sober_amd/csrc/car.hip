@@ -27,29 +27,72 @@ namespace sober {
 
 constexpr int CAR_T = 1024;
 constexpr int CAR_RP = 25;          // Phi rows per thread: N <= 8 * 25
+constexpr int CAR_CQ = 13;          // columns per lane in the row sweeps: N <= 16 * 13
 
-__device__ __forceinline__ double wsum(double v) {      // butterfly: every lane gets the total
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- DPP cross-lane helpers (row = 16 lanes).  ds_bpermute-based __shfl costs an LDS round trip
+// per step; these are plain VALU moves.
+#ifdef CAR_NO_DPP
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+    const int l = threadIdx.x & 63;
+    return __shfl(v, (l & 0x30) | ((l - (CTRL & 15)) & 15), 64);
+}
+#else
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#endif
+constexpr int ROR1 = 0x121, ROR2 = 0x122, ROR4 = 0x124, ROR8 = 0x128;
+
+__device__ __forceinline__ double row16_sum(double v) {   // every lane of a 16-lane row gets the row total
+    v += dpp<ROR8>(v);
+    v += dpp<ROR4>(v);
+    v += dpp<ROR2>(v);
+    v += dpp<ROR1>(v);
     return v;
 }
-
-__device__ __forceinline__ double gsum(double v) {      // sum over the 8 row groups (lane bits 3..5)
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+__device__ __forceinline__ double grp8_sum(double v) {    // lanes {c2 + 2g}: sum over g, same c2
+    v += dpp<ROR8>(v);
+    v += dpp<ROR4>(v);
+    v += dpp<ROR2>(v);
     return v;
 }
+__device__ __forceinline__ double rdlane(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {    // uniform total over the 64 lanes
+    v = row16_sum(v);
+    return ((rdlane(v, 0) + rdlane(v, 16)) + rdlane(v, 32)) + rdlane(v, 48);
+}
 
-// dlarfg: reflector H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0]
-__device__ __forceinline__ void larfg(double alpha, double xnorm, double& beta, double& tau, double& scal) {
-    if (xnorm == 0.0) {
+// dlarfg: reflector H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2
+__device__ __forceinline__ void larfg(double alpha, double ss, double& beta, double& tau, double& scal) {
+    if (ss == 0.0) {
         beta = alpha; tau = 0.0; scal = 0.0;
     } else {
-        beta = -copysign(hypot(alpha, xnorm), alpha);
+        beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
         tau = (beta - alpha) / beta;
         scal = 1.0 / (alpha - beta);
     }
+}
+
+// ratio-test combine: first argmin, a NaN ratio wins (torch.argmin); piv < 0 = no candidate
+__device__ __forceinline__ void amin_take(double& best, int& piv, double ob, int op) {
+    bool take;
+    if (op < 0) take = false;
+    else if (piv < 0) take = true;
+    else {
+        const bool bn = best != best, on = ob != ob;
+        if (bn || on) take = on && (!bn || op < piv);
+        else take = (ob < best) || (ob == best && op < piv);
+    }
+    if (take) { best = ob; piv = op; }
 }
 
 __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int ldx, int N, int m,
@@ -57,7 +100,8 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                                                int32_t* __restrict__ keep_rank,
                                                double* __restrict__ w_star,
                                                int32_t* __restrict__ n_keep_out,
-                                               double* __restrict__ mu_out) {
+                                               double* __restrict__ mu_out,
+                                               double* __restrict__ phi_out) {
     extern __shared__ double lds[];
     double* A = lds;                       // m x N, row-major
     double* taup = lds + (size_t)m * N;    // m
@@ -65,6 +109,15 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     double* scal = ubuf + m;               // [0] = tauq
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CAR_STAMPS
+    unsigned long long st_[8]; int sti_ = 0;
+#define CAR_STAMP() do { st_[sti_++] = __builtin_amdgcn_s_memtime(); st_[sti_++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CAR_STAMP() do { } while (0)
+#endif
+    CAR_STAMP();
+    const int l16 = lane & 15, rid = lane >> 4;          // lane in DPP row, DPP row in wave
+    const int g = l16 >> 1, c2 = l16 & 1;                // row group / column parity inside a DPP row
     const int NC = N - m;
 
     // ---------------- load A = [1 | X]^T ----------------
@@ -77,39 +130,38 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 
     // ---------------- phase 1: Golub-Kahan bidiagonalisation (dgebd2, m < N) ----------------
     for (int i = 0; i < m; ++i) {
-        // ---- right reflector G(i) from row i, columns i..N-1 (every wave computes it redundantly)
+        // ---- right reflector G(i) from row i, columns i..N-1.  Every DPP row (16 lanes x CAR_CQ
+        // columns) holds the whole row: the norm is a row16 all-reduce, computed redundantly.
         double* rowi = A + (size_t)i * N;
-        double vreg[4];
+        double vreg[CAR_CQ];
         double ss = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = i + 1 + lane + 64 * q;
+        for (int q = 0; q < CAR_CQ; ++q) {
+            const int c = i + 1 + l16 + 16 * q;
             vreg[q] = (c < N) ? rowi[c] : 0.0;
             ss = fma(vreg[q], vreg[q], ss);
         }
-        ss = wsum(ss);
-        const double alpha = rowi[i];
+        ss = row16_sum(ss);
         double beta, tau, sc;
-        larfg(alpha, sqrt(ss), beta, tau, sc);
+        larfg(rowi[i], ss, beta, tau, sc);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) vreg[q] *= sc;
-        // apply to rows r > i: each wave owns rows i+1+wave, +16, ... (row-local: no barrier)
-        for (int r = i + 1 + wave; r < m; r += 16) {
+        for (int q = 0; q < CAR_CQ; ++q) vreg[q] *= sc;
+        // apply to rows r > i: one matrix row per DPP row, 64 rows per sweep of the workgroup
+        for (int r = i + 1 + wave * 4 + rid; r < m; r += 64) {
             double* row = A + (size_t)r * N;
-            double a[4];
-            double w = (lane == 0) ? row[i] : 0.0;
+            double a[CAR_CQ];
+            double w = (l16 == 0) ? row[i] : 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = i + 1 + lane + 64 * q;
+            for (int q = 0; q < CAR_CQ; ++q) {
+                const int c = i + 1 + l16 + 16 * q;
                 a[q] = (c < N) ? row[c] : 0.0;
                 w = fma(a[q], vreg[q], w);
             }
-            w = wsum(w);
-            const double t = tau * w;
-            if (lane == 0) row[i] -= t;
+            const double t = tau * row16_sum(w);
+            if (l16 == 0) row[i] -= t;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = i + 1 + lane + 64 * q;
+            for (int q = 0; q < CAR_CQ; ++q) {
+                const int c = i + 1 + l16 + 16 * q;
                 if (c < N) row[c] = fma(-t, vreg[q], a[q]);
             }
         }
@@ -117,10 +169,12 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
         // ---- wave 0: store v_i / taup, build the left reflector H(i) from column i
         if (wave == 0) {
             if (lane == 0) { rowi[i] = beta; taup[i] = tau; }
+            if (rid == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = i + 1 + lane + 64 * q;
-                if (c < N) rowi[c] = vreg[q];
+                for (int q = 0; q < CAR_CQ; ++q) {
+                    const int c = i + 1 + l16 + 16 * q;
+                    if (c < N) rowi[c] = vreg[q];
+                }
             }
             if (i < m - 1) {
                 double ureg[2];
@@ -131,9 +185,9 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                     ureg[q] = (r < m) ? A[(size_t)r * N + i] : 0.0;
                     s2 = fma(ureg[q], ureg[q], s2);
                 }
-                s2 = wsum(s2);
+                s2 = wave_sum(s2);
                 double beta2, tauq, sc2;
-                larfg(A[(size_t)(i + 1) * N + i], sqrt(s2), beta2, tauq, sc2);
+                larfg(A[(size_t)(i + 1) * N + i], s2, beta2, tauq, sc2);
                 if (lane == 0) { ubuf[0] = 1.0; scal[0] = tauq; }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -144,18 +198,18 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
         }
         if (i == m - 1) break;
         __syncthreads();                                               // (2) ubuf / tauq visible
-        // ---- apply H(i) to A(i+1:m-1, i+1:N-1): lane = (row group g, column cl), 8 columns a wave
+        // ---- apply H(i) to A(i+1:m-1, i+1:N-1): a wave owns 8 columns (2 per DPP row), the 8 row
+        // groups of a column sit in one DPP row -> the column dot product is a DPP reduction
         {
             const double tauq = scal[0];
-            const int g = lane >> 3, cl = lane & 7;
             const int L = m - i - 1;                                   // rows i+1 .. m-1
             for (int cb = wave; cb * 8 < N - i - 1; cb += 16) {
-                const int c = i + 1 + cb * 8 + cl;
+                const int c = i + 1 + cb * 8 + rid * 2 + c2;
                 const bool okc = c < N;
                 double part = 0.0;
                 for (int k = g; k < L; k += 8)
                     if (okc) part = fma(ubuf[k], A[(size_t)(i + 1 + k) * N + c], part);
-                const double t = tauq * gsum(part);
+                const double t = tauq * grp8_sum(part);
                 for (int k = g; k < L; k += 8)
                     if (okc) {
                         double* e = A + (size_t)(i + 1 + k) * N + c;
@@ -167,9 +221,10 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     }
     __syncthreads();
 
+    CAR_STAMP();
     // ---------------- phase 2: Phi = G(0) ... G(m-1) [0; I]  (N x NC, in registers) ----------------
-    const int g = lane >> 3, cl = lane & 7;
-    const int col = wave * 8 + cl;                 // my column of Phi
+    // thread (wave, rid, c2, g) owns rows g, g+8, ... of column wave*8 + rid*2 + c2
+    const int col = wave * 8 + rid * 2 + c2;
     const bool okcol = col < NC;
     double phi[CAR_RP];
 #pragma unroll
@@ -186,18 +241,24 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                 vv[k] = (r < N && r > i) ? vi[r] : ((r == i) ? 1.0 : 0.0);
                 part = fma(vv[k], phi[k], part);
             }
-            const double t = tau * gsum(part);
+            const double t = tau * grp8_sum(part);
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) phi[k] = fma(-t, vv[k], phi[k]);
         }
     }
+    if (phi_out != nullptr && okcol) {                                 // stage-level test hook
+#pragma unroll
+        for (int k = 0; k < CAR_RP; ++k)
+            if (g + 8 * k < N) phi_out[(size_t)(g + 8 * k) * NC + col] = phi[k];
+    }
     __syncthreads();                                                   // A is dead from here on
 
+    CAR_STAMP();
     // ---------------- phase 3: the pivots of SOBER/_rchq.py:237-266 ----------------
     double* colbuf = lds;                  // [2][N]
     double* mubuf = lds + 2 * N;           // [2][N]
     for (int r = tid; r < N; r += CAR_T) mubuf[r] = mu_in[r];
-    if (wave == 0 && cl == 0) {
+    if (okcol && col == 0) {
 #pragma unroll
         for (int k = 0; k < CAR_RP; ++k)
             if (g + 8 * k < N) colbuf[g + 8 * k] = phi[k];
@@ -208,7 +269,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     for (int s = 0; s < NC; ++s, cur ^= 1) {
         const double* cb = colbuf + cur * N;
         const double* mb = mubuf + cur * N;
-        // ratio test: first argmin of mu/Phi[:,0] over Phi[:,0] > 0; a NaN ratio wins (torch.argmin)
+        // ratio test: first argmin of mu/Phi[:,0] over Phi[:,0] > 0 (every wave, redundantly)
         double best = 0.0;
         int piv = -1;
         double ph4[4], mu4[4];
@@ -217,43 +278,53 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
             const int r = lane + 64 * q;
             ph4[q] = (r < N) ? cb[r] : 0.0;
             mu4[q] = (r < N) ? mb[r] : 0.0;
-            if (ph4[q] > 0.0) {
-                const double a = mu4[q] / ph4[q];
-                if (piv < 0 || (best == best && (a < best || a != a))) { piv = r; best = a; }
-            }
+            if (ph4[q] > 0.0) amin_take(best, piv, mu4[q] / ph4[q], r);
         }
+#ifdef CAR_ARGMIN_SHFL
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ob = __shfl_xor(best, o, 64);
             const int op = __shfl_xor(piv, o, 64);
-            bool take;
-            if (op < 0) take = false;
-            else if (piv < 0) take = true;
-            else {
-                const bool bn = best != best, on = ob != ob;
-                if (bn || on) take = on && (!bn || op < piv);           // earliest NaN wins
-                else take = (ob < best) || (ob == best && op < piv);
-            }
-            if (take) { best = ob; piv = op; }
+            amin_take(best, piv, ob, op);
         }
+#else
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {                                   // all-reduce inside each DPP row
+            double ob; int op;
+            if (o == 0) { ob = dpp<ROR8>(best); op = __builtin_amdgcn_update_dpp(0, piv, ROR8, 0xf, 0xf, false); }
+            else if (o == 1) { ob = dpp<ROR4>(best); op = __builtin_amdgcn_update_dpp(0, piv, ROR4, 0xf, 0xf, false); }
+            else if (o == 2) { ob = dpp<ROR2>(best); op = __builtin_amdgcn_update_dpp(0, piv, ROR2, 0xf, 0xf, false); }
+            else { ob = dpp<ROR1>(best); op = __builtin_amdgcn_update_dpp(0, piv, ROR1, 0xf, 0xf, false); }
+            amin_take(best, piv, ob, op);
+        }
+        {                                                               // then across the four rows
+            double b0 = rdlane(best, 0);
+            int p0 = __builtin_amdgcn_readlane(piv, 0);
+            amin_take(b0, p0, rdlane(best, 16), __builtin_amdgcn_readlane(piv, 16));
+            amin_take(b0, p0, rdlane(best, 32), __builtin_amdgcn_readlane(piv, 32));
+            amin_take(b0, p0, rdlane(best, 48), __builtin_amdgcn_readlane(piv, 48));
+            best = b0; piv = p0;
+        }
+#endif
         if (piv < 0) break;                                             // Q6 (:241-242), uniform
         const double alpha = best;
         const double pp = cb[piv];
         // mu[:] = mu - alpha * Phi[:,0]; mu[idx] = 0   (two roundings like the tensor expression)
-        if (wave == 0) {
+        if (wave == 15) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = lane + 64 * q;
                 if (r < N) mubuf[(cur ^ 1) * N + r] = (r == piv) ? 0.0 : __dsub_rn(mu4[q], __dmul_rn(alpha, ph4[q]));
             }
         }
-        // rank-1 elimination of my column (if still alive): Phi[:,c] -= Phi[:,0] * Phi[idx,c]/Phi[idx,0]
+        // rank-1 elimination of my column: Phi[:,c] -= Phi[:,0] * (Phi[idx,c] / Phi[idx,0]).  The pivot-row
+        // entry of my column sits in the lane with g == piv % 8 of my own DPP row.
         if (okcol && col > s) {
             const int kp = piv >> 3, gp = piv & 7;
             double mine = 0.0;
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) mine = (k == kp) ? phi[k] : mine;
-            const double prow = __shfl(mine, gp * 8 + cl, 64);
+            const double prow = __shfl(mine, (lane & 0x30) | (gp << 1) | c2, 64);
             const double qv = prow / pp;
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) {
@@ -269,6 +340,10 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
         __syncthreads();
     }
 
+    CAR_STAMP();
+#ifdef CAR_STAMPS
+    if (tid == 0 && phi_out != nullptr) for (int q = 0; q < 8; ++q) ((unsigned long long*)phi_out)[q] = st_[q];
+#endif
     // ---------------- output: w_star = mu[mu > 0], idx_star as ranks ----------------
     if (wave == 0) {
         const double* mb = mubuf + cur * N;
@@ -293,12 +368,12 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 }  // namespace sober
 
 extern "C" int sober_car_supported(int N, int m) {
-    return (m >= 2 && N > m && N <= 8 * sober::CAR_RP && (int64_t)m * N <= 20000 && N - m <= 128) ? 1 : 0;
+    return (m >= 2 && N > m && N <= 8 * sober::CAR_RP && N <= 16 * sober::CAR_CQ && (int64_t)m * N <= 20000 && N - m <= 128) ? 1 : 0;
 }
 
 extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
                                 int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
-                                void* stream) {
+                                double* phi_out, void* stream) {
     if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || ldx < m - 1) return SOBER_E_ARG;
     if (!sober_car_supported(N, m)) return SOBER_E_DIM;
     size_t doubles = (size_t)m * N + 2 * (size_t)m + 8;
@@ -311,7 +386,7 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
         attr_set = true;
     }
     hipLaunchKernelGGL(sober::k_car, dim3(1), dim3(sober::CAR_T), bytes, (hipStream_t)stream, X, ldx, N, m,
-                       mu_in, keep_rank, w_star, n_keep, mu_out);
+                       mu_in, keep_rank, w_star, n_keep, mu_out, phi_out);
     LAUNCH_CHECK();
     return 0;
 }
