@@ -280,7 +280,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
             mu4[q] = (r < N) ? mb[r] : 0.0;
             if (ph4[q] > 0.0) amin_take(best, piv, mu4[q] / ph4[q], r);
         }
-#ifdef CAR_ARGMIN_SHFL
+#ifndef CAR_ARGMIN_DPP   // the DPP variant mis-combines (value, index) under divergent control flow; keep shuffles
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ob = __shfl_xor(best, o, 64);
