@@ -94,6 +94,21 @@ int sober_level_reduce(int kind, const void* rows, const double* rows_norm, int 
                        const double* mu, const double* wmul, double outputscale,
                        int n_chunks, double* partG, int ldg, int col0,
                        double* partTot, int64_t tot_limit, void* stream);
+/* Matrix-core variant of sober_level_reduce for the continuous kernels: rows / cand are AUGMENTED
+ * points (sober_augment_points: centred, scaled, with -|x|^2/2 and 1 in the two slots after the d
+ * coordinates, DA = sober_aug_dim(d) doubles per row), so that one v_mfma_f64_16x16x4 chain yields
+ * -|x~ - y~|^2 / 2 for a 16 x 16 tile of (row, candidate) pairs; the vector pipe only evaluates the
+ * exponential (table-driven FP64 exp) and accumulates.  Same outputs and chunking as
+ * sober_level_reduce.                                                                            */
+int sober_aug_dim(int d);
+int sober_augment_points(const double* X, int64_t n, int d, int64_t ldx, const double* lengthscale,
+                         int ls_len, const double* center, int side, double* out, int da, void* stream);
+int sober_level_reduce_mfma(int kind, const double* rows, int n_rows, const double* cand, int da,
+                            const int32_t* idx, int64_t pos0, int64_t count, int S,
+                            const double* mu, const double* wmul, double outputscale,
+                            int n_chunks, double* partG, int ldg, int col0,
+                            double* partTot, int64_t tot_limit, void* stream);
+
 /* chunk count the library would pick for a level of `count` positions in S sets.                 */
 int sober_level_chunks(int n_rows, int64_t pos0, int64_t count, int S);
 

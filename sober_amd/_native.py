@@ -33,6 +33,10 @@ SIGNATURES = {
     "sober_level_reduce": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp,
                                   _f64, _i32, _vp, _i32, _i32, _vp, _i64, _vp]),
     "sober_level_chunks": (_i32, [_i32, _i64, _i64, _i32]),
+    "sober_aug_dim": (_i32, [_i32]),
+    "sober_augment_points": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "sober_level_reduce_mfma": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _f64, _i32,
+                                       _vp, _i32, _i32, _vp, _i64, _vp]),
     "sober_sum_partials": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_dgemm": (_i32, [_i32, _i32, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _i32, _f64, _vp, _i32, _vp]),
     "sober_barycentres": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -158,6 +162,30 @@ def level_reduce(kind, rows, rows_norm, cand, cand_norm, dt, idx, idx_off, pos0,
                                      mu.data_ptr(), _ptr(wmul), float(outputscale), n_chunks,
                                      partG.data_ptr(), ldg, col0, _ptr(partTot), tot_limit, _stream(mu)),
            "sober_level_reduce")
+
+
+def aug_dim(d: int) -> int:
+    """DA for the matrix-core level kernel, or -1 when d + 2 exceeds the compiled tile set."""
+    r = load().sober_aug_dim(d)
+    return r if r > 0 else -1
+
+
+def augment_points(X, lengthscale, center, side, out):
+    n, d = X.shape
+    _req(X, torch.float64, "X"); _req(out, torch.float64, "out"); _req(center, torch.float64, "center")
+    _check(load().sober_augment_points(X.data_ptr(), n, d, X.stride(0), lengthscale.data_ptr(),
+                                       lengthscale.numel(), center.data_ptr(), side, out.data_ptr(),
+                                       out.shape[1], _stream(X)), "sober_augment_points")
+
+
+def level_reduce_mfma(kind, rows, cand, da, idx, idx_off, pos0, count, S, mu, wmul, outputscale, n_chunks,
+                      partG, ldg, col0, partTot, tot_limit):
+    _req(idx, torch.int32, "idx"); _req(mu, torch.float64, "mu")
+    _check(load().sober_level_reduce_mfma(kind, rows.data_ptr(), rows.shape[0], cand.data_ptr(), da,
+                                          idx.data_ptr() + 4 * idx_off, pos0, count, S, mu.data_ptr(),
+                                          _ptr(wmul), float(outputscale), n_chunks, partG.data_ptr(), ldg,
+                                          col0, _ptr(partTot), tot_limit, _stream(mu)),
+           "sober_level_reduce_mfma")
 
 
 def sum_partials(partG, partTot, n_chunks, n_rows, ldg, S, extraG, extraTot, n_xchunks, n_xcols, G, tot):

@@ -26,6 +26,7 @@ class HipOps:
         nat.load()
         self._pin = {}
         self.prof = None        # list -> (start_event, end_event, kernel entries) per level_reduce launch
+        self.use_mfma = True    # False: VALU-only level kernel (direct differences), kept for A/B runs
 
     # ------------------------------------------------------------------ plan
     def build_plan(self, spec: KernelSpec, mode: str, X_nys, X_cand) -> Plan:
@@ -56,6 +57,17 @@ class HipOps:
             W = woodbury(spec)
             p.T = torch.empty(p.M, p.n_obs, dtype=torch.float64, device=dev)
             nat.dgemm(Kall[p.M:], W, p.T, transa=True)            # K_Xn^T W == KxX W (k symmetric)
+        # matrix-core level kernel: augmented copies of the row table and the pool
+        p.da = nat.aug_dim(X_nys.shape[1]) if (p.kind != nat.KIND_TANIMOTO and self.use_mfma) else -1
+        if p.da > 0:
+            Xn64 = X_nys.to(torch.float64)
+            center = Xn64.mean(0).contiguous()                    # any shift works; this one keeps |x~| small
+            p.rows_aug = torch.empty(p.Mtot, p.da, dtype=torch.float64, device=dev)
+            p.cand_aug = torch.empty(X_cand.shape[0], p.da, dtype=torch.float64, device=dev)
+            nat.augment_points(stacked.to(torch.float64).contiguous(), spec.lengthscale, center, 0, p.rows_aug)
+            Xc = X_cand if (X_cand.dtype == torch.float64 and X_cand.stride(-1) == 1) else \
+                X_cand.to(torch.float64).contiguous()
+            nat.augment_points(Xc, spec.lengthscale, center, 1, p.cand_aug)
         p.P = None
         p.ws = {}
         return p
@@ -112,6 +124,15 @@ class HipOps:
             p.ws[name] = t
         return t
 
+    def _level_reduce(self, p, idx, idx_off, pos0, count, S, mu, n_chunks, partG, ldg, partTot, tot_limit):
+        if p.da > 0:
+            nat.level_reduce_mfma(p.kind, p.rows_aug, p.cand_aug, p.da, idx, idx_off, pos0, count, S, mu,
+                                  p.wmul, p.spec.outputscale, n_chunks, partG, ldg, 0, partTot, tot_limit)
+        else:
+            nat.level_reduce(p.kind, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, p.rows.dt, idx,
+                             idx_off, pos0, count, S, mu, p.wmul, p.spec.outputscale, n_chunks, partG, ldg, 0,
+                             partTot, tot_limit)
+
     def level_moments(self, p: Plan, idx, pos0, count, S, E, mu):
         """Partial (n, S) projected set sums and (S,) set masses over the local list positions
         [pos0, pos0+count) of a level with E full elements (SOBER/_rchq.py:116-164 minus the
@@ -123,8 +144,7 @@ class HipOps:
         partG = self._buf(p, "partG", n_chunks * p.Mtot * S)
         partTot = self._buf(p, "partTot", n_chunks * S)
         ev = self._prof_begin()
-        nat.level_reduce(p.kind, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, p.rows.dt, idx, 0,
-                         pos0, count, S, mu, p.wmul, p.spec.outputscale, n_chunks, partG, S, 0, partTot, ES)
+        self._level_reduce(p, idx, 0, pos0, count, S, mu, n_chunks, partG, S, partTot, ES)
         self._prof_end(ev, count * p.Mtot)
         extraG = extraTot = None
         n_xchunks, XS = 0, 16
@@ -137,9 +157,7 @@ class HipOps:
             extraG = self._buf(p, "extraG", n_xchunks * p.Mtot * XS)
             extraTot = self._buf(p, "extraTot", n_xchunks * XS)
             ev = self._prof_begin()
-            nat.level_reduce(p.kind, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, p.rows.dt, idx,
-                             lo - pos0, 0, n_left, XS, mu, p.wmul, p.spec.outputscale, n_xchunks, extraG,
-                             XS, 0, extraTot, n_left)
+            self._level_reduce(p, idx, lo - pos0, 0, n_left, XS, mu, n_xchunks, extraG, XS, extraTot, n_left)
             self._prof_end(ev, n_left * p.Mtot)
         G = self._buf(p, "G", p.Mtot * S).view(p.Mtot, S)
         tot = torch.empty(S, dtype=torch.float64, device=dev)

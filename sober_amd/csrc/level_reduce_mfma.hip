@@ -1,0 +1,261 @@
+// K1-K3, matrix-core variant for the continuous kernels (RBF, Matern-5/2).
+//
+//   k(x, y) depends on  a = -1/2 |x~ - y~|^2  =  x~.y~ - 1/2|x~|^2 - 1/2|y~|^2        (x~ = (x - c)/l)
+//
+// With augmented points  X' = [x~, -1/2|x~|^2, 1, 0..]  and  Y' = [y~, 1, -1/2|y~|^2, 0..]  (the two
+// extra slots live in the zero padding of the 4-aligned dimension), a = X'.Y' is a plain GEMM with
+// K = DA = roundup4(d + 2): three v_mfma_f64_16x16x4_f64 per 16x16 tile at d = 10.  The matrix pipe
+// produces the exponent argument, the vector pipe only does the exponential and the weighted
+// accumulation -- the two pipes run concurrently across the waves of a SIMD.
+//
+// exp(): no v_exp_f64 exists.  a = n ln2/64 + r, |r| <= ln2/128; exp(a) = 2^(n>>6) * T[n&63] * e^r with
+// a 64-entry table in LDS and a degree-5 polynomial (truncation 3.5e-17): 12 FP64 + 4 int ops
+// (libm's exp is ~2.5x that).  Max relative error ~2.5e-16.
+//
+// Wave tile: 64 rows (4 MFMA row tiles) x 16 sets; lane l holds column j = l & 15 (one candidate ->
+// one set) and rows (l >> 4) + 4*reg of each tile.  Workgroup = 4 waves = 256 rows sharing the staged
+// candidate tile.  Accumulators stay in VGPRs over the whole element chunk: fixed order, no atomics.
+#include "common.hpp"
+
+namespace sober {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int LM_RW = 4;     // waves (64 rows each) per workgroup
+constexpr int LM_SB = 16;    // sets per workgroup = MFMA N
+constexpr int LM_TE = 8;     // elements staged per tile
+
+__device__ __forceinline__ double exp_tab(double a, const double* __restrict__ T) {
+    const double L = 92.33248261689366;             // 64 / ln 2
+    const double C1 = 0.010830424667801708;         // ln2/64 with the low 24 mantissa bits cleared
+    const double C2 = 2.8447437476627285e-11;       // ln2/64 - C1
+    a = fmax(a, -1000.0);                           // exp underflows to 0 long before; keeps n in int32
+    double nf = __builtin_rint(a * L);
+    double r = fma(-nf, C1, a);
+    r = fma(-nf, C2, r);
+    const int n = (int)nf;
+    const double t = T[n & 63];
+    double q = fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
+    q = fma(r, q, 1.6666666666666666e-01);
+    q = fma(r, q, 0.5);
+    const double p = fma(r * r, q, r);
+    return ldexp(fma(t, p, t), n >> 6);
+}
+
+template <int KIND>
+__device__ __forceinline__ double kern_from_arg(double a, const double* __restrict__ T) {
+    if constexpr (KIND == SOBER_KIND_RBF) {
+        return exp_tab(a, T);                                         // exp(-sq/2)
+    } else {
+        const double s5 = 2.23606797749978969641;
+        const double sq = fmax(-2.0 * a, 1e-30);                      // clamp_min(1e-30) before sqrt
+        const double r = sqrt(sq);
+        const double c = (s5 * r + 1.0) + (5.0 / 3.0) * sq;
+        return c * exp_tab(-s5 * r, T);
+    }
+}
+
+template <int KIND, int KT>      // KT = DA / 4 k-steps
+__global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
+    const double* __restrict__ rows, int n_rows,          // n_rows x DA   (A side, augmented)
+    const double* __restrict__ cand,                      // N x DA        (B side, augmented)
+    const int32_t* __restrict__ idx, int64_t pos0, int64_t count, int S,
+    const double* __restrict__ mu, const double* __restrict__ wmul, double os,
+    int64_t e_first, int e_total, int e_per_chunk,
+    double* __restrict__ partG, int ldg, int col0,
+    double* __restrict__ partTot, int64_t tot_limit) {
+    constexpr int DA = 4 * KT;
+    constexpr int SB = LM_SB, TE = LM_TE, NT = TE * SB;
+    __shared__ double s_pts[2][TE][DA][SB];      // k-major: a B fragment read is 512 contiguous bytes
+    __shared__ double s_w[2][NT];
+    __shared__ double s_tot[NT];
+    __shared__ double s_T[64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lj = lane & 15, lk = lane >> 4;
+    const int s0 = blockIdx.x * SB;
+    const int chunk = blockIdx.y;
+    const int row0 = blockIdx.z * (LM_RW * 64) + wave * 64;
+    const int e0 = chunk * e_per_chunk;
+    const int e1 = min(e0 + e_per_chunk, e_total);
+
+    if (tid < 64) s_T[tid] = exp2((double)tid * (1.0 / 64.0));
+
+    // A fragments: lane holds rows[row0 + 16*t + lj][4*ks + lk]
+    double afr[4][KT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = row0 + 16 * t + lj;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) afr[t][ks] = (r < n_rows) ? rows[(size_t)r * DA + 4 * ks + lk] : 0.0;
+    }
+    double4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    // staging: thread tid < NT stages candidate (te = tid / SB, i = tid % SB)
+    const bool stager = tid < NT;
+    const int st_te = tid / SB, st_i = tid % SB;
+    double st[DA];
+    double st_w = 0.0, tot_acc = 0.0;
+
+#define LM_STAGE_LOAD(e_tile)                                                              \
+    if (stager) {                                                                          \
+        const int e_ = (e_tile) + st_te;                                                   \
+        const int s_ = s0 + st_i;                                                          \
+        const int64_t p_ = (e_first + e_) * S + s_;                                        \
+        const bool ok_ = (s_ < S) && (e_ < e1) && (p_ >= pos0) && (p_ < pos0 + count);     \
+        st_w = 0.0;                                                                        \
+        if (ok_) {                                                                         \
+            const int c_ = idx[p_ - pos0];                                                 \
+            const double m_ = mu[c_];                                                      \
+            st_w = (wmul ? m_ * wmul[c_] : m_) * os;                                       \
+            if (p_ < tot_limit) tot_acc += m_;                                             \
+            const double* src_ = cand + (size_t)c_ * DA;                                   \
+            _Pragma("unroll") for (int j = 0; j < DA; ++j) st[j] = src_[j];                \
+        } else {                                                                           \
+            _Pragma("unroll") for (int j = 0; j < DA; ++j) st[j] = 0.0;                    \
+        }                                                                                  \
+    }
+#define LM_STAGE_WRITE(buf)                                                                \
+    if (stager) {                                                                          \
+        _Pragma("unroll") for (int j = 0; j < DA; ++j) s_pts[buf][st_te][j][st_i] = st[j]; \
+        s_w[buf][tid] = st_w;                                                              \
+    }
+
+    int buf = 0;
+    if (e0 < e1) {
+        LM_STAGE_LOAD(e0);
+        LM_STAGE_WRITE(0);
+    }
+    __syncthreads();
+
+    for (int et = e0; et < e1; et += TE) {
+        const bool more = (et + TE) < e1;
+        if (more) { LM_STAGE_LOAD(et + TE); }
+        const int te_cnt = min(TE, e1 - et);
+        for (int te = 0; te < te_cnt; ++te) {
+            double bfr[KT];
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) bfr[ks] = s_pts[buf][te][4 * ks + lk][lj];
+            const double w = s_w[buf][te * SB + lj];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                double4_t c = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KT; ++ks)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[t][ks], bfr[ks], c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] = fma(kern_from_arg<KIND>(c[r], s_T), w, acc[t][r]);
+            }
+        }
+        if (more) { LM_STAGE_WRITE(buf ^ 1); }
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef LM_STAGE_LOAD
+#undef LM_STAGE_WRITE
+
+    // C/D map of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+    if (s0 + lj < S) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * t + lk + 4 * r;
+                if (row < n_rows) partG[((size_t)chunk * n_rows + row) * ldg + col0 + s0 + lj] = acc[t][r];
+            }
+    }
+    if (partTot != nullptr && blockIdx.z == 0) {
+        if (stager) s_tot[tid] = tot_acc;
+        __syncthreads();
+        if (tid < SB && s0 + tid < S) {
+            double t = 0.0;
+#pragma unroll
+            for (int te = 0; te < TE; ++te) t += s_tot[te * SB + tid];
+            partTot[(size_t)chunk * ldg + col0 + s0 + tid] = t;
+        }
+    }
+}
+
+// points -> augmented, centred, scaled rows.  side 0: [x~, -|x~|^2/2, 1, 0..]; side 1: [y~, 1, -|y~|^2/2, 0..]
+__global__ void k_augment_points(const double* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                 const double* __restrict__ ls, int ls_len,
+                                 const double* __restrict__ center, int side, double* __restrict__ out, int da) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double nrm = 0.0;
+    double* o = out + i * da;
+    for (int j = 0; j < d; ++j) {
+        const double v = (X[i * ldx + j] - center[j]) / ls[ls_len == 1 ? 0 : j];
+        o[j] = v;
+        nrm = fma(v, v, nrm);
+    }
+    o[d + side] = -0.5 * nrm;
+    o[d + 1 - side] = 1.0;
+    for (int j = d + 2; j < da; ++j) o[j] = 0.0;
+}
+
+template <int KIND, int KT>
+static int launch_lm(const double* rows, int n_rows, const double* cand, const int32_t* idx, int64_t pos0,
+                     int64_t count, int S, const double* mu, const double* wmul, double os, int n_chunks,
+                     double* partG, int ldg, int col0, double* partTot, int64_t tot_limit, hipStream_t st) {
+    const int64_t e_first = pos0 / S;
+    const int e_total = (int)((pos0 + count + S - 1) / S - e_first);
+    const int e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
+    dim3 grid((S + LM_SB - 1) / LM_SB, n_chunks, (n_rows + LM_RW * 64 - 1) / (LM_RW * 64));
+    hipLaunchKernelGGL((k_level_reduce_mfma<KIND, KT>), grid, dim3(LM_RW * 64), 0, st, rows, n_rows, cand, idx,
+                       pos0, count, S, mu, wmul, os, e_first, e_total, e_per_chunk, partG, ldg, col0, partTot,
+                       tot_limit);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace sober
+
+using namespace sober;
+
+extern "C" int sober_aug_dim(int d) {
+    if (d <= 0) return SOBER_E_ARG;
+    const int da = ((d + 2 + 3) / 4) * 4;
+    return da <= 32 ? da : SOBER_E_DIM;
+}
+
+extern "C" int sober_augment_points(const double* X, int64_t n, int d, int64_t ldx, const double* lengthscale,
+                                    int ls_len, const double* center, int side, double* out, int da,
+                                    void* stream) {
+    if (!X || !lengthscale || !center || !out || n <= 0 || d <= 0 || ldx < d || da < d + 2) return SOBER_E_ARG;
+    if ((ls_len != 1 && ls_len != d) || (side != 0 && side != 1)) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_augment_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, n,
+                       d, ldx, lengthscale, ls_len, center, side, out, da);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_level_reduce_mfma(int kind, const double* rows, int n_rows, const double* cand, int da,
+                                       const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu,
+                                       const double* wmul, double outputscale, int n_chunks, double* partG,
+                                       int ldg, int col0, double* partTot, int64_t tot_limit, void* stream) {
+    if (!rows || !cand || !idx || !mu || !partG) return SOBER_E_ARG;
+    if (n_rows <= 0 || pos0 < 0 || count <= 0 || S <= 0 || n_chunks <= 0 || ldg < col0 + S) return SOBER_E_ARG;
+    if (n_chunks > (pos0 + count + S - 1) / S - pos0 / S) return SOBER_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+#define LM_CASE(K, T)                                                                                          \
+    case 4 * T:                                                                                                \
+        return launch_lm<K, T>(rows, n_rows, cand, idx, pos0, count, S, mu, wmul, outputscale, n_chunks, partG, \
+                               ldg, col0, partTot, tot_limit, st);
+    switch (kind) {
+        case SOBER_KIND_RBF:
+            switch (da) { LM_CASE(SOBER_KIND_RBF, 1) LM_CASE(SOBER_KIND_RBF, 2) LM_CASE(SOBER_KIND_RBF, 3)
+                          LM_CASE(SOBER_KIND_RBF, 4) LM_CASE(SOBER_KIND_RBF, 5) LM_CASE(SOBER_KIND_RBF, 6)
+                          LM_CASE(SOBER_KIND_RBF, 7) LM_CASE(SOBER_KIND_RBF, 8) default: return SOBER_E_DIM; }
+        case SOBER_KIND_MATERN52:
+            switch (da) { LM_CASE(SOBER_KIND_MATERN52, 1) LM_CASE(SOBER_KIND_MATERN52, 2)
+                          LM_CASE(SOBER_KIND_MATERN52, 3) LM_CASE(SOBER_KIND_MATERN52, 4)
+                          LM_CASE(SOBER_KIND_MATERN52, 5) LM_CASE(SOBER_KIND_MATERN52, 6)
+                          LM_CASE(SOBER_KIND_MATERN52, 7) LM_CASE(SOBER_KIND_MATERN52, 8)
+                          default: return SOBER_E_DIM; }
+        default: return SOBER_E_ARG;
+    }
+#undef LM_CASE
+}
