@@ -9,7 +9,7 @@
 // accumulation -- the two pipes run concurrently across the waves of a SIMD.
 //
 // exp(): no v_exp_f64 exists.  a = n ln2/64 + r, |r| <= ln2/128; exp(a) = 2^(n>>6) * T[n&63] * e^r with
-// a 64-entry table in LDS and a degree-5 polynomial (truncation 3.5e-17): 12 FP64 + 4 int ops
+// a 64-entry table in LDS and a degree-5 polynomial (truncation 3.5e-17): 11 FP64 + 4 int ops
 // (libm's exp is ~2.5x that).  Max relative error ~2.5e-16.
 //
 // Wave tile: 64 rows (4 MFMA row tiles) x 16 sets; lane l holds column j = l & 15 (one candidate ->
@@ -25,33 +25,67 @@ constexpr int LM_RW = 4;     // waves (64 rows each) per workgroup
 constexpr int LM_SB = 16;    // sets per workgroup = MFMA N
 constexpr int LM_TE = 8;     // elements staged per tile
 
-__device__ __forceinline__ double exp_tab(double a, const double* __restrict__ T) {
-    const double L = 92.33248261689366;             // 64 / ln 2
-    const double C1 = 0.010830424667801708;         // ln2/64 with the low 24 mantissa bits cleared
-    const double C2 = 2.8447437476627285e-11;       // ln2/64 - C1
-    a = fmax(a, -1000.0);                           // exp underflows to 0 long before; keeps n in int32
-    double nf = __builtin_rint(a * L);
-    double r = fma(-nf, C1, a);
-    r = fma(-nf, C2, r);
-    const int n = (int)nf;
-    const double t = T[n & 63];
-    double q = fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
-    q = fma(r, q, 1.6666666666666666e-01);
-    q = fma(r, q, 0.5);
-    const double p = fma(r * r, q, r);
-    return ldexp(fma(t, p, t), n >> 6);
+// exp of four independent arguments, written stage by stage so that the four dependency chains
+// interleave (one chain alone leaves the FP64 pipe idle for most of its latency).
+//
+// The argument arrives PRE-SCALED: y = a * 64/ln2 (the scale is folded into the augmented rows, so the
+// GEMM delivers y for free).  Then  n = rint(y)  via the 2^52 magic-number add (its low dword IS n),
+// r' = y - n exactly (no Cody-Waite split needed), exp(a) = 2^(n>>6) T[n&63] (1 + p(r')) with the
+// polynomial coefficients pre-multiplied by (ln2/64)^k, and the final scaling by 2^(n>>6) is an
+// integer add on the exponent field.  10 FP64 ops per value (libm: ~30).
+__device__ __forceinline__ void exp_tab4(const double (&y)[4], const double* __restrict__ T, double (&out)[4]) {
+    const double MAGIC = 6755399441055744.0;        // 1.5 * 2^52
+    const double K1 = 1.0830424696249145e-02;       // (ln2/64)^k / k!
+    const double K2 = 5.86490495505617e-05;
+    const double K3 = 2.1173137155464776e-07;
+    const double K4 = 5.732851688640402e-10;
+    const double K5 = 1.2417843701716925e-12;
+    double u[4], r[4], t[4], q[4];
+    int n[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = fmax(y[i], -65000.0) + MAGIC;   // e^-704 ~ 1e-306: keeps 2^(n>>6) a normal number
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n[i] = __double2loint(u[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = T[n[i] & 63];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fmax(y[i], -65000.0) - (u[i] - MAGIC);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = fma(r[i], K5, K4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = fma(r[i], q[i], K3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = fma(r[i], q[i], K2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = fma(r[i], q[i], K1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = q[i] * r[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double v = fma(t[i], q[i], t[i]);                        // in [1, 2)
+        out[i] = __hiloint2double(__double2hiint(v) + ((n[i] >> 6) << 20), __double2loint(v));
+    }
 }
 
 template <int KIND>
-__device__ __forceinline__ double kern_from_arg(double a, const double* __restrict__ T) {
+__device__ __forceinline__ void kern_from_arg4(const double4_t& c, const double* __restrict__ T, double (&k)[4]) {
     if constexpr (KIND == SOBER_KIND_RBF) {
-        return exp_tab(a, T);                                         // exp(-sq/2)
+        const double y[4] = {c[0], c[1], c[2], c[3]};                 // already -sq/2 * 64/ln2
+        exp_tab4(y, T, k);
     } else {
         const double s5 = 2.23606797749978969641;
-        const double sq = fmax(-2.0 * a, 1e-30);                      // clamp_min(1e-30) before sqrt
-        const double r = sqrt(sq);
-        const double c = (s5 * r + 1.0) + (5.0 / 3.0) * sq;
-        return c * exp_tab(-s5 * r, T);
+        const double INV_L = 1.0830424696249145e-02;                   // ln2/64: undo the pre-scaling
+        const double L = 92.33248261689366;
+        double sq[4], rr[4], a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sq[i] = fmax((-2.0 * INV_L) * c[i], 1e-30);   // clamp_min(1e-30) before sqrt
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rr[i] = sqrt(sq[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = (-s5 * L) * rr[i];
+        exp_tab4(a, T, k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k[i] *= (s5 * rr[i] + 1.0) + (5.0 / 3.0) * sq[i];
     }
 }
 
@@ -134,20 +168,50 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
         const bool more = (et + TE) < e1;
         if (more) { LM_STAGE_LOAD(et + TE); }
         const int te_cnt = min(TE, e1 - et);
-        for (int te = 0; te < te_cnt; ++te) {
+        // software pipeline over the elements of the tile: the MFMAs of element te+1 are issued
+        // before the exponentials of element te, so the matrix and vector pipes overlap in-wave
+        double4_t cc[4];
+        double wc;
+        {
             double bfr[KT];
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) bfr[ks] = s_pts[buf][te][4 * ks + lk][lj];
-            const double w = s_w[buf][te * SB + lj];
+            for (int ks = 0; ks < KT; ++ks) bfr[ks] = s_pts[buf][0][4 * ks + lk][lj];
+            wc = s_w[buf][lj];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                double4_t c = (double4_t){0.0, 0.0, 0.0, 0.0};
+                cc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int ks = 0; ks < KT; ++ks)
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[t][ks], bfr[ks], c, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] = fma(kern_from_arg<KIND>(c[r], s_T), w, acc[t][r]);
+                    cc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[t][ks], bfr[ks], cc[t], 0, 0, 0);
             }
+        }
+        for (int te = 0; te < te_cnt; ++te) {
+            double4_t cn[4];
+            double wn = 0.0;
+            const int tn = min(te + 1, TE - 1);                 // last iteration: harmless re-read
+            {
+                double bfr[KT];
+#pragma unroll
+                for (int ks = 0; ks < KT; ++ks) bfr[ks] = s_pts[buf][tn][4 * ks + lk][lj];
+                wn = s_w[buf][tn * SB + lj];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    cn[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int ks = 0; ks < KT; ++ks)
+                        cn[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[t][ks], bfr[ks], cn[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                double k[4];
+                kern_from_arg4<KIND>(cc[t], s_T, k);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] = fma(k[r], wc, acc[t][r]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) cc[t] = cn[t];
+            wc = wn;
         }
         if (more) { LM_STAGE_WRITE(buf ^ 1); }
         __syncthreads();
@@ -178,21 +242,24 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
     }
 }
 
-// points -> augmented, centred, scaled rows.  side 0: [x~, -|x~|^2/2, 1, 0..]; side 1: [y~, 1, -|y~|^2/2, 0..]
+// points -> augmented, centred, scaled rows.  side 1 (pool): [y~, 1, -|y~|^2/2, 0..];
+// side 0 (row table): L * [x~, -|x~|^2/2, 1, 0..] with L = 64/ln2, so that X'.Y' = -|x~ - y~|^2/2 * L is
+// directly the table-exp's scaled argument
 __global__ void k_augment_points(const double* __restrict__ X, int64_t n, int d, int64_t ldx,
                                  const double* __restrict__ ls, int ls_len,
                                  const double* __restrict__ center, int side, double* __restrict__ out, int da) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const double sc = (side == 0) ? 92.33248261689366 : 1.0;
     double nrm = 0.0;
     double* o = out + i * da;
     for (int j = 0; j < d; ++j) {
         const double v = (X[i * ldx + j] - center[j]) / ls[ls_len == 1 ? 0 : j];
-        o[j] = v;
+        o[j] = v * sc;
         nrm = fma(v, v, nrm);
     }
-    o[d + side] = -0.5 * nrm;
-    o[d + 1 - side] = 1.0;
+    o[d + side] = -0.5 * nrm * sc;
+    o[d + 1 - side] = sc;
     for (int j = d + 2; j < da; ++j) o[j] = 0.0;
 }
 
