@@ -28,6 +28,7 @@ namespace sober {
 constexpr int CAR_T = 1024;
 constexpr int CAR_RP = 25;          // Phi rows per thread: N <= 8 * 25
 constexpr int CAR_CQ = 13;          // columns per lane in the row sweeps: N <= 16 * 13
+constexpr int CAR_PAD = 208;        // >= 16 * CAR_CQ and >= 8 * CAR_RP + 8
 
 // ---- DPP cross-lane helpers (row = 16 lanes).  ds_bpermute-based __shfl costs an LDS round trip
 // per step; these are plain VALU moves.
@@ -82,17 +83,15 @@ __device__ __forceinline__ void larfg(double alpha, double ss, double& beta, dou
     }
 }
 
-// ratio-test combine: first argmin, a NaN ratio wins (torch.argmin); piv < 0 = no candidate
+// ratio-test combine, branch-free (selects only): first argmin, a NaN ratio wins (torch.argmin);
+// piv < 0 = no candidate yet
 __device__ __forceinline__ void amin_take(double& best, int& piv, double ob, int op) {
-    bool take;
-    if (op < 0) take = false;
-    else if (piv < 0) take = true;
-    else {
-        const bool bn = best != best, on = ob != ob;
-        if (bn || on) take = on && (!bn || op < piv);
-        else take = (ob < best) || (ob == best && op < piv);
-    }
-    if (take) { best = ob; piv = op; }
+    const bool bn = best != best, on = ob != ob;
+    const bool lt = (ob < best) | ((ob == best) & (op < piv));
+    const bool nn = on & ((!bn) | (op < piv));
+    const bool take = (op >= 0) & ((piv < 0) | ((bn | on) ? nn : lt));
+    best = take ? ob : best;
+    piv = take ? op : piv;
 }
 
 __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int ldx, int N, int m,
@@ -103,10 +102,12 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                                                double* __restrict__ mu_out,
                                                double* __restrict__ phi_out) {
     extern __shared__ double lds[];
-    double* A = lds;                       // m x N, row-major
-    double* taup = lds + (size_t)m * N;    // m
-    double* ubuf = taup + m;               // m   (left reflector of the current step)
-    double* scal = ubuf + m;               // [0] = tauq
+    // m x N row-major, then CAR_PAD doubles of slack: the register-tiled sweeps read fixed strides
+    // (immediate offsets, no per-element clamping -> no address VGPRs) and mask what lies beyond N
+    double* A = lds;
+    double* taup = lds + (size_t)m * N + CAR_PAD;    // m
+    double* ubuf = taup + m;               // m  (left reflector of the current step)
+    double* scal = ubuf + m;               // [0] tauq  [1] tau
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CAR_STAMPS
@@ -129,95 +130,107 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     __syncthreads();
 
     // ---------------- phase 1: Golub-Kahan bidiagonalisation (dgebd2, m < N) ----------------
+    // per step: (A) wave 0 builds G(i) from row i   | barrier
+    //           (B) all waves apply it to rows > i  | barrier
+    //           (C) wave 0 builds H(i) from column i | barrier
+    //           (D) all waves apply it to columns > i | barrier
     for (int i = 0; i < m; ++i) {
-        // ---- right reflector G(i) from row i, columns i..N-1.  Every DPP row (16 lanes x CAR_CQ
-        // columns) holds the whole row: the norm is a row16 all-reduce, computed redundantly.
         double* rowi = A + (size_t)i * N;
-        double vreg[CAR_CQ];
-        double ss = 0.0;
+        if (wave == 0) {                                               // (A)
+            double vr[4];
+            double ss = 0.0;
 #pragma unroll
-        for (int q = 0; q < CAR_CQ; ++q) {
-            const int c = i + 1 + l16 + 16 * q;
-            vreg[q] = (c < N) ? rowi[c] : 0.0;
-            ss = fma(vreg[q], vreg[q], ss);
+            for (int q = 0; q < 4; ++q) {
+                const int c = i + 1 + lane + 64 * q;
+                const double x = rowi[min(c, N - 1)];
+                vr[q] = (c < N) ? x : 0.0;
+                ss = fma(vr[q], vr[q], ss);
+            }
+            ss = wave_sum(ss);
+            double beta, tau, sc;
+            larfg(rowi[i], ss, beta, tau, sc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = i + 1 + lane + 64 * q;
+                if (c < N) rowi[c] = vr[q] * sc;                       // v_i stays in place like dgebd2
+            }
+            if (lane == 0) { rowi[i] = beta; taup[i] = tau; scal[1] = tau; }
         }
-        ss = row16_sum(ss);
-        double beta, tau, sc;
-        larfg(rowi[i], ss, beta, tau, sc);
-#pragma unroll
-        for (int q = 0; q < CAR_CQ; ++q) vreg[q] *= sc;
-        // apply to rows r > i: one matrix row per DPP row, 64 rows per sweep of the workgroup
-        for (int r = i + 1 + wave * 4 + rid; r < m; r += 64) {
-            double* row = A + (size_t)r * N;
-            double a[CAR_CQ];
-            double w = (l16 == 0) ? row[i] : 0.0;
+        if (i == m - 1) break;
+        __syncthreads();
+        {                                                              // (B) one matrix row per DPP row
+            const double tau = scal[1];
+            double vreg[CAR_CQ];
 #pragma unroll
             for (int q = 0; q < CAR_CQ; ++q) {
                 const int c = i + 1 + l16 + 16 * q;
-                a[q] = (c < N) ? row[c] : 0.0;
-                w = fma(a[q], vreg[q], w);
+                const double x = rowi[c];
+                vreg[q] = (c < N) ? x : 0.0;
             }
-            const double t = tau * row16_sum(w);
-            if (l16 == 0) row[i] -= t;
-#pragma unroll
-            for (int q = 0; q < CAR_CQ; ++q) {
-                const int c = i + 1 + l16 + 16 * q;
-                if (c < N) row[c] = fma(-t, vreg[q], a[q]);
-            }
-        }
-        __syncthreads();                                               // (1) rows updated, row i read
-        // ---- wave 0: store v_i / taup, build the left reflector H(i) from column i
-        if (wave == 0) {
-            if (lane == 0) { rowi[i] = beta; taup[i] = tau; }
-            if (rid == 0) {
+            for (int r = i + 1 + wave * 4 + rid; r < m; r += 64) {
+                double* row = A + (size_t)r * N;
+                double a[CAR_CQ];
+                double w0 = (l16 == 0) ? row[i] : 0.0, w1 = 0.0;
 #pragma unroll
                 for (int q = 0; q < CAR_CQ; ++q) {
                     const int c = i + 1 + l16 + 16 * q;
-                    if (c < N) rowi[c] = vreg[q];
+                    a[q] = row[c];
+                    if (q & 1) w1 = fma(a[q], vreg[q], w1); else w0 = fma(a[q], vreg[q], w0);
                 }
-            }
-            if (i < m - 1) {
-                double ureg[2];
-                double s2 = 0.0;
+                const double t = tau * row16_sum(w0 + w1);
+                if (l16 == 0) row[i] -= t;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int r = i + 2 + lane + 64 * q;
-                    ureg[q] = (r < m) ? A[(size_t)r * N + i] : 0.0;
-                    s2 = fma(ureg[q], ureg[q], s2);
-                }
-                s2 = wave_sum(s2);
-                double beta2, tauq, sc2;
-                larfg(A[(size_t)(i + 1) * N + i], s2, beta2, tauq, sc2);
-                if (lane == 0) { ubuf[0] = 1.0; scal[0] = tauq; }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int r = i + 2 + lane + 64 * q;
-                    if (r < m) ubuf[r - i - 1] = ureg[q] * sc2;
+                for (int q = 0; q < CAR_CQ; ++q) {
+                    const int c = i + 1 + l16 + 16 * q;
+                    if (c < N) row[c] = fma(-t, vreg[q], a[q]);
                 }
             }
         }
-        if (i == m - 1) break;
-        __syncthreads();                                               // (2) ubuf / tauq visible
-        // ---- apply H(i) to A(i+1:m-1, i+1:N-1): a wave owns 8 columns (2 per DPP row), the 8 row
-        // groups of a column sit in one DPP row -> the column dot product is a DPP reduction
-        {
+        __syncthreads();
+        if (wave == 0) {                                               // (C)
+            double ureg[2];
+            double s2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = i + 2 + lane + 64 * q;
+                const double x = A[(size_t)min(r, m - 1) * N + i];   // 2 clamped loads only
+                ureg[q] = (r < m) ? x : 0.0;
+                s2 = fma(ureg[q], ureg[q], s2);
+            }
+            s2 = wave_sum(s2);
+            double beta2, tauq, sc2;
+            larfg(A[(size_t)(i + 1) * N + i], s2, beta2, tauq, sc2);
+            if (lane == 0) { ubuf[0] = 1.0; scal[0] = tauq; }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = i + 2 + lane + 64 * q;
+                if (r < m) ubuf[r - i - 1] = ureg[q] * sc2;
+            }
+        }
+        __syncthreads();
+        {                                                              // (D) 8 columns per wave sweep
             const double tauq = scal[0];
             const int L = m - i - 1;                                   // rows i+1 .. m-1
+            const int nk = (L - g + 7) >> 3;                           // my rows: k = g, g+8, ...
             for (int cb = wave; cb * 8 < N - i - 1; cb += 16) {
-                const int c = i + 1 + cb * 8 + rid * 2 + c2;
-                const bool okc = c < N;
+                const int c = min(i + 1 + cb * 8 + rid * 2 + c2, N - 1);   // clamped: duplicates are benign
+                double* colp = A + (size_t)(i + 1 + g) * N + c;
+                double av[13];
                 double part = 0.0;
-                for (int k = g; k < L; k += 8)
-                    if (okc) part = fma(ubuf[k], A[(size_t)(i + 1 + k) * N + c], part);
-                const double t = tauq * grp8_sum(part);
-                for (int k = g; k < L; k += 8)
-                    if (okc) {
-                        double* e = A + (size_t)(i + 1 + k) * N + c;
-                        *e = fma(-t, ubuf[k], *e);
+#pragma unroll
+                for (int kk = 0; kk < 13; ++kk) {
+                    if (kk < nk) {
+                        av[kk] = colp[(size_t)kk * 8 * N];
+                        part = fma(ubuf[g + 8 * kk], av[kk], part);
                     }
+                }
+                const double t = tauq * grp8_sum(part);
+#pragma unroll
+                for (int kk = 0; kk < 13; ++kk)
+                    if (kk < nk) colp[(size_t)kk * 8 * N] = fma(-t, ubuf[g + 8 * kk], av[kk]);
             }
         }
-        __syncthreads();                                               // (3) before the next row step
+        __syncthreads();
     }
     __syncthreads();
 
@@ -233,17 +246,27 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
         for (int i = m - 1; i >= 0; --i) {
             const double* vi = A + (size_t)i * N;          // v_i in columns i+1.., implicit 1 at column i
             const double tau = taup[i];
-            double vv[CAR_RP];
-            double part = 0.0;
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) {
                 const int r = g + 8 * k;
-                vv[k] = (r < N && r > i) ? vi[r] : ((r == i) ? 1.0 : 0.0);
-                part = fma(vv[k], phi[k], part);
+                const double x = vi[r];                                // unconditional load, then select
+                const double v = (r > i && r < N) ? x : ((r == i) ? 1.0 : 0.0);
+                if ((k & 3) == 0) p0 = fma(v, phi[k], p0);
+                else if ((k & 3) == 1) p1 = fma(v, phi[k], p1);
+                else if ((k & 3) == 2) p2 = fma(v, phi[k], p2);
+                else p3 = fma(v, phi[k], p3);
+                if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);   // cap load hoisting: VGPR budget is 128
             }
-            const double t = tau * grp8_sum(part);
+            const double t = tau * grp8_sum((p0 + p1) + (p2 + p3));
 #pragma unroll
-            for (int k = 0; k < CAR_RP; ++k) phi[k] = fma(-t, vv[k], phi[k]);
+            for (int k = 0; k < CAR_RP; ++k) {                         // second pass re-reads v_i from LDS:
+                const int r = g + 8 * k;                               // cheaper than 50 more live VGPRs
+                const double x = vi[r];
+                const double v = (r > i && r < N) ? x : ((r == i) ? 1.0 : 0.0);
+                phi[k] = fma(-t, v, phi[k]);
+                if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     if (phi_out != nullptr && okcol) {                                 // stage-level test hook
@@ -255,8 +278,12 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 
     CAR_STAMP();
     // ---------------- phase 3: the pivots of SOBER/_rchq.py:237-266 ----------------
-    double* colbuf = lds;                  // [2][N]
-    double* mubuf = lds + 2 * N;           // [2][N]
+    // per pivot: wave 15 does the ratio test and the mu update and publishes (piv, alpha) | barrier |
+    //            the column owners eliminate; the owner of the next pivot column publishes it | barrier
+    const int NP = 264;                    // padded stride >= N + 64: fixed-stride over-reads stay in bounds
+    double* colbuf = lds;                  // [2][NP]
+    double* mubuf = lds + 2 * NP;          // [2][NP]
+    double* pscal = lds + 4 * NP;          // [0] alpha  [1] piv
     for (int r = tid; r < N; r += CAR_T) mubuf[r] = mu_in[r];
     if (okcol && col == 0) {
 #pragma unroll
@@ -267,59 +294,43 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 
     int cur = 0;
     for (int s = 0; s < NC; ++s, cur ^= 1) {
-        const double* cb = colbuf + cur * N;
-        const double* mb = mubuf + cur * N;
-        // ratio test: first argmin of mu/Phi[:,0] over Phi[:,0] > 0 (every wave, redundantly)
-        double best = 0.0;
-        int piv = -1;
-        double ph4[4], mu4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = lane + 64 * q;
-            ph4[q] = (r < N) ? cb[r] : 0.0;
-            mu4[q] = (r < N) ? mb[r] : 0.0;
-            if (ph4[q] > 0.0) amin_take(best, piv, mu4[q] / ph4[q], r);
-        }
-#ifndef CAR_ARGMIN_DPP   // the DPP variant mis-combines (value, index) under divergent control flow; keep shuffles
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ob = __shfl_xor(best, o, 64);
-            const int op = __shfl_xor(piv, o, 64);
-            amin_take(best, piv, ob, op);
-        }
-#else
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {                                   // all-reduce inside each DPP row
-            double ob; int op;
-            if (o == 0) { ob = dpp<ROR8>(best); op = __builtin_amdgcn_update_dpp(0, piv, ROR8, 0xf, 0xf, false); }
-            else if (o == 1) { ob = dpp<ROR4>(best); op = __builtin_amdgcn_update_dpp(0, piv, ROR4, 0xf, 0xf, false); }
-            else if (o == 2) { ob = dpp<ROR2>(best); op = __builtin_amdgcn_update_dpp(0, piv, ROR2, 0xf, 0xf, false); }
-            else { ob = dpp<ROR1>(best); op = __builtin_amdgcn_update_dpp(0, piv, ROR1, 0xf, 0xf, false); }
-            amin_take(best, piv, ob, op);
-        }
-        {                                                               // then across the four rows
-            double b0 = rdlane(best, 0);
-            int p0 = __builtin_amdgcn_readlane(piv, 0);
-            amin_take(b0, p0, rdlane(best, 16), __builtin_amdgcn_readlane(piv, 16));
-            amin_take(b0, p0, rdlane(best, 32), __builtin_amdgcn_readlane(piv, 32));
-            amin_take(b0, p0, rdlane(best, 48), __builtin_amdgcn_readlane(piv, 48));
-            best = b0; piv = p0;
-        }
-#endif
-        if (piv < 0) break;                                             // Q6 (:241-242), uniform
-        const double alpha = best;
-        const double pp = cb[piv];
-        // mu[:] = mu - alpha * Phi[:,0]; mu[idx] = 0   (two roundings like the tensor expression)
+        const double* cb = colbuf + cur * NP;
         if (wave == 15) {
+            const double* mb = mubuf + cur * NP;
+            double best = 0.0;
+            int piv = -1;
+            double ph4[4], mu4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = lane + 64 * q;
-                if (r < N) mubuf[(cur ^ 1) * N + r] = (r == piv) ? 0.0 : __dsub_rn(mu4[q], __dmul_rn(alpha, ph4[q]));
+                ph4[q] = cb[r];
+                mu4[q] = mb[r];
+                const bool ok = (r < N) & (ph4[q] > 0.0);
+                amin_take(best, piv, mu4[q] / ph4[q], ok ? r : -1);
             }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64);
+                const int op = __shfl_xor(piv, o, 64);
+                amin_take(best, piv, ob, op);
+            }
+            // mu[:] = mu - alpha * Phi[:,0]; mu[idx] = 0   (two roundings like the tensor expression)
+            if (piv >= 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = lane + 64 * q;
+                    if (r < N) mubuf[(cur ^ 1) * NP + r] = (r == piv) ? 0.0 : __dsub_rn(mu4[q], __dmul_rn(best, ph4[q]));
+                }
+            }
+            if (lane == 0) { pscal[0] = best; pscal[1] = (double)piv; }
         }
-        // rank-1 elimination of my column: Phi[:,c] -= Phi[:,0] * (Phi[idx,c] / Phi[idx,0]).  The pivot-row
-        // entry of my column sits in the lane with g == piv % 8 of my own DPP row.
+        __syncthreads();
+        const int piv = (int)pscal[1];
+        if (piv < 0) break;                                             // Q6 (:241-242), uniform
         if (okcol && col > s) {
+            // rank-1 elimination of my column: Phi[:,c] -= Phi[:,0] * (Phi[idx,c] / Phi[idx,0]).  The
+            // pivot-row entry of my column sits in the lane with g == piv % 8 of my own DPP row.
+            const double pp = cb[piv];
             const int kp = piv >> 3, gp = piv & 7;
             double mine = 0.0;
 #pragma unroll
@@ -329,12 +340,14 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) {
                 const int r = g + 8 * k;
-                if (r < N) phi[k] = (r == piv) ? 0.0 : fma(-qv, cb[r], phi[k]);
+                const double x = cb[r];
+                phi[k] = (r == piv || r >= N) ? 0.0 : fma(-qv, x, phi[k]);
+                if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);
             }
             if (col == s + 1) {                                        // next pivot column
 #pragma unroll
                 for (int k = 0; k < CAR_RP; ++k)
-                    if (g + 8 * k < N) colbuf[(cur ^ 1) * N + g + 8 * k] = phi[k];
+                    if (g + 8 * k < N) colbuf[(cur ^ 1) * NP + g + 8 * k] = phi[k];
             }
         }
         __syncthreads();
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 #endif
     // ---------------- output: w_star = mu[mu > 0], idx_star as ranks ----------------
     if (wave == 0) {
-        const double* mb = mubuf + cur * N;
+        const double* mb = mubuf + cur * NP;
         int base = 0;
         for (int q = 0; q < 4; ++q) {
             const int r = lane + 64 * q;
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 }  // namespace sober
 
 extern "C" int sober_car_supported(int N, int m) {
-    return (m >= 2 && N > m && N <= 8 * sober::CAR_RP && N <= 16 * sober::CAR_CQ && (int64_t)m * N <= 20000 && N - m <= 128) ? 1 : 0;
+    return (m >= 2 && N > m && N <= 8 * sober::CAR_RP && N <= 16 * sober::CAR_CQ && (int64_t)m * N <= 20000 && N - m <= 120) ? 1 : 0;
 }
 
 extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
@@ -376,8 +389,8 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
                                 double* phi_out, void* stream) {
     if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || ldx < m - 1) return SOBER_E_ARG;
     if (!sober_car_supported(N, m)) return SOBER_E_DIM;
-    size_t doubles = (size_t)m * N + 2 * (size_t)m + 8;
-    if (doubles < 4 * (size_t)N) doubles = 4 * (size_t)N;
+    size_t doubles = (size_t)m * N + sober::CAR_PAD + 2 * (size_t)m + 8;
+    if (doubles < 4 * 264 + 8) doubles = 4 * 264 + 8;
     const size_t bytes = doubles * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
