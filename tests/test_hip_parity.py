@@ -354,3 +354,73 @@ def test_host_and_device_car_agree(dev):
     assert torch.equal(i1, i2)
     np.testing.assert_allclose(w1.cpu().numpy(), w2.cpu().numpy(), rtol=W_RTOL)
     assert np.array_equal(i1.cpu().numpy(), z["idx"])
+
+
+# --------------------------------------------------------------------------- #
+# the distributed code path on the device (one rank: every collective still runs through RCCL)
+# --------------------------------------------------------------------------- #
+def test_sharded_path_single_rank_rccl(dev):
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        path = os.path.join(GOLD, "recomb_rbf_b30.npz")
+        case, inp, spec, z = load_case(path)
+        mu = _t(inp["mu0"].copy()).to(dev)
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                             sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu,
+                                             group=dist.group.WORLD, row_offset=0)
+        assert np.array_equal(idx.cpu().numpy(), z["idx"])
+        np.testing.assert_allclose(w.cpu().numpy(), z["w"], rtol=W_RTOL)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------- #
+# BASELINE.json configs 3 and 5 (non-RBF kernels) against the oracle at / near full size
+# --------------------------------------------------------------------------- #
+def _vs_oracle(kind, mode, N, M, d, b, n_obs, seed, dev, bit_p=0.04, ard=True):
+    from tests.golden.synth import synth, build_spec
+    case = dict(kind=kind, mode=mode, N=N, M=M, d=d, b=b, n_obs=n_obs, seed=seed, ard=ard, bit_p=bit_p,
+                mean_const=0.4)
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    mu_ref = _t(inp["mu0"].copy())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(SEED_CALL)
+        idx_ref, w_ref = O.recombination(_t(inp["X_cand"]), _t(inp["X_nys"]), b, O.Kernel(spec, mode),
+                                         init_weights=mu_ref)
+        mu = _t(inp["mu0"].copy()).to(dev)
+        torch.manual_seed(SEED_CALL)
+        idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), b,
+                                         sober_amd.Kernel(kspec(spec), mode), init_weights=mu)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref.numpy())
+    np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=W_RTOL)
+    np.testing.assert_allclose(mu.cpu().numpy(), mu_ref.numpy(), rtol=W_RTOL, atol=0)
+    assert abs(float(w.sum()) - 1.0) < 1e-12 and len(w) <= b
+
+
+def test_cfg3_matern_full_size_vs_oracle(dev):
+    """Hartmann-shaped: d=6, Matern-5/2, N_rec=50k, N_nys=500, batch=200 (batch > 100: the
+    Caratheodory steps take the LAPACK route)."""
+    _vs_oracle(O.MATERN52, "predictive_covariance", 50000, 500, 6, 200, 200, 3, dev)
+
+
+def test_cfg5_tanimoto_weighted_vs_oracle(dev):
+    """Malaria-shaped: 2048-bit fingerprints (4 % set), weighted Tanimoto posterior covariance,
+    batch=100; N reduced to 20k so that the oracle's FP64 0/1 matrices stay small."""
+    _vs_oracle(O.TANIMOTO, "weighted_predictive_covariance", 20000, 300, 2048, 100, 150, 10, dev)
+
+
+def test_cfg4_rbf_d20_vs_oracle(dev):
+    """Rosenbrock-shaped d=20 RBF (the 8-GPU config's kernel shape) on one GPU at N=60k."""
+    _vs_oracle(O.RBF, "predictive_covariance", 60000, 400, 20, 100, 150, 4, dev, ard=False)
