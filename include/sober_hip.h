@@ -168,6 +168,22 @@ int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in
                      int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
                      double* phi_out, void* stream);
 
+/* Dense FP64 Cholesky in one persistent workgroup (n <= sober_chol_max_n()): the lower triangle of A
+ * (n x n row-major, ld) is overwritten by L with (A + shift I) = L L^T; *info = 0 on success, j+1 when
+ * the leading minor of order j+1 is not positive definite (LAPACK dpotrf convention); *min_pivot (may
+ * be NULL) = smallest pivot.  Replaces the `torch.linalg.cholesky` probes of is_psd / make_cov_psd,
+ * SOBER/_utils.py:117-157 (the "Nystrom Cholesky"), and is the core of the CholeskyQR used for the
+ * range finder of torch.svd_lowrank (SOBER/_rchq.py:37).                                           */
+int sober_chol_max_n(void);
+int sober_cholesky(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, void* stream);
+/* Q[r, 0:q] = Y[r, 0:q] R^-1 with R = L^T (L lower triangular q x q, q <= 128): the Q factor of Y when
+ * L L^T = Y^T Y.                                                                                    */
+int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
+                    double* Q, int ldq, void* stream);
+/* out = sqrt(nan_to_num(C) * nan_to_num(C)^T) elementwise (quirk Q2, SOBER/_utils.py:143-144);
+ * flag[0] |= 1 when C is not exactly symmetric (:127).  Zero flag first.                            */
+int sober_abs_sym(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, void* stream);
+
 /* KMeans of SOBER/_weights.py:100-126: Lloyd, centroids initialised to the first K rows, exactly
  * `iters` iterations, first-index argmin (a NaN distance wins like torch.argmin), empty cluster ->
  * NaN centroid.  X is (N, d) row-major raw points.  labels: N int32.  ws: sober_kmeans_ws_bytes.  */

@@ -175,6 +175,7 @@ class RecombinationEngine:
         self.trace = None                      # set to a dict to record per-level data (tests)
         self.timers = {}                       # phase -> seconds (host wall clock, accumulated)
         self.force_host_car = False            # True: LAPACK null space + C++ pivots on the host
+        self.force_host_nystrom = False        # True: make_cov_psd + svd_lowrank entirely on the host
 
     def _tick(self, name, t0):
         t1 = time.perf_counter()
@@ -183,7 +184,21 @@ class RecombinationEngine:
 
     # -- Nystrom basis --------------------------------------------------------
     def nystrom_basis(self, plan, s: int):
+        """-> U (s, M).  Device route when the backend has one (HipOps.nystrom_basis_device); the
+        literal host route (LAPACK) otherwise or when the device route declines."""
         t0 = time.perf_counter()
+        dev_route = getattr(self.ops, "nystrom_basis_device", None)
+        if dev_route is not None and not self.force_host_nystrom:
+            with warnings.catch_warnings():
+                warnings.simplefilter("default")
+                res = dev_route(plan, s, self.tm.max_iter)
+            if res is not None:
+                U, gram = res
+                self._tick("nystrom_device", t0)
+                if self.trace is not None:
+                    (gram_h, U_h) = self.ops.to_host(gram, U)
+                    self.trace.update(gram=gram_h, U=U_h)
+                return U
         gram = self.ops.gram(plan)
         (gram_h,) = self.ops.to_host(gram)
         t0 = self._tick("gram_device", t0)
@@ -204,9 +219,8 @@ class RecombinationEngine:
         n = num_pts - 1
         S = 2 * (n + 1)
         U = self.nystrom_basis(plan, n)
-        if comm.world > 1:
-            U = comm.broadcast0(ops.from_host(U.contiguous())).cpu() if ops.device.type != "cpu" \
-                else comm.broadcast0(U.contiguous())
+        if comm.world > 1:                                  # rank 0's randn draw is the one that counts
+            U = comm.broadcast0(ops.from_host(U.contiguous()) if U.device != ops.device else U.contiguous())
         ops.set_projection(plan, U)
 
         idx_cur, count = ops.nonzero_i32(mu)               # idx_story = arange(N)[mu != 0]  (:63-65)

@@ -46,6 +46,10 @@ SIGNATURES = {
     "sober_car_pivot_host": (_i32, [_vp, _i32, _i32, _vp]),
     "sober_car_supported": (_i32, [_i32, _i32]),
     "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sober_chol_max_n": (_i32, []),
+    "sober_cholesky": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp]),
+    "sober_trsm_rows": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_kmeans_ws_bytes": (_i64, [_i64, _i32, _i32]),
     "sober_kmeans_lloyd": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "sober_reduce_ws_bytes": (_i64, [_i64]),
@@ -255,6 +259,29 @@ def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None):
     _check(load().sober_car_device(X.data_ptr(), X.stride(0), N, n + 1, mu_in.data_ptr(), keep_rank.data_ptr(),
                                    w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
                                    _stream(X)), "sober_car_device")
+
+
+def chol_max_n() -> int:
+    return load().sober_chol_max_n()
+
+
+def cholesky(A, shift, info, min_pivot=None):
+    """In place on the lower triangle of the square device matrix A (unit inner stride)."""
+    n = A.shape[0]
+    _check(load().sober_cholesky(A.data_ptr(), n, A.stride(0), float(shift), info.data_ptr(), _ptr(min_pivot),
+                                 _stream(A)), "sober_cholesky")
+
+
+def trsm_rows(Y, L, Q):
+    m, q = Y.shape
+    _check(load().sober_trsm_rows(Y.data_ptr(), m, q, Y.stride(0), L.data_ptr(), L.stride(0), Q.data_ptr(),
+                                  Q.stride(0), _stream(Y)), "sober_trsm_rows")
+
+
+def abs_sym(C_, out, flag):
+    n = C_.shape[0]
+    _check(load().sober_abs_sym(C_.data_ptr(), n, C_.stride(0), out.data_ptr(), out.stride(0), flag.data_ptr(),
+                                _stream(C_)), "sober_abs_sym")
 
 
 def kmeans_lloyd(X, K, iters, centroids, labels):

@@ -102,6 +102,105 @@ class HipOps:
         nat.dgemm(P1.contiguous(), p.T, P[:, p.M:], alpha=-1.0)
         p.P = P
 
+    # ------------------------------------------------------------------ Nystrom basis on the device
+    def nystrom_basis_device(self, p: Plan, s: int, max_iter: int = 10):
+        """ker_svd_sparsify (SOBER/_rchq.py:34-39) with the N_nys x N_nys work on the GPU:
+          make_cov_psd: |cov| and the symmetry test in one kernel; the jitter rung is found by bisection
+                        with the one-workgroup Cholesky (PD-ness is monotone in the shift), then the
+                        reference's own sequence of diagonal additions is applied;
+          svd_lowrank : randn from the CPU generator (same draw as the reference); range finder with
+                        MFMA GEMMs + CholeskyQR2; only the q x M matrix B goes to the host for LAPACK's
+                        SVD (2 ms), U = Q U_B back on the device.
+        Returns (U (s, M) on the device, the Gram matrix) or None when the literal host path must decide
+        (exactly symmetric Gram, sizes beyond the kernels, ill-conditioned range finder)."""
+        import warnings
+        dev, M = self.device, p.M
+        G = self.gram(p)
+        if M > nat.chol_max_n() or s > 128 or s >= M:
+            return None
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        C = torch.empty_like(G)
+        nat.abs_sym(G, C, flag)
+        if int(flag.item()) == 0:
+            return None                                    # symmetric input: is_psd(cov) itself has to run
+        warnings.warn("Estimated covariance matrix was not positive semi-definite. Conveting...")
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        W = torch.empty_like(C)
+
+        def pd(k):                                         # is_psd(cov after k jitter additions)?
+            W.copy_(C)
+            nat.cholesky(W, 1e-5 * (2 ** k - 1), info)
+            return int(info.item()) == 0
+
+        if pd(0):
+            k_first = 0
+        elif not pd(max_iter):
+            k_first = max_iter + 1
+        else:
+            lo, hi = 0, max_iter                           # pd(lo) False, pd(hi) True
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                if pd(mid):
+                    hi = mid
+                else:
+                    lo = mid
+            k_first = hi
+        diag = C.diagonal()
+        jitter = torch.full((M,), 1e-5, dtype=torch.float64, device=dev)
+        for _ in range(k_first):                           # SOBER/_utils.py:151-152, one rung at a time
+            diag += jitter
+            jitter *= 2
+        if k_first > max_iter:
+            C = torch.diag(C.diagonal().clone())           # :155
+        U = self._svd_lowrank_device(C, s)
+        if U is None:
+            return None
+        return U, G
+
+    def _orth(self, Y, infos, pivs, slot):
+        """CholeskyQR2: orthonormal basis of range(Y) with the flag of Householder QR."""
+        q = Y.shape[1]
+        for it in range(2):
+            Gm = torch.empty(q, q, dtype=torch.float64, device=self.device)
+            nat.dgemm(Y, Y, Gm, transa=True)
+            nat.cholesky(Gm, 0.0, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1])
+            Q = torch.empty_like(Y)
+            nat.trsm_rows(Y, Gm, Q)
+            Y = Q
+        return Y
+
+    def _svd_lowrank_device(self, A, q, niter: int = 2):
+        """torch.svd_lowrank(A, q) (Halko et al. Alg. 4.4 / 5.1, as in torch/_lowrank.py) for a square
+        device matrix; returns -U^T (q, M) like SOBER/_rchq.py:38, or None if CholeskyQR lost rank."""
+        from ._engine import host_lapack_threads
+        dev, M = self.device, A.shape[0]
+        R = torch.randn(M, q, dtype=torch.float64).to(dev)          # CPU generator: the reference's draw
+        n_orth = 1 + 2 * niter
+        infos = torch.zeros(2 * n_orth, dtype=torch.int32, device=dev)
+        pivs = torch.zeros(2 * n_orth, dtype=torch.float64, device=dev)
+        Y = torch.empty(M, q, dtype=torch.float64, device=dev)
+        nat.dgemm(A, R, Y)
+        Q = self._orth(Y, infos, pivs, 0)
+        slot = 2
+        for _ in range(niter):
+            nat.dgemm(A, Q, Y, transa=True)                          # A^H Q
+            Q = self._orth(Y, infos, pivs, slot); slot += 2
+            Y = torch.empty(M, q, dtype=torch.float64, device=dev)
+            nat.dgemm(A, Q, Y)
+            Q = self._orth(Y, infos, pivs, slot); slot += 2
+            Y = torch.empty(M, q, dtype=torch.float64, device=dev)
+        B = torch.empty(q, M, dtype=torch.float64, device=dev)
+        nat.dgemm(Q, A, B, transa=True)                              # Q^H A
+        B_h, infos_h, pivs_h = self.to_host(B, infos, pivs)
+        # second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1
+        if bool((infos_h != 0).any()) or float(pivs_h[1::2].min()) < 0.5:
+            return None
+        with host_lapack_threads(M):
+            Ub, _, _ = torch.linalg.svd(B_h, full_matrices=False)
+        U = torch.empty(M, q, dtype=torch.float64, device=dev)
+        nat.dgemm(Q, self.from_host(Ub.contiguous()), U)
+        return (-1 * U.T).contiguous()
+
     # ------------------------------------------------------------------ levels
     def _prof_begin(self):
         if self.prof is None:

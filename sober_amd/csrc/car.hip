@@ -123,6 +123,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 
     // ---------------- load A = [1 | X]^T ----------------
     for (int j = tid; j < N; j += CAR_T) A[j] = 1.0;
+    for (int j = tid; j < CAR_PAD; j += CAR_T) A[(size_t)m * N + j] = 0.0;   // over-reads hit zeros, never stale NaNs
     for (int t = tid; t < (m - 1) * N; t += CAR_T) {
         const int j = t / (m - 1), i = t % (m - 1);       // X[j][i], coalesced over i
         A[(size_t)(i + 1) * N + j] = X[(size_t)j * ldx + i];

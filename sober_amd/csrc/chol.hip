@@ -1,0 +1,224 @@
+// Dense FP64 Cholesky for the Nystrom side of the path, as ONE persistent workgroup (blocked,
+// right-looking; panel in LDS, trailing update register-tiled), plus the row-wise triangular solve
+// that turns it into a QR factorisation (CholeskyQR).
+//
+//  * SOBER/_utils.py:117-157 (is_psd / make_cov_psd) probes `torch.linalg.cholesky(cov + jitter I)` on
+//    the N_nys x N_nys Gram up to 12 times; only success/failure is used.  k_chol answers that on
+//    the device (info = 0: positive definite; info = j+1: the leading minor of order j+1 is not).
+//  * torch.svd_lowrank (SOBER/_rchq.py:37) orthonormalises five M x q blocks with Householder QR; an
+//    orthonormal basis of the same flag of subspaces comes from Q = Y R^-1 with R^T R = Y^T Y
+//    (applied twice for orthogonality to rounding); Q differs from LAPACK's only by column signs,
+//    which cancel in U = Q U_B.
+#include "common.hpp"
+
+namespace sober {
+
+constexpr int CH_NB = 32;            // panel width
+constexpr int CH_T = 1024;
+constexpr int CH_MAXN = 608;         // panel (n - NB) x NB doubles + diagonal block must fit in 160 KiB LDS
+
+// A (n x n, row-major, ld) is overwritten by L in its lower triangle (upper triangle untouched).
+// shift is added to the diagonal on the fly (the jitter rung), so the caller's matrix can be probed
+// at several rungs from a scratch copy.
+__global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, int ld, double shift,
+                                              int32_t* __restrict__ info, double* __restrict__ min_pivot) {
+    extern __shared__ double lds[];
+    double* D = lds;                         // NB x (NB+1)
+    double* P = lds + CH_NB * (CH_NB + 1);   // (n - kb - nb) x (NB+1) panel, padded against bank conflicts
+    __shared__ int s_fail;
+    __shared__ double s_minp;
+    const int tid = threadIdx.x;
+    constexpr int LDP = CH_NB + 1;
+    if (tid == 0) { s_fail = 0; s_minp = __builtin_inf(); }
+    __syncthreads();
+
+    for (int kb = 0; kb < n; kb += CH_NB) {
+        const int nb = min(CH_NB, n - kb);
+        const int nr = n - kb - nb;                       // rows below the diagonal block
+        // ---- diagonal block -> LDS (lower part), + shift
+        for (int t = tid; t < nb * nb; t += CH_T) {
+            const int i = t / nb, j = t % nb;
+            double v = (j <= i) ? A[(size_t)(kb + i) * ld + kb + j] : 0.0;
+            if (i == j) v += shift;
+            D[i * LDP + j] = v;
+        }
+        __syncthreads();
+        // ---- unblocked Cholesky of D by the first wave (nb <= 32: lane = row)
+        if (tid < 64) {
+            const int i = tid;
+            for (int j = 0; j < nb; ++j) {
+                const double djj = D[j * LDP + j];
+                if (!(djj > 0.0)) {                       // also catches NaN
+                    if (i == 0) s_fail = kb + j + 1;
+                    break;
+                }
+                const double l = sqrt(djj);
+                if (i == 0) s_minp = fmin(s_minp, djj);
+                if (i == j) D[j * LDP + j] = l;
+                if (i > j && i < nb) D[i * LDP + j] /= l;
+                // (single wave: LDS ops are in program order, no barrier needed)
+                if (i > j && i < nb) {
+                    const double lij = D[i * LDP + j];
+                    for (int c = j + 1; c <= i; ++c) D[i * LDP + c] = fma(-lij, D[c * LDP + j], D[i * LDP + c]);
+                }
+            }
+        }
+        __syncthreads();
+        if (s_fail != 0) break;                            // uniform
+        // ---- write L_kk back
+        for (int t = tid; t < nb * nb; t += CH_T) {
+            const int i = t / nb, j = t % nb;
+            if (j <= i) A[(size_t)(kb + i) * ld + kb + j] = D[i * LDP + j];
+        }
+        if (nr == 0) break;
+        // ---- panel: rows below solve x L_kk^T = a  (one row per thread), kept in LDS
+        for (int r = tid; r < nr; r += CH_T) {
+            double x[CH_NB];
+            const double* a = A + (size_t)(kb + nb + r) * ld + kb;
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) x[j] = (j < nb) ? a[j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) {
+                if (j < nb) {
+                    double s = x[j];
+#pragma unroll
+                    for (int k = 0; k < CH_NB; ++k)
+                        if (k < j) s = fma(-x[k], D[j * LDP + k], s);
+                    x[j] = s / D[j * LDP + j];
+                }
+            }
+            double* o = A + (size_t)(kb + nb + r) * ld + kb;
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) {
+                if (j < nb) o[j] = x[j];
+                P[r * LDP + j] = x[j];
+            }
+        }
+        __syncthreads();
+        // ---- trailing update (lower triangle): A[r][c] -= P[r] . P[c], 4x4 register tiles
+        const int nt = (nr + 3) / 4;                       // tiles per side
+        const int ntri = nt * (nt + 1) / 2;
+        for (int t = tid; t < ntri; t += CH_T) {
+            // (tr, tc) with tc <= tr from the linear index
+            int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+            while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+            while (tr * (tr + 1) / 2 > t) --tr;
+            const int tc = t - tr * (tr + 1) / 2;
+            double acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+            const int r0 = tr * 4, c0 = tc * 4;
+            for (int k = 0; k < nb; ++k) {
+                double pr[4], pc[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    pr[a] = P[min(r0 + a, nr - 1) * LDP + k];
+                    pc[a] = P[min(c0 + a, nr - 1) * LDP + k];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = fma(pr[a], pc[b], acc[a][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int r = r0 + a, c = c0 + b;
+                    if (r < nr && c <= r) A[(size_t)(kb + nb + r) * ld + kb + nb + c] -= acc[a][b];
+                }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *info = s_fail;
+        if (min_pivot) *min_pivot = s_minp;
+    }
+}
+
+// Q[r, :] = Y[r, :] R^-1 with R = L^T (L lower, q x q): forward substitution per row, L in LDS.
+__global__ __launch_bounds__(256) void k_trsm_rows(const double* __restrict__ Y, int64_t m, int q, int ldy,
+                                                   const double* __restrict__ L, int ldl,
+                                                   double* __restrict__ Q, int ldq) {
+    extern __shared__ double sl[];                   // q x (q+1)
+    const int LDL = q + 1;
+    for (int t = threadIdx.x; t < q * q; t += blockDim.x) {
+        const int i = t / q, j = t % q;
+        sl[i * LDL + j] = (j <= i) ? L[(size_t)i * ldl + j] : 0.0;
+    }
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const double* y = Y + r * ldy;
+    double* o = Q + r * ldq;
+    // x R = y  <=>  x_j = (y_j - sum_{k<j} x_k L[j][k]) / L[j][j]; x kept in the output row
+    for (int j = 0; j < q; ++j) {
+        double s = y[j];
+        for (int k = 0; k < j; ++k) s = fma(-o[k], sl[j * LDL + k], s);
+        o[j] = s / sl[j * LDL + j];
+    }
+}
+
+// cov -> sqrt(nan_to_num(cov) * nan_to_num(cov).T) (SOBER/_utils.py:143-144) and the exact-symmetry
+// test of :127 on the input: flag[0] |= 1 if some cov[i][j] != cov[j][i].
+__global__ void k_abs_sym(const double* __restrict__ C, int n, int ld, double* __restrict__ out, int ldo,
+                          int32_t* __restrict__ flag) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n) return;
+    double a = C[(size_t)i * ld + j], b = C[(size_t)j * ld + i];
+    if (!(a == b)) atomicOr(flag, 1);
+    const double big = 1.7976931348623157e308;
+    a = (a != a) ? 0.0 : fmin(fmax(a, -big), big);            // torch.nan_to_num
+    b = (b != b) ? 0.0 : fmin(fmax(b, -big), big);
+    out[(size_t)i * ldo + j] = sqrt(a * b);
+}
+
+}  // namespace sober
+
+extern "C" int sober_chol_max_n(void) { return sober::CH_MAXN; }
+
+extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
+                              void* stream) {
+    if (!A || !info || n <= 0 || ld < n) return SOBER_E_ARG;
+    if (n > sober::CH_MAXN) return SOBER_E_DIM;
+    const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
+    const size_t bytes = ((size_t)sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * (sober::CH_NB + 1)) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 64));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sober::k_chol, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift, info,
+                       min_pivot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl, double* Q,
+                               int ldq, void* stream) {
+    if (!Y || !L || !Q || m <= 0 || q <= 0 || q > 128 || ldy < q || ldl < q || ldq < q) return SOBER_E_ARG;
+    const size_t bytes = (size_t)q * (q + 1) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_trsm_rows, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    140 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sober::k_trsm_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), bytes, (hipStream_t)stream, Y,
+                       m, q, ldy, L, ldl, Q, ldq);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_abs_sym(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, void* stream) {
+    if (!C || !out || !flag || n <= 0 || ld < n || ldo < n || n > 65535) return SOBER_E_ARG;
+    hipLaunchKernelGGL(sober::k_abs_sym, dim3((n + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, C, n, ld, out,
+                       ldo, flag);
+    LAUNCH_CHECK();
+    return 0;
+}

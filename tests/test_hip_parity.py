@@ -71,7 +71,11 @@ def test_recombination_vs_golden(path, dev):
     for i, lv in enumerate(trace["levels"]):
         assert np.array_equal(lv["idx_star"].numpy(), z[f"L{i}_idx_star"]), i
         np.testing.assert_allclose(lv["tot_weights"].numpy(), z[f"L{i}_tot_weights"], rtol=W_RTOL)
-        np.testing.assert_allclose(lv["X_tmp"].numpy(), z[f"L{i}_X_tmp"], rtol=1e-6, atol=1e-10)
+        # the Nystrom test functions are defined up to sign (rows of U; the device range finder's Q has
+        # other column signs than Householder's) -- the Caratheodory step is invariant to it
+        X, Xg = lv["X_tmp"].numpy(), z[f"L{i}_X_tmp"]
+        sgn = np.sign(np.sum(X * Xg, axis=0, keepdims=True))
+        np.testing.assert_allclose(X * sgn, Xg, rtol=1e-6, atol=1e-10)
 
 
 def test_recombination_vs_oracle_same_inputs(dev):
@@ -424,3 +428,87 @@ def test_cfg5_tanimoto_weighted_vs_oracle(dev):
 def test_cfg4_rbf_d20_vs_oracle(dev):
     """Rosenbrock-shaped d=20 RBF (the 8-GPU config's kernel shape) on one GPU at N=60k."""
     _vs_oracle(O.RBF, "predictive_covariance", 60000, 400, 20, 100, 150, 4, dev, ard=False)
+
+
+# --------------------------------------------------------------------------- #
+# Nystrom side on the device: Cholesky, CholeskyQR, |cov|
+# --------------------------------------------------------------------------- #
+def test_cholesky_kernel(dev):
+    from sober_amd import _native as nat
+    rng = np.random.default_rng(21)
+    for n in (5, 32, 33, 99, 100, 257, 500, nat.chol_max_n()):
+        A = rng.standard_normal((n, n + 3))
+        S = A @ A.T + 0.5 * np.eye(n)
+        W = _t(S.copy()).to(dev)
+        info = torch.full((1,), 7, dtype=torch.int32, device=dev)
+        piv = torch.zeros(1, dtype=torch.float64, device=dev)
+        nat.cholesky(W, 0.25, info, piv)
+        assert int(info.item()) == 0
+        L = torch.tril(W).cpu().numpy()
+        ref = np.linalg.cholesky(S + 0.25 * np.eye(n))
+        np.testing.assert_allclose(L, ref, rtol=1e-11, atol=1e-12)
+        assert abs(float(piv.item()) - float((np.diag(ref) ** 2).min())) < 1e-9 * float((np.diag(ref) ** 2).max())
+        assert np.array_equal(torch.triu(W, 1).cpu().numpy(), np.triu(S, 1))         # upper part untouched
+    # not positive definite: LAPACK's info convention (leading minor of order info)
+    S = np.eye(40); S[17, 17] = -1.0
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    nat.cholesky(_t(S.copy()).to(dev), 0.0, info)
+    assert int(info.item()) == 18
+    S = np.full((6, 6), np.nan)
+    nat.cholesky(_t(S).to(dev), 0.0, info)
+    assert int(info.item()) == 1
+
+
+def test_choleskyqr_and_abs_sym(dev):
+    from sober_amd import _native as nat
+    from sober_amd._ops_hip import HipOps
+    rng = np.random.default_rng(22)
+    Y = rng.standard_normal((500, 99)) @ np.diag(np.logspace(0, -4, 99))              # cond 1e4
+    ops = HipOps(dev)
+    infos = torch.zeros(2, dtype=torch.int32, device=dev); pivs = torch.zeros(2, dtype=torch.float64, device=dev)
+    Q = ops._orth(_t(Y).to(dev), infos, pivs, 0).cpu().numpy()
+    assert int(infos.abs().sum()) == 0
+    np.testing.assert_allclose(Q.T @ Q, np.eye(99), atol=1e-13)
+    Qh = np.linalg.qr(Y)[0]                                                           # Householder reference
+    sign = np.sign(np.sum(Q * Qh, axis=0))
+    np.testing.assert_allclose(Q * sign, Qh, atol=1e-9)                               # same flag of subspaces
+    C = rng.standard_normal((50, 50)); C[3, 4] = np.nan; C[7, 7] = np.inf
+    out = torch.empty(50, 50, dtype=torch.float64, device=dev); flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    nat.abs_sym(_t(C).to(dev), out, flag)
+    with np.errstate(invalid="ignore"):
+        c = np.nan_to_num(C)
+        ref = np.sqrt(c * c.T)
+    np.testing.assert_array_equal(np.isnan(out.cpu().numpy()), np.isnan(ref))
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-15, equal_nan=True)
+    assert int(flag.item()) == 1
+    Cs = C + C.T; Cs = np.nan_to_num(Cs)
+    flag.zero_(); nat.abs_sym(_t(Cs).to(dev), out, flag)
+    assert int(flag.item()) == 0
+
+
+def test_device_and_host_nystrom_agree(dev):
+    """The device route (Cholesky bisection + CholeskyQR range finder) and the literal LAPACK route
+    give the same basis up to row signs and the same recombination."""
+    from sober_amd._engine import RecombinationEngine
+    for name in ("cfg1_rbf_ard", "rbf_b30", "matern_b20", "tanimoto_weighted", "rbf_medium"):
+        path = os.path.join(GOLD, f"recomb_{name}.npz")
+        outs = []
+        for force_host in (False, True):
+            old = RecombinationEngine.__init__
+
+            def patched(self, *a, _old=old, **k):
+                _old(self, *a, **k)
+                self.force_host_nystrom = force_host
+            RecombinationEngine.__init__ = patched
+            try:
+                tr = {}
+                outs.append(run_hip(path, dev, tr) + (tr,))
+            finally:
+                RecombinationEngine.__init__ = old
+        (_, _, z, i1, w1, _, t1), (_, _, _, i2, w2, _, t2) = outs
+        U1, U2 = t1["U"].numpy(), t2["U"].numpy()
+        sgn = np.sign(np.sum(U1 * U2, axis=1, keepdims=True))
+        assert np.abs(U1 * sgn - U2).max() < 1e-7, name
+        assert torch.equal(i1, i2), name
+        np.testing.assert_allclose(w1.cpu().numpy(), w2.cpu().numpy(), rtol=W_RTOL)
+        assert np.array_equal(i1.cpu().numpy(), z["idx"]), name
