@@ -139,6 +139,68 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
     }
 }
 
+// Small SPD matrix (q <= 128) entirely in LDS: unblocked right-looking Cholesky with the whole
+// workgroup, then L^-1 by forward substitution on the identity (one thread per column).  Writes
+// Rinv = (L^-1)^T = R^-1 (q x q, upper triangular, row-major) so that Q = Y Rinv is one GEMM.
+__global__ __launch_bounds__(1024) void k_chol_small_inv(const double* __restrict__ G, int q, int ldg,
+                                                         double* __restrict__ Rinv, int ldr,
+                                                         int32_t* __restrict__ info,
+                                                         double* __restrict__ min_pivot) {
+    extern __shared__ double sm[];
+    const int LDS_ = q + 1;
+    double* L = sm;                      // q x (q+1)
+    double* X = sm + (size_t)q * LDS_;   // q x (q+1): L^-1
+    __shared__ int s_fail;
+    __shared__ double s_minp;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) { s_fail = 0; s_minp = __builtin_inf(); }
+    for (int t = tid; t < q * q; t += nt) {
+        const int i = t / q, j = t % q;
+        L[i * LDS_ + j] = (j <= i) ? G[(size_t)i * ldg + j] : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < q; ++j) {
+        const double djj = L[j * LDS_ + j];
+        if (!(djj > 0.0)) {
+            if (tid == 0) s_fail = j + 1;
+            break;                                            // uniform: every thread read the same value
+        }
+        const double l = sqrt(djj);
+        __syncthreads();                                      // everyone has read d_jj before it changes
+        if (tid == 0) { L[j * LDS_ + j] = l; s_minp = fmin(s_minp, djj); }
+        for (int i = j + 1 + tid; i < q; i += nt) L[i * LDS_ + j] /= l;
+        __syncthreads();
+        // trailing update, lower triangle: element (i, c), j < c <= i
+        const int nrem = q - j - 1;
+        for (int t = tid; t < nrem * nrem; t += nt) {
+            const int i = j + 1 + t / nrem, c = j + 1 + t % nrem;
+            if (c <= i) L[i * LDS_ + c] = fma(-L[i * LDS_ + j], L[c * LDS_ + j], L[i * LDS_ + c]);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_fail == 0) {
+        // X = L^-1: column c by forward substitution; X[i][c] = (delta_ic - sum_{k<i} L[i][k] X[k][c]) / L[i][i]
+        for (int c = tid; c < q; c += nt) {
+            for (int i = 0; i < q; ++i) {
+                double sacc = (i == c) ? 1.0 : 0.0;
+                if (i > c)
+                    for (int k = c; k < i; ++k) sacc = fma(-L[i * LDS_ + k], X[k * LDS_ + c], sacc);
+                X[i * LDS_ + c] = (i >= c) ? sacc / L[i * LDS_ + i] : 0.0;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < q * q; t += nt) {
+            const int i = t / q, j = t % q;
+            Rinv[(size_t)i * ldr + j] = X[j * LDS_ + i];       // transpose: R^-1 = (L^-1)^T
+        }
+    }
+    if (tid == 0) {
+        *info = s_fail;
+        if (min_pivot) *min_pivot = s_minp;
+    }
+}
+
 // Q[r, :] = Y[r, :] R^-1 with R = L^T (L lower, q x q): forward substitution per row, L in LDS.
 __global__ __launch_bounds__(256) void k_trsm_rows(const double* __restrict__ Y, int64_t m, int q, int ldy,
                                                    const double* __restrict__ L, int ldl,
@@ -195,6 +257,22 @@ extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* i
     }
     hipLaunchKernelGGL(sober::k_chol, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift, info,
                        min_pivot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_chol_small_inv(const double* G, int q, int ldg, double* Rinv, int ldr, int32_t* info,
+                                    double* min_pivot, void* stream) {
+    if (!G || !Rinv || !info || q <= 0 || q > 128 || ldg < q || ldr < q) return SOBER_E_ARG;
+    const size_t bytes = 2 * (size_t)q * (q + 1) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol_small_inv, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 64));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sober::k_chol_small_inv, dim3(1), dim3(1024), bytes, (hipStream_t)stream, G, q, ldg, Rinv, ldr,
+                       info, min_pivot);
     LAUNCH_CHECK();
     return 0;
 }
