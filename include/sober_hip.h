@@ -176,10 +176,10 @@ int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in
  * range finder of torch.svd_lowrank (SOBER/_rchq.py:37).                                           */
 int sober_chol_max_n(void);
 int sober_cholesky(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, void* stream);
-/* Small SPD G (q <= 128): Cholesky G = L L^T entirely in LDS and Rinv = (L^T)^-1 (q x q, upper
- * triangular), so that the CholeskyQR factor is one GEMM: Q = Y Rinv.  info / min_pivot as above.     */
-int sober_chol_small_inv(const double* G, int q, int ldg, double* Rinv, int ldr, int32_t* info,
-                         double* min_pivot, void* stream);
+/* Small SPD G (q <= 128): Cholesky G = L L^T entirely in LDS; Lout receives L (q x q lower
+ * triangular, zeros above).  info / min_pivot as above.                                              */
+int sober_chol_small(const double* G, int q, int ldg, double* Lout, int ldl, int32_t* info,
+                     double* min_pivot, void* stream);
 /* Q[r, 0:q] = Y[r, 0:q] R^-1 with R = L^T (L lower triangular q x q, q <= 128): the Q factor of Y when
  * L L^T = Y^T Y.                                                                                    */
 int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,

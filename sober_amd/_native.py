@@ -48,7 +48,7 @@ SIGNATURES = {
     "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sober_chol_max_n": (_i32, []),
     "sober_cholesky": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp]),
-    "sober_chol_small_inv": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "sober_chol_small": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_trsm_rows": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_kmeans_ws_bytes": (_i64, [_i64, _i32, _i32]),
@@ -273,10 +273,10 @@ def cholesky(A, shift, info, min_pivot=None):
                                  _stream(A)), "sober_cholesky")
 
 
-def chol_small_inv(G, Rinv, info, min_pivot=None):
+def chol_small(G, Rinv, info, min_pivot=None):
     q = G.shape[0]
-    _check(load().sober_chol_small_inv(G.data_ptr(), q, G.stride(0), Rinv.data_ptr(), Rinv.stride(0),
-                                       info.data_ptr(), _ptr(min_pivot), _stream(G)), "sober_chol_small_inv")
+    _check(load().sober_chol_small(G.data_ptr(), q, G.stride(0), Rinv.data_ptr(), Rinv.stride(0),
+                                       info.data_ptr(), _ptr(min_pivot), _stream(G)), "sober_chol_small")
 
 
 def trsm_rows(Y, L, Q):

@@ -163,10 +163,10 @@ class HipOps:
         for it in range(2):
             Gm = torch.empty(q, q, dtype=torch.float64, device=self.device)
             nat.dgemm(Y, Y, Gm, transa=True)
-            Rinv = torch.zeros(q, q, dtype=torch.float64, device=self.device)
-            nat.chol_small_inv(Gm, Rinv, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1])
+            Lc = torch.zeros(q, q, dtype=torch.float64, device=self.device)
+            nat.chol_small(Gm, Lc, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1])
             Q = torch.empty_like(Y)
-            nat.dgemm(Y, Rinv, Q)                               # Q = Y R^-1 on the matrix cores
+            nat.trsm_rows(Y, Lc, Q)                             # Q = Y R^-1, one wave per row
             Y = Q
         return Y
 

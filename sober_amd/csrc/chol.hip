@@ -140,16 +140,14 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
 }
 
 // Small SPD matrix (q <= 128) entirely in LDS: unblocked right-looking Cholesky with the whole
-// workgroup, then L^-1 by forward substitution on the identity (one thread per column).  Writes
-// Rinv = (L^-1)^T = R^-1 (q x q, upper triangular, row-major) so that Q = Y Rinv is one GEMM.
-__global__ __launch_bounds__(1024) void k_chol_small_inv(const double* __restrict__ G, int q, int ldg,
+// workgroup; writes L (q x q lower triangular, row-major).
+__global__ __launch_bounds__(1024) void k_chol_small(const double* __restrict__ G, int q, int ldg,
                                                          double* __restrict__ Rinv, int ldr,
                                                          int32_t* __restrict__ info,
                                                          double* __restrict__ min_pivot) {
     extern __shared__ double sm[];
     const int LDS_ = q + 1;
     double* L = sm;                      // q x (q+1)
-    double* X = sm + (size_t)q * LDS_;   // q x (q+1): L^-1
     __shared__ int s_fail;
     __shared__ double s_minp;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -180,19 +178,9 @@ __global__ __launch_bounds__(1024) void k_chol_small_inv(const double* __restric
     }
     __syncthreads();
     if (s_fail == 0) {
-        // X = L^-1: column c by forward substitution; X[i][c] = (delta_ic - sum_{k<i} L[i][k] X[k][c]) / L[i][i]
-        for (int c = tid; c < q; c += nt) {
-            for (int i = 0; i < q; ++i) {
-                double sacc = (i == c) ? 1.0 : 0.0;
-                if (i > c)
-                    for (int k = c; k < i; ++k) sacc = fma(-L[i * LDS_ + k], X[k * LDS_ + c], sacc);
-                X[i * LDS_ + c] = (i >= c) ? sacc / L[i * LDS_ + i] : 0.0;
-            }
-        }
-        __syncthreads();
         for (int t = tid; t < q * q; t += nt) {
             const int i = t / q, j = t % q;
-            Rinv[(size_t)i * ldr + j] = X[j * LDS_ + i];       // transpose: R^-1 = (L^-1)^T
+            Rinv[(size_t)i * ldr + j] = (j <= i) ? L[i * LDS_ + j] : 0.0;      // output: L (lower triangular)
         }
     }
     if (tid == 0) {
@@ -201,7 +189,28 @@ __global__ __launch_bounds__(1024) void k_chol_small_inv(const double* __restric
     }
 }
 
-// Q[r, :] = Y[r, :] R^-1 with R = L^T (L lower, q x q): forward substitution per row, L in LDS.
+// Q[r, :] = Y[r, :] R^-1 with R = L^T (L lower, q x q <= 128): ONE WAVE PER ROW.  Forward substitution
+// x_j = (y_j - sum_{k<j} x_k L[j][k]) / L[j][j]; lane l holds x_l and x_{l+64}, the dot product over k is
+// split across the lanes and reduced with DPP; L is staged in LDS once per workgroup.
+__device__ __forceinline__ double trsm_wsum(double v) {
+    int lo, hi;
+#define TS_DPP(CTRL)                                                                   \
+    lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);     \
+    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);     \
+    v += __hiloint2double(hi, lo);
+    TS_DPP(0x128) TS_DPP(0x124) TS_DPP(0x122) TS_DPP(0x121)                            // row_ror 8,4,2,1
+#undef TS_DPP
+    const double a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
+                                      __builtin_amdgcn_readlane(__double2loint(v), 0));
+    const double b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
+                                      __builtin_amdgcn_readlane(__double2loint(v), 16));
+    const double c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32),
+                                      __builtin_amdgcn_readlane(__double2loint(v), 32));
+    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48),
+                                      __builtin_amdgcn_readlane(__double2loint(v), 48));
+    return ((a + b) + c) + d;
+}
+
 __global__ __launch_bounds__(256) void k_trsm_rows(const double* __restrict__ Y, int64_t m, int q, int ldy,
                                                    const double* __restrict__ L, int ldl,
                                                    double* __restrict__ Q, int ldq) {
@@ -212,16 +221,28 @@ __global__ __launch_bounds__(256) void k_trsm_rows(const double* __restrict__ Y,
         sl[i * LDL + j] = (j <= i) ? L[(size_t)i * ldl + j] : 0.0;
     }
     __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= m) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= m) return;                              // whole wave
     const double* y = Y + r * ldy;
-    double* o = Q + r * ldq;
-    // x R = y  <=>  x_j = (y_j - sum_{k<j} x_k L[j][k]) / L[j][j]; x kept in the output row
+    double x0 = 0.0, x1 = 0.0;                       // x[lane], x[lane + 64] (0 until solved)
+    const double y0 = (lane < q) ? y[lane] : 0.0;
+    const double y1 = (lane + 64 < q) ? y[lane + 64] : 0.0;
     for (int j = 0; j < q; ++j) {
-        double s = y[j];
-        for (int k = 0; k < j; ++k) s = fma(-o[k], sl[j * LDL + k], s);
-        o[j] = s / sl[j * LDL + j];
+        const double* lj = sl + j * LDL;             // row j of L: zero beyond column j
+        double part = x0 * lj[lane];
+        if (q > 64) part = fma(x1, (lane + 64 < q) ? lj[lane + 64] : 0.0, part);
+        const double dot = trsm_wsum(part);          // unsolved x are 0, L[j][k>j] are 0
+        const double yj = (j < 64) ? __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y0), j & 63),
+                                                      __builtin_amdgcn_readlane(__double2loint(y0), j & 63))
+                                   : __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y1), j & 63),
+                                                      __builtin_amdgcn_readlane(__double2loint(y1), j & 63));
+        const double xj = (yj - dot) / lj[j];
+        if (j < 64) x0 = (lane == j) ? xj : x0; else x1 = (lane + 64 == j) ? xj : x1;
     }
+    double* o = Q + r * ldq;
+    if (lane < q) o[lane] = x0;
+    if (lane + 64 < q) o[lane + 64] = x1;
 }
 
 // cov -> sqrt(nan_to_num(cov) * nan_to_num(cov).T) (SOBER/_utils.py:143-144) and the exact-symmetry
@@ -261,17 +282,17 @@ extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* i
     return 0;
 }
 
-extern "C" int sober_chol_small_inv(const double* G, int q, int ldg, double* Rinv, int ldr, int32_t* info,
+extern "C" int sober_chol_small(const double* G, int q, int ldg, double* Rinv, int ldr, int32_t* info,
                                     double* min_pivot, void* stream) {
     if (!G || !Rinv || !info || q <= 0 || q > 128 || ldg < q || ldr < q) return SOBER_E_ARG;
-    const size_t bytes = 2 * (size_t)q * (q + 1) * sizeof(double);
+    const size_t bytes = (size_t)q * (q + 1) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol_small_inv, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 64));
         attr_set = true;
     }
-    hipLaunchKernelGGL(sober::k_chol_small_inv, dim3(1), dim3(1024), bytes, (hipStream_t)stream, G, q, ldg, Rinv, ldr,
+    hipLaunchKernelGGL(sober::k_chol_small, dim3(1), dim3(1024), bytes, (hipStream_t)stream, G, q, ldg, Rinv, ldr,
                        info, min_pivot);
     LAUNCH_CHECK();
     return 0;
@@ -287,7 +308,7 @@ extern "C" int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const
                                     140 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(sober::k_trsm_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), bytes, (hipStream_t)stream, Y,
+    hipLaunchKernelGGL(sober::k_trsm_rows, dim3((unsigned)((m + 3) / 4)), dim3(256), bytes, (hipStream_t)stream, Y,
                        m, q, ldy, L, ldl, Q, ldq);
     LAUNCH_CHECK();
     return 0;
