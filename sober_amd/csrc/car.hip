@@ -105,7 +105,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     // m x N row-major, then CAR_PAD doubles of slack: the register-tiled sweeps read fixed strides
     // (immediate offsets, no per-element clamping -> no address VGPRs) and mask what lies beyond N
     double* A = lds;
-    double* taup = lds + (size_t)m * N + CAR_PAD;    // m
+    double* taup = lds + (size_t)m * (((size_t)N + 7) & ~(size_t)7) + CAR_PAD;    // m
     double* ubuf = taup + m;               // m  (left reflector of the current step)
     double* scal = ubuf + m;               // [0] tauq  [1] tau
 
@@ -120,13 +120,15 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     const int l16 = lane & 15, rid = lane >> 4;          // lane in DPP row, DPP row in wave
     const int g = l16 >> 1, c2 = l16 & 1;                // row group / column parity inside a DPP row
     const int NC = N - m;
+    const int NS = (N + 7) & ~7;                         // LDS row stride: zero columns N..NS-1 (phase 2 walks 8-strided)
 
     // ---------------- load A = [1 | X]^T ----------------
+    for (int j = tid; j < m * NS + CAR_PAD; j += CAR_T) A[j] = 0.0;   // padding / over-reads hit zeros, never stale NaNs
+    __syncthreads();
     for (int j = tid; j < N; j += CAR_T) A[j] = 1.0;
-    for (int j = tid; j < CAR_PAD; j += CAR_T) A[(size_t)m * N + j] = 0.0;   // over-reads hit zeros, never stale NaNs
     for (int t = tid; t < (m - 1) * N; t += CAR_T) {
         const int j = t / (m - 1), i = t % (m - 1);       // X[j][i], coalesced over i
-        A[(size_t)(i + 1) * N + j] = X[(size_t)j * ldx + i];
+        A[(size_t)(i + 1) * NS + j] = X[(size_t)j * ldx + i];
     }
     __syncthreads();
 
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     //           (C) wave 0 builds H(i) from column i | barrier
     //           (D) all waves apply it to columns > i | barrier
     for (int i = 0; i < m; ++i) {
-        double* rowi = A + (size_t)i * N;
+        double* rowi = A + (size_t)i * NS;
         if (wave == 0) {                                               // (A)
             double vr[4];
             double ss = 0.0;
@@ -155,7 +157,10 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                 const int c = i + 1 + lane + 64 * q;
                 if (c < N) rowi[c] = vr[q] * sc;                       // v_i stays in place like dgebd2
             }
-            if (lane == 0) { rowi[i] = beta; taup[i] = tau; scal[1] = tau; }
+            // phase 2 reads row i as the full reflector vector [0 .. 0, 1, v_i]: materialise it (the
+            // bidiagonal entries and the left reflectors stored left of the diagonal are not needed)
+            if (lane == 0) { rowi[i] = 1.0; taup[i] = tau; scal[1] = tau; }
+            for (int c = lane; c < i; c += 64) rowi[c] = 0.0;
         }
         if (i == m - 1) break;
         __syncthreads();
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                 vreg[q] = (c < N) ? x : 0.0;
             }
             for (int r = i + 1 + wave * 4 + rid; r < m; r += 64) {
-                double* row = A + (size_t)r * N;
+                double* row = A + (size_t)r * NS;
                 double a[CAR_CQ];
                 double w0 = (l16 == 0) ? row[i] : 0.0, w1 = 0.0;
 #pragma unroll
@@ -194,13 +199,13 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int r = i + 2 + lane + 64 * q;
-                const double x = A[(size_t)min(r, m - 1) * N + i];   // 2 clamped loads only
+                const double x = A[(size_t)min(r, m - 1) * NS + i];   // 2 clamped loads only
                 ureg[q] = (r < m) ? x : 0.0;
                 s2 = fma(ureg[q], ureg[q], s2);
             }
             s2 = wave_sum(s2);
             double beta2, tauq, sc2;
-            larfg(A[(size_t)(i + 1) * N + i], s2, beta2, tauq, sc2);
+            larfg(A[(size_t)(i + 1) * NS + i], s2, beta2, tauq, sc2);
             if (lane == 0) { ubuf[0] = 1.0; scal[0] = tauq; }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -215,20 +220,20 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
             const int nk = (L - g + 7) >> 3;                           // my rows: k = g, g+8, ...
             for (int cb = wave; cb * 8 < N - i - 1; cb += 16) {
                 const int c = min(i + 1 + cb * 8 + rid * 2 + c2, N - 1);   // clamped: duplicates are benign
-                double* colp = A + (size_t)(i + 1 + g) * N + c;
+                double* colp = A + (size_t)(i + 1 + g) * NS + c;
                 double av[13];
                 double part = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < 13; ++kk) {
                     if (kk < nk) {
-                        av[kk] = colp[(size_t)kk * 8 * N];
+                        av[kk] = colp[(size_t)kk * 8 * NS];
                         part = fma(ubuf[g + 8 * kk], av[kk], part);
                     }
                 }
                 const double t = tauq * grp8_sum(part);
 #pragma unroll
                 for (int kk = 0; kk < 13; ++kk)
-                    if (kk < nk) colp[(size_t)kk * 8 * N] = fma(-t, ubuf[g + 8 * kk], av[kk]);
+                    if (kk < nk) colp[(size_t)kk * 8 * NS] = fma(-t, ubuf[g + 8 * kk], av[kk]);
             }
         }
         __syncthreads();
@@ -244,28 +249,26 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 #pragma unroll
     for (int k = 0; k < CAR_RP; ++k) phi[k] = (okcol && (g + 8 * k) == m + col) ? 1.0 : 0.0;
     if (wave * 8 < NC) {
+        const int kmax = (N + 7) >> 3;                     // rows g + 8k, k < kmax cover 0 .. N-1 (+ padding)
         for (int i = m - 1; i >= 0; --i) {
-            const double* vi = A + (size_t)i * N;          // v_i in columns i+1.., implicit 1 at column i
+            const double* vi = A + (size_t)i * NS + g;     // row i now holds [0.., 1, v_i, 0 pad]; stride-8 walk
             const double tau = taup[i];
             double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) {
-                const int r = g + 8 * k;
-                const double x = vi[r];                                // unconditional load, then select
-                const double v = (r > i && r < N) ? x : ((r == i) ? 1.0 : 0.0);
-                if ((k & 3) == 0) p0 = fma(v, phi[k], p0);
-                else if ((k & 3) == 1) p1 = fma(v, phi[k], p1);
-                else if ((k & 3) == 2) p2 = fma(v, phi[k], p2);
-                else p3 = fma(v, phi[k], p3);
+                if (k < kmax) {
+                    const double v = vi[8 * k];
+                    if ((k & 3) == 0) p0 = fma(v, phi[k], p0);
+                    else if ((k & 3) == 1) p1 = fma(v, phi[k], p1);
+                    else if ((k & 3) == 2) p2 = fma(v, phi[k], p2);
+                    else p3 = fma(v, phi[k], p3);
+                }
                 if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);   // cap load hoisting: VGPR budget is 128
             }
             const double t = tau * grp8_sum((p0 + p1) + (p2 + p3));
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) {                         // second pass re-reads v_i from LDS:
-                const int r = g + 8 * k;                               // cheaper than 50 more live VGPRs
-                const double x = vi[r];
-                const double v = (r > i && r < N) ? x : ((r == i) ? 1.0 : 0.0);
-                phi[k] = fma(-t, v, phi[k]);
+                if (k < kmax) phi[k] = fma(-t, vi[8 * k], phi[k]);     // cheaper than 50 more live VGPRs
                 if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -279,12 +282,16 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 
     CAR_STAMP();
     // ---------------- phase 3: the pivots of SOBER/_rchq.py:237-266 ----------------
-    // per pivot: wave 15 does the ratio test and the mu update and publishes (piv, alpha) | barrier |
-    //            the column owners eliminate; the owner of the next pivot column publishes it | barrier
-    const int NP = 264;                    // padded stride >= N + 64: fixed-stride over-reads stay in bounds
-    double* colbuf = lds;                  // [2][NP]
+    // One barrier per pivot.  Step s: every column owner eliminates with (piv_s, alpha_s) read from LDS;
+    // the wave that owns pivot column s+1 then, still inside the same step, publishes that column,
+    // applies the mu update of step s (:253-254) and runs the ratio test of step s+1 (:239-247).
+    const int NP = 264;                    // padded stride >= N + 64
+    double* colbuf = lds;                  // [2][NP]   current / next pivot column (zero beyond N)
     double* mubuf = lds + 2 * NP;          // [2][NP]
-    double* pscal = lds + 4 * NP;          // [0] alpha  [1] piv
+    double* pscal = lds + 4 * NP;          // [2][2]    (alpha, piv) of the current / next step
+    const int kmax = (N + 7) >> 3;
+    for (int r = tid; r < 2 * NP; r += CAR_T) colbuf[r] = 0.0;
+    __syncthreads();
     for (int r = tid; r < N; r += CAR_T) mubuf[r] = mu_in[r];
     if (okcol && col == 0) {
 #pragma unroll
@@ -293,57 +300,69 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     }
     __syncthreads();
 
+    // ratio test on (column cp, weights held in mu4): first argmin of mu/Phi over Phi > 0 (NaN wins)
+#define CAR_RATIO_TEST(cp, outp)                                                          \
+    {                                                                                     \
+        double best_ = 0.0; int piv_ = -1;                                                \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                   \
+            const int r = lane + 64 * q;                                                  \
+            const double ph = (cp)[r];                                                    \
+            const bool ok = (r < N) & (ph > 0.0);                                         \
+            amin_take(best_, piv_, mu4[q] / ph, ok ? r : -1);                             \
+        }                                                                                 \
+        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) {                              \
+            const double ob = __shfl_xor(best_, o, 64);                                   \
+            const int op = __shfl_xor(piv_, o, 64);                                       \
+            amin_take(best_, piv_, ob, op);                                               \
+        }                                                                                 \
+        if (lane == 0) { (outp)[0] = best_; (outp)[1] = (double)piv_; }                   \
+    }
+    if (wave == 0) {
+        double mu4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mu4[q] = mubuf[lane + 64 * q];
+        CAR_RATIO_TEST(colbuf, pscal);
+    }
+    __syncthreads();
+
     int cur = 0;
     for (int s = 0; s < NC; ++s, cur ^= 1) {
         const double* cb = colbuf + cur * NP;
-        if (wave == 15) {
-            const double* mb = mubuf + cur * NP;
-            double best = 0.0;
-            int piv = -1;
-            double ph4[4], mu4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = lane + 64 * q;
-                ph4[q] = cb[r];
-                mu4[q] = mb[r];
-                const bool ok = (r < N) & (ph4[q] > 0.0);
-                amin_take(best, piv, mu4[q] / ph4[q], ok ? r : -1);
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o, 64);
-                const int op = __shfl_xor(piv, o, 64);
-                amin_take(best, piv, ob, op);
-            }
-            // mu[:] = mu - alpha * Phi[:,0]; mu[idx] = 0   (two roundings like the tensor expression)
-            if (piv >= 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = lane + 64 * q;
-                    if (r < N) mubuf[(cur ^ 1) * NP + r] = (r == piv) ? 0.0 : __dsub_rn(mu4[q], __dmul_rn(best, ph4[q]));
-                }
-            }
-            if (lane == 0) { pscal[0] = best; pscal[1] = (double)piv; }
-        }
-        __syncthreads();
-        const int piv = (int)pscal[1];
+        const double alpha = pscal[cur * 2];
+        const int piv = (int)pscal[cur * 2 + 1];
         if (piv < 0) break;                                             // Q6 (:241-242), uniform
+        const int kp = piv >> 3, gp = piv & 7;
         if (okcol && col > s) {
             // rank-1 elimination of my column: Phi[:,c] -= Phi[:,0] * (Phi[idx,c] / Phi[idx,0]).  The
             // pivot-row entry of my column sits in the lane with g == piv % 8 of my own DPP row.
-            const double pp = cb[piv];
-            const int kp = piv >> 3, gp = piv & 7;
             double mine = 0.0;
-#pragma unroll
-            for (int k = 0; k < CAR_RP; ++k) mine = (k == kp) ? phi[k] : mine;
+            switch (kp) {                                               // uniform: a scalar jump, no select chain
+#define CAR_CASE(K) case K: mine = phi[K]; break;
+                CAR_CASE(0) CAR_CASE(1) CAR_CASE(2) CAR_CASE(3) CAR_CASE(4) CAR_CASE(5) CAR_CASE(6) CAR_CASE(7)
+                CAR_CASE(8) CAR_CASE(9) CAR_CASE(10) CAR_CASE(11) CAR_CASE(12) CAR_CASE(13) CAR_CASE(14)
+                CAR_CASE(15) CAR_CASE(16) CAR_CASE(17) CAR_CASE(18) CAR_CASE(19) CAR_CASE(20) CAR_CASE(21)
+                CAR_CASE(22) CAR_CASE(23) CAR_CASE(24)
+#undef CAR_CASE
+                default: break;
+            }
             const double prow = __shfl(mine, (lane & 0x30) | (gp << 1) | c2, 64);
-            const double qv = prow / pp;
+            const double qv = prow / cb[piv];
+            const double* cbg = cb + g;
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) {
-                const int r = g + 8 * k;
-                const double x = cb[r];
-                phi[k] = (r == piv || r >= N) ? 0.0 : fma(-qv, x, phi[k]);
+                if (k < kmax) phi[k] = fma(-qv, cbg[8 * k], phi[k]);    // column is zero beyond N
                 if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == gp) {                                              // Phi[idx, :] = 0 (:266), exactly
+                switch (kp) {
+#define CAR_CASE(K) case K: phi[K] = 0.0; break;
+                    CAR_CASE(0) CAR_CASE(1) CAR_CASE(2) CAR_CASE(3) CAR_CASE(4) CAR_CASE(5) CAR_CASE(6) CAR_CASE(7)
+                    CAR_CASE(8) CAR_CASE(9) CAR_CASE(10) CAR_CASE(11) CAR_CASE(12) CAR_CASE(13) CAR_CASE(14)
+                    CAR_CASE(15) CAR_CASE(16) CAR_CASE(17) CAR_CASE(18) CAR_CASE(19) CAR_CASE(20) CAR_CASE(21)
+                    CAR_CASE(22) CAR_CASE(23) CAR_CASE(24)
+#undef CAR_CASE
+                    default: break;
+                }
             }
             if (col == s + 1) {                                        // next pivot column
 #pragma unroll
@@ -351,8 +370,24 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                     if (g + 8 * k < N) colbuf[(cur ^ 1) * NP + g + 8 * k] = phi[k];
             }
         }
+        if (wave == min((s + 1) >> 3, 15)) {
+            // mu[:] = mu - alpha * Phi[:,0]; mu[idx] = 0   (two roundings like the tensor expression)
+            const double* mb = mubuf + cur * NP;
+            double mu4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = lane + 64 * q;
+                mu4[q] = (r == piv) ? 0.0 : __dsub_rn(mb[r], __dmul_rn(alpha, cb[r]));
+                if (r < N) mubuf[(cur ^ 1) * NP + r] = mu4[q];
+            }
+            if (s + 1 < NC) {
+                const double* cn = colbuf + (cur ^ 1) * NP;            // written above by lanes of THIS wave
+                CAR_RATIO_TEST(cn, pscal + (cur ^ 1) * 2);
+            }
+        }
         __syncthreads();
     }
+#undef CAR_RATIO_TEST
 
     CAR_STAMP();
 #ifdef CAR_STAMPS
@@ -382,7 +417,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 }  // namespace sober
 
 extern "C" int sober_car_supported(int N, int m) {
-    return (m >= 2 && N > m && N <= 8 * sober::CAR_RP && N <= 16 * sober::CAR_CQ && (int64_t)m * N <= 20000 && N - m <= 120) ? 1 : 0;
+    return (m >= 2 && N > m && N <= 8 * sober::CAR_RP && N <= 16 * sober::CAR_CQ && (int64_t)m * ((N + 7) & ~7) <= 20000 && N - m <= 120) ? 1 : 0;
 }
 
 extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
@@ -390,7 +425,7 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
                                 double* phi_out, void* stream) {
     if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || ldx < m - 1) return SOBER_E_ARG;
     if (!sober_car_supported(N, m)) return SOBER_E_DIM;
-    size_t doubles = (size_t)m * N + sober::CAR_PAD + 2 * (size_t)m + 8;
+    size_t doubles = (size_t)m * ((N + 7) & ~7) + sober::CAR_PAD + 2 * (size_t)m + 8;
     if (doubles < 4 * 264 + 8) doubles = 4 * 264 + 8;
     const size_t bytes = doubles * sizeof(double);
     static bool attr_set = false;
