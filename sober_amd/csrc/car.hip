@@ -105,9 +105,9 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     // m x N row-major, then CAR_PAD doubles of slack: the register-tiled sweeps read fixed strides
     // (immediate offsets, no per-element clamping -> no address VGPRs) and mask what lies beyond N
     double* A = lds;
-    double* taup = lds + (size_t)m * (((size_t)N + 7) & ~(size_t)7) + CAR_PAD;    // m
-    double* ubuf = taup + m;               // m  (left reflector of the current step)
-    double* scal = ubuf + m;               // [0] tauq  [1] tau
+    double* taup = lds + (size_t)m * (8 * CAR_RP) + CAR_PAD;    // m
+    double* ubuf = taup + m;               // 104: left reflector of the current step over absolute rows
+    double* scal = ubuf + 104;             // [0] tauq  [1] tau
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CAR_STAMPS
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     const int l16 = lane & 15, rid = lane >> 4;          // lane in DPP row, DPP row in wave
     const int g = l16 >> 1, c2 = l16 & 1;                // row group / column parity inside a DPP row
     const int NC = N - m;
-    const int NS = (N + 7) & ~7;                         // LDS row stride: zero columns N..NS-1 (phase 2 walks 8-strided)
+    constexpr int NS = 8 * CAR_RP;                       // LDS row stride (200): columns N..NS-1 stay zero, so the
+                                                         // register-tiled sweeps need no per-element bounds
 
     // ---------------- load A = [1 | X]^T ----------------
     for (int j = tid; j < m * NS + CAR_PAD; j += CAR_T) A[j] = 0.0;   // padding / over-reads hit zeros, never stale NaNs
@@ -133,10 +134,13 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     __syncthreads();
 
     // ---------------- phase 1: Golub-Kahan bidiagonalisation (dgebd2, m < N) ----------------
-    // per step: (A) wave 0 builds G(i) from row i   | barrier
-    //           (B) all waves apply it to rows > i  | barrier
-    //           (C) wave 0 builds H(i) from column i | barrier
-    //           (D) all waves apply it to columns > i | barrier
+    // per step: (A) wave 0 builds G(i) from row i and stores the FULL reflector vector
+    //               v~ = [0 .. 0, 1, v_i, 0 pad] in row i                          | barrier
+    //           (B) all waves apply it to rows > i: row -= tau (row . v~) v~        | barrier
+    //           (C) wave 0 builds H(i) from column i, full vector u~ in ubuf        | barrier
+    //           (D) all waves apply it to columns > i                               | barrier
+    // Because v~ / u~ carry their own zeros, (B) and (D) sweep fixed 16- / 8-strided patterns with
+    // unconditional LDS traffic; only whole blocks left of / above the diagonal are skipped (uniform).
     for (int i = 0; i < m; ++i) {
         double* rowi = A + (size_t)i * NS;
         if (wave == 0) {                                               // (A)
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = i + 1 + lane + 64 * q;
-                const double x = rowi[min(c, N - 1)];
+                const double x = rowi[min(c, NS - 1)];
                 vr[q] = (c < N) ? x : 0.0;
                 ss = fma(vr[q], vr[q], ss);
             }
@@ -155,10 +159,8 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = i + 1 + lane + 64 * q;
-                if (c < N) rowi[c] = vr[q] * sc;                       // v_i stays in place like dgebd2
+                if (c < N) rowi[c] = vr[q] * sc;
             }
-            // phase 2 reads row i as the full reflector vector [0 .. 0, 1, v_i]: materialise it (the
-            // bidiagonal entries and the left reflectors stored left of the diagonal are not needed)
             if (lane == 0) { rowi[i] = 1.0; taup[i] = tau; scal[1] = tau; }
             for (int c = lane; c < i; c += 64) rowi[c] = 0.0;
         }
@@ -166,30 +168,30 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
         __syncthreads();
         {                                                              // (B) one matrix row per DPP row
             const double tau = scal[1];
+            const int q0 = i >> 4;                                     // 16-column blocks left of the diagonal: skip
             double vreg[CAR_CQ];
 #pragma unroll
             for (int q = 0; q < CAR_CQ; ++q) {
-                const int c = i + 1 + l16 + 16 * q;
-                const double x = rowi[c];
-                vreg[q] = (c < N) ? x : 0.0;
+                double x = 0.0;
+                if (q >= q0) x = rowi[min(l16 + 16 * q, NS - 1)];      // uniform branch
+                vreg[q] = (l16 + 16 * q < NS) ? x : 0.0;
             }
             for (int r = i + 1 + wave * 4 + rid; r < m; r += 64) {
-                double* row = A + (size_t)r * NS;
+                double* row = A + (size_t)r * NS + l16;
                 double a[CAR_CQ];
-                double w0 = (l16 == 0) ? row[i] : 0.0, w1 = 0.0;
+                double w0 = 0.0, w1 = 0.0;
 #pragma unroll
                 for (int q = 0; q < CAR_CQ; ++q) {
-                    const int c = i + 1 + l16 + 16 * q;
-                    a[q] = row[c];
-                    if (q & 1) w1 = fma(a[q], vreg[q], w1); else w0 = fma(a[q], vreg[q], w0);
+                    if (q >= q0) {
+                        a[q] = row[16 * q];                            // q = 12 over-reads the next row: v~ is 0 there
+                        if (q & 1) w1 = fma(a[q], vreg[q], w1); else w0 = fma(a[q], vreg[q], w0);
+                    }
                 }
                 const double t = tau * row16_sum(w0 + w1);
-                if (l16 == 0) row[i] -= t;
 #pragma unroll
-                for (int q = 0; q < CAR_CQ; ++q) {
-                    const int c = i + 1 + l16 + 16 * q;
-                    if (c < N) row[c] = fma(-t, vreg[q], a[q]);
-                }
+                for (int q = 0; q < CAR_CQ - 1; ++q)
+                    if (q >= q0) row[16 * q] = fma(-t, vreg[q], a[q]);
+                if (l16 < NS - 16 * (CAR_CQ - 1)) row[16 * (CAR_CQ - 1)] = fma(-t, vreg[CAR_CQ - 1], a[CAR_CQ - 1]);
             }
         }
         __syncthreads();
@@ -199,41 +201,48 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int r = i + 2 + lane + 64 * q;
-                const double x = A[(size_t)min(r, m - 1) * NS + i];   // 2 clamped loads only
+                const double x = A[(size_t)min(r, m - 1) * NS + i];
                 ureg[q] = (r < m) ? x : 0.0;
                 s2 = fma(ureg[q], ureg[q], s2);
             }
             s2 = wave_sum(s2);
             double beta2, tauq, sc2;
             larfg(A[(size_t)(i + 1) * NS + i], s2, beta2, tauq, sc2);
-            if (lane == 0) { ubuf[0] = 1.0; scal[0] = tauq; }
+            if (lane == 0) scal[0] = tauq;
+            // u~ over absolute row indices 0 .. 103: zeros up to row i, 1 at row i+1, u below, zeros from m on
+            for (int r = lane; r < 104; r += 64)
+                if (r <= i + 1 || r >= m) ubuf[r] = (r == i + 1) ? 1.0 : 0.0;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int r = i + 2 + lane + 64 * q;
-                if (r < m) ubuf[r - i - 1] = ureg[q] * sc2;
+                if (r < m) ubuf[r] = ureg[q] * sc2;
             }
         }
         __syncthreads();
         {                                                              // (D) 8 columns per wave sweep
             const double tauq = scal[0];
-            const int L = m - i - 1;                                   // rows i+1 .. m-1
-            const int nk = (L - g + 7) >> 3;                           // my rows: k = g, g+8, ...
+            const int kk0 = (i + 1) >> 3;                              // 8-row blocks above row i+1: skip
+            const int kkf = m >> 3;                                    // blocks kk < kkf are complete (rows < m)
             for (int cb = wave; cb * 8 < N - i - 1; cb += 16) {
                 const int c = min(i + 1 + cb * 8 + rid * 2 + c2, N - 1);   // clamped: duplicates are benign
-                double* colp = A + (size_t)(i + 1 + g) * NS + c;
+                double* colp = A + (size_t)g * NS + c;
                 double av[13];
-                double part = 0.0;
+                double pa = 0.0, pb = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < 13; ++kk) {
-                    if (kk < nk) {
+                    if (kk >= kk0 && kk < kkf) {                       // uniform
                         av[kk] = colp[(size_t)kk * 8 * NS];
-                        part = fma(ubuf[g + 8 * kk], av[kk], part);
+                        if (kk & 1) pb = fma(ubuf[g + 8 * kk], av[kk], pb); else pa = fma(ubuf[g + 8 * kk], av[kk], pa);
                     }
                 }
-                const double t = tauq * grp8_sum(part);
+                double alast = 0.0;
+                const bool lastok = (kkf < 13) && (g + 8 * kkf < m);   // the one partial block, per lane
+                if (lastok) { alast = colp[(size_t)kkf * 8 * NS]; pa = fma(ubuf[g + 8 * kkf], alast, pa); }
+                const double t = tauq * grp8_sum(pa + pb);
 #pragma unroll
                 for (int kk = 0; kk < 13; ++kk)
-                    if (kk < nk) colp[(size_t)kk * 8 * NS] = fma(-t, ubuf[g + 8 * kk], av[kk]);
+                    if (kk >= kk0 && kk < kkf) colp[(size_t)kk * 8 * NS] = fma(-t, ubuf[g + 8 * kk], av[kk]);
+                if (lastok) colp[(size_t)kkf * 8 * NS] = fma(-t, ubuf[g + 8 * kkf], alast);
             }
         }
         __syncthreads();
@@ -249,15 +258,14 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 #pragma unroll
     for (int k = 0; k < CAR_RP; ++k) phi[k] = (okcol && (g + 8 * k) == m + col) ? 1.0 : 0.0;
     if (wave * 8 < NC) {
-        const int kmax = (N + 7) >> 3;                     // rows g + 8k, k < kmax cover 0 .. N-1 (+ padding)
         for (int i = m - 1; i >= 0; --i) {
             const double* vi = A + (size_t)i * NS + g;     // row i now holds [0.., 1, v_i, 0 pad]; stride-8 walk
             const double tau = taup[i];
             double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) {
-                if (k < kmax) {
-                    const double v = vi[8 * k];
+                {
+                    const double v = vi[8 * k];                        // zero beyond column N-1
                     if ((k & 3) == 0) p0 = fma(v, phi[k], p0);
                     else if ((k & 3) == 1) p1 = fma(v, phi[k], p1);
                     else if ((k & 3) == 2) p2 = fma(v, phi[k], p2);
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
             const double t = tau * grp8_sum((p0 + p1) + (p2 + p3));
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) {                         // second pass re-reads v_i from LDS:
-                if (k < kmax) phi[k] = fma(-t, vi[8 * k], phi[k]);     // cheaper than 50 more live VGPRs
+                phi[k] = fma(-t, vi[8 * k], phi[k]);                   // cheaper than 50 more live VGPRs
                 if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -289,7 +297,6 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     double* colbuf = lds;                  // [2][NP]   current / next pivot column (zero beyond N)
     double* mubuf = lds + 2 * NP;          // [2][NP]
     double* pscal = lds + 4 * NP;          // [2][2]    (alpha, piv) of the current / next step
-    const int kmax = (N + 7) >> 3;
     for (int r = tid; r < 2 * NP; r += CAR_T) colbuf[r] = 0.0;
     __syncthreads();
     for (int r = tid; r < N; r += CAR_T) mubuf[r] = mu_in[r];
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
             const double* cbg = cb + g;
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) {
-                if (k < kmax) phi[k] = fma(-qv, cbg[8 * k], phi[k]);    // column is zero beyond N
+                phi[k] = fma(-qv, cbg[8 * k], phi[k]);                  // column is zero beyond N
                 if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);
             }
             if (g == gp) {                                              // Phi[idx, :] = 0 (:266), exactly
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 }  // namespace sober
 
 extern "C" int sober_car_supported(int N, int m) {
-    return (m >= 2 && N > m && N <= 8 * sober::CAR_RP && N <= 16 * sober::CAR_CQ && (int64_t)m * ((N + 7) & ~7) <= 20000 && N - m <= 120) ? 1 : 0;
+    return (m >= 2 && N > m && N <= 8 * sober::CAR_RP && N <= 16 * sober::CAR_CQ && m <= 100 && N - m <= 120) ? 1 : 0;
 }
 
 extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
@@ -425,7 +432,7 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
                                 double* phi_out, void* stream) {
     if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || ldx < m - 1) return SOBER_E_ARG;
     if (!sober_car_supported(N, m)) return SOBER_E_DIM;
-    size_t doubles = (size_t)m * ((N + 7) & ~7) + sober::CAR_PAD + 2 * (size_t)m + 8;
+    size_t doubles = (size_t)m * (8 * sober::CAR_RP) + sober::CAR_PAD + (size_t)m + 104 + 8;
     if (doubles < 4 * 264 + 8) doubles = 4 * 264 + 8;
     const size_t bytes = doubles * sizeof(double);
     static bool attr_set = false;
