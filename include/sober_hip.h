@@ -176,6 +176,10 @@ int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in
  * range finder of torch.svd_lowrank (SOBER/_rchq.py:37).                                           */
 int sober_chol_max_n(void);
 int sober_cholesky(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, void* stream);
+/* All rungs of the jitter ladder in one launch: workgroup b factorises (src + shifts[b] I) in slab b of
+ * `work` (n_shifts * n * n doubles) and sets info[b] (0 = positive definite).  src is not modified.     */
+int sober_cholesky_probe(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
+                         double* work, int32_t* info, void* stream);
 /* Small SPD G (q <= 128): Cholesky G = L L^T entirely in LDS; Lout receives L (q x q lower
  * triangular, zeros above).  info / min_pivot as above.                                              */
 int sober_chol_small(const double* G, int q, int ldg, double* Lout, int ldl, int32_t* info,

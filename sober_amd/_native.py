@@ -48,6 +48,7 @@ SIGNATURES = {
     "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sober_chol_max_n": (_i32, []),
     "sober_cholesky": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp]),
+    "sober_cholesky_probe": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_chol_small": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_trsm_rows": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
@@ -271,6 +272,12 @@ def cholesky(A, shift, info, min_pivot=None):
     n = A.shape[0]
     _check(load().sober_cholesky(A.data_ptr(), n, A.stride(0), float(shift), info.data_ptr(), _ptr(min_pivot),
                                  _stream(A)), "sober_cholesky")
+
+
+def cholesky_probe(src, shifts, work, info):
+    n = src.shape[0]
+    _check(load().sober_cholesky_probe(src.data_ptr(), n, src.stride(0), shifts.data_ptr(), shifts.numel(),
+                                       work.data_ptr(), info.data_ptr(), _stream(src)), "sober_cholesky_probe")
 
 
 def chol_small(G, Rinv, info, min_pivot=None):

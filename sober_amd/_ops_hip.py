@@ -124,27 +124,18 @@ class HipOps:
         if int(flag.item()) == 0:
             return None                                    # symmetric input: is_psd(cov) itself has to run
         warnings.warn("Estimated covariance matrix was not positive semi-definite. Conveting...")
-        info = torch.zeros(1, dtype=torch.int32, device=dev)
-        W = torch.empty_like(C)
-
-        def pd(k):                                         # is_psd(cov after k jitter additions)?
-            W.copy_(C)
-            nat.cholesky(W, 1e-5 * (2 ** k - 1), info)
-            return int(info.item()) == 0
-
-        if pd(0):
-            k_first = 0
-        elif not pd(max_iter):
-            k_first = max_iter + 1
-        else:
-            lo, hi = 0, max_iter                           # pd(lo) False, pd(hi) True
-            while hi - lo > 1:
-                mid = (lo + hi) // 2
-                if pd(mid):
-                    hi = mid
-                else:
-                    lo = mid
-            k_first = hi
+        # every rung of the ladder (after k = 0 .. max_iter jitter additions) is probed at once: one
+        # workgroup per rung, one launch; the CPU draws svd_lowrank's randn meanwhile (it is the next
+        # consumer of the generator in the reference too: make_cov_psd draws nothing)
+        n_r = max_iter + 1
+        shifts = torch.tensor([1e-5 * (2 ** k - 1) for k in range(n_r)], dtype=torch.float64, device=dev)
+        info = torch.zeros(n_r, dtype=torch.int32, device=dev)
+        work = self._buf(p, "chol_work", n_r * M * M)
+        nat.cholesky_probe(C, shifts, work, info)
+        R = torch.randn(M, s, dtype=torch.float64)
+        (info_h,) = self.to_host(info)
+        ok = (info_h == 0).tolist()
+        k_first = ok.index(True) if any(ok) else max_iter + 1
         diag = C.diagonal()
         jitter = torch.full((M,), 1e-5, dtype=torch.float64, device=dev)
         for _ in range(k_first):                           # SOBER/_utils.py:151-152, one rung at a time
@@ -152,7 +143,7 @@ class HipOps:
             jitter *= 2
         if k_first > max_iter:
             C = torch.diag(C.diagonal().clone())           # :155
-        U = self._svd_lowrank_device(C, s)
+        U = self._svd_lowrank_device(C, s, R)
         if U is None:
             return None
         return U, G
@@ -170,12 +161,12 @@ class HipOps:
             Y = Q
         return Y
 
-    def _svd_lowrank_device(self, A, q, niter: int = 2):
+    def _svd_lowrank_device(self, A, q, R_host, niter: int = 2):
         """torch.svd_lowrank(A, q) (Halko et al. Alg. 4.4 / 5.1, as in torch/_lowrank.py) for a square
         device matrix; returns -U^T (q, M) like SOBER/_rchq.py:38, or None if CholeskyQR lost rank."""
         from ._engine import host_lapack_threads
         dev, M = self.device, A.shape[0]
-        R = torch.randn(M, q, dtype=torch.float64).to(dev)          # CPU generator: the reference's draw
+        R = R_host.to(dev)                                           # CPU generator: the reference's draw
         n_orth = 1 + 2 * niter
         infos = torch.zeros(2 * n_orth, dtype=torch.int32, device=dev)
         pivs = torch.zeros(2 * n_orth, dtype=torch.float64, device=dev)
@@ -190,14 +181,23 @@ class HipOps:
             nat.dgemm(A, Q, Y)
             Q = self._orth(Y, infos, pivs, slot); slot += 2
             Y = torch.empty(M, q, dtype=torch.float64, device=dev)
-        B = torch.empty(q, M, dtype=torch.float64, device=dev)
-        nat.dgemm(Q, A, B, transa=True)                              # Q^H A
-        B_h, infos_h, pivs_h = self.to_host(B, infos, pivs)
+        # B = Q^H A (q x M).  Its left singular vectors are those of the q x q factor of B^T = Qb Rb:
+        # B = Rb^T Qb^T  =>  U_B = left singular vectors of Rb^T.  CholeskyQR2 of B^T on the device, so
+        # only q x q goes to the host for LAPACK's SVD (0.6 ms instead of 2.2 ms for q x M).
+        Bt = torch.empty(M, q, dtype=torch.float64, device=dev)
+        nat.dgemm(A, Q, Bt, transa=True)                             # (Q^H A)^T = A^T Q
+        infos_b = torch.zeros(2, dtype=torch.int32, device=dev)
+        pivs_b = torch.zeros(2, dtype=torch.float64, device=dev)
+        Qb = self._orth(Bt, infos_b, pivs_b, 0)
+        Rb = torch.empty(q, q, dtype=torch.float64, device=dev)
+        nat.dgemm(Qb, Bt, Rb, transa=True)                           # Rb = Qb^T B^T  (upper triangular)
+        Rb_h, infos_h, pivs_h, infos_bh, pivs_bh = self.to_host(Rb, infos, pivs, infos_b, pivs_b)
         # second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1
-        if bool((infos_h != 0).any()) or float(pivs_h[1::2].min()) < 0.5:
+        if bool((infos_h != 0).any()) or float(pivs_h[1::2].min()) < 0.5 or bool((infos_bh != 0).any()) \
+                or float(pivs_bh[1]) < 0.5:
             return None
         with host_lapack_threads(M):
-            Ub, _, _ = torch.linalg.svd(B_h, full_matrices=False)
+            Ub, _, _ = torch.linalg.svd(Rb_h.T.contiguous(), full_matrices=False)
         U = torch.empty(M, q, dtype=torch.float64, device=dev)
         nat.dgemm(Q, self.from_host(Ub.contiguous()), U)
         return (-1 * U.T).contiguous()

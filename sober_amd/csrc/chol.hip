@@ -20,9 +20,26 @@ constexpr int CH_MAXN = 608;         // panel (n - NB) x NB doubles + diagonal b
 // A (n x n, row-major, ld) is overwritten by L in its lower triangle (upper triangle untouched).
 // shift is added to the diagonal on the fly (the jitter rung), so the caller's matrix can be probed
 // at several rungs from a scratch copy.
+// Batched form (gridDim.x > 1): workgroup b factorises (src + shifts[b] I) in its own n x n slab of
+// `A` (slab stride n*ld doubles) and reports info[b]; used to probe every rung of the jitter ladder of
+// SOBER/_utils.py:145-156 in ONE launch (the rungs are independent).
 __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, int ld, double shift,
-                                              int32_t* __restrict__ info, double* __restrict__ min_pivot) {
+                                              int32_t* __restrict__ info, double* __restrict__ min_pivot,
+                                              const double* __restrict__ src, int lds_src,
+                                              const double* __restrict__ shifts) {
     extern __shared__ double lds[];
+    if (src != nullptr) {                     // batched: copy the lower triangle into my slab first
+        A += (size_t)blockIdx.x * n * ld;
+        info += blockIdx.x;
+        if (min_pivot) min_pivot += blockIdx.x;
+        shift = shifts[blockIdx.x];
+        for (int t = threadIdx.x; t < n * n; t += CH_T) {
+            const int i = t / n, j = t % n;
+            if (j <= i) A[(size_t)i * ld + j] = src[(size_t)i * lds_src + j];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     double* D = lds;                         // NB x (NB+1)
     double* P = lds + CH_NB * (CH_NB + 1);   // (n - kb - nb) x (NB+1) panel, padded against bank conflicts
     __shared__ int s_fail;
@@ -277,7 +294,21 @@ extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* i
         attr_set = true;
     }
     hipLaunchKernelGGL(sober::k_chol, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift, info,
-                       min_pivot);
+                       min_pivot, (const double*)nullptr, 0, (const double*)nullptr);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_cholesky_probe(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
+                                    double* work, int32_t* info, void* stream) {
+    if (!src || !shifts || !work || !info || n <= 0 || ld_src < n || n_shifts <= 0) return SOBER_E_ARG;
+    if (n > sober::CH_MAXN) return SOBER_E_DIM;
+    const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
+    const size_t bytes = ((size_t)sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * (sober::CH_NB + 1)) * sizeof(double);
+    HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024 - 64));
+    hipLaunchKernelGGL(sober::k_chol, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
+                       info, (double*)nullptr, src, ld_src, shifts);
     LAUNCH_CHECK();
     return 0;
 }
