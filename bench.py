@@ -115,9 +115,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # dominant kernel: HIP-event time of every k_level_reduce launch in the timed region
+    # dominant kernel: HIP-event time of every k_level_reduce launch in the timed region, minus the
+    # cost of an empty event pair on the same stream (calibrated here; ~5 us, comparable to the deep
+    # levels' launches -- without it the event sum would not agree with rocprofv3's kernel durations)
     prof, ops.prof = ops.prof, None
-    kern_ms = sum(a.elapsed_time(b_) for a, b_, _ in prof)
+    cal = []
+    for _ in range(200):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record(); cal.append((e0, e1))
+    torch.cuda.synchronize()
+    ev_overhead = float(np.median([a.elapsed_time(b_) for a, b_ in cal]))
+    kern_ms = sum(max(a.elapsed_time(b_) - ev_overhead, 0.0) for a, b_, _ in prof)
     entries = sum(e for _, _, e in prof)
     flop_per_entry = 2 * CFG2["d"] + 2 + CK[CFG2["kind"]]
     achieved = entries * flop_per_entry / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
@@ -146,16 +154,24 @@ def main():
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 return O.recombination(Xc, Xn, b, ok, init_weights=m)
-        cpu_step()                                            # warm-up
-        c0 = time.perf_counter()
-        for _ in range(args.cpu_steps):
-            cpu_step()
-        cpu_s = (time.perf_counter() - c0) / args.cpu_steps
-        cpu_baseline = {"value": N_loc / cpu_s, "unit": "candidates/s", "cores": torch.get_num_threads(),
+        # the reference-shaped CPU path barely scales with cores (memory-bound temporaries): time it at the
+        # host's full thread count AND at 8 threads, report the faster one
+        runs = {}
+        for th in sorted({os.cpu_count() // 2 or 1, 8}):
+            torch.set_num_threads(th)
+            cpu_step()                                        # warm-up
+            c0 = time.perf_counter()
+            for _ in range(args.cpu_steps):
+                cpu_step()
+            runs[th] = (time.perf_counter() - c0) / args.cpu_steps
+        best = min(runs, key=runs.get)
+        cpu_s = runs[best]
+        cpu_baseline = {"value": N_loc / cpu_s, "unit": "candidates/s", "cores": best,
                         "kind": "port", "ms_per_step": cpu_s * 1e3,
+                        "ms_per_step_by_threads": {str(k): v * 1e3 for k, v in runs.items()},
                         "sample": f"{args.cpu_steps} full recombination steps of the same workload "
                                   f"(N_rec=100k, N_nys=500, d=10, batch=100) after 1 warm-up, oracle "
-                                  f"(torch CPU FP64, reference-shaped), {torch.get_num_threads()} threads"}
+                                  f"(torch CPU FP64, reference-shaped), best of {sorted(runs)} threads"}
 
     ms_per_step = elapsed / args.steps * 1e3
     out = {
@@ -172,10 +188,13 @@ def main():
                                   if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
-                     "kernel": "k_level_reduce", "launches": len(prof), "kernel_ms_per_step": kern_ms / args.steps,
-                     "note": "FP64 compute-bound (VALU f64 + software exp; FP64 vector and matrix "
-                             "peaks are both 78.6 TFLOP/s on MI355X); algorithmic flop = entries * "
-                             f"(2d+2+C_k) = entries * {flop_per_entry}"},
+                     "kernel": "k_level_reduce_mfma", "launches": len(prof), "kernel_ms_per_step": kern_ms / args.steps,
+                     "event_pair_overhead_ms": ev_overhead,
+                     "note": "FP64 compute-bound: -|x-y|^2/2 on v_mfma_f64_16x16x4 (augmented GEMM), "
+                             "table-driven FP64 exp on the VALU; MI355X FP64 vector and matrix peaks are "
+                             "both 78.6 TFLOP/s and share the DP units (scripts/fp64_pipes_probe.hip); "
+                             f"algorithmic flop = entries * (2d+2+C_k) = entries * {flop_per_entry}; all "
+                             "launches of a step are averaged (level 0 alone runs ~2x the average)"},
         "cpu_baseline": cpu_baseline,
         "parity": parity,
         "phases_ms_per_step": {k: v / args.steps * 1e3 for k, v in timers.items()},
