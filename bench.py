@@ -36,6 +36,7 @@ from tests.golden.synth import SEED_CALL, build_spec, synth  # noqa: E402
 CFG2 = dict(kind="rbf", mode="predictive_covariance", N=100000, M=500, d=10, b=100, n_obs=200, seed=0)
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector = FP64 matrix (vendor)
 CK = {"rbf": 28, "matern52": 40}
+PMC_TRAFFIC_BYTES_PER_LAUNCH = 23.4e6   # measured, see the comment at "traffic" below
 
 
 def t(a):
@@ -187,7 +188,13 @@ def main():
                    "parallelism": f"pool row-sharded x{world}, one all-reduce of (n*S+S) f64 per level"
                                   if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP64_PEAK_TFLOPS,
+                     # HBM bytes per launch (mean over the 11 launches of a step) from rocprofv3 PMC passes of
+                     # THIS workload: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction of
+                     # MI355X_MICROARCH.md; separate --pmc passes; profiles/r01_pmc_level_reduce.csv).
+                     # Algorithmic bytes are ~1.7 MB/launch: the excess is the per-chunk partial-sum
+                     # buffers (n_chunks * Mtot * S * 8 B written, then re-read by k_sum_partials).
+                     "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if world == 1 else None,
                      "kernel": "k_level_reduce_mfma", "launches": len(prof), "kernel_ms_per_step": kern_ms / args.steps,
                      "event_pair_overhead_ms": ev_overhead,
                      "note": "FP64 compute-bound: -|x-y|^2/2 on v_mfma_f64_16x16x4 (augmented GEMM), "
