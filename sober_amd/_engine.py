@@ -154,6 +154,29 @@ def car_host(X: torch.Tensor, mu: torch.Tensor):
     return mu[keep], torch.arange(N)[keep]
 
 
+def second_elimination_host(Xp, obj_p, w_star, idx_star):
+    """The extra null-vector elimination of the acquisition-guided branch, SOBER/_rchq.py:87-106 and
+    :177-196 (host tensors): among the feasible recombinations move towards larger sum w * calc_obj
+    and drop one more point."""
+    dt = Xp.dtype
+    Xp = torch.cat((Xp, torch.ones(1, len(idx_star), dtype=dt)), 0)
+    with host_lapack_threads(Xp.shape[1]):
+        _, _, w_null = torch.linalg.svd(Xp)
+    w_null = w_null[-1]
+    if torch.dot(obj_p, w_null) < 0:
+        w_null = -w_null
+    lm = len(w_star)
+    plis = w_null > 0
+    alpha = torch.zeros(lm, dtype=dt)
+    alpha[plis] = w_star[plis] / w_null[plis]
+    idx_sp = torch.arange(lm)[plis]
+    idx_sp = idx_sp[torch.argmin(alpha[plis])]
+    w_star = w_star - alpha[idx_sp] * w_null
+    w_star[idx_sp] = 0.0
+    keep = w_star > 0
+    return w_star[keep], idx_star[keep]
+
+
 def survivors_before(p: int, S: int, E: int, kept_prefix, n_keep: int, last_kept: bool) -> int:
     """Number of surviving list positions strictly below global position p after a level that kept
     the sets with kept_prefix[s] = #kept sets < s (closed-form compaction)."""
@@ -211,11 +234,21 @@ class RecombinationEngine:
         return U
 
     # -- the halving loop -------------------------------------------------------
-    def run(self, plan, mu: torch.Tensor, num_pts: int):
+    def run(self, plan, mu: torch.Tensor, num_pts: int, obj: Optional[torch.Tensor] = None):
         """Mod_Tchernychova_Lyons, SOBER/_rchq.py:51-221.  `mu` (local weights, device, float64)
-        is modified in place (Q3).  Returns (idx_star int64 global indices, w_star) on the device,
-        identical on every rank."""
+        is modified in place (Q3).  `obj` = -calc_obj(samp) for the local candidates (or None).
+        Returns (idx_star int64 global indices, w_star) on the device, identical on every rank."""
         ops, comm = self.ops, self.comm
+        self.obj = obj
+        self.obj_head = None
+        if obj is not None:
+            # quirk of the final level (:89): the reference indexes the GLOBAL obj with list positions,
+            # so the first 2b entries of the pool's obj are needed by every rank
+            head = obj[:2 * num_pts].clone()
+            if comm.world > 1:
+                cnt = comm.allgather_counts(int(head.numel()))
+                head = comm.allgather_rows(head, cnt)[:2 * num_pts]
+            self.obj_head = head
         n = num_pts - 1
         S = 2 * (n + 1)
         U = self.nystrom_basis(plan, n)
@@ -242,7 +275,12 @@ class RecombinationEngine:
             r = R - E * S
             t0 = time.perf_counter()
             Xtr, tot = ops.level_moments(plan, idx_cur, pos0, count, S, E, mu)
-            comm.allreduce_sum(Xtr, tot)
+            if obj is None:
+                comm.allreduce_sum(Xtr, tot)
+            else:                                           # one more "test function" row (:138-150,157-159)
+                orow = self._obj_set_sums(obj, mu, idx_cur, pos0, count, S, E)
+                comm.allreduce_sum(Xtr, tot, orow)
+                Xtr = torch.cat([Xtr, orow.unsqueeze(0)], 0)
             X_tmp = ops.barycentres(Xtr, tot)               # :151,166
             keep_rank_d, w_star_d, keep_rank, n_keep = self._car(X_tmp, tot, R, E, r, levels, t0)  # :173-175
             last_kept = bool(keep_rank[S - 1] >= 0)
@@ -262,6 +300,26 @@ class RecombinationEngine:
             idx_cur, idx_new = idx_new, idx_cur
             pos0, count, R = new_pos0, new_end - new_pos0, R_new
 
+    def _obj_set_sums(self, obj, mu, idx_cur, pos0, count, S, E):
+        """X_for_obj of SOBER/_rchq.py:138-146 plus the leftover addition to the last set (:157-163)
+        for the local positions: sum of obj*mu per set, leftovers counted in set p mod S AND in set S-1
+        (same quirk Q1 as the kernel rows).  Reshape-sum: fixed order, no atomics."""
+        dev = mu.device
+        if count == 0:
+            return torch.zeros(S, dtype=torch.float64, device=dev)
+        c = idx_cur[:count].long()
+        v = obj[c] * mu[c]
+        e_first = pos0 // S
+        e_total = (pos0 + count + S - 1) // S - e_first
+        dense = torch.zeros(e_total * S, dtype=torch.float64, device=dev)
+        off = pos0 - e_first * S
+        dense[off:off + count] = v
+        out = dense.view(e_total, S).sum(0)
+        n_left = pos0 + count - max(pos0, E * S)
+        if n_left > 0:
+            out[S - 1] += v[count - n_left:].sum()
+        return out
+
     # -- one Caratheodory step ---------------------------------------------------
     def _car(self, X_dev, mu_dev, R, E, r, levels, t0, kind="level"):
         """Tchernychova_Lyons_CAR on (X_dev (N', n'), mu_dev (N')).  On-chip HIP kernel when the
@@ -269,8 +327,9 @@ class RecombinationEngine:
         w_star, the host copy of keep_rank and n_keep."""
         ops = self.ops
         Np, n1 = X_dev.shape[0], X_dev.shape[1] + 1
+        use_obj = getattr(self, "obj", None) is not None
         on_device = getattr(ops, "car_supported", None) is not None and ops.car_supported(Np, n1) \
-            and not self.force_host_car
+            and not self.force_host_car and not use_obj
         if on_device:
             keep_rank_d, w_star_d, n_keep_d, _ = ops.car_device(X_dev, mu_dev)
             if levels is not None:
@@ -286,10 +345,14 @@ class RecombinationEngine:
         X_h, mu_h = ops.to_host(X_dev, mu_dev)
         t0 = self._tick("levels_device", t0)
         w_star, idx_star = car_host(X_h, mu_h.clone())
-        self._tick("car_host", t0)
-        if levels is not None:
+        if levels is not None:                              # (trace = the Caratheodory step's own output)
             levels.append(dict(kind=kind, R=R, E=E, r=r, X_tmp=X_h.clone(), tot_weights=mu_h.clone(),
                                idx_star=idx_star.clone(), w_star=w_star.clone()))
+        if use_obj:                                         # :177-196 / :87-106
+            nfun = X_h.shape[1] - 1
+            obj_p = X_h[idx_star, nfun] if kind == "level" else self.obj_head.cpu()[idx_star]
+            w_star, idx_star = second_elimination_host(X_h[idx_star, :nfun].T.contiguous(), obj_p, w_star, idx_star)
+        self._tick("car_host", t0)
         n_keep = int(idx_star.numel())
         keep_rank = torch.full((Np,), -1, dtype=torch.int32)
         keep_rank[idx_star] = torch.arange(n_keep, dtype=torch.int32)
@@ -311,11 +374,15 @@ class RecombinationEngine:
     def _finish_direct(self, plan, idx_cur, count, R, mu, levels):
         ops, comm = self.ops, self.comm
         n = plan.n
+        obj = getattr(self, "obj", None)
+        nf = n + (1 if obj is not None else 0)
         if count > 0:
             X_loc = ops.direct_columns(plan, idx_cur, count)           # rows of (U @ K).T  (:78)
             mu_loc = mu[idx_cur[:count].long()]
+            if obj is not None:                                        # :80-81
+                X_loc = torch.cat([X_loc, obj[idx_cur[:count].long()].unsqueeze(1)], 1).contiguous()
         else:
-            X_loc = torch.zeros(0, n, dtype=torch.float64, device=ops.device)
+            X_loc = torch.zeros(0, nf, dtype=torch.float64, device=ops.device)
             mu_loc = torch.zeros(0, dtype=torch.float64, device=ops.device)
         counts = comm.allgather_counts(count)
         X_all = comm.allgather_rows(X_loc, counts)

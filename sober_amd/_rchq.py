@@ -3,6 +3,8 @@
     idx_star, w_star = recombination(pts_rec, pts_nys, num_pts, kernel, device, dtype,
                                      init_weights=None, calc_obj=None)
 
+`calc_obj(samp) -> (N,)` (the acquisition-guided branch, :67-69) is supported: the extra objective row
+is summed on the device, the two small eliminations per level run on the host's LAPACK.
 `kernel` is a `sober_amd.Kernel` (RBF / Matern-5/2 / Tanimoto posterior covariance, weighted or
 raw): the whole step then runs on the fused HIP path -- the (E, M, S) kernel tensor of
 SOBER/_rchq.py:124 is never materialised.  As in the reference, `device`/`dtype` are accepted and
@@ -34,9 +36,6 @@ def recombination(pts_rec, pts_nys, num_pts, kernel, device=None, dtype=None, in
                   of the pool (global row index = row_offset + local index) and every rank returns
                   the same global (idx_star, w_star); one small all-reduce per level.
     """
-    if calc_obj is not None:
-        raise NotImplementedError("the acquisition-guided branch (calc_obj, SOBER/_rchq.py:67-69) "
-                                  "is not on the MI355X path yet")
     if not isinstance(kernel, Kernel):
         raise TypeError("sober_amd.recombination needs a sober_amd.Kernel (the fused HIP path reads the "
                         f"kernel's hyper-parameters); got {type(kernel).__name__}")
@@ -65,7 +64,10 @@ def recombination(pts_rec, pts_nys, num_pts, kernel, device=None, dtype=None, in
     eng = RecombinationEngine(_ops, comm, row_offset=row_offset)
     eng.trace = _trace
     plan = _ops.build_plan(kernel.spec(dev), kernel.mode, X_nys, X_cand)
-    idx_star, w_star = eng.run(plan, mu, int(num_pts))
+    obj = None
+    if calc_obj is not None:                                              # :67-69, once on all candidates
+        obj = (-1 * calc_obj(X_cand)).detach().to(dev, torch.float64).reshape(-1).contiguous()
+    idx_star, w_star = eng.run(plan, mu, int(num_pts), obj)
     if _timers is not None:
         for k, v in eng.timers.items():
             _timers[k] = _timers.get(k, 0.0) + v

@@ -12,11 +12,10 @@ import torch
 import sober_amd
 from sober_amd._engine import RecombinationEngine, car_host, ker_svd_sparsify_host, survivors_before
 from tests._oracle_ops import OracleOps
-from tests.golden.synth import SEED_CALL, load_case
+from tests.golden.synth import SEED_CALL, calc_obj_fn, load_case
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "recomb_*.npz"))
-               if "cfg2" not in p and "calc_obj" not in p)
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "recomb_*.npz")) if "cfg2" not in p)
 
 
 def _t(a):
@@ -37,6 +36,7 @@ def run_engine(path, ops=None, trace=None):
         warnings.simplefilter("ignore")
         idx, w = sober_amd.recombination(_t(inp["X_cand"]), _t(inp["X_nys"]), case["b"],
                                          kernel_from(spec, case["mode"]), init_weights=mu,
+                                         calc_obj=calc_obj_fn if case["calc_obj"] else None,
                                          _ops=ops or OracleOps(), _trace=trace)
     return z, idx, w, mu
 
@@ -112,9 +112,6 @@ def test_api_errors():
         sober_amd.recombination(x, x[:10], 5, lambda a, b: a @ b.T, _ops=OracleOps())
     with pytest.raises(ValueError):
         sober_amd.recombination(x, x[:10], 5, sober_amd.Kernel(spec, "nope"), _ops=OracleOps())
-    with pytest.raises(NotImplementedError):
-        sober_amd.recombination(x, x[:10], 5, sober_amd.Kernel(spec), calc_obj=lambda s: s.sum(1),
-                                _ops=OracleOps())
 
 
 def test_no_cpu_fallback():

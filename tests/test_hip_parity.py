@@ -14,12 +14,12 @@ import torch
 import sober_amd
 from oracle import sober_oracle as O
 from tests._oracle_ops import OracleOps
-from tests.golden.synth import SEED_CALL, load_case
+from tests.golden.synth import SEED_CALL, calc_obj_fn, load_case
 
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-SMALL = sorted(p for p in glob.glob(os.path.join(GOLD, "recomb_*.npz")) if "calc_obj" not in p and "cfg2" not in p)
+SMALL = sorted(p for p in glob.glob(os.path.join(GOLD, "recomb_*.npz")) if "cfg2" not in p)
 W_RTOL = 1e-7
 
 
@@ -48,7 +48,8 @@ def run_hip(path, dev, trace=None):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
-                                         kernel, dev, torch.double, init_weights=mu, _trace=trace)
+                                         kernel, dev, torch.double, init_weights=mu,
+                                         calc_obj=calc_obj_fn if case["calc_obj"] else None, _trace=trace)
     return case, inp, z, idx, w, mu
 
 

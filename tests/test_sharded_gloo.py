@@ -27,7 +27,7 @@ def _worker(rank, world, port, name, cuts, outq):
     try:
         import sober_amd
         from tests._oracle_ops import OracleOps
-        from tests.golden.synth import SEED_CALL, load_case
+        from tests.golden.synth import SEED_CALL, calc_obj_fn, load_case
         torch.set_num_threads(1)
         case, inp, spec, z = load_case(os.path.join(GOLD, f"recomb_{name}.npz"))
         ks = sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs, spec.S_cache,
@@ -42,6 +42,7 @@ def _worker(rank, world, port, name, cuts, outq):
                 torch.manual_seed(SEED_CALL)
             idx, w = sober_amd.recombination(X, torch.from_numpy(inp["X_nys"]), case["b"],
                                              sober_amd.Kernel(ks, case["mode"]), init_weights=mu,
+                                             calc_obj=calc_obj_fn if case["calc_obj"] else None,
                                              group=dist.group.WORLD, row_offset=lo, _ops=OracleOps())
         outq.put((rank, idx.numpy(), w.numpy(), mu.numpy()))
     finally:
@@ -68,6 +69,7 @@ def _run(name, cuts):
     ("rbf_b30", [0, 700, 3000]),                  # uneven: ranges never align with the 2b sets
     ("rbf_zero_weights", [0, 1300, 2500]),        # mu == 0 entries drop out of the list per rank
     ("matern_b20", [0, 900, 1800, 3000]),         # three ranks
+    ("rbf_calc_obj", [0, 800, 2000]),             # acquisition-guided branch, sharded
 ])
 def test_sharded_equals_unsharded(name, cuts):
     z = np.load(os.path.join(GOLD, f"recomb_{name}.npz"))
