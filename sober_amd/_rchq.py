@@ -36,17 +36,20 @@ def recombination(pts_rec, pts_nys, num_pts, kernel, device=None, dtype=None, in
                   of the pool (global row index = row_offset + local index) and every rank returns
                   the same global (idx_star, w_star); one small all-reduce per level.
     """
-    if not isinstance(kernel, Kernel):
-        raise TypeError("sober_amd.recombination needs a sober_amd.Kernel (the fused HIP path reads the "
-                        f"kernel's hyper-parameters); got {type(kernel).__name__}")
-    if kernel.mode not in MODES:
+    fused = isinstance(kernel, Kernel)
+    if not fused and not callable(kernel):
+        raise TypeError(f"kernel must be a sober_amd.Kernel or a callable kernel(x, y); got {type(kernel).__name__}")
+    if fused and kernel.mode not in MODES:
         raise ValueError('mode should be from ["predictive_covariance", '
                          '"weighted_predictive_covariance", "kernel"]')
     if _ops is None:
-        from ._ops_hip import HipOps
+        from ._ops_hip import CallableKernelOps, HipOps
         glob_dev, _ = setting_parameters()
         dev = _device_of(pts_rec, glob_dev)
-        _ops = HipOps(dev)                       # raises when there is no HIP device / library
+        # raises when there is no HIP device / library.  A sober_amd.Kernel takes the fused path; any other
+        # callable (the reference's kernel protocol, e.g. BASQ's gspace_kernel) is evaluated by the caller's
+        # own torch code and only the kernel matrix itself is outside the HIP path
+        _ops = HipOps(dev) if fused else CallableKernelOps(dev)
     dev = _ops.device
 
     N = pts_rec.shape[0]
@@ -63,7 +66,8 @@ def recombination(pts_rec, pts_nys, num_pts, kernel, device=None, dtype=None, in
     comm = DistComm(group) if group is not None else SoloComm()
     eng = RecombinationEngine(_ops, comm, row_offset=row_offset)
     eng.trace = _trace
-    plan = _ops.build_plan(kernel.spec(dev), kernel.mode, X_nys, X_cand)
+    plan = _ops.build_plan(kernel.spec(dev), kernel.mode, X_nys, X_cand) if fused else \
+        _ops.build_plan(kernel, "callable", X_nys, X_cand)
     obj = None
     if calc_obj is not None:                                              # :67-69, once on all candidates
         obj = (-1 * calc_obj(X_cand)).detach().to(dev, torch.float64).reshape(-1).contiguous()

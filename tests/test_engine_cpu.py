@@ -109,7 +109,7 @@ def test_api_errors():
                                 torch.zeros(3, 2, dtype=torch.double), torch.eye(3, dtype=torch.double))
     x = torch.rand(50, 2, dtype=torch.double)
     with pytest.raises(TypeError):
-        sober_amd.recombination(x, x[:10], 5, lambda a, b: a @ b.T, _ops=OracleOps())
+        sober_amd.recombination(x, x[:10], 5, "not a kernel", _ops=OracleOps())
     with pytest.raises(ValueError):
         sober_amd.recombination(x, x[:10], 5, sober_amd.Kernel(spec, "nope"), _ops=OracleOps())
 

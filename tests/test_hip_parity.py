@@ -513,3 +513,21 @@ def test_device_and_host_nystrom_agree(dev):
         assert torch.equal(i1, i2), name
         np.testing.assert_allclose(w1.cpu().numpy(), w2.cpu().numpy(), rtol=W_RTOL)
         assert np.array_equal(i1.cpu().numpy(), z["idx"]), name
+
+
+def test_arbitrary_callable_kernel(dev):
+    """The reference's kernel protocol: any callable kernel(x, y).  Here the callable is the
+    (materialising) sober_amd.Kernel.__call__ wrapped in a lambda, so the fused path must agree."""
+    path = os.path.join(GOLD, "recomb_rbf_b30.npz")
+    case, inp, spec, z = load_case(path)
+    kern = sober_amd.Kernel(kspec(spec), case["mode"])
+    mu = _t(inp["mu0"].copy()).to(dev)
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                         lambda x, y: kern(x, y), init_weights=mu)
+    assert np.array_equal(idx.cpu().numpy(), z["idx"])
+    np.testing.assert_allclose(w.cpu().numpy(), z["w"], rtol=W_RTOL)
+    nz = torch.nonzero(mu.cpu()).flatten().numpy()
+    assert np.array_equal(nz, z["mu_after_idx"])
