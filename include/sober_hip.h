@@ -164,9 +164,10 @@ int sober_car_pivot_host(double* h_Phi, int N, int m, double* h_mu);
  * receives the null-space basis before the pivots (test hook).
  * sober_car_supported(N, m) = 1 iff the on-chip kernel covers the size (batch <= 100).           */
 int sober_car_supported(int N, int m);
+int64_t sober_car_ws_bytes(int N, int m);
 int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
                      int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
-                     double* phi_out, void* stream);
+                     double* phi_out, void* ws, int64_t ws_bytes, void* stream);
 
 /* Dense FP64 Cholesky in one persistent workgroup (n <= sober_chol_max_n()): the lower triangle of A
  * (n x n row-major, ld) is overwritten by L with (A + shift I) = L L^T; *info = 0 on success, j+1 when

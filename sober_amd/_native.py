@@ -45,7 +45,8 @@ SIGNATURES = {
     "sober_i64_to_i32": (_i32, [_vp, _i64, _vp, _vp]),
     "sober_car_pivot_host": (_i32, [_vp, _i32, _i32, _vp]),
     "sober_car_supported": (_i32, [_i32, _i32]),
-    "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sober_car_ws_bytes": (_i64, [_i32, _i32]),
+    "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_chol_max_n": (_i32, []),
     "sober_cholesky": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp]),
     "sober_cholesky_probe": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
@@ -251,6 +252,9 @@ def car_pivot_host(Phi: torch.Tensor, mu: torch.Tensor) -> int:
     return r
 
 
+_CAR_WS = {}      # per-device scratch for k_car's reflector vectors (caller-owned, reused)
+
+
 def car_supported(N: int, m: int) -> bool:
     return bool(load().sober_car_supported(N, m))
 
@@ -258,9 +262,14 @@ def car_supported(N: int, m: int) -> bool:
 def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None):
     """X (N, m-1) float64 device (unit inner stride), mu_in (N)."""
     N, n = X.shape
+    nbytes = load().sober_car_ws_bytes(N, n + 1)
+    ws = _CAR_WS.get(X.device)
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=X.device)
+        _CAR_WS[X.device] = ws
     _check(load().sober_car_device(X.data_ptr(), X.stride(0), N, n + 1, mu_in.data_ptr(), keep_rank.data_ptr(),
                                    w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
-                                   _stream(X)), "sober_car_device")
+                                   ws.data_ptr(), nbytes, _stream(X)), "sober_car_device")
 
 
 def chol_max_n() -> int:

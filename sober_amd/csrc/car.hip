@@ -29,6 +29,7 @@ constexpr int CAR_T = 1024;
 constexpr int CAR_RP = 25;          // Phi rows per thread: N <= 8 * 25
 constexpr int CAR_CQ = 13;          // columns per lane in the row sweeps: N <= 16 * 13
 constexpr int CAR_PAD = 208;        // >= 16 * CAR_CQ and >= 8 * CAR_RP + 8
+constexpr int CAR_P1 = 672 + 64 * 208;  // phase-1 exchange buffers (doubles)
 
 // ---- DPP cross-lane helpers (row = 16 lanes).  ds_bpermute-based __shfl costs an LDS round trip
 // per step; these are plain VALU moves.
@@ -100,14 +101,22 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                                                double* __restrict__ w_star,
                                                int32_t* __restrict__ n_keep_out,
                                                double* __restrict__ mu_out,
-                                               double* __restrict__ phi_out) {
+                                               double* __restrict__ phi_out,
+                                               double* __restrict__ vws) {
     extern __shared__ double lds[];
-    // m x N row-major, then CAR_PAD doubles of slack: the register-tiled sweeps read fixed strides
-    // (immediate offsets, no per-element clamping -> no address VGPRs) and mask what lies beyond N
-    double* A = lds;
-    double* taup = lds + (size_t)m * (8 * CAR_RP) + CAR_PAD;    // m
-    double* ubuf = taup + m;               // 104: left reflector of the current step over absolute rows
-    double* scal = ubuf + 104;             // [0] tauq  [1] tau
+    // LDS map.  Phases 2-3: [0, m*NS + CAR_PAD) = the reflector vectors v~_i as rows (NS = 200 doubles,
+    // zero padded; fixed-stride sweeps over-read into zeros), then taup[m].  Phase 1 keeps the matrix
+    // itself in REGISTERS and uses the same base region for its small exchange buffers.
+    constexpr int NS = 8 * CAR_RP;
+    const int REG = max(m * NS + CAR_PAD, CAR_P1);
+    double* A = lds;                         // phases 2-3: rows of v~
+    double* taup = lds + REG;                // m
+    double* scal = taup + m;                 // [0] tauq  [1] tau
+    double* vbuf = lds;                      // phase 1: current v~ (208)
+    double* ubuf = lds + 208;                //          current u~ (128)
+    double* colb = lds + 336;                //          column i of the matrix (128)
+    double* zsum = lds + 464;                //          u~^T A per column (208)
+    double* zpart = lds + 672;               //          64 x 208 partial column sums
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CAR_STAMPS
@@ -120,78 +129,86 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     const int l16 = lane & 15, rid = lane >> 4;          // lane in DPP row, DPP row in wave
     const int g = l16 >> 1, c2 = l16 & 1;                // row group / column parity inside a DPP row
     const int NC = N - m;
-    constexpr int NS = 8 * CAR_RP;                       // LDS row stride (200): columns N..NS-1 stay zero, so the
-                                                         // register-tiled sweeps need no per-element bounds
 
-    // ---------------- load A = [1 | X]^T ----------------
-    for (int j = tid; j < m * NS + CAR_PAD; j += CAR_T) A[j] = 0.0;   // padding / over-reads hit zeros, never stale NaNs
-    __syncthreads();
-    for (int j = tid; j < N; j += CAR_T) A[j] = 1.0;
-    for (int t = tid; t < (m - 1) * N; t += CAR_T) {
-        const int j = t / (m - 1), i = t % (m - 1);       // X[j][i], coalesced over i
-        A[(size_t)(i + 1) * NS + j] = X[(size_t)j * ldx + i];
+    // ---------------- phase 1: Golub-Kahan bidiagonalisation (dgebd2, m < N), matrix in VGPRs ----------------
+    // 2-D block-cyclic ownership: thread (R = tid >> 4, C = tid & 15) holds A[r][c] for r in {R, R + 64},
+    // c = C + 16 q (q < 13): 26 doubles.  A matrix row lives in ONE DPP row (16 lanes), so row dot products
+    // are DPP reductions; column dot products go through a 64 x 208 partial buffer in LDS.  LDS traffic per
+    // step is ~4x lower than with the matrix itself in LDS (which is what bounded the previous version).
+    // per step: (A) the owner DPP row builds G(i), publishes v~ (LDS + global scratch for phase 2)  | barrier
+    //           (B) everyone applies it to its rows > i; column i is published                      | barrier
+    //           (C) wave 0 builds H(i) from column i                                                 | barrier
+    //           (D) partial column sums -> LDS | barrier | 208 threads finish the sums | barrier | update
+    const int R = tid >> 4, C = l16;
+    double a0[CAR_CQ], a1[CAR_CQ];
+#pragma unroll
+    for (int q = 0; q < CAR_CQ; ++q) {
+        const int c = C + 16 * q;
+        const bool okc = c < N;
+        a0[q] = (okc && R < m) ? ((R == 0) ? 1.0 : X[(size_t)c * ldx + (R - 1)]) : 0.0;
+        a1[q] = (okc && R + 64 < m) ? X[(size_t)c * ldx + (R + 63)] : 0.0;
     }
-    __syncthreads();
-
-    // ---------------- phase 1: Golub-Kahan bidiagonalisation (dgebd2, m < N) ----------------
-    // per step: (A) wave 0 builds G(i) from row i and stores the FULL reflector vector
-    //               v~ = [0 .. 0, 1, v_i, 0 pad] in row i                          | barrier
-    //           (B) all waves apply it to rows > i: row -= tau (row . v~) v~        | barrier
-    //           (C) wave 0 builds H(i) from column i, full vector u~ in ubuf        | barrier
-    //           (D) all waves apply it to columns > i                               | barrier
-    // Because v~ / u~ carry their own zeros, (B) and (D) sweep fixed 16- / 8-strided patterns with
-    // unconditional LDS traffic; only whole blocks left of / above the diagonal are skipped (uniform).
     for (int i = 0; i < m; ++i) {
-        double* rowi = A + (size_t)i * NS;
-        if (wave == 0) {                                               // (A)
-            double vr[4];
-            double ss = 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = i + 1 + lane + 64 * q;
-                const double x = rowi[min(c, NS - 1)];
-                vr[q] = (c < N) ? x : 0.0;
-                ss = fma(vr[q], vr[q], ss);
+        const bool hi = i >= 64;                         // row i is the a1 (hi) or a0 row of DPP row (i & 63)
+        const int qi = i >> 4, ci = i & 15;              // column i = lane ci, slot qi
+        if (R == (i & 63)) {                                           // (A)
+#define CAR_STEP_A(ARR)                                                                       \
+            {                                                                                 \
+                double ss = 0.0, al = 0.0;                                                    \
+                _Pragma("unroll") for (int q = 0; q < CAR_CQ; ++q) {                          \
+                    const int c = C + 16 * q;                                                 \
+                    ss = (c > i) ? fma(ARR[q], ARR[q], ss) : ss;                              \
+                    al = (c == i) ? ARR[q] : al;                                              \
+                }                                                                             \
+                ss = row16_sum(ss);                                                           \
+                al = row16_sum(al);                                                           \
+                double beta, tau, sc;                                                         \
+                larfg(al, ss, beta, tau, sc);                                                 \
+                _Pragma("unroll") for (int q = 0; q < CAR_CQ; ++q) {                          \
+                    const int c = C + 16 * q;                                                 \
+                    const double v = (c < i) ? 0.0 : ((c == i) ? 1.0 : ARR[q] * sc);          \
+                    vbuf[c] = v;                                                              \
+                    if (c < NS) vws[(size_t)i * NS + c] = v;                                  \
+                }                                                                             \
+                if (C == 0) { taup[i] = tau; scal[1] = tau; }                                 \
             }
-            ss = wave_sum(ss);
-            double beta, tau, sc;
-            larfg(rowi[i], ss, beta, tau, sc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = i + 1 + lane + 64 * q;
-                if (c < N) rowi[c] = vr[q] * sc;
-            }
-            if (lane == 0) { rowi[i] = 1.0; taup[i] = tau; scal[1] = tau; }
-            for (int c = lane; c < i; c += 64) rowi[c] = 0.0;
+            if (hi) CAR_STEP_A(a1) else CAR_STEP_A(a0)
+#undef CAR_STEP_A
         }
         if (i == m - 1) break;
         __syncthreads();
-        {                                                              // (B) one matrix row per DPP row
+        {                                                              // (B)
             const double tau = scal[1];
-            const int q0 = i >> 4;                                     // 16-column blocks left of the diagonal: skip
             double vreg[CAR_CQ];
 #pragma unroll
-            for (int q = 0; q < CAR_CQ; ++q) {
-                double x = 0.0;
-                if (q >= q0) x = rowi[min(l16 + 16 * q, NS - 1)];      // uniform branch
-                vreg[q] = (l16 + 16 * q < NS) ? x : 0.0;
-            }
-            for (int r = i + 1 + wave * 4 + rid; r < m; r += 64) {
-                double* row = A + (size_t)r * NS + l16;
-                double a[CAR_CQ];
+            for (int q = 0; q < CAR_CQ; ++q) vreg[q] = vbuf[C + 16 * q];
+            if (R > i && R < m) {
                 double w0 = 0.0, w1 = 0.0;
 #pragma unroll
-                for (int q = 0; q < CAR_CQ; ++q) {
-                    if (q >= q0) {
-                        a[q] = row[16 * q];                            // q = 12 over-reads the next row: v~ is 0 there
-                        if (q & 1) w1 = fma(a[q], vreg[q], w1); else w0 = fma(a[q], vreg[q], w0);
-                    }
-                }
+                for (int q = 0; q < CAR_CQ; ++q) { if (q & 1) w1 = fma(a0[q], vreg[q], w1); else w0 = fma(a0[q], vreg[q], w0); }
                 const double t = tau * row16_sum(w0 + w1);
 #pragma unroll
-                for (int q = 0; q < CAR_CQ - 1; ++q)
-                    if (q >= q0) row[16 * q] = fma(-t, vreg[q], a[q]);
-                if (l16 < NS - 16 * (CAR_CQ - 1)) row[16 * (CAR_CQ - 1)] = fma(-t, vreg[CAR_CQ - 1], a[CAR_CQ - 1]);
+                for (int q = 0; q < CAR_CQ; ++q) a0[q] = fma(-t, vreg[q], a0[q]);
+            }
+            if (R + 64 > i && R + 64 < m) {
+                double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+                for (int q = 0; q < CAR_CQ; ++q) { if (q & 1) w1 = fma(a1[q], vreg[q], w1); else w0 = fma(a1[q], vreg[q], w0); }
+                const double t = tau * row16_sum(w0 + w1);
+#pragma unroll
+                for (int q = 0; q < CAR_CQ; ++q) a1[q] = fma(-t, vreg[q], a1[q]);
+            }
+            if (C == ci) {                                             // publish column i
+                double x0 = 0.0, x1 = 0.0;
+                switch (qi) {                                          // uniform
+#define CAR_CASE(K) case K: x0 = a0[K]; x1 = a1[K]; break;
+                    CAR_CASE(0) CAR_CASE(1) CAR_CASE(2) CAR_CASE(3) CAR_CASE(4) CAR_CASE(5) CAR_CASE(6)
+                    CAR_CASE(7) CAR_CASE(8) CAR_CASE(9) CAR_CASE(10) CAR_CASE(11) CAR_CASE(12)
+#undef CAR_CASE
+                    default: break;
+                }
+                colb[R] = x0;
+                colb[R + 64] = x1;
             }
         }
         __syncthreads();
@@ -201,16 +218,16 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int r = i + 2 + lane + 64 * q;
-                const double x = A[(size_t)min(r, m - 1) * NS + i];
+                const double x = colb[min(r, 127)];
                 ureg[q] = (r < m) ? x : 0.0;
                 s2 = fma(ureg[q], ureg[q], s2);
             }
             s2 = wave_sum(s2);
             double beta2, tauq, sc2;
-            larfg(A[(size_t)(i + 1) * NS + i], s2, beta2, tauq, sc2);
+            larfg(colb[i + 1], s2, beta2, tauq, sc2);
             if (lane == 0) scal[0] = tauq;
-            // u~ over absolute row indices 0 .. 103: zeros up to row i, 1 at row i+1, u below, zeros from m on
-            for (int r = lane; r < 104; r += 64)
+            // u~ over absolute rows 0 .. 127: zeros up to row i, 1 at row i+1, u below, zeros from m on
+            for (int r = lane; r < 128; r += 64)
                 if (r <= i + 1 || r >= m) ubuf[r] = (r == i + 1) ? 1.0 : 0.0;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -219,34 +236,39 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
             }
         }
         __syncthreads();
-        {                                                              // (D) 8 columns per wave sweep
-            const double tauq = scal[0];
-            const int kk0 = (i + 1) >> 3;                              // 8-row blocks above row i+1: skip
-            const int kkf = m >> 3;                                    // blocks kk < kkf are complete (rows < m)
-            for (int cb = wave; cb * 8 < N - i - 1; cb += 16) {
-                const int c = min(i + 1 + cb * 8 + rid * 2 + c2, N - 1);   // clamped: duplicates are benign
-                double* colp = A + (size_t)g * NS + c;
-                double av[13];
-                double pa = 0.0, pb = 0.0;
+        const double u0 = ubuf[R], u1 = ubuf[R + 64];                  // (D)
 #pragma unroll
-                for (int kk = 0; kk < 13; ++kk) {
-                    if (kk >= kk0 && kk < kkf) {                       // uniform
-                        av[kk] = colp[(size_t)kk * 8 * NS];
-                        if (kk & 1) pb = fma(ubuf[g + 8 * kk], av[kk], pb); else pa = fma(ubuf[g + 8 * kk], av[kk], pa);
-                    }
-                }
-                double alast = 0.0;
-                const bool lastok = (kkf < 13) && (g + 8 * kkf < m);   // the one partial block, per lane
-                if (lastok) { alast = colp[(size_t)kkf * 8 * NS]; pa = fma(ubuf[g + 8 * kkf], alast, pa); }
-                const double t = tauq * grp8_sum(pa + pb);
+        for (int q = 0; q < CAR_CQ; ++q) zpart[R * 208 + C + 16 * q] = fma(u1, a1[q], u0 * a0[q]);
+        __syncthreads();
+        if (tid < 208) {
+            double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
 #pragma unroll
-                for (int kk = 0; kk < 13; ++kk)
-                    if (kk >= kk0 && kk < kkf) colp[(size_t)kk * 8 * NS] = fma(-t, ubuf[g + 8 * kk], av[kk]);
-                if (lastok) colp[(size_t)kkf * 8 * NS] = fma(-t, ubuf[g + 8 * kkf], alast);
+            for (int w = 0; w < 64; w += 4) {
+                z0 += zpart[(w + 0) * 208 + tid];
+                z1 += zpart[(w + 1) * 208 + tid];
+                z2 += zpart[(w + 2) * 208 + tid];
+                z3 += zpart[(w + 3) * 208 + tid];
             }
+            zsum[tid] = (z0 + z1) + (z2 + z3);
         }
         __syncthreads();
+        {
+            const double tq = scal[0];
+            const double f0 = tq * u0, f1 = tq * u1;
+#pragma unroll
+            for (int q = 0; q < CAR_CQ; ++q) {
+                const int c = C + 16 * q;
+                const double z = (c > i) ? zsum[c] : 0.0;              // H(i) acts on columns i+1 .. N-1 only
+                a0[q] = fma(-f0, z, a0[q]);
+                a1[q] = fma(-f1, z, a1[q]);
+            }
+        }
+        // (the next (A) touches registers and vbuf only; vbuf was last read before barrier 2)
     }
+    __threadfence_block();
+    __syncthreads();
+    // reflector vectors: global scratch -> LDS rows for phases 2 and 3
+    for (int t = tid; t < m * NS + CAR_PAD; t += CAR_T) A[t] = (t < m * NS) ? vws[t] : 0.0;
     __syncthreads();
 
     CAR_STAMP();
@@ -427,12 +449,20 @@ extern "C" int sober_car_supported(int N, int m) {
     return (m >= 2 && N > m && N <= 8 * sober::CAR_RP && N <= 16 * sober::CAR_CQ && m <= 100 && N - m <= 120) ? 1 : 0;
 }
 
+extern "C" int64_t sober_car_ws_bytes(int N, int m) {
+    (void)N;
+    return (int64_t)m * 8 * sober::CAR_RP * (int64_t)sizeof(double);
+}
+
 extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
                                 int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
-                                double* phi_out, void* stream) {
-    if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || ldx < m - 1) return SOBER_E_ARG;
+                                double* phi_out, void* ws, int64_t ws_bytes, void* stream) {
+    if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || !ws || ldx < m - 1) return SOBER_E_ARG;
     if (!sober_car_supported(N, m)) return SOBER_E_DIM;
-    size_t doubles = (size_t)m * (8 * sober::CAR_RP) + sober::CAR_PAD + (size_t)m + 104 + 8;
+    if (ws_bytes < sober_car_ws_bytes(N, m)) return SOBER_E_WS;
+    size_t base = (size_t)m * (8 * sober::CAR_RP) + sober::CAR_PAD;
+    if (base < (size_t)sober::CAR_P1) base = sober::CAR_P1;
+    size_t doubles = base + (size_t)m + 8;
     if (doubles < 4 * 264 + 8) doubles = 4 * 264 + 8;
     const size_t bytes = doubles * sizeof(double);
     static bool attr_set = false;
@@ -442,7 +472,7 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
         attr_set = true;
     }
     hipLaunchKernelGGL(sober::k_car, dim3(1), dim3(sober::CAR_T), bytes, (hipStream_t)stream, X, ldx, N, m,
-                       mu_in, keep_rank, w_star, n_keep, mu_out, phi_out);
+                       mu_in, keep_rank, w_star, n_keep, mu_out, phi_out, (double*)ws);
     LAUNCH_CHECK();
     return 0;
 }
