@@ -200,6 +200,15 @@ int64_t sober_kmeans_ws_bytes(int64_t N, int d, int K);
 int sober_kmeans_lloyd(const double* X, int64_t N, int d, int K, int iters,
                        double* centroids, int32_t* labels, void* ws, int64_t ws_bytes, void* stream);
 
+/* Posterior variance (and optionally the LFI weight pi) over a pool, SOBER/_gp.py:212-238 and
+ * SOBER/_pi.py:31-38: KX = k(X_obs, pool) (n_obs x N, sober_pairwise), V = W KX (sober_dgemm);
+ * var[j] = k(x_j, x_j) - sum_i KX[i][j] V[i][j] + noise; pi[j] = Phi((mean[j] - eta)/sqrt(var[j])),
+ * log_flag: log(pi + FP32 eps).  norms != NULL selects the Tanimoto k(x, x).                        */
+int sober_predict_finish(const double* KX, const double* V, int n_obs, int64_t N, int64_t ld,
+                         const double* mean, double kxx_const, const double* norms, double outputscale,
+                         double noise, double* var_out, double eta, double* lfi_out, int log_flag,
+                         void* stream);
+
 /* cleansing_weights of SOBER/_weights.py:21-38, in place: w < eps -> 0, inf/nan -> eps, then
  * normalise by the sum (or 1/n everywhere when the sum is 0).  ws: sober_reduce_ws_bytes(n).     */
 int64_t sober_reduce_ws_bytes(int64_t n);

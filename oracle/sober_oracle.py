@@ -142,6 +142,46 @@ def predict_mean(x, spec: GPSpec):
     return spec.mean_const + base_kernel(spec, x, spec.X_obs) @ spec.alpha
 
 
+def predict(x, spec: GPSpec):
+    """SOBER/_gp.py:212-238 -> (pred.mean, pred.variance) of likelihood(model(x)) for an exact GP
+    [upstream gpytorch exact prediction, parity unpinned; LOVE / fast_pred_var approximations are not
+    modelled]: mean = m + k(x,X) alpha, var = k(x,x) - diag(k(x,X) W k(X,x)) + noise."""
+    Kx = base_kernel(spec, x, spec.X_obs)
+    W, _, noise = get_cov_cache(spec)
+    mean = predict_mean(x, spec)
+    if spec.kind == TANIMOTO:
+        n2 = (x ** 2).sum(-1)
+        kxx = (n2 + 1e-6) / (1e-6 + n2) * spec.outputscale
+    elif spec.kind == MATERN52:                       # k(x, x): r = sqrt(clamp(0, 1e-30)) = 1e-15
+        r = 1e-15
+        kxx = (math.sqrt(5.0) * r + 1.0 + (5.0 / 3.0) * r ** 2) * math.exp(-math.sqrt(5.0) * r) * spec.outputscale
+    else:
+        kxx = spec.outputscale
+    var = kxx - ((Kx @ W) * Kx).sum(-1) + noise
+    return mean, var
+
+
+class PI:
+    """SOBER/_pi.py:5-56 (label 'lfi'): pi(x) = Phi((mean(x) - eta) / sqrt(var(x))), eta = max posterior mean
+    at the observations."""
+
+    def __init__(self, spec: GPSpec, label="lfi"):
+        self.spec, self.label = spec, label
+        self.eta = predict(spec.X_obs, spec)[0].max().item()
+
+    def lfi(self, X_cand, log=False):
+        mu_pred, var_pred = predict(X_cand, self.spec)
+        lfi = torch.distributions.Normal(0, 1).cdf((mu_pred - self.eta) / var_pred.sqrt())
+        return (lfi + torch.finfo().eps).log() if log else lfi
+
+    def __call__(self, X_cand, log=False):
+        if self.label == "ts":
+            raise NotImplementedError("Not implemented yet")
+        elif self.label == "lfi":
+            return self.lfi(X_cand, log=log)
+        raise ValueError("Label should be either 'ts' or 'lfi'.")
+
+
 def weighted_covariance(x, y, spec: GPSpec):
     """SOBER/_kernel.py:33-47."""
     mu_x = predict_mean(x, spec)

@@ -10,8 +10,9 @@ from ._kernel import Kernel, KernelSpec, spec_from_model
 from ._rchq import rc_kernel_svd, recombination
 from ._weights import KMeans, WeightsStabiliser
 from ._sampler import RecombinationSampler
+from ._pi import PI, predict, predict_mean
 
 __all__ = ["setting_parameters", "TensorManager", "SafeTensorOperator", "Utils", "Kernel", "KernelSpec",
            "spec_from_model", "recombination", "rc_kernel_svd", "WeightsStabiliser", "KMeans",
-           "RecombinationSampler"]
+           "RecombinationSampler", "PI", "predict", "predict_mean"]
 __version__ = "0.1.0"

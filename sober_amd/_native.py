@@ -55,6 +55,7 @@ SIGNATURES = {
     "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_kmeans_ws_bytes": (_i64, [_i64, _i32, _i32]),
     "sober_kmeans_lloyd": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "sober_predict_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f64, _vp, _f64, _f64, _vp, _f64, _vp, _i32, _vp]),
     "sober_reduce_ws_bytes": (_i64, [_i64]),
     "sober_cleansing_weights": (_i32, [_vp, _i64, _f64, _vp, _i64, _vp]),
 }
@@ -312,6 +313,14 @@ def kmeans_lloyd(X, K, iters, centroids, labels):
     _req(X, torch.float64, "X"); _req(centroids, torch.float64, "centroids"); _req(labels, torch.int32, "labels")
     _check(load().sober_kmeans_lloyd(X.data_ptr(), N, d, K, iters, centroids.data_ptr(), labels.data_ptr(),
                                      None, 0, _stream(X)), "sober_kmeans_lloyd")
+
+
+def predict_finish(KX, V, mean, kxx_const, norms, outputscale, noise, var_out, eta=0.0, lfi_out=None, log=False):
+    n_obs, N = KX.shape
+    _check(load().sober_predict_finish(KX.data_ptr(), V.data_ptr(), n_obs, N, KX.stride(0), _ptr(mean),
+                                       float(kxx_const), _ptr(norms), float(outputscale), float(noise),
+                                       var_out.data_ptr(), float(eta), _ptr(lfi_out), int(bool(log)),
+                                       _stream(KX)), "sober_predict_finish")
 
 
 def cleansing_weights(w, eps):

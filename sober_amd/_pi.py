@@ -1,0 +1,93 @@
+"""GP prediction over a candidate pool and the LFI weight pi(x):
+`predict` (SOBER/_gp.py:212-238) and `PI` (SOBER/_pi.py:5-56) with the reference's names.
+
+    mean(x) = m + k(x, X_obs) alpha
+    var(x)  = k(x, x) - k(x, X_obs) W k(X_obs, x) + noise          (exact GP; LOVE is upstream-only)
+    pi(x)   = Phi((mean(x) - eta) / sqrt(var(x))),   eta = max_i mean(X_obs_i)
+
+The pool is processed in column chunks: KX = k(X_obs, chunk) by `sober_pairwise`, V = W KX on the
+FP64 matrix cores (`sober_dgemm`), the column-wise quadratic form and Phi in `sober_predict_finish`.
+"""
+import math
+
+import torch
+
+from . import _native as nat
+from ._kernel import posterior_mean, prepare_points, spec_from_model, woodbury
+
+CHUNK = 1 << 18
+
+
+def _kxx_const(spec):
+    if spec.kind == "rbf":
+        return spec.outputscale
+    if spec.kind == "matern52":                           # r = sqrt(clamp_min(0, 1e-30)) = 1e-15
+        r = 1e-15
+        return (math.sqrt(5.0) * r + 1.0 + (5.0 / 3.0) * r * r) * math.exp(-math.sqrt(5.0) * r) * spec.outputscale
+    return 0.0                                            # tanimoto: per point, from the popcounts
+
+
+def _predict(spec, X, eta=None, log=False):
+    dev = X.device
+    kind = nat.KIND_BY_NAME[spec.kind]
+    pobs = prepare_points(spec, spec.X_obs)
+    W = woodbury(spec)
+    n_obs, N = len(pobs), X.shape[0]
+    mean = torch.empty(N, dtype=torch.float64, device=dev)
+    var = torch.empty(N, dtype=torch.float64, device=dev)
+    lfi = torch.empty(N, dtype=torch.float64, device=dev) if eta is not None else None
+    for lo in range(0, N, CHUNK):
+        hi = min(N, lo + CHUNK)
+        pts = prepare_points(spec, X[lo:hi])
+        n = hi - lo
+        mean[lo:hi] = posterior_mean(spec, pts)
+        KX = torch.empty(n_obs, n, dtype=torch.float64, device=dev)
+        nat.pairwise(kind, pobs.data, pobs.norm, pts.data, pts.norm, None, n, pts.dt, spec.outputscale, KX)
+        V = torch.empty_like(KX)
+        nat.dgemm(W, KX, V)
+        nat.predict_finish(KX, V, mean[lo:hi], _kxx_const(spec), pts.norm, spec.outputscale, spec.noise,
+                           var[lo:hi], 0.0 if eta is None else eta, None if lfi is None else lfi[lo:hi], log)
+    return mean, var, lfi
+
+
+def predict(test_x, model):
+    """SOBER/_gp.py:212-238 -> (pred.mean, pred.variance) on the device."""
+    spec = spec_from_model(model).to(test_x.device)
+    x = test_x.reshape(-1, test_x.shape[-1])
+    mean, var, _ = _predict(spec, x.to(torch.float64))
+    return mean.reshape(test_x.shape[:-1]), var.reshape(test_x.shape[:-1])
+
+
+def predict_mean(test_x, model):
+    """SOBER/_gp.py:240-253."""
+    return predict(test_x, model)[0]
+
+
+class PI:
+    """SOBER/_pi.py:5-56."""
+
+    def __init__(self, model, label="lfi"):
+        self.model = model
+        self.label = label
+        self.Xobs = spec_from_model(model).X_obs
+        self._spec = None
+        self.eta = None
+
+    def _prepare(self, device):
+        if self._spec is None or self._spec.X_obs.device != torch.device(device):
+            self._spec = spec_from_model(self.model).to(device)
+            m_obs, _, _ = _predict(self._spec, self._spec.X_obs)
+            self.eta = float(m_obs.max().item())          # current maximum (:17)
+        return self._spec
+
+    def lfi(self, X_cand, log=False):
+        spec = self._prepare(X_cand.device)
+        _, _, out = _predict(spec, X_cand.to(torch.float64), eta=self.eta, log=log)
+        return out
+
+    def __call__(self, X_cand, log=False):
+        if self.label == "ts":
+            raise NotImplementedError("Not implemented yet")
+        elif self.label == "lfi":
+            return self.lfi(X_cand, log=log)
+        raise ValueError("Label should be either 'ts' or 'lfi'.")

@@ -179,6 +179,38 @@ __global__ void k_i64_to_i32(const int64_t* __restrict__ in, int64_t n, int32_t*
     if (t < n) out[t] = (int32_t)in[t];
 }
 
+// ------------------------------------------------------------------ GP prediction over a pool
+// var[j] = kxx_j - sum_i KX[i][j] * V[i][j] + noise   with V = W KX  (SOBER/_gp.py:212-238, exact GP);
+// optionally pi[j] = Phi((mean[j] - eta) / sqrt(var[j]))  (SOBER/_pi.py:31-38), log variant adds FP32 eps.
+__global__ void k_predict_finish(const double* __restrict__ KX, const double* __restrict__ V, int n_obs,
+                                 int64_t N, int64_t ld, const double* __restrict__ mean, double kxx_const,
+                                 const double* __restrict__ norms, double outputscale, double noise,
+                                 double* __restrict__ var_out, double eta, double* __restrict__ lfi_out,
+                                 int log_flag) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    double q0 = 0.0, q1 = 0.0;
+    int i = 0;
+    for (; i + 1 < n_obs; i += 2) {
+        q0 = fma(KX[(size_t)i * ld + j], V[(size_t)i * ld + j], q0);
+        q1 = fma(KX[(size_t)(i + 1) * ld + j], V[(size_t)(i + 1) * ld + j], q1);
+    }
+    if (i < n_obs) q0 = fma(KX[(size_t)i * ld + j], V[(size_t)i * ld + j], q0);
+    double kxx = kxx_const;
+    if (norms != nullptr) {                                   // Tanimoto: k(x, x) = (|x|^2 + eps) / (eps + |x|^2)
+        const double n2 = norms[j];
+        kxx = (n2 + 1e-6) / (1e-6 + n2) * outputscale;
+    }
+    const double var = kxx - (q0 + q1) + noise;
+    var_out[j] = var;
+    if (lfi_out != nullptr) {
+        const double z = (mean[j] - eta) / sqrt(var);
+        double p = 0.5 * erfc(-z * 0.70710678118654752440);
+        if (log_flag) p = log(p + 1.1920928955078125e-07);     // + torch.finfo().eps (FP32 eps, quirk Q5)
+        lfi_out[j] = p;
+    }
+}
+
 // ------------------------------------------------------------------ cleansing_weights
 constexpr int CW_BLOCKS = 256, CW_THREADS = 256;
 
@@ -381,6 +413,18 @@ extern "C" int sober_scatter_weights(const int32_t* idx_cur, const int32_t* sel,
 extern "C" int sober_i64_to_i32(const int64_t* in, int64_t n, int32_t* out, void* stream) {
     if (!in || !out || n <= 0) return SOBER_E_ARG;
     hipLaunchKernelGGL(k_i64_to_i32, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, in, n, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_predict_finish(const double* KX, const double* V, int n_obs, int64_t N, int64_t ld,
+                                    const double* mean, double kxx_const, const double* norms,
+                                    double outputscale, double noise, double* var_out, double eta,
+                                    double* lfi_out, int log_flag, void* stream) {
+    if (!KX || !V || !var_out || n_obs <= 0 || N <= 0 || ld < N) return SOBER_E_ARG;
+    if (lfi_out && !mean) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_predict_finish, dim3(nblk(N, 256)), dim3(256), 0, (hipStream_t)stream, KX, V, n_obs, N, ld,
+                       mean, kxx_const, norms, outputscale, noise, var_out, eta, lfi_out, log_flag);
     LAUNCH_CHECK();
     return 0;
 }

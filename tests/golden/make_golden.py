@@ -69,7 +69,7 @@ def load_reference():
     pkg.__path__ = [REF]
     sys.modules["SOBER"] = pkg
     out = {}
-    for name in ("_settings", "_utils", "_weights", "_rchq", "_gp", "_kernel"):
+    for name in ("_settings", "_utils", "_weights", "_rchq", "_gp", "_kernel", "_pi"):
         spec = importlib.util.spec_from_file_location(f"SOBER.{name}", f"{REF}/{name}.py")
         m = importlib.util.module_from_spec(spec)
         sys.modules[f"SOBER.{name}"] = m
@@ -82,6 +82,7 @@ def load_reference():
 class _Pred:
     def __init__(self, mean, variance):
         self.mean, self.variance = mean, variance
+        self.loc = mean
 
 
 class _Lik:
@@ -110,8 +111,8 @@ class DuckModel:
         return self
 
     def __call__(self, x):
-        mean = O.predict_mean(x, self.spec)
-        return _Pred(mean, torch.zeros_like(mean))
+        mean, var = O.predict(x, self.spec)
+        return _Pred(mean, var - self.spec.noise)            # latent variance; the likelihood adds the noise
 
 
 CASES = [
@@ -361,8 +362,30 @@ def gen_kernel_calls(ref):
     np.savez_compressed(os.path.join(HERE, "kernel_calls.npz"), **out)
 
 
+def gen_pi(ref):
+    """PI.lfi / PI.__call__ of SOBER/_pi.py and predict of SOBER/_gp.py:212-238 through the duck model."""
+    import torch as _torch
+    ref["_pi"].torch = _torch                 # _pi.py uses torch without importing it (SURVEY 2)
+    out = {}
+    for kind in (O.RBF, O.MATERN52, O.TANIMOTO):
+        case = dict(kind=kind, N=400, M=10, d=24 if kind == O.TANIMOTO else 4, n_obs=15, seed=600, ard=True,
+                    mean_const=0.25, outputscale=1.4)
+        inp = synth(case)
+        spec = build_spec(case, inp)
+        model = DuckModel(spec)
+        pi = ref["_pi"].PI(model, label="lfi")
+        X = torch.from_numpy(inp["X_cand"])
+        mean, var = ref["_gp"].predict(X, model)
+        out.update({f"{kind}_X": inp["X_cand"], f"{kind}_X_obs": inp["X_obs"], f"{kind}_S_cache": spec.S_cache.numpy(),
+                    f"{kind}_alpha": spec.alpha.numpy(), f"{kind}_ls": spec.lengthscale.numpy(),
+                    f"{kind}_mean": mean.numpy(), f"{kind}_var": var.numpy(), f"{kind}_eta": pi.eta,
+                    f"{kind}_lfi": pi(X).numpy(), f"{kind}_loglfi": pi(X, log=True).numpy()})
+    np.savez_compressed(os.path.join(HERE, "pi.npz"), **out)
+
+
 if __name__ == "__main__":
     ref = load_reference()
+    gen_pi(ref)
     gen_tanimoto()
     gen_kernel_calls(ref)
     gen_psd(ref)

@@ -531,3 +531,51 @@ def test_arbitrary_callable_kernel(dev):
     np.testing.assert_allclose(w.cpu().numpy(), z["w"], rtol=W_RTOL)
     nz = torch.nonzero(mu.cpu()).flatten().numpy()
     assert np.array_equal(nz, z["mu_after_idx"])
+
+
+# --------------------------------------------------------------------------- #
+# GP prediction over the pool and the LFI weights
+# --------------------------------------------------------------------------- #
+def test_predict_and_pi_vs_reference(dev):
+    z = np.load(os.path.join(GOLD, "pi.npz"))
+    for kind in (O.RBF, O.MATERN52, O.TANIMOTO):
+        ks = sober_amd.KernelSpec(kind, _t(z[f"{kind}_ls"]), 1.4, _t(z[f"{kind}_X_obs"]), _t(z[f"{kind}_S_cache"]),
+                                  1e-2, 0.25, _t(z[f"{kind}_alpha"]))
+        X = _t(z[f"{kind}_X"]).to(dev)
+        mean, var = sober_amd.predict(X, ks)
+        np.testing.assert_allclose(mean.cpu().numpy(), z[f"{kind}_mean"], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(var.cpu().numpy(), z[f"{kind}_var"], rtol=1e-10, atol=1e-13)
+        pi = sober_amd.PI(ks)
+        out = pi(X)
+        assert abs(pi.eta - float(z[f"{kind}_eta"])) < 1e-12
+        np.testing.assert_allclose(out.cpu().numpy(), z[f"{kind}_lfi"], rtol=1e-9, atol=1e-15)
+        np.testing.assert_allclose(pi(X, log=True).cpu().numpy(), z[f"{kind}_loglfi"], rtol=1e-9, atol=1e-12)
+        m3, v3 = sober_amd.predict(X.reshape(20, 20, -1), ks)                     # 3-D inputs like _kernel.py:41
+        assert m3.shape == (20, 20) and torch.equal(m3.reshape(-1), mean)
+    with pytest.raises(NotImplementedError):
+        sober_amd.PI(ks, "ts")(X)
+    with pytest.raises(ValueError):
+        sober_amd.PI(ks, "nope")(X)
+
+
+def test_pi_weights_feed_recombination(dev):
+    """The step before the hot path (SOBER/_sampler.py:173-187): w = pi(x) / prior.pdf(x), scrubbed, then
+    recombined -- all on the device, against the same pipeline on the oracle."""
+    rng = np.random.default_rng(31)
+    N, M, d, b, n_obs = 4000, 100, 4, 12, 40
+    X = rng.random((N, d)); Xo = rng.random((n_obs, d))
+    spec = O.make_spec(O.RBF, _t(Xo), _t(0.3 * np.ones(d)), outputscale=1.2, y_obs=_t(rng.standard_normal(n_obs)),
+                       mean_const=0.1)
+    w_ref = O.cleansing_weights(O.PI(spec)(_t(X)) / 1.0)                          # uniform prior pdf = 1
+    ks = kspec(spec)
+    w = sober_amd.WeightsStabiliser().cleansing_weights(sober_amd.PI(ks)(_t(X).to(dev)))
+    np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=1e-8, atol=1e-18)
+    Xn = X[:M].copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(3)
+        idx_ref, wr = O.recombination(_t(X), _t(Xn), b, O.Kernel(spec), init_weights=w_ref.clone())
+        torch.manual_seed(3)
+        idx, ww = sober_amd.recombination(_t(X).to(dev), _t(Xn).to(dev), b, sober_amd.Kernel(ks), init_weights=w)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref.numpy())
+    np.testing.assert_allclose(ww.cpu().numpy(), wr.numpy(), rtol=1e-6)

@@ -157,3 +157,22 @@ def test_weights_match_reference():
     assert np.array_equal(O.weighted_resampling(_t(w), 40).numpy(), z["c_idx_weighted"])
     assert O.check_weights(_t(z["c_in"])) == bool(z["check_true"])
     assert O.check_weights(_t(np.r_[np.ones(10), np.zeros(5)])) == bool(z["check_false"])
+
+
+def test_pi_and_predict_match_reference():
+    """SOBER/_pi.py (PI.lfi, eta) and SOBER/_gp.py:predict through the duck model."""
+    z = np.load(os.path.join(GOLD, "pi.npz"))
+    for kind in (O.RBF, O.MATERN52, O.TANIMOTO):
+        spec = O.GPSpec(kind, _t(z[f"{kind}_ls"]), 1.4, _t(z[f"{kind}_X_obs"]), _t(z[f"{kind}_S_cache"]),
+                        1e-2, 0.25, _t(z[f"{kind}_alpha"]))
+        X = _t(z[f"{kind}_X"])
+        mean, var = O.predict(X, spec)
+        assert np.array_equal(mean.numpy(), z[f"{kind}_mean"]) and np.array_equal(var.numpy(), z[f"{kind}_var"])
+        pi = O.PI(spec)
+        assert pi.eta == float(z[f"{kind}_eta"])
+        assert np.array_equal(pi(X).numpy(), z[f"{kind}_lfi"])
+        assert np.array_equal(pi(X, log=True).numpy(), z[f"{kind}_loglfi"])
+    with pytest.raises(NotImplementedError):
+        O.PI(spec, "ts")(X)
+    with pytest.raises(ValueError):
+        O.PI(spec, "nope")(X)
