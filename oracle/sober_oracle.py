@@ -545,3 +545,51 @@ def make_spec(kind, X_obs, lengthscale, outputscale=1.0, noise=1e-2, mean_const=
     if y_obs is not None:
         spec.alpha = (spec.S_cache @ spec.S_cache.T) @ (y_obs - mean_const)
     return spec
+
+
+# --------------------------------------------------------------------------- #
+# WKDE prior  (SOBER/_wkde.py)
+# --------------------------------------------------------------------------- #
+def wkde_fit(X, Y, n_dims, n_kde=4096, bw_method="scott"):
+    """WeightedKernelDensityEstimation.initialisation, SOBER/_wkde.py:52-80, set_bandwidth 87-96,
+    _compute_covariance 98-108.  WeightsStabiliser(eps=0, thresh=n_kde).  Consumes the global CPU
+    generator exactly like the reference (torch.multinomial in deweighted_resampling)."""
+    n_kde_init = min(n_kde, len(X))
+    nk = n_kde_init
+    if not (Y.sum() == 0) and not (len(Y.unique()) < n_kde):          # check_weights with thresh = n_kde
+        idx = weighted_resampling(cleansing_weights(1 / Y, eps=0), nk)
+    else:
+        idx = torch.arange(Y.size(0))[cleansing_weights(Y, eps=0) > 0]
+        nk = len(idx)
+        if nk < 1:
+            raise ValueError("Invalid weights")
+        elif nk > n_kde_init:
+            nk = n_kde_init
+            idx = weighted_resampling(cleansing_weights(1 / Y, eps=0), nk)
+    Xobs = X[idx]
+    weights = cleansing_weights(Y[idx], eps=0)
+    neff = 1.0 / (weights ** 2).sum()
+    if bw_method == "scott":
+        bw = neff.pow(-1.0 / (n_dims + 4))
+    else:
+        bw = (neff * (n_dims + 2.0) / 4.0).pow(-1.0 / (n_dims + 4))
+    mean = weights @ Xobs
+    resid = Xobs - mean.unsqueeze(0)
+    data_cov = (resid.T * weights.unsqueeze(0)) @ resid
+    data_cov /= 1 - weights.pow(2).sum()
+    cov = make_cov_psd(data_cov * bw.pow(2))
+    return Xobs, weights, cov, bw
+
+
+def wkde_pdf(Xobs, weights, cov, X, bounds=None):
+    """WeightedKernelDensityEstimation.pdf, SOBER/_wkde.py:109-145 (compute_cdf=False): materialises the
+    (n_X * n_kde, d) differences like the reference."""
+    from torch.distributions.multivariate_normal import MultivariateNormal
+    n_X, n_kde, d = len(X), len(Xobs), X.shape[1]
+    x_AA = (Xobs.repeat(n_X, 1, 1) - X.unsqueeze(1)).reshape(int(n_kde * n_X), d)
+    mvn = MultivariateNormal(torch.zeros(d, dtype=X.dtype), make_cov_psd(cov))
+    Npdfs = mvn.log_prob(x_AA).exp().reshape(n_X, n_kde)
+    if bounds is not None:
+        Npdfs[(X < bounds[0]).any(axis=1)] = 0
+        Npdfs[(X > bounds[1]).any(axis=1)] = 0
+    return weights @ Npdfs.T

@@ -11,8 +11,10 @@ from ._rchq import rc_kernel_svd, recombination
 from ._weights import KMeans, WeightsStabiliser
 from ._sampler import RecombinationSampler
 from ._pi import PI, predict, predict_mean
+from ._wkde import WeightedKernelDensityEstimation
 
 __all__ = ["setting_parameters", "TensorManager", "SafeTensorOperator", "Utils", "Kernel", "KernelSpec",
            "spec_from_model", "recombination", "rc_kernel_svd", "WeightsStabiliser", "KMeans",
-           "RecombinationSampler", "PI", "predict", "predict_mean"]
+           "RecombinationSampler", "PI", "predict", "predict_mean",
+           "WeightedKernelDensityEstimation"]
 __version__ = "0.1.0"

@@ -383,8 +383,47 @@ def gen_pi(ref):
     np.savez_compressed(os.path.join(HERE, "pi.npz"), **out)
 
 
+def gen_wkde(ref):
+    """WeightedKernelDensityEstimation of SOBER/_wkde.py: construction (seeded) + pdf, with and without bounds."""
+    import abc
+    prior = types.ModuleType("SOBER._prior")
+    TM = ref["_utils"].TensorManager
+
+    class BasePrior(abc.ABC, TM):                      # SOBER/_prior.py:12-24 needs _tmvn/mvnorm: stub the base only
+        def __init__(self):
+            TM.__init__(self)
+    prior.BasePrior = BasePrior
+    sys.modules["SOBER._prior"] = prior
+    mv = types.ModuleType("SOBER.mvnorm")
+    mv.multivariate_normal_cdf = None
+    sys.modules["SOBER.mvnorm"] = mv
+    spec = importlib.util.spec_from_file_location("SOBER._wkde", f"{REF}/_wkde.py")
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["SOBER._wkde"] = m
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(700)
+    out = {}
+    for tag, d, n, n_kde, bounded in (("a", 3, 3000, 256, True), ("b", 5, 800, 4096, False)):
+        X = rng.random((n, d))
+        W = rng.random(n) ** 3
+        bounds = torch.tensor([[0.0] * d, [1.0] * d], dtype=torch.double) if bounded else None
+        torch.manual_seed(11)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            kde = m.WeightedKernelDensityEstimation(torch.from_numpy(X.copy()), torch.from_numpy(W.copy()), d,
+                                                    bounds=bounds, n_kde=n_kde)
+            Xq = rng.random((500, d)) * 1.2 - 0.1
+            pdf = kde.pdf(torch.from_numpy(Xq))
+        out.update({f"{tag}_X": X, f"{tag}_W": W, f"{tag}_n_kde": n_kde, f"{tag}_bounded": bounded,
+                    f"{tag}_Xobs": kde.Xobs.numpy(), f"{tag}_weights": kde.weights.numpy(),
+                    f"{tag}_cov": kde.covariance.numpy(), f"{tag}_bw": float(kde.bw), f"{tag}_Xq": Xq,
+                    f"{tag}_pdf": pdf.numpy()})
+    np.savez_compressed(os.path.join(HERE, "wkde.npz"), **out)
+
+
 if __name__ == "__main__":
     ref = load_reference()
+    gen_wkde(ref)
     gen_pi(ref)
     gen_tanimoto()
     gen_kernel_calls(ref)

@@ -127,3 +127,22 @@ def test_no_cpu_fallback():
         sober_amd.KMeans(x, 4)
     with pytest.raises(RuntimeError):
         sober_amd.WeightsStabiliser().cleansing_weights(torch.rand(8, dtype=torch.double))
+
+
+def test_wkde_fit_matches_reference():
+    """Host-side fit of sober_amd.WeightedKernelDensityEstimation (no GPU needed) against the golden."""
+    z = np.load(os.path.join(GOLD, "wkde.npz"))
+    for tag in "ab":
+        d = z[f"{tag}_X"].shape[1]
+        bounds = torch.tensor([[0.0] * d, [1.0] * d], dtype=torch.double) if bool(z[f"{tag}_bounded"]) else None
+        torch.manual_seed(11)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            kde = sober_amd.WeightedKernelDensityEstimation(_t(z[f"{tag}_X"].copy()), _t(z[f"{tag}_W"].copy()), d,
+                                                            bounds=bounds, n_kde=int(z[f"{tag}_n_kde"]))
+        assert np.array_equal(kde.Xobs.numpy(), z[f"{tag}_Xobs"])
+        assert np.array_equal(kde.weights.numpy(), z[f"{tag}_weights"])
+        np.testing.assert_allclose(kde.covariance.numpy(), z[f"{tag}_cov"], rtol=1e-13)
+        assert abs(float(kde.bw) - float(z[f"{tag}_bw"])) < 1e-15
+        with pytest.raises(RuntimeError):
+            kde.pdf(_t(z[f"{tag}_Xq"]))                       # CPU tensor: no fallback

@@ -579,3 +579,24 @@ def test_pi_weights_feed_recombination(dev):
         idx, ww = sober_amd.recombination(_t(X).to(dev), _t(Xn).to(dev), b, sober_amd.Kernel(ks), init_weights=w)
     assert np.array_equal(idx.cpu().numpy(), idx_ref.numpy())
     np.testing.assert_allclose(ww.cpu().numpy(), wr.numpy(), rtol=1e-6)
+
+
+# --------------------------------------------------------------------------- #
+# WKDE prior density
+# --------------------------------------------------------------------------- #
+def test_wkde_pdf_vs_reference(dev):
+    z = np.load(os.path.join(GOLD, "wkde.npz"))
+    for tag in "ab":
+        d = z[f"{tag}_X"].shape[1]
+        bounds = torch.tensor([[0.0] * d, [1.0] * d], dtype=torch.double) if bool(z[f"{tag}_bounded"]) else None
+        torch.manual_seed(11)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            kde = sober_amd.WeightedKernelDensityEstimation(_t(z[f"{tag}_X"].copy()), _t(z[f"{tag}_W"].copy()), d,
+                                                            bounds=bounds, n_kde=int(z[f"{tag}_n_kde"]))
+        pdf = kde.pdf(_t(z[f"{tag}_Xq"]).to(dev))
+        np.testing.assert_allclose(pdf.cpu().numpy(), z[f"{tag}_pdf"], rtol=1e-10, atol=1e-300)
+        assert np.array_equal(pdf.cpu().numpy() == 0, z[f"{tag}_pdf"] == 0)          # bounds mask
+        lp = kde.logpdf(_t(z[f"{tag}_Xq"]).to(dev)).cpu().numpy()
+        m = z[f"{tag}_pdf"] > 0
+        np.testing.assert_allclose(lp[m], np.log(z[f"{tag}_pdf"][m]), rtol=1e-9, atol=1e-10)

@@ -176,3 +176,20 @@ def test_pi_and_predict_match_reference():
         O.PI(spec, "ts")(X)
     with pytest.raises(ValueError):
         O.PI(spec, "nope")(X)
+
+
+def test_wkde_matches_reference():
+    """SOBER/_wkde.py: fit (seeded component selection, bandwidth, covariance) and pdf."""
+    z = np.load(os.path.join(GOLD, "wkde.npz"))
+    for tag in "ab":
+        d = z[f"{tag}_X"].shape[1]
+        torch.manual_seed(11)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Xobs, w, cov, bw = O.wkde_fit(_t(z[f"{tag}_X"].copy()), _t(z[f"{tag}_W"].copy()), d,
+                                          n_kde=int(z[f"{tag}_n_kde"]))
+            assert np.array_equal(Xobs.numpy(), z[f"{tag}_Xobs"]) and np.array_equal(w.numpy(), z[f"{tag}_weights"])
+            assert np.array_equal(cov.numpy(), z[f"{tag}_cov"]) and float(bw) == float(z[f"{tag}_bw"])
+            bounds = torch.tensor([[0.0] * d, [1.0] * d], dtype=torch.double) if bool(z[f"{tag}_bounded"]) else None
+            pdf = O.wkde_pdf(Xobs, w, cov, _t(z[f"{tag}_Xq"]), bounds)
+        assert np.array_equal(pdf.numpy(), z[f"{tag}_pdf"])
