@@ -14,6 +14,8 @@ for it in range(5):
     torch.cuda.synchronize()
     st = ph.view(torch.int64).flatten()[:8].cpu().numpy()
     cyc = np.diff(st[0::2]); rt = np.diff(st[1::2])
+    sub = ph.view(torch.int64).flatten()[16:22].cpu().numpy()
+    if sub.sum() > 0: print("phase-1 sub-phases (wave 0 cycles): A+bar, B+bar, C+bar, D1+bar, D2+bar, D3:", sub, "per step", sub / 100.0)
     print("cycles phase1/2/3:", cyc, " realtime(100MHz ticks):", rt, " => us:", rt / 100.0, " clock GHz:", cyc.sum() / (rt.sum() / 100.0) / 1e3)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

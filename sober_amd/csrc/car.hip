@@ -50,6 +50,10 @@ __device__ __forceinline__ double dpp(double v) {
 #endif
 constexpr int ROR1 = 0x121, ROR2 = 0x122, ROR4 = 0x124, ROR8 = 0x128;
 
+// workgroup barrier that waits for this wave's LDS traffic only: global stores (the reflector vectors
+// going to scratch) keep draining in the background instead of stalling every step
+#define CAR_LDS_BARRIER() do { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); } while (0)
+
 __device__ __forceinline__ double row16_sum(double v) {   // every lane of a 16-lane row gets the row total
     v += dpp<ROR8>(v);
     v += dpp<ROR4>(v);
@@ -148,6 +152,12 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
         a0[q] = (okc && R < m) ? ((R == 0) ? 1.0 : X[(size_t)c * ldx + (R - 1)]) : 0.0;
         a1[q] = (okc && R + 64 < m) ? X[(size_t)c * ldx + (R + 63)] : 0.0;
     }
+#ifdef CAR_STAMPS2
+    unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+#define CAR_SUB(K) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_[K] += t_ - tl_; tl_ = t_; } while (0)
+#else
+#define CAR_SUB(K) do { } while (0)
+#endif
     for (int i = 0; i < m; ++i) {
         const bool hi = i >= 64;                         // row i is the a1 (hi) or a0 row of DPP row (i & 63)
         const int qi = i >> 4, ci = i & 15;              // column i = lane ci, slot qi
@@ -176,7 +186,8 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
 #undef CAR_STEP_A
         }
         if (i == m - 1) break;
-        __syncthreads();
+        CAR_LDS_BARRIER();
+        CAR_SUB(0);
         {                                                              // (B)
             const double tau = scal[1];
             double vreg[CAR_CQ];
@@ -211,7 +222,8 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                 colb[R + 64] = x1;
             }
         }
-        __syncthreads();
+        CAR_LDS_BARRIER();
+        CAR_SUB(1);
         if (wave == 0) {                                               // (C)
             double ureg[2];
             double s2 = 0.0;
@@ -235,23 +247,28 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                 if (r < m) ubuf[r] = ureg[q] * sc2;
             }
         }
-        __syncthreads();
+        CAR_LDS_BARRIER();
+        CAR_SUB(2);
         const double u0 = ubuf[R], u1 = ubuf[R + 64];                  // (D)
 #pragma unroll
         for (int q = 0; q < CAR_CQ; ++q) zpart[R * 208 + C + 16 * q] = fma(u1, a1[q], u0 * a0[q]);
-        __syncthreads();
-        if (tid < 208) {
-            double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+        CAR_LDS_BARRIER();
+        CAR_SUB(3);
+        if (tid < 832) {                                               // 4 lanes per column, 16 partials each
+            const int cc = tid >> 2, part = tid & 3;
+            double z0 = 0.0, z1 = 0.0;
 #pragma unroll
-            for (int w = 0; w < 64; w += 4) {
-                z0 += zpart[(w + 0) * 208 + tid];
-                z1 += zpart[(w + 1) * 208 + tid];
-                z2 += zpart[(w + 2) * 208 + tid];
-                z3 += zpart[(w + 3) * 208 + tid];
+            for (int w = 0; w < 16; w += 2) {
+                z0 += zpart[(part * 16 + w) * 208 + cc];
+                z1 += zpart[(part * 16 + w + 1) * 208 + cc];
             }
-            zsum[tid] = (z0 + z1) + (z2 + z3);
+            double zz = z0 + z1;
+            zz += dpp<0xB1>(zz);                                       // quad_perm [1,0,3,2]
+            zz += dpp<0x4E>(zz);                                       // quad_perm [2,3,0,1]
+            if (part == 0) zsum[cc] = zz;
         }
-        __syncthreads();
+        CAR_LDS_BARRIER();
+        CAR_SUB(4);
         {
             const double tq = scal[0];
             const double f0 = tq * u0, f1 = tq * u1;
@@ -264,7 +281,9 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
             }
         }
         // (the next (A) touches registers and vbuf only; vbuf was last read before barrier 2)
+        CAR_SUB(5);
     }
+
     __threadfence_block();
     __syncthreads();
     // reflector vectors: global scratch -> LDS rows for phases 2 and 3
@@ -421,6 +440,9 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     CAR_STAMP();
 #ifdef CAR_STAMPS
     if (tid == 0 && phi_out != nullptr) for (int q = 0; q < 8; ++q) ((unsigned long long*)phi_out)[q] = st_[q];
+#endif
+#ifdef CAR_STAMPS2
+    if (tid == 0 && phi_out != nullptr) for (int q = 0; q < 6; ++q) ((unsigned long long*)phi_out)[16 + q] = acc_[q];
 #endif
     // ---------------- output: w_star = mu[mu > 0], idx_star as ranks ----------------
     if (wave == 0) {
