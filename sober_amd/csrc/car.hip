@@ -348,6 +348,12 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     }
     __syncthreads();
 
+#define CAR_AMIN_ROW(CTRL)                                                                 \
+        {                                                                                 \
+            const double ob_ = dpp<CTRL>(best_);                                          \
+            const int op_ = __builtin_amdgcn_update_dpp(0, piv_, CTRL, 0xf, 0xf, false);  \
+            amin_take(best_, piv_, ob_, op_);                                             \
+        }
     // ratio test on (column cp, weights held in mu4): first argmin of mu/Phi over Phi > 0 (NaN wins)
 #define CAR_RATIO_TEST(cp, outp)                                                          \
     {                                                                                     \
@@ -358,10 +364,13 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
             const bool ok = (r < N) & (ph > 0.0);                                         \
             amin_take(best_, piv_, mu4[q] / ph, ok ? r : -1);                             \
         }                                                                                 \
-        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) {                              \
-            const double ob = __shfl_xor(best_, o, 64);                                   \
-            const int op = __shfl_xor(piv_, o, 64);                                       \
-            amin_take(best_, piv_, ob, op);                                               \
+        CAR_AMIN_ROW(ROR8) CAR_AMIN_ROW(ROR4) CAR_AMIN_ROW(ROR2) CAR_AMIN_ROW(ROR1)       \
+        {                                                                                 \
+            double b0_ = rdlane(best_, 0); int p0_ = __builtin_amdgcn_readlane(piv_, 0);  \
+            amin_take(b0_, p0_, rdlane(best_, 16), __builtin_amdgcn_readlane(piv_, 16));  \
+            amin_take(b0_, p0_, rdlane(best_, 32), __builtin_amdgcn_readlane(piv_, 32));  \
+            amin_take(b0_, p0_, rdlane(best_, 48), __builtin_amdgcn_readlane(piv_, 48));  \
+            best_ = b0_; piv_ = p0_;                                                      \
         }                                                                                 \
         if (lane == 0) { (outp)[0] = best_; (outp)[1] = (double)piv_; }                   \
     }
