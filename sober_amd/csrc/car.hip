@@ -337,7 +337,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     const int NP = 264;                    // padded stride >= N + 64
     double* colbuf = lds;                  // [2][NP]   current / next pivot column (zero beyond N)
     double* mubuf = lds + 2 * NP;          // [2][NP]
-    double* pscal = lds + 4 * NP;          // [2][2]    (alpha, piv) of the current / next step
+    double* pscal = lds + 4 * NP;          // [2][4]    (alpha, piv, 1/Phi[piv,0]) of the current / next step
     for (int r = tid; r < 2 * NP; r += CAR_T) colbuf[r] = 0.0;
     __syncthreads();
     for (int r = tid; r < N; r += CAR_T) mubuf[r] = mu_in[r];
@@ -372,7 +372,8 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
             amin_take(b0_, p0_, rdlane(best_, 48), __builtin_amdgcn_readlane(piv_, 48));  \
             best_ = b0_; piv_ = p0_;                                                      \
         }                                                                                 \
-        if (lane == 0) { (outp)[0] = best_; (outp)[1] = (double)piv_; }                   \
+        if (lane == 0) { (outp)[0] = best_; (outp)[1] = (double)piv_;                     \
+                         (outp)[2] = 1.0 / (cp)[max(piv_, 0)]; }                          \
     }
     if (wave == 0) {
         double mu4[4];
@@ -385,8 +386,9 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
     int cur = 0;
     for (int s = 0; s < NC; ++s, cur ^= 1) {
         const double* cb = colbuf + cur * NP;
-        const double alpha = pscal[cur * 2];
-        const int piv = (int)pscal[cur * 2 + 1];
+        const double alpha = pscal[cur * 4];
+        const int piv = (int)pscal[cur * 4 + 1];
+        const double rpp = pscal[cur * 4 + 2];
         if (piv < 0) break;                                             // Q6 (:241-242), uniform
         const int kp = piv >> 3, gp = piv & 7;
         if (okcol && col > s) {
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
                 default: break;
             }
             const double prow = __shfl(mine, (lane & 0x30) | (gp << 1) | c2, 64);
-            const double qv = prow / cb[piv];
+            const double qv = prow * rpp;                               // Phi[idx,c] / Phi[idx,0]
             const double* cbg = cb + g;
 #pragma unroll
             for (int k = 0; k < CAR_RP; ++k) {
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
             }
             if (s + 1 < NC) {
                 const double* cn = colbuf + (cur ^ 1) * NP;            // written above by lanes of THIS wave
-                CAR_RATIO_TEST(cn, pscal + (cur ^ 1) * 2);
+                CAR_RATIO_TEST(cn, pscal + (cur ^ 1) * 4);
             }
         }
         __syncthreads();

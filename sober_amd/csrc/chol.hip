@@ -185,11 +185,14 @@ __global__ __launch_bounds__(1024) void k_chol_small(const double* __restrict__ 
         if (tid == 0) { L[j * LDS_ + j] = l; s_minp = fmin(s_minp, djj); }
         for (int i = j + 1 + tid; i < q; i += nt) L[i * LDS_ + j] /= l;
         __syncthreads();
-        // trailing update, lower triangle: element (i, c), j < c <= i
-        const int nrem = q - j - 1;
-        for (int t = tid; t < nrem * nrem; t += nt) {
-            const int i = j + 1 + t / nrem, c = j + 1 + t % nrem;
-            if (c <= i) L[i * LDS_ + c] = fma(-L[i * LDS_ + j], L[c * LDS_ + j], L[i * LDS_ + c]);
+        // trailing update, lower triangle: element (i, c), j < c <= i; 32 x 32 thread grid, no index division
+        {
+            const int ty = tid >> 5, tx = tid & 31;
+            for (int i = j + 1 + ty; i < q; i += 32) {
+                const double lij = L[i * LDS_ + j];
+                for (int c = j + 1 + tx; c <= i; c += 32)
+                    L[i * LDS_ + c] = fma(-lij, L[c * LDS_ + j], L[i * LDS_ + c]);
+            }
         }
         __syncthreads();
     }
