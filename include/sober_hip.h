@@ -154,6 +154,9 @@ int sober_i64_to_i32(const int64_t* in, int64_t n, int32_t* out, void* stream);
  * h_mu (N) is updated in place.  Same IEEE operation order as the reference's tensor expressions
  * (no FMA contraction).  Returns the number of pivots performed (< m when quirk Q6 fires).        */
 int sober_car_pivot_host(double* h_Phi, int N, int m, double* h_mu);
+/* Same loop with one division per column (q_c = Phi[idx,c]/Phi[idx,0]) instead of one per element: last-bit
+ * differences, ~6x faster; used for N > 200 (batch > 100), where the host route runs.               */
+int sober_car_pivot_host_fast(double* h_Phi, int N, int m, double* h_mu);
 
 /* DEVICE Caratheodory step (K5 + K6): the whole Tchernychova_Lyons_CAR of SOBER/_rchq.py:224-270 in
  * one persistent workgroup.  X (N, m-1) row-major barycentres (ld = ldx), mu_in (N) set masses.
@@ -185,8 +188,8 @@ int sober_cholesky_probe(const double* src, int n, int ld_src, const double* shi
  * triangular, zeros above).  info / min_pivot as above.                                              */
 int sober_chol_small(const double* G, int q, int ldg, double* Lout, int ldl, int32_t* info,
                      double* min_pivot, void* stream);
-/* Q[r, 0:q] = Y[r, 0:q] R^-1 with R = L^T (L lower triangular q x q, q <= 128): the Q factor of Y when
- * L L^T = Y^T Y.                                                                                    */
+/* Q[r, 0:q] = Y[r, 0:q] R^-1 with R = L^T (L lower triangular q x q, q <= 256; only its lower triangle
+ * is read): the Q factor of Y when L L^T = Y^T Y.                                                                                    */
 int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
                     double* Q, int ldq, void* stream);
 /* out = sqrt(nan_to_num(C) * nan_to_num(C)^T) elementwise (quirk Q2, SOBER/_utils.py:143-144);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "sober_scatter_weights": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sober_i64_to_i32": (_i32, [_vp, _i64, _vp, _vp]),
     "sober_car_pivot_host": (_i32, [_vp, _i32, _i32, _vp]),
+    "sober_car_pivot_host_fast": (_i32, [_vp, _i32, _i32, _vp]),
     "sober_car_supported": (_i32, [_i32, _i32]),
     "sober_car_ws_bytes": (_i64, [_i32, _i32]),
     "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -242,13 +243,14 @@ def i64_to_i32(src, dst):
            "sober_i64_to_i32")
 
 
-def car_pivot_host(Phi: torch.Tensor, mu: torch.Tensor) -> int:
+def car_pivot_host(Phi: torch.Tensor, mu: torch.Tensor, fast=None) -> int:
     """Host tensors (CPU, float64, contiguous).  Phi (N, m) is destroyed, mu updated in place."""
     if Phi.is_cuda or mu.is_cuda:
         raise SoberHipError("car_pivot_host takes host tensors")
     _req(Phi, torch.float64, "Phi"); _req(mu, torch.float64, "mu")
     N, m = Phi.shape
-    r = load().sober_car_pivot_host(Phi.data_ptr(), N, m, mu.data_ptr())
+    fn = load().sober_car_pivot_host_fast if (fast or (fast is None and N > 200)) else load().sober_car_pivot_host
+    r = fn(Phi.data_ptr(), N, m, mu.data_ptr())
     _check(min(r, 0), "sober_car_pivot_host")
     return r
 

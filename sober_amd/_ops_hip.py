@@ -116,7 +116,7 @@ class HipOps:
         import warnings
         dev, M = self.device, p.M
         G = self.gram(p)
-        if M > nat.chol_max_n() or s > 128 or s >= M:
+        if M > nat.chol_max_n() or s > 256 or s >= M:
             return None
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         C = torch.empty_like(G)
@@ -154,8 +154,12 @@ class HipOps:
         for it in range(2):
             Gm = torch.empty(q, q, dtype=torch.float64, device=self.device)
             nat.dgemm(Y, Y, Gm, transa=True)
-            Lc = torch.zeros(q, q, dtype=torch.float64, device=self.device)
-            nat.chol_small(Gm, Lc, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1])
+            if q <= 128:                                    # LDS-resident factorisation
+                Lc = torch.zeros(q, q, dtype=torch.float64, device=self.device)
+                nat.chol_small(Gm, Lc, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1])
+            else:                                           # blocked one-workgroup Cholesky, in place
+                Lc = Gm
+                nat.cholesky(Lc, 0.0, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1])
             Q = torch.empty_like(Y)
             nat.trsm_rows(Y, Lc, Q)                             # Q = Y R^-1, one wave per row
             Y = Q

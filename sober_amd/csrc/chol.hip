@@ -231,38 +231,47 @@ __device__ __forceinline__ double trsm_wsum(double v) {
     return ((a + b) + c) + d;
 }
 
+template <bool L_IN_LDS>
 __global__ __launch_bounds__(256) void k_trsm_rows(const double* __restrict__ Y, int64_t m, int q, int ldy,
                                                    const double* __restrict__ L, int ldl,
                                                    double* __restrict__ Q, int ldq) {
-    extern __shared__ double sl[];                   // q x (q+1)
-    const int LDL = q + 1;
-    for (int t = threadIdx.x; t < q * q; t += blockDim.x) {
-        const int i = t / q, j = t % q;
-        sl[i * LDL + j] = (j <= i) ? L[(size_t)i * ldl + j] : 0.0;
+    extern __shared__ double sl[];                   // q x (q+1) when L_IN_LDS (q <= 128)
+    const int LDL = L_IN_LDS ? q + 1 : ldl;
+    if constexpr (L_IN_LDS) {
+        for (int t = threadIdx.x; t < q * q; t += blockDim.x) {
+            const int i = t / q, j = t % q;
+            sl[i * LDL + j] = (j <= i) ? L[(size_t)i * ldl + j] : 0.0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    const double* Lp = L_IN_LDS ? sl : L;            // q <= 256: rows of L straight from L2
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= m) return;                              // whole wave
     const double* y = Y + r * ldy;
-    double x0 = 0.0, x1 = 0.0;                       // x[lane], x[lane + 64] (0 until solved)
-    const double y0 = (lane < q) ? y[lane] : 0.0;
-    const double y1 = (lane + 64 < q) ? y[lane + 64] : 0.0;
+    double x[4] = {0.0, 0.0, 0.0, 0.0};              // x[lane + 64 t] (0 until solved)
+    double yv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) yv[t] = (lane + 64 * t < q) ? y[lane + 64 * t] : 0.0;
     for (int j = 0; j < q; ++j) {
-        const double* lj = sl + j * LDL;             // row j of L: zero beyond column j
-        double part = x0 * lj[lane];
-        if (q > 64) part = fma(x1, (lane + 64 < q) ? lj[lane + 64] : 0.0, part);
-        const double dot = trsm_wsum(part);          // unsolved x are 0, L[j][k>j] are 0
-        const double yj = (j < 64) ? __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y0), j & 63),
-                                                      __builtin_amdgcn_readlane(__double2loint(y0), j & 63))
-                                   : __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y1), j & 63),
-                                                      __builtin_amdgcn_readlane(__double2loint(y1), j & 63));
+        const double* lj = Lp + (size_t)j * LDL;     // row j of L; entries right of the diagonal meet x = 0
+        double part = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (64 * t < q) part = fma(x[t], (lane + 64 * t <= j) ? lj[lane + 64 * t] : 0.0, part);
+        const double dot = trsm_wsum(part);
+        const int jt = j >> 6, jl = j & 63;
+        const double ysel = (jt == 0) ? yv[0] : (jt == 1) ? yv[1] : (jt == 2) ? yv[2] : yv[3];
+        const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ysel), jl),
+                                           __builtin_amdgcn_readlane(__double2loint(ysel), jl));
         const double xj = (yj - dot) / lj[j];
-        if (j < 64) x0 = (lane == j) ? xj : x0; else x1 = (lane + 64 == j) ? xj : x1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = (lane + 64 * t == j) ? xj : x[t];
     }
     double* o = Q + r * ldq;
-    if (lane < q) o[lane] = x0;
-    if (lane + 64 < q) o[lane + 64] = x1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (lane + 64 * t < q) o[lane + 64 * t] = x[t];
 }
 
 // cov -> sqrt(nan_to_num(cov) * nan_to_num(cov).T) (SOBER/_utils.py:143-144) and the exact-symmetry
@@ -334,16 +343,21 @@ extern "C" int sober_chol_small(const double* G, int q, int ldg, double* Rinv, i
 
 extern "C" int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl, double* Q,
                                int ldq, void* stream) {
-    if (!Y || !L || !Q || m <= 0 || q <= 0 || q > 128 || ldy < q || ldl < q || ldq < q) return SOBER_E_ARG;
-    const size_t bytes = (size_t)q * (q + 1) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_trsm_rows, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    140 * 1024));
-        attr_set = true;
+    if (!Y || !L || !Q || m <= 0 || q <= 0 || q > 256 || ldy < q || ldl < q || ldq < q) return SOBER_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((m + 3) / 4)), block(256);
+    if (q <= 128) {
+        const size_t bytes = (size_t)q * (q + 1) * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute((const void*)sober::k_trsm_rows<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(sober::k_trsm_rows<true>, grid, block, bytes, st, Y, m, q, ldy, L, ldl, Q, ldq);
+    } else {
+        hipLaunchKernelGGL(sober::k_trsm_rows<false>, grid, block, 0, st, Y, m, q, ldy, L, ldl, Q, ldq);
     }
-    hipLaunchKernelGGL(sober::k_trsm_rows, dim3((unsigned)((m + 3) / 4)), dim3(256), bytes, (hipStream_t)stream, Y,
-                       m, q, ldy, L, ldl, Q, ldq);
     LAUNCH_CHECK();
     return 0;
 }

@@ -473,6 +473,13 @@ def test_choleskyqr_and_abs_sym(dev):
     Qh = np.linalg.qr(Y)[0]                                                           # Householder reference
     sign = np.sign(np.sum(Q * Qh, axis=0))
     np.testing.assert_allclose(Q * sign, Qh, atol=1e-9)                               # same flag of subspaces
+    Y2 = rng.standard_normal((500, 199)) @ np.diag(np.logspace(0, -3, 199))           # q > 128: global-memory route
+    infos2 = torch.zeros(2, dtype=torch.int32, device=dev); pivs2 = torch.zeros(2, dtype=torch.float64, device=dev)
+    Q2 = ops._orth(_t(Y2).to(dev), infos2, pivs2, 0).cpu().numpy()
+    assert int(infos2.abs().sum()) == 0
+    np.testing.assert_allclose(Q2.T @ Q2, np.eye(199), atol=1e-13)
+    Qh2 = np.linalg.qr(Y2)[0]
+    np.testing.assert_allclose(Q2 * np.sign(np.sum(Q2 * Qh2, axis=0)), Qh2, atol=1e-9)
     C = rng.standard_normal((50, 50)); C[3, 4] = np.nan; C[7, 7] = np.inf
     out = torch.empty(50, 50, dtype=torch.float64, device=dev); flag = torch.zeros(1, dtype=torch.int32, device=dev)
     nat.abs_sym(_t(C).to(dev), out, flag)
