@@ -217,6 +217,14 @@ int sober_predict_finish(const double* KX, const double* V, int n_obs, int64_t N
 int64_t sober_reduce_ws_bytes(int64_t n);
 int sober_cleansing_weights(double* w, int64_t n, double eps, void* ws, int64_t ws_bytes, void* stream);
 
+/* Draws of the weighted KDE prior, SOBER/_wkde.py:162-219 (MultivariateNormal(X_c, Sigma).sample and the
+ * bounds test of rejection_sampling): x[r] = Xobs[comp[r]] + L eps[r] with L L^T = Sigma (d x d row-major,
+ * lower triangle read; d <= 64), inside[r] = 1 iff lo <= x[r] <= hi component-wise (lo = hi = NULL: no
+ * bounds, inside may be NULL).  eps: n x d standard normals supplied by the caller's generator.          */
+int sober_wkde_draw(const double* eps, int64_t n, int d, const int32_t* comp, const double* Xobs, int ldx,
+                    const double* L, const double* lo, const double* hi, double* x, int32_t* inside,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -593,3 +593,39 @@ def wkde_pdf(Xobs, weights, cov, X, bounds=None):
         Npdfs[(X < bounds[0]).any(axis=1)] = 0
         Npdfs[(X > bounds[1]).any(axis=1)] = 0
     return weights @ Npdfs.T
+
+
+def wkde_sample(Xobs, weights, cov, N_rec, bounds=None, n_repeat=10):
+    """WeightedKernelDensityEstimation.sample, SOBER/_wkde.py:221-248, with sample_from_Gaussian
+    (:189-219) and rejection_sampling (:162-187): component i contributes int(w_i N_rec) draws
+    (doubled when the truncated counts fall short), each a MultivariateNormal(X_i, cov) sample --
+    rejected outside the bounds, 10x oversampled per round, at most 10 rounds -- and the surplus is
+    thinned by torch.multinomial without replacement.  Consumes the global CPU generator in the
+    reference's order: one (cnt, d) [or (10 cnt, d) per round] normal draw per component."""
+    from torch.distributions.multivariate_normal import MultivariateNormal
+    cnts = weights * N_rec
+    cnt_kde = cnts.type(torch.int)
+    if cnt_kde.sum() < N_rec:
+        cnt_kde = (2 * cnts).type(torch.int)
+    parts = []
+    for i, cnt in enumerate(cnt_kde):
+        cnt = int(cnt)
+        if cnt == 0 or bool((cov == 0).all()):
+            continue
+        c = make_cov_psd(cov)
+        if bounds is None:
+            parts.append(MultivariateNormal(Xobs[i], c).sample(torch.Size([cnt])))
+            continue
+        got = torch.empty(0, Xobs.shape[1], dtype=Xobs.dtype)
+        for _ in range(n_repeat):
+            c = make_cov_psd(c)
+            raw = MultivariateNormal(Xobs[i], c).sample(torch.Size([int(n_repeat * cnt)]))
+            out = torch.logical_or((raw < bounds[0]).any(axis=1), (raw > bounds[1]).any(axis=1))
+            got = torch.cat([got, raw[out.logical_not()]])
+            if len(got) >= cnt:
+                break
+        parts.append(got[:cnt])
+    samples = torch.cat(parts) if parts else torch.empty(0, Xobs.shape[1], dtype=Xobs.dtype)
+    if len(samples) > N_rec:
+        samples = samples[torch.multinomial(torch.ones(len(samples), dtype=Xobs.dtype), N_rec)]
+    return samples

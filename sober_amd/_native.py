@@ -59,6 +59,7 @@ SIGNATURES = {
     "sober_predict_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f64, _vp, _f64, _f64, _vp, _f64, _vp, _i32, _vp]),
     "sober_reduce_ws_bytes": (_i64, [_i64]),
     "sober_cleansing_weights": (_i32, [_vp, _i64, _f64, _vp, _i64, _vp]),
+    "sober_wkde_draw": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -331,3 +332,12 @@ def cleansing_weights(w, eps):
     ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=w.device)
     _check(load().sober_cleansing_weights(w.data_ptr(), w.numel(), float(eps), ws.data_ptr(), nbytes,
                                           _stream(w)), "sober_cleansing_weights")
+
+
+def wkde_draw(eps, comp, Xobs, L, lo, hi, x, inside):
+    n, d = eps.shape
+    _check(load().sober_wkde_draw(eps.data_ptr(), n, d, comp.data_ptr(), Xobs.data_ptr(), Xobs.stride(0),
+                                  L.data_ptr(), lo.data_ptr() if lo is not None else None,
+                                  hi.data_ptr() if hi is not None else None, x.data_ptr(),
+                                  inside.data_ptr() if inside is not None else None, _stream(eps)),
+           "sober_wkde_draw")

@@ -10,8 +10,8 @@ factor of Sigma (one small GEMM on the matrix cores), after which the mixture is
 
 Fitting (component selection, Scott/Silverman bandwidth, weighted covariance, PSD repair) is small
 host-side tensor algebra and follows the reference line by line; like the reference it draws from
-the global generator of the tensors' device (torch.multinomial).  `sample` is not on the device path
-yet."""
+the global generator of the tensors' device (torch.multinomial).  `sample` batches all components
+of a rejection round into one launch of `sober_wkde_draw`."""
 import copy
 import math
 
@@ -76,6 +76,16 @@ class WeightedKernelDensityEstimation(_HostWeights, SafeTensorOperator):
         self._compute_covariance()
         self._whitened = None
 
+    def to(self, device):
+        """Move the fitted mixture (components, weights, covariance, bounds) to `device`."""
+        self.Xobs, self.weights = self.Xobs.to(device), self.weights.to(device)
+        self.covariance = self.covariance.to(device)
+        if self.bounds is not None:
+            self.bounds = self.bounds.to(device)
+        self.device = self.Xobs.device
+        self._whitened = None
+        return self
+
     def set_bandwidth(self):
         """SOBER/_wkde.py:87-96."""
         self.neff = 1.0 / (self.weights ** 2).sum()
@@ -137,5 +147,94 @@ class WeightedKernelDensityEstimation(_HostWeights, SafeTensorOperator):
         """SOBER/_wkde.py:147-160."""
         return self.pdf(X).log()
 
-    def sample(self, N_rec):
-        raise NotImplementedError("WKDE sampling (SOBER/_wkde.py:221-248) is not on the MI355X path yet")
+    def sample(self, N_rec, stream="device", n_repeat=10):
+        """SOBER/_wkde.py:221-248 with sample_from_Gaussian (:189-219) and rejection_sampling (:162-187).
+
+        Component i contributes int(w_i N_rec) draws (2x when the truncated counts fall short) of
+        N(X_i, Sigma); with bounds each round draws 10x the missing count and keeps the first
+        accepted ones, at most `n_repeat` rounds; a surplus is thinned by multinomial without
+        replacement.  The reference loops over up to 4096 components in Python; here all components
+        of a round are ONE batch: the normals, one `sober_wkde_draw` launch (affine map + bounds
+        test) and a segmented prefix count that keeps the first `cnt_i` accepted rows of each
+        component.
+
+        stream="device": normals and the final thinning come from the device generator (what the
+        reference does when its tensors live on the GPU).  stream="reference": they come from the
+        global CPU generator in the reference's call order (one (cnt_i, d) / (10 cnt_i, d) draw per
+        component), so a CPU run of the reference with the same seed gives the same samples -- as
+        long as every component fills up in its first rejection round (the reference redraws a
+        short component before moving on, which this batched order cannot follow; `last_sample_exact`
+        records whether that happened)."""
+        if stream not in ("device", "reference"):
+            raise ValueError("stream must be 'device' or 'reference'")
+        dev = self.Xobs.device
+        if not self.Xobs.is_cuda:
+            raise nat.SoberHipError("WeightedKernelDensityEstimation.sample: the KDE must live on the HIP device")
+        d = self.n_dims
+        cnts = self.weights * N_rec                                                    # :231-234
+        cnt_kde = cnts.type(torch.int)
+        if cnt_kde.sum() < N_rec:
+            cnt_kde = (2 * cnts).type(torch.int)
+        cnt = cnt_kde.cpu().to(torch.int64)
+        self.last_sample_exact = True
+        empty = torch.empty(0, d, dtype=self.Xobs.dtype, device=dev)
+        if bool((self.covariance == 0).all()) or int(cnt.sum()) == 0:                  # :203-208
+            return empty
+        cov = self.make_cov_psd(self.covariance.cpu().to(torch.float64).clone())
+        L = torch.linalg.cholesky(cov).contiguous().to(dev)
+        Xo = self.Xobs.to(torch.float64).contiguous()
+        bounded = self.bounds is not None
+        lo = hi = None
+        if bounded:
+            bd = self.bounds.to(dev, torch.float64)
+            lo, hi = bd[0].contiguous(), bd[1].contiguous()
+
+        def draw(comp_ids, per_comp):
+            """rows of components `comp_ids` (host int64), `per_comp` rows each -> x, inside, comp_of_row"""
+            total = int(per_comp.sum())
+            if stream == "reference":
+                eps = torch.cat([torch.randn(int(k), d, dtype=torch.float64) for k in per_comp.tolist()]).to(dev)
+            else:
+                eps = torch.randn(total, d, dtype=torch.float64, device=dev)
+            comp = torch.repeat_interleave(comp_ids.to(dev), per_comp.to(dev)).to(torch.int32)
+            x = torch.empty(total, d, dtype=torch.float64, device=dev)
+            inside = torch.empty(total, dtype=torch.int32, device=dev) if bounded else None
+            nat.wkde_draw(eps, comp, Xo, L, lo, hi, x, inside)
+            return x, inside, comp
+
+        active = torch.nonzero(cnt > 0).flatten()
+        if not bounded:
+            samples, _, _ = draw(active, cnt[active])
+        else:
+            have = torch.zeros_like(cnt)
+            parts, keys = [], []
+            for rnd in range(n_repeat):                                               # :177-187
+                need = cnt[active] - have[active]
+                per = cnt[active] * n_repeat                                          # int(n_repeat * cnt) rows per round
+                x, inside, comp = draw(active, per)
+                starts = torch.cumsum(per, 0) - per                                   # first row of each component
+                csum = torch.cumsum(inside, 0, dtype=torch.int64)
+                starts_d = starts.to(dev)
+                before = torch.where(starts_d > 0, csum[(starts_d - 1).clamp(min=0)], torch.zeros_like(starts_d))
+                rank = csum - inside - torch.repeat_interleave(before, per.to(dev))   # accepted rows ahead of me
+                need_row = torch.repeat_interleave(need.to(dev), per.to(dev))
+                keep = (inside > 0) & (rank < need_row)
+                parts.append(x[keep])
+                keys.append(comp[keep].to(torch.int64))
+                ends = torch.cumsum(per, 0).to(dev) - 1
+                accepted = (csum[ends] - before).cpu()
+                have[active] += torch.minimum(accepted, need)
+                active = active[have[active] < cnt[active]]
+                if active.numel() == 0:
+                    break
+                self.last_sample_exact = False                                        # a component needed a redraw
+            samples = torch.cat(parts)
+            if len(parts) > 1:                                                        # component-major like the reference
+                samples = samples[torch.sort(torch.cat(keys), stable=True).indices]
+        if len(samples) > N_rec:                                                      # :245-247
+            if stream == "reference":
+                indice = torch.multinomial(torch.ones(len(samples), dtype=self.Xobs.dtype), N_rec).to(dev)
+            else:
+                indice = torch.multinomial(torch.ones(len(samples), dtype=self.Xobs.dtype, device=dev), N_rec)
+            samples = samples[indice]
+        return samples.to(self.Xobs.dtype)

@@ -254,6 +254,29 @@ __global__ void k_clean_scale(double* __restrict__ w, int64_t n, const double* _
     w[i] = (tot != 0.0) ? w[i] / tot : 1.0 / (double)n;     // :34-37
 }
 
+// KDE component draws (SOBER/_wkde.py:162-219): x = X_c + L eps per row, inside = 1 iff lo <= x <= hi
+__global__ void k_wkde_draw(const double* __restrict__ eps, int64_t n, int d, const int32_t* __restrict__ comp,
+                            const double* __restrict__ Xobs, int ldx, const double* __restrict__ L,
+                            const double* __restrict__ lo, const double* __restrict__ hi,
+                            double* __restrict__ x, int32_t* __restrict__ inside) {
+    extern __shared__ double sL[];                                   // d x d, lower triangle used
+    for (int t = threadIdx.x; t < d * d; t += blockDim.x) sL[t] = L[t];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double* e = eps + r * d;
+    const double* loc = Xobs + (size_t)comp[r] * ldx;
+    bool ok = true;
+    for (int k = 0; k < d; ++k) {
+        double acc = 0.0;
+        for (int j = 0; j <= k; ++j) acc = fma(sL[k * d + j], e[j], acc);
+        const double v = loc[k] + acc;
+        x[r * d + k] = v;
+        if (lo) ok = ok && !(v < lo[k]) && !(v > hi[k]);
+    }
+    if (inside) inside[r] = ok ? 1 : 0;
+}
+
 }  // namespace sober
 
 using namespace sober;
@@ -442,6 +465,17 @@ extern "C" int sober_cleansing_weights(double* w, int64_t n, double eps, void* w
     hipLaunchKernelGGL(k_clean_total, dim3(1), dim3(CW_BLOCKS), 0, st, part);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_clean_scale, dim3(nblk(n, 256)), dim3(256), 0, st, w, n, part);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_wkde_draw(const double* eps, int64_t n, int d, const int32_t* comp, const double* Xobs,
+                               int ldx, const double* L, const double* lo, const double* hi, double* x,
+                               int32_t* inside, void* stream) {
+    if (!eps || !comp || !Xobs || !L || !x || n <= 0 || d <= 0 || d > 64 || ldx < d) return SOBER_E_ARG;
+    if ((lo == nullptr) != (hi == nullptr) || (lo && !inside)) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_wkde_draw, dim3(nblk(n, 256)), dim3(256), (size_t)d * d * sizeof(double),
+                       (hipStream_t)stream, eps, n, d, comp, Xobs, ldx, L, lo, hi, x, inside);
     LAUNCH_CHECK();
     return 0;
 }

@@ -414,22 +414,23 @@ def gen_wkde(ref):
                                                     bounds=bounds, n_kde=n_kde)
             Xq = rng.random((500, d)) * 1.2 - 0.1
             pdf = kde.pdf(torch.from_numpy(Xq))
+            n_rec = 2000 if bounded else 1500
+            torch.manual_seed(5)
+            smp = kde.sample(n_rec)                       # SOBER/_wkde.py:221-248, CPU generator
         out.update({f"{tag}_X": X, f"{tag}_W": W, f"{tag}_n_kde": n_kde, f"{tag}_bounded": bounded,
                     f"{tag}_Xobs": kde.Xobs.numpy(), f"{tag}_weights": kde.weights.numpy(),
                     f"{tag}_cov": kde.covariance.numpy(), f"{tag}_bw": float(kde.bw), f"{tag}_Xq": Xq,
-                    f"{tag}_pdf": pdf.numpy()})
+                    f"{tag}_pdf": pdf.numpy(), f"{tag}_n_rec": n_rec, f"{tag}_sample": smp.numpy()})
     np.savez_compressed(os.path.join(HERE, "wkde.npz"), **out)
 
 
 if __name__ == "__main__":
+    # python make_golden.py [recombination kmeans weights psd tanimoto kernel_calls pi wkde]   (default: all)
     ref = load_reference()
-    gen_wkde(ref)
-    gen_pi(ref)
-    gen_tanimoto()
-    gen_kernel_calls(ref)
-    gen_psd(ref)
-    gen_weights(ref)
-    gen_kmeans(ref)
-    gen_recombination(ref)
+    gens = {"recombination": gen_recombination, "kmeans": gen_kmeans, "weights": gen_weights, "psd": gen_psd,
+            "tanimoto": lambda ref: gen_tanimoto(), "kernel_calls": gen_kernel_calls, "pi": gen_pi,
+            "wkde": gen_wkde}
+    for name in (sys.argv[1:] or list(gens)):
+        gens[name](ref)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print(f"total fixture size {tot / 1e6:.2f} MB")

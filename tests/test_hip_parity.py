@@ -607,3 +607,58 @@ def test_wkde_pdf_vs_reference(dev):
         lp = kde.logpdf(_t(z[f"{tag}_Xq"]).to(dev)).cpu().numpy()
         m = z[f"{tag}_pdf"] > 0
         np.testing.assert_allclose(lp[m], np.log(z[f"{tag}_pdf"][m]), rtol=1e-9, atol=1e-10)
+
+
+def test_wkde_sample_vs_reference(dev):
+    """SOBER/_wkde.py:221-248: with the CPU generator stream of the reference the batched device sampler
+    returns the reference's samples (bounded = rejection rounds, unbounded), same order."""
+    z = np.load(os.path.join(GOLD, "wkde.npz"))
+    for tag in "ab":
+        d = z[f"{tag}_X"].shape[1]
+        bounds = torch.tensor([[0.0] * d, [1.0] * d], dtype=torch.double) if bool(z[f"{tag}_bounded"]) else None
+        torch.manual_seed(11)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            kde = sober_amd.WeightedKernelDensityEstimation(_t(z[f"{tag}_X"].copy()), _t(z[f"{tag}_W"].copy()), d,
+                                                            bounds=bounds, n_kde=int(z[f"{tag}_n_kde"])).to(dev)
+            torch.manual_seed(5)
+            smp = kde.sample(int(z[f"{tag}_n_rec"]), stream="reference")
+        assert kde.last_sample_exact
+        assert smp.shape == z[f"{tag}_sample"].shape
+        np.testing.assert_allclose(smp.cpu().numpy(), z[f"{tag}_sample"], rtol=0, atol=1e-12)
+        # the oracle on the same stream agrees too
+        torch.manual_seed(5)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            so = O.wkde_sample(kde.Xobs.cpu(), kde.weights.cpu(), kde.covariance.cpu(), int(z[f"{tag}_n_rec"]), bounds)
+        np.testing.assert_allclose(smp.cpu().numpy(), so.numpy(), rtol=0, atol=1e-12)
+
+
+def test_wkde_sample_device_stream(dev):
+    """Device-generator draws: right count, inside the bounds, mixture moments within sampling error;
+    a narrow box forces several rejection rounds (the segmented keep-first-cnt logic)."""
+    rng = np.random.default_rng(9)
+    d, n = 4, 5000
+    X = rng.random((n, d)) * 0.5 + 0.25
+    W = rng.random(n)
+    torch.manual_seed(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kde = sober_amd.WeightedKernelDensityEstimation(_t(X), _t(W), d, bounds=None, n_kde=1024).to(dev)
+        s = kde.sample(200000)
+    assert s.shape == (200000, d) and s.is_cuda
+    w = kde.weights.cpu().numpy(); Xo = kde.Xobs.cpu().numpy(); cov = kde.covariance.cpu().numpy()
+    mean = w @ Xo
+    tot_cov = (Xo - mean).T @ ((Xo - mean) * w[:, None]) + cov
+    sn = s.cpu().numpy()
+    np.testing.assert_allclose(sn.mean(0), mean, atol=5e-3)          # counts are int(w_i N): small truncation bias
+    np.testing.assert_allclose(np.cov(sn.T), tot_cov, atol=5e-3)
+    lo, hi = 0.3, 0.7                                                   # tight box: ~(0.4/0.9)^4 acceptance at best
+    kde.bounds = torch.tensor([[lo] * d, [hi] * d], dtype=torch.double, device=dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s2 = kde.sample(50000)
+    assert s2.shape == (50000, d)
+    assert bool(((s2 >= lo) & (s2 <= hi)).all())
+    # truncation keeps the component mix: the mean stays near the centre of the box
+    np.testing.assert_allclose(s2.cpu().numpy().mean(0), 0.5 * np.ones(d), atol=2e-2)

@@ -192,4 +192,7 @@ def test_wkde_matches_reference():
             assert np.array_equal(cov.numpy(), z[f"{tag}_cov"]) and float(bw) == float(z[f"{tag}_bw"])
             bounds = torch.tensor([[0.0] * d, [1.0] * d], dtype=torch.double) if bool(z[f"{tag}_bounded"]) else None
             pdf = O.wkde_pdf(Xobs, w, cov, _t(z[f"{tag}_Xq"]), bounds)
+            torch.manual_seed(5)
+            smp = O.wkde_sample(Xobs, w, cov, int(z[f"{tag}_n_rec"]), bounds)
         assert np.array_equal(pdf.numpy(), z[f"{tag}_pdf"])
+        assert np.array_equal(smp.numpy(), z[f"{tag}_sample"])                      # same CPU generator stream
