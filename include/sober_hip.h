@@ -225,6 +225,22 @@ int sober_wkde_draw(const double* eps, int64_t n, int d, const int32_t* comp, co
                     const double* L, const double* lo, const double* hi, double* x, int32_t* inside,
                     void* stream);
 
+/* K1-K3 for a kernel matrix that is resident in HBM: Kmat[c*ldk + r] = k(x_r, cand_c), r < n_rows <= 1024
+ * (candidate-major).  Same contract as sober_level_reduce -- partG[(chunk*n_rows + r)*ldg + col0 + s] =
+ * sum over the chunk's elements of Kmat[idx[p - pos0]][r] * mu * (wmul), p = e*S + s in [pos0, pos0+count);
+ * partTot likewise for the set masses (positions < tot_limit) -- but the kernel values are gathered, not
+ * evaluated.  Used for callables that follow the kernel protocol of SOBER/_rchq.py:9,20 and for BASQ's
+ * g-space kernel.  n_chunks from sober_level_chunks.                                                  */
+int sober_level_gather(const double* Kmat, int n_rows, int64_t ldk, const int32_t* idx, int64_t pos0,
+                       int64_t count, int S, const double* mu, const double* wmul, int n_chunks,
+                       double* partG, int ldg, int col0, double* partTot, int64_t tot_limit, void* stream);
+
+/* Epilogue of ScaleMmltGP.gspace_kernel, SOBER/BASQ/_scale_mmlt.py:256-275, in place on K (n x m):
+ * K[c][r] <- mug_rows[r] * mug_cand[c] * (exp(K[c][r] - corr[c][r]) - 1), where on entry K = os*k(cand, x)
+ * and corr = k(cand, X) W k(X, x) (the posterior correction of SOBER/_gp.py:295).                      */
+int sober_gspace_finish(double* K, const double* corr, int64_t n, int m, int64_t ldk, int64_t ldc,
+                        const double* mug_cand, const double* mug_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -629,3 +629,50 @@ def wkde_sample(Xobs, weights, cov, N_rec, bounds=None, n_repeat=10):
     if len(samples) > N_rec:
         samples = samples[torch.multinomial(torch.ones(len(samples), dtype=Xobs.dtype), N_rec)]
     return samples
+
+
+# --------------------------------------------------------------------------- #
+# BASQ quadrature kernel provider  (SOBER/BASQ/_scale_mmlt.py, _basq.py)
+# --------------------------------------------------------------------------- #
+def gspace_mean_predict(x, spec: GPSpec):
+    """ScaleMmltGP.gspace_mean_predict -> gspace_predict, SOBER/BASQ/_scale_mmlt.py:206-245:
+    mu_g = exp(mu_h + var_h / 2) - 1 with (mu_h, var_h) = predict(x, model) (noise included)."""
+    mu_h, var_h = predict(x, spec)
+    return (mu_h + 0.5 * var_h).exp() - 1
+
+
+def gspace_predict(x, spec: GPSpec):
+    """SOBER/BASQ/_scale_mmlt.py:206-219."""
+    mu_h, var_h = predict(x, spec)
+    mu_g = (mu_h + 0.5 * var_h).exp() - 1
+    return mu_g, (mu_g ** 2) * (var_h.exp() - 1)
+
+
+def gspace_kernel(x, y, spec: GPSpec, jitter=0.0):
+    """ScaleMmltGP.gspace_kernel, SOBER/BASQ/_scale_mmlt.py:256-275:
+    mu_g(x) mu_g(y) (exp(C_h(x, y)) - 1), C_h = predictive_covariance; y may be (E, S, d)."""
+    mu_g_x = gspace_mean_predict(x, spec)
+    mu_g_y = gspace_mean_predict(y, spec)
+    cov = predictive_covariance(x, y, spec)
+    if cov.dim() == 2:
+        C = mu_g_x.unsqueeze(1) * mu_g_y.unsqueeze(0) * (cov.exp() - 1)
+    else:
+        C = mu_g_x.unsqueeze(1).unsqueeze(0) * mu_g_y.unsqueeze(1) * (cov.exp() - 1)
+    d = min(len(x), len(y))
+    C[range(d), range(d)] = C[range(d), range(d)] + jitter                     # :273-274 as written
+    return C
+
+
+def basq_quadrature(X_cand, n_nys, n_res, spec: GPSpec, beta):
+    """BASQ.quadrature, SOBER/BASQ/_basq.py:43-81, from the prior sample on: uniform weights, Nystrom
+    points = the first n_nys candidates, recombination with the g-space kernel, then
+    EML = w . mu_g(x), ELML = log EML + beta (beta when EML <= 0), AVLML = log |w K(x,x) w|."""
+    n = len(X_cand)
+    w_IS = torch.ones(n, dtype=X_cand.dtype) / n
+    kern = lambda a, b: gspace_kernel(a, b, spec)                              # noqa: E731
+    idx, w = recombination(X_cand, X_cand[:n_nys], n_res, kern, init_weights=w_IS)
+    x = X_cand[idx]
+    EML = w @ gspace_mean_predict(x, spec)
+    ELML = beta if EML <= 0 else math.log(float(EML)) + beta
+    AVLML = float((w @ gspace_kernel(x, x, spec) @ w).abs().log())
+    return idx, w, float(ELML), AVLML

@@ -59,6 +59,9 @@ SIGNATURES = {
     "sober_predict_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f64, _vp, _f64, _f64, _vp, _f64, _vp, _i32, _vp]),
     "sober_reduce_ws_bytes": (_i64, [_i64]),
     "sober_cleansing_weights": (_i32, [_vp, _i64, _f64, _vp, _i64, _vp]),
+    "sober_level_gather": (_i32, [_vp, _i32, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i64,
+                                  _vp]),
+    "sober_gspace_finish": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp]),
     "sober_wkde_draw": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
@@ -341,3 +344,19 @@ def wkde_draw(eps, comp, Xobs, L, lo, hi, x, inside):
                                   hi.data_ptr() if hi is not None else None, x.data_ptr(),
                                   inside.data_ptr() if inside is not None else None, _stream(eps)),
            "sober_wkde_draw")
+
+
+def level_gather(Kmat, idx, idx_off, pos0, count, S, mu, wmul, n_chunks, partG, ldg, col0, partTot, tot_limit):
+    _req(idx, torch.int32, "idx"); _req(mu, torch.float64, "mu"); _req(Kmat, torch.float64, "Kmat")
+    if Kmat.stride(1) != 1:
+        raise SoberHipError("level_gather: Kmat needs unit inner stride")
+    _check(load().sober_level_gather(Kmat.data_ptr(), Kmat.shape[1], Kmat.stride(0),
+                                     idx.data_ptr() + 4 * idx_off, pos0, count, S, mu.data_ptr(), _ptr(wmul),
+                                     n_chunks, partG.data_ptr(), ldg, col0, _ptr(partTot), tot_limit,
+                                     _stream(partG)), "sober_level_gather")
+
+
+def gspace_finish(K, corr, mug_cand, mug_rows):
+    n, m = K.shape
+    _check(load().sober_gspace_finish(K.data_ptr(), corr.data_ptr(), n, m, K.stride(0), corr.stride(0),
+                                      mug_cand.data_ptr(), mug_rows.data_ptr(), _stream(K)), "sober_gspace_finish")

@@ -343,73 +343,60 @@ class HipOps:
         return t.to(self.device, dtype=dtype, non_blocking=False)
 
 
-class CallableKernelOps(HipOps):
-    """Backend for an ARBITRARY kernel callable `kernel(x, y)` (the protocol of SOBER/_rchq.py:9,20: 2-D
-    `x`, 2-D or 3-D `y`) -- e.g. BASQ's gspace_kernel (SOBER/BASQ/_scale_mmlt.py:256-275) or a
-    user-defined positive-definite function.  The kernel matrix itself comes from the caller's torch
-    code on the device; everything around it (set sums without the (E, M, S) tensor, Nystrom basis,
-    projection on the matrix cores, Caratheodory steps, weight update) is the same HIP path."""
+class MatrixKernelOps(HipOps):
+    """Backend for kernels whose matrix against the Nystrom points is RESIDENT in HBM: Kmat = K(X_cand, X_nys),
+    (N, M) candidate-major -- 400 MB at N = 100k, M = 500, a corner of the MI355X's 288 GB.  It is built once
+    per step and every level is then the HBM-bound gather-sum `sober_level_gather`; nothing else differs
+    from the fused path (Nystrom basis, projection on the matrix cores, Caratheodory steps, weight update).
 
-    CHUNK_ELEMS = 256          # elements (rows of the (E, S) grouping) evaluated per kernel call
+    Two kinds of kernel arrive here:
+      * a native provider with `materialise(X_cand, X_nys) -> (N, M)` (BASQ's g-space kernel, whose
+        exp(C_h) - 1 is non-linear in the posterior covariance, so the sum-first shortcut of the fused
+        path does not apply -- SURVEY.md 8 row f4);
+      * ANY callable `kernel(x, y)` following the protocol of SOBER/_rchq.py:9,20 (2-D `x`, 2-D or 3-D
+        `y`): its matrix is evaluated chunk-wise by the caller's own torch code on the device, once."""
+
+    CHUNK_ROWS = 1 << 15       # candidates per call of a foreign callable
 
     def build_plan(self, kernel_fn, mode, X_nys, X_cand) -> Plan:
         p = Plan()
-        p.kernel_fn, p.mode = kernel_fn, "callable"
+        p.kernel_fn, p.mode = kernel_fn, "matrix"
         p.X_nys, p.X_cand = X_nys, X_cand
         p.M = p.Mtot = X_nys.shape[0]
         p.weighted, p.T, p.P, p.wmul, p.da = False, None, None, None, -1
         p.ws = {}
+        N = X_cand.shape[0]
+        if hasattr(kernel_fn, "materialise"):
+            p.Kmat = kernel_fn.materialise(X_cand, X_nys)
+        else:
+            p.Kmat = torch.empty(N, p.M, dtype=torch.float64, device=self.device)
+            for lo in range(0, N, self.CHUNK_ROWS):
+                hi = min(N, lo + self.CHUNK_ROWS)
+                p.Kmat[lo:hi] = kernel_fn(X_nys, X_cand[lo:hi]).to(torch.float64).T
+        if tuple(p.Kmat.shape) != (N, p.M) or p.Kmat.dtype != torch.float64 or p.Kmat.stride(1) != 1:
+            raise nat.SoberHipError(f"kernel matrix must be ({N}, {p.M}) float64 row-major, got "
+                                    f"{tuple(p.Kmat.shape)} {p.Kmat.dtype}")
         return p
 
     def gram(self, p):
+        if hasattr(p.kernel_fn, "materialise"):
+            return p.kernel_fn.materialise(p.X_nys, p.X_nys, gram=True)
         return p.kernel_fn(p.X_nys, p.X_nys).to(torch.float64).contiguous()
 
     def set_projection(self, p, U):
         p.P = U.to(self.device, torch.float64).contiguous()
         p.n = p.P.shape[0]
 
-    def _weighted_columns(self, p, c, mu):
-        K = p.kernel_fn(p.X_nys, p.X_cand[c]).to(torch.float64)          # (M, len(c))
-        return K * mu[c].unsqueeze(0)
-
-    def level_moments(self, p, idx, pos0, count, S, E, mu):
-        dev = self.device
-        G = torch.zeros(p.M, S, dtype=torch.float64, device=dev)
-        tot = torch.zeros(S, dtype=torch.float64, device=dev)
-        ES = E * S
-        if count > 0:
-            step = self.CHUNK_ELEMS * S
-            a = 0
-            while a < count:                                   # chunks aligned to whole elements of the grouping
-                gpos = pos0 + a
-                # a sharded range may start inside an element: take that partial element on its own first
-                b = min(count, a + (S - gpos % S)) if gpos % S else min(count, a + step)
-                c = idx[a:b].long()
-                KW = self._weighted_columns(p, c, mu)
-                n = b - a
-                off = gpos % S
-                dense = torch.zeros(p.M, ((off + n + S - 1) // S) * S, dtype=torch.float64, device=dev)
-                dense[:, off:off + n] = KW
-                G += dense.view(p.M, -1, S).sum(1)             # set = position mod S (incl. Q1 first placement)
-                m = mu[c]
-                pos = gpos + torch.arange(n, device=dev)
-                main = pos < ES
-                dm = torch.zeros(dense.shape[1], dtype=torch.float64, device=dev)
-                dm[off:off + n] = torch.where(main, m, torch.zeros_like(m))
-                tot += dm.view(-1, S).sum(0)
-                if bool((~main).any()):                        # Q1 second placement -> set S-1
-                    G[:, S - 1] += KW[:, ~main].sum(1)
-                    tot[S - 1] += m[~main].sum()
-                a = b
-        Xtr = torch.empty(p.n, S, dtype=torch.float64, device=dev)
-        nat.dgemm(p.P, G.contiguous(), Xtr)
-        return Xtr, tot
+    def _level_reduce(self, p, idx, idx_off, pos0, count, S, mu, n_chunks, partG, ldg, partTot, tot_limit):
+        nat.level_gather(p.Kmat, idx, idx_off, pos0, count, S, mu, None, n_chunks, partG, ldg, 0, partTot, tot_limit)
 
     def direct_columns(self, p, idx, count):
-        c = idx[:count].long()
-        K = p.kernel_fn(p.X_nys, p.X_cand[c]).to(torch.float64).contiguous()
+        Kc = p.Kmat[idx[:count].long()].contiguous()                      # (count, M)
         Xtr = torch.empty(p.n, count, dtype=torch.float64, device=self.device)
-        nat.dgemm(p.P, K, Xtr)
+        nat.dgemm(p.P, Kc, Xtr, transb=True)
         out = torch.empty(count, p.n, dtype=torch.float64, device=self.device)
         nat.barycentres(Xtr, p.n, count, None, out)
         return out
+
+
+CallableKernelOps = MatrixKernelOps

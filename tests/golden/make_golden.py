@@ -424,12 +424,75 @@ def gen_wkde(ref):
     np.savez_compressed(os.path.join(HERE, "wkde.npz"), **out)
 
 
+def gen_basq(ref):
+    """BASQ provider: ScaleMmltGP.gspace_kernel / gspace_mean_predict
+    (SOBER/BASQ/_scale_mmlt.py:206-275) and BASQ.quadrature (SOBER/BASQ/_basq.py:43-81) run from the
+    reference's own methods.  ScaleMmltGP.__init__ trains a gpytorch model (not installed), so the
+    instance is created without it and given the duck-typed GP; BASQ likewise gets a fixed prior sample."""
+    pkg = types.ModuleType("SOBER.BASQ")
+    pkg.__path__ = [f"{REF}/BASQ"]
+    sys.modules["SOBER.BASQ"] = pkg
+    spec_ = importlib.util.spec_from_file_location("SOBER.BASQ._scale_mmlt", f"{REF}/BASQ/_scale_mmlt.py")
+    sm = importlib.util.module_from_spec(spec_)
+    sys.modules["SOBER.BASQ._scale_mmlt"] = sm
+    spec_.loader.exec_module(sm)
+    smp = types.ModuleType("SOBER._sampler")                # _basq.py imports MixtureSampler only to build it
+    smp.MixtureSampler = lambda *a, **k: None
+    sys.modules["SOBER._sampler"] = smp
+    spec_ = importlib.util.spec_from_file_location("SOBER.BASQ._basq", f"{REF}/BASQ/_basq.py")
+    bq = importlib.util.module_from_spec(spec_)
+    sys.modules["SOBER.BASQ._basq"] = bq
+    spec_.loader.exec_module(bq)
+
+    out = {}
+    for tag, kind, d, n_obs, N, M, b, seed in (("a", O.RBF, 4, 40, 4000, 80, 12, 21),
+                                               ("b", O.MATERN52, 3, 30, 2500, 64, 10, 22)):
+        rng = np.random.default_rng(seed)
+        X_obs = rng.random((n_obs, d))
+        ls = 0.35 * (1.0 + np.arange(d) / d)
+        y_h = np.log(np.exp(-8.0 * ((X_obs - 0.5) ** 2).sum(1)) + 1.0) * 3.0       # h-space observations
+        spec = O.make_spec(kind, torch.from_numpy(X_obs), torch.from_numpy(ls), outputscale=1.3, noise=1e-3,
+                           mean_const=0.15, y_obs=torch.from_numpy(y_h))
+        g = object.__new__(sm.ScaleMmltGP)
+        ref["_utils"].Utils.__init__(g)
+        g.model = DuckModel(spec)
+        g.jitter = g.tensor(0)
+        g.beta = torch.tensor(-3.25, dtype=torch.double)
+        X_cand = rng.random((N, d))
+        Xc = torch.from_numpy(X_cand)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            K2 = g.gspace_kernel(Xc[:10], Xc[100:150])
+            K3 = g.gspace_kernel(Xc[:10], Xc[200:260].reshape(3, 20, d))
+            mug = g.gspace_mean_predict(Xc[:100])
+            mug2, varg = g.gspace_predict(Xc[:100])
+            basq = object.__new__(bq.BASQ)
+            ref["_utils"].TensorManager.__init__(basq)
+            basq.prior = types.SimpleNamespace(sample=lambda n: Xc[:n])
+            basq.kernel, basq.pred_mean, basq.beta = g.gspace_kernel, g.gspace_mean_predict, g.beta
+            torch.manual_seed(SEED_CALL)
+            with contextlib.redirect_stdout(None):
+                ELML, AVLML = basq.quadrature(N, M, b)
+            # the same recombination once more to store its indices and weights
+            torch.manual_seed(SEED_CALL)
+            w_IS = torch.ones(N, dtype=torch.double) / N
+            idx, w = ref["_rchq"].recombination(Xc, Xc[:M], b, g.gspace_kernel, torch.device("cpu"), torch.double,
+                                                init_weights=w_IS)
+        out.update({f"{tag}_kind": kind, f"{tag}_X_obs": X_obs, f"{tag}_ls": ls, f"{tag}_alpha": spec.alpha.numpy(),
+                    f"{tag}_S_cache": spec.S_cache.numpy(), f"{tag}_X_cand": X_cand, f"{tag}_M": M, f"{tag}_b": b,
+                    f"{tag}_K2": K2.numpy(), f"{tag}_K3": K3.numpy(), f"{tag}_mug": mug.numpy(),
+                    f"{tag}_varg": varg.numpy(), f"{tag}_ELML": ELML, f"{tag}_AVLML": AVLML,
+                    f"{tag}_idx": idx.numpy(), f"{tag}_w": w.numpy(), f"{tag}_EML": float(basq.EML)})
+        print(f"basq {tag}: |idx|={len(idx)} ELML={ELML:.6f} AVLML={AVLML:.6f}")
+    np.savez_compressed(os.path.join(HERE, "basq.npz"), **out)
+
+
 if __name__ == "__main__":
-    # python make_golden.py [recombination kmeans weights psd tanimoto kernel_calls pi wkde]   (default: all)
+    # python make_golden.py [recombination kmeans weights psd tanimoto kernel_calls pi wkde basq]   (default: all)
     ref = load_reference()
     gens = {"recombination": gen_recombination, "kmeans": gen_kmeans, "weights": gen_weights, "psd": gen_psd,
             "tanimoto": lambda ref: gen_tanimoto(), "kernel_calls": gen_kernel_calls, "pi": gen_pi,
-            "wkde": gen_wkde}
+            "wkde": gen_wkde, "basq": gen_basq}
     for name in (sys.argv[1:] or list(gens)):
         gens[name](ref)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))

@@ -662,3 +662,74 @@ def test_wkde_sample_device_stream(dev):
     assert bool(((s2 >= lo) & (s2 <= hi)).all())
     # truncation keeps the component mix: the mean stays near the centre of the box
     np.testing.assert_allclose(s2.cpu().numpy().mean(0), 0.5 * np.ones(d), atol=2e-2)
+
+
+# --------------------------------------------------------------------------- #
+# kernel matrices resident in HBM (callables, BASQ's g-space kernel)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("n_rows,S,N,count,pos0", [(500, 200, 30000, 23456, 0), (64, 22, 5000, 4999, 7),
+                                                   (130, 16, 3000, 1000, 333), (1000, 8, 2000, 2000, 0)])
+def test_level_gather_vs_numpy(dev, n_rows, S, N, count, pos0):
+    """sober_level_gather + sober_sum_partials against a dense numpy restatement of SOBER/_rchq.py:124-150."""
+    from sober_amd import _native as nat
+    rng = np.random.default_rng(n_rows + S)
+    Kmat = rng.standard_normal((N, n_rows))
+    idx = rng.permutation(N)[:count].astype(np.int32)
+    mu = rng.random(N)
+    tot_limit = pos0 + count - 5
+    Kd, idxd, mud = _t(Kmat).to(dev), _t(idx).to(dev), _t(mu).to(dev)
+    n_chunks = nat.level_chunks(n_rows, pos0, count, S)
+    partG = torch.full((n_chunks * n_rows * S,), float("nan"), dtype=torch.float64, device=dev)
+    partTot = torch.full((n_chunks * S,), float("nan"), dtype=torch.float64, device=dev)
+    nat.level_gather(Kd, idxd, 0, pos0, count, S, mud, None, n_chunks, partG, S, 0, partTot, tot_limit)
+    G = torch.empty(n_rows, S, dtype=torch.float64, device=dev)
+    tot = torch.empty(S, dtype=torch.float64, device=dev)
+    nat.sum_partials(partG, partTot, n_chunks, n_rows, S, S, None, None, 0, 16, G, tot)
+    Gref = np.zeros((n_rows, S)); totref = np.zeros(S)
+    pos = pos0 + np.arange(count)
+    np.add.at(Gref.T, pos % S, Kmat[idx] * mu[idx][:, None])
+    np.add.at(totref, (pos % S)[pos < tot_limit], mu[idx][pos < tot_limit])
+    np.testing.assert_allclose(G.cpu().numpy(), Gref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(tot.cpu().numpy(), totref, rtol=1e-13)
+
+
+def _basq_kspec(z, tag):
+    return sober_amd.KernelSpec(str(z[f"{tag}_kind"]), _t(z[f"{tag}_ls"]), 1.3, _t(z[f"{tag}_X_obs"]),
+                                _t(z[f"{tag}_S_cache"]), 1e-3, 0.15, _t(z[f"{tag}_alpha"]))
+
+
+def test_basq_gspace_kernel_vs_reference(dev):
+    """ScaleMmltGP.gspace_kernel / gspace_predict (SOBER/BASQ/_scale_mmlt.py:206-275) on the device against the
+    reference's own output: 2-D and 3-D second argument."""
+    z = np.load(os.path.join(GOLD, "basq.npz"))
+    for tag in "ab":
+        model = sober_amd.ScaleMmlt(_basq_kspec(z, tag), beta=-3.25)
+        Xc = _t(z[f"{tag}_X_cand"]).to(dev)
+        d = Xc.shape[1]
+        K2 = model.gspace_kernel(Xc[:10], Xc[100:150])
+        np.testing.assert_allclose(K2.cpu().numpy(), z[f"{tag}_K2"], rtol=1e-9, atol=1e-13)
+        K3 = model.gspace_kernel(Xc[:10], Xc[200:260].reshape(3, 20, d))
+        assert K3.shape == (3, 10, 20)
+        np.testing.assert_allclose(K3.cpu().numpy(), z[f"{tag}_K3"], rtol=1e-9, atol=1e-13)
+        mug, varg = model.gspace_predict(Xc[:100])
+        np.testing.assert_allclose(mug.cpu().numpy(), z[f"{tag}_mug"], rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(varg.cpu().numpy(), z[f"{tag}_varg"], rtol=1e-8, atol=1e-14)
+        np.testing.assert_allclose(model.gspace_mean_predict(Xc[:100]).cpu().numpy(), z[f"{tag}_mug"], rtol=1e-10,
+                                   atol=1e-14)
+
+
+def test_basq_quadrature_vs_reference(dev):
+    """BASQ.quadrature (SOBER/BASQ/_basq.py:43-81): recombination with the g-space kernel through the HBM-resident
+    matrix + gather levels selects the reference's points and weights; ELML / AVLML follow."""
+    z = np.load(os.path.join(GOLD, "basq.npz"))
+    for tag in "ab":
+        model = sober_amd.ScaleMmlt(_basq_kspec(z, tag), beta=-3.25)
+        Xc = _t(z[f"{tag}_X_cand"]).to(dev)
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ELML, AVLML, EML, idx, w = sober_amd.basq_quadrature(Xc, int(z[f"{tag}_M"]), int(z[f"{tag}_b"]), model)
+        assert np.array_equal(idx.cpu().numpy(), z[f"{tag}_idx"])
+        np.testing.assert_allclose(w.cpu().numpy(), z[f"{tag}_w"], rtol=W_RTOL)
+        assert abs(ELML - float(z[f"{tag}_ELML"])) < 1e-6 and abs(AVLML - float(z[f"{tag}_AVLML"])) < 1e-5
+        assert abs(EML - float(z[f"{tag}_EML"])) < 1e-6 * abs(EML)

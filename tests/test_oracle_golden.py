@@ -196,3 +196,30 @@ def test_wkde_matches_reference():
             smp = O.wkde_sample(Xobs, w, cov, int(z[f"{tag}_n_rec"]), bounds)
         assert np.array_equal(pdf.numpy(), z[f"{tag}_pdf"])
         assert np.array_equal(smp.numpy(), z[f"{tag}_sample"])                      # same CPU generator stream
+
+
+def _basq_spec(z, tag):
+    kind = str(z[f"{tag}_kind"])
+    return O.GPSpec(kind, _t(z[f"{tag}_ls"]), 1.3, _t(z[f"{tag}_X_obs"]), _t(z[f"{tag}_S_cache"]), 1e-3, 0.15,
+                    _t(z[f"{tag}_alpha"]))
+
+
+def test_basq_gspace_matches_reference():
+    """SOBER/BASQ/_scale_mmlt.py:206-275 and SOBER/BASQ/_basq.py:43-81 (row f4): g-space kernel (2-D and 3-D
+    second argument), g-space prediction, and the quadrature built on recombination with that kernel."""
+    z = np.load(os.path.join(GOLD, "basq.npz"))
+    for tag in "ab":
+        spec = _basq_spec(z, tag)
+        Xc = _t(z[f"{tag}_X_cand"])
+        d = Xc.shape[1]
+        assert np.array_equal(O.gspace_kernel(Xc[:10], Xc[100:150], spec).numpy(), z[f"{tag}_K2"])
+        assert np.array_equal(O.gspace_kernel(Xc[:10], Xc[200:260].reshape(3, 20, d), spec).numpy(), z[f"{tag}_K3"])
+        mug, varg = O.gspace_predict(Xc[:100], spec)
+        assert np.array_equal(mug.numpy(), z[f"{tag}_mug"]) and np.array_equal(varg.numpy(), z[f"{tag}_varg"])
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx, w, ELML, AVLML = O.basq_quadrature(Xc, int(z[f"{tag}_M"]), int(z[f"{tag}_b"]), spec, -3.25)
+        assert np.array_equal(idx.numpy(), z[f"{tag}_idx"])
+        assert np.array_equal(w.numpy(), z[f"{tag}_w"])
+        assert ELML == float(z[f"{tag}_ELML"]) and AVLML == float(z[f"{tag}_AVLML"])
