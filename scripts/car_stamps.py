@@ -1,3 +1,4 @@
+"""Per-segment cycle counts of k_car_pivot, waves 0 and 1 (build car.hip with -DCAR_STAMPS)."""
 import numpy as np, torch, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sober_amd import _native as nat
@@ -8,16 +9,15 @@ N, n = X.shape; m = n + 1
 Xd, mud = torch.from_numpy(X).to(dev), torch.from_numpy(mu).to(dev)
 kr = torch.empty(N, dtype=torch.int32, device=dev); ws = torch.empty(N, dtype=torch.float64, device=dev)
 nk = torch.empty(1, dtype=torch.int32, device=dev); mo = torch.empty(N, dtype=torch.float64, device=dev)
-ph = torch.zeros(N, N - m, dtype=torch.float64, device=dev)
-for it in range(5):
-    nat.car_device(Xd, mud, kr, ws, nk, mo, ph)
+for it in range(3):
+    nat.car_device(Xd, mud, kr, ws, nk, mo)
     torch.cuda.synchronize()
-    st = ph.view(torch.int64).flatten()[:8].cpu().numpy()
-    cyc = np.diff(st[0::2]); rt = np.diff(st[1::2])
-    sub = ph.view(torch.int64).flatten()[16:22].cpu().numpy()
-    if sub.sum() > 0: print("phase-1 sub-phases (wave 0 cycles): A+bar, B+bar, C+bar, D1+bar, D2+bar, D3:", sub, "per step", sub / 100.0)
-    print("cycles phase1/2/3:", cyc, " realtime(100MHz ticks):", rt, " => us:", rt / 100.0, " clock GHz:", cyc.sum() / (rt.sum() / 100.0) / 1e3)
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for it in range(20): nat.car_device(Xd, mud, kr, ws, nk, mo, ph)
-e1.record(); torch.cuda.synchronize(); print("avg ms per call", e0.elapsed_time(e1) / 20)
+    scratch = nat._CAR_WS[Xd.device]
+    Phi = scratch[m * 208 + 128:]
+    sub = Phi.view(torch.int64)[207 * 128 + 112: 207 * 128 + 128].cpu().numpy()
+    print("pivot kernel ticks per pivot [read+mu, owner ratio (avg), non-owner elim, barrier wait]: wave0", sub[:4] / 100.0, " wave1", sub[8:12] / 100.0,
+          " owner: iteration start -> published:", sub[4] / max(sub[5], 1), "ticks x", sub[5], " owner's own barrier wait:", sub[6] / max(sub[5], 1), " barrier wait + deferred block:", sub[7] / max(sub[5], 1))
+    arr = Phi.view(torch.int64)[206 * 128 + 64: 206 * 128 + 80].cpu().numpy()
+    print("per-wave mean arrival at the barrier (ticks after iteration start):", (arr / 100.0).round())
+    a50 = Phi.view(torch.int64)[205 * 128 + 64: 205 * 128 + 80].cpu().numpy()
+    print("arrival at step 50 (owner = wave 3):", a50)

@@ -44,6 +44,30 @@ for name, case in CFG.items():
                      sum_w=float(w.sum()))
     print(name, out[name], flush=True)
     del X
+# BASQ quadrature (row f4) at the cfg-2 shape: g-space kernel, per-candidate posterior correction, matrix in HBM
+case = dict(CFG["cfg2"], mean_const=0.15)
+inp = synth(case); spec = build_spec(case, inp)
+rng = np.random.default_rng(5)
+alpha = (spec.S_cache @ spec.S_cache.T) @ t(np.log(np.exp(-2.0 * ((inp["X_obs"] - 0.5) ** 2).sum(1)) + 1.0))
+ks = sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs, spec.S_cache, spec.noise, 0.15, alpha)
+model = sober_amd.ScaleMmlt(ks, beta=-1.0)
+X = t(inp["X_cand"]).to(dev)
+def qstep():
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return sober_amd.basq_quadrature(X, case["M"], case["b"], model)
+qstep(); torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter(); r = qstep(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+Kmat = model.gspace_kernel.materialise(X, X[:case["M"]]); torch.cuda.synchronize()
+t_mat = time.perf_counter() - t0
+out["basq_quadrature_cfg2_shape"] = dict(ms=float(np.median(ts) * 1e3), materialise_ms=t_mat * 1e3, ELML=r[0], AVLML=r[1],
+                                         n_sel=int(r[3].numel()))
+print("basq", out["basq_quadrature_cfg2_shape"], flush=True)
+del X, Kmat
 # KMeans Nystrom subsample (SOBER/_weights.py:100-126): reference 45 s at this size on 8 cores
 rng = np.random.default_rng(0)
 Xk = t(rng.random((100000, 10))).to(dev)

@@ -27,7 +27,7 @@ from ._kernel import posterior_mean, prepare_points, spec_from_model, woodbury
 from ._pi import _predict
 from ._rchq import recombination
 
-CHUNK = 1 << 16
+CHUNK = 1 << 15          # sober_pairwise: at most 65535 rows on the a side
 
 
 class GspaceKernel:

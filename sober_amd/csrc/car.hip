@@ -1,5 +1,4 @@
-// K5 + K6 on the device: Tchernychova_Lyons_CAR (SOBER/_rchq.py:224-270) as ONE persistent
-// workgroup (1024 threads, everything on chip).
+// K5 + K6 on the device: Tchernychova_Lyons_CAR (SOBER/_rchq.py:224-270), everything on chip.
 //
 // The reference takes the null space of A = [1 | X]^T (m x N, m < N <= 2m) from LAPACK's full SVD:
 // Phi = Vh[m:, :].T.  Which basis of the null space comes back decides which points survive
@@ -8,28 +7,34 @@
 // the product of the RIGHT Householder reflectors of the Golub-Kahan bidiagonalisation of A
 // (dgebrd, lower-bidiagonal case m < N, dlarfg sign convention) -- checked against
 // torch.linalg.svd on the reference's own per-level inputs in tests/test_car_algorithm.py (CPU) and
-// tests/test_hip_parity.py (GPU).  That product is a deterministic
-// function of A, so it can be recomputed here:
+// tests/test_hip_parity.py (GPU).  That product is a deterministic function of A, so it can be
+// recomputed here.  Three launches on one stream, each shaped by what bounds its phase:
 //
-//   phase 1  bidiagonalise A in LDS (m*N doubles = 160,000 B at batch 100: the whole 160 KiB LDS
-//            of one CU, which is why this is a one-workgroup kernel), keeping the right reflectors
-//            v_i in place like dgebd2;
-//   phase 2  Phi = P [0; I] by backward accumulation, Phi distributed over the VGPRs of 13 waves
-//            (8 columns x 8 row groups per wave, cross-group sums by DPP/shuffle: no barriers);
-//   phase 3  the N-m pivots of :237-266 on the register-resident Phi: ratio test = wave argmin with
-//            first-index tie break, rank-1 elimination, one barrier per pivot.
+//   k_car_bidiag  1 workgroup x 256 threads.  The m bidiagonalisation steps are a chain of workgroup-wide
+//                 reductions (two norms, two matrix-vector products per step): latency, not arithmetic.
+//                 Four waves -- one per SIMD -- keep the barriers and the LDS exchanges cheap; the matrix
+//                 lives in VGPRs (7 x 13 doubles per thread), a matrix row inside ONE 16-lane DPP row so
+//                 that row dot products never leave the wave.  Reflectors v_i, tau_i -> global scratch.
+//   k_car_phi     Phi = P [0; I] by backward accumulation.  The columns of Phi are independent, so this
+//                 phase is spread over ceil((N-m)/8) workgroups of one wave (8 columns each, 16 lanes x 13
+//                 rows per column): ~10 us instead of >100 us inside a single workgroup.
+//   k_car_pivot   1 workgroup x 512 threads, Phi in VGPRs (4 columns x 13 rows per thread): the N-m
+//                 pivots of :237-266, one barrier per pivot.  Every DPP row carries its own copy of the
+//                 weights, so the DPP row that owns the next pivot column runs the ratio test on its
+//                 registers (16-lane DPP argmin with first-index tie break) straight after its own
+//                 elimination step.
 //
-// Limits: N <= 200, m*N <= 20,000, N-m <= 128 (batch <= 100).  Larger batches use the host LAPACK
-// path (sober_car_pivot_host).
+// Limits: N <= 208, m <= 112, N - m <= 112 (batch <= 100).  Larger batches use the host LAPACK path
+// (sober_car_pivot_host_fast).
 #include "common.hpp"
 
 namespace sober {
 
-constexpr int CAR_T = 1024;
-constexpr int CAR_RP = 25;          // Phi rows per thread: N <= 8 * 25
-constexpr int CAR_CQ = 13;          // columns per lane in the row sweeps: N <= 16 * 13
-constexpr int CAR_PAD = 208;        // >= 16 * CAR_CQ and >= 8 * CAR_RP + 8
-constexpr int CAR_P1 = 672 + 64 * 208;  // phase-1 exchange buffers (doubles)
+constexpr int CAR_MS = 7;           // matrix row slots per thread in the bidiagonalisation: m <= 16 * 7
+constexpr int CAR_CQ = 13;          // 16-lane slots along N: N <= 16 * 13
+constexpr int CAR_NS = 16 * CAR_CQ; // stride of a reflector / of the LDS columns
+constexpr int CAR_PC = 128;         // stride of a Phi row in the global scratch: N - m <= 128
+constexpr int CAR_BT = 256;         // threads of k_car_bidiag
 
 // ---- DPP cross-lane helpers (row = 16 lanes).  ds_bpermute-based __shfl costs an LDS round trip
 // per step; these are plain VALU moves.
@@ -77,6 +82,24 @@ __device__ __forceinline__ double wave_sum(double v) {    // uniform total over 
     return ((rdlane(v, 0) + rdlane(v, 16)) + rdlane(v, 32)) + rdlane(v, 48);
 }
 
+// 64-bit integer DPP move; lanes the control does not write keep their own value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+constexpr int BCAST15 = 0x142, BCAST31 = 0x143;   // lane 15 -> next row (rows 1, 3); lane 31 -> rows 2, 3
+
+// order-preserving map double -> uint64 for the ratio test: NaN -> 0 (torch.argmin lets a NaN win),
+// -inf < ... < -0 < +0 < ... < +inf in unsigned order
+__device__ __forceinline__ unsigned long long ratio_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned long long k = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    return (x != x) ? 0ull : k;
+}
+
 // dlarfg: reflector H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2
 __device__ __forceinline__ void larfg(double alpha, double ss, double& beta, double& tau, double& scal) {
     if (ss == 0.0) {
@@ -99,369 +122,459 @@ __device__ __forceinline__ void amin_take(double& best, int& piv, double ob, int
     piv = take ? op : piv;
 }
 
-__global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int ldx, int N, int m,
-                                               const double* __restrict__ mu_in,
-                                               int32_t* __restrict__ keep_rank,
-                                               double* __restrict__ w_star,
-                                               int32_t* __restrict__ n_keep_out,
-                                               double* __restrict__ mu_out,
-                                               double* __restrict__ phi_out,
-                                               double* __restrict__ vws) {
-    extern __shared__ double lds[];
-    // LDS map.  Phases 2-3: [0, m*NS + CAR_PAD) = the reflector vectors v~_i as rows (NS = 200 doubles,
-    // zero padded; fixed-stride sweeps over-read into zeros), then taup[m].  Phase 1 keeps the matrix
-    // itself in REGISTERS and uses the same base region for its small exchange buffers.
-    constexpr int NS = 8 * CAR_RP;
-    const int REG = max(m * NS + CAR_PAD, CAR_P1);
-    double* A = lds;                         // phases 2-3: rows of v~
-    double* taup = lds + REG;                // m
-    double* scal = taup + m;                 // [0] tauq  [1] tau
-    double* vbuf = lds;                      // phase 1: current v~ (208)
-    double* ubuf = lds + 208;                //          current u~ (128)
-    double* colb = lds + 336;                //          column i of the matrix (128)
-    double* zsum = lds + 464;                //          u~^T A per column (208)
-    double* zpart = lds + 672;               //          64 x 208 partial column sums
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef CAR_STAMPS
-    unsigned long long st_[8]; int sti_ = 0;
-#define CAR_STAMP() do { st_[sti_++] = __builtin_amdgcn_s_memtime(); st_[sti_++] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define CAR_STAMP() do { } while (0)
-#endif
-    CAR_STAMP();
-    const int l16 = lane & 15, rid = lane >> 4;          // lane in DPP row, DPP row in wave
-    const int g = l16 >> 1, c2 = l16 & 1;                // row group / column parity inside a DPP row
-    const int NC = N - m;
+// ---------------- phase 1: Golub-Kahan bidiagonalisation (dgebd2, m < N), matrix in VGPRs ----------------
+// Thread (R = tid >> 4, C = tid & 15) holds A[R + 16 k][C + 16 q], k < 7, q < 13.
+// per step: (A) the owner DPP row builds G(i), publishes v~ (LDS + global)                         | barrier
+//           (B) everyone applies it to its rows > i; column i is published                          | barrier
+//           (C) every wave builds H(i) from column i for itself; partial column sums u~^T A -> LDS   | barrier
+//           (D) 208 threads finish the sums                                                         | barrier
+//           then the rank-1 update with H(i)
+// Steps 16 S .. 16 S + 15 only touch row slots k >= S and column slots q >= S: the step body is instantiated
+// once per S so that the finished part of the matrix costs no instructions (the kernel is bound by the
+// instruction count of its one wave per SIMD, ~6 cycles per FP64 VALU op).
+struct CarLds {
+    double* vbuf; double* colb; double* zsum; double* zpart; double* scal;
+};
 
-    // ---------------- phase 1: Golub-Kahan bidiagonalisation (dgebd2, m < N), matrix in VGPRs ----------------
-    // 2-D block-cyclic ownership: thread (R = tid >> 4, C = tid & 15) holds A[r][c] for r in {R, R + 64},
-    // c = C + 16 q (q < 13): 26 doubles.  A matrix row lives in ONE DPP row (16 lanes), so row dot products
-    // are DPP reductions; column dot products go through a 64 x 208 partial buffer in LDS.  LDS traffic per
-    // step is ~4x lower than with the matrix itself in LDS (which is what bounded the previous version).
-    // per step: (A) the owner DPP row builds G(i), publishes v~ (LDS + global scratch for phase 2)  | barrier
-    //           (B) everyone applies it to its rows > i; column i is published                      | barrier
-    //           (C) wave 0 builds H(i) from column i                                                 | barrier
-    //           (D) partial column sums -> LDS | barrier | 208 threads finish the sums | barrier | update
-    const int R = tid >> 4, C = l16;
-    double a0[CAR_CQ], a1[CAR_CQ];
+template <int S>
+__device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], int m, const CarLds& L,
+                                                 double* __restrict__ vws, double* __restrict__ taup) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int R = tid >> 4, C = tid & 15;
+    const int i_end = min(16 * S + 16, m);
+    for (int i = 16 * S; i < i_end; ++i) {
+        const int li = i & 15;                               // row i: DPP row li, slot S; column i: lane li, slot S
+        if (R == li) {                                                 // (A)
+            double ss0 = 0.0, ss1 = 0.0;
+            {
+                const double x = a[S][S];
+                ss0 = (C > li) ? x * x : 0.0;
+            }
 #pragma unroll
-    for (int q = 0; q < CAR_CQ; ++q) {
-        const int c = C + 16 * q;
-        const bool okc = c < N;
-        a0[q] = (okc && R < m) ? ((R == 0) ? 1.0 : X[(size_t)c * ldx + (R - 1)]) : 0.0;
-        a1[q] = (okc && R + 64 < m) ? X[(size_t)c * ldx + (R + 63)] : 0.0;
+            for (int q = S + 1; q < CAR_CQ; ++q) { if (q & 1) ss1 = fma(a[S][q], a[S][q], ss1); else ss0 = fma(a[S][q], a[S][q], ss0); }
+            const double ss = row16_sum(ss0 + ss1);
+            const double al = row16_sum((C == li) ? a[S][S] : 0.0);
+            double beta, tau, sc;
+            larfg(al, ss, beta, tau, sc);
+#pragma unroll
+            for (int q = 0; q < CAR_CQ; ++q) {
+                const int c = C + 16 * q;
+                double v;
+                if (q < S) v = 0.0;
+                else if (q == S) v = (C < li) ? 0.0 : ((C == li) ? 1.0 : a[S][S] * sc);
+                else v = a[S][q] * sc;
+                L.vbuf[c] = v;
+                vws[(size_t)i * CAR_NS + c] = v;
+            }
+            if (C == 0) { taup[i] = tau; L.scal[1] = tau; }
+        }
+        if (i == m - 1) return;
+        CAR_LDS_BARRIER();
+        {                                                              // (B)
+            const double tau = L.scal[1];
+            double v[CAR_CQ];
+#pragma unroll
+            for (int q = S; q < CAR_CQ; ++q) v[q] = L.vbuf[C + 16 * q];
+#pragma unroll
+            for (int k = S; k < CAR_MS; ++k) {
+                double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+                for (int q = S; q < CAR_CQ; ++q) { if (q & 1) w1 = fma(a[k][q], v[q], w1); else w0 = fma(a[k][q], v[q], w0); }
+                double t = tau * row16_sum(w0 + w1);
+                t = (R + 16 * k > i) ? t : 0.0;                        // rows <= i stay (rows >= m are zero)
+#pragma unroll
+                for (int q = S; q < CAR_CQ; ++q) a[k][q] = fma(-t, v[q], a[k][q]);
+            }
+            if (C == li) {                                             // publish column i
+#pragma unroll
+                for (int k = S; k < CAR_MS; ++k) L.colb[R + 16 * k] = a[k][S];
+            }
+        }
+        CAR_LDS_BARRIER();
+        double u[CAR_MS], tauq;
+        {                                                              // (C), redundantly in every wave
+            const double x0 = L.colb[lane], x1 = L.colb[lane + 64];    // zero from row m on
+            double s2 = ((lane >= i + 2) ? x0 * x0 : 0.0) + ((lane + 64 >= i + 2) ? x1 * x1 : 0.0);
+            s2 = wave_sum(s2);
+            double beta2, sc2;
+            larfg(L.colb[i + 1], s2, beta2, tauq, sc2);
+#pragma unroll
+            for (int k = S; k < CAR_MS; ++k) {
+                const int r = R + 16 * k;
+                u[k] = (r <= i) ? 0.0 : ((r == i + 1) ? 1.0 : L.colb[r] * sc2);
+            }
+            double zp[CAR_CQ];
+#pragma unroll
+            for (int q = S; q < CAR_CQ; ++q) zp[q] = u[S] * a[S][q];
+#pragma unroll
+            for (int k = S + 1; k < CAR_MS; ++k)
+#pragma unroll
+                for (int q = S; q < CAR_CQ; ++q) zp[q] = fma(u[k], a[k][q], zp[q]);
+#pragma unroll
+            for (int q = S; q < CAR_CQ; ++q) L.zpart[R * CAR_NS + C + 16 * q] = zp[q];
+        }
+        CAR_LDS_BARRIER();
+        if (tid >= 16 * S && tid < CAR_NS) {                           // (D): columns of the live slots
+            double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; w += 2) {
+                z0 += L.zpart[w * CAR_NS + tid];
+                z1 += L.zpart[(w + 1) * CAR_NS + tid];
+            }
+            L.zsum[tid] = z0 + z1;
+        }
+        CAR_LDS_BARRIER();
+        {
+            double zq[CAR_CQ];
+#pragma unroll
+            for (int q = S; q < CAR_CQ; ++q) {
+                const int c = C + 16 * q;
+                zq[q] = (c > i) ? L.zsum[c] : 0.0;                     // H(i) acts on columns i+1 .. N-1 only
+            }
+#pragma unroll
+            for (int k = S; k < CAR_MS; ++k) {
+                const double f = tauq * u[k];
+#pragma unroll
+                for (int q = S; q < CAR_CQ; ++q) a[k][q] = fma(-f, zq[q], a[k][q]);
+            }
+        }
+        // (the next (A) touches registers, vbuf and scal[1] only; both were last read before the 2nd barrier)
     }
-#ifdef CAR_STAMPS2
-    unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+}
+
+__global__ __launch_bounds__(CAR_BT) void k_car_bidiag(const double* __restrict__ X, int ldx, int N, int m,
+                                                       double* __restrict__ vws, double* __restrict__ taup) {
+    __shared__ double vbuf[CAR_NS];
+    __shared__ double colb[128];
+    __shared__ double zsum[CAR_NS];
+    __shared__ double zpart[16 * CAR_NS];
+    __shared__ double scal[4];
+    const int tid = threadIdx.x;
+    const int R = tid >> 4, C = tid & 15;
+    double a[CAR_MS][CAR_CQ];
+#pragma unroll
+    for (int k = 0; k < CAR_MS; ++k)
+#pragma unroll
+        for (int q = 0; q < CAR_CQ; ++q) {
+            const int r = R + 16 * k, c = C + 16 * q;
+            a[k][q] = (c < N && r < m) ? ((r == 0) ? 1.0 : X[(size_t)c * ldx + (r - 1)]) : 0.0;
+        }
+    if (tid < 128) colb[tid] = 0.0;
+    __syncthreads();
+    const CarLds L{vbuf, colb, zsum, zpart, scal};
+    car_bidiag_block<0>(a, m, L, vws, taup);
+    if (m > 16) car_bidiag_block<1>(a, m, L, vws, taup);
+    if (m > 32) car_bidiag_block<2>(a, m, L, vws, taup);
+    if (m > 48) car_bidiag_block<3>(a, m, L, vws, taup);
+    if (m > 64) car_bidiag_block<4>(a, m, L, vws, taup);
+    if (m > 80) car_bidiag_block<5>(a, m, L, vws, taup);
+    if (m > 96) car_bidiag_block<6>(a, m, L, vws, taup);
+}
+
+// ---------------- phase 2: Phi = G(0) ... G(m-1) [0; I]  (N x NC) ----------------
+// The columns of Phi are independent: ONE WAVE PER COLUMN (lane l holds rows l + 64 q, q < 4), four waves per
+// workgroup, 32 workgroups.  A step is 4 + 4 FMAs and one 64-lane sum; three register buffers rotate through
+// the reflectors so that an L2 round trip (longer than a step) is always two steps ahead.
+__global__ __launch_bounds__(256) void k_car_phi(const double* __restrict__ vws, const double* __restrict__ taup,
+                                                 int N, int m, double* __restrict__ Phi,
+                                                 double* __restrict__ phi_out) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int NC = N - m;
+    double phi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) phi[q] = ((lane + 64 * q) == m + col && col < NC) ? 1.0 : 0.0;
+    if (col < NC) {                                                    // wave-uniform
+        const int r3 = min(lane + 192, CAR_NS - 1);                    // slot 3 exists for lanes 0..15 only
+        const bool ok3 = lane + 192 < CAR_NS;
+        // loads are unconditional (index clamped): a conditional load would make the compiler wait for ALL
+        // outstanding loads at the next use instead of counting them
+#define CAR_LOAD(BUF, TAU, I)                                                              \
+    {                                                                                      \
+        const double* src_ = vws + (size_t)max((I), 0) * CAR_NS;                           \
+        BUF[0] = src_[lane]; BUF[1] = src_[lane + 64]; BUF[2] = src_[lane + 128];          \
+        BUF[3] = src_[r3];                                                                 \
+        TAU = taup[max((I), 0)];                                                           \
+    }
+#define CAR_APPLY(V, TAU, I)                                                               \
+    if ((I) >= 0) {                                                                        \
+        const double v3_ = ok3 ? V[3] : 0.0;                                               \
+        const double d_ = fma(V[0], phi[0], V[1] * phi[1]) + fma(V[2], phi[2], v3_ * phi[3]); \
+        const double t_ = TAU * wave_sum(d_);                                              \
+        phi[0] = fma(-t_, V[0], phi[0]); phi[1] = fma(-t_, V[1], phi[1]);                  \
+        phi[2] = fma(-t_, V[2], phi[2]); phi[3] = fma(-t_, v3_, phi[3]);                   \
+    }
+        double vA[4], vB[4], vC[4];
+        double tA = 0.0, tB = 0.0, tC = 0.0;
+        CAR_LOAD(vA, tA, m - 1)
+        CAR_LOAD(vB, tB, m - 2)
+        for (int i = m - 1; i >= 0; i -= 3) {
+            CAR_LOAD(vC, tC, i - 2)
+            CAR_APPLY(vA, tA, i)
+            CAR_LOAD(vA, tA, i - 3)
+            CAR_APPLY(vB, tB, i - 1)
+            CAR_LOAD(vB, tB, i - 4)
+            CAR_APPLY(vC, tC, i - 2)
+        }
+#undef CAR_LOAD
+#undef CAR_APPLY
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = lane + 64 * q;
+        if (r < CAR_NS) {
+            Phi[(size_t)r * CAR_PC + col] = (r < N) ? phi[q] : 0.0;
+            if (phi_out != nullptr && col < NC && r < N) phi_out[(size_t)r * NC + col] = phi[q];
+        }
+    }
+}
+
+// ---------------- phase 3: the pivots of SOBER/_rchq.py:237-266 ----------------
+// Wave w owns columns w, w + 16, ...; lane l holds rows l + 64 q (q < 4) of each.  One barrier per pivot.
+// A dependent FP64 operation costs ~15 ns on one wave, so the kernel is shaped around the length of the
+// dependency chain from "pivot s known" to "pivot s+1 known":
+//   * the weights travel from owner to owner through LDS (only the wave that runs the ratio test needs them; a
+//     dead row -- Phi[idx, :] = 0 of :266 -- is marked by -0.0); the wave that owns column s+1 has that column in a FIXED
+//     register set (its columns are consumed in order; the array is rotated after each ownership), eliminates
+//     it first and runs the ratio test of step s+1 (:239-247) on its registers, while its other columns are
+//     updated by independent instructions the scheduler interleaves into the same block;
+//   * the 4 quotients AND the 4 reciprocals of a lane are issued together (IEEE division, interleaved chains);
+//   * quotients become order-preserving 64-bit keys; the 64-lane minimum is taken on the high and then the low
+//     word with single-instruction DPP steps, the first index then comes from ballots on the scalar unit;
+//   * the slot of the pivot row is picked by selects (no register-indexed branches) and the pivot row is not
+//     zeroed in the registers (:266) but marked dead: every later reader of that row goes through the mask.
+#ifndef CAR_PW_
+#define CAR_PW_ 16
+#endif
+constexpr int CAR_PW = CAR_PW_;            // waves in k_car_pivot
+#ifndef CAR_PJW_
+#define CAR_PJW_ 7                        // 8 spills at 1024 threads (128 VGPRs); 7 x 16 = 112 columns cover batch 100
+#endif
+constexpr int CAR_PJW = CAR_PJW_;          // columns per wave: N - m <= CAR_PW * CAR_PJW
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_min_u32(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {        // total in lane 63
+    v = dpp_min_u32<ROR8, 0xf>(v);
+    v = dpp_min_u32<ROR4, 0xf>(v);
+    v = dpp_min_u32<ROR2, 0xf>(v);
+    v = dpp_min_u32<ROR1, 0xf>(v);
+    v = dpp_min_u32<BCAST15, 0xa>(v);
+    v = dpp_min_u32<BCAST31, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ __launch_bounds__(CAR_PW * 64) void k_car_pivot(const double* __restrict__ Phi, int N, int m,
+                                                           const double* __restrict__ mu_in,
+                                                           int32_t* __restrict__ keep_rank,
+                                                           double* __restrict__ w_star,
+                                                           int32_t* __restrict__ n_keep_out,
+                                                           double* __restrict__ mu_out) {
+    __shared__ double colbuf[2 * 256];     // current / next pivot column (zero beyond N)
+    __shared__ double pscal[2 * 4];        // (alpha, piv, 1/Phi[piv,0]) of the current / next step
+    __shared__ double mubuf[256];          // the weights after the last finished update; -0.0 marks a dead row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NC = N - m;
+    double phi[CAR_PJW][4];                // phi[0] = my next column to become the pivot column
+    bool inr[4];
+#pragma unroll
+    for (int j = 0; j < CAR_PJW; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = lane + 64 * q;
+            phi[j][q] = (r < CAR_NS && wave + CAR_PW * j < CAR_PC) ? Phi[(size_t)r * CAR_PC + wave + CAR_PW * j] : 0.0;
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) inr[q] = lane + 64 * q < N;
+    if (tid < 512) colbuf[tid] = 0.0;
+    __syncthreads();
+    int nlive = (NC > wave) ? (NC - wave + CAR_PW - 1) / CAR_PW : 0;   // my columns not yet consumed as pivot columns
+
+    // publish column phi[0] as the pivot column of buffer nb and run the ratio test on it: first argmin of
+    // mu/Phi over Phi > 0, a NaN quotient wins (:239-247)
+#define CAR_RATIO_TEST(nb)                                                                \
+    {                                                                                     \
+        double rt_[4], rc_[4];                                                            \
+        unsigned kh_[4], kl_[4];                                                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                   \
+            colbuf[(nb) * 256 + lane + 64 * q] = phi[0][q];       /* zero beyond N */     \
+            rt_[q] = mu4[q] / phi[0][q];                                                  \
+            rc_[q] = 1.0 / phi[0][q];                                                     \
+        }                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                   \
+            const unsigned long long k_ = ratio_key(rt_[q]);                              \
+            const bool ok_ = inr[q] & (phi[0][q] > 0.0) & !dead[q];                       \
+            kh_[q] = ok_ ? (unsigned)(k_ >> 32) : 0xffffffffu;                            \
+            kl_[q] = ok_ ? (unsigned)k_ : 0xffffffffu;                                    \
+        }                                                                                 \
+        const unsigned h01_ = min(kh_[0], kh_[1]), h23_ = min(kh_[2], kh_[3]);            \
+        const unsigned H_ = wave_min_u32(min(h01_, h23_));                                \
+        const unsigned long long m0_ = __ballot(kh_[0] == H_), m1_ = __ballot(kh_[1] == H_); \
+        const unsigned long long m2_ = __ballot(kh_[2] == H_), m3_ = __ballot(kh_[3] == H_); \
+        unsigned L_ = 0;                                                                  \
+        const bool single_ = (__popcll(m0_) + __popcll(m1_) + __popcll(m2_) + __popcll(m3_)) == 1; \
+        if (!single_) {                      /* rare: several quotients share the high word */ \
+            unsigned l_[4];                                                               \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) l_[q] = (kh_[q] == H_) ? kl_[q] : 0xffffffffu; \
+            L_ = wave_min_u32(min(min(l_[0], l_[1]), min(l_[2], l_[3])));                 \
+        }                                                                                 \
+        int piv_ = -1;                                                                    \
+        double al_ = 0.0, rp_ = 1.0;                                                      \
+        if (H_ != 0xffffffffu) {         /* uniform; an all-ones high word = no candidate (or masked) */ \
+            const unsigned long long b0_ = single_ ? m0_ : __ballot((kh_[0] == H_) & (kl_[0] == L_)); \
+            const unsigned long long b1_ = single_ ? m1_ : __ballot((kh_[1] == H_) & (kl_[1] == L_)); \
+            const unsigned long long b2_ = single_ ? m2_ : __ballot((kh_[2] == H_) & (kl_[2] == L_)); \
+            const unsigned long long b3_ = single_ ? m3_ : __ballot((kh_[3] == H_) & (kl_[3] == L_)); \
+            if (b0_)      { const int f_ = __ffsll((long long)b0_) - 1; piv_ = f_;       al_ = rdlane(rt_[0], f_); rp_ = rdlane(rc_[0], f_); } \
+            else if (b1_) { const int f_ = __ffsll((long long)b1_) - 1; piv_ = f_ + 64;  al_ = rdlane(rt_[1], f_); rp_ = rdlane(rc_[1], f_); } \
+            else if (b2_) { const int f_ = __ffsll((long long)b2_) - 1; piv_ = f_ + 128; al_ = rdlane(rt_[2], f_); rp_ = rdlane(rc_[2], f_); } \
+            else          { const int f_ = __ffsll((long long)b3_) - 1; piv_ = f_ + 192; al_ = rdlane(rt_[3], f_); rp_ = rdlane(rc_[3], f_); } \
+        }                                                                                 \
+        if (lane == 0) { pscal[(nb) * 4] = al_; pscal[(nb) * 4 + 1] = (double)piv_;       \
+                         pscal[(nb) * 4 + 2] = rp_; }                                     \
+    }
+    // rank-1 elimination of column J: Phi[:,c] -= Phi[:,0] * (Phi[idx,c] / Phi[idx,0])  (:260-266)
+#define CAR_ELIM(J)                                                                       \
+    {                                                                                     \
+        const double lo_ = kp0 ? phi[J][0] : phi[J][1], hi_ = kp2 ? phi[J][2] : phi[J][3]; \
+        const double qv_ = rdlane(kplo ? lo_ : hi_, lp) * rpp_;                           \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) phi[J][q] = fma(-qv_, pc[q], phi[J][q]); \
+    }
+    // eliminate live columns FROM .. nlive-1 (consumed columns are zero; uniform branches)
+#define CAR_ELIM_IF(J, FROM) if ((J) >= (FROM) && (J) < CAR_PJW && (J) < nlive) CAR_ELIM((J) < CAR_PJW ? (J) : 0)
+#define CAR_ELIM_LIVE(FROM)                                                               \
+    CAR_ELIM_IF(0, FROM) CAR_ELIM_IF(1, FROM) CAR_ELIM_IF(2, FROM) CAR_ELIM_IF(3, FROM)   \
+    CAR_ELIM_IF(4, FROM) CAR_ELIM_IF(5, FROM) CAR_ELIM_IF(6, FROM) CAR_ELIM_IF(7, FROM)   \
+    CAR_ELIM_IF(8, FROM) CAR_ELIM_IF(9, FROM) CAR_ELIM_IF(10, FROM) CAR_ELIM_IF(11, FROM) \
+    CAR_ELIM_IF(12, FROM) CAR_ELIM_IF(13, FROM) CAR_ELIM_IF(14, FROM) CAR_ELIM_IF(15, FROM)
+    // weights after pivot `PIV` (alpha A, pivot column PCOL) from the weights in mubuf; -0.0 = dead row
+#define CAR_MU_STEP(A, PIV, PCOL)                                                         \
+    double mu4[4];                                                                        \
+    bool dead[4];                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                       \
+        const double mp_ = mubuf[lane + 64 * q];                                          \
+        dead[q] = ((__double2hiint(mp_) == (int)0x80000000) & (__double2loint(mp_) == 0)) | (lane + 64 * q == (PIV)); \
+        mu4[q] = dead[q] ? -0.0 : __dsub_rn(mp_, __dmul_rn((A), (PCOL)[q]));              \
+    }
+    if (wave == 0) {                                                   // column 0 is the first pivot column
+        double mu4[4];
+        bool dead[4] = {false, false, false, false};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mu4[q] = inr[q] ? mu_in[lane + 64 * q] + 0.0 : 0.0;         // (+ 0.0: an input -0.0 is not a dead row)
+            mubuf[lane + 64 * q] = mu4[q];
+        }
+        CAR_RATIO_TEST(0)
+#pragma unroll
+        for (int j = 0; j + 1 < CAR_PJW; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) phi[j][q] = phi[j + 1][q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) phi[CAR_PJW - 1][q] = 0.0;
+        --nlive;
+    }
+    __syncthreads();
+#ifdef CAR_STAMPS
+    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime(), arr_ = 0;
 #define CAR_SUB(K) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_[K] += t_ - tl_; tl_ = t_; } while (0)
 #else
 #define CAR_SUB(K) do { } while (0)
 #endif
-    for (int i = 0; i < m; ++i) {
-        const bool hi = i >= 64;                         // row i is the a1 (hi) or a0 row of DPP row (i & 63)
-        const int qi = i >> 4, ci = i & 15;              // column i = lane ci, slot qi
-        if (R == (i & 63)) {                                           // (A)
-#define CAR_STEP_A(ARR)                                                                       \
-            {                                                                                 \
-                double ss = 0.0, al = 0.0;                                                    \
-                _Pragma("unroll") for (int q = 0; q < CAR_CQ; ++q) {                          \
-                    const int c = C + 16 * q;                                                 \
-                    ss = (c > i) ? fma(ARR[q], ARR[q], ss) : ss;                              \
-                    al = (c == i) ? ARR[q] : al;                                              \
-                }                                                                             \
-                ss = row16_sum(ss);                                                           \
-                al = row16_sum(al);                                                           \
-                double beta, tau, sc;                                                         \
-                larfg(al, ss, beta, tau, sc);                                                 \
-                _Pragma("unroll") for (int q = 0; q < CAR_CQ; ++q) {                          \
-                    const int c = C + 16 * q;                                                 \
-                    const double v = (c < i) ? 0.0 : ((c == i) ? 1.0 : ARR[q] * sc);          \
-                    vbuf[c] = v;                                                              \
-                    if (c < NS) vws[(size_t)i * NS + c] = v;                                  \
-                }                                                                             \
-                if (C == 0) { taup[i] = tau; scal[1] = tau; }                                 \
-            }
-            if (hi) CAR_STEP_A(a1) else CAR_STEP_A(a0)
-#undef CAR_STEP_A
-        }
-        if (i == m - 1) break;
-        CAR_LDS_BARRIER();
-        CAR_SUB(0);
-        {                                                              // (B)
-            const double tau = scal[1];
-            double vreg[CAR_CQ];
-#pragma unroll
-            for (int q = 0; q < CAR_CQ; ++q) vreg[q] = vbuf[C + 16 * q];
-            if (R > i && R < m) {
-                double w0 = 0.0, w1 = 0.0;
-#pragma unroll
-                for (int q = 0; q < CAR_CQ; ++q) { if (q & 1) w1 = fma(a0[q], vreg[q], w1); else w0 = fma(a0[q], vreg[q], w0); }
-                const double t = tau * row16_sum(w0 + w1);
-#pragma unroll
-                for (int q = 0; q < CAR_CQ; ++q) a0[q] = fma(-t, vreg[q], a0[q]);
-            }
-            if (R + 64 > i && R + 64 < m) {
-                double w0 = 0.0, w1 = 0.0;
-#pragma unroll
-                for (int q = 0; q < CAR_CQ; ++q) { if (q & 1) w1 = fma(a1[q], vreg[q], w1); else w0 = fma(a1[q], vreg[q], w0); }
-                const double t = tau * row16_sum(w0 + w1);
-#pragma unroll
-                for (int q = 0; q < CAR_CQ; ++q) a1[q] = fma(-t, vreg[q], a1[q]);
-            }
-            if (C == ci) {                                             // publish column i
-                double x0 = 0.0, x1 = 0.0;
-                switch (qi) {                                          // uniform
-#define CAR_CASE(K) case K: x0 = a0[K]; x1 = a1[K]; break;
-                    CAR_CASE(0) CAR_CASE(1) CAR_CASE(2) CAR_CASE(3) CAR_CASE(4) CAR_CASE(5) CAR_CASE(6)
-                    CAR_CASE(7) CAR_CASE(8) CAR_CASE(9) CAR_CASE(10) CAR_CASE(11) CAR_CASE(12)
-#undef CAR_CASE
-                    default: break;
-                }
-                colb[R] = x0;
-                colb[R + 64] = x1;
-            }
-        }
-        CAR_LDS_BARRIER();
-        CAR_SUB(1);
-        if (wave == 0) {                                               // (C)
-            double ureg[2];
-            double s2 = 0.0;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int r = i + 2 + lane + 64 * q;
-                const double x = colb[min(r, 127)];
-                ureg[q] = (r < m) ? x : 0.0;
-                s2 = fma(ureg[q], ureg[q], s2);
-            }
-            s2 = wave_sum(s2);
-            double beta2, tauq, sc2;
-            larfg(colb[i + 1], s2, beta2, tauq, sc2);
-            if (lane == 0) scal[0] = tauq;
-            // u~ over absolute rows 0 .. 127: zeros up to row i, 1 at row i+1, u below, zeros from m on
-            for (int r = lane; r < 128; r += 64)
-                if (r <= i + 1 || r >= m) ubuf[r] = (r == i + 1) ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int r = i + 2 + lane + 64 * q;
-                if (r < m) ubuf[r] = ureg[q] * sc2;
-            }
-        }
-        CAR_LDS_BARRIER();
-        CAR_SUB(2);
-        const double u0 = ubuf[R], u1 = ubuf[R + 64];                  // (D)
-#pragma unroll
-        for (int q = 0; q < CAR_CQ; ++q) zpart[R * 208 + C + 16 * q] = fma(u1, a1[q], u0 * a0[q]);
-        CAR_LDS_BARRIER();
-        CAR_SUB(3);
-        if (tid < 832) {                                               // 4 lanes per column, 16 partials each
-            const int cc = tid >> 2, part = tid & 3;
-            double z0 = 0.0, z1 = 0.0;
-#pragma unroll
-            for (int w = 0; w < 16; w += 2) {
-                z0 += zpart[(part * 16 + w) * 208 + cc];
-                z1 += zpart[(part * 16 + w + 1) * 208 + cc];
-            }
-            double zz = z0 + z1;
-            zz += dpp<0xB1>(zz);                                       // quad_perm [1,0,3,2]
-            zz += dpp<0x4E>(zz);                                       // quad_perm [2,3,0,1]
-            if (part == 0) zsum[cc] = zz;
-        }
-        CAR_LDS_BARRIER();
-        CAR_SUB(4);
-        {
-            const double tq = scal[0];
-            const double f0 = tq * u0, f1 = tq * u1;
-#pragma unroll
-            for (int q = 0; q < CAR_CQ; ++q) {
-                const int c = C + 16 * q;
-                const double z = (c > i) ? zsum[c] : 0.0;              // H(i) acts on columns i+1 .. N-1 only
-                a0[q] = fma(-f0, z, a0[q]);
-                a1[q] = fma(-f1, z, a1[q]);
-            }
-        }
-        // (the next (A) touches registers and vbuf only; vbuf was last read before barrier 2)
-        CAR_SUB(5);
-    }
 
-    __threadfence_block();
-    __syncthreads();
-    // reflector vectors: global scratch -> LDS rows for phases 2 and 3
-    for (int t = tid; t < m * NS + CAR_PAD; t += CAR_T) A[t] = (t < m * NS) ? vws[t] : 0.0;
-    __syncthreads();
-
-    CAR_STAMP();
-    // ---------------- phase 2: Phi = G(0) ... G(m-1) [0; I]  (N x NC, in registers) ----------------
-    // thread (wave, rid, c2, g) owns rows g, g+8, ... of column wave*8 + rid*2 + c2
-    const int col = wave * 8 + rid * 2 + c2;
-    const bool okcol = col < NC;
-    double phi[CAR_RP];
-#pragma unroll
-    for (int k = 0; k < CAR_RP; ++k) phi[k] = (okcol && (g + 8 * k) == m + col) ? 1.0 : 0.0;
-    if (wave * 8 < NC) {
-        for (int i = m - 1; i >= 0; --i) {
-            const double* vi = A + (size_t)i * NS + g;     // row i now holds [0.., 1, v_i, 0 pad]; stride-8 walk
-            const double tau = taup[i];
-            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-#pragma unroll
-            for (int k = 0; k < CAR_RP; ++k) {
-                {
-                    const double v = vi[8 * k];                        // zero beyond column N-1
-                    if ((k & 3) == 0) p0 = fma(v, phi[k], p0);
-                    else if ((k & 3) == 1) p1 = fma(v, phi[k], p1);
-                    else if ((k & 3) == 2) p2 = fma(v, phi[k], p2);
-                    else p3 = fma(v, phi[k], p3);
-                }
-                if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);   // cap load hoisting: VGPR budget is 128
-            }
-            const double t = tau * grp8_sum((p0 + p1) + (p2 + p3));
-#pragma unroll
-            for (int k = 0; k < CAR_RP; ++k) {                         // second pass re-reads v_i from LDS:
-                phi[k] = fma(-t, vi[8 * k], phi[k]);                   // cheaper than 50 more live VGPRs
-                if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    if (phi_out != nullptr && okcol) {                                 // stage-level test hook
-#pragma unroll
-        for (int k = 0; k < CAR_RP; ++k)
-            if (g + 8 * k < N) phi_out[(size_t)(g + 8 * k) * NC + col] = phi[k];
-    }
-    __syncthreads();                                                   // A is dead from here on
-
-    CAR_STAMP();
-    // ---------------- phase 3: the pivots of SOBER/_rchq.py:237-266 ----------------
-    // One barrier per pivot.  Step s: every column owner eliminates with (piv_s, alpha_s) read from LDS;
-    // the wave that owns pivot column s+1 then, still inside the same step, publishes that column,
-    // applies the mu update of step s (:253-254) and runs the ratio test of step s+1 (:239-247).
-    const int NP = 264;                    // padded stride >= N + 64
-    double* colbuf = lds;                  // [2][NP]   current / next pivot column (zero beyond N)
-    double* mubuf = lds + 2 * NP;          // [2][NP]
-    double* pscal = lds + 4 * NP;          // [2][4]    (alpha, piv, 1/Phi[piv,0]) of the current / next step
-    for (int r = tid; r < 2 * NP; r += CAR_T) colbuf[r] = 0.0;
-    __syncthreads();
-    for (int r = tid; r < N; r += CAR_T) mubuf[r] = mu_in[r];
-    if (okcol && col == 0) {
-#pragma unroll
-        for (int k = 0; k < CAR_RP; ++k)
-            if (g + 8 * k < N) colbuf[g + 8 * k] = phi[k];
-    }
-    __syncthreads();
-
-#define CAR_AMIN_ROW(CTRL)                                                                 \
-        {                                                                                 \
-            const double ob_ = dpp<CTRL>(best_);                                          \
-            const int op_ = __builtin_amdgcn_update_dpp(0, piv_, CTRL, 0xf, 0xf, false);  \
-            amin_take(best_, piv_, ob_, op_);                                             \
-        }
-    // ratio test on (column cp, weights held in mu4): first argmin of mu/Phi over Phi > 0 (NaN wins)
-#define CAR_RATIO_TEST(cp, outp)                                                          \
-    {                                                                                     \
-        double best_ = 0.0; int piv_ = -1;                                                \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                   \
-            const int r = lane + 64 * q;                                                  \
-            const double ph = (cp)[r];                                                    \
-            const bool ok = (r < N) & (ph > 0.0);                                         \
-            amin_take(best_, piv_, mu4[q] / ph, ok ? r : -1);                             \
-        }                                                                                 \
-        CAR_AMIN_ROW(ROR8) CAR_AMIN_ROW(ROR4) CAR_AMIN_ROW(ROR2) CAR_AMIN_ROW(ROR1)       \
-        {                                                                                 \
-            double b0_ = rdlane(best_, 0); int p0_ = __builtin_amdgcn_readlane(piv_, 0);  \
-            amin_take(b0_, p0_, rdlane(best_, 16), __builtin_amdgcn_readlane(piv_, 16));  \
-            amin_take(b0_, p0_, rdlane(best_, 32), __builtin_amdgcn_readlane(piv_, 32));  \
-            amin_take(b0_, p0_, rdlane(best_, 48), __builtin_amdgcn_readlane(piv_, 48));  \
-            best_ = b0_; piv_ = p0_;                                                      \
-        }                                                                                 \
-        if (lane == 0) { (outp)[0] = best_; (outp)[1] = (double)piv_;                     \
-                         (outp)[2] = 1.0 / (cp)[max(piv_, 0)]; }                          \
-    }
-    if (wave == 0) {
-        double mu4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mu4[q] = mubuf[lane + 64 * q];
-        CAR_RATIO_TEST(colbuf, pscal);
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int s = 0; s < NC; ++s, cur ^= 1) {
-        const double* cb = colbuf + cur * NP;
+    int cur = 0, s = 0;
+    for (; s < NC; ++s, cur ^= 1) {
+#ifdef CAR_STAMPS
+        const unsigned long long it0_ = tl_;
+#endif
         const double alpha = pscal[cur * 4];
         const int piv = (int)pscal[cur * 4 + 1];
         const double rpp = pscal[cur * 4 + 2];
+        double rpp_ = rpp;
         if (piv < 0) break;                                             // Q6 (:241-242), uniform
-        const int kp = piv >> 3, gp = piv & 7;
-        if (okcol && col > s) {
-            // rank-1 elimination of my column: Phi[:,c] -= Phi[:,0] * (Phi[idx,c] / Phi[idx,0]).  The
-            // pivot-row entry of my column sits in the lane with g == piv % 8 of my own DPP row.
-            double mine = 0.0;
-            switch (kp) {                                               // uniform: a scalar jump, no select chain
-#define CAR_CASE(K) case K: mine = phi[K]; break;
-                CAR_CASE(0) CAR_CASE(1) CAR_CASE(2) CAR_CASE(3) CAR_CASE(4) CAR_CASE(5) CAR_CASE(6) CAR_CASE(7)
-                CAR_CASE(8) CAR_CASE(9) CAR_CASE(10) CAR_CASE(11) CAR_CASE(12) CAR_CASE(13) CAR_CASE(14)
-                CAR_CASE(15) CAR_CASE(16) CAR_CASE(17) CAR_CASE(18) CAR_CASE(19) CAR_CASE(20) CAR_CASE(21)
-                CAR_CASE(22) CAR_CASE(23) CAR_CASE(24)
-#undef CAR_CASE
-                default: break;
-            }
-            const double prow = __shfl(mine, (lane & 0x30) | (gp << 1) | c2, 64);
-            const double qv = prow * rpp;                               // Phi[idx,c] / Phi[idx,0]
-            const double* cbg = cb + g;
+        const int kp = piv >> 6, lp = piv & 63;
+        const bool kp0 = kp == 0, kp2 = kp == 2, kplo = kp < 2;
+        double pc[4];
 #pragma unroll
-            for (int k = 0; k < CAR_RP; ++k) {
-                phi[k] = fma(-qv, cbg[8 * k], phi[k]);                  // column is zero beyond N
-                if ((k % 6) == 5) __builtin_amdgcn_sched_barrier(0);
-            }
-            if (g == gp) {                                              // Phi[idx, :] = 0 (:266), exactly
-                switch (kp) {
-#define CAR_CASE(K) case K: phi[K] = 0.0; break;
-                    CAR_CASE(0) CAR_CASE(1) CAR_CASE(2) CAR_CASE(3) CAR_CASE(4) CAR_CASE(5) CAR_CASE(6) CAR_CASE(7)
-                    CAR_CASE(8) CAR_CASE(9) CAR_CASE(10) CAR_CASE(11) CAR_CASE(12) CAR_CASE(13) CAR_CASE(14)
-                    CAR_CASE(15) CAR_CASE(16) CAR_CASE(17) CAR_CASE(18) CAR_CASE(19) CAR_CASE(20) CAR_CASE(21)
-                    CAR_CASE(22) CAR_CASE(23) CAR_CASE(24)
-#undef CAR_CASE
-                    default: break;
-                }
-            }
-            if (col == s + 1) {                                        // next pivot column
+        for (int q = 0; q < 4; ++q) pc[q] = colbuf[cur * 256 + lane + 64 * q];
+        CAR_SUB(0);
+        const int nxt = s + 1;
+        const bool owner = nxt < NC && (nxt % CAR_PW) == wave;          // phi[0] is the next pivot column
+        if (owner) {
+            __builtin_amdgcn_s_setprio(3);                              // the critical chain of the step
+            // mu[:] = mu - alpha * Phi[:,0]; mu[idx] = 0   (two roundings like the tensor expression, :253-254)
+            CAR_MU_STEP(alpha, piv, pc)
 #pragma unroll
-                for (int k = 0; k < CAR_RP; ++k)
-                    if (g + 8 * k < N) colbuf[(cur ^ 1) * NP + g + 8 * k] = phi[k];
-            }
-        }
-        if (wave == min((s + 1) >> 3, 15)) {
-            // mu[:] = mu - alpha * Phi[:,0]; mu[idx] = 0   (two roundings like the tensor expression)
-            const double* mb = mubuf + cur * NP;
-            double mu4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = lane + 64 * q;
-                mu4[q] = (r == piv) ? 0.0 : __dsub_rn(mb[r], __dmul_rn(alpha, cb[r]));
-                if (r < N) mubuf[(cur ^ 1) * NP + r] = mu4[q];
-            }
-            if (s + 1 < NC) {
-                const double* cn = colbuf + (cur ^ 1) * NP;            // written above by lanes of THIS wave
-                CAR_RATIO_TEST(cn, pscal + (cur ^ 1) * 4);
-            }
-        }
-        __syncthreads();
-    }
-#undef CAR_RATIO_TEST
-
-    CAR_STAMP();
+            for (int q = 0; q < 4; ++q) mubuf[lane + 64 * q] = mu4[q];
+            CAR_ELIM(0)
+            CAR_RATIO_TEST(cur ^ 1)
+            __builtin_amdgcn_s_setprio(0);
+            CAR_SUB(1);
 #ifdef CAR_STAMPS
-    if (tid == 0 && phi_out != nullptr) for (int q = 0; q < 8; ++q) ((unsigned long long*)phi_out)[q] = st_[q];
+            acc_[4] += tl_ - it0_; acc_[5] += 1;
 #endif
-#ifdef CAR_STAMPS2
-    if (tid == 0 && phi_out != nullptr) for (int q = 0; q < 6; ++q) ((unsigned long long*)phi_out)[16 + q] = acc_[q];
+        } else {
+            CAR_ELIM_LIVE(0)
+            CAR_SUB(2);
+        }
+#ifdef CAR_STAMPS
+        arr_ += __builtin_amdgcn_s_memtime() - it0_;
+        if (s == 50 && lane == 0) ((unsigned long long*)Phi)[(size_t)205 * CAR_PC + 64 + wave] = __builtin_amdgcn_s_memtime() - it0_;
 #endif
+        __syncthreads();
+#ifdef CAR_STAMPS
+        if (owner) { acc_[6] += __builtin_amdgcn_s_memtime() - tl_; }
+#endif
+        if (owner) {
+            // off the critical path: the owner catches up with its other columns while the next owner (another
+            // wave) is already working on step s+1; then its next column moves to slot 0.  (The empty asm pins
+            // this register-only code behind the barrier: the compiler is otherwise free to hoist it.)
+            asm volatile("" : "+v"(rpp_));
+            CAR_ELIM_LIVE(1)
+#pragma unroll
+            for (int j = 0; j + 1 < CAR_PJW; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) phi[j][q] = phi[j + 1][q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) phi[CAR_PJW - 1][q] = 0.0;
+            --nlive;
+#ifdef CAR_STAMPS
+            acc_[7] += __builtin_amdgcn_s_memtime() - tl_;
+#endif
+        }
+        CAR_SUB(3);
+    }
+#ifdef CAR_STAMPS
+    if (lane == 0) ((unsigned long long*)Phi)[(size_t)206 * CAR_PC + 64 + wave] = arr_;
+    if (lane == 0 && wave < 2) for (int q_ = 0; q_ < 8; ++q_) ((unsigned long long*)Phi)[(size_t)207 * CAR_PC + 112 + 8 * wave + q_] = acc_[q_];
+#endif
+#undef CAR_RATIO_TEST
+#undef CAR_ELIM
+#undef CAR_ELIM_LIVE
+#undef CAR_ELIM_IF
+
     // ---------------- output: w_star = mu[mu > 0], idx_star as ranks ----------------
     if (wave == 0) {
-        const double* mb = mubuf + cur * NP;
+        double fin[4];
+        if (s == NC && NC > 0) {                                        // the update of the last pivot is still due
+            const int lc = (NC - 1) & 1;
+            const double* pcl = colbuf + lc * 256;
+            const double pcv[4] = {pcl[lane], pcl[lane + 64], pcl[lane + 128], pcl[lane + 192]};
+            CAR_MU_STEP(pscal[lc * 4], (int)pscal[lc * 4 + 1], pcv)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fin[q] = mu4[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fin[q] = mubuf[lane + 64 * q];
+        }
         int base = 0;
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = lane + 64 * q;
-            const double v = (r < N) ? mb[r] : 0.0;
+            const double v = (r < N) ? fin[q] + 0.0 : 0.0;              // -0.0 (dead) -> +0.0
             const bool keep = (r < N) && (v > 0.0);
             const unsigned long long bal = __ballot(keep);
             const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
@@ -474,17 +587,19 @@ __global__ __launch_bounds__(CAR_T) void k_car(const double* __restrict__ X, int
         }
         if (lane == 0) *n_keep_out = base;
     }
+#undef CAR_MU_STEP
 }
 
 }  // namespace sober
 
 extern "C" int sober_car_supported(int N, int m) {
-    return (m >= 2 && N > m && N <= 8 * sober::CAR_RP && N <= 16 * sober::CAR_CQ && m <= 100 && N - m <= 120) ? 1 : 0;
+    return (m >= 2 && N > m && N <= sober::CAR_NS && m <= 16 * sober::CAR_MS && N - m <= sober::CAR_PW * sober::CAR_PJW) ? 1 : 0;
 }
 
+// scratch: reflectors (m x 208), tau (m, padded to 128), Phi (208 x 128)
 extern "C" int64_t sober_car_ws_bytes(int N, int m) {
     (void)N;
-    return (int64_t)m * 8 * sober::CAR_RP * (int64_t)sizeof(double);
+    return ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC) * (int64_t)sizeof(double);
 }
 
 extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
@@ -493,19 +608,16 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
     if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || !ws || ldx < m - 1) return SOBER_E_ARG;
     if (!sober_car_supported(N, m)) return SOBER_E_DIM;
     if (ws_bytes < sober_car_ws_bytes(N, m)) return SOBER_E_WS;
-    size_t base = (size_t)m * (8 * sober::CAR_RP) + sober::CAR_PAD;
-    if (base < (size_t)sober::CAR_P1) base = sober::CAR_P1;
-    size_t doubles = base + (size_t)m + 8;
-    if (doubles < 4 * 264 + 8) doubles = 4 * 264 + 8;
-    const size_t bytes = doubles * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(sober::k_car, dim3(1), dim3(sober::CAR_T), bytes, (hipStream_t)stream, X, ldx, N, m,
-                       mu_in, keep_rank, w_star, n_keep, mu_out, phi_out, (double*)ws);
+    hipStream_t st = (hipStream_t)stream;
+    double* vws = (double*)ws;
+    double* taup = vws + (size_t)m * sober::CAR_NS;
+    double* Phi = taup + 128;
+    hipLaunchKernelGGL(sober::k_car_bidiag, dim3(1), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(sober::k_car_phi, dim3(sober::CAR_PC / 4), dim3(256), 0, st, vws, taup, N, m, Phi, phi_out);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(sober::k_car_pivot, dim3(1), dim3(sober::CAR_PW * 64), 0, st, Phi, N, m, mu_in, keep_rank, w_star,
+                       n_keep, mu_out);
     LAUNCH_CHECK();
     return 0;
 }

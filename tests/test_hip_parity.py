@@ -733,3 +733,18 @@ def test_basq_quadrature_vs_reference(dev):
         np.testing.assert_allclose(w.cpu().numpy(), z[f"{tag}_w"], rtol=W_RTOL)
         assert abs(ELML - float(z[f"{tag}_ELML"])) < 1e-6 and abs(AVLML - float(z[f"{tag}_AVLML"])) < 1e-5
         assert abs(EML - float(z[f"{tag}_EML"])) < 1e-6 * abs(EML)
+
+
+def test_gspace_materialise_chunks(dev):
+    """The HBM-resident g-space matrix over a pool larger than one chunk: rows sampled across the chunk
+    boundaries agree with the oracle's kernel."""
+    z = np.load(os.path.join(GOLD, "basq.npz"))
+    spec = O.GPSpec(str(z["a_kind"]), _t(z["a_ls"]), 1.3, _t(z["a_X_obs"]), _t(z["a_S_cache"]), 1e-3, 0.15, _t(z["a_alpha"]))
+    gk = sober_amd.GspaceKernel(_basq_kspec(z, "a"))
+    rng = np.random.default_rng(77)
+    X = rng.random((70001, 4)); Xn = X[:48].copy()
+    K = gk.materialise(_t(X).to(dev), _t(Xn).to(dev))
+    assert K.shape == (70001, 48)
+    rows = np.r_[0, 1, 32767, 32768, 32769, 65535, 65536, 70000, rng.integers(0, 70001, 40)]
+    ref = O.gspace_kernel(_t(Xn), _t(X[rows]), spec).numpy().T
+    np.testing.assert_allclose(K[rows].cpu().numpy(), ref, rtol=1e-9, atol=1e-12)     # exp(C) - 1 cancels for small C
