@@ -196,6 +196,10 @@ int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const double* L,
  * flag[0] |= 1 when C is not exactly symmetric (:127).  Zero flag first.                            */
 int sober_abs_sym(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, void* stream);
 
+/* k rungs of make_cov_psd's jitter ladder (SOBER/_utils.py:151-152) with the reference's sequence of
+ * roundings: jitter = 1e-5; repeat k times { diag(A) += jitter; jitter *= 2 }.                        */
+int sober_jitter_ladder(double* A, int n, int ld, int k, void* stream);
+
 /* KMeans of SOBER/_weights.py:100-126: Lloyd, centroids initialised to the first K rows, exactly
  * `iters` iterations, first-index argmin (a NaN distance wins like torch.argmin), empty cluster ->
  * NaN centroid.  X is (N, d) row-major raw points.  labels: N int32.  ws: sober_kmeans_ws_bytes.  */

@@ -54,6 +54,7 @@ SIGNATURES = {
     "sober_chol_small": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_trsm_rows": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "sober_jitter_ladder": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "sober_kmeans_ws_bytes": (_i64, [_i64, _i32, _i32]),
     "sober_kmeans_lloyd": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "sober_predict_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f64, _vp, _f64, _f64, _vp, _f64, _vp, _i32, _vp]),
@@ -360,3 +361,7 @@ def gspace_finish(K, corr, mug_cand, mug_rows):
     n, m = K.shape
     _check(load().sober_gspace_finish(K.data_ptr(), corr.data_ptr(), n, m, K.stride(0), corr.stride(0),
                                       mug_cand.data_ptr(), mug_rows.data_ptr(), _stream(K)), "sober_gspace_finish")
+
+
+def jitter_ladder(A, k):
+    _check(load().sober_jitter_ladder(A.data_ptr(), A.shape[0], A.stride(0), int(k), _stream(A)), "sober_jitter_ladder")

@@ -136,11 +136,8 @@ class HipOps:
         (info_h,) = self.to_host(info)
         ok = (info_h == 0).tolist()
         k_first = ok.index(True) if any(ok) else max_iter + 1
-        diag = C.diagonal()
-        jitter = torch.full((M,), 1e-5, dtype=torch.float64, device=dev)
-        for _ in range(k_first):                           # SOBER/_utils.py:151-152, one rung at a time
-            diag += jitter
-            jitter *= 2
+        # SOBER/_utils.py:150-156: k_first additions (max_iter + 1 of them before the diagonal fallback), one launch
+        nat.jitter_ladder(C, k_first)
         if k_first > max_iter:
             C = torch.diag(C.diagonal().clone())           # :155
         U = self._svd_lowrank_device(C, s, R)

@@ -276,17 +276,40 @@ __global__ __launch_bounds__(256) void k_trsm_rows(const double* __restrict__ Y,
 
 // cov -> sqrt(nan_to_num(cov) * nan_to_num(cov).T) (SOBER/_utils.py:143-144) and the exact-symmetry
 // test of :127 on the input: flag[0] |= 1 if some cov[i][j] != cov[j][i].
-__global__ void k_abs_sym(const double* __restrict__ C, int n, int ld, double* __restrict__ out, int ldo,
-                          int32_t* __restrict__ flag) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j >= n) return;
-    double a = C[(size_t)i * ld + j], b = C[(size_t)j * ld + i];
-    if (!(a == b)) atomicOr(flag, 1);
+__global__ __launch_bounds__(256) void k_abs_sym(const double* __restrict__ C, int n, int ld,
+                                                 double* __restrict__ out, int ldo, int32_t* __restrict__ flag) {
+    // 32 x 32 tile and its mirror image through LDS: both reads are row-contiguous
+    __shared__ double tm[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = j0 + r, j = i0 + tx;                            // mirror tile element C[j0 + r][i0 + tx]
+        tm[r][tx] = (i < n && j < n) ? C[(size_t)i * ld + j] : 0.0;
+    }
+    __syncthreads();
+    bool asym = false;
     const double big = 1.7976931348623157e308;
-    a = (a != a) ? 0.0 : fmin(fmax(a, -big), big);            // torch.nan_to_num
-    b = (b != b) ? 0.0 : fmin(fmax(b, -big), big);
-    out[(size_t)i * ldo + j] = sqrt(a * b);
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, j = j0 + tx;
+        if (i < n && j < n) {
+            double a = C[(size_t)i * ld + j], b = tm[tx][r];          // C[j][i]
+            asym |= !(a == b);
+            a = (a != a) ? 0.0 : fmin(fmax(a, -big), big);            // torch.nan_to_num
+            b = (b != b) ? 0.0 : fmin(fmax(b, -big), big);
+            out[(size_t)i * ldo + j] = sqrt(a * b);
+        }
+    }
+    if (__syncthreads_or(asym) && threadIdx.x == 0) atomicOr(flag, 1);
+}
+
+// the jitter ladder of make_cov_psd (SOBER/_utils.py:151-152), k rungs at once with the reference's own
+// sequence of roundings: jitter = 1e-5; repeat k times { diag += jitter; jitter *= 2 }
+__global__ void k_jitter_ladder(double* __restrict__ A, int n, int ld, int k) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double d = A[(size_t)i * ld + i], jit = 1e-5;
+    for (int t = 0; t < k; ++t) { d = __dadd_rn(d, jit); jit = __dmul_rn(jit, 2.0); }
+    A[(size_t)i * ld + i] = d;
 }
 
 }  // namespace sober
@@ -364,8 +387,16 @@ extern "C" int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const
 
 extern "C" int sober_abs_sym(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, void* stream) {
     if (!C || !out || !flag || n <= 0 || ld < n || ldo < n || n > 65535) return SOBER_E_ARG;
-    hipLaunchKernelGGL(sober::k_abs_sym, dim3((n + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, C, n, ld, out,
-                       ldo, flag);
+    hipLaunchKernelGGL(sober::k_abs_sym, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, (hipStream_t)stream, C, n,
+                       ld, out, ldo, flag);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_jitter_ladder(double* A, int n, int ld, int k, void* stream) {
+    if (!A || n <= 0 || ld < n || k < 0) return SOBER_E_ARG;
+    if (k == 0) return 0;
+    hipLaunchKernelGGL(sober::k_jitter_ladder, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, n, ld, k);
     LAUNCH_CHECK();
     return 0;
 }

@@ -127,46 +127,63 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    // staging: thread tid < NT stages candidate (te = tid / SB, i = tid % SB)
+    // staging: thread tid < NT stages candidate (te = tid / SB, i = tid % SB) of the NEXT tile while the
+    // current one is being consumed.  The address chain idx -> (mu, candidate row) is two global round
+    // trips, so the index is fetched TWO tiles ahead and the row ONE tile ahead.  Every load is
+    // unconditional (clamped position, zero weight for padding): with loads under a branch the compiler
+    // can no longer count outstanding loads and falls back to waiting for all of them before the MFMAs.
     const bool stager = tid < NT;
     const int st_te = tid / SB, st_i = tid % SB;
     double st[DA];
-    double st_w = 0.0, tot_acc = 0.0;
+    double tot_acc = 0.0, m_raw = 0.0, wv_raw = 0.0;
+    bool ok_st = false, ok_tot = false;
+    const double* wm_ptr = wmul ? wmul : mu;
+    const int64_t p_last = pos0 + count - 1;
+    int c_pref = 0;                                   // idx of my candidate two tiles ahead
 
+#define LM_POS(e_tile, P, OK)                                                              \
+    const int e_##P = (e_tile) + st_te;                                                    \
+    const int s_##P = s0 + st_i;                                                           \
+    const int64_t P = (e_first + e_##P) * S + s_##P;                                       \
+    const bool OK = stager && (s_##P < S) && (e_##P < e1) && (P >= pos0) && (P <= p_last);
+#define LM_PREFETCH_IDX(e_tile)                                                            \
+    {                                                                                      \
+        LM_POS(e_tile, pp_, okp_)                                                          \
+        const int64_t pc_ = okp_ ? pp_ : pos0;                                             \
+        c_pref = idx[pc_ - pos0];                                                          \
+    }
+    // consume the prefetched index: ISSUE the loads of (weight, row) for that tile -- nothing here may touch
+    // the loaded values (their first use decides where the compiler waits): that happens in LM_STAGE_WRITE,
+    // after the tile in flight has been consumed
 #define LM_STAGE_LOAD(e_tile)                                                              \
-    if (stager) {                                                                          \
-        const int e_ = (e_tile) + st_te;                                                   \
-        const int s_ = s0 + st_i;                                                          \
-        const int64_t p_ = (e_first + e_) * S + s_;                                        \
-        const bool ok_ = (s_ < S) && (e_ < e1) && (p_ >= pos0) && (p_ < pos0 + count);     \
-        st_w = 0.0;                                                                        \
-        if (ok_) {                                                                         \
-            const int c_ = idx[p_ - pos0];                                                 \
-            const double m_ = mu[c_];                                                      \
-            st_w = (wmul ? m_ * wmul[c_] : m_) * os;                                       \
-            if (p_ < tot_limit) tot_acc += m_;                                             \
-            const double* src_ = cand + (size_t)c_ * DA;                                   \
-            _Pragma("unroll") for (int j = 0; j < DA; ++j) st[j] = src_[j];                \
-        } else {                                                                           \
-            _Pragma("unroll") for (int j = 0; j < DA; ++j) st[j] = 0.0;                    \
-        }                                                                                  \
+    {                                                                                      \
+        LM_POS(e_tile, pl_, okl_)                                                          \
+        const int c_ = okl_ ? c_pref : 0;                                                  \
+        m_raw = mu[c_];                                                                    \
+        wv_raw = wm_ptr[c_];                                                               \
+        const double* src_ = cand + (size_t)c_ * DA;                                       \
+        _Pragma("unroll") for (int j = 0; j < DA; ++j) st[j] = src_[j];                    \
+        ok_st = okl_;                                                                      \
+        ok_tot = okl_ && pl_ < tot_limit;                                                  \
     }
 #define LM_STAGE_WRITE(buf)                                                                \
     if (stager) {                                                                          \
-        _Pragma("unroll") for (int j = 0; j < DA; ++j) s_pts[buf][st_te][j][st_i] = st[j]; \
-        s_w[buf][tid] = st_w;                                                              \
+        _Pragma("unroll") for (int j = 0; j < DA; ++j) s_pts[buf][st_te][j][st_i] = ok_st ? st[j] : 0.0; \
+        s_w[buf][tid] = ok_st ? (wmul ? m_raw * wv_raw : m_raw) * os : 0.0;                \
+        tot_acc += ok_tot ? m_raw : 0.0;                                                   \
     }
 
     int buf = 0;
-    if (e0 < e1) {
-        LM_STAGE_LOAD(e0);
-        LM_STAGE_WRITE(0);
-    }
+    LM_PREFETCH_IDX(e0)
+    __builtin_amdgcn_s_waitcnt(0);                     // A fragments + first index: nothing pending at loop entry
+    LM_STAGE_LOAD(e0)
+    LM_PREFETCH_IDX(e0 + TE)
+    LM_STAGE_WRITE(0)
     __syncthreads();
 
     for (int et = e0; et < e1; et += TE) {
-        const bool more = (et + TE) < e1;
-        if (more) { LM_STAGE_LOAD(et + TE); }
+        LM_STAGE_LOAD(et + TE)                                          // (padding when there is no next tile)
+        LM_PREFETCH_IDX(et + 2 * TE)
         const int te_cnt = min(TE, e1 - et);
         // software pipeline over the elements of the tile: the MFMAs of element te+1 are issued
         // before the exponentials of element te, so the matrix and vector pipes overlap in-wave
@@ -213,12 +230,14 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
             for (int t = 0; t < 4; ++t) cc[t] = cn[t];
             wc = wn;
         }
-        if (more) { LM_STAGE_WRITE(buf ^ 1); }
+        LM_STAGE_WRITE(buf ^ 1)                                         // (zeros when there is no next tile)
         __syncthreads();
         buf ^= 1;
     }
 #undef LM_STAGE_LOAD
 #undef LM_STAGE_WRITE
+#undef LM_PREFETCH_IDX
+#undef LM_POS
 
     // C/D map of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
     if (s0 + lj < S) {
