@@ -60,25 +60,42 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
             D[i * LDP + j] = v;
         }
         __syncthreads();
-        // ---- unblocked Cholesky of D by the first wave (nb <= 32: lane = row)
+        // ---- unblocked Cholesky of D by the first wave, IN REGISTERS: lane = row, d[c] = column c of my row.
+        // Column j: pivot and the multipliers L[c][j] are wave-uniform v_readlane broadcasts, the rank-1 update
+        // is one FMA per remaining column -- no LDS round trips inside the 32-step dependency chain.
         if (tid < 64) {
             const int i = tid;
-            for (int j = 0; j < nb; ++j) {
-                const double djj = D[j * LDP + j];
-                if (!(djj > 0.0)) {                       // also catches NaN
-                    if (i == 0) s_fail = kb + j + 1;
-                    break;
-                }
-                const double l = sqrt(djj);
-                if (i == 0) s_minp = fmin(s_minp, djj);
-                if (i == j) D[j * LDP + j] = l;
-                if (i > j && i < nb) D[i * LDP + j] /= l;
-                // (single wave: LDS ops are in program order, no barrier needed)
-                if (i > j && i < nb) {
-                    const double lij = D[i * LDP + j];
-                    for (int c = j + 1; c <= i; ++c) D[i * LDP + c] = fma(-lij, D[c * LDP + j], D[i * LDP + c]);
+            double d[CH_NB];
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) d[c] = (i < nb && c <= i) ? D[i * LDP + c] : 0.0;
+            int fail = 0;
+            double minp = s_minp;
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) {
+                if (j < nb && fail == 0) {                // uniform
+                    const double djj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d[j]), j),
+                                                        __builtin_amdgcn_readlane(__double2loint(d[j]), j));
+                    if (!(djj > 0.0)) {                   // also catches NaN
+                        fail = kb + j + 1;
+                    } else {
+                        const double l = sqrt(djj);
+                        minp = fmin(minp, djj);
+                        d[j] = (i == j) ? l : ((i > j) ? d[j] / l : 0.0);
+#pragma unroll
+                        for (int c = j + 1; c < CH_NB; ++c) {
+                            const double lcj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d[j]), c),
+                                                                __builtin_amdgcn_readlane(__double2loint(d[j]), c));
+                            d[c] = fma(-d[j], lcj, d[c]);  // rows i < c hold unused upper-triangle values
+                        }
+                    }
                 }
             }
+            if (i < nb) {
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c)
+                    if (c <= i) D[i * LDP + c] = d[c];
+            }
+            if (i == 0) { s_fail = fail; s_minp = minp; }
         }
         __syncthreads();
         if (s_fail != 0) break;                            // uniform
