@@ -13,42 +13,69 @@ namespace sober {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double ld_op(const double* M, int ld, int trans, int r, int c, int R, int C) {
-    // element (r, c) of op(M) with shape R x C; zero outside
-    if (r >= R || c >= C) return 0.0;
-    return trans ? M[(size_t)c * ld + r] : M[(size_t)r * ld + c];
+    // element (r, c) of op(M) with shape R x C; zero outside.  The load itself is unconditional (clamped
+    // index): a load under a branch would make the compiler wait for every outstanding load at the next use.
+    const bool ok = (r < R) & (c < C);
+    const int rc = min(r, R - 1), cc = min(c, C - 1);
+    const double v = trans ? M[(size_t)cc * ld + rc] : M[(size_t)rc * ld + cc];
+    return ok ? v : 0.0;
 }
 
+// SPLIT = 1: workgroup tile 32 x 32, each wave owns one 16 x 16 MFMA tile over the whole K.
+// SPLIT = 4: the workgroup owns ONE 16 x 16 tile and its four waves each take a quarter of K (partial tiles
+//            are added through LDS).  The GEMMs on this path are small and latency bound -- a wave's K loop is
+//            a chain of L2 round trips -- so for few tiles the chain is cut in four instead.
+// Fragments of the next 16 k are in flight while the MFMAs of the current 16 k issue.
+template <int SPLIT>
 __global__ __launch_bounds__(256) void k_dgemm(int transa, int transb, int m, int n, int k,
                                                double alpha, const double* __restrict__ A, int lda,
                                                const double* __restrict__ B, int ldb, double beta,
                                                double* __restrict__ C, int ldc) {
+    __shared__ double red[SPLIT == 4 ? 3 * 256 : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // workgroup tile 32 x 32; each wave owns one 16 x 16 MFMA tile (the matrices here are small:
-    // favour many waves over register blocking)
-    const int i0 = blockIdx.y * 32 + (wave >> 1) * 16;
-    const int j0 = blockIdx.x * 32 + (wave & 1) * 16;
-    if (i0 >= m || j0 >= n) return;
+    int i0, j0, kbeg, kend;
+    if constexpr (SPLIT == 4) {
+        i0 = blockIdx.y * 16;
+        j0 = blockIdx.x * 16;
+        const int kq = (((k + 3) / 4) + 15) / 16 * 16;                // quarter of K, multiple of 16
+        kbeg = min(wave * kq, k);
+        kend = min(kbeg + kq, k);
+    } else {
+        i0 = blockIdx.y * 32 + (wave >> 1) * 16;
+        j0 = blockIdx.x * 32 + (wave & 1) * 16;
+        kbeg = 0;
+        kend = k;
+        if (i0 >= m || j0 >= n) return;
+    }
     const int li = lane & 15, lk = lane >> 4;
 
     double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-    int k0 = 0;
-    for (; k0 + 16 <= k; k0 += 16) {             // 4 k-steps per trip: loads issued ahead of the MFMAs
-        double af[4], bf[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            af[u] = ld_op(A, lda, transa, i0 + li, k0 + 4 * u + lk, m, k);
-            bf[u] = ld_op(B, ldb, transb, k0 + 4 * u + lk, j0 + li, k, n);
-        }
+    double af[4], bf[4], an[4], bn[4];
+#define DG_LOAD(AF, BF, K0)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+        AF[u] = ld_op(A, lda, transa, i0 + li, (K0) + 4 * u + lk, m, kend);                   \
+        BF[u] = ld_op(B, ldb, transb, (K0) + 4 * u + lk, j0 + li, kend, n);                   \
+    }
+    DG_LOAD(af, bf, kbeg)
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        DG_LOAD(an, bn, k0 + 16)                                      // (zeros beyond kend)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { af[u] = an[u]; bf[u] = bn[u]; }
     }
-    for (; k0 < k; k0 += 4) {
-        const double af = ld_op(A, lda, transa, i0 + li, k0 + lk, m, k);
-        const double bf = ld_op(B, ldb, transb, k0 + lk, j0 + li, k, n);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+#undef DG_LOAD
+    if constexpr (SPLIT == 4) {
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave - 1) * 256 + r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = ((acc[r] + red[r * 64 + lane]) + red[256 + r * 64 + lane]) + red[512 + r * 64 + lane];
     }
-
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + lk + 4 * r;
@@ -68,9 +95,16 @@ extern "C" int sober_dgemm(int transa, int transb, int m, int n, int k, double a
                            void* stream) {
     if (!A || !B || !C || m <= 0 || n <= 0 || k <= 0) return SOBER_E_ARG;
     if (lda < (transa ? m : k) || ldb < (transb ? k : n) || ldc < n) return SOBER_E_ARG;
-    dim3 grid((n + 31) / 32, (m + 31) / 32);
-    hipLaunchKernelGGL(sober::k_dgemm, grid, dim3(256), 0, (hipStream_t)stream, transa, transb, m, n, k,
-                       alpha, A, lda, B, ldb, beta, C, ldc);
+    const long tiles = (long)((n + 15) / 16) * ((m + 15) / 16);
+    if (tiles <= 2048 && k >= 64) {                  // few tiles: cut the K chain in four
+        dim3 grid((n + 15) / 16, (m + 15) / 16);
+        hipLaunchKernelGGL(sober::k_dgemm<4>, grid, dim3(256), 0, (hipStream_t)stream, transa, transb, m, n, k,
+                           alpha, A, lda, B, ldb, beta, C, ldc);
+    } else {
+        dim3 grid((n + 31) / 32, (m + 31) / 32);
+        hipLaunchKernelGGL(sober::k_dgemm<1>, grid, dim3(256), 0, (hipStream_t)stream, transa, transb, m, n, k,
+                           alpha, A, lda, B, ldb, beta, C, ldc);
+    }
     LAUNCH_CHECK();
     return 0;
 }
