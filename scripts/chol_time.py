@@ -1,9 +1,22 @@
-"""Time the batched Cholesky probe (11 rungs of a 500 x 500 Gram) and the small-matrix kernels."""
+"""Time the one-workgroup Cholesky kernels: the 11-rung probe of a 500 x 500 Gram, single factorisations at
+n = 99 / 198 / 500, chol_small; with a -DCH_STAMPS build also the per-phase ticks of k_chol."""
 import numpy as np, torch, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sober_amd import _native as nat
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
+
+
+def timed(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
 M = 500
 X = rng.random((M, 10))
 K = np.exp(-0.5 * ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1) / 0.6)
@@ -11,15 +24,25 @@ C = torch.from_numpy(K).to(dev)
 shifts = torch.tensor([1e-5 * (2 ** k - 1) for k in range(11)], dtype=torch.float64, device=dev)
 info = torch.zeros(11, dtype=torch.int32, device=dev)
 work = torch.empty(11 * M * M, dtype=torch.float64, device=dev)
-for _ in range(3): nat.cholesky_probe(C, shifts, work, info)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20): nat.cholesky_probe(C, shifts, work, info)
-e1.record(); torch.cuda.synchronize()
-print("cholesky_probe 500x500 x 11 rungs: %.1f us" % (e0.elapsed_time(e1) / 20 * 1e3), "info", info.cpu().tolist())
-L = work[:M * M].view(M, M).cpu().numpy()
+t = timed(lambda: nat.cholesky_probe(C, shifts, work, info))
+print("cholesky_probe 500x500 x 11 rungs: %.1f us" % t, "info", info.cpu().tolist())
 k = int(np.argmax(info.cpu().numpy() == 0))
 Lk = np.tril(work[k * M * M:(k + 1) * M * M].view(M, M).cpu().numpy())
 ref = np.linalg.cholesky(K + float(shifts[k]) * np.eye(M))
 print("rung", k, "max |L - numpy|", np.abs(Lk - ref).max())
+for n in (99, 128, 198, 500):
+    A = rng.standard_normal((n, 2 * n)); S = A @ A.T / n + 0.5 * np.eye(n)
+    Sd = torch.from_numpy(S).to(dev)
+    W = Sd.clone(); inf1 = torch.zeros(1, dtype=torch.int32, device=dev); piv = torch.zeros(1, dtype=torch.float64, device=dev)
+    def run():
+        W.copy_(Sd); nat.cholesky(W, 0.0, inf1, piv)
+    tc = timed(lambda: W.copy_(Sd))
+    t = timed(run)
+    run(); torch.cuda.synchronize()
+    Wh = W.cpu().numpy()
+    err = np.abs(np.tril(Wh) - np.linalg.cholesky(S)).max()
+    print("k_chol n=%d: %.1f us (copy %.1f us subtracted), err %.2e, stamps(ticks a/b/c/d) %s" % (n, t - tc, tc, err, Wh[0, 8:12].tolist()))
+    if n <= 128:
+        Lc = torch.zeros(n, n, dtype=torch.float64, device=dev)
+        t = timed(lambda: nat.chol_small(Sd, Lc, inf1, piv))
+        print("k_chol_small n=%d: %.1f us, err %.2e" % (n, t, np.abs(Lc.cpu().numpy() - np.linalg.cholesky(S)).max()))

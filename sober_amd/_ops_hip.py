@@ -145,22 +145,38 @@ class HipOps:
             return None
         return U, G
 
-    def _orth(self, Y, infos, pivs, slot):
-        """CholeskyQR2: orthonormal basis of range(Y) with the flag of Householder QR."""
+    def _orth(self, Y, infos, pivs, slot, passes: int = 2, want_q: bool = True):
+        """CholeskyQR2: orthonormal basis of range(Y) with the flag of Householder QR.
+        passes=1 (the intermediate blocks of the power iteration): the same subspace to the same accuracy
+        (the first triangular solve decides it), orthonormal only to cond(Y)^2 eps -- which is all the next
+        product A Q needs; pivs[slot + 1] then holds min pivot / max diagonal of the Gram matrix (~ cond^-2).
+        want_q=False: only the triangular factors are needed; returns (L1, L2) with Y = Q (L2 L1)^T."""
         q = Y.shape[1]
-        for it in range(2):
+        Ls = []
+        for it in range(passes):
             Gm = torch.empty(q, q, dtype=torch.float64, device=self.device)
             nat.dgemm(Y, Y, Gm, transa=True)
+            dmax = Gm.diagonal().amax() if passes == 1 else None
             if q <= 128:                                    # LDS-resident factorisation
                 Lc = torch.zeros(q, q, dtype=torch.float64, device=self.device)
                 nat.chol_small(Gm, Lc, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1])
             else:                                           # blocked one-workgroup Cholesky, in place
                 Lc = Gm
                 nat.cholesky(Lc, 0.0, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1])
+                Lc = Lc.tril_()
+            if passes == 1:
+                pivs[slot + 1] = pivs[slot] / dmax
+            Ls.append(Lc)
+            if not want_q and it == passes - 1:
+                return Ls
             Q = torch.empty_like(Y)
             nat.trsm_rows(Y, Lc, Q)                             # Q = Y R^-1, one wave per row
             Y = Q
         return Y
+
+    # single-pass CholeskyQR is accepted for an intermediate block while min pivot / max diagonal of its Gram
+    # matrix (~ cond(Y)^-2) stays above this: orthonormality then holds to ~1e-6 and the subspace to eps cond(Y)
+    ORTH1_MIN_RATIO = 1e-10
 
     def _svd_lowrank_device(self, A, q, R_host, niter: int = 2):
         """torch.svd_lowrank(A, q) (Halko et al. Alg. 4.4 / 5.1, as in torch/_lowrank.py) for a square
@@ -173,32 +189,40 @@ class HipOps:
         pivs = torch.zeros(2 * n_orth, dtype=torch.float64, device=dev)
         Y = torch.empty(M, q, dtype=torch.float64, device=dev)
         nat.dgemm(A, R, Y)
-        Q = self._orth(Y, infos, pivs, 0)
-        slot = 2
+        # torch/_lowrank.py orthonormalises after every product; only range(Q) of the LAST block enters the
+        # result, the earlier QRs are there for conditioning -- one CholeskyQR pass each does that
+        last = 2 * niter
+        Q = self._orth(Y, infos, pivs, 0, passes=1 if last > 0 else 2)
+        slot, k = 2, 0
         for _ in range(niter):
+            k += 1
             nat.dgemm(A, Q, Y, transa=True)                          # A^H Q
-            Q = self._orth(Y, infos, pivs, slot); slot += 2
+            Q = self._orth(Y, infos, pivs, slot, passes=1); slot += 2
             Y = torch.empty(M, q, dtype=torch.float64, device=dev)
+            k += 1
             nat.dgemm(A, Q, Y)
-            Q = self._orth(Y, infos, pivs, slot); slot += 2
+            Q = self._orth(Y, infos, pivs, slot, passes=2 if k == last else 1); slot += 2
             Y = torch.empty(M, q, dtype=torch.float64, device=dev)
         # B = Q^H A (q x M).  Its left singular vectors are those of the q x q factor of B^T = Qb Rb:
-        # B = Rb^T Qb^T  =>  U_B = left singular vectors of Rb^T.  CholeskyQR2 of B^T on the device, so
-        # only q x q goes to the host for LAPACK's SVD (0.6 ms instead of 2.2 ms for q x M).
+        # B = Rb^T Qb^T  =>  U_B = left singular vectors of Rb^T.  CholeskyQR2 of B^T on the device
+        # (B^T = Q1 L1^T, Q1 = Q2 L2^T  =>  Rb^T = L1 L2; Q2 itself is never formed), so only q x q goes to
+        # the host for LAPACK's SVD (0.6 ms instead of 2.2 ms for q x M).
         Bt = torch.empty(M, q, dtype=torch.float64, device=dev)
         nat.dgemm(A, Q, Bt, transa=True)                             # (Q^H A)^T = A^T Q
         infos_b = torch.zeros(2, dtype=torch.int32, device=dev)
         pivs_b = torch.zeros(2, dtype=torch.float64, device=dev)
-        Qb = self._orth(Bt, infos_b, pivs_b, 0)
-        Rb = torch.empty(q, q, dtype=torch.float64, device=dev)
-        nat.dgemm(Qb, Bt, Rb, transa=True)                           # Rb = Qb^T B^T  (upper triangular)
-        Rb_h, infos_h, pivs_h, infos_bh, pivs_bh = self.to_host(Rb, infos, pivs, infos_b, pivs_b)
-        # second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1
-        if bool((infos_h != 0).any()) or float(pivs_h[1::2].min()) < 0.5 or bool((infos_bh != 0).any()) \
-                or float(pivs_bh[1]) < 0.5:
+        L1, L2 = self._orth(Bt, infos_b, pivs_b, 0, want_q=False)
+        RbT = torch.empty(q, q, dtype=torch.float64, device=dev)
+        nat.dgemm(L1, L2, RbT)                                       # Rb^T = L1 L2 (lower triangular)
+        RbT_h, infos_h, pivs_h, infos_bh, pivs_bh = self.to_host(RbT, infos, pivs, infos_b, pivs_b)
+        # a second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1
+        single = [s for s in range(0, 2 * n_orth, 2) if s // 2 != last]
+        if bool((infos_h != 0).any()) or bool((infos_bh != 0).any()) or float(pivs_bh[1]) < 0.5 \
+                or float(pivs_h[2 * last + 1]) < 0.5 \
+                or any(not (float(pivs_h[s + 1]) >= self.ORTH1_MIN_RATIO) for s in single):
             return None
         with host_lapack_threads(M):
-            Ub, _, _ = torch.linalg.svd(Rb_h.T.contiguous(), full_matrices=False)
+            Ub, _, _ = torch.linalg.svd(RbT_h, full_matrices=False)
         U = torch.empty(M, q, dtype=torch.float64, device=dev)
         nat.dgemm(Q, self.from_host(Ub.contiguous()), U)
         return (-1 * U.T).contiguous()

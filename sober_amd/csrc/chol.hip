@@ -14,8 +14,19 @@
 namespace sober {
 
 constexpr int CH_NB = 32;            // panel width
-constexpr int CH_T = 1024;
-constexpr int CH_MAXN = 608;         // panel (n - NB) x NB doubles + diagonal block must fit in 160 KiB LDS
+constexpr int CH_T = 512;             // 8 waves: 256 VGPRs per lane for the register-resident diagonal block
+constexpr int CH_LDPP = CH_NB + 4;   // row stride of the LDS panel: 16 rows x 4 k of an MFMA fragment fall on distinct bank pairs
+constexpr int CH_MAXN = 536;         // panel (n - NB) x LDPP doubles + two NB x (NB+1) blocks must fit in 160 KiB LDS
+
+typedef double ch_double4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH_G = 4;              // tiles of the trailing update per wave and trip
+__device__ double ch_sink[CH_T];     // where the stores of lanes outside the lower triangle go (never read)
+
+__device__ __forceinline__ double ch_rdlane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 
 // A (n x n, row-major, ld) is overwritten by L in its lower triangle (upper triangle untouched).
 // shift is added to the diagonal on the fly (the jitter rung), so the caller's matrix can be probed
@@ -23,6 +34,13 @@ constexpr int CH_MAXN = 608;         // panel (n - NB) x NB doubles + diagonal b
 // Batched form (gridDim.x > 1): workgroup b factorises (src + shifts[b] I) in its own n x n slab of
 // `A` (slab stride n*ld doubles) and reports info[b]; used to probe every rung of the jitter ladder of
 // SOBER/_utils.py:145-156 in ONE launch (the rungs are independent).
+//
+// Right-looking, panel width 32, per panel:
+//   (b) wave 0 factorises the 32 x 32 diagonal block IN REGISTERS (lane = row; pivots and multipliers are
+//       v_readlane broadcasts) and inverts it (lane = column of the inverse);
+//   (c) the panel below is L21 = A21 L11^-T as a small GEMM on the matrix cores (no per-row substitution chain);
+//   (d) the trailing update A22 -= L21 L21^T runs on the matrix cores from the LDS-resident panel, one 16 x 16
+//       tile per wave and trip, the next tile of A22 already in flight.
 __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, int ld, double shift,
                                               int32_t* __restrict__ info, double* __restrict__ min_pivot,
                                               const double* __restrict__ src, int lds_src,
@@ -33,140 +51,219 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
         info += blockIdx.x;
         if (min_pivot) min_pivot += blockIdx.x;
         shift = shifts[blockIdx.x];
-        for (int t = threadIdx.x; t < n * n; t += CH_T) {
-            const int i = t / n, j = t % n;
-            if (j <= i) A[(size_t)i * ld + j] = src[(size_t)i * lds_src + j];
-        }
+        for (int i = threadIdx.x >> 6; i < n; i += CH_T / 64)
+            for (int j = threadIdx.x & 63; j <= i; j += 64) A[(size_t)i * ld + j] = src[(size_t)i * lds_src + j];
         __threadfence_block();
         __syncthreads();
     }
-    double* D = lds;                         // NB x (NB+1)
-    double* P = lds + CH_NB * (CH_NB + 1);   // (n - kb - nb) x (NB+1) panel, padded against bank conflicts
+    constexpr int LDP = CH_NB + 1;
+    double* D = lds;                         // NB x (NB+1): diagonal block / L11
+    double* Xs = lds + CH_NB * LDP;          // NB x (NB+1): L11^-1
+    constexpr int LDPP = CH_LDPP;
+    double* P = lds + 2 * CH_NB * LDP;       // (n - kb - nb) x LDPP panel
     __shared__ int s_fail;
     __shared__ double s_minp;
-    const int tid = threadIdx.x;
-    constexpr int LDP = CH_NB + 1;
+    __shared__ double s_dinv[CH_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
     if (tid == 0) { s_fail = 0; s_minp = __builtin_inf(); }
     __syncthreads();
+#ifdef CH_STAMPS
+    long long st_t[5] = {0, 0, 0, 0, 0}, st_last = wall_clock64();
+#define CH_STAMP(K) { const long long now_ = wall_clock64(); st_t[K] += now_ - st_last; st_last = now_; }
+#else
+#define CH_STAMP(K)
+#endif
 
     for (int kb = 0; kb < n; kb += CH_NB) {
         const int nb = min(CH_NB, n - kb);
         const int nr = n - kb - nb;                       // rows below the diagonal block
-        // ---- diagonal block -> LDS (lower part), + shift
-        for (int t = tid; t < nb * nb; t += CH_T) {
-            const int i = t / nb, j = t % nb;
-            double v = (j <= i) ? A[(size_t)(kb + i) * ld + kb + j] : 0.0;
-            if (i == j) v += shift;
+        // ---- (a) diagonal block -> LDS (lower part), + shift; zero padded to 32 x 32
+#pragma unroll
+        for (int t = tid; t < CH_NB * CH_NB; t += CH_T) {
+            const int i = t >> 5, j = t & 31;
+            double v = (i < nb && j <= i) ? A[(size_t)(kb + i) * ld + kb + j] : 0.0;
+            if (i == j && i < nb) v += shift;
             D[i * LDP + j] = v;
         }
         __syncthreads();
-        // ---- unblocked Cholesky of D by the first wave, IN REGISTERS: lane = row, d[c] = column c of my row.
-        // Column j: pivot and the multipliers L[c][j] are wave-uniform v_readlane broadcasts, the rank-1 update
-        // is one FMA per remaining column -- no LDS round trips inside the 32-step dependency chain.
-        if (tid < 64) {
-            const int i = tid;
+        CH_STAMP(0)
+        // ---- (b) wave 0: Cholesky of D in registers, then its inverse
+        if (wave == 0) {
+            const int i = lane;
             double d[CH_NB];
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) d[c] = (i < nb && c <= i) ? D[i * LDP + c] : 0.0;
+            for (int c = 0; c < CH_NB; ++c) d[c] = (i < CH_NB) ? D[min(i, CH_NB - 1) * LDP + c] : 0.0;
             int fail = 0;
             double minp = s_minp;
+            double my_rinv = 1.0;                         // lane j: 1 / L[j][j] (identity padding: 1)
 #pragma unroll
             for (int j = 0; j < CH_NB; ++j) {
                 if (j < nb && fail == 0) {                // uniform
-                    const double djj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d[j]), j),
-                                                        __builtin_amdgcn_readlane(__double2loint(d[j]), j));
+                    const double djj = ch_rdlane(d[j], j);
                     if (!(djj > 0.0)) {                   // also catches NaN
                         fail = kb + j + 1;
                     } else {
-                        const double l = sqrt(djj);
+                        // multipliers through the reciprocal square root: one short dependent sequence per
+                        // column instead of sqrt followed by a division (off-diagonal entries within 2 ulp)
+                        const double l = sqrt(djj), rinv = rsqrt(djj);
                         minp = fmin(minp, djj);
-                        d[j] = (i == j) ? l : ((i > j) ? d[j] / l : 0.0);
+                        my_rinv = (i == j) ? rinv : my_rinv;
+                        d[j] = (i == j) ? l : ((i > j) ? d[j] * rinv : 0.0);
 #pragma unroll
-                        for (int c = j + 1; c < CH_NB; ++c) {
-                            const double lcj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d[j]), c),
-                                                                __builtin_amdgcn_readlane(__double2loint(d[j]), c));
-                            d[c] = fma(-d[j], lcj, d[c]);  // rows i < c hold unused upper-triangle values
-                        }
+                        for (int c = j + 1; c < CH_NB; ++c)
+                            d[c] = fma(-d[j], ch_rdlane(d[j], c), d[c]);   // rows i < c: unused upper-triangle values
                     }
                 }
             }
-            if (i < nb) {
-#pragma unroll
-                for (int c = 0; c < CH_NB; ++c)
-                    if (c <= i) D[i * LDP + c] = d[c];
-            }
             if (i == 0) { s_fail = fail; s_minp = minp; }
+            if (fail == 0) {
+                // L11 -> LDS (padding rows >= nb become identity rows so that the inverse exists)
+                if (i < CH_NB) {
+#pragma unroll
+                    for (int c = 0; c < CH_NB; ++c)
+                        D[i * LDP + c] = (i < nb) ? ((c <= i) ? d[c] : 0.0) : ((c == i) ? 1.0 : 0.0);
+                    s_dinv[i] = my_rinv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // X = L11^-1 by columns, lane = column jx of X, column-oriented substitution: once x[k] is final,
+                // the updates of the rows below are independent of one another; L[r][k] and 1/L[k][k] are
+                // wave-uniform LDS reads (broadcasts) that do not depend on x
+                const int jx = lane;
+                double x[CH_NB];
+#pragma unroll
+                for (int r = 0; r < CH_NB; ++r) x[r] = (r == jx) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) {
+                    x[k] *= s_dinv[k];
+#pragma unroll
+                    for (int r = k + 1; r < CH_NB; ++r) x[r] = fma(-D[r * LDP + k], x[k], x[r]);
+                }
+                if (i < CH_NB) {
+#pragma unroll
+                    for (int c = 0; c < CH_NB; ++c) Xs[c * LDP + jx] = x[c];                 // X[c][jx]
+                }
+            }
         }
         __syncthreads();
+        CH_STAMP(1)
         if (s_fail != 0) break;                            // uniform
         // ---- write L_kk back
-        for (int t = tid; t < nb * nb; t += CH_T) {
-            const int i = t / nb, j = t % nb;
-            if (j <= i) A[(size_t)(kb + i) * ld + kb + j] = D[i * LDP + j];
+#pragma unroll
+        for (int t = tid; t < CH_NB * CH_NB; t += CH_T) {
+            const int i = t >> 5, j = t & 31;
+            if (i < nb && j <= i) A[(size_t)(kb + i) * ld + kb + j] = D[i * LDP + j];
         }
         if (nr == 0) break;
-        // ---- panel: rows below solve x L_kk^T = a  (one row per thread), kept in LDS
-        for (int r = tid; r < nr; r += CH_T) {
-            double x[CH_NB];
-            const double* a = A + (size_t)(kb + nb + r) * ld + kb;
+        // ---- (c) panel: L21 = A21 X^T on the matrix cores, one 16 x 32 row block per wave and trip (A21 rows are
+        // read once, the next block's rows are in flight during the MFMAs); result kept in LDS
+        {
+            const int ntile = (nr + 15) / 16;
+            double af[8], an[8];
+            if (wave < ntile) {
+                const double* arow = A + (size_t)(kb + nb + min(wave * 16 + li, nr - 1)) * ld + kb;
 #pragma unroll
-            for (int j = 0; j < CH_NB; ++j) x[j] = (j < nb) ? a[j] : 0.0;
-#pragma unroll
-            for (int j = 0; j < CH_NB; ++j) {
-                if (j < nb) {
-                    double s = x[j];
-#pragma unroll
-                    for (int k = 0; k < CH_NB; ++k)
-                        if (k < j) s = fma(-x[k], D[j * LDP + k], s);
-                    x[j] = s / D[j * LDP + j];
-                }
+                for (int u = 0; u < 8; ++u) af[u] = arow[min(4 * u + lk, nb - 1)];
             }
-            double* o = A + (size_t)(kb + nb + r) * ld + kb;
+            for (int t = wave; t < ntile; t += CH_T / 64) {
+                const int r0 = t * 16;
+                {
+                    const int tn = min(t + CH_T / 64, ntile - 1);
+                    const double* arow = A + (size_t)(kb + nb + min(tn * 16 + li, nr - 1)) * ld + kb;
 #pragma unroll
-            for (int j = 0; j < CH_NB; ++j) {
-                if (j < nb) o[j] = x[j];
-                P[r * LDP + j] = x[j];
+                    for (int u = 0; u < 8; ++u) an[u] = arow[min(4 * u + lk, nb - 1)];
+                }
+                ch_double4 acc0 = (ch_double4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = 4 * u + lk;
+                    const double a = (k < nb) ? af[u] : 0.0;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xs[li * LDP + k], acc0, 0, 0, 0);   // B[k][j] = X[j][k]
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xs[(16 + li) * LDP + k], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = r0 + lk + 4 * r;
+                    if (row < nr) {
+                        P[row * LDPP + li] = acc0[r];
+                        P[row * LDPP + 16 + li] = acc1[r];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) af[u] = an[u];
             }
         }
         __syncthreads();
-        // ---- trailing update (lower triangle): A[r][c] -= P[r] . P[c], 4x4 register tiles
-        const int nt = (nr + 3) / 4;                       // tiles per side
-        const int ntri = nt * (nt + 1) / 2;
-        for (int t = tid; t < ntri; t += CH_T) {
-            // (tr, tc) with tc <= tr from the linear index
-            int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-            while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-            while (tr * (tr + 1) / 2 > t) --tr;
-            const int tc = t - tr * (tr + 1) / 2;
-            double acc[4][4];
+        CH_STAMP(2)
+        // L21 goes back to A from LDS
+        for (int r = tid >> 5; r < nr; r += CH_T / 32) {
+            const int j = tid & 31;
+            if (j < nb) A[(size_t)(kb + nb + r) * ld + kb + j] = P[r * LDPP + j];
+        }
+        // ---- (d) trailing update (lower triangle): A22[r][c] -= P[r] . P[c], 16 x 16 tiles on the matrix cores.
+        // A wave walks its tiles (linear index wave, wave + 8, ...) in batches of CH_G; the whole loop body is
+        // straight-line code -- loads of the next batch, MFMAs, then stores that are redirected to a sink instead
+        // of being predicated -- so that the s_waitcnt in front of a batch's first use counts exactly and the
+        // stores just issued are not waited for (loads and stores share vmcnt on gfx950).
+        {
+            const int nt = (nr + 15) / 16;                 // tiles per side
+            int ntr = 0, ntc = __builtin_amdgcn_readfirstlane(wave);       // cursor over this wave's tiles
+            while (ntc > ntr) { ntc -= ntr + 1; ++ntr; }
+            int tr[CH_G], tc[CH_G], trn[CH_G], tcn[CH_G];
+            double cv[CH_G][4], cn[CH_G][4];
+            double* const a22 = A + (size_t)(kb + nb) * ld + kb + nb;
+#define CH_TAKE(R, C)                                                       \
+            { R = ntr; C = ntc; ntc += CH_T / 64; while (ntc > ntr) { ntc -= ntr + 1; ++ntr; } }
+#define CH_LOAD(DST, R, C)                                                  \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                   \
+                DST[e] = a22[(size_t)min((R) * 16 + lk + 4 * e, nr - 1) * ld + min((C) * 16 + li, nr - 1)];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int g = 0; g < CH_G; ++g) { CH_TAKE(tr[g], tc[g]) CH_LOAD(cv[g], tr[g], tc[g]) }
+            while (tr[0] < nt) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-            const int r0 = tr * 4, c0 = tc * 4;
-            for (int k = 0; k < nb; ++k) {
-                double pr[4], pc[4];
+                for (int g = 0; g < CH_G; ++g) { CH_TAKE(trn[g], tcn[g]) CH_LOAD(cn[g], trn[g], tcn[g]) }
+                ch_double4 acc[CH_G][2];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    pr[a] = P[min(r0 + a, nr - 1) * LDP + k];
-                    pc[a] = P[min(c0 + a, nr - 1) * LDP + k];
+                for (int g = 0; g < CH_G; ++g) {
+                    acc[g][0] = (ch_double4){0.0, 0.0, 0.0, 0.0};
+                    acc[g][1] = acc[g][0];
+                    const int ra = min(tr[g] * 16 + li, nr - 1), rb = min(tc[g] * 16 + li, nr - 1);
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        acc[g][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(P[ra * LDPP + 4 * u + lk],
+                                                                         P[rb * LDPP + 4 * u + lk], acc[g][0], 0, 0, 0);
+                        acc[g][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(P[ra * LDPP + 4 * u + 4 + lk],
+                                                                         P[rb * LDPP + 4 * u + 4 + lk], acc[g][1], 0, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int g = 0; g < CH_G; ++g) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] = fma(pr[a], pc[b], acc[a][b]);
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = tr[g] * 16 + lk + 4 * e, col = tc[g] * 16 + li;
+                        double* dst = (row < nr && col <= row) ? a22 + (size_t)row * ld + col : ch_sink + tid;
+                        *dst = cv[g][e] - (acc[g][0][e] + acc[g][1][e]);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < CH_G; ++g) {
+                    tr[g] = trn[g]; tc[g] = tcn[g];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cv[g][e] = cn[g][e];
+                }
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int r = r0 + a, c = c0 + b;
-                    if (r < nr && c <= r) A[(size_t)(kb + nb + r) * ld + kb + nb + c] -= acc[a][b];
-                }
+#undef CH_TAKE
+#undef CH_LOAD
         }
         __threadfence_block();
         __syncthreads();
+        CH_STAMP(3)
     }
+#ifdef CH_STAMPS
+    if (tid == 0 && n >= 16)                               // debugging build: ticks (100 MHz) in row 0's upper triangle
+        for (int k = 0; k < 4; ++k) A[8 + k] = (double)st_t[k];
+#endif
     if (tid == 0) {
         *info = s_fail;
         if (min_pivot) *min_pivot = s_minp;
@@ -338,11 +435,11 @@ extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* i
     if (!A || !info || n <= 0 || ld < n) return SOBER_E_ARG;
     if (n > sober::CH_MAXN) return SOBER_E_DIM;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
-    const size_t bytes = ((size_t)sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * (sober::CH_NB + 1)) * sizeof(double);
+    const size_t bytes = ((size_t)2 * sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * sober::CH_LDPP) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 64));
+                                    160 * 1024 - 512));
         attr_set = true;
     }
     hipLaunchKernelGGL(sober::k_chol, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift, info,
@@ -356,9 +453,9 @@ extern "C" int sober_cholesky_probe(const double* src, int n, int ld_src, const 
     if (!src || !shifts || !work || !info || n <= 0 || ld_src < n || n_shifts <= 0) return SOBER_E_ARG;
     if (n > sober::CH_MAXN) return SOBER_E_DIM;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
-    const size_t bytes = ((size_t)sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * (sober::CH_NB + 1)) * sizeof(double);
+    const size_t bytes = ((size_t)2 * sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * sober::CH_LDPP) * sizeof(double);
     HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024 - 64));
+                                160 * 1024 - 512));
     hipLaunchKernelGGL(sober::k_chol, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
                        info, (double*)nullptr, src, ld_src, shifts);
     LAUNCH_CHECK();
@@ -372,7 +469,7 @@ extern "C" int sober_chol_small(const double* G, int q, int ldg, double* Rinv, i
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 64));
+                                    160 * 1024 - 512));
         attr_set = true;
     }
     hipLaunchKernelGGL(sober::k_chol_small, dim3(1), dim3(1024), bytes, (hipStream_t)stream, G, q, ldg, Rinv, ldr,
