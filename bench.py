@@ -104,6 +104,7 @@ def main():
     torch.cuda.synchronize()
 
     ops.prof = []
+    ops.prof_reserve(16 * args.steps)                    # event pairs for the level_reduce launches, created up front
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -121,9 +122,12 @@ def main():
     # levels' launches -- without it the event sum would not agree with rocprofv3's kernel durations)
     prof, ops.prof = ops.prof, None
     cal = []
-    for _ in range(200):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); e1.record(); cal.append((e0, e1))
+    from sober_amd import _native as nat
+    ops.prof_reserve(200)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(200):                               # same mechanism as the executor's brackets
+        e0, e1 = ops._prof_pair()
+        nat.record_event_pair(e0, e1, st); cal.append((e0, e1))
     torch.cuda.synchronize()
     ev_overhead = float(np.median([a.elapsed_time(b_) for a, b_ in cal]))
     kern_ms = sum(max(a.elapsed_time(b_) - ev_overhead, 0.0) for a, b_, _ in prof)

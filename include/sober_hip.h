@@ -245,6 +245,54 @@ int sober_level_gather(const double* Kmat, int n_rows, int64_t ldk, const int32_
 int sober_gspace_finish(double* K, const double* corr, int64_t n, int m, int64_t ldk, int64_t ldc,
                         const double* mug_cand, const double* mug_rows, void* stream);
 
+/* ---- level executor: one level of Mod_Tchernychova_Lyons (SOBER/_rchq.py:116-175) per call ----------------
+ * The halving loop is a chain of ~10 small launches per level with one host decision at its end (how many
+ * sets survived); issuing them one by one from the host language costs more than the kernels run.  A job
+ * describes the per-step constants once and the per-level position range; sober_level_moments enqueues
+ *   level_reduce (variant) -> level_reduce over the leftovers -> sum_partials -> P G          => Xtr, tot
+ * and sober_level_car enqueues
+ *   barycentres -> Caratheodory step (sober_car_device) -> async copy of keep_rank[0:S] and n_keep to h_flags.
+ * Between the two a sharded run all-reduces Xtr and tot.  Nothing synchronises; the caller
+ * waits on the stream before reading h_flags (pinned host memory, S + 1 int32).
+ * Workspaces are caller-owned with fixed capacities: partG SOBER_LEVEL_MAX_CHUNKS * n_rows * S doubles,
+ * partTot MAX_CHUNKS * S, extraG MAX_CHUNKS * n_rows * SOBER_LEVEL_XS, extraTot MAX_CHUNKS * XS.            */
+#define SOBER_LEVEL_VALU        0    /* sober_level_reduce      (rows/cand = scaled points or packed words) */
+#define SOBER_LEVEL_MFMA        1    /* sober_level_reduce_mfma (rows/cand = augmented points)              */
+#define SOBER_LEVEL_GATHER      2    /* sober_level_gather      (cand = Kmat, candidate-major, ld = kmat_ld) */
+#define SOBER_LEVEL_MAX_CHUNKS  64
+#define SOBER_LEVEL_XS          16   /* pseudo-sets of the leftover launch, folded into set S-1             */
+typedef struct sober_level_job {
+    /* per step */
+    int32_t variant, kind;
+    const void* rows;   const double* rows_norm;
+    const void* cand;   const double* cand_norm;
+    int32_t n_rows, dim;                        /* dim: DT (VALU), DA (MFMA), unused (GATHER)               */
+    int64_t kmat_ld;
+    const double* wmul; double outputscale;
+    int32_t S, n;
+    const double* P;                            /* n x n_rows projection, SOBER/_rchq.py:148                */
+    double *partG, *partTot, *extraG, *extraTot;
+    double *G, *Xtr, *tot;                      /* n_rows x S, n x S, S                                     */
+    double *X_tmp;                              /* S x n barycentres                                        */
+    int32_t* keep_rank;                         /* S + 1 int32: keep_rank[S] = n_keep                       */
+    double *w_star, *mu_out;                    /* S each                                                   */
+    void* car_ws; int64_t car_ws_bytes;         /* sober_car_ws_bytes(S, n + 1)                             */
+    int32_t* h_flags;                           /* pinned host, S + 1 int32                                 */
+    void* ev[4];                                /* optional hipEvent_t: recorded before / after the level_reduce
+                                                   launch (ev[0], ev[1]) and the leftover launch (ev[2], ev[3]) */
+    /* per level */
+    const int32_t* idx; int64_t pos0, count, E;
+    const double* mu;
+    int32_t phase;                              /* sober_level_moments: 0 = everything, 1 = set sums only (up to G, tot),
+                                                   2 = projection only (Xtr = P G).  The set sums of the first level do
+                                                   not depend on the Nystrom basis: they run while the host still works
+                                                   on it.                                                                */
+} sober_level_job;
+int sober_level_moments(const sober_level_job* job, void* stream);
+int sober_level_car(const sober_level_job* job, void* stream);
+/* ev0, ev1 (hipEvent_t) recorded back to back: the empty bracket, for calibrating the ev[] timings.       */
+int sober_record_event_pair(void* ev0, void* ev1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

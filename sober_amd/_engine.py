@@ -21,6 +21,7 @@ import time
 import warnings
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _native as nat
@@ -206,15 +207,18 @@ class RecombinationEngine:
         return t1
 
     # -- Nystrom basis --------------------------------------------------------
-    def nystrom_basis(self, plan, s: int):
+    def nystrom_basis(self, plan, s: int, overlap=None):
         """-> U (s, M).  Device route when the backend has one (HipOps.nystrom_basis_device); the
-        literal host route (LAPACK) otherwise or when the device route declines."""
+        literal host route (LAPACK) otherwise or when the device route declines.  `overlap`: callable
+        that enqueues device work independent of U; the device route calls it (once) while the host
+        still works on the basis."""
         t0 = time.perf_counter()
         dev_route = getattr(self.ops, "nystrom_basis_device", None)
         if dev_route is not None and not self.force_host_nystrom:
             with warnings.catch_warnings():
                 warnings.simplefilter("default")
-                res = dev_route(plan, s, self.tm.max_iter)
+                res = dev_route(plan, s, self.tm.max_iter, overlap) if overlap is not None \
+                    else dev_route(plan, s, self.tm.max_iter)
             if res is not None:
                 U, gram = res
                 self._tick("nystrom_device", t0)
@@ -251,15 +255,29 @@ class RecombinationEngine:
             self.obj_head = head
         n = num_pts - 1
         S = 2 * (n + 1)
-        U = self.nystrom_basis(plan, n)
+        # the live list and the first level's set sums do not depend on the Nystrom basis: on the device
+        # route they are enqueued while the host runs the small SVD of svd_lowrank
+        state = {}
+
+        def first_sums():
+            idx_cur, count = ops.nonzero_i32(mu)           # idx_story = arange(N)[mu != 0]  (:63-65)
+            counts = comm.allgather_counts(count)
+            state.update(idx_cur=idx_cur, count=count, pos0=sum(counts[:comm.rank]), R=sum(counts))
+            if state["R"] > S and getattr(ops, "level_car", None) is not None and count > 0:
+                ops.level_moments(plan, idx_cur, state["pos0"], count, S, state["R"] // S, mu, phase=1, n=n)
+                state["sums_ready"] = True
+
+        def head_once():
+            if not state:
+                first_sums()
+
+        U = self.nystrom_basis(plan, n, overlap=head_once)
         if comm.world > 1:                                  # rank 0's randn draw is the one that counts
             U = comm.broadcast0(ops.from_host(U.contiguous()) if U.device != ops.device else U.contiguous())
         ops.set_projection(plan, U)
-
-        idx_cur, count = ops.nonzero_i32(mu)               # idx_story = arange(N)[mu != 0]  (:63-65)
-        counts = comm.allgather_counts(count)
-        pos0 = sum(counts[:comm.rank])
-        R = sum(counts)
+        head_once()
+        idx_cur, count, pos0, R = state["idx_cur"], state["count"], state["pos0"], state["R"]
+        sums_ready = state.get("sums_ready", False)
         idx_new = ops.empty_i32(count)
         levels = [] if self.trace is not None else None
 
@@ -274,19 +292,34 @@ class RecombinationEngine:
             E = R // S
             r = R - E * S
             t0 = time.perf_counter()
-            Xtr, tot = ops.level_moments(plan, idx_cur, pos0, count, S, E, mu)
+            if sums_ready:                                  # first level: the set sums are already there
+                Xtr, tot = ops.level_moments(plan, idx_cur, pos0, count, S, E, mu, phase=2)
+                sums_ready = False
+            else:
+                Xtr, tot = ops.level_moments(plan, idx_cur, pos0, count, S, E, mu)
             if obj is None:
                 comm.allreduce_sum(Xtr, tot)
             else:                                           # one more "test function" row (:138-150,157-159)
                 orow = self._obj_set_sums(obj, mu, idx_cur, pos0, count, S, E)
                 comm.allreduce_sum(Xtr, tot, orow)
                 Xtr = torch.cat([Xtr, orow.unsqueeze(0)], 0)
-            X_tmp = ops.barycentres(Xtr, tot)               # :151,166
-            keep_rank_d, w_star_d, keep_rank, n_keep = self._car(X_tmp, tot, R, E, r, levels, t0)  # :173-175
-            last_kept = bool(keep_rank[S - 1] >= 0)
-            kept_prefix = torch.zeros(S + 1, dtype=torch.int64)
-            kept_prefix[1:] = torch.cumsum((keep_rank >= 0).to(torch.int64), 0)
-            kept_prefix = kept_prefix.tolist()
+            if obj is None and not self.force_host_car and getattr(ops, "level_car", None) is not None \
+                    and ops.car_supported(S, n + 1):
+                # barycentres + on-chip Caratheodory step + flags to the host: one executor call (:151,166,173-175)
+                keep_rank_d, w_star_d, keep_np, n_keep = ops.level_car(plan, S)
+                self._tick("levels_device", t0)
+                if levels is not None:
+                    X_h, mu_h, w_h = ops.level_trace(plan)
+                    levels.append(dict(kind="level", R=R, E=E, r=r, X_tmp=X_h, tot_weights=mu_h,
+                                       idx_star=torch.from_numpy(np.flatnonzero(keep_np >= 0)),
+                                       w_star=w_h[:n_keep].clone()))
+            else:
+                X_tmp = ops.barycentres(Xtr, tot)           # :151,166
+                keep_rank_d, w_star_d, keep_rank, n_keep = self._car(X_tmp, tot, R, E, r, levels, t0)  # :173-175
+                keep_np = keep_rank.numpy()
+            kept = keep_np >= 0
+            last_kept = bool(kept[S - 1])
+            kept_prefix = [0] + np.cumsum(kept).tolist()
             R_new = E * n_keep + (r if last_kept else 0)
             if R_new >= R:
                 raise RuntimeError(

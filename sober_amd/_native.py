@@ -64,7 +64,31 @@ SIGNATURES = {
                                   _vp]),
     "sober_gspace_finish": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp]),
     "sober_wkde_draw": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sober_level_moments": (_i32, [_vp, _vp]),
+    "sober_level_car": (_i32, [_vp, _vp]),
+    "sober_record_event_pair": (_i32, [_vp, _vp, _vp]),
 }
+
+LEVEL_VALU, LEVEL_MFMA, LEVEL_GATHER = 0, 1, 2
+LEVEL_MAX_CHUNKS, LEVEL_XS = 64, 16
+
+
+class LevelJob(C.Structure):
+    """struct sober_level_job of include/sober_hip.h (field for field)."""
+    _fields_ = [
+        ("variant", _i32), ("kind", _i32),
+        ("rows", _vp), ("rows_norm", _vp), ("cand", _vp), ("cand_norm", _vp),
+        ("n_rows", _i32), ("dim", _i32), ("kmat_ld", _i64),
+        ("wmul", _vp), ("outputscale", _f64),
+        ("S", _i32), ("n", _i32), ("P", _vp),
+        ("partG", _vp), ("partTot", _vp), ("extraG", _vp), ("extraTot", _vp),
+        ("G", _vp), ("Xtr", _vp), ("tot", _vp), ("X_tmp", _vp),
+        ("keep_rank", _vp), ("w_star", _vp), ("mu_out", _vp),
+        ("car_ws", _vp), ("car_ws_bytes", _i64), ("h_flags", _vp),
+        ("ev", _vp * 4),
+        ("idx", _vp), ("pos0", _i64), ("count", _i64), ("E", _i64), ("mu", _vp),
+        ("phase", _i32),
+    ]
 
 _lib: Optional[C.CDLL] = None
 
@@ -361,6 +385,23 @@ def gspace_finish(K, corr, mug_cand, mug_rows):
     n, m = K.shape
     _check(load().sober_gspace_finish(K.data_ptr(), corr.data_ptr(), n, m, K.stride(0), corr.stride(0),
                                       mug_cand.data_ptr(), mug_rows.data_ptr(), _stream(K)), "sober_gspace_finish")
+
+
+def car_ws_bytes(N: int, m: int) -> int:
+    return load().sober_car_ws_bytes(N, m)
+
+
+def level_moments(job: LevelJob, stream: int):
+    _check(load().sober_level_moments(C.addressof(job), stream), "sober_level_moments")
+
+
+def level_car(job: LevelJob, stream: int):
+    _check(load().sober_level_car(C.addressof(job), stream), "sober_level_car")
+
+
+def record_event_pair(ev0, ev1, stream: int):
+    """torch.cuda.Event pair (already recorded once, so that their handles exist) re-recorded back to back."""
+    _check(load().sober_record_event_pair(ev0.cuda_event, ev1.cuda_event, stream), "sober_record_event_pair")
 
 
 def jitter_ladder(A, k):

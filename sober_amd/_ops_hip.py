@@ -103,7 +103,7 @@ class HipOps:
         p.P = P
 
     # ------------------------------------------------------------------ Nystrom basis on the device
-    def nystrom_basis_device(self, p: Plan, s: int, max_iter: int = 10):
+    def nystrom_basis_device(self, p: Plan, s: int, max_iter: int = 10, overlap=None):
         """ker_svd_sparsify (SOBER/_rchq.py:34-39) with the N_nys x N_nys work on the GPU:
           make_cov_psd: |cov| and the symmetry test in one kernel; the jitter rung is found by bisection
                         with the one-workgroup Cholesky (PD-ness is monotone in the shift), then the
@@ -140,7 +140,7 @@ class HipOps:
         nat.jitter_ladder(C, k_first)
         if k_first > max_iter:
             C = torch.diag(C.diagonal().clone())           # :155
-        U = self._svd_lowrank_device(C, s, R)
+        U = self._svd_lowrank_device(C, s, R, overlap=overlap)
         if U is None:
             return None
         return U, G
@@ -178,7 +178,7 @@ class HipOps:
     # matrix (~ cond(Y)^-2) stays above this: orthonormality then holds to ~1e-6 and the subspace to eps cond(Y)
     ORTH1_MIN_RATIO = 1e-10
 
-    def _svd_lowrank_device(self, A, q, R_host, niter: int = 2):
+    def _svd_lowrank_device(self, A, q, R_host, niter: int = 2, overlap=None):
         """torch.svd_lowrank(A, q) (Halko et al. Alg. 4.4 / 5.1, as in torch/_lowrank.py) for a square
         device matrix; returns -U^T (q, M) like SOBER/_rchq.py:38, or None if CholeskyQR lost rank."""
         from ._engine import host_lapack_threads
@@ -214,7 +214,9 @@ class HipOps:
         L1, L2 = self._orth(Bt, infos_b, pivs_b, 0, want_q=False)
         RbT = torch.empty(q, q, dtype=torch.float64, device=dev)
         nat.dgemm(L1, L2, RbT)                                       # Rb^T = L1 L2 (lower triangular)
-        RbT_h, infos_h, pivs_h, infos_bh, pivs_bh = self.to_host(RbT, infos, pivs, infos_b, pivs_b)
+        # `overlap` (the engine's device work that does not need U) is enqueued behind the copies, so the GPU
+        # keeps running while the host does the small SVD
+        RbT_h, infos_h, pivs_h, infos_bh, pivs_bh = self.to_host(RbT, infos, pivs, infos_b, pivs_b, before_sync=overlap)
         # a second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1
         single = [s for s in range(0, 2 * n_orth, 2) if s // 2 != last]
         if bool((infos_h != 0).any()) or bool((infos_bh != 0).any()) or float(pivs_bh[1]) < 0.5 \
@@ -228,19 +230,23 @@ class HipOps:
         return (-1 * U.T).contiguous()
 
     # ------------------------------------------------------------------ levels
-    def _prof_begin(self):
-        if self.prof is None:
-            return None
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(torch.cuda.current_stream(self.device))      # the stream the kernel is launched on
-        return ev
+    def prof_reserve(self, n_pairs: int):
+        """Pre-create event pairs for `self.prof` (so that a timed region does not pay for their creation)."""
+        pool = getattr(self, "_ev_pool", None)
+        if pool is None:
+            pool = self._ev_pool = []
+        st = torch.cuda.current_stream(self.device)
+        for _ in range(n_pairs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st); e1.record(st)                    # creates the hipEvent_t; the executor re-records it
+            pool.append((e0, e1))
 
-    def _prof_end(self, ev, entries):
-        if ev is None:
-            return
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev1.record(torch.cuda.current_stream(self.device))
-        self.prof.append((ev, ev1, int(entries)))
+    def _prof_pair(self):
+        pool = getattr(self, "_ev_pool", None)
+        if not pool:
+            self.prof_reserve(1)
+            pool = self._ev_pool
+        return pool.pop()
 
     def _buf(self, p, name, numel):
         t = p.ws.get(name)
@@ -249,47 +255,106 @@ class HipOps:
             p.ws[name] = t
         return t
 
-    def _level_reduce(self, p, idx, idx_off, pos0, count, S, mu, n_chunks, partG, ldg, partTot, tot_limit):
-        if p.da > 0:
-            nat.level_reduce_mfma(p.kind, p.rows_aug, p.cand_aug, p.da, idx, idx_off, pos0, count, S, mu,
-                                  p.wmul, p.spec.outputscale, n_chunks, partG, ldg, 0, partTot, tot_limit)
+    def _job(self, p: Plan, S: int, n: int = None) -> nat.LevelJob:
+        """The level executor's job (include/sober_hip.h: sober_level_job): per-step constants and
+        workspaces, built once per plan; only the position range changes from level to level.  The
+        projection P may still be missing (set sums of the first level): it is attached when it exists."""
+        n = p.n if n is None else n
+        job = p.ws.get("job")
+        if job is not None and job.S == S and job.n == n:
+            if p.P is not None and job.P != p.P.data_ptr():
+                if p.P.stride(0) != p.Mtot or p.P.stride(1) != 1:
+                    p.P = p.P.contiguous()
+                job.P = p.P.data_ptr()
+            return job
+        dev, f64 = self.device, torch.float64
+        job = nat.LevelJob()
+        Kmat = getattr(p, "Kmat", None)
+        if Kmat is not None:
+            job.variant, job.kind = nat.LEVEL_GATHER, 0
+            job.cand, job.kmat_ld, job.n_rows = Kmat.data_ptr(), Kmat.stride(0), Kmat.shape[1]
+            job.outputscale = 1.0
+        elif p.da > 0:
+            job.variant, job.kind = nat.LEVEL_MFMA, p.kind
+            job.rows, job.cand, job.dim, job.n_rows = p.rows_aug.data_ptr(), p.cand_aug.data_ptr(), p.da, p.Mtot
+            job.outputscale = float(p.spec.outputscale)
         else:
-            nat.level_reduce(p.kind, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, p.rows.dt, idx,
-                             idx_off, pos0, count, S, mu, p.wmul, p.spec.outputscale, n_chunks, partG, ldg, 0,
-                             partTot, tot_limit)
+            job.variant, job.kind = nat.LEVEL_VALU, p.kind
+            job.rows, job.rows_norm = p.rows.data.data_ptr(), nat._ptr(p.rows.norm)
+            job.cand, job.cand_norm = p.cand.data.data_ptr(), nat._ptr(p.cand.norm)
+            job.dim, job.n_rows = p.rows.dt, p.Mtot
+            job.outputscale = float(p.spec.outputscale)
+        job.wmul = nat._ptr(p.wmul)
+        if p.P is not None and (p.P.stride(0) != p.Mtot or p.P.stride(1) != 1):
+            p.P = p.P.contiguous()
+        job.S, job.n, job.P = S, n, nat._ptr(p.P)
+        nr, mc, xs = job.n_rows, nat.LEVEL_MAX_CHUNKS, nat.LEVEL_XS
+        w = p.ws
+        w["partG"], w["partTot"] = torch.empty(mc * nr * S, dtype=f64, device=dev), torch.empty(mc * S, dtype=f64, device=dev)
+        w["extraG"], w["extraTot"] = torch.empty(mc * nr * xs, dtype=f64, device=dev), torch.empty(mc * xs, dtype=f64, device=dev)
+        w["G"] = torch.empty(nr, S, dtype=f64, device=dev)
+        w["Xtr"], w["tot"] = torch.empty(n, S, dtype=f64, device=dev), torch.empty(S, dtype=f64, device=dev)
+        w["X_tmp"] = torch.empty(S, n, dtype=f64, device=dev)
+        w["keep_rank"] = torch.empty(S + 1, dtype=torch.int32, device=dev)
+        w["w_star"], w["mu_out"] = torch.empty(S, dtype=f64, device=dev), torch.empty(S, dtype=f64, device=dev)
+        w["h_flags"] = torch.empty(S + 1, dtype=torch.int32, pin_memory=True)
+        w["h_flags_np"] = w["h_flags"].numpy()
+        for k in ("partG", "partTot", "extraG", "extraTot", "G", "Xtr", "tot", "X_tmp", "keep_rank", "w_star", "mu_out",
+                  "h_flags"):
+            setattr(job, k, w[k].data_ptr())
+        if nat.car_supported(S, n + 1):
+            nbytes = nat.car_ws_bytes(S, n + 1)
+            w["car_ws"] = torch.empty(max(nbytes // 8, 1), dtype=f64, device=dev)
+            job.car_ws, job.car_ws_bytes = w["car_ws"].data_ptr(), nbytes
+        w["job"] = job
+        return job
 
-    def level_moments(self, p: Plan, idx, pos0, count, S, E, mu):
+    def level_moments(self, p: Plan, idx, pos0, count, S, E, mu, phase: int = 0, n: int = None):
         """Partial (n, S) projected set sums and (S,) set masses over the local list positions
         [pos0, pos0+count) of a level with E full elements (SOBER/_rchq.py:116-164 minus the
         division).  Q1: leftovers (p >= E*S) are summed into set p mod S AND into set S-1; only
-        the latter reaches `tot`."""
-        dev = self.device
-        ES = E * S
-        n_chunks = nat.level_chunks(p.Mtot, pos0, count, S)
-        partG = self._buf(p, "partG", n_chunks * p.Mtot * S)
-        partTot = self._buf(p, "partTot", n_chunks * S)
-        ev = self._prof_begin()
-        self._level_reduce(p, idx, 0, pos0, count, S, mu, n_chunks, partG, S, partTot, ES)
-        self._prof_end(ev, count * p.Mtot)
-        extraG = extraTot = None
-        n_xchunks, XS = 0, 16
-        lo = max(pos0, ES)                                   # first local leftover position
-        n_left = pos0 + count - lo
-        if n_left > 0:
-            # second placement of the leftovers (:153-164): the same kernel over the leftover
-            # positions alone, spread over XS pseudo-sets that sum_partials folds into set S-1
-            n_xchunks = nat.level_chunks(p.Mtot, 0, n_left, XS)
-            extraG = self._buf(p, "extraG", n_xchunks * p.Mtot * XS)
-            extraTot = self._buf(p, "extraTot", n_xchunks * XS)
-            ev = self._prof_begin()
-            self._level_reduce(p, idx, lo - pos0, 0, n_left, XS, mu, n_xchunks, extraG, XS, extraTot, n_left)
-            self._prof_end(ev, n_left * p.Mtot)
-        G = self._buf(p, "G", p.Mtot * S).view(p.Mtot, S)
-        tot = torch.empty(S, dtype=torch.float64, device=dev)
-        nat.sum_partials(partG, partTot, n_chunks, p.Mtot, S, S, extraG, extraTot, n_xchunks, XS, G, tot)
-        Xtr = torch.empty(p.n, S, dtype=torch.float64, device=dev)
-        nat.dgemm(p.P, G, Xtr)
-        return Xtr, tot
+        the latter reaches `tot`.  One call of the level executor (csrc/level_exec.cpp): level_reduce,
+        the leftover launch, sum_partials and the projection P G.  The returned tensors are the plan's
+        workspaces: they are overwritten by the next level.
+        phase 1: only the set sums (they do not depend on the Nystrom basis; `n` = its size, for the
+        workspaces); phase 2: only the projection of the sums left by a phase-1 call."""
+        job = self._job(p, S, n)
+        job.phase = phase
+        if phase == 2:
+            nat.level_moments(job, nat._stream(p.ws["G"]))
+            return p.ws["Xtr"], p.ws["tot"]
+        nat._req(idx, torch.int32, "idx"); nat._req(mu, torch.float64, "mu")
+        job.idx, job.pos0, job.count, job.E, job.mu = idx.data_ptr(), pos0, count, E, mu.data_ptr()
+        pairs = None
+        if self.prof is not None:
+            n_left = pos0 + count - max(pos0, E * S)
+            pairs = [self._prof_pair(), self._prof_pair() if n_left > 0 else None]
+            for k, pr in enumerate(pairs):
+                job.ev[2 * k] = pr[0].cuda_event if pr else None
+                job.ev[2 * k + 1] = pr[1].cuda_event if pr else None
+        nat.level_moments(job, nat._stream(mu))
+        if pairs is not None:
+            self.prof.append((pairs[0][0], pairs[0][1], int(count * job.n_rows)))
+            if pairs[1] is not None:
+                self.prof.append((pairs[1][0], pairs[1][1], int(n_left * job.n_rows)))
+            for k in range(4):
+                job.ev[k] = None
+        return p.ws["Xtr"], p.ws["tot"]
+
+    def level_car(self, p: Plan, S: int):
+        """Barycentres (SOBER/_rchq.py:151,166) + the on-chip Caratheodory step (:173-175) on the plan's Xtr / tot,
+        then keep_rank and n_keep to the host -- one executor call, one stream synchronisation.
+        Returns (keep_rank_d int32 (S,), w_star_d (S,), keep_rank host numpy int32 (S,), n_keep)."""
+        job = self._job(p, S)
+        st = torch.cuda.current_stream(self.device)
+        nat.level_car(job, st.cuda_stream)
+        st.synchronize()
+        flags = p.ws["h_flags_np"]
+        return p.ws["keep_rank"][:S], p.ws["w_star"], flags[:S].copy(), int(flags[S])
+
+    def level_trace(self, p: Plan):
+        """Host copies of the last level's barycentres, set masses and kept weights (test traces)."""
+        return self.to_host(p.ws["X_tmp"], p.ws["tot"], p.ws["w_star"])
 
     def direct_columns(self, p: Plan, idx, count):
         """(count, n) rows U @ kernel(pt_nys, samp[idx]) of the final direct level
@@ -347,7 +412,10 @@ class HipOps:
     def empty_i32(self, n):
         return torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
 
-    def to_host(self, *tensors):
+    def to_host(self, *tensors, before_sync=None):
+        """Device tensors -> host copies through pinned staging buffers, one synchronisation.  `before_sync`
+        (optional callable) runs after the copies are enqueued: whatever it enqueues overlaps with the host
+        work that follows this call (the wait is on the copies only)."""
         outs = []
         for i, t in enumerate(tensors):
             key = (i, t.dtype, tuple(t.shape))
@@ -357,7 +425,13 @@ class HipOps:
                 self._pin[key] = buf
             buf.copy_(t, non_blocking=True)
             outs.append(buf)
-        torch.cuda.current_stream(self.device).synchronize()
+        if before_sync is None:
+            torch.cuda.current_stream(self.device).synchronize()
+        else:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            before_sync()
+            ev.synchronize()
         return [o.clone() for o in outs]
 
     def from_host(self, t, dtype=None):
@@ -407,9 +481,6 @@ class MatrixKernelOps(HipOps):
     def set_projection(self, p, U):
         p.P = U.to(self.device, torch.float64).contiguous()
         p.n = p.P.shape[0]
-
-    def _level_reduce(self, p, idx, idx_off, pos0, count, S, mu, n_chunks, partG, ldg, partTot, tot_limit):
-        nat.level_gather(p.Kmat, idx, idx_off, pos0, count, S, mu, None, n_chunks, partG, ldg, 0, partTot, tot_limit)
 
     def direct_columns(self, p, idx, count):
         Kc = p.Kmat[idx[:count].long()].contiguous()                      # (count, M)

@@ -1,0 +1,97 @@
+// Level executor: the launch sequence of one level of the halving loop behind one C call each side of the
+// (optional) all-reduce.  Pure host code: it only sequences the library's own entry points on the caller's
+// stream, so a level costs two calls from the host language instead of ten.
+#include <hip/hip_runtime.h>
+
+#include "../../include/sober_hip.h"
+
+#define LX_TRY(call)                 \
+    do {                             \
+        const int rc_ = (call);      \
+        if (rc_ != 0) return rc_;    \
+    } while (0)
+
+#define LX_EVENT(K)                                                                      \
+    if (j->ev[K]) {                                                                      \
+        const hipError_t e_ = hipEventRecord((hipEvent_t)j->ev[K], (hipStream_t)stream); \
+        if (e_ != hipSuccess) return (int)e_;                                            \
+    }
+
+static int lx_reduce(const sober_level_job* j, const int32_t* idx, int64_t pos0, int64_t count, int S, int n_chunks,
+                     double* partG, double* partTot, int64_t tot_limit, void* stream) {
+    switch (j->variant) {
+        case SOBER_LEVEL_MFMA:
+            return sober_level_reduce_mfma(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand, j->dim,
+                                           idx, pos0, count, S, j->mu, j->wmul, j->outputscale, n_chunks, partG, S, 0,
+                                           partTot, tot_limit, stream);
+        case SOBER_LEVEL_VALU:
+            return sober_level_reduce(j->kind, j->rows, j->rows_norm, j->n_rows, j->cand, j->cand_norm, j->dim, idx,
+                                      pos0, count, S, j->mu, j->wmul, j->outputscale, n_chunks, partG, S, 0, partTot,
+                                      tot_limit, stream);
+        case SOBER_LEVEL_GATHER:
+            return sober_level_gather((const double*)j->cand, j->n_rows, j->kmat_ld, idx, pos0, count, S, j->mu,
+                                      j->wmul, n_chunks, partG, S, 0, partTot, tot_limit, stream);
+        default:
+            return SOBER_E_ARG;
+    }
+}
+
+extern "C" int sober_level_moments(const sober_level_job* j, void* stream) {
+    if (!j || !j->G || !j->tot || j->n_rows <= 0 || j->S <= 0 || j->n <= 0 || j->phase < 0 || j->phase > 2)
+        return SOBER_E_ARG;
+    const int S = j->S;
+    if (j->phase == 2) {
+        if (!j->P || !j->Xtr) return SOBER_E_ARG;
+        return sober_dgemm(0, 0, j->n, S, j->n_rows, 1.0, j->P, j->n_rows, j->G, S, 0.0, j->Xtr, S, stream);
+    }
+    if (!j->cand || !j->idx || !j->mu || !j->partG || !j->partTot || (j->phase == 0 && (!j->P || !j->Xtr)))
+        return SOBER_E_ARG;
+    if (j->count <= 0 || j->pos0 < 0 || j->E < 0) return SOBER_E_ARG;
+    const int64_t ES = j->E * S;
+    const int n_chunks = sober_level_chunks(j->n_rows, j->pos0, j->count, S);
+    if (n_chunks <= 0 || n_chunks > SOBER_LEVEL_MAX_CHUNKS) return n_chunks <= 0 ? n_chunks : SOBER_E_WS;
+    // first placement: every live position, set = p mod S (leftovers land in sets 0..r-1, quirk Q1); tot over p < ES
+    LX_EVENT(0)
+    LX_TRY(lx_reduce(j, j->idx, j->pos0, j->count, S, n_chunks, j->partG, j->partTot, ES, stream));
+    LX_EVENT(1)
+    // second placement of the leftovers (SOBER/_rchq.py:153-164): the same kernel over the leftover positions
+    // alone, spread over XS pseudo-sets that sum_partials folds into set S-1
+    const int64_t lo = j->pos0 > ES ? j->pos0 : ES;
+    const int64_t n_left = j->pos0 + j->count - lo;
+    int n_xchunks = 0;
+    if (n_left > 0) {
+        if (!j->extraG || !j->extraTot) return SOBER_E_ARG;
+        n_xchunks = sober_level_chunks(j->n_rows, 0, n_left, SOBER_LEVEL_XS);
+        if (n_xchunks <= 0 || n_xchunks > SOBER_LEVEL_MAX_CHUNKS) return n_xchunks <= 0 ? n_xchunks : SOBER_E_WS;
+        LX_EVENT(2)
+        LX_TRY(lx_reduce(j, j->idx + (lo - j->pos0), 0, n_left, SOBER_LEVEL_XS, n_xchunks, j->extraG, j->extraTot,
+                         n_left, stream));
+        LX_EVENT(3)
+    }
+    LX_TRY(sober_sum_partials(j->partG, j->partTot, n_chunks, j->n_rows, S, S, n_left > 0 ? j->extraG : nullptr,
+                              n_left > 0 ? j->extraTot : nullptr, n_xchunks, SOBER_LEVEL_XS, j->G, S, j->tot, stream));
+    if (j->phase == 1) return 0;
+    return sober_dgemm(0, 0, j->n, S, j->n_rows, 1.0, j->P, j->n_rows, j->G, S, 0.0, j->Xtr, S, stream);
+}
+
+extern "C" int sober_level_car(const sober_level_job* j, void* stream) {
+    if (!j || !j->Xtr || !j->tot || !j->X_tmp || !j->keep_rank || !j->w_star || !j->mu_out || !j->car_ws || !j->h_flags)
+        return SOBER_E_ARG;
+    const int S = j->S, n = j->n;
+    if (!sober_car_supported(S, n + 1)) return SOBER_E_DIM;
+    LX_TRY(sober_barycentres(j->Xtr, S, n, S, j->tot, j->X_tmp, stream));
+    LX_TRY(sober_car_device(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
+                            nullptr, j->car_ws, j->car_ws_bytes, stream));
+    const hipError_t e = hipMemcpyAsync(j->h_flags, j->keep_rank, sizeof(int32_t) * (size_t)(S + 1),
+                                        hipMemcpyDeviceToHost, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// Two events recorded back to back on the stream: what an empty ev[0]/ev[1] bracket of sober_level_moments
+// measures (the calibration of the caller's kernel timing).
+extern "C" int sober_record_event_pair(void* ev0, void* ev1, void* stream) {
+    if (!ev0 || !ev1) return SOBER_E_ARG;
+    hipError_t e = hipEventRecord((hipEvent_t)ev0, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipEventRecord((hipEvent_t)ev1, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
