@@ -271,7 +271,9 @@ class RecombinationEngine:
             if not state:
                 first_sums()
 
-        U = self.nystrom_basis(plan, n, overlap=head_once)
+        # (sharded runs keep the collectives in one fixed order on every rank: no overlap there, the ranks'
+        # Nystrom routes may differ -- each draws its own randn -- and only rank 0's result is used)
+        U = self.nystrom_basis(plan, n, overlap=head_once if comm.world == 1 else None)
         if comm.world > 1:                                  # rank 0's randn draw is the one that counts
             U = comm.broadcast0(ops.from_host(U.contiguous()) if U.device != ops.device else U.contiguous())
         ops.set_projection(plan, U)

@@ -40,16 +40,23 @@ __device__ __forceinline__ void exp_tab4(const double (&y)[4], const double* __r
     const double K3 = 2.1173137155464776e-07;
     const double K4 = 5.732851688640402e-10;
     const double K5 = 1.2417843701716925e-12;
-    double u[4], r[4], t[4], q[4];
+    double yc[4], u[4], r[4], t[4], q[4];
     int n[4];
+    // clamp at about -65000 (e^-704 ~ 1e-306 keeps 2^(n>>6) a normal number) as an UNSIGNED MIN ON THE HIGH DWORD:
+    // for negative doubles a larger bit pattern is a more negative value, non-negative ones compare below any
+    // negative pattern and pass unchanged (NaN too).  An integer op: it does not take a slot of the FP64 units,
+    // which the exponentials and the MFMAs share.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = fmax(y[i], -65000.0) + MAGIC;   // e^-704 ~ 1e-306: keeps 2^(n>>6) a normal number
+    for (int i = 0; i < 4; ++i)
+        yc[i] = __hiloint2double((int)min((unsigned)__double2hiint(y[i]), 0xC0EFBD00u), __double2loint(y[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = yc[i] + MAGIC;
 #pragma unroll
     for (int i = 0; i < 4; ++i) n[i] = __double2loint(u[i]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[i] = T[n[i] & 63];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = fmax(y[i], -65000.0) - (u[i] - MAGIC);
+    for (int i = 0; i < 4; ++i) r[i] = yc[i] - (u[i] - MAGIC);
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = fma(r[i], K5, K4);
 #pragma unroll
@@ -63,7 +70,9 @@ __device__ __forceinline__ void exp_tab4(const double (&y)[4], const double* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const double v = fma(t[i], q[i], t[i]);                        // in [1, 2)
-        out[i] = __hiloint2double(__double2hiint(v) + ((n[i] >> 6) << 20), __double2loint(v));
+        int hi;                                                        // exponent field += n >> 6: shift + fused shift-add
+        asm("v_lshl_add_u32 %0, %1, 20, %2" : "=v"(hi) : "v"(n[i] >> 6), "v"(__double2hiint(v)));
+        out[i] = __hiloint2double(hi, __double2loint(v));
     }
 }
 
@@ -181,15 +190,16 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
     LM_STAGE_WRITE(0)
     __syncthreads();
 
+    const bool rows_live = row0 < n_rows;               // a wave wholly past the row table only helps staging
     for (int et = e0; et < e1; et += TE) {
         LM_STAGE_LOAD(et + TE)                                          // (padding when there is no next tile)
         LM_PREFETCH_IDX(et + 2 * TE)
-        const int te_cnt = min(TE, e1 - et);
+        const int te_cnt = rows_live ? min(TE, e1 - et) : 0;
         // software pipeline over the elements of the tile: the MFMAs of element te+1 are issued
         // before the exponentials of element te, so the matrix and vector pipes overlap in-wave
-        double4_t cc[4];
-        double wc;
-        {
+        double4_t cc[4] = {};
+        double wc = 0.0;
+        if (rows_live) {
             double bfr[KT];
 #pragma unroll
             for (int ks = 0; ks < KT; ++ks) bfr[ks] = s_pts[buf][0][4 * ks + lk][lj];
