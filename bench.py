@@ -99,16 +99,22 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    # the warm-up steps run exactly what the timed steps run, event brackets included (their first use costs
+    # tens of ms in a fresh process)
+    ops.prof = []
+    ops.prof_reserve(16 * (args.steps + args.warmup + 1))    # event pairs for the level_reduce launches, created up front
+    idx, w = step()                                      # initialisation (library load, workspaces, first-use paths)
     for _ in range(args.warmup):
         idx, w = step()
     torch.cuda.synchronize()
-
     ops.prof = []
-    ops.prof_reserve(16 * args.steps)                    # event pairs for the level_reduce launches, created up front
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per_step = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         idx, w = step(timers)
+        per_step.append(time.perf_counter() - ts)          # (host clock at return: the result tensors are final)
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -209,6 +215,7 @@ def main():
         "cpu_baseline": cpu_baseline,
         "parity": parity,
         "phases_ms_per_step": {k: v / args.steps * 1e3 for k, v in timers.items()},
+        "ms_each_step": [round(v * 1e3, 3) for v in per_step],
         "n_selected": int(idx.numel()),
     }
     print(json.dumps(out))

@@ -180,6 +180,14 @@ int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in
  * range finder of torch.svd_lowrank (SOBER/_rchq.py:37).                                           */
 int sober_chol_max_n(void);
 int sober_cholesky(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, void* stream);
+/* Same, and xinv (ceil(n/32) blocks of 32 x 32 doubles, row-major) receives the inverses of the 32 x 32 diagonal
+ * blocks of L (identity-padded in the last block) -- the operands of sober_trsm_blocks.                       */
+int sober_cholesky_inv(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, double* xinv,
+                       void* stream);
+/* Q = Y L^-T like sober_trsm_rows (q <= 256), blocked on the matrix cores with the inverted diagonal blocks of
+ * sober_cholesky_inv: block-to-block dependency only.                                                          */
+int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl, const double* Xinv,
+                      double* Q, int ldq, void* stream);
 /* All rungs of the jitter ladder in one launch: workgroup b factorises (src + shifts[b] I) in slab b of
  * `work` (n_shifts * n * n doubles) and sets info[b] (0 = positive definite).  src is not modified.     */
 int sober_cholesky_probe(const double* src, int n, int ld_src, const double* shifts, int n_shifts,

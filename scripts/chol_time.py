@@ -46,3 +46,12 @@ for n in (99, 128, 198, 500):
         Lc = torch.zeros(n, n, dtype=torch.float64, device=dev)
         t = timed(lambda: nat.chol_small(Sd, Lc, inf1, piv))
         print("k_chol_small n=%d: %.1f us, err %.2e" % (n, t, np.abs(Lc.cpu().numpy() - np.linalg.cholesky(S)).max()))
+
+for m, q in ((500, 99), (500, 199)):
+    Y = torch.from_numpy(rng.standard_normal((m, q))).to(dev)
+    G = (Y.T @ Y).contiguous(); Gd = G.clone()
+    inf1 = torch.zeros(1, dtype=torch.int32, device=dev); piv = torch.zeros(1, dtype=torch.float64, device=dev)
+    xinv = torch.empty(((q + 31) // 32) * 1024, dtype=torch.float64, device=dev)
+    nat.cholesky_inv(Gd, 0.0, inf1, piv, xinv)
+    Q = torch.empty_like(Y)
+    print("q=%d trsm_rows %.1f us, trsm_blocks %.1f us" % (q, timed(lambda: nat.trsm_rows(Y, Gd, Q)), timed(lambda: nat.trsm_blocks(Y, Gd, xinv, Q))))

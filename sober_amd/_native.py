@@ -50,6 +50,8 @@ SIGNATURES = {
     "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_chol_max_n": (_i32, []),
     "sober_cholesky": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp]),
+    "sober_cholesky_inv": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
+    "sober_trsm_blocks": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sober_cholesky_probe": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_chol_small": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_trsm_rows": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
@@ -313,6 +315,21 @@ def cholesky(A, shift, info, min_pivot=None):
     n = A.shape[0]
     _check(load().sober_cholesky(A.data_ptr(), n, A.stride(0), float(shift), info.data_ptr(), _ptr(min_pivot),
                                  _stream(A)), "sober_cholesky")
+
+
+def cholesky_inv(A, shift, info, min_pivot, xinv):
+    """cholesky() that also leaves the inverted 32 x 32 diagonal blocks of L in xinv (ceil(n/32) * 1024 doubles)."""
+    n = A.shape[0]
+    if xinv.numel() < ((n + 31) // 32) * 1024:
+        raise SoberHipError("cholesky_inv: xinv too small")
+    _check(load().sober_cholesky_inv(A.data_ptr(), n, A.stride(0), float(shift), info.data_ptr(), _ptr(min_pivot),
+                                     xinv.data_ptr(), _stream(A)), "sober_cholesky_inv")
+
+
+def trsm_blocks(Y, L, xinv, Q):
+    m, q = Y.shape
+    _check(load().sober_trsm_blocks(Y.data_ptr(), m, q, Y.stride(0), L.data_ptr(), L.stride(0), xinv.data_ptr(),
+                                    Q.data_ptr(), Q.stride(0), _stream(Y)), "sober_trsm_blocks")
 
 
 def cholesky_probe(src, shifts, work, info):

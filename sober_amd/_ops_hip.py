@@ -157,20 +157,18 @@ class HipOps:
             Gm = torch.empty(q, q, dtype=torch.float64, device=self.device)
             nat.dgemm(Y, Y, Gm, transa=True)
             dmax = Gm.diagonal().amax() if passes == 1 else None
-            if q <= 128:                                    # LDS-resident factorisation
-                Lc = torch.zeros(q, q, dtype=torch.float64, device=self.device)
-                nat.chol_small(Gm, Lc, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1])
-            else:                                           # blocked one-workgroup Cholesky, in place
-                Lc = Gm
-                nat.cholesky(Lc, 0.0, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1])
-                Lc = Lc.tril_()
+            # one-workgroup blocked Cholesky, in place; it leaves the inverted 32 x 32 diagonal blocks behind,
+            # which turn Q = Y R^-1 into block-to-block MFMA work (sober_trsm_blocks)
+            Lc = Gm
+            xinv = torch.empty(((q + 31) // 32) * 1024, dtype=torch.float64, device=self.device)
+            nat.cholesky_inv(Lc, 0.0, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1], xinv)
             if passes == 1:
                 pivs[slot + 1] = pivs[slot] / dmax
             Ls.append(Lc)
             if not want_q and it == passes - 1:
-                return Ls
+                return [l.tril_() for l in Ls]              # (the factorisation leaves the upper triangle untouched)
             Q = torch.empty_like(Y)
-            nat.trsm_rows(Y, Lc, Q)                             # Q = Y R^-1, one wave per row
+            nat.trsm_blocks(Y, Lc, xinv, Q)                     # Q = Y R^-1
             Y = Q
         return Y
 

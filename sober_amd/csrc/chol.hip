@@ -44,7 +44,7 @@ __device__ __forceinline__ double ch_rdlane(double v, int l) {
 __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, int ld, double shift,
                                               int32_t* __restrict__ info, double* __restrict__ min_pivot,
                                               const double* __restrict__ src, int lds_src,
-                                              const double* __restrict__ shifts) {
+                                              const double* __restrict__ shifts, double* __restrict__ xout) {
     extern __shared__ double lds[];
     if (src != nullptr) {                     // batched: copy the lower triangle into my slab first
         A += (size_t)blockIdx.x * n * ld;
@@ -143,6 +143,11 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
                 if (i < CH_NB) {
 #pragma unroll
                     for (int c = 0; c < CH_NB; ++c) Xs[c * LDP + jx] = x[c];                 // X[c][jx]
+                    if (xout != nullptr) {                    // the inverted diagonal blocks feed k_trsm_blocks
+                        double* xo = xout + (size_t)(kb / CH_NB) * CH_NB * CH_NB;
+#pragma unroll
+                        for (int c = 0; c < CH_NB; ++c) xo[c * CH_NB + jx] = x[c];
+                    }
                 }
             }
         }
@@ -388,6 +393,79 @@ __global__ __launch_bounds__(256) void k_trsm_rows(const double* __restrict__ Y,
         if (lane + 64 * t < q) o[lane + 64 * t] = x[t];
 }
 
+// Q = Y L^-T (the Q factor of CholeskyQR) on the matrix cores, from the INVERTED 32 x 32 diagonal blocks that
+// k_chol leaves behind (xinv): for column block jb
+//     Q_jb = (Y_jb - sum_{kb < jb} Q_kb L[jb][kb]^T) X_jb^T ,      X_jb = L[jb][jb]^-1 ,
+// so the only sequential dependency is block to block (q / 32 steps), not column to column.  One wave per 16 rows
+// of Y; its finished Q blocks stay in LDS in the A-fragment-friendly layout for the later blocks.
+constexpr int TB_WAVES = 2;
+__global__ __launch_bounds__(TB_WAVES * 64) void k_trsm_blocks(const double* __restrict__ Y, int64_t m, int q, int ldy,
+                                                              const double* __restrict__ L, int ldl,
+                                                              const double* __restrict__ Xinv,
+                                                              double* __restrict__ Q, int ldq) {
+    extern __shared__ double tb_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int qpad = ((q + 31) / 32) * 32, LS = qpad + 4;             // stash row stride: fragments on distinct bank pairs
+    double* stash = tb_lds + (size_t)wave * (16 * LS + 16 * 36);      // 16 x LS: the Q blocks finished so far
+    double* tbuf = stash + 16 * LS;                                   // 16 x 36: the block being multiplied by X^T
+    const int64_t R0 = ((int64_t)blockIdx.x * TB_WAVES + wave) * 16;
+    if (R0 >= m) return;                                              // whole wave; no workgroup barrier below
+    const int nblk = qpad / 32;
+    for (int jb = 0; jb < nblk; ++jb) {
+        const int c0 = 32 * jb;
+        ch_double4 acc[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = min(R0 + lk + 4 * r, m - 1);
+                const int col = c0 + 16 * jt + li;
+                const double v = Y[row * ldy + min(col, q - 1)];
+                acc[jt][r] = (col < q) ? v : 0.0;
+            }
+        for (int kb = 0; kb < jb; ++kb) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kc = 32 * kb + 4 * u + lk;                  // kc < c0 <= q - 1... (kb < jb: a full block)
+                const double a = -stash[li * LS + kc];
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    const int lr = c0 + 16 * jt + li;                 // row of L = column of this block
+                    const double b = L[(size_t)min(lr, q - 1) * ldl + kc];
+                    acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (lr < q) ? b : 0.0, acc[jt], 0, 0, 0);
+                }
+            }
+        }
+        // T = acc -> LDS (row-major 16 x 32), back as A fragments: out = T X_jb^T
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tbuf[(lk + 4 * r) * 36 + 16 * jt + li] = acc[jt][r];
+        __builtin_amdgcn_wave_barrier();
+        const double* X = Xinv + (size_t)jb * 32 * 32;
+        ch_double4 out[2] = {(ch_double4){0.0, 0.0, 0.0, 0.0}, (ch_double4){0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double a = tbuf[li * 36 + 4 * u + lk];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+                out[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[(16 * jt + li) * 32 + 4 * u + lk], out[jt], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = R0 + lk + 4 * r;
+                const int col = c0 + 16 * jt + li;
+                stash[(lk + 4 * r) * LS + col] = out[jt][r];
+                if (row < m && col < q) Q[row * ldq + col] = out[jt][r];
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // cov -> sqrt(nan_to_num(cov) * nan_to_num(cov).T) (SOBER/_utils.py:143-144) and the exact-symmetry
 // test of :127 on the input: flag[0] |= 1 if some cov[i][j] != cov[j][i].
 __global__ __launch_bounds__(256) void k_abs_sym(const double* __restrict__ C, int n, int ld,
@@ -430,8 +508,8 @@ __global__ void k_jitter_ladder(double* __restrict__ A, int n, int ld, int k) {
 
 extern "C" int sober_chol_max_n(void) { return sober::CH_MAXN; }
 
-extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
-                              void* stream) {
+extern "C" int sober_cholesky_inv(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
+                                  double* xinv, void* stream) {
     if (!A || !info || n <= 0 || ld < n) return SOBER_E_ARG;
     if (n > sober::CH_MAXN) return SOBER_E_DIM;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
@@ -443,7 +521,30 @@ extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* i
         attr_set = true;
     }
     hipLaunchKernelGGL(sober::k_chol, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift, info,
-                       min_pivot, (const double*)nullptr, 0, (const double*)nullptr);
+                       min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
+                              void* stream) {
+    return sober_cholesky_inv(A, n, ld, shift, info, min_pivot, nullptr, stream);
+}
+
+extern "C" int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
+                                 const double* Xinv, double* Q, int ldq, void* stream) {
+    if (!Y || !L || !Xinv || !Q || m <= 0 || q <= 0 || q > 256 || ldy < q || ldl < q || ldq < q) return SOBER_E_ARG;
+    const int qpad = ((q + 31) / 32) * 32;
+    const size_t bytes = (size_t)sober::TB_WAVES * (16 * (qpad + 4) + 16 * 36) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_trsm_blocks, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    120 * 1024));
+        attr_set = true;
+    }
+    const int64_t row_blocks = (m + 15) / 16;
+    hipLaunchKernelGGL(sober::k_trsm_blocks, dim3((unsigned)((row_blocks + sober::TB_WAVES - 1) / sober::TB_WAVES)),
+                       dim3(sober::TB_WAVES * 64), bytes, (hipStream_t)stream, Y, m, q, ldy, L, ldl, Xinv, Q, ldq);
     LAUNCH_CHECK();
     return 0;
 }
@@ -457,7 +558,7 @@ extern "C" int sober_cholesky_probe(const double* src, int n, int ld_src, const 
     HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 512));
     hipLaunchKernelGGL(sober::k_chol, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
-                       info, (double*)nullptr, src, ld_src, shifts);
+                       info, (double*)nullptr, src, ld_src, shifts, (double*)nullptr);
     LAUNCH_CHECK();
     return 0;
 }

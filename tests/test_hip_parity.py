@@ -494,6 +494,26 @@ def test_choleskyqr_and_abs_sym(dev):
     assert int(flag.item()) == 0
 
 
+def test_trsm_blocks(dev):
+    """Q = Y L^-T from the inverted diagonal blocks of the blocked Cholesky vs. numpy's triangular solve."""
+    from sober_amd import _native as nat
+    rng = np.random.default_rng(5)
+    for m, q in ((500, 99), (37, 32), (16, 5), (500, 199), (1000, 256), (130, 33)):
+        Y = rng.standard_normal((m, q))
+        G = Y.T @ Y + 0.1 * np.eye(q)
+        Gd = _t(G.copy()).to(dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev); piv = torch.zeros(1, dtype=torch.float64, device=dev)
+        xinv = torch.full((((q + 31) // 32) * 1024,), float("nan"), dtype=torch.float64, device=dev)
+        nat.cholesky_inv(Gd, 0.0, info, piv, xinv)
+        assert int(info.item()) == 0
+        Lr = np.linalg.cholesky(G)
+        np.testing.assert_allclose(np.tril(Gd.cpu().numpy()), Lr, rtol=1e-11, atol=1e-12)
+        Qd = torch.empty(m, q, dtype=torch.float64, device=dev)
+        nat.trsm_blocks(_t(Y).to(dev), Gd, xinv, Qd)
+        ref = np.linalg.solve(Lr, Y.T).T                       # Y L^-T
+        np.testing.assert_allclose(Qd.cpu().numpy(), ref, rtol=1e-10, atol=1e-11)
+
+
 def test_device_and_host_nystrom_agree(dev):
     """The device route (Cholesky bisection + CholeskyQR range finder) and the literal LAPACK route
     give the same basis up to row signs and the same recombination."""
