@@ -41,7 +41,7 @@ for n in (99, 128, 198, 500):
     run(); torch.cuda.synchronize()
     Wh = W.cpu().numpy()
     err = np.abs(np.tril(Wh) - np.linalg.cholesky(S)).max()
-    print("k_chol n=%d: %.1f us (copy %.1f us subtracted), err %.2e, stamps(ticks a/b/c/d) %s" % (n, t - tc, tc, err, Wh[0, 8:12].tolist()))
+    print("k_chol n=%d: %.1f us (copy %.1f us subtracted), err %.2e, stamps(ticks a/b-inverse/c/d/b-factorisation) %s" % (n, t - tc, tc, err, Wh[0, 8:13].tolist()))
     if n <= 128:
         Lc = torch.zeros(n, n, dtype=torch.float64, device=dev)
         t = timed(lambda: nat.chol_small(Sd, Lc, inf1, piv))
