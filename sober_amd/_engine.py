@@ -67,10 +67,17 @@ class DistComm:
             t.copy_(flat[o:o + t.numel()].view_as(t))
             o += t.numel()
 
+    def _dev(self):
+        return torch.device("cuda", torch.cuda.current_device()) \
+            if self.dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+
     def allgather_counts(self, n: int):
-        out = [None] * self.world
-        self.dist.all_gather_object(out, int(n), group=self.group)
-        return out
+        """One int per rank (a plain tensor all-gather: all_gather_object would pickle through the device)."""
+        dev = self._dev()
+        mine = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+        outs = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        self.dist.all_gather(outs, mine, group=self.group)
+        return torch.cat(outs).tolist()
 
     def broadcast0(self, t: torch.Tensor):
         """Rank 0's tensor to everyone (the Nystrom basis: its randn draw must be shared)."""
@@ -262,7 +269,10 @@ class RecombinationEngine:
         def first_sums():
             idx_cur, count = ops.nonzero_i32(mu)           # idx_story = arange(N)[mu != 0]  (:63-65)
             counts = comm.allgather_counts(count)
-            state.update(idx_cur=idx_cur, count=count, pos0=sum(counts[:comm.rank]), R=sum(counts))
+            bounds = [0]
+            for c in counts:
+                bounds.append(bounds[-1] + c)              # every rank's range of list positions, kept in closed form
+            state.update(idx_cur=idx_cur, count=count, pos0=bounds[comm.rank], R=bounds[-1], bounds=bounds)
             if state["R"] > S and getattr(ops, "level_car", None) is not None and count > 0:
                 ops.level_moments(plan, idx_cur, state["pos0"], count, S, state["R"] // S, mu, phase=1, n=n)
                 state["sums_ready"] = True
@@ -279,6 +289,7 @@ class RecombinationEngine:
         ops.set_projection(plan, U)
         head_once()
         idx_cur, count, pos0, R = state["idx_cur"], state["count"], state["pos0"], state["R"]
+        bounds = state["bounds"]
         sums_ready = state.get("sums_ready", False)
         idx_new = ops.empty_i32(count)
         levels = [] if self.trace is not None else None
@@ -289,7 +300,7 @@ class RecombinationEngine:
             if R <= n + 1:                                  # :72-75
                 return self._finish_small(mu)
             if R <= S:                                      # :77-114
-                return self._finish_direct(plan, idx_cur, count, R, mu, levels)
+                return self._finish_direct(plan, idx_cur, bounds, R, mu, levels)
 
             E = R // S
             r = R - E * S
@@ -300,7 +311,11 @@ class RecombinationEngine:
             else:
                 Xtr, tot = ops.level_moments(plan, idx_cur, pos0, count, S, E, mu)
             if obj is None:
-                comm.allreduce_sum(Xtr, tot)
+                flat = getattr(ops, "level_flat", None)    # Xtr and tot in one buffer: one message, no packing
+                if flat is not None:
+                    comm.allreduce_sum(flat(plan))
+                else:
+                    comm.allreduce_sum(Xtr, tot)
             else:                                           # one more "test function" row (:138-150,157-159)
                 orow = self._obj_set_sums(obj, mu, idx_cur, pos0, count, S, E)
                 comm.allreduce_sum(Xtr, tot, orow)
@@ -327,8 +342,8 @@ class RecombinationEngine:
                 raise RuntimeError(
                     "recombination made no progress (the Caratheodory step cancelled nothing, "
                     "SOBER/_rchq.py:241-242); the reference would loop forever here")
-            new_pos0 = survivors_before(pos0, S, E, kept_prefix, n_keep, last_kept)
-            new_end = survivors_before(pos0 + count, S, E, kept_prefix, n_keep, last_kept)
+            bounds = [survivors_before(b_, S, E, kept_prefix, n_keep, last_kept) for b_ in bounds]
+            new_pos0, new_end = bounds[comm.rank], bounds[comm.rank + 1]
             if count > 0:
                 ops.level_update(idx_cur, pos0, count, S, E, keep_rank_d, w_star_d, tot, n_keep, mu,
                                  idx_new, new_pos0)                                           # :198-221
@@ -394,21 +409,24 @@ class RecombinationEngine:
         return ops.from_host(keep_rank), ops.from_host(w_star), keep_rank, n_keep
 
     # -- terminal branches ------------------------------------------------------
-    def _gather_result(self, idx_local, w_local):
+    def _gather_result(self, idx_local, w_local, counts=None):
         comm = self.comm
         idx_glob = idx_local.to(torch.int64) + self.row_offset
         if comm.world == 1:
             return idx_glob, w_local
-        counts = comm.allgather_counts(int(idx_glob.numel()))
+        if counts is None:
+            counts = comm.allgather_counts(int(idx_glob.numel()))
         return comm.allgather_rows(idx_glob, counts), comm.allgather_rows(w_local, counts)
 
     def _finish_small(self, mu):
         idx_star = torch.nonzero(mu > 0).flatten()          # arange(len(mu))[mu > 0]  (:73)
         return self._gather_result(idx_star, mu[idx_star])
 
-    def _finish_direct(self, plan, idx_cur, count, R, mu, levels):
+    def _finish_direct(self, plan, idx_cur, bounds, R, mu, levels):
         ops, comm = self.ops, self.comm
         n = plan.n
+        counts = [bounds[r + 1] - bounds[r] for r in range(comm.world)]    # known everywhere: no exchange
+        count = counts[comm.rank]
         obj = getattr(self, "obj", None)
         nf = n + (1 if obj is not None else 0)
         if count > 0:
@@ -419,17 +437,18 @@ class RecombinationEngine:
         else:
             X_loc = torch.zeros(0, nf, dtype=torch.float64, device=ops.device)
             mu_loc = torch.zeros(0, dtype=torch.float64, device=ops.device)
-        counts = comm.allgather_counts(count)
         X_all = comm.allgather_rows(X_loc, counts)
         mu_all = comm.allgather_rows(mu_loc, counts)
         t0 = time.perf_counter()
         keep_rank_d, w_star_d, keep_rank, n_keep = self._car(X_all, mu_all, R, 0, 0, levels, t0, kind="final")  # :84-85
         idx_star = torch.nonzero(keep_rank >= 0).flatten()
-        lo = sum(counts[:comm.rank])
+        lo = bounds[comm.rank]
         mine = (idx_star >= lo) & (idx_star < lo + count)
+        # how many selected points each rank owns (the Caratheodory step is replicated: every rank knows)
+        sel_counts = [int(((idx_star >= bounds[r]) & (idx_star < bounds[r + 1])).sum()) for r in range(comm.world)]
         sel = (idx_star[mine] - lo).to(torch.int32)
         ranks = keep_rank[idx_star[mine]].long()
         mu.zero_()                                                     # mu[:] = 0  (:109)
         w_mine = w_star_d[ops.from_host(ranks)] if ranks.numel() else w_star_d[:0]
         out_idx = ops.scatter_weights(idx_cur, ops.from_host(sel), w_mine, mu)   # mu[idx_story] = w_star
-        return self._gather_result(out_idx, w_mine)
+        return self._gather_result(out_idx, w_mine, sel_counts)

@@ -291,7 +291,8 @@ class HipOps:
         w["partG"], w["partTot"] = torch.empty(mc * nr * S, dtype=f64, device=dev), torch.empty(mc * S, dtype=f64, device=dev)
         w["extraG"], w["extraTot"] = torch.empty(mc * nr * xs, dtype=f64, device=dev), torch.empty(mc * xs, dtype=f64, device=dev)
         w["G"] = torch.empty(nr, S, dtype=f64, device=dev)
-        w["Xtr"], w["tot"] = torch.empty(n, S, dtype=f64, device=dev), torch.empty(S, dtype=f64, device=dev)
+        w["XT"] = torch.empty(n * S + S, dtype=f64, device=dev)      # Xtr and tot back to back: one all-reduce message
+        w["Xtr"], w["tot"] = w["XT"][:n * S].view(n, S), w["XT"][n * S:]
         w["X_tmp"] = torch.empty(S, n, dtype=f64, device=dev)
         w["keep_rank"] = torch.empty(S + 1, dtype=torch.int32, device=dev)
         w["w_star"], w["mu_out"] = torch.empty(S, dtype=f64, device=dev), torch.empty(S, dtype=f64, device=dev)
@@ -318,6 +319,9 @@ class HipOps:
         workspaces); phase 2: only the projection of the sums left by a phase-1 call."""
         job = self._job(p, S, n)
         job.phase = phase
+        if count <= 0 and phase != 2:                       # a rank without live positions contributes zeros
+            p.ws["XT"].zero_(); p.ws["G"].zero_()
+            return p.ws["Xtr"], p.ws["tot"]
         if phase == 2:
             nat.level_moments(job, nat._stream(p.ws["G"]))
             return p.ws["Xtr"], p.ws["tot"]
@@ -338,6 +342,10 @@ class HipOps:
             for k in range(4):
                 job.ev[k] = None
         return p.ws["Xtr"], p.ws["tot"]
+
+    def level_flat(self, p: Plan):
+        """The projected set sums and the set masses of the last `level_moments` as ONE flat tensor (n*S + S)."""
+        return p.ws["XT"]
 
     def level_car(self, p: Plan, S: int):
         """Barycentres (SOBER/_rchq.py:151,166) + the on-chip Caratheodory step (:173-175) on the plan's Xtr / tot,
