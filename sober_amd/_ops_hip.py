@@ -4,6 +4,8 @@
 kernels on the current stream.  The level logic lives in `_engine.py`."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _native as nat
@@ -212,20 +214,42 @@ class HipOps:
         L1, L2 = self._orth(Bt, infos_b, pivs_b, 0, want_q=False)
         RbT = torch.empty(q, q, dtype=torch.float64, device=dev)
         nat.dgemm(L1, L2, RbT)                                       # Rb^T = L1 L2 (lower triangular)
-        # `overlap` (the engine's device work that does not need U) is enqueued behind the copies, so the GPU
-        # keeps running while the host does the small SVD
-        RbT_h, infos_h, pivs_h, infos_bh, pivs_bh = self.to_host(RbT, infos, pivs, infos_b, pivs_b, before_sync=overlap)
+        # Opt-in (SOBER_DEVICE_SVD=1): left singular vectors of the q x q factor by one-sided Jacobi on the device
+        # (csrc/jacobi.hip), so that the step does not leave the GPU here.  Measured on the MI355X at q = 99:
+        # 0.81 ms (6 sweeps, LDS-bandwidth bound at 1.4 us per round) against 0.87 ms for the host's LAPACK --
+        # but the host SVD overlaps with the first level's set sums, so the step is 0.35 ms FASTER with the host
+        # route.  It becomes the default once its columns stay in VGPRs between rounds.
+        on_device = q <= 128 and bool(os.environ.get("SOBER_DEVICE_SVD"))
+        if on_device:
+            Ub = torch.empty(q, q, dtype=torch.float64, device=dev)
+            sig = torch.empty(q, dtype=torch.float64, device=dev)
+            sweeps = torch.zeros(1, dtype=torch.int32, device=dev)
+            nat.jacobi_left(RbT, Ub, sig, sweeps, max_sweeps=self.JACOBI_MAX_SWEEPS)
+            U = torch.empty(M, q, dtype=torch.float64, device=dev)
+            nat.dgemm(Q, Ub, U)
+            Ut = (-1 * U.T).contiguous()
+            infos_h, pivs_h, infos_bh, pivs_bh, sweeps_h = self.to_host(infos, pivs, infos_b, pivs_b, sweeps,
+                                                                        before_sync=overlap)
+        else:
+            # `overlap` (the engine's device work that does not need U) is enqueued behind the copies, so the GPU
+            # keeps running while the host does the small SVD
+            RbT_h, infos_h, pivs_h, infos_bh, pivs_bh = self.to_host(RbT, infos, pivs, infos_b, pivs_b,
+                                                                     before_sync=overlap)
         # a second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1
         single = [s for s in range(0, 2 * n_orth, 2) if s // 2 != last]
         if bool((infos_h != 0).any()) or bool((infos_bh != 0).any()) or float(pivs_bh[1]) < 0.5 \
                 or float(pivs_h[2 * last + 1]) < 0.5 \
                 or any(not (float(pivs_h[s + 1]) >= self.ORTH1_MIN_RATIO) for s in single):
             return None
+        if on_device:
+            return Ut if int(sweeps_h[0]) < self.JACOBI_MAX_SWEEPS else None      # (not converged: host route)
         with host_lapack_threads(M):
             Ub, _, _ = torch.linalg.svd(RbT_h, full_matrices=False)
         U = torch.empty(M, q, dtype=torch.float64, device=dev)
         nat.dgemm(Q, self.from_host(Ub.contiguous()), U)
         return (-1 * U.T).contiguous()
+
+    JACOBI_MAX_SWEEPS = 30
 
     # ------------------------------------------------------------------ levels
     def prof_reserve(self, n_pairs: int):

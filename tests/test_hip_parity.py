@@ -494,6 +494,26 @@ def test_choleskyqr_and_abs_sym(dev):
     assert int(flag.item()) == 0
 
 
+def test_jacobi_left(dev):
+    """One-sided Jacobi on the device vs. LAPACK: singular values to high relative accuracy, left singular
+    vectors up to sign -- on graded triangular factors like the one svd_lowrank's range finder leaves."""
+    from sober_amd import _native as nat
+    rng = np.random.default_rng(11)
+    for q, decay in ((99, 5.0), (9, 3.0), (128, 7.0), (30, 0.0), (2, 1.0), (1, 0.0)):
+        Y = rng.standard_normal((4 * q + 3, q)) @ np.diag(np.logspace(0, -decay, q))
+        T = np.linalg.cholesky(Y.T @ Y)                                 # lower triangular, graded
+        Ud = torch.empty(q, q, dtype=torch.float64, device=dev)
+        sg = torch.empty(q, dtype=torch.float64, device=dev)
+        sw = torch.zeros(1, dtype=torch.int32, device=dev)
+        nat.jacobi_left(_t(T).to(dev), Ud, sg, sw)
+        Ur, sr, _ = np.linalg.svd(T)
+        U, sgh = Ud.cpu().numpy(), sg.cpu().numpy()
+        assert 0 < int(sw.item()) < 30, int(sw.item())                   # converged, not cut off
+        np.testing.assert_allclose(sgh, sr, rtol=1e-12)
+        np.testing.assert_allclose(U.T @ U, np.eye(q), atol=1e-13)
+        np.testing.assert_allclose(np.abs(np.sum(U * Ur, axis=0)), np.ones(q), atol=1e-9)    # same vectors up to sign
+
+
 def test_trsm_blocks(dev):
     """Q = Y L^-T from the inverted diagonal blocks of the blocked Cholesky vs. numpy's triangular solve."""
     from sober_amd import _native as nat
