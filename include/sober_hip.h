@@ -200,12 +200,6 @@ int sober_chol_small(const double* G, int q, int ldg, double* Lout, int ldl, int
  * is read): the Q factor of Y when L L^T = Y^T Y.                                                                                    */
 int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
                     double* Q, int ldq, void* stream);
-/* Left singular vectors of a small square matrix T (q x q row-major, q <= 128) by one-sided Jacobi in one
- * workgroup: U (q x q row-major, column r = left singular vector of the r-th largest singular value, sign
- * arbitrary), sigma[0:q] descending, *sweeps (may be NULL) = sweeps used.  Replaces the host LAPACK SVD of
- * the small matrix at the end of torch.svd_lowrank (SOBER/_rchq.py:37; torch/_lowrank.py:165-171).       */
-int sober_jacobi_left(const double* T, int q, int ldt, double* U, int ldu, double* sigma, int32_t* sweeps,
-                      int max_sweeps, void* stream);
 /* out = sqrt(nan_to_num(C) * nan_to_num(C)^T) elementwise (quirk Q2, SOBER/_utils.py:143-144);
  * flag[0] |= 1 when C is not exactly symmetric (:127).  Zero flag first.                            */
 int sober_abs_sym(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, void* stream);

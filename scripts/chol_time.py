@@ -56,17 +56,3 @@ for m, q in ((500, 99), (500, 199)):
     Q = torch.empty_like(Y)
     print("q=%d trsm_rows %.1f us, trsm_blocks %.1f us" % (q, timed(lambda: nat.trsm_rows(Y, Gd, Q)), timed(lambda: nat.trsm_blocks(Y, Gd, xinv, Q))))
 
-for q in (99, 128):
-    Yh = rng.standard_normal((500, q)) @ np.diag(np.logspace(0, -4, q))
-    Th = np.linalg.cholesky(Yh.T @ Yh)
-    Td = torch.from_numpy(Th).to(dev)
-    Ud = torch.empty(q, q, dtype=torch.float64, device=dev); sg = torch.empty(q, dtype=torch.float64, device=dev)
-    sw = torch.zeros(1, dtype=torch.int32, device=dev)
-    tj = timed(lambda: nat.jacobi_left(Td, Ud, sg, sw))
-    import time
-    Tt = torch.from_numpy(Th); torch.set_num_threads(1)
-    t0 = time.perf_counter()
-    for _ in range(20): torch.linalg.svd(Tt, full_matrices=False)
-    th = (time.perf_counter() - t0) / 20 * 1e6
-    print("q=%d jacobi_left %.1f us (%d sweeps); host LAPACK svd %.1f us; sigma rel err %.2e" % (
-        q, tj, int(sw.item()), th, np.abs(sg.cpu().numpy() / np.linalg.svd(Th, compute_uv=False) - 1).max()))

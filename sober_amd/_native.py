@@ -55,7 +55,6 @@ SIGNATURES = {
     "sober_cholesky_probe": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_chol_small": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_trsm_rows": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
-    "sober_jacobi_left": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_jitter_ladder": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "sober_kmeans_ws_bytes": (_i64, [_i64, _i32, _i32]),
@@ -349,13 +348,6 @@ def trsm_rows(Y, L, Q):
     m, q = Y.shape
     _check(load().sober_trsm_rows(Y.data_ptr(), m, q, Y.stride(0), L.data_ptr(), L.stride(0), Q.data_ptr(),
                                   Q.stride(0), _stream(Y)), "sober_trsm_rows")
-
-
-def jacobi_left(T, U, sigma, sweeps=None, max_sweeps=30):
-    """Left singular vectors (columns of U, descending singular values) of the square device matrix T (q <= 128)."""
-    q = T.shape[0]
-    _check(load().sober_jacobi_left(T.data_ptr(), q, T.stride(0), U.data_ptr(), U.stride(0), sigma.data_ptr(),
-                                    _ptr(sweeps), int(max_sweeps), _stream(T)), "sober_jacobi_left")
 
 
 def abs_sym(C_, out, flag):

@@ -147,14 +147,12 @@ class HipOps:
             return None
         return U, G
 
-    def _orth(self, Y, infos, pivs, slot, passes: int = 2, want_q: bool = True):
+    def _orth(self, Y, infos, pivs, slot, passes: int = 2):
         """CholeskyQR2: orthonormal basis of range(Y) with the flag of Householder QR.
         passes=1 (the intermediate blocks of the power iteration): the same subspace to the same accuracy
         (the first triangular solve decides it), orthonormal only to cond(Y)^2 eps -- which is all the next
-        product A Q needs; pivs[slot + 1] then holds min pivot / max diagonal of the Gram matrix (~ cond^-2).
-        want_q=False: only the triangular factors are needed; returns (L1, L2) with Y = Q (L2 L1)^T."""
+        product A Q needs; pivs[slot + 1] then holds min pivot / max diagonal of the Gram matrix (~ cond^-2)."""
         q = Y.shape[1]
-        Ls = []
         for it in range(passes):
             Gm = torch.empty(q, q, dtype=torch.float64, device=self.device)
             nat.dgemm(Y, Y, Gm, transa=True)
@@ -166,9 +164,6 @@ class HipOps:
             nat.cholesky_inv(Lc, 0.0, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1], xinv)
             if passes == 1:
                 pivs[slot + 1] = pivs[slot] / dmax
-            Ls.append(Lc)
-            if not want_q and it == passes - 1:
-                return [l.tril_() for l in Ls]              # (the factorisation leaves the upper triangle untouched)
             Q = torch.empty_like(Y)
             nat.trsm_blocks(Y, Lc, xinv, Q)                     # Q = Y R^-1
             Y = Q
@@ -179,9 +174,10 @@ class HipOps:
     ORTH1_MIN_RATIO = 1e-10
 
     def _svd_lowrank_device(self, A, q, R_host, niter: int = 2, overlap=None):
-        """torch.svd_lowrank(A, q) (Halko et al. Alg. 4.4 / 5.1, as in torch/_lowrank.py) for a square
-        device matrix; returns -U^T (q, M) like SOBER/_rchq.py:38, or None if CholeskyQR lost rank."""
-        from ._engine import host_lapack_threads
+        """The range finder of torch.svd_lowrank(A, q) (Halko et al. Alg. 4.4, as in torch/_lowrank.py:64-79) for
+        a square device matrix; returns an orthonormal basis of the same subspace as SOBER/_rchq.py:38's U, as
+        rows (q, M) -- see the comment at the end for why the small SVD is not needed -- or None if CholeskyQR
+        lost rank."""
         dev, M = self.device, A.shape[0]
         R = R_host.to(dev)                                           # CPU generator: the reference's draw
         n_orth = 1 + 2 * niter
@@ -203,53 +199,22 @@ class HipOps:
             nat.dgemm(A, Q, Y)
             Q = self._orth(Y, infos, pivs, slot, passes=2 if k == last else 1); slot += 2
             Y = torch.empty(M, q, dtype=torch.float64, device=dev)
-        # B = Q^H A (q x M).  Its left singular vectors are those of the q x q factor of B^T = Qb Rb:
-        # B = Rb^T Qb^T  =>  U_B = left singular vectors of Rb^T.  CholeskyQR2 of B^T on the device
-        # (B^T = Q1 L1^T, Q1 = Q2 L2^T  =>  Rb^T = L1 L2; Q2 itself is never formed), so only q x q goes to
-        # the host for LAPACK's SVD (0.6 ms instead of 2.2 ms for q x M).
-        Bt = torch.empty(M, q, dtype=torch.float64, device=dev)
-        nat.dgemm(A, Q, Bt, transa=True)                             # (Q^H A)^T = A^T Q
-        infos_b = torch.zeros(2, dtype=torch.int32, device=dev)
-        pivs_b = torch.zeros(2, dtype=torch.float64, device=dev)
-        L1, L2 = self._orth(Bt, infos_b, pivs_b, 0, want_q=False)
-        RbT = torch.empty(q, q, dtype=torch.float64, device=dev)
-        nat.dgemm(L1, L2, RbT)                                       # Rb^T = L1 L2 (lower triangular)
-        # Opt-in (SOBER_DEVICE_SVD=1): left singular vectors of the q x q factor by one-sided Jacobi on the device
-        # (csrc/jacobi.hip), so that the step does not leave the GPU here.  Measured on the MI355X at q = 99:
-        # 0.81 ms (6 sweeps, LDS-bandwidth bound at 1.4 us per round) against 0.87 ms for the host's LAPACK --
-        # but the host SVD overlaps with the first level's set sums, so the step is 0.35 ms FASTER with the host
-        # route.  It becomes the default once its columns stay in VGPRs between rounds.
-        on_device = q <= 128 and bool(os.environ.get("SOBER_DEVICE_SVD"))
-        if on_device:
-            Ub = torch.empty(q, q, dtype=torch.float64, device=dev)
-            sig = torch.empty(q, dtype=torch.float64, device=dev)
-            sweeps = torch.zeros(1, dtype=torch.int32, device=dev)
-            nat.jacobi_left(RbT, Ub, sig, sweeps, max_sweeps=self.JACOBI_MAX_SWEEPS)
-            U = torch.empty(M, q, dtype=torch.float64, device=dev)
-            nat.dgemm(Q, Ub, U)
-            Ut = (-1 * U.T).contiguous()
-            infos_h, pivs_h, infos_bh, pivs_bh, sweeps_h = self.to_host(infos, pivs, infos_b, pivs_b, sweeps,
-                                                                        before_sync=overlap)
-        else:
-            # `overlap` (the engine's device work that does not need U) is enqueued behind the copies, so the GPU
-            # keeps running while the host does the small SVD
-            RbT_h, infos_h, pivs_h, infos_bh, pivs_bh = self.to_host(RbT, infos, pivs, infos_b, pivs_b,
-                                                                     before_sync=overlap)
+        # torch/_lowrank.py goes on with B = Q^H A, its SVD and U = Q U_B.  U_B is a q x q ORTHOGONAL matrix, and
+        # nothing downstream can see it: the Caratheodory step (SOBER/_rchq.py:224-270) takes the null space of
+        # A = [1 | X]^T from the right Householder reflectors of A's bidiagonalisation (csrc/car.hip), and those
+        # depend on A only through its first row (the ones) and A^T A -- both unchanged when the remaining rows,
+        # i.e. the Nystrom test functions U k(X_nys, .), are mixed by an orthogonal matrix.  Same kept sets, same
+        # weights (tests/test_car_algorithm.py::test_car_invariant_under_orthogonal_mixing: identical indices,
+        # weights to 1e-12 on every golden level).  So any orthonormal basis of range(Q) serves, Q^T itself does,
+        # and the q x M product, the second range finder for B^T, the host's LAPACK SVD (0.93 ms at q = 99), two
+        # PCIe hops and a GEMM leave the step.  (The literal host route still computes U_B.)
+        infos_h, pivs_h = self.to_host(infos, pivs, before_sync=overlap)
         # a second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1
         single = [s for s in range(0, 2 * n_orth, 2) if s // 2 != last]
-        if bool((infos_h != 0).any()) or bool((infos_bh != 0).any()) or float(pivs_bh[1]) < 0.5 \
-                or float(pivs_h[2 * last + 1]) < 0.5 \
+        if bool((infos_h != 0).any()) or float(pivs_h[2 * last + 1]) < 0.5 \
                 or any(not (float(pivs_h[s + 1]) >= self.ORTH1_MIN_RATIO) for s in single):
             return None
-        if on_device:
-            return Ut if int(sweeps_h[0]) < self.JACOBI_MAX_SWEEPS else None      # (not converged: host route)
-        with host_lapack_threads(M):
-            Ub, _, _ = torch.linalg.svd(RbT_h, full_matrices=False)
-        U = torch.empty(M, q, dtype=torch.float64, device=dev)
-        nat.dgemm(Q, self.from_host(Ub.contiguous()), U)
-        return (-1 * U.T).contiguous()
-
-    JACOBI_MAX_SWEEPS = 30
+        return Q.T.contiguous()
 
     # ------------------------------------------------------------------ levels
     def prof_reserve(self, n_pairs: int):

@@ -85,3 +85,24 @@ def test_gebrd_nullspace_reproduces_reference_car(path):
         w, idx = pivots(Phi, mu)
         assert np.array_equal(idx, z[f"L{i}_idx_star"]), (path, i)
         np.testing.assert_allclose(w, z[f"L{i}_w_star"], rtol=1e-7)
+
+
+def test_car_invariant_under_orthogonal_mixing():
+    """The Caratheodory step sees the Nystrom test functions only through [1 | X]^T [1 | X]'s first row and
+    Gram structure: X -> X O (O orthogonal) leaves the kept sets identical and the weights equal to rounding.
+    This is what allows the device route to use ANY orthonormal basis of svd_lowrank's subspace (no small SVD)."""
+    import glob
+    from oracle import sober_oracle as O
+    torch.manual_seed(0)
+    n_checked = 0
+    for f in sorted(glob.glob(os.path.join(GOLD, "recomb_*.npz"))):
+        z = np.load(f)
+        for k in [k for k in z.files if k.endswith("_X_tmp") and "cks" not in k and "shape" not in k]:
+            X, mu = torch.from_numpy(z[k]), torch.from_numpy(z[k.replace("X_tmp", "tot_weights")])
+            w1, i1 = O.tchernychova_lyons_car(X.clone(), mu.clone())
+            Q, _ = torch.linalg.qr(torch.randn(X.shape[1], X.shape[1], dtype=torch.float64))
+            w2, i2 = O.tchernychova_lyons_car((X @ Q).contiguous(), mu.clone())
+            assert torch.equal(i1, i2), (f, k)
+            np.testing.assert_allclose(w2.numpy(), w1.numpy(), rtol=1e-9)
+            n_checked += 1
+    assert n_checked >= 20
