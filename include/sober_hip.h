@@ -207,6 +207,11 @@ int sober_abs_sym(const double* C, int n, int ld, double* out, int ldo, int32_t*
 /* k rungs of make_cov_psd's jitter ladder (SOBER/_utils.py:151-152) with the reference's sequence of
  * roundings: jitter = 1e-5; repeat k times { diag(A) += jitter; jitter *= 2 }.                        */
 int sober_jitter_ladder(double* A, int n, int ld, int k, void* stream);
+/* The same with k taken on the device from sober_cholesky_probe's info[0:n_rungs]: k = first rung that is
+ * positive definite; if none is, all n_rungs additions are made and A is reduced to its diagonal
+ * (`cov.diag().diag()`, :153-156); *k_out = k.                                                             */
+int sober_jitter_ladder_auto(double* A, int n, int ld, const int32_t* info, int n_rungs, int32_t* k_out,
+                             void* stream);
 
 /* KMeans of SOBER/_weights.py:100-126: Lloyd, centroids initialised to the first K rows, exactly
  * `iters` iterations, first-index argmin (a NaN distance wins like torch.argmin), empty cluster ->

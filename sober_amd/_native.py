@@ -57,6 +57,7 @@ SIGNATURES = {
     "sober_trsm_rows": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_jitter_ladder": (_i32, [_vp, _i32, _i32, _i32, _vp]),
+    "sober_jitter_ladder_auto": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_kmeans_ws_bytes": (_i64, [_i64, _i32, _i32]),
     "sober_kmeans_lloyd": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "sober_predict_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f64, _vp, _f64, _f64, _vp, _f64, _vp, _i32, _vp]),
@@ -419,6 +420,11 @@ def level_car(job: LevelJob, stream: int):
 def record_event_pair(ev0, ev1, stream: int):
     """torch.cuda.Event pair (already recorded once, so that their handles exist) re-recorded back to back."""
     _check(load().sober_record_event_pair(ev0.cuda_event, ev1.cuda_event, stream), "sober_record_event_pair")
+
+
+def jitter_ladder_auto(A, info, k_out):
+    _check(load().sober_jitter_ladder_auto(A.data_ptr(), A.shape[0], A.stride(0), info.data_ptr(), info.numel(),
+                                           k_out.data_ptr(), _stream(A)), "sober_jitter_ladder_auto")
 
 
 def jitter_ladder(A, k):

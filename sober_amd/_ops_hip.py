@@ -120,31 +120,35 @@ class HipOps:
         G = self.gram(p)
         if M > nat.chol_max_n() or s > 256 or s >= M:
             return None
-        flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        C = torch.empty_like(G)
-        nat.abs_sym(G, C, flag)
-        if int(flag.item()) == 0:
-            return None                                    # symmetric input: is_psd(cov) itself has to run
-        warnings.warn("Estimated covariance matrix was not positive semi-definite. Conveting...")
-        # every rung of the ladder (after k = 0 .. max_iter jitter additions) is probed at once: one
-        # workgroup per rung, one launch; the CPU draws svd_lowrank's randn meanwhile (it is the next
-        # consumer of the generator in the reference too: make_cov_psd draws nothing)
+        # everything up to the basis is enqueued without a host decision in between: the symmetry flag of the input
+        # and the rung the ladder took are read back together with the range finder's health flags at the end
         n_r = max_iter + 1
-        shifts = torch.tensor([1e-5 * (2 ** k - 1) for k in range(n_r)], dtype=torch.float64, device=dev)
-        info = torch.zeros(n_r, dtype=torch.int32, device=dev)
+        flags = torch.zeros(2 + n_r, dtype=torch.int32, device=dev)      # [0] not symmetric, [1] rung taken, [2:] info
+        C = torch.empty_like(G)
+        nat.abs_sym(G, C, flags[:1])
+        # every rung of the ladder (after k = 0 .. max_iter jitter additions) is probed at once: one
+        # workgroup per rung, one launch; the first positive definite rung is applied on the device with the
+        # reference's own sequence of diagonal additions -- or, when none is, the diagonal fallback
+        # (SOBER/_utils.py:150-156)
+        key = ("shifts", n_r)
+        shifts = self._pin.get(key)
+        if shifts is None:
+            shifts = self._pin[key] = torch.tensor([1e-5 * (2 ** k - 1) for k in range(n_r)], dtype=torch.float64,
+                                                   device=dev)
         work = self._buf(p, "chol_work", n_r * M * M)
-        nat.cholesky_probe(C, shifts, work, info)
+        nat.cholesky_probe(C, shifts, work, flags[2:])
+        nat.jitter_ladder_auto(C, flags[2:], flags[1:2])
+        # svd_lowrank's randn comes from the CPU generator (it is the next consumer of the generator in the
+        # reference too: make_cov_psd draws nothing), drawn while the probes run.  Should the input turn out
+        # exactly symmetric (is_psd(cov) itself has to run, on the host) or the range finder lose rank, the
+        # generator is put back and the literal host route decides.
+        rng_state = torch.get_rng_state()
         R = torch.randn(M, s, dtype=torch.float64)
-        (info_h,) = self.to_host(info)
-        ok = (info_h == 0).tolist()
-        k_first = ok.index(True) if any(ok) else max_iter + 1
-        # SOBER/_utils.py:150-156: k_first additions (max_iter + 1 of them before the diagonal fallback), one launch
-        nat.jitter_ladder(C, k_first)
-        if k_first > max_iter:
-            C = torch.diag(C.diagonal().clone())           # :155
-        U = self._svd_lowrank_device(C, s, R, overlap=overlap)
-        if U is None:
+        U, flags_h = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=flags)
+        if int(flags_h[0]) == 0 or U is None:
+            torch.set_rng_state(rng_state)                 # the host route draws the same randn again
             return None
+        warnings.warn("Estimated covariance matrix was not positive semi-definite. Conveting...")
         return U, G
 
     def _orth(self, Y, infos, pivs, slot, passes: int = 2):
@@ -173,7 +177,7 @@ class HipOps:
     # matrix (~ cond(Y)^-2) stays above this: orthonormality then holds to ~1e-6 and the subspace to eps cond(Y)
     ORTH1_MIN_RATIO = 1e-10
 
-    def _svd_lowrank_device(self, A, q, R_host, niter: int = 2, overlap=None):
+    def _svd_lowrank_device(self, A, q, R_host, niter: int = 2, overlap=None, extra=None):
         """The range finder of torch.svd_lowrank(A, q) (Halko et al. Alg. 4.4, as in torch/_lowrank.py:64-79) for
         a square device matrix; returns an orthonormal basis of the same subspace as SOBER/_rchq.py:38's U, as
         rows (q, M) -- see the comment at the end for why the small SVD is not needed -- or None if CholeskyQR
@@ -208,13 +212,18 @@ class HipOps:
         # weights to 1e-12 on every golden level).  So any orthonormal basis of range(Q) serves, Q^T itself does,
         # and the q x M product, the second range finder for B^T, the host's LAPACK SVD (0.93 ms at q = 99), two
         # PCIe hops and a GEMM leave the step.  (The literal host route still computes U_B.)
-        infos_h, pivs_h = self.to_host(infos, pivs, before_sync=overlap)
+        if extra is None:
+            infos_h, pivs_h = self.to_host(infos, pivs, before_sync=overlap)
+            extra_h = None
+        else:
+            infos_h, pivs_h, extra_h = self.to_host(infos, pivs, extra, before_sync=overlap)
         # a second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1
         single = [s for s in range(0, 2 * n_orth, 2) if s // 2 != last]
         if bool((infos_h != 0).any()) or float(pivs_h[2 * last + 1]) < 0.5 \
                 or any(not (float(pivs_h[s + 1]) >= self.ORTH1_MIN_RATIO) for s in single):
-            return None
-        return Q.T.contiguous()
+            return (None, extra_h) if extra is not None else None
+        Ut = Q.T.contiguous()
+        return (Ut, extra_h) if extra is not None else Ut
 
     # ------------------------------------------------------------------ levels
     def prof_reserve(self, n_pairs: int):

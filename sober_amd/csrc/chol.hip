@@ -504,6 +504,26 @@ __global__ void k_jitter_ladder(double* __restrict__ A, int n, int ld, int k) {
     A[(size_t)i * ld + i] = d;
 }
 
+// the same ladder with the rung chosen ON THE DEVICE from the probe's verdicts: k = index of the first rung with
+// info == 0; when none of the n_rungs is positive definite, all n_rungs additions are made and the matrix is
+// reduced to its diagonal -- `cov = cov.diag().diag()` of SOBER/_utils.py:153-156 (n_iter > max_iter).
+// *k_out = k.  No host decision between the probe and the range finder.
+__global__ void k_jitter_ladder_auto(double* __restrict__ A, int n, int ld, const int32_t* __restrict__ info,
+                                     int n_rungs, int32_t* __restrict__ k_out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    int k = 0;
+    while (k < n_rungs && info[k] != 0) ++k;               // (uniform)
+    if (i == 0 && j == 0) *k_out = k;
+    if (j >= n) return;
+    if (i == j) {
+        double d = A[(size_t)i * ld + i], jit = 1e-5;
+        for (int t = 0; t < k; ++t) { d = __dadd_rn(d, jit); jit = __dmul_rn(jit, 2.0); }
+        A[(size_t)i * ld + i] = d;
+    } else if (k == n_rungs) {
+        A[(size_t)i * ld + j] = 0.0;
+    }
+}
+
 }  // namespace sober
 
 extern "C" int sober_chol_max_n(void) { return sober::CH_MAXN; }
@@ -612,6 +632,15 @@ extern "C" int sober_jitter_ladder(double* A, int n, int ld, int k, void* stream
     if (!A || n <= 0 || ld < n || k < 0) return SOBER_E_ARG;
     if (k == 0) return 0;
     hipLaunchKernelGGL(sober::k_jitter_ladder, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, n, ld, k);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_jitter_ladder_auto(double* A, int n, int ld, const int32_t* info, int n_rungs, int32_t* k_out,
+                                        void* stream) {
+    if (!A || !info || !k_out || n <= 0 || ld < n || n_rungs <= 0) return SOBER_E_ARG;
+    hipLaunchKernelGGL(sober::k_jitter_ladder_auto, dim3((n + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, A, n,
+                       ld, info, n_rungs, k_out);
     LAUNCH_CHECK();
     return 0;
 }
