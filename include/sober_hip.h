@@ -295,7 +295,7 @@ typedef struct sober_level_job {
                                                    launch (ev[0], ev[1]) and the leftover launch (ev[2], ev[3]) */
     /* per level */
     const int32_t* idx; int64_t pos0, count, E;
-    const double* mu;
+    double* mu;                                 /* read by the set sums; rescaled by sober_level_loop's updates */
     int32_t phase;                              /* sober_level_moments: 0 = everything, 1 = set sums only (up to G, tot),
                                                    2 = projection only (Xtr = P G).  The set sums of the first level do
                                                    not depend on the Nystrom basis: they run while the host still works
@@ -303,6 +303,18 @@ typedef struct sober_level_job {
 } sober_level_job;
 int sober_level_moments(const sober_level_job* job, void* stream);
 int sober_level_car(const sober_level_job* job, void* stream);
+/* The whole halving loop of an UNSHARDED pool (SOBER/_rchq.py:116-221, repeated while R > S) in one call: per level
+ * sober_level_moments, sober_level_car, a stream synchronisation (the host has to know how many sets survived
+ * before it can size the next level), sober_level_update, buffer swap -- without a round trip through the host
+ * language between them.  idx_a holds the R live positions on entry, idx_b is the other half of the ping-pong.
+ * first_sums_ready != 0: the set sums of the first level are already in job->G / job->tot (phase 1 was run by the
+ * caller).  events: NULL or 4 hipEvent_t per level (see job->ev).  Outputs: level_R[l] = live positions at level l,
+ * *n_levels, *R_final (<= S), *in_b = 1 when the final live list is in idx_b.  Returns SOBER_E_NOPROGRESS when a
+ * level cancels nothing (the reference would loop forever, :241-242), SOBER_E_WS when max_levels is too small.  */
+#define SOBER_E_NOPROGRESS -4
+int sober_level_loop(sober_level_job* job, int64_t R, int32_t* idx_a, int32_t* idx_b, int first_sums_ready,
+                     void** events, int max_levels, int64_t* level_R, int32_t* n_levels, int64_t* R_final,
+                     int32_t* in_b, void* stream);
 /* ev0, ev1 (hipEvent_t) recorded back to back: the empty bracket, for calibrating the ev[] timings.       */
 int sober_record_event_pair(void* ev0, void* ev1, void* stream);
 

@@ -296,6 +296,13 @@ class RecombinationEngine:
 
         if self.trace is not None:
             self.trace["levels"] = levels
+        if comm.world == 1 and obj is None and levels is None and not self.force_host_car and R > S \
+                and getattr(ops, "level_loop", None) is not None and ops.car_supported(S, n + 1):
+            # unsharded pool, on-chip Caratheodory step: the whole loop below runs inside the level executor
+            t0 = time.perf_counter()
+            idx_cur, idx_new, R = ops.level_loop(plan, idx_cur, idx_new, R, S, mu, sums_ready)
+            pos0, count, bounds, sums_ready = 0, R, [0, R], False
+            self._tick("levels_device", t0)
         while True:
             if R <= n + 1:                                  # :72-75
                 return self._finish_small(mu)

@@ -70,6 +70,7 @@ SIGNATURES = {
     "sober_level_moments": (_i32, [_vp, _vp]),
     "sober_level_car": (_i32, [_vp, _vp]),
     "sober_record_event_pair": (_i32, [_vp, _vp, _vp]),
+    "sober_level_loop": (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 
 LEVEL_VALU, LEVEL_MFMA, LEVEL_GATHER = 0, 1, 2
@@ -415,6 +416,27 @@ def level_moments(job: LevelJob, stream: int):
 
 def level_car(job: LevelJob, stream: int):
     _check(load().sober_level_car(C.addressof(job), stream), "sober_level_car")
+
+
+E_NOPROGRESS = -4
+MAX_LEVELS = 64
+
+
+def level_loop(job: LevelJob, R: int, idx_a, idx_b, first_sums_ready: bool, events, stream: int):
+    """sober_level_loop: -> (level_R list, R_final, final list is idx_b?).  events: None or a flat list of
+    4 * MAX_LEVELS hipEvent_t handles (None entries allowed)."""
+    level_R = (_i64 * MAX_LEVELS)()
+    n_levels, in_b, R_final = _i32(0), _i32(0), _i64(0)
+    ev = None
+    if events is not None:
+        ev = (_vp * (4 * MAX_LEVELS))(*events)
+    rc = load().sober_level_loop(C.addressof(job), R, idx_a.data_ptr(), idx_b.data_ptr(), int(bool(first_sums_ready)),
+                                 ev, MAX_LEVELS, level_R, C.byref(n_levels), C.byref(R_final), C.byref(in_b), stream)
+    if rc == E_NOPROGRESS:
+        raise RuntimeError("recombination made no progress (the Caratheodory step cancelled nothing, "
+                           "SOBER/_rchq.py:241-242); the reference would loop forever here")
+    _check(rc, "sober_level_loop")
+    return list(level_R[:n_levels.value]), int(R_final.value), bool(in_b.value)
 
 
 def record_event_pair(ev0, ev1, stream: int):

@@ -341,6 +341,37 @@ class HipOps:
                 job.ev[k] = None
         return p.ws["Xtr"], p.ws["tot"]
 
+    def level_loop(self, p: Plan, idx_cur, idx_new, R: int, S: int, mu, sums_ready: bool):
+        """The whole halving loop of an unsharded pool while R > S (SOBER/_rchq.py:116-221) in ONE call of the
+        level executor (csrc/level_exec.cpp: sober_level_loop) -- no trip through Python between a level's
+        verdict and the next level's launches.  Returns (idx_cur, idx_new, R) for the terminal branch."""
+        import math
+        job = self._job(p, S)
+        nat._req(mu, torch.float64, "mu"); nat._req(idx_cur, torch.int32, "idx"); nat._req(idx_new, torch.int32, "idx")
+        job.mu = mu.data_ptr()
+        events = pairs = None
+        if self.prof is not None:
+            n_max = min(nat.MAX_LEVELS, int(math.log2(max(R / S, 1.0))) + 3)
+            pairs = [(self._prof_pair(), self._prof_pair()) for _ in range(n_max)]
+            events = [None] * (4 * nat.MAX_LEVELS)
+            for l, (a, b) in enumerate(pairs):
+                events[4 * l:4 * l + 4] = [a[0].cuda_event, a[1].cuda_event, b[0].cuda_event, b[1].cuda_event]
+        level_R, R_final, in_b = nat.level_loop(job, R, idx_cur, idx_new, sums_ready, events, nat._stream(mu))
+        if pairs is not None:
+            for l, (a, b) in enumerate(pairs):
+                if l == 0 and sums_ready:                   # (that level's launches were bracketed by the phase-1 call)
+                    self._ev_pool.extend([a, b])
+                elif l < len(level_R):
+                    Rl = level_R[l]
+                    self.prof.append((a[0], a[1], int(Rl * job.n_rows)))
+                    if Rl % S:
+                        self.prof.append((b[0], b[1], int((Rl % S) * job.n_rows)))
+                    else:
+                        self._ev_pool.append(b)
+                else:
+                    self._ev_pool.extend([a, b])
+        return (idx_new, idx_cur, R_final) if in_b else (idx_cur, idx_new, R_final)
+
     def level_flat(self, p: Plan):
         """The projected set sums and the set masses of the last `level_moments` as ONE flat tensor (n*S + S)."""
         return p.ws["XT"]

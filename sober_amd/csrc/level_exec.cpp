@@ -87,6 +87,41 @@ extern "C" int sober_level_car(const sober_level_job* j, void* stream) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, int32_t* idx_b, int first_sums_ready,
+                                void** events, int max_levels, int64_t* level_R, int32_t* n_levels, int64_t* R_final,
+                                int32_t* in_b, void* stream) {
+    if (!j || !idx_a || !idx_b || !level_R || !n_levels || !R_final || !in_b || !j->h_flags || !j->mu || R <= 0)
+        return SOBER_E_ARG;
+    const int S = j->S;
+    int32_t *cur = idx_a, *nxt = idx_b;
+    int levels = 0;
+    while (R > S) {
+        if (levels >= max_levels) return SOBER_E_WS;
+        const int64_t E = R / S, r = R - E * S;
+        j->idx = cur; j->pos0 = 0; j->count = R; j->E = E;
+        j->phase = (levels == 0 && first_sums_ready) ? 2 : 0;
+        for (int k = 0; k < 4; ++k) j->ev[k] = events ? events[4 * levels + k] : nullptr;
+        LX_TRY(sober_level_moments(j, stream));
+        LX_TRY(sober_level_car(j, stream));
+        const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // the host decides the next level's size
+        if (e != hipSuccess) return (int)e;
+        const int n_keep = j->h_flags[S];
+        const bool last_kept = j->h_flags[S - 1] >= 0;
+        const int64_t R_new = E * n_keep + (last_kept ? r : 0);             // :198-221
+        level_R[levels++] = R;
+        if (R_new >= R) { *n_levels = levels; return SOBER_E_NOPROGRESS; }
+        LX_TRY(sober_level_update(cur, 0, R, S, E, j->keep_rank, j->w_star, j->tot, n_keep, j->mu, nxt, 0, stream));
+        int32_t* t = cur; cur = nxt; nxt = t;
+        R = R_new;
+    }
+    for (int k = 0; k < 4; ++k) j->ev[k] = nullptr;
+    j->phase = 0;
+    *n_levels = levels;
+    *R_final = R;
+    *in_b = (cur == idx_b) ? 1 : 0;
+    return 0;
+}
+
 // Two events recorded back to back on the stream: what an empty ev[0]/ev[1] bracket of sober_level_moments
 // measures (the calibration of the caller's kernel timing).
 extern "C" int sober_record_event_pair(void* ev0, void* ev1, void* stream) {
