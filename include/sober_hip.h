@@ -146,6 +146,13 @@ int sober_level_update(const int32_t* idx_cur, int64_t pos0, int64_t count, int 
 int sober_scatter_weights(const int32_t* idx_cur, const int32_t* sel, const double* w, int n_sel,
                           double* mu, int64_t* out_idx, void* stream);
 
+/* out[t] = src[idx[t]], t < n.                                                                       */
+int sober_gather_f64(const double* src, const int32_t* idx, int64_t n, double* out, void* stream);
+/* The same write-back driven by the Caratheodory step's keep_rank[0:n] on the device (no host list): position t
+ * with rank k = keep_rank[t] >= 0 gives mu[idx[t]] = w_star[k], out_idx[k] = idx[t] + row_offset, out_w[k] = w_star[k]. */
+int sober_final_scatter(const int32_t* idx, int n, const int32_t* keep_rank, const double* w_star,
+                        int64_t row_offset, double* mu, int64_t* out_idx, double* out_w, void* stream);
+
 /* idx[p] = p-th index with mu != 0 is the caller's job (torch.nonzero); helper: int64 -> int32.   */
 int sober_i64_to_i32(const int64_t* in, int64_t n, int32_t* out, void* stream);
 
@@ -315,6 +322,14 @@ int sober_level_car(const sober_level_job* job, void* stream);
 int sober_level_loop(sober_level_job* job, int64_t R, int32_t* idx_a, int32_t* idx_b, int first_sums_ready,
                      void** events, int max_levels, int64_t* level_R, int32_t* n_levels, int64_t* R_final,
                      int32_t* in_b, void* stream);
+/* The final direct level of an unsharded pool (n + 1 < R <= S, SOBER/_rchq.py:77-114) in one call: kernel columns of
+ * the R live candidates (sober_pairwise on the SCALED points rows_sc / cand_sc, dt doubles or words per row), P K,
+ * transpose, their weights, the Caratheodory step, mu[0:N] = 0 and the device-side write-back.  K: n_rows x R scratch,
+ * mu_live: R scratch.  out_idx / out_w: R entries, the first n_keep valid; n_keep arrives in job->h_flags[S] (pinned)
+ * once the stream has been synchronised.                                                                        */
+int sober_level_final(const sober_level_job* job, const void* rows_sc, const double* rows_norm, const void* cand_sc,
+                      const double* cand_norm, int dt, const int32_t* idx, int R, int64_t N, int64_t row_offset,
+                      double* K, double* mu_live, int64_t* out_idx, double* out_w, void* stream);
 /* ev0, ev1 (hipEvent_t) recorded back to back: the empty bracket, for calibrating the ev[] timings.       */
 int sober_record_event_pair(void* ev0, void* ev1, void* stream);
 

@@ -435,6 +435,13 @@ class RecombinationEngine:
         counts = [bounds[r + 1] - bounds[r] for r in range(comm.world)]    # known everywhere: no exchange
         count = counts[comm.rank]
         obj = getattr(self, "obj", None)
+        if comm.world == 1 and obj is None and levels is None and not self.force_host_car \
+                and getattr(ops, "level_final", None) is not None:
+            t0 = time.perf_counter()
+            res = ops.level_final(plan, idx_cur, R, 2 * (n + 1), mu, self.row_offset)
+            if res is not None:
+                self._tick("levels_device", t0)
+                return res
         nf = n + (1 if obj is not None else 0)
         if count > 0:
             X_loc = ops.direct_columns(plan, idx_cur, count)           # rows of (U @ K).T  (:78)

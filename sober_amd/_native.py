@@ -70,6 +70,9 @@ SIGNATURES = {
     "sober_level_moments": (_i32, [_vp, _vp]),
     "sober_level_car": (_i32, [_vp, _vp]),
     "sober_record_event_pair": (_i32, [_vp, _vp, _vp]),
+    "sober_gather_f64": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "sober_final_scatter": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "sober_level_final": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sober_level_loop": (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 
@@ -437,6 +440,14 @@ def level_loop(job: LevelJob, R: int, idx_a, idx_b, first_sums_ready: bool, even
                            "SOBER/_rchq.py:241-242); the reference would loop forever here")
     _check(rc, "sober_level_loop")
     return list(level_R[:n_levels.value]), int(R_final.value), bool(in_b.value)
+
+
+def level_final(job: LevelJob, rows, rows_norm, cand, cand_norm, dt, idx, R, N, row_offset, K, mu_live, out_idx,
+                out_w, stream: int):
+    _check(load().sober_level_final(C.addressof(job), rows.data_ptr(), _ptr(rows_norm), cand.data_ptr(),
+                                    _ptr(cand_norm), dt, idx.data_ptr(), int(R), int(N), int(row_offset),
+                                    K.data_ptr(), mu_live.data_ptr(), out_idx.data_ptr(), out_w.data_ptr(), stream),
+           "sober_level_final")
 
 
 def record_event_pair(ev0, ev1, stream: int):

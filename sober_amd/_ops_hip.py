@@ -372,6 +372,28 @@ class HipOps:
                     self._ev_pool.extend([a, b])
         return (idx_new, idx_cur, R_final) if in_b else (idx_cur, idx_new, R_final)
 
+    def level_final(self, p: Plan, idx_cur, R: int, S: int, mu, row_offset: int):
+        """The final direct level of an unsharded pool (n + 1 < R <= S, SOBER/_rchq.py:77-114) without leaving the
+        device: one executor call, one synchronisation (for the number of survivors).  -> (idx int64, w) or None
+        when this plan needs the step-by-step route (weighted mode, resident kernel matrix, size)."""
+        if p.weighted or getattr(p, "Kmat", None) is not None or not nat.car_supported(R, p.n + 1):
+            return None
+        job = self._job(p, S)
+        if not job.car_ws:
+            return None
+        dev, f64 = self.device, torch.float64
+        job.mu = mu.data_ptr()
+        K = self._buf(p, "K_final", job.n_rows * S)
+        mu_live = self._buf(p, "mu_live", S)
+        out_idx = torch.empty(S, dtype=torch.int64, device=dev)
+        out_w = torch.empty(S, dtype=f64, device=dev)
+        st = torch.cuda.current_stream(dev)
+        nat.level_final(job, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, p.rows.dt, idx_cur, R, mu.numel(),
+                        row_offset, K, mu_live, out_idx, out_w, st.cuda_stream)
+        st.synchronize()
+        n_keep = int(p.ws["h_flags_np"][S])
+        return out_idx[:n_keep], out_w[:n_keep]
+
     def level_flat(self, p: Plan):
         """The projected set sums and the set masses of the last `level_moments` as ONE flat tensor (n*S + S)."""
         return p.ws["XT"]

@@ -122,6 +122,30 @@ extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, i
     return 0;
 }
 
+extern "C" int sober_level_final(const sober_level_job* j, const void* rows_sc, const double* rows_norm,
+                                 const void* cand_sc, const double* cand_norm, int dt, const int32_t* idx, int R,
+                                 int64_t N, int64_t row_offset, double* K, double* mu_live, int64_t* out_idx,
+                                 double* out_w, void* stream) {
+    if (!j || !rows_sc || !cand_sc || !idx || !K || !mu_live || !out_idx || !out_w || !j->P || !j->Xtr || !j->X_tmp ||
+        !j->keep_rank || !j->w_star || !j->mu_out || !j->car_ws || !j->h_flags || !j->mu)
+        return SOBER_E_ARG;
+    const int S = j->S, n = j->n;
+    if (R <= n + 1 || R > S || N <= 0) return SOBER_E_ARG;
+    if (!sober_car_supported(R, n + 1)) return SOBER_E_DIM;
+    LX_TRY(sober_pairwise(j->kind, rows_sc, rows_norm, j->n_rows, cand_sc, cand_norm, idx, R, dt, j->outputscale, K, R,
+                          stream));                                                  // kernel(pt_nys, samp[idx])  (:78)
+    LX_TRY(sober_dgemm(0, 0, n, R, j->n_rows, 1.0, j->P, j->n_rows, K, R, 0.0, j->Xtr, R, stream));
+    LX_TRY(sober_barycentres(j->Xtr, R, n, R, nullptr, j->X_tmp, stream));          // (U K)^T, no division
+    LX_TRY(sober_gather_f64(j->mu, idx, R, mu_live, stream));                       // :84
+    LX_TRY(sober_car_device(j->X_tmp, n, R, n + 1, mu_live, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
+                            nullptr, j->car_ws, j->car_ws_bytes, stream));          // :85
+    hipError_t e = hipMemsetAsync(j->mu, 0, sizeof(double) * (size_t)N, (hipStream_t)stream);   // mu[:] = 0  (:109)
+    if (e != hipSuccess) return (int)e;
+    LX_TRY(sober_final_scatter(idx, R, j->keep_rank, j->w_star, row_offset, j->mu, out_idx, out_w, stream));
+    e = hipMemcpyAsync(j->h_flags + S, j->keep_rank + S, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // Two events recorded back to back on the stream: what an empty ev[0]/ev[1] bracket of sober_level_moments
 // measures (the calibration of the caller's kernel timing).
 extern "C" int sober_record_event_pair(void* ev0, void* ev1, void* stream) {

@@ -174,6 +174,30 @@ __global__ void k_scatter_weights(const int32_t* __restrict__ idx_cur, const int
     out_idx[k] = c;
 }
 
+// out[t] = src[idx[t]]  (the weights of the live positions, SOBER/_rchq.py:84)
+__global__ void k_gather_f64(const double* __restrict__ src, const int32_t* __restrict__ idx, int64_t n,
+                             double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = src[idx[t]];
+}
+
+// Final direct level write-back on the device (SOBER/_rchq.py:108-114; mu[:] = 0 is the caller's memset): position t
+// survives iff keep_rank[t] >= 0; its rank k orders the result: mu[idx[t]] = w_star[k], out_idx[k] = idx[t] + row_offset,
+// out_w[k] = w_star[k].
+__global__ void k_final_scatter(const int32_t* __restrict__ idx, int n, const int32_t* __restrict__ keep_rank,
+                                const double* __restrict__ w_star, int64_t row_offset, double* __restrict__ mu,
+                                int64_t* __restrict__ out_idx, double* __restrict__ out_w) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int k = keep_rank[t];
+    if (k < 0) return;
+    const int c = idx[t];
+    const double w = w_star[k];
+    mu[c] = w;
+    out_idx[k] = (int64_t)c + row_offset;
+    out_w[k] = w;
+}
+
 __global__ void k_i64_to_i32(const int64_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) out[t] = (int32_t)in[t];
@@ -429,6 +453,22 @@ extern "C" int sober_scatter_weights(const int32_t* idx_cur, const int32_t* sel,
     if (!idx_cur || !sel || !w || !mu || !out_idx || n_sel <= 0) return SOBER_E_ARG;
     hipLaunchKernelGGL(k_scatter_weights, dim3(nblk(n_sel, 256)), dim3(256), 0, (hipStream_t)stream,
                        idx_cur, sel, w, n_sel, mu, out_idx);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_gather_f64(const double* src, const int32_t* idx, int64_t n, double* out, void* stream) {
+    if (!src || !idx || !out || n <= 0) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_gather_f64, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, n, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_final_scatter(const int32_t* idx, int n, const int32_t* keep_rank, const double* w_star,
+                                   int64_t row_offset, double* mu, int64_t* out_idx, double* out_w, void* stream) {
+    if (!idx || !keep_rank || !w_star || !mu || !out_idx || !out_w || n <= 0) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_final_scatter, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, idx, n, keep_rank, w_star,
+                       row_offset, mu, out_idx, out_w);
     LAUNCH_CHECK();
     return 0;
 }
