@@ -110,6 +110,8 @@ def main():
     ops.prof = []
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
+    import gc
+    gc.collect(); gc.disable()                           # no collector pauses inside the timed region
     per_step = []
     for _ in range(args.steps):
         ts = time.perf_counter()
@@ -117,6 +119,7 @@ def main():
         per_step.append(time.perf_counter() - ts)          # (host clock at return: the result tensors are final)
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
