@@ -191,22 +191,14 @@ int sober_cholesky(double* A, int n, int ld, double shift, int32_t* info, double
  * blocks of L (identity-padded in the last block) -- the operands of sober_trsm_blocks.                       */
 int sober_cholesky_inv(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, double* xinv,
                        void* stream);
-/* Q = Y L^-T like sober_trsm_rows (q <= 256), blocked on the matrix cores with the inverted diagonal blocks of
- * sober_cholesky_inv: block-to-block dependency only.                                                          */
+/* Q[r, 0:q] = Y[r, 0:q] L^-T (L lower triangular q x q, q <= 256: the Q factor of Y when L L^T = Y^T Y), blocked
+ * on the matrix cores with the inverted diagonal blocks of sober_cholesky_inv: block-to-block dependency only.                                                          */
 int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl, const double* Xinv,
                       double* Q, int ldq, void* stream);
 /* All rungs of the jitter ladder in one launch: workgroup b factorises (src + shifts[b] I) in slab b of
  * `work` (n_shifts * n * n doubles) and sets info[b] (0 = positive definite).  src is not modified.     */
 int sober_cholesky_probe(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
                          double* work, int32_t* info, void* stream);
-/* Small SPD G (q <= 128): Cholesky G = L L^T entirely in LDS; Lout receives L (q x q lower
- * triangular, zeros above).  info / min_pivot as above.                                              */
-int sober_chol_small(const double* G, int q, int ldg, double* Lout, int ldl, int32_t* info,
-                     double* min_pivot, void* stream);
-/* Q[r, 0:q] = Y[r, 0:q] R^-1 with R = L^T (L lower triangular q x q, q <= 256; only its lower triangle
- * is read): the Q factor of Y when L L^T = Y^T Y.                                                                                    */
-int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
-                    double* Q, int ldq, void* stream);
 /* out = sqrt(nan_to_num(C) * nan_to_num(C)^T) elementwise (quirk Q2, SOBER/_utils.py:143-144);
  * flag[0] |= 1 when C is not exactly symmetric (:127).  Zero flag first.                            */
 int sober_abs_sym(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, void* stream);

@@ -1,5 +1,5 @@
 """Time the one-workgroup Cholesky kernels: the 11-rung probe of a 500 x 500 Gram, single factorisations at
-n = 99 / 198 / 500, chol_small; with a -DCH_STAMPS build also the per-phase ticks of k_chol."""
+n = 99 / 198 / 500, the blocked TRSM; with a -DCH_STAMPS build also the per-phase ticks of k_chol."""
 import numpy as np, torch, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sober_amd import _native as nat
@@ -42,10 +42,6 @@ for n in (99, 128, 198, 500):
     Wh = W.cpu().numpy()
     err = np.abs(np.tril(Wh) - np.linalg.cholesky(S)).max()
     print("k_chol n=%d: %.1f us (copy %.1f us subtracted), err %.2e, stamps(ticks a/b-inverse/c/d/b-factorisation) %s" % (n, t - tc, tc, err, Wh[0, 8:13].tolist()))
-    if n <= 128:
-        Lc = torch.zeros(n, n, dtype=torch.float64, device=dev)
-        t = timed(lambda: nat.chol_small(Sd, Lc, inf1, piv))
-        print("k_chol_small n=%d: %.1f us, err %.2e" % (n, t, np.abs(Lc.cpu().numpy() - np.linalg.cholesky(S)).max()))
 
 for m, q in ((500, 99), (500, 199)):
     Y = torch.from_numpy(rng.standard_normal((m, q))).to(dev)
@@ -54,5 +50,5 @@ for m, q in ((500, 99), (500, 199)):
     xinv = torch.empty(((q + 31) // 32) * 1024, dtype=torch.float64, device=dev)
     nat.cholesky_inv(Gd, 0.0, inf1, piv, xinv)
     Q = torch.empty_like(Y)
-    print("q=%d trsm_rows %.1f us, trsm_blocks %.1f us" % (q, timed(lambda: nat.trsm_rows(Y, Gd, Q)), timed(lambda: nat.trsm_blocks(Y, Gd, xinv, Q))))
+    print("q=%d trsm_blocks %.1f us" % (q, timed(lambda: nat.trsm_blocks(Y, Gd, xinv, Q))))
 

@@ -53,8 +53,6 @@ SIGNATURES = {
     "sober_cholesky_inv": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
     "sober_trsm_blocks": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sober_cholesky_probe": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
-    "sober_chol_small": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
-    "sober_trsm_rows": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_jitter_ladder": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "sober_jitter_ladder_auto": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
@@ -341,18 +339,6 @@ def cholesky_probe(src, shifts, work, info):
     n = src.shape[0]
     _check(load().sober_cholesky_probe(src.data_ptr(), n, src.stride(0), shifts.data_ptr(), shifts.numel(),
                                        work.data_ptr(), info.data_ptr(), _stream(src)), "sober_cholesky_probe")
-
-
-def chol_small(G, Rinv, info, min_pivot=None):
-    q = G.shape[0]
-    _check(load().sober_chol_small(G.data_ptr(), q, G.stride(0), Rinv.data_ptr(), Rinv.stride(0),
-                                       info.data_ptr(), _ptr(min_pivot), _stream(G)), "sober_chol_small")
-
-
-def trsm_rows(Y, L, Q):
-    m, q = Y.shape
-    _check(load().sober_trsm_rows(Y.data_ptr(), m, q, Y.stride(0), L.data_ptr(), L.stride(0), Q.data_ptr(),
-                                  Q.stride(0), _stream(Y)), "sober_trsm_rows")
 
 
 def abs_sym(C_, out, flag):

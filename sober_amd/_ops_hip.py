@@ -106,15 +106,16 @@ class HipOps:
 
     # ------------------------------------------------------------------ Nystrom basis on the device
     def nystrom_basis_device(self, p: Plan, s: int, max_iter: int = 10, overlap=None):
-        """ker_svd_sparsify (SOBER/_rchq.py:34-39) with the N_nys x N_nys work on the GPU:
-          make_cov_psd: |cov| and the symmetry test in one kernel; the jitter rung is found by bisection
-                        with the one-workgroup Cholesky (PD-ness is monotone in the shift), then the
-                        reference's own sequence of diagonal additions is applied;
-          svd_lowrank : randn from the CPU generator (same draw as the reference); range finder with
-                        MFMA GEMMs + CholeskyQR2; only the q x M matrix B goes to the host for LAPACK's
-                        SVD (2 ms), U = Q U_B back on the device.
+        """ker_svd_sparsify (SOBER/_rchq.py:34-39) with the N_nys x N_nys work on the GPU, no host decision inside:
+          make_cov_psd: |cov| and the symmetry test in one kernel; every rung of the jitter ladder probed by one
+                        launch of the one-workgroup Cholesky; the first positive definite rung (or the diagonal
+                        fallback) applied on the device with the reference's own sequence of additions;
+          svd_lowrank : randn from the CPU generator (same draw as the reference); range finder with MFMA GEMMs
+                        + CholeskyQR on the matrix cores; the result is an orthonormal basis of the reference's
+                        subspace (the final rotation U_B is invisible downstream, see _svd_lowrank_device).
         Returns (U (s, M) on the device, the Gram matrix) or None when the literal host path must decide
-        (exactly symmetric Gram, sizes beyond the kernels, ill-conditioned range finder)."""
+        (exactly symmetric Gram, sizes beyond the kernels, ill-conditioned range finder); the CPU generator is
+        then back where it was."""
         import warnings
         dev, M = self.device, p.M
         G = self.gram(p)

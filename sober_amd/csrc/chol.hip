@@ -275,124 +275,6 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
     }
 }
 
-// Small SPD matrix (q <= 128) entirely in LDS: unblocked right-looking Cholesky with the whole
-// workgroup; writes L (q x q lower triangular, row-major).
-__global__ __launch_bounds__(1024) void k_chol_small(const double* __restrict__ G, int q, int ldg,
-                                                         double* __restrict__ Rinv, int ldr,
-                                                         int32_t* __restrict__ info,
-                                                         double* __restrict__ min_pivot) {
-    extern __shared__ double sm[];
-    const int LDS_ = q + 1;
-    double* L = sm;                      // q x (q+1)
-    __shared__ int s_fail;
-    __shared__ double s_minp;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    if (tid == 0) { s_fail = 0; s_minp = __builtin_inf(); }
-    for (int t = tid; t < q * q; t += nt) {
-        const int i = t / q, j = t % q;
-        L[i * LDS_ + j] = (j <= i) ? G[(size_t)i * ldg + j] : 0.0;
-    }
-    __syncthreads();
-    for (int j = 0; j < q; ++j) {
-        const double djj = L[j * LDS_ + j];
-        if (!(djj > 0.0)) {
-            if (tid == 0) s_fail = j + 1;
-            break;                                            // uniform: every thread read the same value
-        }
-        const double l = sqrt(djj);
-        __syncthreads();                                      // everyone has read d_jj before it changes
-        if (tid == 0) { L[j * LDS_ + j] = l; s_minp = fmin(s_minp, djj); }
-        for (int i = j + 1 + tid; i < q; i += nt) L[i * LDS_ + j] /= l;
-        __syncthreads();
-        // trailing update, lower triangle: element (i, c), j < c <= i; 32 x 32 thread grid, no index division
-        {
-            const int ty = tid >> 5, tx = tid & 31;
-            for (int i = j + 1 + ty; i < q; i += 32) {
-                const double lij = L[i * LDS_ + j];
-                for (int c = j + 1 + tx; c <= i; c += 32)
-                    L[i * LDS_ + c] = fma(-lij, L[c * LDS_ + j], L[i * LDS_ + c]);
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (s_fail == 0) {
-        for (int t = tid; t < q * q; t += nt) {
-            const int i = t / q, j = t % q;
-            Rinv[(size_t)i * ldr + j] = (j <= i) ? L[i * LDS_ + j] : 0.0;      // output: L (lower triangular)
-        }
-    }
-    if (tid == 0) {
-        *info = s_fail;
-        if (min_pivot) *min_pivot = s_minp;
-    }
-}
-
-// Q[r, :] = Y[r, :] R^-1 with R = L^T (L lower, q x q <= 128): ONE WAVE PER ROW.  Forward substitution
-// x_j = (y_j - sum_{k<j} x_k L[j][k]) / L[j][j]; lane l holds x_l and x_{l+64}, the dot product over k is
-// split across the lanes and reduced with DPP; L is staged in LDS once per workgroup.
-__device__ __forceinline__ double trsm_wsum(double v) {
-    int lo, hi;
-#define TS_DPP(CTRL)                                                                   \
-    lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);     \
-    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);     \
-    v += __hiloint2double(hi, lo);
-    TS_DPP(0x128) TS_DPP(0x124) TS_DPP(0x122) TS_DPP(0x121)                            // row_ror 8,4,2,1
-#undef TS_DPP
-    const double a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
-                                      __builtin_amdgcn_readlane(__double2loint(v), 0));
-    const double b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
-                                      __builtin_amdgcn_readlane(__double2loint(v), 16));
-    const double c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32),
-                                      __builtin_amdgcn_readlane(__double2loint(v), 32));
-    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48),
-                                      __builtin_amdgcn_readlane(__double2loint(v), 48));
-    return ((a + b) + c) + d;
-}
-
-template <bool L_IN_LDS>
-__global__ __launch_bounds__(256) void k_trsm_rows(const double* __restrict__ Y, int64_t m, int q, int ldy,
-                                                   const double* __restrict__ L, int ldl,
-                                                   double* __restrict__ Q, int ldq) {
-    extern __shared__ double sl[];                   // q x (q+1) when L_IN_LDS (q <= 128)
-    const int LDL = L_IN_LDS ? q + 1 : ldl;
-    if constexpr (L_IN_LDS) {
-        for (int t = threadIdx.x; t < q * q; t += blockDim.x) {
-            const int i = t / q, j = t % q;
-            sl[i * LDL + j] = (j <= i) ? L[(size_t)i * ldl + j] : 0.0;
-        }
-        __syncthreads();
-    }
-    const double* Lp = L_IN_LDS ? sl : L;            // q <= 256: rows of L straight from L2
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= m) return;                              // whole wave
-    const double* y = Y + r * ldy;
-    double x[4] = {0.0, 0.0, 0.0, 0.0};              // x[lane + 64 t] (0 until solved)
-    double yv[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) yv[t] = (lane + 64 * t < q) ? y[lane + 64 * t] : 0.0;
-    for (int j = 0; j < q; ++j) {
-        const double* lj = Lp + (size_t)j * LDL;     // row j of L; entries right of the diagonal meet x = 0
-        double part = 0.0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (64 * t < q) part = fma(x[t], (lane + 64 * t <= j) ? lj[lane + 64 * t] : 0.0, part);
-        const double dot = trsm_wsum(part);
-        const int jt = j >> 6, jl = j & 63;
-        const double ysel = (jt == 0) ? yv[0] : (jt == 1) ? yv[1] : (jt == 2) ? yv[2] : yv[3];
-        const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ysel), jl),
-                                           __builtin_amdgcn_readlane(__double2loint(ysel), jl));
-        const double xj = (yj - dot) / lj[j];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) x[t] = (lane + 64 * t == j) ? xj : x[t];
-    }
-    double* o = Q + r * ldq;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-        if (lane + 64 * t < q) o[lane + 64 * t] = x[t];
-}
-
 // Q = Y L^-T (the Q factor of CholeskyQR) on the matrix cores, from the INVERTED 32 x 32 diagonal blocks that
 // k_chol leaves behind (xinv): for column block jb
 //     Q_jb = (Y_jb - sum_{kb < jb} Q_kb L[jb][kb]^T) X_jb^T ,      X_jb = L[jb][jb]^-1 ,
@@ -579,43 +461,6 @@ extern "C" int sober_cholesky_probe(const double* src, int n, int ld_src, const 
                                 160 * 1024 - 512));
     hipLaunchKernelGGL(sober::k_chol, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
                        info, (double*)nullptr, src, ld_src, shifts, (double*)nullptr);
-    LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int sober_chol_small(const double* G, int q, int ldg, double* Rinv, int ldr, int32_t* info,
-                                    double* min_pivot, void* stream) {
-    if (!G || !Rinv || !info || q <= 0 || q > 128 || ldg < q || ldr < q) return SOBER_E_ARG;
-    const size_t bytes = (size_t)q * (q + 1) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 512));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(sober::k_chol_small, dim3(1), dim3(1024), bytes, (hipStream_t)stream, G, q, ldg, Rinv, ldr,
-                       info, min_pivot);
-    LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int sober_trsm_rows(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl, double* Q,
-                               int ldq, void* stream) {
-    if (!Y || !L || !Q || m <= 0 || q <= 0 || q > 256 || ldy < q || ldl < q || ldq < q) return SOBER_E_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((m + 3) / 4)), block(256);
-    if (q <= 128) {
-        const size_t bytes = (size_t)q * (q + 1) * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute((const void*)sober::k_trsm_rows<true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(sober::k_trsm_rows<true>, grid, block, bytes, st, Y, m, q, ldy, L, ldl, Q, ldq);
-    } else {
-        hipLaunchKernelGGL(sober::k_trsm_rows<false>, grid, block, 0, st, Y, m, q, ldy, L, ldl, Q, ldq);
-    }
     LAUNCH_CHECK();
     return 0;
 }
