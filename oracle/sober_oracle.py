@@ -676,3 +676,22 @@ def basq_quadrature(X_cand, n_nys, n_res, spec: GPSpec, beta):
     ELML = beta if EML <= 0 else math.log(float(EML)) + beta
     AVLML = float((w @ gspace_kernel(x, x, spec) @ w).abs().log())
     return idx, w, float(ELML), AVLML
+
+
+# --------------------------------------------------------------------------- #
+# dataset path: candidate pruning in front of the recombination (SOBER/_sampler.py:325-349)
+# --------------------------------------------------------------------------- #
+def adaptive_pruning(weights, n_rec, n_nys, thresh=1e-3):
+    """EmpiricalSampler.adaptive_pruning, SOBER/_sampler.py:325-349, statement for statement."""
+    indices = weights.argsort(descending=True)                              # :337
+    try:
+        n_accepted = torch.where(weights[indices] > thresh)[0][-1] + 1       # :339
+        if n_accepted >= n_rec:                                             # :340-345
+            n_pruned = n_rec
+        elif n_nys >= n_accepted:
+            n_pruned = n_nys
+        else:
+            n_pruned = n_accepted
+    except Exception:                                                       # :346-347 (no weight above thresh)
+        n_pruned = n_nys
+    return indices[:n_pruned]                                               # :348-349

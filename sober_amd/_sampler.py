@@ -1,5 +1,8 @@
 """`RecombinationSampler` (SOBER/_sampler.py:11-59): the funnel from `Sober.next_batch` into
-`recombination`."""
+`recombination`; `adaptive_pruning` (SOBER/_sampler.py:325-349): the candidate pruning of the dataset path
+(`sampling_datasets`, :351-382) that sits directly in front of it."""
+import torch
+
 from ._rchq import recombination
 from ._utils import TensorManager
 from ._weights import WeightsStabiliser
@@ -17,3 +20,25 @@ class RecombinationSampler(WeightsStabiliser, TensorManager):
             X_cand, X_nys, batch_size, self.kernel, self.device, self.dtype,
             init_weights=weights, calc_obj=calc_obj)
         return idx_rchq, w_rchq
+
+    def adaptive_pruning(self, weights, n_rec, n_nys, thresh=1e-3):
+        """SOBER/_sampler.py:325-349: keep the heaviest candidates of a dataset prior -- all those with weight
+        > thresh, but at most n_rec and at least n_nys; no weight above thresh -> the n_nys heaviest (the
+        reference's `except` branch).  One device sort; returns the kept indices, heaviest first."""
+        return adaptive_pruning(weights, n_rec, n_nys, thresh)
+
+
+def adaptive_pruning(weights, n_rec, n_nys, thresh=1e-3):
+    indices = weights.argsort(descending=True)
+    above = torch.where(weights[indices] > thresh)[0]
+    if above.numel() == 0:                                 # IndexError in the reference -> n_nys
+        n_pruned = n_nys
+    else:
+        n_accepted = int(above[-1]) + 1
+        if n_accepted >= n_rec:
+            n_pruned = n_rec
+        elif n_nys >= n_accepted:
+            n_pruned = n_nys
+        else:
+            n_pruned = n_accepted
+    return indices[:n_pruned]

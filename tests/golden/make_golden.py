@@ -487,12 +487,42 @@ def gen_basq(ref):
     np.savez_compressed(os.path.join(HERE, "basq.npz"), **out)
 
 
+def gen_pruning(ref):
+    """EmpiricalSampler.adaptive_pruning of SOBER/_sampler.py:325-349 (it does not touch `self`): every branch."""
+    import types
+    for name, names in (("SOBER._prior", ("Uniform", "BinaryPrior", "CategoricalPrior", "MixedBinaryPrior",
+                                          "MixedCategoricalPrior")),
+                        ("SOBER._prior_update", ("update_mixed_prior", "update_binary_prior",
+                                                 "update_categorical_prior", "update_continuous_prior"))):
+        m = types.ModuleType(name)
+        for n in names:
+            setattr(m, n, object)
+        sys.modules[name] = m
+    spec = importlib.util.spec_from_file_location("SOBER._sampler", f"{REF}/_sampler.py")
+    smp = importlib.util.module_from_spec(spec)
+    sys.modules["SOBER._sampler"] = smp
+    spec.loader.exec_module(smp)
+    fn = smp.EmpiricalSampler.adaptive_pruning
+    g = torch.Generator().manual_seed(3)
+    out = {}
+    cases = [("many_above", torch.rand(5000, generator=g, dtype=torch.double), 1000, 100),      # n_accepted >= n_rec
+             ("few_above", torch.rand(5000, generator=g, dtype=torch.double) * 1.02e-3, 1000, 300),   # n_nys >= n_accepted
+             ("between", torch.rand(5000, generator=g, dtype=torch.double) * 1.2e-3, 2000, 100),      # n_accepted kept
+             ("none_above", torch.rand(500, generator=g, dtype=torch.double) * 1e-4, 100, 20)]        # except branch
+    for tag, w, n_rec, n_nys in cases:
+        idx = fn(None, w, n_rec, n_nys)
+        out[f"{tag}_w"], out[f"{tag}_idx"] = w.numpy(), idx.numpy()
+        out[f"{tag}_args"] = np.array([n_rec, n_nys])
+        print(f"pruning {tag}: kept {len(idx)} of {len(w)}")
+    np.savez_compressed(os.path.join(HERE, "pruning.npz"), **out)
+
+
 if __name__ == "__main__":
-    # python make_golden.py [recombination kmeans weights psd tanimoto kernel_calls pi wkde basq]   (default: all)
+    # python make_golden.py [recombination kmeans weights psd tanimoto kernel_calls pi wkde basq pruning]   (default: all)
     ref = load_reference()
     gens = {"recombination": gen_recombination, "kmeans": gen_kmeans, "weights": gen_weights, "psd": gen_psd,
             "tanimoto": lambda ref: gen_tanimoto(), "kernel_calls": gen_kernel_calls, "pi": gen_pi,
-            "wkde": gen_wkde, "basq": gen_basq}
+            "wkde": gen_wkde, "basq": gen_basq, "pruning": gen_pruning}
     for name in (sys.argv[1:] or list(gens)):
         gens[name](ref)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))

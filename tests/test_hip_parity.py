@@ -494,6 +494,18 @@ def test_choleskyqr_and_abs_sym(dev):
     assert int(flag.item()) == 0
 
 
+def test_adaptive_pruning_on_device(dev):
+    """Dataset path, SOBER/_sampler.py:325-349: the device sort keeps the reference's candidates in its order."""
+    z = np.load(os.path.join(GOLD, "pruning.npz"))
+    for tag in sorted({k[:-4] for k in z.files if k.endswith("_idx")}):
+        w = _t(z[f"{tag}_w"]).to(dev)
+        n_rec, n_nys = (int(v) for v in z[f"{tag}_args"])
+        idx = sober_amd.adaptive_pruning(w, n_rec, n_nys)
+        assert idx.is_cuda and np.array_equal(idx.cpu().numpy(), z[f"{tag}_idx"]), tag
+        assert np.array_equal(sober_amd.RecombinationSampler(None).adaptive_pruning(w, n_rec, n_nys).cpu().numpy(),
+                              z[f"{tag}_idx"])
+
+
 def test_trsm_blocks(dev):
     """Q = Y L^-T from the inverted diagonal blocks of the blocked Cholesky vs. numpy's triangular solve."""
     from sober_amd import _native as nat

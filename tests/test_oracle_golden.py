@@ -223,3 +223,17 @@ def test_basq_gspace_matches_reference():
         assert np.array_equal(idx.numpy(), z[f"{tag}_idx"])
         assert np.array_equal(w.numpy(), z[f"{tag}_w"])
         assert ELML == float(z[f"{tag}_ELML"]) and AVLML == float(z[f"{tag}_AVLML"])
+
+
+def test_adaptive_pruning_matches_reference():
+    """Dataset path (SOBER/_sampler.py:325-349): oracle and the product's torch-level mirror vs the reference's
+    own outputs on every branch (weights are distinct, so the sort order is unique)."""
+    import sober_amd
+    z = np.load(os.path.join(GOLD, "pruning.npz"))
+    tags = sorted({k[:-4] for k in z.files if k.endswith("_idx")})
+    assert len(tags) == 4
+    for tag in tags:
+        w = torch.from_numpy(z[f"{tag}_w"])
+        n_rec, n_nys = (int(v) for v in z[f"{tag}_args"])
+        assert np.array_equal(O.adaptive_pruning(w, n_rec, n_nys).numpy(), z[f"{tag}_idx"]), tag
+        assert np.array_equal(sober_amd.adaptive_pruning(w, n_rec, n_nys).numpy(), z[f"{tag}_idx"]), tag
