@@ -16,7 +16,10 @@ CFG = {
                  seed=10, bit_p=0.04, mean_const=0.3),
 }
 out = {}
+ONLY = [a for a in sys.argv[1:] if a in CFG]
 for name, case in CFG.items():
+    if ONLY and name not in ONLY:
+        continue
     if name == "cfg5":                      # 250k x 2048 FP64 = 4 GB on the host: build on the device
         g = torch.Generator(device=dev); g.manual_seed(10)
         X = (torch.rand(case["N"], case["d"], device=dev, generator=g) < 0.04).to(torch.float64)
@@ -44,6 +47,8 @@ for name, case in CFG.items():
                      sum_w=float(w.sum()))
     print(name, out[name], flush=True)
     del X
+if ONLY:
+    sys.exit(0)
 # BASQ quadrature (row f4) at the cfg-2 shape: g-space kernel, per-candidate posterior correction, matrix in HBM
 case = dict(CFG["cfg2"], mean_const=0.15)
 inp = synth(case); spec = build_spec(case, inp)

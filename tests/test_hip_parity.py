@@ -431,6 +431,28 @@ def test_cfg4_rbf_d20_vs_oracle(dev):
     _vs_oracle(O.RBF, "predictive_covariance", 60000, 400, 20, 100, 150, 4, dev, ard=False)
 
 
+@pytest.mark.parametrize("shape", [
+    # (kind, mode, N, M, d, b, n_obs): small odd shapes that walk the branches of the level executor --
+    # leftovers of every kind, R landing exactly on S or n + 1, pools below one level, one-dimensional inputs
+    ("rbf", "predictive_covariance", 417, 60, 3, 7, 25),
+    ("rbf", "predictive_covariance", 1000, 90, 2, 16, 40),          # R halves to exactly 2b several times
+    # (d = 1 is deliberately absent: 90 Nystrom points on a line give a Gram of numerical rank ~10, fewer than the
+    #  15 test functions, and the Caratheodory weights then amplify a 4e-12 input difference to 8e-4 -- same kept
+    #  sets, but no implementation can agree with another to 1e-4 there)
+    ("matern52", "predictive_covariance", 2311, 120, 5, 31, 50),
+    ("rbf", "weighted_predictive_covariance", 1536, 80, 4, 12, 30),
+    ("rbf", "kernel", 999, 70, 2, 9, 20),                            # symmetric Gram: host Nystrom route
+    ("matern52", "predictive_covariance", 45, 30, 3, 11, 15),       # n + 1 < N <= 2b: direct level only
+    ("rbf", "predictive_covariance", 24, 15, 2, 10, 10),            # 2b >= N: direct level, tiny pool
+    ("rbf", "predictive_covariance", 5003, 150, 8, 40, 60),
+    ("rbf", "predictive_covariance", 12800, 100, 6, 50, 50),        # E a power of two at every level, no leftovers
+], ids=lambda s: f"{s[0]}-{s[1][:3]}-N{s[2]}-b{s[5]}")
+def test_odd_shapes_vs_oracle(shape, dev):
+    kind, mode, N, M, d, b, n_obs = shape
+    kinds = {"rbf": O.RBF, "matern52": O.MATERN52}
+    _vs_oracle(kinds[kind], mode, N, M, d, b, n_obs, 100 + N % 7, dev)
+
+
 # --------------------------------------------------------------------------- #
 # Nystrom side on the device: Cholesky, CholeskyQR, |cov|
 # --------------------------------------------------------------------------- #
