@@ -274,22 +274,45 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
 // points -> augmented, centred, scaled rows.  side 1 (pool): [y~, 1, -|y~|^2/2, 0..];
 // side 0 (row table): L * [x~, -|x~|^2/2, 1, 0..] with L = 64/ln2, so that X'.Y' = -|x~ - y~|^2/2 * L is
 // directly the table-exp's scaled argument
-__global__ void k_augment_points(const double* __restrict__ X, int64_t n, int d, int64_t ldx,
-                                 const double* __restrict__ ls, int ls_len,
-                                 const double* __restrict__ center, int side, double* __restrict__ out, int da) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// One 16-lane DPP row per point (lane l holds coordinates l and l + 16: DA <= 32): the row of X is read and the
+// augmented row written as contiguous 128-byte segments, |x~|^2 is an in-row DPP reduction.
+template <int CTRL>
+__device__ __forceinline__ double aug_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(256) void k_augment_points(const double* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                        const double* __restrict__ ls, int ls_len,
+                                                        const double* __restrict__ center, int side,
+                                                        double* __restrict__ out, int da) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l16 = threadIdx.x & 15;
+    const bool live = i < n;
+    const int64_t ir = live ? i : n - 1;
     const double sc = (side == 0) ? 92.33248261689366 : 1.0;
-    double nrm = 0.0;
-    double* o = out + i * da;
-    for (int j = 0; j < d; ++j) {
-        const double v = (X[i * ldx + j] - center[j]) / ls[ls_len == 1 ? 0 : j];
-        o[j] = v * sc;
-        nrm = fma(v, v, nrm);
+    double v[2], nrm = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = l16 + 16 * h, jc = min(j, d - 1);
+        const double x = (X[ir * ldx + jc] - center[jc]) / ls[ls_len == 1 ? 0 : jc];
+        v[h] = (j < d) ? x : 0.0;
+        nrm = fma(v[h], v[h], nrm);
     }
-    o[d + side] = -0.5 * nrm * sc;
-    o[d + 1 - side] = sc;
-    for (int j = d + 2; j < da; ++j) o[j] = 0.0;
+    nrm += aug_dpp<0x128>(nrm);                       // row_ror 8, 4, 2, 1: every lane gets the row total
+    nrm += aug_dpp<0x124>(nrm);
+    nrm += aug_dpp<0x122>(nrm);
+    nrm += aug_dpp<0x121>(nrm);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = l16 + 16 * h;
+        double o = v[h] * sc;
+        if (j == d + side) o = -0.5 * nrm * sc;
+        else if (j == d + 1 - side) o = sc;
+        else if (j >= d) o = 0.0;
+        if (live && j < da) out[i * da + j] = o;
+    }
 }
 
 template <int KIND, int KT>
@@ -322,7 +345,8 @@ extern "C" int sober_augment_points(const double* X, int64_t n, int d, int64_t l
                                     void* stream) {
     if (!X || !lengthscale || !center || !out || n <= 0 || d <= 0 || ldx < d || da < d + 2) return SOBER_E_ARG;
     if ((ls_len != 1 && ls_len != d) || (side != 0 && side != 1)) return SOBER_E_ARG;
-    hipLaunchKernelGGL(k_augment_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, n,
+    if (da > 32) return SOBER_E_DIM;
+    hipLaunchKernelGGL(k_augment_points, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, X, n,
                        d, ldx, lengthscale, ls_len, center, side, out, da);
     LAUNCH_CHECK();
     return 0;
