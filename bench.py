@@ -108,10 +108,10 @@ def main():
         idx, w = step()
     torch.cuda.synchronize()
     ops.prof = []
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
     import gc
     gc.collect(); gc.disable()                           # no collector pauses inside the timed region
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
     per_step = []
     for _ in range(args.steps):
         ts = time.perf_counter()
