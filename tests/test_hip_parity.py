@@ -803,3 +803,64 @@ def test_gspace_materialise_chunks(dev):
     rows = np.r_[0, 1, 32767, 32768, 32769, 65535, 65536, 70000, rng.integers(0, 70001, 40)]
     ref = O.gspace_kernel(_t(Xn), _t(X[rows]), spec).numpy().T
     np.testing.assert_allclose(K[rows].cpu().numpy(), ref, rtol=1e-9, atol=1e-12)     # exp(C) - 1 cancels for small C
+
+
+# --------------------------------------------------------------------------- #
+# the sharded DEVICE path with more than one rank: two (three) processes share the one GPU of the test box and
+# talk through gloo (which carries device tensors through the host) -- every kernel, offset and collective of
+# the N > 1 path runs for real; only the transport differs from RCCL
+# --------------------------------------------------------------------------- #
+def _shard_worker(rank, world, port, name, cuts, outq):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        case, inp, spec, z = load_case(os.path.join(GOLD, f"recomb_{name}.npz"))
+        lo, hi = cuts[rank], cuts[rank + 1]
+        X = _t(inp["X_cand"][lo:hi].copy()).to(dev)
+        mu = _t(inp["mu0"][lo:hi].copy()).to(dev)
+        torch.manual_seed(SEED_CALL + 17 * rank)              # ranks deliberately disagree: U is broadcast
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if rank == 0:
+                torch.manual_seed(SEED_CALL)
+            idx, w = sober_amd.recombination(X, _t(inp["X_nys"]).to(dev), case["b"],
+                                             sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu,
+                                             group=dist.group.WORLD, row_offset=lo)
+        outq.put((rank, idx.cpu().numpy(), w.cpu().numpy(), mu.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,cuts", [
+    ("rbf_medium", [0, 8100, 20000]),             # b = 50: on-chip Caratheodory steps, uneven ranges
+    ("rbf_b30", [0, 700, 1900, 3000]),            # three ranks
+    ("cfg2_rbf", [0, 50000, 100000]),             # BASELINE.json config 2, the shape the 2-GPU bench runs
+])
+def test_sharded_device_path_two_ranks_one_gpu(name, cuts, dev):
+    import socket
+    import torch.multiprocessing as mp
+    z = np.load(os.path.join(GOLD, f"recomb_{name}.npz"))
+    assert cuts[-1] == int(z["N"])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = len(cuts) - 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, name, cuts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    mu_all = np.concatenate([o[3] for o in outs])
+    for rank, idx, w, _ in outs:
+        assert np.array_equal(idx, z["idx"]), (name, rank)           # global indices, every rank
+        np.testing.assert_allclose(w, z["w"], rtol=W_RTOL)
+    nz = np.flatnonzero(mu_all)
+    assert np.array_equal(nz, z["mu_after_idx"])                      # Q3 across the shards
+    np.testing.assert_allclose(mu_all[nz], z["mu_after_val"], rtol=W_RTOL)
