@@ -9,13 +9,13 @@ from ._utils import SafeTensorOperator, TensorManager, Utils
 from ._kernel import Kernel, KernelSpec, spec_from_model
 from ._rchq import rc_kernel_svd, recombination
 from ._weights import KMeans, WeightsStabiliser
-from ._sampler import RecombinationSampler, adaptive_pruning
+from ._sampler import EmpiricalSampler, RecombinationSampler, adaptive_pruning
 from ._pi import PI, predict, predict_mean
 from ._wkde import WeightedKernelDensityEstimation
 from ._basq import GspaceKernel, ScaleMmlt, quadrature as basq_quadrature
 
 __all__ = ["setting_parameters", "TensorManager", "SafeTensorOperator", "Utils", "Kernel", "KernelSpec",
            "spec_from_model", "recombination", "rc_kernel_svd", "WeightsStabiliser", "KMeans",
-           "RecombinationSampler", "adaptive_pruning", "PI", "predict", "predict_mean",
+           "RecombinationSampler", "EmpiricalSampler", "adaptive_pruning", "PI", "predict", "predict_mean",
            "WeightedKernelDensityEstimation", "GspaceKernel", "ScaleMmlt", "basq_quadrature"]
 __version__ = "0.1.0"

@@ -28,6 +28,41 @@ class RecombinationSampler(WeightsStabiliser, TensorManager):
         return adaptive_pruning(weights, n_rec, n_nys, thresh)
 
 
+class EmpiricalSampler(RecombinationSampler):
+    """The dataset path of SOBER/_sampler.py:61-85,351-382 (`prior.type == "dataset"`, e.g. the malaria
+    fingerprints): candidates are the prior's available rows, their weights come from `pi` (sober_amd.PI for the
+    LFI sampler), the heaviest are kept (`adaptive_pruning`), scrubbed (`cleansing_weights`) and a Nystrom sample is
+    drawn with probability ~ 1 / weight (`deweighted_resampling`) -- everything on the device; `sampling_recombination`
+    then takes (X_cand, X_nys, weights).  The continuous path (`sampling_candidates`: prior updates, WKDE refits) is
+    candidate GENERATION and stays with the reference."""
+
+    def __init__(self, prior, pi, kernel, thresh=5, label="dataset", dataset_pruning=True):
+        super().__init__(kernel, thresh=thresh)
+        self.thresh_initial = thresh
+        self.prior = prior
+        self.pi = pi
+        self.label = label
+        self.dataset_pruning = dataset_pruning
+        self.flag = False
+
+    def sampling_datasets(self, n_rec, n_nys):
+        """SOBER/_sampler.py:351-382 -> (idx_sampled, X_cand, X_nys, weights) with pruning, else (X_cand, X_nys,
+        weights)."""
+        assert n_rec > n_nys
+        X_cand = self.prior.available_candidates()
+        weights = self.pi(X_cand)
+        if self.dataset_pruning:
+            idx_sampled = self.adaptive_pruning(weights, n_rec, n_nys)
+            X_cand = X_cand[idx_sampled]
+            weights = weights[idx_sampled]
+        weights = self.cleansing_weights(weights.contiguous())
+        idx_nys = self.deweighted_resampling(weights, n_nys)
+        X_nys = X_cand[idx_nys]
+        if self.dataset_pruning:
+            return idx_sampled, X_cand, X_nys, weights
+        return X_cand, X_nys, weights
+
+
 def adaptive_pruning(weights, n_rec, n_nys, thresh=1e-3):
     indices = weights.argsort(descending=True)
     above = torch.where(weights[indices] > thresh)[0]

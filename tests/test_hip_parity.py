@@ -528,6 +528,46 @@ def test_adaptive_pruning_on_device(dev):
                               z[f"{tag}_idx"])
 
 
+def test_dataset_path_end_to_end(dev):
+    """`EmpiricalSampler.sampling_datasets` (SOBER/_sampler.py:351-382) feeding `sampling_recombination`: a binary
+    fingerprint pool, Tanimoto posterior covariance, weights supplied by `pi`.  The pruning matches the oracle's,
+    the scrubbed weights match the oracle's cleansing, the recombination that follows preserves the Nystrom test
+    functions' integrals (the resampling itself is RNG-defined and stays torch's)."""
+    from tests.golden.synth import synth, build_spec
+    case = dict(kind=O.TANIMOTO, mode="predictive_covariance", N=6000, M=60, d=256, b=12, n_obs=40, seed=21,
+                ard=False, bit_p=0.08, mean_const=0.4)
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    X = _t(inp["X_cand"]).to(dev)
+    g = torch.Generator().manual_seed(9)
+    w_raw = torch.rand(case["N"], generator=g, dtype=torch.float64) ** 6            # many below the 1e-3 threshold
+    w_raw[::97] = 0.0
+
+    class Prior:
+        type = "dataset"
+        def available_candidates(self):
+            return X
+
+    kern = sober_amd.Kernel(kspec(spec), case["mode"])
+    smp = sober_amd.EmpiricalSampler(Prior(), lambda Xc: w_raw.to(dev).clone(), kern)
+    n_rec, n_nys = 3000, 60
+    torch.manual_seed(3)
+    idx_s, Xc, Xn, w = smp.sampling_datasets(n_rec, n_nys)
+    idx_ref = O.adaptive_pruning(w_raw, n_rec, n_nys)
+    assert np.array_equal(idx_s.cpu().numpy(), idx_ref.numpy())
+    w_ref = O.cleansing_weights(w_raw[idx_ref].clone())
+    np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=1e-13, atol=0)
+    assert Xc.shape == (len(idx_ref), case["d"]) and Xn.shape == (n_nys, case["d"])
+    assert torch.equal(Xc, X[idx_s])
+    mu = w.clone()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx, wq = smp.sampling_recombination(Xc, Xn, mu, case["b"])
+    assert 0 < len(idx) <= case["b"] and bool((wq > 0).all())
+    assert abs(float(wq.sum()) - float(w.sum())) < 1e-12
+    assert int((mu != 0).sum()) == len(idx)                                       # Q3: the caller's weights are the result
+
+
 def test_trsm_blocks(dev):
     """Q = Y L^-T from the inverted diagonal blocks of the blocked Cholesky vs. numpy's triangular solve."""
     from sober_amd import _native as nat
