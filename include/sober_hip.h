@@ -172,12 +172,26 @@ int sober_car_pivot_host_fast(double* h_Phi, int N, int m, double* h_mu);
  * followed by the N-m pivots of :237-266.  Outputs: keep_rank[N] (rank of each surviving row in
  * idx_star, -1 if cancelled), w_star[0:n_keep], *n_keep, mu_out[N]; phi_out (N x (N-m), may be NULL)
  * receives the null-space basis before the pivots (test hook).
- * sober_car_supported(N, m) = 1 iff the on-chip kernel covers the size (batch <= 100).           */
+ * Two implementations behind the same entry point: one compute unit (csrc/car.hip: N <= 208, m <= 112,
+ * batch <= 100) and, beyond that, a multi-CU version (csrc/car_mc.hip: N <= 448, m <= 256, batch <= 224:
+ * the matrix spread over ceil(N/52) workgroups with ONE cross-workgroup exchange per bidiagonalisation
+ * step, the pivots as a streaming pipeline of 32 waves).  n_keep = -1 reports a give-up of the multi-CU
+ * exchange (bounded spins).
+ * sober_car_supported(N, m) = 1 iff one of the two covers the size.                               */
 int sober_car_supported(int N, int m);
 int64_t sober_car_ws_bytes(int N, int m);
 int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
                      int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
                      double* phi_out, void* ws, int64_t ws_bytes, void* stream);
+/* The multi-CU implementation by itself (any size it covers, also the small ones: test and timing hook). */
+int sober_car_mc_supported(int N, int m);
+int64_t sober_car_mc_ws_bytes(int N, int m);
+int sober_car_mc_device(const double* X, int ldx, int N, int m, const double* mu_in,
+                        int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
+                        double* phi_out, void* ws, int64_t ws_bytes, void* stream);
+/* Self test of the gfx950 lane-swap reductions the multi-CU kernels rely on: in (64) ->
+ * out[0:64] = sum over the wave, out[64:128] = sum over lanes l, l^16, l^32, l^48.                  */
+int sober_mc_selftest(const double* in, double* out, void* stream);
 
 /* Dense FP64 Cholesky in one persistent workgroup (n <= sober_chol_max_n()): the lower triangle of A
  * (n x n row-major, ld) is overwritten by L with (A + shift I) = L L^T; *info = 0 on success, j+1 when

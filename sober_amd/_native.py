@@ -48,6 +48,10 @@ SIGNATURES = {
     "sober_car_supported": (_i32, [_i32, _i32]),
     "sober_car_ws_bytes": (_i64, [_i32, _i32]),
     "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sober_car_mc_supported": (_i32, [_i32, _i32]),
+    "sober_car_mc_ws_bytes": (_i64, [_i32, _i32]),
+    "sober_car_mc_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sober_mc_selftest": (_i32, [_vp, _vp, _vp]),
     "sober_chol_max_n": (_i32, []),
     "sober_cholesky": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp]),
     "sober_cholesky_inv": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
@@ -296,17 +300,26 @@ def car_supported(N: int, m: int) -> bool:
     return bool(load().sober_car_supported(N, m))
 
 
-def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None):
-    """X (N, m-1) float64 device (unit inner stride), mu_in (N)."""
+def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None, multi_cu=False):
+    """X (N, m-1) float64 device (unit inner stride), mu_in (N).  multi_cu=True: the multi-CU kernels of
+    csrc/car_mc.hip whatever the size (test and timing hook; sober_car_device picks by size)."""
     N, n = X.shape
-    nbytes = load().sober_car_ws_bytes(N, n + 1)
+    lib = load()
+    nbytes = max(lib.sober_car_ws_bytes(N, n + 1), lib.sober_car_mc_ws_bytes(N, n + 1) if multi_cu else 0)
     ws = _CAR_WS.get(X.device)
     if ws is None or ws.numel() * 8 < nbytes:
         ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=X.device)
         _CAR_WS[X.device] = ws
-    _check(load().sober_car_device(X.data_ptr(), X.stride(0), N, n + 1, mu_in.data_ptr(), keep_rank.data_ptr(),
-                                   w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
-                                   ws.data_ptr(), nbytes, _stream(X)), "sober_car_device")
+    fn, name = (lib.sober_car_mc_device, "sober_car_mc_device") if multi_cu else (lib.sober_car_device, "sober_car_device")
+    _check(fn(X.data_ptr(), X.stride(0), N, n + 1, mu_in.data_ptr(), keep_rank.data_ptr(),
+              w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
+              ws.data_ptr(), nbytes, _stream(X)), name)
+
+
+def mc_selftest(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(128, dtype=torch.float64, device=x.device)
+    _check(load().sober_mc_selftest(x.data_ptr(), out.data_ptr(), _stream(x)), "sober_mc_selftest")
+    return out
 
 
 def chol_max_n() -> int:

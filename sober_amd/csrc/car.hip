@@ -592,21 +592,36 @@ __global__ __launch_bounds__(CAR_PW * 64) void k_car_pivot(const double* __restr
 
 }  // namespace sober
 
-extern "C" int sober_car_supported(int N, int m) {
+extern "C" int sober_car_mc_supported(int N, int m);
+extern "C" int64_t sober_car_mc_ws_bytes(int N, int m);
+extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const double* mu_in, int32_t* keep_rank,
+                                   double* w_star, int32_t* n_keep, double* mu_out, double* phi_out, void* ws,
+                                   int64_t ws_bytes, void* stream);
+
+// one compute unit (batch <= 100)
+static int car_one_cu(int N, int m) {
     return (m >= 2 && N > m && N <= sober::CAR_NS && m <= 16 * sober::CAR_MS && N - m <= sober::CAR_PW * sober::CAR_PJW) ? 1 : 0;
 }
 
+extern "C" int sober_car_supported(int N, int m) {
+    return (car_one_cu(N, m) || sober_car_mc_supported(N, m)) ? 1 : 0;
+}
+
 // scratch: reflectors (m x 208), tau (m, padded to 128), Phi (208 x 128)
+// (a workspace sized for (N, m) also serves every (N' <= N, m): the final direct level)
 extern "C" int64_t sober_car_ws_bytes(int N, int m) {
-    (void)N;
-    return ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC) * (int64_t)sizeof(double);
+    const int64_t one = ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC) * (int64_t)sizeof(double);
+    if (car_one_cu(N, m)) return one;
+    const int64_t mc = sober_car_mc_ws_bytes(N, m);
+    return mc > one ? mc : one;
 }
 
 extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
                                 int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
                                 double* phi_out, void* ws, int64_t ws_bytes, void* stream) {
     if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || !ws || ldx < m - 1) return SOBER_E_ARG;
-    if (!sober_car_supported(N, m)) return SOBER_E_DIM;
+    if (!car_one_cu(N, m))                                  // beyond one compute unit: car_mc.hip
+        return sober_car_mc_device(X, ldx, N, m, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out, ws, ws_bytes, stream);
     if (ws_bytes < sober_car_ws_bytes(N, m)) return SOBER_E_WS;
     hipStream_t st = (hipStream_t)stream;
     double* vws = (double*)ws;

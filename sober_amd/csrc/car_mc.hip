@@ -1,0 +1,726 @@
+// Tchernychova_Lyons_CAR (SOBER/_rchq.py:224-270) for batches beyond one compute unit: N <= 448, m <= 256
+// (batch <= 224; BASELINE.json configs[2] has batch 200 -> A = [1 | X]^T is 200 x 400 = 640 KB, four times the
+// LDS and 1.25 x the whole VGPR file of a CU).  Same mathematics and the same reflectors as car.hip (the null-space
+// basis LAPACK's gesdd returns: Phi = G(0) ... G(m-1) [0; I] with G(i) the right Householder reflectors of the
+// Golub-Kahan bidiagonalisation, dgebd2 / dlarfg conventions); what changes is where the matrix lives and how the
+// workgroups talk.
+//
+//   k_mc_bidiag  G = ceil(N / 52) workgroups x 4 waves, one wave per SIMD.  The matrix lives in VGPRs, lane <-> row
+//                (row = lane + 64 s), a wave owns whole columns (column c -> wave c mod 4G).  One step i then needs
+//                ONE exchange across the workgroups: every wave's partial of q = A[:, c > i] . row_i (a per-lane FMA
+//                chain, no cross-lane traffic) is summed over the workgroup in LDS and over the G workgroups through
+//                L2; with q, |row_i|^2 and column i on every CU, G(i), column i after G(i), H(i) and w = A v are
+//                computed redundantly by every wave, z = u^T A is local to the owner of a column (a wave-level
+//                transposed reduction through a private LDS tile), and the two rank-1 updates are fused.
+//                The exchange uses data-tagged granules (cdna_hip_programming.md Guideline 16, form R2): a double
+//                travels as two 8-byte {32 data bits, 32-bit tag = step + 1} words in one 16-byte write-through (sc1)
+//                store, the reader polls the granule itself with sc1 loads until both tags match -- no flag, no
+//                fence, no placement assumption.  Two slots alternate (a slot is rewritten at step i + 2, and nobody
+//                can publish step i + 1 before it has finished reading step i).
+//   k_mc_phi     Phi = P [0; I]: one wave per column, backward accumulation (as k_car_phi, 7 row slots).
+//   k_mc_pivot   the N - m pivots of :237-266 as a streaming pipeline of 32 independent waves (no barrier at all):
+//                a wave owns 8 consecutive columns of Phi (lane <-> row, 7 slots); it applies the published pivots
+//                (column, index, alpha, 1 / Phi[idx, 0]) to its columns in order as they arrive, and when the next
+//                pivot column is its own it runs the ratio test and publishes.  Inside a block of 8 pivots there is
+//                no exchange; a block hand-over costs one L2 hop.  Every pivot has its own slot (tag = pivot + 1).
+//
+// The communication area is zeroed by a hipMemsetAsync ahead of the launches of EVERY call; all spins are bounded
+// (a give-up writes an error word that makes the step report n_keep = -1).
+#include "common.hpp"
+
+namespace sober {
+namespace mc {
+
+constexpr int RS_MAX = 4;             // row slots of the bidiagonalisation: m <= 256
+constexpr int CPW = 13;               // columns per wave in the bidiagonalisation
+constexpr int NQ = 7;                 // 64-lane slots along N
+constexpr int NS = 64 * NQ;           // 448: stride of a reflector vector and of a Phi column
+constexpr int GMAX = 9;               // workgroups of the bidiagonalisation: ceil(448 / (4 * 13))
+constexpr int BC = 8;                 // pivot columns per wave
+constexpr int PWAVES = 32;            // waves of the pivot kernel: N - m <= 256
+constexpr int KMAX = BC * PWAVES;
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+// byte offsets inside the zeroed communication area
+constexpr unsigned OFF_ERR = 0;                                   // error word (+ padding)
+constexpr unsigned OFF_Q = 64;                                    // [2][GMAX][256] granules: per-CU partial row dots
+constexpr unsigned OFF_C = OFF_Q + 2u * GMAX * 256u * 16u;        // [2][256]: column i
+constexpr unsigned OFF_S = OFF_C + 2u * 256u * 16u;               // [2][16]: per-CU partial |row_i|^2
+constexpr unsigned OFF_H = OFF_S + 2u * 16u * 16u;                // [KMAX][4]: pivot headers (alpha, 1/pivot, index)
+constexpr unsigned OFF_P = OFF_H + (unsigned)KMAX * 64u;          // [K][NS]: pivot columns
+__host__ __device__ constexpr unsigned comm_bytes(int K) { return OFF_P + (unsigned)K * NS * 16u; }
+
+// ---- cross-lane helpers --------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int ROR1 = 0x121, ROR2 = 0x122, ROR4 = 0x124, ROR8 = 0x128;
+constexpr int BCAST15 = 0x142, BCAST31 = 0x143;
+
+__device__ __forceinline__ double row16_allsum(double v) {     // every lane of a 16-lane row: the row total, bitwise equal
+    v += dpp<ROR8>(v);
+    v += dpp<ROR4>(v);
+    v += dpp<ROR2>(v);
+    v += dpp<ROR1>(v);
+    return v;
+}
+// sum over the four 16-lane rows (lanes l, l^16, l^32, l^48), bitwise equal in all four; gfx950 lane swaps:
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second,
+// v_permlane32_swap the upper half of the first with the lower half of the second
+__device__ __forceinline__ double xrow_allsum(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(v);
+    hi = __double2hiint(v);
+    auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
+__device__ __forceinline__ double wave_allsum(double v) { return xrow_allsum(row16_allsum(v)); }
+
+__device__ __forceinline__ double rdlane(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// dlarfg: H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2, v = x * scal
+__device__ __forceinline__ void larfg(double alpha, double ss, double& beta, double& tau, double& scal) {
+    if (ss == 0.0) {
+        beta = alpha; tau = 0.0; scal = 0.0;
+    } else {
+        beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
+        tau = (beta - alpha) / beta;
+        scal = 1.0 / (alpha - beta);
+    }
+}
+
+// ---- granules -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_granule(rsrc_t rs, unsigned off, double v, unsigned tag) {
+    u32x4 g;
+    g.x = (unsigned)__double2loint(v); g.y = tag; g.z = (unsigned)__double2hiint(v); g.w = tag;
+    __builtin_amdgcn_raw_buffer_store_b128(g, rs, off, 0, 16);                   // aux 16 = sc1 (write-through)
+}
+__device__ __forceinline__ u32x4 load_granule(rsrc_t rs, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);                // sc1: not served from this CU's L1
+}
+__device__ __forceinline__ bool granule_ok(const u32x4& g, unsigned tag) { return (g.y == tag) & (g.w == tag); }
+__device__ __forceinline__ double granule_val(const u32x4& g) { return __hiloint2double((int)g.z, (int)g.x); }
+
+__device__ __forceinline__ unsigned load_err(rsrc_t rs) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, OFF_ERR, 0, 16);
+}
+__device__ __forceinline__ void store_err(rsrc_t rs, unsigned code) {
+    __builtin_amdgcn_raw_buffer_store_b32(code, rs, OFF_ERR, 0, 16);
+}
+// one more unsuccessful poll: true = give up (limit reached, or somebody else already gave up)
+__device__ __forceinline__ bool spin_fail(rsrc_t rs, unsigned& spins, unsigned code) {
+    ++spins;
+    if ((spins & 1023u) == 0u && load_err(rs) != 0u) return true;
+    if (spins > SPIN_LIMIT) { store_err(rs, code); return true; }
+    __builtin_amdgcn_s_sleep(1);
+    return false;
+}
+
+// ================================================================================================================
+// phase 1: bidiagonalisation
+// ================================================================================================================
+template <int RS>
+struct BidiagLds {
+    double lq[4][64 * RS];        // per-wave partial row dots
+    double lqt[64 * RS];          // all-reduced row dots
+    double lcol[64 * RS];         // column i
+    double ltr[4][64 * 17];       // per-wave transposition tile of the column sums
+    double lss[4];
+    int ldead;
+};
+
+// steps i = 64 SL .. min(64 SL + 63, m - 1); false = abort
+template <int RS, int SL>
+__device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m, int G, int gw, int cu, int wv,
+                                             BidiagLds<RS>& L, rsrc_t rs, double* __restrict__ vws,
+                                             double* __restrict__ taup) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int NW = 4 * G;
+    const int i_end = min(64 * SL + 64, m);
+    for (int i = 64 * SL; i < i_end; ++i) {
+        const int li = i & 63;
+        const unsigned tag = (unsigned)i + 1u;
+        const unsigned par = (unsigned)i & 1u;
+        // ---- 1. row i of my live columns (wave-uniform), my share of |row_i|^2 and of q = A[:, c > i] row_i
+        double r[CPW];
+        double ssp = 0.0;
+        double qp[RS];
+#pragma unroll
+        for (int s = 0; s < RS; ++s) qp[s] = 0.0;
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            r[j] = 0.0;
+            if (j * NW + gw > i) {                                  // uniform
+                const double rj = rdlane(a[j][SL], li);
+                r[j] = rj;
+                ssp = fma(rj, rj, ssp);
+#pragma unroll
+                for (int s = SL; s < RS; ++s) qp[s] = fma(a[j][s], rj, qp[s]);
+            }
+        }
+        // ---- 2. combine inside the workgroup, publish the CU's partial; the owner of column i publishes it
+#pragma unroll
+        for (int s = SL; s < RS; ++s) L.lq[wv][s * 64 + lane] = qp[s];
+        if (lane == 0) L.lss[wv] = ssp;
+        if (gw == i % NW) {                                         // uniform
+            const int ji = i / NW;
+#pragma unroll
+            for (int s = SL; s < RS; ++s) {
+                double cv = 0.0;
+#pragma unroll
+                for (int j = 0; j < CPW; ++j) cv = (j == ji) ? a[j][s] : cv;
+                if (s * 64 + lane >= i) put_granule(rs, OFF_C + (par * 256u + (unsigned)(s * 64 + lane)) * 16u, cv, tag);
+            }
+        }
+        __syncthreads();
+        if (tid > i && tid < 64 * RS) {
+            const double qc = ((L.lq[0][tid] + L.lq[1][tid]) + L.lq[2][tid]) + L.lq[3][tid];
+            put_granule(rs, OFF_Q + ((par * GMAX + (unsigned)cu) * 256u + (unsigned)tid) * 16u, qc, tag);
+        }
+        if (tid == 0) {
+            const double sc = ((L.lss[0] + L.lss[1]) + L.lss[2]) + L.lss[3];
+            put_granule(rs, OFF_S + (par * 16u + (unsigned)cu) * 16u, sc, tag);
+        }
+        // ---- 3. gather: sentinel first (the G partial norms and the diagonal entry: uniform addresses), then
+        //         this thread's row of the G partials and of column i
+        double sst = 0.0, alpha = 0.0, qt = 0.0, ct = 0.0;
+        {
+            const bool mine = tid > i && tid < 64 * RS;
+            const unsigned row = mine ? (unsigned)tid : (unsigned)i;
+            unsigned spins = 0;
+            bool ok;
+            for (;;) {
+                u32x4 gs[GMAX], ga;
+#pragma unroll
+                for (int g = 0; g < GMAX; ++g) gs[g] = load_granule(rs, OFF_S + (par * 16u + (unsigned)min(g, G - 1)) * 16u);
+                ga = load_granule(rs, OFF_C + (par * 256u + (unsigned)i) * 16u);
+                ok = granule_ok(ga, tag);
+                sst = 0.0;
+#pragma unroll
+                for (int g = 0; g < GMAX; ++g) {
+                    ok &= granule_ok(gs[g], tag);
+                    sst += (g < G) ? granule_val(gs[g]) : 0.0;
+                }
+                alpha = granule_val(ga);
+                if (__all(ok)) break;
+                if (spin_fail(rs, spins, 0x100u + (unsigned)i)) break;
+                asm volatile("" ::: "memory");
+            }
+            if (__all(ok)) {
+                for (;;) {
+                    u32x4 gq[GMAX], gc;
+#pragma unroll
+                    for (int g = 0; g < GMAX; ++g)
+                        gq[g] = load_granule(rs, OFF_Q + ((par * GMAX + (unsigned)min(g, G - 1)) * 256u + row) * 16u);
+                    gc = load_granule(rs, OFF_C + (par * 256u + row) * 16u);
+                    ok = granule_ok(gc, tag);
+                    qt = 0.0;
+#pragma unroll
+                    for (int g = 0; g < GMAX; ++g) {
+                        ok &= granule_ok(gq[g], tag);
+                        qt += (g < G) ? granule_val(gq[g]) : 0.0;
+                    }
+                    ct = granule_val(gc);
+                    ok |= !mine;
+                    if (__all(ok)) break;
+                    if (spin_fail(rs, spins, 0x200u + (unsigned)i)) break;
+                    asm volatile("" ::: "memory");
+                }
+            }
+            if (mine) { L.lqt[tid] = qt; L.lcol[tid] = ct; }
+            if (!__all(ok) && lane == 0) L.ldead = 1;
+        }
+        __syncthreads();
+        if (L.ldead) return false;
+        // ---- 4. G(i): every wave for itself
+        double beta, tau, scal;
+        larfg(alpha, sst, beta, tau, scal);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                const int c = j * NW + gw;
+                if (c > i && c < N) vws[(size_t)i * NS + c] = r[j] * scal;
+            }
+            if (gw == 0) taup[i] = tau;
+        }
+        if (i == m - 1) return true;
+        double tw[RS], nc[RS], w[RS];
+#pragma unroll
+        for (int s = SL; s < RS; ++s) {
+            const int row = s * 64 + lane;
+            const double q = L.lqt[row], c0 = L.lcol[row];
+            const bool live = row > i && row < 64 * RS;
+            const double ws = live ? fma(scal, q, c0) : 0.0;        // w = A[:, i:] [1; v]  (rows > i)
+            w[s] = ws;
+            nc[s] = live ? fma(-tau, ws, c0) : 0.0;                 // column i after G(i)
+            tw[s] = tau * ws;
+        }
+        // ---- 5. H(i) from column i, rows i+1 .. m-1
+        const int i1 = i + 1, l1 = i1 & 63;
+        const bool nxt = (i1 >> 6) != SL;                           // uniform: row i+1 opens the next slot
+        double p1 = 0.0, p2 = 0.0;
+#pragma unroll
+        for (int s = SL; s < RS; ++s) {
+            const bool in = s * 64 + lane > i1;
+            p1 = fma(in ? nc[s] : 0.0, nc[s], p1);
+            p2 = fma(in ? nc[s] : 0.0, w[s], p2);
+        }
+        p1 = wave_allsum(p1);
+        p2 = wave_allsum(p2);
+        constexpr int SN = (SL + 1 < RS) ? SL + 1 : SL;
+        const double alpha2 = rdlane(nxt ? nc[SN] : nc[SL], l1);
+        const double w1 = rdlane(nxt ? w[SN] : w[SL], l1);
+        double beta2, tauq, sc2;
+        larfg(alpha2, p1, beta2, tauq, sc2);
+        const double uw = fma(sc2, p2, w1);                         // u^T w
+        double u[RS], tu[RS];
+#pragma unroll
+        for (int s = SL; s < RS; ++s) {
+            const int row = s * 64 + lane;
+            u[s] = (row <= i) ? 0.0 : ((row == i1) ? 1.0 : nc[s] * sc2);
+            tu[s] = tauq * u[s];
+        }
+        // ---- 6. z_c = u^T A[:, c] for my live columns: per-lane partials, transposed through the wave's LDS tile
+        double* tr = L.ltr[wv];
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            if (j * NW + gw > i) {                                  // uniform
+                double zp = 0.0;
+#pragma unroll
+                for (int s = SL; s < RS; ++s) zp = fma(u[s], a[j][s], zp);
+                tr[lane * 17 + j] = zp;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+        {
+            const int jj = lane & 15, pg = lane >> 4;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += tr[(16 * pg + k) * 17 + jj];
+        }
+        acc = xrow_allsum(acc);                                     // lane l: z of local column l & 15
+        __builtin_amdgcn_wave_barrier();
+        // ---- 7. both rank-1 updates fused: A <- A - tau w [1; v]^T - tauq u z'^T,  z' = z - tau (u^T w) [1; v]
+        const double tuw = tau * uw;
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            if (j * NW + gw > i) {                                  // uniform
+                const double vj = r[j] * scal;
+                const double zj = fma(-tuw, vj, rdlane(acc, j));
+#pragma unroll
+                for (int s = SL; s < RS; ++s) a[j][s] = fma(-tu[s], zj, fma(-tw[s], vj, a[j][s]));
+            }
+        }
+    }
+    return true;
+}
+
+template <int RS>
+__global__ __launch_bounds__(256) void k_mc_bidiag(const double* __restrict__ X, int ldx, int N, int m, int G,
+                                                   double* __restrict__ vws, double* __restrict__ taup, void* comm,
+                                                   unsigned cbytes) {
+    __shared__ BidiagLds<RS> L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cu = blockIdx.x, NW = 4 * G, gw = cu * 4 + wv;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
+    double a[CPW][RS];
+#pragma unroll
+    for (int j = 0; j < CPW; ++j)
+#pragma unroll
+        for (int s = 0; s < RS; ++s) {
+            const int row = s * 64 + lane, c = j * NW + gw;
+            a[j][s] = (c < N && row < m) ? ((row == 0) ? 1.0 : X[(size_t)c * ldx + (row - 1)]) : 0.0;
+        }
+    if (tid == 0) L.ldead = 0;
+    __syncthreads();
+    bool ok = bidiag_steps<RS, 0>(a, N, m, G, gw, cu, wv, L, rs, vws, taup);
+    if constexpr (RS > 1) { if (ok && m > 64) ok = bidiag_steps<RS, 1>(a, N, m, G, gw, cu, wv, L, rs, vws, taup); }
+    if constexpr (RS > 2) { if (ok && m > 128) ok = bidiag_steps<RS, 2>(a, N, m, G, gw, cu, wv, L, rs, vws, taup); }
+    if constexpr (RS > 3) { if (ok && m > 192) ok = bidiag_steps<RS, 3>(a, N, m, G, gw, cu, wv, L, rs, vws, taup); }
+}
+
+// ================================================================================================================
+// phase 2: Phi = G(0) ... G(m-1) [0; I], one wave per column; PhiT[col][row] (a column is contiguous)
+// ================================================================================================================
+__global__ __launch_bounds__(256) void k_mc_phi(const double* __restrict__ vws, const double* __restrict__ taup, int N,
+                                                int m, double* __restrict__ PhiT, double* __restrict__ phi_out) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int K = N - m;
+    if (col >= K) return;                                           // wave-uniform
+    double phi[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) phi[q] = (lane + 64 * q == m + col) ? 1.0 : 0.0;
+    // reflector i: zero below i, one at i, the stored entries above; three register buffers rotate so that an L2
+    // round trip is always two steps ahead
+#define MC_LOAD(BUF, TAU, I)                                                               \
+    {                                                                                      \
+        const int ii_ = max((I), 0);                                                       \
+        const double* src_ = vws + (size_t)ii_ * NS;                                       \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) BUF[q] = src_[lane + 64 * q];       \
+        TAU = taup[ii_];                                                                   \
+    }
+#define MC_APPLY(V, TAU, I)                                                                \
+    if ((I) >= 0) {                                                                        \
+        double v_[NQ];                                                                     \
+        double d_ = 0.0;                                                                   \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                   \
+            const int row_ = lane + 64 * q;                                                \
+            v_[q] = (row_ > (I) && row_ < N) ? V[q] : ((row_ == (I)) ? 1.0 : 0.0);         \
+            d_ = fma(v_[q], phi[q], d_);                                                   \
+        }                                                                                  \
+        const double t_ = TAU * wave_allsum(d_);                                           \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) phi[q] = fma(-t_, v_[q], phi[q]);   \
+    }
+    double vA[NQ], vB[NQ], vC[NQ];
+    double tA = 0.0, tB = 0.0, tC = 0.0;
+    MC_LOAD(vA, tA, m - 1)
+    MC_LOAD(vB, tB, m - 2)
+    for (int i = m - 1; i >= 0; i -= 3) {
+        MC_LOAD(vC, tC, i - 2)
+        MC_APPLY(vA, tA, i)
+        MC_LOAD(vA, tA, i - 3)
+        MC_APPLY(vB, tB, i - 1)
+        MC_LOAD(vB, tB, i - 4)
+        MC_APPLY(vC, tC, i - 2)
+    }
+#undef MC_LOAD
+#undef MC_APPLY
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int row = lane + 64 * q;
+        PhiT[(size_t)col * NS + row] = (row < N) ? phi[q] : 0.0;
+        if (phi_out != nullptr && row < N) phi_out[(size_t)row * K + col] = phi[q];
+    }
+}
+
+// ================================================================================================================
+// phase 3: the pivots
+// ================================================================================================================
+// order-preserving map double -> uint64 for the ratio test: NaN -> 0 (torch.argmin lets a NaN win)
+__device__ __forceinline__ unsigned long long ratio_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned long long k = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    return (x != x) ? 0ull : k;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_min_u32(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {        // uniform result
+    v = dpp_min_u32<ROR8, 0xf>(v);
+    v = dpp_min_u32<ROR4, 0xf>(v);
+    v = dpp_min_u32<ROR2, 0xf>(v);
+    v = dpp_min_u32<ROR1, 0xf>(v);
+    v = dpp_min_u32<BCAST15, 0xa>(v);
+    v = dpp_min_u32<BCAST31, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+struct PivState {
+    double mu[NQ];
+    bool dead[NQ];      // Phi[idx, :] = 0 of :266: the row is marked, readers go through the mask
+    bool inr[NQ];
+};
+
+// ratio test of :239-247 on column `col`: first argmin of mu / col over col > 0 (a NaN quotient wins); piv = -1: none
+__device__ __forceinline__ void ratio_test(const double (&col)[NQ], const PivState& st, int& piv, double& al, double& rp) {
+    double rt[NQ], rc[NQ];
+    unsigned kh[NQ], kl[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        rt[q] = st.mu[q] / col[q];
+        rc[q] = 1.0 / col[q];
+    }
+    unsigned hmin = 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const unsigned long long k = ratio_key(rt[q]);
+        const bool ok = st.inr[q] & (col[q] > 0.0) & !st.dead[q];
+        kh[q] = ok ? (unsigned)(k >> 32) : 0xffffffffu;
+        kl[q] = ok ? (unsigned)k : 0xffffffffu;
+        hmin = min(hmin, kh[q]);
+    }
+    const unsigned H = wave_min_u32(hmin);
+    piv = -1; al = 0.0; rp = 1.0;
+    if (H == 0xffffffffu) return;                                     // uniform: no candidate (:241-242)
+    unsigned long long mb[NQ];
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { mb[q] = __ballot(kh[q] == H); cnt += __popcll(mb[q]); }
+    if (cnt != 1) {                                                   // rare: several quotients share the high word
+        unsigned lmin = 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) lmin = min(lmin, (kh[q] == H) ? kl[q] : 0xffffffffu);
+        const unsigned Lw = wave_min_u32(lmin);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) mb[q] = __ballot((kh[q] == H) & (kl[q] == Lw));
+    }
+    bool found = false;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (!found && mb[q] != 0ull) {                                // uniform
+            const int f = __ffsll((long long)mb[q]) - 1;
+            piv = f + 64 * q;
+            al = rdlane(rt[q], f);
+            rp = rdlane(rc[q], f);
+            found = true;
+        }
+    }
+}
+
+// mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (two roundings like the tensor expression, :253-254)
+__device__ __forceinline__ void mu_step(PivState& st, const double (&col)[NQ], double alpha, int piv, int lane) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        st.dead[q] = st.dead[q] | (lane + 64 * q == piv);
+        st.mu[q] = st.dead[q] ? 0.0 : __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q]));
+    }
+}
+
+// rank-1 elimination of my columns J0 .. BC-1 with the pivot (col, piv, rpp):
+//   Phi[:, c] -= Phi[:, 0] * (Phi[idx, c] / Phi[idx, 0])   (:260-266)
+template <int KP, int J0>
+__device__ __forceinline__ void elim_kp(double (&phi)[BC][NQ], const double (&col)[NQ], int lp, double rpp) {
+#pragma unroll
+    for (int j = J0; j < BC; ++j) {
+        const double qv = rdlane(phi[j][KP], lp) * rpp;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) phi[j][q] = fma(-qv, col[q], phi[j][q]);
+    }
+}
+template <int J0>
+__device__ __forceinline__ void elim(double (&phi)[BC][NQ], const double (&col)[NQ], int piv, double rpp) {
+    const int kp = piv >> 6, lp = piv & 63;
+    switch (kp) {                                                     // uniform
+        case 0: elim_kp<0, J0>(phi, col, lp, rpp); break;
+        case 1: elim_kp<1, J0>(phi, col, lp, rpp); break;
+        case 2: elim_kp<2, J0>(phi, col, lp, rpp); break;
+        case 3: elim_kp<3, J0>(phi, col, lp, rpp); break;
+        case 4: elim_kp<4, J0>(phi, col, lp, rpp); break;
+        case 5: elim_kp<5, J0>(phi, col, lp, rpp); break;
+        default: elim_kp<6, J0>(phi, col, lp, rpp); break;
+    }
+}
+
+// wait for pivot s: header (alpha, 1/pivot, index) and this lane's rows of the pivot column; false = give up
+__device__ __forceinline__ bool consume(rsrc_t rs, int s, int lane, double (&col)[NQ], double& alpha, double& rpp,
+                                        int& piv) {
+    const unsigned tag = (unsigned)s + 1u;
+    const unsigned hoff = OFF_H + (unsigned)s * 64u;
+    const unsigned coff = OFF_P + ((unsigned)s * NS + (unsigned)lane) * 16u;
+    unsigned spins = 0;
+    for (;;) {                                                        // sentinel: the index word (stored last)
+        const u32x4 g = load_granule(rs, hoff + 32u);
+        if (__all(granule_ok(g, tag))) break;
+        if (spin_fail(rs, spins, 0x400u + (unsigned)s)) return false;
+        asm volatile("" ::: "memory");
+    }
+    for (;;) {
+        u32x4 h0 = load_granule(rs, hoff), h1 = load_granule(rs, hoff + 16u), h2 = load_granule(rs, hoff + 32u);
+        u32x4 gc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) gc[q] = load_granule(rs, coff + (unsigned)q * 1024u);
+        bool ok = granule_ok(h0, tag) && granule_ok(h1, tag) && granule_ok(h2, tag);
+        alpha = granule_val(h0); rpp = granule_val(h1); piv = (int)granule_val(h2);
+        if (piv < 0) { if (__all(ok)) return true; }
+        else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { ok &= granule_ok(gc[q], tag); col[q] = granule_val(gc[q]); }
+            if (__all(ok)) return true;
+        }
+        if (spin_fail(rs, spins, 0x500u + (unsigned)s)) return false;
+        asm volatile("" ::: "memory");
+    }
+}
+
+__device__ __forceinline__ void publish(rsrc_t rs, int s, int lane, const double (&col)[NQ], double alpha, double rpp,
+                                        int piv) {
+    const unsigned tag = (unsigned)s + 1u;
+    const unsigned hoff = OFF_H + (unsigned)s * 64u;
+    if (piv >= 0) {
+        const unsigned coff = OFF_P + ((unsigned)s * NS + (unsigned)lane) * 16u;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) put_granule(rs, coff + (unsigned)q * 1024u, col[q], tag);
+    }
+    if (lane == 0) {
+        put_granule(rs, hoff, alpha, tag);
+        put_granule(rs, hoff + 16u, rpp, tag);
+        put_granule(rs, hoff + 32u, (double)piv, tag);
+    }
+}
+
+// my column JL is the next pivot column: ratio test, publish, update the weights and my later columns
+template <int JL>
+__device__ __forceinline__ bool produce(double (&phi)[BC][NQ], PivState& st, rsrc_t rs, int s, int lane) {
+    double col[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[JL][q];
+    int piv;
+    double al, rp;
+    ratio_test(col, st, piv, al, rp);
+    publish(rs, s, lane, col, al, rp, piv);
+    if (piv < 0) return false;                                        // Q6: the loop ends here (:241-242)
+    mu_step(st, col, al, piv, lane);
+    if constexpr (JL + 1 < BC) elim<JL + 1>(phi, col, piv, rp);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ PhiT, int N, int m,
+                                                  const double* __restrict__ mu_in, int32_t* __restrict__ keep_rank,
+                                                  double* __restrict__ w_star, int32_t* __restrict__ n_keep_out,
+                                                  double* __restrict__ mu_out, void* comm, unsigned cbytes) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K = N - m;
+    const int c0 = gw * BC;
+    if (c0 >= K && gw != 0) return;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
+    double phi[BC][NQ];
+    PivState st;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int row = lane + 64 * q;
+        st.inr[q] = row < N;
+        st.dead[q] = false;
+        st.mu[q] = st.inr[q] ? mu_in[row] + 0.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < BC; ++j) phi[j][q] = (c0 + j < K && row < N) ? PhiT[(size_t)(c0 + j) * NS + row] : 0.0;
+    }
+    bool fail = load_err(rs) != 0u;                                   // the bidiagonalisation gave up
+    bool stop = false;
+    double col[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) col[q] = 0.0;
+    // the pivots before my block: apply them to all my columns as they arrive
+    for (int s = 0; s < min(c0, K) && !fail && !stop; ++s) {
+        double al, rp;
+        int piv;
+        if (!consume(rs, s, lane, col, al, rp, piv)) { fail = true; break; }
+        if (piv < 0) { stop = true; break; }
+        mu_step(st, col, al, piv, lane);
+        elim<0>(phi, col, piv, rp);
+    }
+    // my block
+    if (!fail && !stop && c0 < K) {
+        bool go = true;
+#define MC_PRODUCE(JL) if (go && c0 + JL < K) go = produce<JL>(phi, st, rs, c0 + JL, lane);
+        MC_PRODUCE(0) MC_PRODUCE(1) MC_PRODUCE(2) MC_PRODUCE(3)
+        MC_PRODUCE(4) MC_PRODUCE(5) MC_PRODUCE(6) MC_PRODUCE(7)
+#undef MC_PRODUCE
+        stop = !go;
+    }
+    if (gw != 0) return;
+    // wave 0 follows the remaining pivots for the weights and writes the result
+    for (int s = c0 + BC; s < K && !fail && !stop; ++s) {
+        double al, rp;
+        int piv;
+        if (!consume(rs, s, lane, col, al, rp, piv)) { fail = true; break; }
+        if (piv < 0) { stop = true; break; }
+        mu_step(st, col, al, piv, lane);
+    }
+    // ---------------- output: w_star = mu[mu > 0], idx_star as ranks ----------------
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int row = lane + 64 * q;
+        const double v = (row < N) ? st.mu[q] + 0.0 : 0.0;
+        const bool keep = (row < N) && (v > 0.0);
+        const unsigned long long bal = __ballot(keep);
+        const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (row < N) {
+            keep_rank[row] = keep ? rank : -1;
+            mu_out[row] = v;
+            if (keep) w_star[rank] = v;
+        }
+        base += __popcll(bal);
+    }
+    if (lane == 0) *n_keep_out = fail ? -1 : base;
+}
+
+// lane-swap self test: out[l] = wave_allsum(in[l]), out[64 + l] = xrow_allsum(in[l])
+__global__ void k_mc_selftest(const double* __restrict__ in, double* __restrict__ out) {
+    const int l = threadIdx.x;
+    out[l] = wave_allsum(in[l]);
+    out[64 + l] = xrow_allsum(in[l]);
+}
+
+}  // namespace mc
+}  // namespace sober
+
+extern "C" int sober_car_mc_supported(int N, int m) {
+    using namespace sober::mc;
+    return (m >= 2 && N > m && N <= NS && m <= 64 * RS_MAX && N - m <= KMAX) ? 1 : 0;
+}
+
+// scratch: [communication area, zeroed per call] [reflectors m x 448] [tau, 256] [Phi^T (N - m) x 448]
+extern "C" int64_t sober_car_mc_ws_bytes(int N, int m) {
+    using namespace sober::mc;
+    (void)N; (void)m;
+    const int64_t comm = ((int64_t)comm_bytes(KMAX) + 255) / 256 * 256;
+    return comm + ((int64_t)64 * RS_MAX * NS + 256 + (int64_t)KMAX * NS) * (int64_t)sizeof(double);
+}
+
+extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const double* mu_in, int32_t* keep_rank,
+                                   double* w_star, int32_t* n_keep, double* mu_out, double* phi_out, void* ws,
+                                   int64_t ws_bytes, void* stream) {
+    using namespace sober::mc;
+    if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || !ws || ldx < m - 1) return SOBER_E_ARG;
+    if (!sober_car_mc_supported(N, m)) return SOBER_E_DIM;
+    if (ws_bytes < sober_car_mc_ws_bytes(N, m)) return SOBER_E_WS;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = N - m;
+    const unsigned cbytes = comm_bytes(K);
+    const int64_t comm_pad = ((int64_t)comm_bytes(KMAX) + 255) / 256 * 256;
+    char* base = (char*)ws;
+    double* vws = (double*)(base + comm_pad);
+    double* taup = vws + (size_t)64 * RS_MAX * NS;
+    double* PhiT = taup + 256;
+    HIP_TRY(hipMemsetAsync(ws, 0, (size_t)cbytes, st));
+    const int G = (N + 4 * CPW - 1) / (4 * CPW);
+    const int RS = (m + 63) / 64;
+    switch (RS) {
+        case 1:
+        case 2:
+            hipLaunchKernelGGL(k_mc_bidiag<2>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes);
+            break;
+        case 3:
+            hipLaunchKernelGGL(k_mc_bidiag<3>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes);
+            break;
+        default:
+            hipLaunchKernelGGL(k_mc_bidiag<4>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes);
+            break;
+    }
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mc_phi, dim3((K + 3) / 4), dim3(256), 0, st, vws, taup, N, m, PhiT, phi_out);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mc_pivot, dim3(PWAVES / 4), dim3(256), 0, st, PhiT, N, m, mu_in, keep_rank, w_star, n_keep,
+                       mu_out, ws, cbytes);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_mc_selftest(const double* in, double* out, void* stream) {
+    if (!in || !out) return SOBER_E_ARG;
+    hipLaunchKernelGGL(sober::mc::k_mc_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -338,6 +338,120 @@ def test_car_device_vs_reference_levels(dev):
     assert n_checked >= 60
 
 
+def test_lane_swap_reductions(dev):
+    """The gfx950 lane-swap sums under the multi-CU kernels (v_permlane16_swap / v_permlane32_swap semantics)."""
+    from sober_amd import _native as nat
+    x = torch.arange(64, dtype=torch.float64) * 1.25 + 0.5
+    out = nat.mc_selftest(x.to(dev)).cpu()
+    assert torch.equal(out[:64], torch.full((64,), float(x.sum()), dtype=torch.float64))
+    want = x.view(4, 16).sum(0).repeat(4)
+    assert torch.equal(out[64:], want)
+
+
+def _car_mc_case(N, m, seed, dev, decay=0.0):
+    """Random barycentres (optionally with decaying column scales like Nystrom test functions) -> device step with
+    the multi-CU kernels, numpy restatement (tests/test_car_algorithm.py) and LAPACK null space beside it."""
+    from sober_amd import _native as nat
+    from tests.test_car_algorithm import nullspace_gebrd, pivots
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, m - 1)) * np.exp(-decay * np.arange(m - 1))[None, :]
+    mu = rng.random(N) + 0.05
+    mu /= mu.sum()
+    Xd, mud = _t(X).to(dev), _t(mu).to(dev)
+    kr = torch.empty(N, dtype=torch.int32, device=dev)
+    ws = torch.zeros(N, dtype=torch.float64, device=dev)
+    nk = torch.empty(1, dtype=torch.int32, device=dev)
+    mo = torch.empty(N, dtype=torch.float64, device=dev)
+    phi = torch.empty(N, N - m, dtype=torch.float64, device=dev)
+    nat.car_device(Xd, mud, kr, ws, nk, mo, phi_out=phi, multi_cu=True)
+    torch.cuda.synchronize()
+    A = np.vstack([np.ones(N), X.T])
+    Phi_np = nullspace_gebrd(A)
+    return X, mu, kr.cpu().numpy(), ws.cpu().numpy(), int(nk.item()), mo.cpu().numpy(), phi.cpu().numpy(), Phi_np, A
+
+
+@pytest.mark.parametrize("N,m", [(200, 100), (400, 200), (400, 201), (300, 200), (448, 256), (250, 131), (130, 70),
+                                 (202, 200), (64, 20)])
+def test_car_multi_cu_vs_gebrd_restatement(N, m, dev):
+    """Multi-CU Caratheodory kernels (csrc/car_mc.hip): null-space basis = the dgebd2 reflectors' (numpy restatement,
+    itself pinned to LAPACK's SVD on the reference's inputs in tests/test_car_algorithm.py) and = torch.linalg.svd's
+    Vh[m:]; the pivots select the restatement's sets with the same weights."""
+    from tests.test_car_algorithm import pivots
+    X, mu, kr, ws, nk, mo, phi, Phi_np, A = _car_mc_case(N, m, 1000 + N + m, dev)
+    assert nk > 0, "the multi-CU exchange gave up"
+    np.testing.assert_allclose(phi, Phi_np, rtol=0, atol=2e-12)
+    Vh = torch.linalg.svd(torch.from_numpy(A))[2].numpy()
+    np.testing.assert_allclose(phi, Vh[m:].T, rtol=0, atol=1e-9)
+    w_np, idx_np = pivots(Phi_np, mu)
+    idx = np.flatnonzero(kr >= 0)
+    assert np.array_equal(idx, idx_np)
+    assert np.array_equal(kr[idx], np.arange(nk))
+    np.testing.assert_allclose(ws[:nk], w_np, rtol=1e-9)
+    assert np.array_equal(np.flatnonzero(mo > 0), idx)
+    # a recombination: positive weights, mass and the m - 1 moments preserved
+    assert (ws[:nk] > 0).all() and nk <= m
+    np.testing.assert_allclose(ws[:nk].sum(), mu.sum(), rtol=1e-12)
+    np.testing.assert_allclose(ws[:nk] @ X[idx], mu @ X, rtol=0, atol=1e-12)
+
+
+def test_car_multi_cu_equals_one_cu_kernels(dev):
+    """Same step through both device implementations on the reference's level inputs (batch 100): same sets,
+    weights to rounding; and the oracle's LAPACK route on a batch-200 level."""
+    from sober_amd import _native as nat
+    from oracle import sober_oracle as O
+    z = np.load(os.path.join(GOLD, "recomb_matern_medium.npz"))
+    for i in range(int(z["n_levels"])):
+        X, mu = _t(z[f"L{i}_X_tmp"]).to(dev), _t(z[f"L{i}_tot_weights"]).to(dev)
+        N = X.shape[0]
+        outs = []
+        for mc in (False, True):
+            kr = torch.empty(N, dtype=torch.int32, device=dev)
+            ws = torch.zeros(N, dtype=torch.float64, device=dev)
+            nk = torch.empty(1, dtype=torch.int32, device=dev)
+            mo = torch.empty(N, dtype=torch.float64, device=dev)
+            nat.car_device(X, mu, kr, ws, nk, mo, multi_cu=mc)
+            outs.append((kr.cpu().numpy(), ws.cpu().numpy(), int(nk.item())))
+        (k1, w1, n1), (k2, w2, n2) = outs
+        assert n1 == n2 and np.array_equal(k1, k2), i
+        np.testing.assert_allclose(w2[:n2], w1[:n1], rtol=1e-10)
+        assert np.array_equal(np.flatnonzero(k2 >= 0), z[f"L{i}_idx_star"])
+        np.testing.assert_allclose(w2[:n2], z[f"L{i}_w_star"], rtol=W_RTOL)
+    # batch 200 against the oracle (torch.linalg.svd null space + the reference's pivot loop)
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((400, 199)) * np.exp(-0.02 * np.arange(199))[None, :]
+    mu = rng.random(400) + 0.1
+    w_ref, i_ref = O.tchernychova_lyons_car(_t(X).clone(), _t(mu).clone())
+    kr = torch.empty(400, dtype=torch.int32, device=dev)
+    ws = torch.zeros(400, dtype=torch.float64, device=dev)
+    nk = torch.empty(1, dtype=torch.int32, device=dev)
+    mo = torch.empty(400, dtype=torch.float64, device=dev)
+    nat.car_device(_t(X).to(dev), _t(mu).to(dev), kr, ws, nk, mo)            # dispatches to the multi-CU kernels
+    n = int(nk.item())
+    assert np.array_equal(np.flatnonzero(kr.cpu().numpy() >= 0), i_ref.numpy())
+    np.testing.assert_allclose(ws.cpu().numpy()[:n], w_ref.numpy(), rtol=1e-8)
+
+
+def test_car_multi_cu_zero_masses(dev):
+    """Zero set masses (alpha = 0 pivots, first-index ties) through the multi-CU pivots."""
+    from sober_amd import _native as nat
+    from tests.test_car_algorithm import nullspace_gebrd, pivots
+    rng = np.random.default_rng(11)
+    N, m = 300, 180
+    X = rng.standard_normal((N, m - 1))
+    mu = rng.random(N) + 0.05
+    mu[::7] = 0.0                                                          # zero masses: alpha = 0 pivots
+    A = np.vstack([np.ones(N), X.T])
+    w_np, idx_np = pivots(nullspace_gebrd(A), mu)
+    kr = torch.empty(N, dtype=torch.int32, device=dev)
+    ws = torch.zeros(N, dtype=torch.float64, device=dev)
+    nk = torch.empty(1, dtype=torch.int32, device=dev)
+    mo = torch.empty(N, dtype=torch.float64, device=dev)
+    nat.car_device(_t(X).to(dev), _t(mu).to(dev), kr, ws, nk, mo, multi_cu=True)
+    n = int(nk.item())
+    assert np.array_equal(np.flatnonzero(kr.cpu().numpy() >= 0), idx_np)
+    np.testing.assert_allclose(ws.cpu().numpy()[:n], w_np, rtol=1e-9)
+
+
 def test_host_and_device_car_agree(dev):
     """The LAPACK route (used for batch > 100) and the on-chip route give the same step."""
     path = os.path.join(GOLD, "recomb_matern_medium.npz")
