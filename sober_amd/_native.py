@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsober_hip.so")
+# (SOBER_HIP_LIB: a diagnostic build of the same library, e.g. the in-kernel-stamp build `make stamps`)
+LIB_PATH = os.environ.get("SOBER_HIP_LIB") or os.path.join(_HERE, "libsober_hip.so")
 ABI_VERSION = 1
 
 KIND_RBF, KIND_MATERN52, KIND_TANIMOTO = 0, 1, 2

@@ -40,6 +40,7 @@ constexpr int BC = 8;                 // pivot columns per wave
 constexpr int PWAVES = 32;            // waves of the pivot kernel: N - m <= 256
 constexpr int KMAX = BC * PWAVES;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr int DBG_WORDS = 8192;       // stamp block at the end of the workspace (diagnostic build)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -93,16 +94,47 @@ __device__ __forceinline__ double rdlane(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// v_rcp_f64 / v_rsq_f64 seeds + Newton steps: <= 1 ulp, a third of the dependent chain of the IEEE sequences
+// (the reflector scalars sit on the critical path of every step); operands far outside the normal range take the
+// IEEE route
+__device__ __forceinline__ double fast_rcp(double c) {
+    double r = __builtin_amdgcn_rcp(c);
+    double e = fma(-c, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-c, r, 1.0);
+    return fma(r, e, r);
+}
 // dlarfg: H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2, v = x * scal
 __device__ __forceinline__ void larfg(double alpha, double ss, double& beta, double& tau, double& scal) {
     if (ss == 0.0) {
         beta = alpha; tau = 0.0; scal = 0.0;
+        return;
+    }
+    const double n2 = fma(alpha, alpha, ss);
+    if (n2 > 1e-200 && n2 < 1e200) {
+        double r = __builtin_amdgcn_rsq(n2);                  // 1 / sqrt(n2)
+        double h = 0.5 * r;
+        double e = fma(-(n2 * r), h, 0.5);
+        r = fma(r, e, r);
+        h = 0.5 * r;
+        e = fma(-(n2 * r), h, 0.5);
+        r = fma(r, e, r);
+        double nr = n2 * r;                                   // sqrt(n2), one correction step
+        nr = fma(fma(-nr, nr, n2), 0.5 * r, nr);
+        beta = -copysign(nr, alpha);
+        double ib = fast_rcp(beta);
+        tau = (beta - alpha) * ib;
+        tau = fma(fma(-tau, beta, beta - alpha), ib, tau);    // residual correction of the quotient
+        scal = fast_rcp(alpha - beta);
     } else {
-        beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
+        beta = -copysign(sqrt(n2), alpha);
         tau = (beta - alpha) / beta;
         scal = 1.0 / (alpha - beta);
     }
 }
+
+// workgroup barrier that waits for this wave's LDS traffic only (global stores and loads stay in flight)
+#define MC_LDS_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 // ---- granules -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void put_granule(rsrc_t rs, unsigned off, double v, unsigned tag) {
@@ -131,6 +163,20 @@ __device__ __forceinline__ bool spin_fail(rsrc_t rs, unsigned& spins, unsigned c
     return false;
 }
 
+// in-kernel stamps (diagnostic build only, `make stamps`): per-segment cycle sums of every wave -> the debug block
+// at the end of the workspace, which nothing else reads
+#ifdef MC_STAMPS
+#define MC_STAMP_DECL unsigned long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_) :: "memory");
+#define MC_STAMP(K) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    acc_[K] += t_ - tl_; tl_ = t_; } while (0)
+#define MC_STAMP_FLUSH(DBG, SLOT) do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 12; ++k_) (DBG)[(SLOT) * 12 + k_] = acc_[k_]; } while (0)
+#else
+#define MC_STAMP_DECL
+#define MC_STAMP(K) do { } while (0)
+#define MC_STAMP_FLUSH(DBG, SLOT) do { } while (0)
+#endif
+
 // ================================================================================================================
 // phase 1: bidiagonalisation
 // ================================================================================================================
@@ -139,8 +185,10 @@ struct BidiagLds {
     double lq[4][64 * RS];        // per-wave partial row dots
     double lqt[64 * RS];          // all-reduced row dots
     double lcol[64 * RS];         // column i
+    double lcp[64 * RS];          // column i on its way out (owner wave -> publisher waves)
     double ltr[4][64 * 17];       // per-wave transposition tile of the column sums
     double lss[4];
+    double lsc[2];                // |row_i|^2, A[i][i] after the exchange
     int ldead;
 };
 
@@ -148,11 +196,13 @@ struct BidiagLds {
 template <int RS, int SL>
 __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m, int G, int gw, int cu, int wv,
                                              BidiagLds<RS>& L, rsrc_t rs, double* __restrict__ vws,
-                                             double* __restrict__ taup) {
+                                             double* __restrict__ taup, unsigned long long* dbg) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int NW = 4 * G;
     const int i_end = min(64 * SL + 64, m);
+    MC_STAMP_DECL
     for (int i = 64 * SL; i < i_end; ++i) {
+        MC_STAMP(0);
         const int li = i & 63;
         const unsigned tag = (unsigned)i + 1u;
         const unsigned par = (unsigned)i & 1u;
@@ -166,49 +216,75 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m,
         for (int j = 0; j < CPW; ++j) {
             r[j] = 0.0;
             if (j * NW + gw > i) {                                  // uniform
-                const double rj = rdlane(a[j][SL], li);
+                double rj = rdlane(a[j][SL], li);
+                asm volatile("" : "+v"(rj));                          // lives in a VGPR (the SGPR file is the scarce one)
                 r[j] = rj;
                 ssp = fma(rj, rj, ssp);
 #pragma unroll
                 for (int s = SL; s < RS; ++s) qp[s] = fma(a[j][s], rj, qp[s]);
             }
         }
-        // ---- 2. combine inside the workgroup, publish the CU's partial; the owner of column i publishes it
+        MC_STAMP(1);
+        // ---- 2. combine inside the workgroup (LDS); the owner of column i hands it to the publishers
 #pragma unroll
         for (int s = SL; s < RS; ++s) L.lq[wv][s * 64 + lane] = qp[s];
         if (lane == 0) L.lss[wv] = ssp;
-        if (gw == i % NW) {                                         // uniform
+        const int gwi = i % NW;                                     // uniform: the wave that owns column i
+        if (gw == gwi) {
             const int ji = i / NW;
 #pragma unroll
             for (int s = SL; s < RS; ++s) {
                 double cv = 0.0;
 #pragma unroll
                 for (int j = 0; j < CPW; ++j) cv = (j == ji) ? a[j][s] : cv;
-                if (s * 64 + lane >= i) put_granule(rs, OFF_C + (par * 256u + (unsigned)(s * 64 + lane)) * 16u, cv, tag);
+                L.lcp[s * 64 + lane] = cv;
             }
         }
-        __syncthreads();
-        if (tid > i && tid < 64 * RS) {
-            const double qc = ((L.lq[0][tid] + L.lq[1][tid]) + L.lq[2][tid]) + L.lq[3][tid];
-            put_granule(rs, OFF_Q + ((par * GMAX + (unsigned)cu) * 256u + (unsigned)tid) * 16u, qc, tag);
-        }
-        if (tid == 0) {
-            const double sc = ((L.lss[0] + L.lss[1]) + L.lss[2]) + L.lss[3];
-            put_granule(rs, OFF_S + (par * 16u + (unsigned)cu) * 16u, sc, tag);
-        }
-        // ---- 3. gather: sentinel first (the G partial norms and the diagonal entry: uniform addresses), then
-        //         this thread's row of the G partials and of column i
-        double sst = 0.0, alpha = 0.0, qt = 0.0, ct = 0.0;
-        {
-            const bool mine = tid > i && tid < 64 * RS;
-            const unsigned row = mine ? (unsigned)tid : (unsigned)i;
+        MC_LDS_BARRIER();
+        MC_STAMP(2);
+        // ---- 3. the exchange.  Waves 0-1 publish (two rows per thread), waves 2-3 poll (two rows per thread): a
+        //         wave's loads return behind its own older stores (one vmcnt queue), and a write-through store is
+        //         acknowledged from the memory side -- the pollers must not have any in flight.
+        if (wv < 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = tid + 128 * h;
+                if (row > i && row < 64 * RS) {
+                    const double qc = ((L.lq[0][row] + L.lq[1][row]) + L.lq[2][row]) + L.lq[3][row];
+                    put_granule(rs, OFF_Q + ((par * GMAX + (unsigned)cu) * 256u + (unsigned)row) * 16u, qc, tag);
+                }
+                if (cu == (gwi >> 2) && row >= i && row < 64 * RS)
+                    put_granule(rs, OFF_C + (par * 256u + (unsigned)row) * 16u, L.lcp[row], tag);
+            }
+            if (tid == 0) {
+                const double sc = ((L.lss[0] + L.lss[1]) + L.lss[2]) + L.lss[3];
+                put_granule(rs, OFF_S + (par * 16u + (unsigned)cu) * 16u, sc, tag);
+            }
+        } else {
+            const int t2 = tid - 128;
+            unsigned rowh[2];
+            bool mine[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = t2 + 128 * h;
+                mine[h] = row > i && row < 64 * RS;
+                rowh[h] = mine[h] ? (unsigned)row : (unsigned)i;
+            }
             unsigned spins = 0;
             bool ok;
+            double sst = 0.0, alpha = 0.0, qt[2], ct[2];
             for (;;) {
-                u32x4 gs[GMAX], ga;
+                u32x4 gs[GMAX], ga, gq[2][GMAX], gc[2];
 #pragma unroll
                 for (int g = 0; g < GMAX; ++g) gs[g] = load_granule(rs, OFF_S + (par * 16u + (unsigned)min(g, G - 1)) * 16u);
                 ga = load_granule(rs, OFF_C + (par * 256u + (unsigned)i) * 16u);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int g = 0; g < GMAX; ++g)
+                        gq[h][g] = load_granule(rs, OFF_Q + ((par * GMAX + (unsigned)min(g, G - 1)) * 256u + rowh[h]) * 16u);
+                    gc[h] = load_granule(rs, OFF_C + (par * 256u + rowh[h]) * 16u);
+                }
                 ok = granule_ok(ga, tag);
                 sst = 0.0;
 #pragma unroll
@@ -217,36 +293,33 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m,
                     sst += (g < G) ? granule_val(gs[g]) : 0.0;
                 }
                 alpha = granule_val(ga);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bool okh = granule_ok(gc[h], tag);
+                    qt[h] = 0.0;
+#pragma unroll
+                    for (int g = 0; g < GMAX; ++g) {
+                        okh &= granule_ok(gq[h][g], tag);
+                        qt[h] += (g < G) ? granule_val(gq[h][g]) : 0.0;
+                    }
+                    ct[h] = granule_val(gc[h]);
+                    ok &= okh | !mine[h];
+                }
                 if (__all(ok)) break;
                 if (spin_fail(rs, spins, 0x100u + (unsigned)i)) break;
                 asm volatile("" ::: "memory");
             }
-            if (__all(ok)) {
-                for (;;) {
-                    u32x4 gq[GMAX], gc;
 #pragma unroll
-                    for (int g = 0; g < GMAX; ++g)
-                        gq[g] = load_granule(rs, OFF_Q + ((par * GMAX + (unsigned)min(g, G - 1)) * 256u + row) * 16u);
-                    gc = load_granule(rs, OFF_C + (par * 256u + row) * 16u);
-                    ok = granule_ok(gc, tag);
-                    qt = 0.0;
-#pragma unroll
-                    for (int g = 0; g < GMAX; ++g) {
-                        ok &= granule_ok(gq[g], tag);
-                        qt += (g < G) ? granule_val(gq[g]) : 0.0;
-                    }
-                    ct = granule_val(gc);
-                    ok |= !mine;
-                    if (__all(ok)) break;
-                    if (spin_fail(rs, spins, 0x200u + (unsigned)i)) break;
-                    asm volatile("" ::: "memory");
-                }
-            }
-            if (mine) { L.lqt[tid] = qt; L.lcol[tid] = ct; }
+            for (int h = 0; h < 2; ++h)
+                if (mine[h]) { L.lqt[rowh[h]] = qt[h]; L.lcol[rowh[h]] = ct[h]; }
+            if (t2 == 0) { L.lsc[0] = sst; L.lsc[1] = alpha; }
             if (!__all(ok) && lane == 0) L.ldead = 1;
         }
-        __syncthreads();
+        MC_STAMP(3);
+        MC_LDS_BARRIER();
+        MC_STAMP(4);
         if (L.ldead) return false;
+        const double sst = L.lsc[0], alpha = L.lsc[1];
         // ---- 4. G(i): every wave for itself
         double beta, tau, scal;
         larfg(alpha, sst, beta, tau, scal);
@@ -258,7 +331,8 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m,
             }
             if (gw == 0) taup[i] = tau;
         }
-        if (i == m - 1) return true;
+        if (i == m - 1) { MC_STAMP_FLUSH(dbg, (blockIdx.x * 4 + wv) * 4 + SL); return true; }
+        MC_STAMP(5);
         double tw[RS], nc[RS], w[RS];
 #pragma unroll
         for (int s = SL; s < RS; ++s) {
@@ -295,6 +369,7 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m,
             u[s] = (row <= i) ? 0.0 : ((row == i1) ? 1.0 : nc[s] * sc2);
             tu[s] = tauq * u[s];
         }
+        MC_STAMP(6);
         // ---- 6. z_c = u^T A[:, c] for my live columns: per-lane partials, transposed through the wave's LDS tile
         double* tr = L.ltr[wv];
 #pragma unroll
@@ -316,6 +391,7 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m,
         }
         acc = xrow_allsum(acc);                                     // lane l: z of local column l & 15
         __builtin_amdgcn_wave_barrier();
+        MC_STAMP(7);
         // ---- 7. both rank-1 updates fused: A <- A - tau w [1; v]^T - tauq u z'^T,  z' = z - tau (u^T w) [1; v]
         const double tuw = tau * uw;
 #pragma unroll
@@ -327,14 +403,16 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m,
                 for (int s = SL; s < RS; ++s) a[j][s] = fma(-tu[s], zj, fma(-tw[s], vj, a[j][s]));
             }
         }
+        MC_STAMP(8);
     }
+    MC_STAMP_FLUSH(dbg, (blockIdx.x * 4 + wv) * 4 + SL);
     return true;
 }
 
 template <int RS>
 __global__ __launch_bounds__(256) void k_mc_bidiag(const double* __restrict__ X, int ldx, int N, int m, int G,
                                                    double* __restrict__ vws, double* __restrict__ taup, void* comm,
-                                                   unsigned cbytes) {
+                                                   unsigned cbytes, unsigned long long* dbg) {
     __shared__ BidiagLds<RS> L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -350,10 +428,10 @@ __global__ __launch_bounds__(256) void k_mc_bidiag(const double* __restrict__ X,
         }
     if (tid == 0) L.ldead = 0;
     __syncthreads();
-    bool ok = bidiag_steps<RS, 0>(a, N, m, G, gw, cu, wv, L, rs, vws, taup);
-    if constexpr (RS > 1) { if (ok && m > 64) ok = bidiag_steps<RS, 1>(a, N, m, G, gw, cu, wv, L, rs, vws, taup); }
-    if constexpr (RS > 2) { if (ok && m > 128) ok = bidiag_steps<RS, 2>(a, N, m, G, gw, cu, wv, L, rs, vws, taup); }
-    if constexpr (RS > 3) { if (ok && m > 192) ok = bidiag_steps<RS, 3>(a, N, m, G, gw, cu, wv, L, rs, vws, taup); }
+    bool ok = bidiag_steps<RS, 0>(a, N, m, G, gw, cu, wv, L, rs, vws, taup, dbg);
+    if constexpr (RS > 1) { if (ok && m > 64) ok = bidiag_steps<RS, 1>(a, N, m, G, gw, cu, wv, L, rs, vws, taup, dbg); }
+    if constexpr (RS > 2) { if (ok && m > 128) ok = bidiag_steps<RS, 2>(a, N, m, G, gw, cu, wv, L, rs, vws, taup, dbg); }
+    if constexpr (RS > 3) { if (ok && m > 192) ok = bidiag_steps<RS, 3>(a, N, m, G, gw, cu, wv, L, rs, vws, taup, dbg); }
 }
 
 // ================================================================================================================
@@ -676,7 +754,7 @@ extern "C" int64_t sober_car_mc_ws_bytes(int N, int m) {
     using namespace sober::mc;
     (void)N; (void)m;
     const int64_t comm = ((int64_t)comm_bytes(KMAX) + 255) / 256 * 256;
-    return comm + ((int64_t)64 * RS_MAX * NS + 256 + (int64_t)KMAX * NS) * (int64_t)sizeof(double);
+    return comm + ((int64_t)64 * RS_MAX * NS + 256 + (int64_t)KMAX * NS + DBG_WORDS) * (int64_t)sizeof(double);
 }
 
 extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const double* mu_in, int32_t* keep_rank,
@@ -694,19 +772,20 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
     double* vws = (double*)(base + comm_pad);
     double* taup = vws + (size_t)64 * RS_MAX * NS;
     double* PhiT = taup + 256;
+    unsigned long long* dbg = (unsigned long long*)(PhiT + (size_t)KMAX * NS);
     HIP_TRY(hipMemsetAsync(ws, 0, (size_t)cbytes, st));
     const int G = (N + 4 * CPW - 1) / (4 * CPW);
     const int RS = (m + 63) / 64;
     switch (RS) {
         case 1:
         case 2:
-            hipLaunchKernelGGL(k_mc_bidiag<2>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes);
+            hipLaunchKernelGGL(k_mc_bidiag<2>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes, dbg);
             break;
         case 3:
-            hipLaunchKernelGGL(k_mc_bidiag<3>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes);
+            hipLaunchKernelGGL(k_mc_bidiag<3>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes, dbg);
             break;
         default:
-            hipLaunchKernelGGL(k_mc_bidiag<4>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes);
+            hipLaunchKernelGGL(k_mc_bidiag<4>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes, dbg);
             break;
     }
     LAUNCH_CHECK();
