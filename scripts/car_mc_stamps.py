@@ -18,12 +18,12 @@ for it in range(3):
 torch.cuda.synchronize()
 buf = nat._CAR_WS[Xd.device]
 dbg = buf[-8192:].cpu().numpy().view(np.uint64).astype(np.float64)
-G = (N + 51) // 52
+G = 9
 names = ["loop", "row+q", "lds+barA", "exchange", "barB", "G(i)+stores", "H(i)", "z", "update"]
 d = dbg[:G * 4 * 4 * 12].reshape(G * 4, 4, 12)       # [wave][SL][segment]
 tot = d.sum(1)                                          # per wave over all steps
 print("N %d m %d G %d: mean s_memtime cycles per step and segment" % (N, m, G))
-for role, sel in (("publishers (waves 0-1)", [w for w in range(G * 4) if w % 4 < 2]),
-                  ("pollers (waves 2-3)", [w for w in range(G * 4) if w % 4 >= 2])):
+for role, sel in (("waves 0-1", [w for w in range(G * 4) if w % 4 < 2]),
+                  ("waves 2-3", [w for w in range(G * 4) if w % 4 >= 2])):
     t = tot[sel].mean(0) / m
     print(role, " ".join("%s %.0f" % (n, v) for n, v in zip(names, t[:9])), "| sum %.0f" % t[:9].sum())

@@ -5,8 +5,8 @@
 // Golub-Kahan bidiagonalisation, dgebd2 / dlarfg conventions); what changes is where the matrix lives and how the
 // workgroups talk.
 //
-//   k_mc_bidiag  G = ceil(N / 52) workgroups x 4 waves, one wave per SIMD.  The matrix lives in VGPRs, lane <-> row
-//                (row = lane + 64 s), a wave owns whole columns (column c -> wave c mod 4G).  One step i then needs
+//   k_mc_bidiag  G = 9 workgroups x 4 waves, one wave per SIMD.  The matrix lives in VGPRs, lane <-> row
+//                (row = lane + 64 s), a wave owns whole columns (column c -> wave c mod 36).  One step i then needs
 //                ONE exchange across the workgroups: every wave's partial of q = A[:, c > i] . row_i (a per-lane FMA
 //                chain, no cross-lane traffic) is summed over the workgroup in LDS and over the G workgroups through
 //                L2; with q, |row_i|^2 and column i on every CU, G(i), column i after G(i), H(i) and w = A v are
@@ -35,11 +35,13 @@ constexpr int RS_MAX = 4;             // row slots of the bidiagonalisation: m <
 constexpr int CPW = 13;               // columns per wave in the bidiagonalisation
 constexpr int NQ = 7;                 // 64-lane slots along N
 constexpr int NS = 64 * NQ;           // 448: stride of a reflector vector and of a Phi column
-constexpr int GMAX = 9;               // workgroups of the bidiagonalisation: ceil(448 / (4 * 13))
+constexpr int GMAX = 9;               // workgroups of the bidiagonalisation, always all nine: 36 waves x 13 >= 448
+constexpr int NW = 4 * GMAX;          // column c lives in wave c mod 36
 constexpr int BC = 8;                 // pivot columns per wave
 constexpr int PWAVES = 32;            // waves of the pivot kernel: N - m <= 256
 constexpr int KMAX = BC * PWAVES;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr int ELECT_GRID = 128;       // workgroups launched per kernel: some XCD gets >= 16 of them whatever the placement
 constexpr int DBG_WORDS = 8192;       // stamp block at the end of the workspace (diagnostic build)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -47,7 +49,9 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 // byte offsets inside the zeroed communication area
 constexpr unsigned OFF_ERR = 0;                                   // error word (+ padding)
-constexpr unsigned OFF_Q = 64;                                    // [2][GMAX][256] granules: per-CU partial row dots
+constexpr unsigned OFF_EL_B = 16;                                 // election of the bidiagonalisation: count[8], winner
+constexpr unsigned OFF_EL_P = 64;                                 // election of the pivot kernel: count[8], winner
+constexpr unsigned OFF_Q = 128;                                   // [2][GMAX][256] granules: per-CU partial row dots
 constexpr unsigned OFF_C = OFF_Q + 2u * GMAX * 256u * 16u;        // [2][256]: column i
 constexpr unsigned OFF_S = OFF_C + 2u * 256u * 16u;               // [2][16]: per-CU partial |row_i|^2
 constexpr unsigned OFF_H = OFF_S + 2u * 16u * 16u;                // [KMAX][4]: pivot headers (alpha, 1/pivot, index)
@@ -104,33 +108,32 @@ __device__ __forceinline__ double fast_rcp(double c) {
     e = fma(-c, r, 1.0);
     return fma(r, e, r);
 }
-// dlarfg: H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2, v = x * scal
+// dlarfg: H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2, v = x * scal.
+// Branch-free (a taken branch costs a single resident wave 50-80 cycles of instruction fetch): operands far
+// outside the normal range are rescaled by 2^(+-300) with selects, ss = 0 gives the identity (tau = 0).
 __device__ __forceinline__ void larfg(double alpha, double ss, double& beta, double& tau, double& scal) {
-    if (ss == 0.0) {
-        beta = alpha; tau = 0.0; scal = 0.0;
-        return;
-    }
-    const double n2 = fma(alpha, alpha, ss);
-    if (n2 > 1e-200 && n2 < 1e200) {
-        double r = __builtin_amdgcn_rsq(n2);                  // 1 / sqrt(n2)
-        double h = 0.5 * r;
-        double e = fma(-(n2 * r), h, 0.5);
-        r = fma(r, e, r);
-        h = 0.5 * r;
-        e = fma(-(n2 * r), h, 0.5);
-        r = fma(r, e, r);
-        double nr = n2 * r;                                   // sqrt(n2), one correction step
-        nr = fma(fma(-nr, nr, n2), 0.5 * r, nr);
-        beta = -copysign(nr, alpha);
-        double ib = fast_rcp(beta);
-        tau = (beta - alpha) * ib;
-        tau = fma(fma(-tau, beta, beta - alpha), ib, tau);    // residual correction of the quotient
-        scal = fast_rcp(alpha - beta);
-    } else {
-        beta = -copysign(sqrt(n2), alpha);
-        tau = (beta - alpha) / beta;
-        scal = 1.0 / (alpha - beta);
-    }
+    const double n2r = fma(alpha, alpha, ss);
+    const bool tiny = n2r < 1e-200, huge = n2r > 1e200;
+    const double f = tiny ? 0x1p300 : (huge ? 0x1p-300 : 1.0), fi = tiny ? 0x1p-300 : (huge ? 0x1p300 : 1.0);
+    const double al = alpha * f;
+    const double n2 = fma(al, al, (ss * f) * f);
+    double r = __builtin_amdgcn_rsq(n2);                      // 1 / sqrt(n2)
+    double h = 0.5 * r;
+    double e = fma(-(n2 * r), h, 0.5);
+    r = fma(r, e, r);
+    h = 0.5 * r;
+    e = fma(-(n2 * r), h, 0.5);
+    r = fma(r, e, r);
+    double nr = n2 * r;                                       // sqrt(n2), one correction step
+    nr = fma(fma(-nr, nr, n2), 0.5 * r, nr);
+    const double bs = -copysign(nr, al);
+    const double ib = fast_rcp(bs);
+    double t = (bs - al) * ib;
+    t = fma(fma(-t, bs, bs - al), ib, t);                     // residual correction of the quotient
+    const bool none = ss == 0.0;
+    beta = none ? alpha : bs * fi;
+    tau = none ? 0.0 : t;
+    scal = none ? 0.0 : fast_rcp(al - bs) * f;
 }
 
 // workgroup barrier that waits for this wave's LDS traffic only (global stores and loads stay in flight)
@@ -140,10 +143,10 @@ __device__ __forceinline__ void larfg(double alpha, double ss, double& beta, dou
 __device__ __forceinline__ void put_granule(rsrc_t rs, unsigned off, double v, unsigned tag) {
     u32x4 g;
     g.x = (unsigned)__double2loint(v); g.y = tag; g.z = (unsigned)__double2hiint(v); g.w = tag;
-    __builtin_amdgcn_raw_buffer_store_b128(g, rs, off, 0, 16);                   // aux 16 = sc1 (write-through)
+    __builtin_amdgcn_raw_buffer_store_b128(g, rs, off, 0, 0);                    // plain: the line stays in the XCD's L2
 }
 __device__ __forceinline__ u32x4 load_granule(rsrc_t rs, unsigned off) {
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);                // sc1: not served from this CU's L1
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);                // sc1: past this CU's L1, served by L2
 }
 __device__ __forceinline__ bool granule_ok(const u32x4& g, unsigned tag) { return (g.y == tag) & (g.w == tag); }
 __device__ __forceinline__ double granule_val(const u32x4& g) { return __hiloint2double((int)g.z, (int)g.x); }
@@ -161,6 +164,31 @@ __device__ __forceinline__ bool spin_fail(rsrc_t rs, unsigned& spins, unsigned c
     if (spins > SPIN_LIMIT) { store_err(rs, code); return true; }
     __builtin_amdgcn_s_sleep(1);
     return false;
+}
+
+// Workers of one launch all sit on ONE XCD, by construction: every workgroup reads its XCC id from the hardware
+// register and takes a ticket on that XCD's counter; the XCD whose n-th ticket is drawn first wins, its tickets
+// 0 .. n-1 are the workers (ticket = worker index), everybody else exits.  128 workgroups over 8 XCDs: some XCD
+// always collects n <= 16 of them, whatever the dispatcher does.  What this buys: the workers share one L2, so a
+// plain store by one is seen by an L1-bypassing (sc1) load of another after an L2 round trip (~0.1 us) -- the
+// write-through + fabric path between XCDs costs 0.75 us per round trip and two to three of them per exchange.
+// Called by thread 0; -1 = not a worker.
+__device__ __forceinline__ int elect(void* comm, unsigned base, int n, rsrc_t rs) {
+    unsigned* cnt = (unsigned*)((char*)comm + base);
+    unsigned* win = cnt + 8;
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;       // HW_REG_XCC_ID
+    const unsigned t = __hip_atomic_fetch_add(cnt + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t >= (unsigned)n) return -1;
+    if (t == (unsigned)n - 1u) {
+        unsigned expect = 0u;
+        __hip_atomic_compare_exchange_strong(win, &expect, xcc + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned spins = 0, w;
+    while ((w = __hip_atomic_load(win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+        if (spin_fail(rs, spins, 0x10u)) return -1;
+    }
+    return (w == xcc + 1u) ? (int)t : -1;
 }
 
 // in-kernel stamps (diagnostic build only, `make stamps`): per-segment cycle sums of every wave -> the debug block
@@ -192,13 +220,23 @@ struct BidiagLds {
     int ldead;
 };
 
+// BODY(j) for the live register slots j = 0 .. nlive-1, written out (an early exit inside `#pragma unroll` keeps the
+// loop rolled and the arrays in scratch): not-taken compares while live, ONE taken branch at the first dead slot
+#define MC_FOR_LIVE(NL, BODY)                                                                      \
+    do {                                                                                           \
+        if ((NL) <= 0) break; BODY(0)  if ((NL) <= 1) break; BODY(1)  if ((NL) <= 2) break; BODY(2)   \
+        if ((NL) <= 3) break; BODY(3)  if ((NL) <= 4) break; BODY(4)  if ((NL) <= 5) break; BODY(5)   \
+        if ((NL) <= 6) break; BODY(6)  if ((NL) <= 7) break; BODY(7)  if ((NL) <= 8) break; BODY(8)   \
+        if ((NL) <= 9) break; BODY(9)  if ((NL) <= 10) break; BODY(10) if ((NL) <= 11) break; BODY(11) \
+        if ((NL) <= 12) break; BODY(12)                                                            \
+    } while (0)
+
 // steps i = 64 SL .. min(64 SL + 63, m - 1); false = abort
 template <int RS, int SL>
-__device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m, int G, int gw, int cu, int wv,
+__device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], double (&r)[CPW], int m, int gw, int cu, int wv,
                                              BidiagLds<RS>& L, rsrc_t rs, double* __restrict__ vws,
                                              double* __restrict__ taup, unsigned long long* dbg) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int NW = 4 * G;
     const int i_end = min(64 * SL + 64, m);
     MC_STAMP_DECL
     for (int i = 64 * SL; i < i_end; ++i) {
@@ -206,139 +244,107 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m,
         const int li = i & 63;
         const unsigned tag = (unsigned)i + 1u;
         const unsigned par = (unsigned)i & 1u;
-        // ---- 1. row i of my live columns (wave-uniform), my share of |row_i|^2 and of q = A[:, c > i] row_i
-        double r[CPW];
+        // my columns, kept in REVERSE order (register slot j holds column (CPW-1-j) NW + gw), so that the live ones
+        // (c > i) are the slots j < nlive: the loops below leave at the first dead slot -- one taken branch
+        const int nlive = CPW - ((i >= gw) ? (i - gw) / NW + 1 : 0);  // uniform
+        // ---- 1. row i of my live columns (wave-uniform values, kept in VGPRs: the SGPR file is the scarce one),
+        //         my share of |row_i|^2 and of q = A[:, c > i] row_i
         double ssp = 0.0;
         double qp[RS];
 #pragma unroll
         for (int s = 0; s < RS; ++s) qp[s] = 0.0;
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            r[j] = 0.0;
-            if (j * NW + gw > i) {                                  // uniform
-                double rj = rdlane(a[j][SL], li);
-                asm volatile("" : "+v"(rj));                          // lives in a VGPR (the SGPR file is the scarce one)
-                r[j] = rj;
-                ssp = fma(rj, rj, ssp);
-#pragma unroll
-                for (int s = SL; s < RS; ++s) qp[s] = fma(a[j][s], rj, qp[s]);
-            }
+#define MC_ROWQ(J)                                                                         \
+        {                                                                                  \
+            double rj_ = rdlane(a[J][SL], li);                                             \
+            asm volatile("" : "+v"(rj_));                                                  \
+            r[J] = rj_;                                                                    \
+            ssp = fma(rj_, rj_, ssp);                                                      \
+            _Pragma("unroll") for (int s = SL; s < RS; ++s) qp[s] = fma(a[J][s], rj_, qp[s]); \
         }
+        MC_FOR_LIVE(nlive, MC_ROWQ);
+#undef MC_ROWQ
         MC_STAMP(1);
-        // ---- 2. combine inside the workgroup (LDS); the owner of column i hands it to the publishers
+        // ---- 2. combine inside the workgroup (LDS); the owner of column i hands it over
 #pragma unroll
         for (int s = SL; s < RS; ++s) L.lq[wv][s * 64 + lane] = qp[s];
         if (lane == 0) L.lss[wv] = ssp;
         const int gwi = i % NW;                                     // uniform: the wave that owns column i
         if (gw == gwi) {
-            const int ji = i / NW;
-#pragma unroll
-            for (int s = SL; s < RS; ++s) {
-                double cv = 0.0;
-#pragma unroll
-                for (int j = 0; j < CPW; ++j) cv = (j == ji) ? a[j][s] : cv;
-                L.lcp[s * 64 + lane] = cv;
+#define MC_COLI(J) case J: { _Pragma("unroll") for (int s = SL; s < RS; ++s) L.lcp[s * 64 + lane] = a[CPW - 1 - J][s]; } break;
+            switch (i / NW) {
+                MC_COLI(0) MC_COLI(1) MC_COLI(2) MC_COLI(3) MC_COLI(4) MC_COLI(5) MC_COLI(6)
+                MC_COLI(7) MC_COLI(8) MC_COLI(9) MC_COLI(10) MC_COLI(11) MC_COLI(12)
+                default: break;
             }
+#undef MC_COLI
         }
         MC_LDS_BARRIER();
         MC_STAMP(2);
-        // ---- 3. the exchange.  Waves 0-1 publish (two rows per thread), waves 2-3 poll (two rows per thread): a
-        //         wave's loads return behind its own older stores (one vmcnt queue), and a write-through store is
-        //         acknowledged from the memory side -- the pollers must not have any in flight.
-        if (wv < 2) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = tid + 128 * h;
-                if (row > i && row < 64 * RS) {
-                    const double qc = ((L.lq[0][row] + L.lq[1][row]) + L.lq[2][row]) + L.lq[3][row];
-                    put_granule(rs, OFF_Q + ((par * GMAX + (unsigned)cu) * 256u + (unsigned)row) * 16u, qc, tag);
-                }
-                if (cu == (gwi >> 2) && row >= i && row < 64 * RS)
-                    put_granule(rs, OFF_C + (par * 256u + (unsigned)row) * 16u, L.lcp[row], tag);
-            }
-            if (tid == 0) {
-                const double sc = ((L.lss[0] + L.lss[1]) + L.lss[2]) + L.lss[3];
-                put_granule(rs, OFF_S + (par * 16u + (unsigned)cu) * 16u, sc, tag);
-            }
-        } else {
-            const int t2 = tid - 128;
-            unsigned rowh[2];
-            bool mine[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = t2 + 128 * h;
-                mine[h] = row > i && row < 64 * RS;
-                rowh[h] = mine[h] ? (unsigned)row : (unsigned)i;
-            }
-            unsigned spins = 0;
-            bool ok;
-            double sst = 0.0, alpha = 0.0, qt[2], ct[2];
-            for (;;) {
-                u32x4 gs[GMAX], ga, gq[2][GMAX], gc[2];
-#pragma unroll
-                for (int g = 0; g < GMAX; ++g) gs[g] = load_granule(rs, OFF_S + (par * 16u + (unsigned)min(g, G - 1)) * 16u);
-                ga = load_granule(rs, OFF_C + (par * 256u + (unsigned)i) * 16u);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
+        // ---- 3. the exchange: thread t > i owns row t (publishes this CU's partial q_t, gathers the nine partials
+        //         and column i's entry), thread i carries the partial norms in the slot of the (finished) row i and
+        //         the diagonal entry A[i][i]; measured forms: scripts/xcd_exchange_probe.hip
+        {
+            const bool mine = tid >= i && tid < 64 * RS;
+            bool ok = true;
+            if (mine) {
+                double pv;
+                if (tid == i) pv = ((L.lss[0] + L.lss[1]) + L.lss[2]) + L.lss[3];
+                else pv = ((L.lq[0][tid] + L.lq[1][tid]) + L.lq[2][tid]) + L.lq[3][tid];
+                put_granule(rs, OFF_Q + ((par * GMAX + (unsigned)cu) * 256u + (unsigned)tid) * 16u, pv, tag);
+                if (cu == (gwi >> 2)) put_granule(rs, OFF_C + (par * 256u + (unsigned)tid) * 16u, L.lcp[tid], tag);
+                unsigned spins = 0;
+                double qt = 0.0, ct = 0.0;
+                for (;;) {
+                    u32x4 gq[GMAX], gc;
 #pragma unroll
                     for (int g = 0; g < GMAX; ++g)
-                        gq[h][g] = load_granule(rs, OFF_Q + ((par * GMAX + (unsigned)min(g, G - 1)) * 256u + rowh[h]) * 16u);
-                    gc[h] = load_granule(rs, OFF_C + (par * 256u + rowh[h]) * 16u);
-                }
-                ok = granule_ok(ga, tag);
-                sst = 0.0;
-#pragma unroll
-                for (int g = 0; g < GMAX; ++g) {
-                    ok &= granule_ok(gs[g], tag);
-                    sst += (g < G) ? granule_val(gs[g]) : 0.0;
-                }
-                alpha = granule_val(ga);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    bool okh = granule_ok(gc[h], tag);
-                    qt[h] = 0.0;
+                        gq[g] = load_granule(rs, OFF_Q + ((par * GMAX + (unsigned)g) * 256u + (unsigned)tid) * 16u);
+                    gc = load_granule(rs, OFF_C + (par * 256u + (unsigned)tid) * 16u);
+                    ok = granule_ok(gc, tag);
+                    qt = 0.0;
 #pragma unroll
                     for (int g = 0; g < GMAX; ++g) {
-                        okh &= granule_ok(gq[h][g], tag);
-                        qt[h] += (g < G) ? granule_val(gq[h][g]) : 0.0;
+                        ok &= granule_ok(gq[g], tag);
+                        qt += granule_val(gq[g]);
                     }
-                    ct[h] = granule_val(gc[h]);
-                    ok &= okh | !mine[h];
+                    ct = granule_val(gc);
+                    if (__all(ok)) break;
+                    if (spin_fail(rs, spins, 0x100u + (unsigned)i)) break;
+                    asm volatile("" ::: "memory");
                 }
-                if (__all(ok)) break;
-                if (spin_fail(rs, spins, 0x100u + (unsigned)i)) break;
-                asm volatile("" ::: "memory");
+                L.lqt[tid] = qt;
+                L.lcol[tid] = ct;
+                if (tid == i) { L.lsc[0] = qt; L.lsc[1] = ct; }
+                if (!ok) L.ldead = 1;
             }
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                if (mine[h]) { L.lqt[rowh[h]] = qt[h]; L.lcol[rowh[h]] = ct[h]; }
-            if (t2 == 0) { L.lsc[0] = sst; L.lsc[1] = alpha; }
-            if (!__all(ok) && lane == 0) L.ldead = 1;
         }
         MC_STAMP(3);
         MC_LDS_BARRIER();
         MC_STAMP(4);
         if (L.ldead) return false;
         const double sst = L.lsc[0], alpha = L.lsc[1];
-        // ---- 4. G(i): every wave for itself
+        // ---- 4. G(i): every wave for itself; r <- v = row_i * scal
         double beta, tau, scal;
         larfg(alpha, sst, beta, tau, scal);
+#define MC_VSCALE(J) r[J] *= scal;
+        MC_FOR_LIVE(nlive, MC_VSCALE);
+#undef MC_VSCALE
         if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < CPW; ++j) {
-                const int c = j * NW + gw;
-                if (c > i && c < N) vws[(size_t)i * NS + c] = r[j] * scal;
-            }
+            double* vrow = vws + (size_t)i * NS + gw;
+            // (slot 0 = column 432 + gw, which exists for gw < 16 only)
+#define MC_VSTORE(J) if (J > 0 || gw < NS - (CPW - 1) * NW) vrow[(CPW - 1 - J) * NW] = r[J];
+            MC_FOR_LIVE(nlive, MC_VSTORE);
+#undef MC_VSTORE
             if (gw == 0) taup[i] = tau;
         }
-        if (i == m - 1) { MC_STAMP_FLUSH(dbg, (blockIdx.x * 4 + wv) * 4 + SL); return true; }
+        if (i == m - 1) { MC_STAMP_FLUSH(dbg, (cu * 4 + wv) * 4 + SL); return true; }
         MC_STAMP(5);
         double tw[RS], nc[RS], w[RS];
 #pragma unroll
         for (int s = SL; s < RS; ++s) {
             const int row = s * 64 + lane;
             const double q = L.lqt[row], c0 = L.lcol[row];
-            const bool live = row > i && row < 64 * RS;
+            const bool live = row > i;
             const double ws = live ? fma(scal, q, c0) : 0.0;        // w = A[:, i:] [1; v]  (rows > i)
             w[s] = ws;
             nc[s] = live ? fma(-tau, ws, c0) : 0.0;                 // column i after G(i)
@@ -372,15 +378,14 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m,
         MC_STAMP(6);
         // ---- 6. z_c = u^T A[:, c] for my live columns: per-lane partials, transposed through the wave's LDS tile
         double* tr = L.ltr[wv];
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            if (j * NW + gw > i) {                                  // uniform
-                double zp = 0.0;
-#pragma unroll
-                for (int s = SL; s < RS; ++s) zp = fma(u[s], a[j][s], zp);
-                tr[lane * 17 + j] = zp;
-            }
+#define MC_ZPART(J)                                                                        \
+        {                                                                                  \
+            double zp_ = 0.0;                                                              \
+            _Pragma("unroll") for (int s = SL; s < RS; ++s) zp_ = fma(u[s], a[J][s], zp_); \
+            tr[lane * 17 + J] = zp_;                                                       \
         }
+        MC_FOR_LIVE(nlive, MC_ZPART);
+#undef MC_ZPART
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         double acc = 0.0;
@@ -394,44 +399,49 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], int N, int m,
         MC_STAMP(7);
         // ---- 7. both rank-1 updates fused: A <- A - tau w [1; v]^T - tauq u z'^T,  z' = z - tau (u^T w) [1; v]
         const double tuw = tau * uw;
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            if (j * NW + gw > i) {                                  // uniform
-                const double vj = r[j] * scal;
-                const double zj = fma(-tuw, vj, rdlane(acc, j));
-#pragma unroll
-                for (int s = SL; s < RS; ++s) a[j][s] = fma(-tu[s], zj, fma(-tw[s], vj, a[j][s]));
-            }
+#define MC_UPDATE(J)                                                                       \
+        {                                                                                  \
+            const double zj_ = fma(-tuw, r[J], rdlane(acc, J));                            \
+            _Pragma("unroll") for (int s = SL; s < RS; ++s) a[J][s] = fma(-tu[s], zj_, fma(-tw[s], r[J], a[J][s])); \
         }
+        MC_FOR_LIVE(nlive, MC_UPDATE);
+#undef MC_UPDATE
         MC_STAMP(8);
     }
-    MC_STAMP_FLUSH(dbg, (blockIdx.x * 4 + wv) * 4 + SL);
+    MC_STAMP_FLUSH(dbg, (cu * 4 + wv) * 4 + SL);
     return true;
 }
 
 template <int RS>
-__global__ __launch_bounds__(256) void k_mc_bidiag(const double* __restrict__ X, int ldx, int N, int m, int G,
+__global__ __launch_bounds__(256) void k_mc_bidiag(const double* __restrict__ X, int ldx, int N, int m,
                                                    double* __restrict__ vws, double* __restrict__ taup, void* comm,
                                                    unsigned cbytes, unsigned long long* dbg) {
     __shared__ BidiagLds<RS> L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cu = blockIdx.x, NW = 4 * G, gw = cu * 4 + wv;
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
-    double a[CPW][RS];
+    if (tid == 0) L.ldead = elect(comm, OFF_EL_B, GMAX, rs);
+    __syncthreads();
+    const int cu = __builtin_amdgcn_readfirstlane(L.ldead);
+    if (cu < 0) return;
+    __syncthreads();
+    const int gw = cu * 4 + wv;
+    double a[CPW][RS], r[CPW];
 #pragma unroll
-    for (int j = 0; j < CPW; ++j)
+    for (int j = 0; j < CPW; ++j) {
+        r[j] = 0.0;
 #pragma unroll
         for (int s = 0; s < RS; ++s) {
-            const int row = s * 64 + lane, c = j * NW + gw;
+            const int row = s * 64 + lane, c = (CPW - 1 - j) * NW + gw;      // reverse order: bidiag_steps
             a[j][s] = (c < N && row < m) ? ((row == 0) ? 1.0 : X[(size_t)c * ldx + (row - 1)]) : 0.0;
         }
+    }
     if (tid == 0) L.ldead = 0;
     __syncthreads();
-    bool ok = bidiag_steps<RS, 0>(a, N, m, G, gw, cu, wv, L, rs, vws, taup, dbg);
-    if constexpr (RS > 1) { if (ok && m > 64) ok = bidiag_steps<RS, 1>(a, N, m, G, gw, cu, wv, L, rs, vws, taup, dbg); }
-    if constexpr (RS > 2) { if (ok && m > 128) ok = bidiag_steps<RS, 2>(a, N, m, G, gw, cu, wv, L, rs, vws, taup, dbg); }
-    if constexpr (RS > 3) { if (ok && m > 192) ok = bidiag_steps<RS, 3>(a, N, m, G, gw, cu, wv, L, rs, vws, taup, dbg); }
+    bool ok = bidiag_steps<RS, 0>(a, r, m, gw, cu, wv, L, rs, vws, taup, dbg);
+    if constexpr (RS > 1) { if (ok && m > 64) ok = bidiag_steps<RS, 1>(a, r, m, gw, cu, wv, L, rs, vws, taup, dbg); }
+    if constexpr (RS > 2) { if (ok && m > 128) ok = bidiag_steps<RS, 2>(a, r, m, gw, cu, wv, L, rs, vws, taup, dbg); }
+    if constexpr (RS > 3) { if (ok && m > 192) ok = bidiag_steps<RS, 3>(a, r, m, gw, cu, wv, L, rs, vws, taup, dbg); }
 }
 
 // ================================================================================================================
@@ -666,12 +676,17 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
                                                   const double* __restrict__ mu_in, int32_t* __restrict__ keep_rank,
                                                   double* __restrict__ w_star, int32_t* __restrict__ n_keep_out,
                                                   double* __restrict__ mu_out, void* comm, unsigned cbytes) {
+    __shared__ int lcu;
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
+    if (threadIdx.x == 0) lcu = elect(comm, OFF_EL_P, PWAVES / 4, rs);
+    __syncthreads();
+    const int cu = __builtin_amdgcn_readfirstlane(lcu);
+    if (cu < 0) return;
+    const int gw = cu * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int K = N - m;
     const int c0 = gw * BC;
     if (c0 >= K && gw != 0) return;
-    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
     double phi[BC][NQ];
     PivState st;
 #pragma unroll
@@ -774,24 +789,24 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
     double* PhiT = taup + 256;
     unsigned long long* dbg = (unsigned long long*)(PhiT + (size_t)KMAX * NS);
     HIP_TRY(hipMemsetAsync(ws, 0, (size_t)cbytes, st));
-    const int G = (N + 4 * CPW - 1) / (4 * CPW);
+    const int G = ELECT_GRID;
     const int RS = (m + 63) / 64;
     switch (RS) {
         case 1:
         case 2:
-            hipLaunchKernelGGL(k_mc_bidiag<2>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes, dbg);
+            hipLaunchKernelGGL(k_mc_bidiag<2>, dim3(G), dim3(256), 0, st, X, ldx, N, m, vws, taup, ws, cbytes, dbg);
             break;
         case 3:
-            hipLaunchKernelGGL(k_mc_bidiag<3>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes, dbg);
+            hipLaunchKernelGGL(k_mc_bidiag<3>, dim3(G), dim3(256), 0, st, X, ldx, N, m, vws, taup, ws, cbytes, dbg);
             break;
         default:
-            hipLaunchKernelGGL(k_mc_bidiag<4>, dim3(G), dim3(256), 0, st, X, ldx, N, m, G, vws, taup, ws, cbytes, dbg);
+            hipLaunchKernelGGL(k_mc_bidiag<4>, dim3(G), dim3(256), 0, st, X, ldx, N, m, vws, taup, ws, cbytes, dbg);
             break;
     }
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mc_phi, dim3((K + 3) / 4), dim3(256), 0, st, vws, taup, N, m, PhiT, phi_out);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_mc_pivot, dim3(PWAVES / 4), dim3(256), 0, st, PhiT, N, m, mu_in, keep_rank, w_star, n_keep,
+    hipLaunchKernelGGL(k_mc_pivot, dim3(ELECT_GRID), dim3(256), 0, st, PhiT, N, m, mu_in, keep_rank, w_star, n_keep,
                        mu_out, ws, cbytes);
     LAUNCH_CHECK();
     return 0;
