@@ -27,3 +27,15 @@ for role, sel in (("waves 0-1", [w for w in range(G * 4) if w % 4 < 2]),
                   ("waves 2-3", [w for w in range(G * 4) if w % 4 >= 2])):
     t = tot[sel].mean(0) / m
     print(role, " ".join("%s %.0f" % (n, v) for n, v in zip(names, t[:9])), "| sum %.0f" % t[:9].sum())
+# pivot kernel: per wave [256 + gw][12]
+pn = ["p.mask", "p.ratio", "p.publish", "p.mu+elim+rot", "c.loop", "c.wait", "c.handover", "c.apply"]
+dp = dbg[256 * 12:(256 + 32) * 12].reshape(32, 12)
+K = N - m
+print("pivot kernel, cycles per wave (sum over its pivots); chain = sum of produce + hand-over waits")
+for w in (0, 1, 2, 8, 16, 24):
+    if w * 8 < K:
+        print("wave %2d " % w + " ".join("%s %.0f" % (n, v) for n, v in zip(pn, dp[w][:8])))
+nb = (K + 7) // 8
+prod = dp[:nb, :4].sum()
+hand = dp[1:nb, 6].sum()
+print("blocks %d: produce total %.0f cycles (%.0f per pivot), hand-over waits %.0f (%.0f per block)" % (nb, prod, prod / K, hand, hand / max(nb - 1, 1)))

@@ -13,12 +13,14 @@
 //                computed redundantly by every wave, z = u^T A is local to the owner of a column (a wave-level
 //                transposed reduction through a private LDS tile), and the two rank-1 updates are fused.
 //                The exchange uses data-tagged granules (cdna_hip_programming.md Guideline 16, form R2): a double
-//                travels as two 8-byte {32 data bits, 32-bit tag = step + 1} words in one 16-byte write-through (sc1)
-//                store, the reader polls the granule itself with sc1 loads until both tags match -- no flag, no
-//                fence, no placement assumption.  Two slots alternate (a slot is rewritten at step i + 2, and nobody
-//                can publish step i + 1 before it has finished reading step i).
+//                travels as two 8-byte {32 data bits, 32-bit tag = step + 1} words in one 16-byte store, the reader
+//                polls the granule itself with L1-bypassing (sc1) loads until both tags match -- no flag, no fence.
+//                The nine workgroups are ELECTED ONTO ONE XCD (elect(): XCC id from the hardware register + a ticket
+//                per XCD), so the stores are plain stores into the L2 all workers share: an exchange costs 0.9 us
+//                instead of 1.4-1.5 us through the fabric (scripts/xcd_exchange_probe.hip).  Two slots alternate (a
+//                slot is rewritten at step i + 2, and nobody can publish step i + 1 before it has read step i).
 //   k_mc_phi     Phi = P [0; I]: one wave per column, backward accumulation (as k_car_phi, 7 row slots).
-//   k_mc_pivot   the N - m pivots of :237-266 as a streaming pipeline of 32 independent waves (no barrier at all):
+//   k_mc_pivot   the N - m pivots of :237-266 as a streaming pipeline of 32 independent waves on one XCD (no barrier):
 //                a wave owns 8 consecutive columns of Phi (lane <-> row, 7 slots); it applies the published pivots
 //                (column, index, alpha, 1 / Phi[idx, 0]) to its columns in order as they arrive, and when the next
 //                pivot column is its own it runs the ratio test and publishes.  Inside a block of 8 pivots there is
@@ -616,8 +618,8 @@ __device__ __forceinline__ bool consume(rsrc_t rs, int s, int lane, double (&col
     const unsigned hoff = OFF_H + (unsigned)s * 64u;
     const unsigned coff = OFF_P + ((unsigned)s * NS + (unsigned)lane) * 16u;
     unsigned spins = 0;
-    for (;;) {                                                        // sentinel: the index word (stored last)
-        const u32x4 g = load_granule(rs, hoff + 32u);
+    for (;;) {                                                        // light spin: the index word (stored last); 31
+        const u32x4 g = load_granule(rs, hoff + 32u);                 // waves polling whole columns slow the producer
         if (__all(granule_ok(g, tag))) break;
         if (spin_fail(rs, spins, 0x400u + (unsigned)s)) return false;
         asm volatile("" ::: "memory");
@@ -627,14 +629,13 @@ __device__ __forceinline__ bool consume(rsrc_t rs, int s, int lane, double (&col
         u32x4 gc[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) gc[q] = load_granule(rs, coff + (unsigned)q * 1024u);
-        bool ok = granule_ok(h0, tag) && granule_ok(h1, tag) && granule_ok(h2, tag);
-        alpha = granule_val(h0); rpp = granule_val(h1); piv = (int)granule_val(h2);
-        if (piv < 0) { if (__all(ok)) return true; }
-        else {
+        const bool okh = granule_ok(h0, tag) && granule_ok(h1, tag) && granule_ok(h2, tag);
+        alpha = granule_val(h0); rpp = granule_val(h1);
+        piv = okh ? (int)granule_val(h2) : 0;
+        bool ok = okh;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { ok &= granule_ok(gc[q], tag); col[q] = granule_val(gc[q]); }
-            if (__all(ok)) return true;
-        }
+        for (int q = 0; q < NQ; ++q) { ok &= granule_ok(gc[q], tag) | (piv < 0); col[q] = granule_val(gc[q]); }
+        if (__all(ok)) return true;
         if (spin_fail(rs, spins, 0x500u + (unsigned)s)) return false;
         asm volatile("" ::: "memory");
     }
@@ -656,26 +657,47 @@ __device__ __forceinline__ void publish(rsrc_t rs, int s, int lane, const double
     }
 }
 
-// my column JL is the next pivot column: ratio test, publish, update the weights and my later columns
-template <int JL>
-__device__ __forceinline__ bool produce(double (&phi)[BC][NQ], PivState& st, rsrc_t rs, int s, int lane) {
+// my next column (register slot 0) is the pivot column: ratio test, publish, update the weights and my later
+// columns, then the slots move down by one.  A LOOP body on purpose: written out per column the kernel is 16 copies
+// of the ratio test, every one executed once and fetched cold.
+#ifdef MC_STAMPS
+#define MC_PSTAMP_ARGS , unsigned long long (&acc_)[12], unsigned long long& tl_
+#define MC_PSTAMP_PASS , acc_, tl_
+#else
+#define MC_PSTAMP_ARGS
+#define MC_PSTAMP_PASS
+#endif
+__device__ __forceinline__ bool produce(double (&phi)[BC][NQ], PivState& st, rsrc_t rs, int s, int lane MC_PSTAMP_ARGS) {
     double col[NQ];
+    MC_STAMP(0);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[JL][q];
+    for (int q = 0; q < NQ; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[0][q];
     int piv;
     double al, rp;
+    // (a reciprocal-based pre-selection with exact division for the winner only was measured slower: 302 vs 257 us
+    //  at 200 pivots -- the seven IEEE divisions pipeline well, the extra selection logic does not)
     ratio_test(col, st, piv, al, rp);
+    MC_STAMP(1);
     publish(rs, s, lane, col, al, rp, piv);
+    MC_STAMP(2);
     if (piv < 0) return false;                                        // Q6: the loop ends here (:241-242)
     mu_step(st, col, al, piv, lane);
-    if constexpr (JL + 1 < BC) elim<JL + 1>(phi, col, piv, rp);
+    elim<1>(phi, col, piv, rp);                                       // (consumed slots hold zeros and stay zero)
+#pragma unroll
+    for (int j = 0; j + 1 < BC; ++j)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) phi[j][q] = phi[j + 1][q];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) phi[BC - 1][q] = 0.0;
+    MC_STAMP(3);
     return true;
 }
 
 __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ PhiT, int N, int m,
                                                   const double* __restrict__ mu_in, int32_t* __restrict__ keep_rank,
                                                   double* __restrict__ w_star, int32_t* __restrict__ n_keep_out,
-                                                  double* __restrict__ mu_out, void* comm, unsigned cbytes) {
+                                                  double* __restrict__ mu_out, void* comm, unsigned cbytes,
+                                                  unsigned long long* dbg) {
     __shared__ int lcu;
     const int lane = threadIdx.x & 63;
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
@@ -700,6 +722,7 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
     }
     bool fail = load_err(rs) != 0u;                                   // the bidiagonalisation gave up
     bool stop = false;
+    MC_STAMP_DECL
     double col[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) col[q] = 0.0;
@@ -707,20 +730,22 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
     for (int s = 0; s < min(c0, K) && !fail && !stop; ++s) {
         double al, rp;
         int piv;
+        MC_STAMP(4);
         if (!consume(rs, s, lane, col, al, rp, piv)) { fail = true; break; }
+        if (s + 1 == min(c0, K)) MC_STAMP(6); else MC_STAMP(5);       // 6: the wait for the hand-over
         if (piv < 0) { stop = true; break; }
         mu_step(st, col, al, piv, lane);
         elim<0>(phi, col, piv, rp);
+        MC_STAMP(7);
     }
     // my block
     if (!fail && !stop && c0 < K) {
         bool go = true;
-#define MC_PRODUCE(JL) if (go && c0 + JL < K) go = produce<JL>(phi, st, rs, c0 + JL, lane);
-        MC_PRODUCE(0) MC_PRODUCE(1) MC_PRODUCE(2) MC_PRODUCE(3)
-        MC_PRODUCE(4) MC_PRODUCE(5) MC_PRODUCE(6) MC_PRODUCE(7)
-#undef MC_PRODUCE
+        const int s_end = min(c0 + BC, K);
+        for (int sp = c0; sp < s_end && go; ++sp) go = produce(phi, st, rs, sp, lane MC_PSTAMP_PASS);
         stop = !go;
     }
+    MC_STAMP_FLUSH(dbg, 256 + gw);
     if (gw != 0) return;
     // wave 0 follows the remaining pivots for the weights and writes the result
     for (int s = c0 + BC; s < K && !fail && !stop; ++s) {
@@ -807,7 +832,7 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
     hipLaunchKernelGGL(k_mc_phi, dim3((K + 3) / 4), dim3(256), 0, st, vws, taup, N, m, PhiT, phi_out);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mc_pivot, dim3(ELECT_GRID), dim3(256), 0, st, PhiT, N, m, mu_in, keep_rank, w_star, n_keep,
-                       mu_out, ws, cbytes);
+                       mu_out, ws, cbytes, dbg);
     LAUNCH_CHECK();
     return 0;
 }
