@@ -1,0 +1,68 @@
+"""`Sober` with the reference's constructor and `next_batch` (SOBER/_sober.py:9-195) for the recombination hot
+path: pi = `sober_amd.PI` (LFI weights over the pool), kernel = `sober_amd.Kernel`, the candidate funnel of
+`sober_amd.EmpiricalSampler`, `sampling_recombination` -> HIP.  What the reference does AROUND the path stays with
+the reference: GP fitting, the FBGP / BQ model families (`PI_FBGP`, `PI_BQ`), prior updates and WKDE refits
+(`_prior_update.py`).  A continuous/mixed prior therefore needs the caller's `prior_updater` (any callable
+`(sampler, X, weights) -> None`, e.g. the reference's `update_prior` bound to its own prior classes); the dataset
+prior (`prior.type == "dataset"`) needs nothing else."""
+import torch
+
+from ._kernel import Kernel
+from ._pi import PI
+from ._sampler import EmpiricalSampler
+
+
+class Sober(EmpiricalSampler):
+    def __init__(self, prior, model, thresh=5, sampler_type="lfi", kernel_type="predictive_covariance",
+                 dataset_pruning=True, prior_updater=None):
+        """SOBER/_sober.py:10-39."""
+        self.sampler_type = sampler_type
+        self.kernel_type = kernel_type
+        self.dataset_pruning = dataset_pruning
+        self.check_model_type(model)
+        pi, kernel = self.initialisation(model)
+        self.n_batches_until_reset = 3
+        super().__init__(prior, pi, kernel, thresh=thresh, label=prior.type, dataset_pruning=dataset_pruning,
+                         prior_updater=prior_updater)
+
+    def check_model_type(self, model):
+        """SOBER/_sober.py:41-54.  The fully Bayesian and the BQ model families are outside this path."""
+        if hasattr(model, "is_fbgp") or hasattr(model, "is_bq"):
+            raise NotImplementedError(
+                "sober_amd.Sober covers exact-GP models; FBGP / BQ models bring their own kernel callable "
+                "(marginal_predictive_covariance / gspace_kernel): pass it to sober_amd.RecombinationSampler")
+        self.fbgp = False
+        self.is_bq = False
+        targets = getattr(model, "train_targets", None)
+        self.n_init = len(targets) if targets is not None else 0
+
+    def initialisation(self, model):
+        """SOBER/_sober.py:56-72."""
+        return PI(model, label=self.sampler_type), Kernel(model, mode=self.kernel_type)
+
+    def update_model(self, model):
+        """SOBER/_sober.py:74-82."""
+        self.pi, self.kernel = self.initialisation(model)
+
+    def next_batch(self, n_rec, n_nys, batch_size, calc_obj=None, return_weights=False, recycle_prior=True,
+                   verbose=False):
+        """SOBER/_sober.py:125-195: candidates + Nystrom sample + weights -> recombination -> one of the
+        reference's three return shapes: (w_rchq, X_batch) | (idx_rchq, X_batch) for a dataset prior (indices
+        into the prior's available rows when pruning is on) | X_batch."""
+        if not self.label == "dataset":
+            X_cand, X_nys, weights = self.sampling_candidates(n_rec, n_nys, verbose=verbose)
+        else:
+            empirical_measure = self.sampling_datasets(n_rec, n_nys)
+            if self.dataset_pruning:
+                idx_sampled, X_cand, X_nys, weights = empirical_measure
+            else:
+                X_cand, X_nys, weights = empirical_measure
+        idx_rchq, w_rchq = self.sampling_recombination(X_cand, X_nys, weights, batch_size, calc_obj=calc_obj)
+        X_batch = X_cand[idx_rchq]
+        if return_weights:
+            return w_rchq, X_batch
+        elif self.label == "dataset":
+            if self.dataset_pruning:
+                idx_rchq = idx_sampled[idx_rchq]
+            return idx_rchq, X_batch
+        return X_batch

@@ -13,6 +13,9 @@ class WeightsStabiliser:
         SOBER/_weights.py:7)."""
         self.eps_weights = eps
         self.thresh = thresh
+        # True: the random draws of weighted_resampling come from the CPU generator on a host copy of the weights,
+        # i.e. the stream the reference consumes when it runs on the CPU (parity tests; one small D2H copy)
+        self.reference_stream = False
 
     def cleansing_weights(self, weights):
         """SOBER/_weights.py:21-38, in place on the device."""
@@ -38,7 +41,10 @@ class WeightsStabiliser:
         """SOBER/_weights.py:57-77 (torch.multinomial: RNG-defined, stays in torch)."""
         n_positive_weights = (weights > 0).sum()
         if n_positive_weights > n_nys:
-            idx_nys = torch.multinomial(weights, n_nys)
+            if getattr(self, "reference_stream", False):
+                idx_nys = torch.multinomial(weights.cpu(), n_nys).to(weights.device)
+            else:
+                idx_nys = torch.multinomial(weights, n_nys)
         else:
             idx_positive = torch.arange(len(weights), device=weights.device)[weights > 0]
             idx_rand = torch.randperm(len(weights))[:int(n_nys - n_positive_weights)].to(weights.device)

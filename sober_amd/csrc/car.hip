@@ -100,15 +100,40 @@ __device__ __forceinline__ unsigned long long ratio_key(double x) {
     return (x != x) ? 0ull : k;
 }
 
-// dlarfg: reflector H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2
+// dlarfg: reflector H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2, v = x * scal.
+// v_rsq_f64 / v_rcp_f64 seeds + Newton steps (<= 1 ulp) instead of the IEEE sqrt and the two IEEE divisions: a third
+// of the dependent chain that sits on the critical path of every step, and no branch (a taken branch costs a single
+// resident wave 50-80 cycles of instruction fetch); operands far outside the normal range are rescaled with selects
+__device__ __forceinline__ double car_rcp(double c) {
+    double r = __builtin_amdgcn_rcp(c);
+    double e = fma(-c, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-c, r, 1.0);
+    return fma(r, e, r);
+}
 __device__ __forceinline__ void larfg(double alpha, double ss, double& beta, double& tau, double& scal) {
-    if (ss == 0.0) {
-        beta = alpha; tau = 0.0; scal = 0.0;
-    } else {
-        beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
-        tau = (beta - alpha) / beta;
-        scal = 1.0 / (alpha - beta);
-    }
+    const double n2r = fma(alpha, alpha, ss);
+    const bool tiny = n2r < 1e-200, huge = n2r > 1e200;
+    const double f = tiny ? 0x1p300 : (huge ? 0x1p-300 : 1.0), fi = tiny ? 0x1p-300 : (huge ? 0x1p300 : 1.0);
+    const double al = alpha * f;
+    const double n2 = fma(al, al, (ss * f) * f);
+    double r = __builtin_amdgcn_rsq(n2);
+    double h = 0.5 * r;
+    double e = fma(-(n2 * r), h, 0.5);
+    r = fma(r, e, r);
+    h = 0.5 * r;
+    e = fma(-(n2 * r), h, 0.5);
+    r = fma(r, e, r);
+    double nr = n2 * r;
+    nr = fma(fma(-nr, nr, n2), 0.5 * r, nr);
+    const double bs = -copysign(nr, al);
+    const double ib = car_rcp(bs);
+    double t = (bs - al) * ib;
+    t = fma(fma(-t, bs, bs - al), ib, t);
+    const bool none = ss == 0.0;
+    beta = none ? alpha : bs * fi;
+    tau = none ? 0.0 : t;
+    scal = none ? 0.0 : car_rcp(al - bs) * f;
 }
 
 // ratio-test combine, branch-free (selects only): first argmin, a NaN ratio wins (torch.argmin);

@@ -517,12 +517,110 @@ def gen_pruning(ref):
     np.savez_compressed(os.path.join(HERE, "pruning.npz"), **out)
 
 
+def load_sampler_sober(ref):
+    """SOBER/_sampler.py and SOBER/_sober.py from their own files.  The prior machinery around the path (`_prior.py`,
+    `_prior_update.py`: truncated MVNs, WKDE refits) is not under test: empty stand-ins for the import lines, and
+    `update_continuous_prior` keeps the prior as it is."""
+    ref["_pi"].torch = torch                       # _pi.py uses torch without importing it (SURVEY 2)
+    prior = types.ModuleType("SOBER._prior")
+    for n in ("Uniform", "BinaryPrior", "CategoricalPrior", "MixedBinaryPrior", "MixedCategoricalPrior"):
+        setattr(prior, n, type(n, (), {}))
+    sys.modules["SOBER._prior"] = prior
+    upd = types.ModuleType("SOBER._prior_update")
+    upd.update_mixed_prior = upd.update_binary_prior = upd.update_categorical_prior = None
+    upd.update_continuous_prior = lambda X, w, prior, n_dims: prior
+    sys.modules["SOBER._prior_update"] = upd
+    for name in ("PI_FBGP", "PI_BQ"):              # imported by name in _sober.py (other model families)
+        if not hasattr(ref["_pi"], name):
+            setattr(ref["_pi"], name, None)
+    for name in ("_sampler", "_sober"):
+        spec = importlib.util.spec_from_file_location(f"SOBER.{name}", f"{REF}/{name}.py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f"SOBER.{name}"] = m
+        spec.loader.exec_module(m)
+        ref[name] = m
+    return ref
+
+
+class DatasetPrior:
+    type = "dataset"
+
+    def __init__(self, X):
+        self.X = X
+
+    def available_candidates(self):
+        return self.X
+
+
+class UniformPrior:
+    """Unit-cube prior with the three members `sampling_candidates` touches; draws on the CPU generator."""
+    type = "continuous"
+
+    def __init__(self, d, device=None):
+        self.n_dims, self.device = d, device
+        self.bounds = torch.stack([torch.zeros(d, dtype=torch.double), torch.ones(d, dtype=torch.double)])
+
+    def sample(self, n):
+        x = torch.rand(n, self.n_dims, dtype=torch.double)
+        return x if self.device is None else x.to(self.device)
+
+    def pdf(self, X):
+        return torch.ones(len(X), dtype=torch.double, device=X.device)
+
+
+SOBER_CASES = {
+    "dataset": dict(kind=O.TANIMOTO, N=64, M=8, d=64, n_obs=20, seed=77, mean_const=0.2,
+                    kernel_type="weighted_predictive_covariance", pool_seed=3, pool_n=900, pool_p=0.1,
+                    n_rec=600, n_nys=40, batch=8, seed_call=123),
+    "continuous": dict(kind=O.RBF, N=64, M=8, d=3, n_obs=15, seed=78, mean_const=0.2,
+                       kernel_type="predictive_covariance", n_rec=1500, n_nys=48, batch=8, seed_call=321),
+}
+
+
+def sober_model(case):
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    model = DuckModel(spec)
+    model.train_targets = torch.zeros(case["n_obs"], dtype=torch.double)
+    return model, spec
+
+
+def gen_sober(ref):
+    """`Sober.next_batch` of SOBER/_sober.py:125-195 with its three return shapes: (w_rchq, X_batch) |
+    (idx_rchq, X_batch) on a dataset prior with and without pruning | X_batch on a sampled (continuous) prior."""
+    load_sampler_sober(ref)
+    out = {}
+    c = SOBER_CASES["dataset"]
+    rng = np.random.default_rng(c["pool_seed"])
+    pool = torch.from_numpy((rng.random((c["pool_n"], c["d"])) < c["pool_p"]).astype(np.float64))
+    model, _ = sober_model(c)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for pruning in (True, False):
+            for rw in (False, True):
+                sober = ref["_sober"].Sober(DatasetPrior(pool), model, kernel_type=c["kernel_type"],
+                                            dataset_pruning=pruning)
+                torch.manual_seed(c["seed_call"])
+                a, Xb = sober.next_batch(c["n_rec"], c["n_nys"], c["batch"], return_weights=rw)
+                tag = f"dataset_p{int(pruning)}_w{int(rw)}"
+                out[tag + "_first"], out[tag + "_X"] = a.numpy(), Xb.numpy()
+                print(tag, a.shape, Xb.shape)
+        c = SOBER_CASES["continuous"]
+        model, _ = sober_model(c)
+        sober = ref["_sober"].Sober(UniformPrior(c["d"]), model, kernel_type=c["kernel_type"])
+        torch.manual_seed(c["seed_call"])
+        Xb = sober.next_batch(c["n_rec"], c["n_nys"], c["batch"])
+        out["continuous_X"] = Xb.numpy()
+        print("continuous", Xb.shape)
+    np.savez_compressed(os.path.join(HERE, "sober_next_batch.npz"), **out)
+
+
 if __name__ == "__main__":
-    # python make_golden.py [recombination kmeans weights psd tanimoto kernel_calls pi wkde basq pruning]   (default: all)
+    # python make_golden.py [recombination kmeans weights psd tanimoto kernel_calls pi wkde basq pruning sober]   (default: all)
     ref = load_reference()
     gens = {"recombination": gen_recombination, "kmeans": gen_kmeans, "weights": gen_weights, "psd": gen_psd,
             "tanimoto": lambda ref: gen_tanimoto(), "kernel_calls": gen_kernel_calls, "pi": gen_pi,
-            "wkde": gen_wkde, "basq": gen_basq, "pruning": gen_pruning}
+            "wkde": gen_wkde, "basq": gen_basq, "pruning": gen_pruning, "sober": gen_sober}
     for name in (sys.argv[1:] or list(gens)):
         gens[name](ref)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))

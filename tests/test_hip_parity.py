@@ -308,6 +308,47 @@ def test_cleansing_weights_vs_golden(dev):
     assert idx.shape == (40,) and len(idx.unique()) == 40
 
 
+def test_sober_next_batch_vs_reference(dev):
+    """`sober_amd.Sober.next_batch` against the reference's `Sober.next_batch` (SOBER/_sober.py:125-195; fixture from
+    tests/golden/make_golden.py::gen_sober): the three return shapes, a dataset prior with and without pruning (pi
+    weights, pruning, scrubbing, 1/weight Nystrom draw, recombination all on the device) and a sampled continuous prior
+    (KMeans Nystrom subsample, SOBER/_sampler.py:316-320)."""
+    from tests.golden import make_golden as MG
+    z = np.load(os.path.join(GOLD, "sober_next_batch.npz"))
+
+    def model_for(c):
+        model, spec = MG.sober_model(c)
+        model.kernel_spec = sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs,
+                                                 spec.S_cache, spec.noise, spec.mean_const, spec.alpha)
+        return model
+
+    c = MG.SOBER_CASES["dataset"]
+    rng = np.random.default_rng(c["pool_seed"])
+    pool = _t((rng.random((c["pool_n"], c["d"])) < c["pool_p"]).astype(np.float64)).to(dev)
+    model = model_for(c)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for pruning in (True, False):
+            for rw in (False, True):
+                sober = sober_amd.Sober(MG.DatasetPrior(pool), model, kernel_type=c["kernel_type"],
+                                        dataset_pruning=pruning)
+                sober.reference_stream = True              # the reference's CPU draws (torch.multinomial)
+                torch.manual_seed(c["seed_call"])
+                a, Xb = sober.next_batch(c["n_rec"], c["n_nys"], c["batch"], return_weights=rw)
+                tag = f"dataset_p{int(pruning)}_w{int(rw)}"
+                if rw:
+                    np.testing.assert_allclose(a.cpu().numpy(), z[tag + "_first"], rtol=W_RTOL)
+                else:
+                    assert a.dtype == torch.int64 and np.array_equal(a.cpu().numpy(), z[tag + "_first"]), tag
+                assert np.array_equal(Xb.cpu().numpy(), z[tag + "_X"]), tag
+        c = MG.SOBER_CASES["continuous"]
+        sober = sober_amd.Sober(MG.UniformPrior(c["d"], device=dev), model_for(c), kernel_type=c["kernel_type"],
+                                prior_updater=lambda s, X, w: None)     # the fixture's stand-in keeps the prior too
+        torch.manual_seed(c["seed_call"])
+        Xb = sober.next_batch(c["n_rec"], c["n_nys"], c["batch"])
+    assert isinstance(Xb, torch.Tensor) and np.array_equal(Xb.cpu().numpy(), z["continuous_X"])
+
+
 # --------------------------------------------------------------------------- #
 # Caratheodory step on the device
 # --------------------------------------------------------------------------- #
