@@ -213,6 +213,12 @@ int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, const double* 
  * `work` (n_shifts * n * n doubles) and sets info[b] (0 = positive definite).  src is not modified.     */
 int sober_cholesky_probe(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
                          double* work, int32_t* info, void* stream);
+/* The same, and min_pivot[b] (may be NULL) = smallest pivot rung b met: the failing one (<= 0) when info[b] != 0.
+ * is_psd (SOBER/_utils.py:117-129) asks LAPACK's Cholesky AND `linalg.eig >= 0`: a rung whose smallest pivot is
+ * within rounding of zero is one where those and this kernel may disagree -- the caller then lets the host's
+ * LAPACK decide (sober_amd/_ops_hip.py:nystrom_basis_device).                                                    */
+int sober_cholesky_probe_piv(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
+                             double* work, int32_t* info, double* min_pivot, void* stream);
 /* out = sqrt(nan_to_num(C) * nan_to_num(C)^T) elementwise (quirk Q2, SOBER/_utils.py:143-144);
  * flag[0] |= 1 when C is not exactly symmetric (:127).  Zero flag first.                            */
 int sober_abs_sym(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, void* stream);

@@ -23,7 +23,7 @@ import math
 import torch
 
 from . import _native as nat
-from ._kernel import posterior_mean, prepare_points, spec_from_model, woodbury
+from ._kernel import KernelSpec, posterior_mean, prepare_points, same_device, spec_from_model, woodbury
 from ._pi import _predict
 from ._rchq import recombination
 
@@ -40,8 +40,11 @@ class GspaceKernel:
         self.jitter = float(jitter)                        # ScaleMmltGP.jitter (:73), 0 in the reference
 
     def spec(self, device):
-        if self._spec is None or self._spec.X_obs.device != torch.device(device):
-            self._spec = spec_from_model(self._model).to(device)
+        """(a live model is read again on every call, a KernelSpec snapshot once per device: sober_amd/_kernel.py)"""
+        dev = same_device(device)
+        live = not isinstance(self._model, KernelSpec)
+        if live or self._spec is None or same_device(self._spec.X_obs.device) != dev:
+            self._spec = spec_from_model(self._model).to(dev)
             if self._spec.alpha is None:
                 raise ValueError("the g-space kernel needs the posterior-mean cache (KernelSpec.alpha / "
                                  "model.prediction_strategy.mean_cache)")

@@ -99,35 +99,20 @@ class DistComm:
 # --------------------------------------------------------------------------- #
 # host pieces of the algorithm
 # --------------------------------------------------------------------------- #
-HOST_THREAD_CAP = 8      # process-wide torch CPU thread cap applied on first use (None = leave alone)
-
-
-def _cap_host_threads_once():
-    """One-time, process-wide: torch's default of one CPU thread per core is pathological for the
-    small host LAPACK problems on this path on a many-core GPU host (MI355X box, 128 threads:
-    eigvalsh(500x500) 361 ms vs 8.7 ms with one thread, svd(100x200) 20 ms vs 1.3 ms), and bouncing
-    between 128 and 1 threads per call costs ~15 ms of pool wake-ups per step.  Cap the pool once
-    (module attribute HOST_THREAD_CAP, None disables), then flip 8 <-> 1 around each LAPACK section,
-    which is free."""
-    global _capped
-    if _capped:
-        return
-    _capped = True
-    if HOST_THREAD_CAP is not None and torch.get_num_threads() > HOST_THREAD_CAP:
-        torch.set_num_threads(HOST_THREAD_CAP)
-
-
-_capped = False
+HOST_LAPACK_THREADS = 8  # threads for the large host LAPACK sections (eigvalsh / svd_lowrank of the Nystrom Gram)
 
 
 class host_lapack_threads:
-    """Run a host LAPACK section with the thread count that is fastest for its size."""
+    """Run ONE host LAPACK section with the thread count that is fastest for its size, then put the caller's
+    setting back.  torch's default of one CPU thread per core is pathological for the small LAPACK problems of the
+    fallback routes on a many-core GPU host (MI355X box, 128 threads: eigvalsh(500x500) 361 ms vs 8.7 ms with
+    one thread, svd(100x200) 20 ms vs 1.3 ms).  Scoped on purpose: the surrounding BO loop's own CPU work (the GP
+    fit) keeps whatever thread count its owner chose."""
 
     def __init__(self, size: int):
-        self.n = 1 if size <= 1024 else HOST_THREAD_CAP or 8
+        self.n = 1 if size <= 1024 else HOST_LAPACK_THREADS
 
     def __enter__(self):
-        _cap_host_threads_once()
         self.old = torch.get_num_threads()
         if self.old != self.n:
             torch.set_num_threads(self.n)
@@ -214,14 +199,15 @@ class RecombinationEngine:
         return t1
 
     # -- Nystrom basis --------------------------------------------------------
-    def nystrom_basis(self, plan, s: int, overlap=None):
+    def nystrom_basis(self, plan, s: int, overlap=None, literal=False):
         """-> U (s, M).  Device route when the backend has one (HipOps.nystrom_basis_device); the
         literal host route (LAPACK) otherwise or when the device route declines.  `overlap`: callable
         that enqueues device work independent of U; the device route calls it (once) while the host
-        still works on the basis."""
+        still works on the basis.  `literal`: take the host route (it returns svd_lowrank's U itself,
+        final rotation U_B included)."""
         t0 = time.perf_counter()
         dev_route = getattr(self.ops, "nystrom_basis_device", None)
-        if dev_route is not None and not self.force_host_nystrom:
+        if dev_route is not None and not self.force_host_nystrom and not literal:
             with warnings.catch_warnings():
                 warnings.simplefilter("default")
                 res = dev_route(plan, s, self.tm.max_iter, overlap) if overlap is not None \
@@ -281,9 +267,17 @@ class RecombinationEngine:
             if not state:
                 first_sums()
 
+        # The device Nystrom route returns an orthonormal basis of svd_lowrank's subspace WITHOUT the final rotation
+        # U_B.  That is invisible to a Caratheodory step whose null space comes from the bidiagonalisation's right
+        # reflectors (the device kernels; also what MKL's gesdd returns), but not to every LAPACK: with another
+        # vendor's gesdd/gesvd the null-space basis of [1 | X O]^T differs from that of [1 | X]^T.  So whenever the
+        # Caratheodory steps of this run go to the host's LAPACK the literal route (U_B included) is taken and the
+        # run reproduces the reference on the same machine whatever its LAPACK.
+        car_on_host = self.force_host_car or obj is not None or getattr(ops, "car_supported", None) is None \
+            or not ops.car_supported(S, n + 1)
         # (sharded runs keep the collectives in one fixed order on every rank: no overlap there, the ranks'
         # Nystrom routes may differ -- each draws its own randn -- and only rank 0's result is used)
-        U = self.nystrom_basis(plan, n, overlap=head_once if comm.world == 1 else None)
+        U = self.nystrom_basis(plan, n, overlap=head_once if comm.world == 1 else None, literal=car_on_host)
         if comm.world > 1:                                  # rank 0's randn draw is the one that counts
             U = comm.broadcast0(ops.from_host(U.contiguous()) if U.device != ops.device else U.contiguous())
         ops.set_projection(plan, U)

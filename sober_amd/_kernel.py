@@ -44,6 +44,14 @@ class KernelSpec:
                           f(self.S_cache), float(self.noise), float(self.mean_const), f(self.alpha))
 
 
+def same_device(device) -> torch.device:
+    """torch.device with the index made explicit (torch.device("cuda") and cuda:0 are the same device here)."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
 def _kernel_family(k):
     name = type(k).__name__
     if name == "RBFKernel":
@@ -114,7 +122,7 @@ def prepare_points(spec: KernelSpec, X: torch.Tensor) -> PointSet:
     n, d = X.shape
     kind = nat.KIND_BY_NAME[spec.kind]
     if kind == nat.KIND_TANIMOTO:
-        nw = nat.bit_words(d)
+        nw = nat.bit_words(d, generic=True)
         words = torch.empty(n, nw, dtype=torch.int64, device=X.device)
         norms = torch.empty(n, dtype=torch.float64, device=X.device)
         bad = torch.zeros(1, dtype=torch.int32, device=X.device)
@@ -122,7 +130,7 @@ def prepare_points(spec: KernelSpec, X: torch.Tensor) -> PointSet:
         if int(bad.item()) != 0:
             raise ValueError("Tanimoto kernel: inputs must be 0/1 fingerprints")
         return PointSet(words.view(torch.float64), norms, nw)
-    dt = nat.padded_dim(d)
+    dt = nat.padded_dim(d, generic=True)
     out = torch.empty(n, dt, dtype=torch.float64, device=X.device)
     nat.scale_points(X, spec.lengthscale, out)
     return PointSet(out, None, dt)
@@ -138,8 +146,15 @@ class Kernel:
 
     # -- spec handling ------------------------------------------------------
     def spec(self, device) -> KernelSpec:
-        if self._spec_dev is None or self._spec_dev.X_obs.device != torch.device(device):
-            self._spec_dev = spec_from_model(self.model).to(device)
+        """The model's hyperparameters and caches on `device`.  The reference reads the LIVE gpytorch model on
+        every call (SOBER/_gp.py:268-276,292-294), so a model retrained in place must not be served from a stale
+        snapshot: a live model is read again on every call (a handful of small tensors); only a KernelSpec --
+        a snapshot by construction -- is cached per device."""
+        dev = same_device(device)
+        if not isinstance(self.model, KernelSpec):
+            return spec_from_model(self.model).to(dev)
+        if self._spec_dev is None or same_device(self._spec_dev.X_obs.device) != dev:
+            self._spec_dev = self.model.to(dev)
         return self._spec_dev
 
     def update_model(self, model):
@@ -210,6 +225,19 @@ def posterior_mean(spec, pts: PointSet):
     kind = nat.KIND_BY_NAME[spec.kind]
     pobs = prepare_points(spec, spec.X_obs)
     out = torch.empty(len(pts), dtype=torch.float64, device=pts.data.device)
+    if not nat.fused_dim_supported(kind, spec.X_obs.shape[1]):
+        # beyond the register-tiled kernels (d > 32, > 2048 bits): K(X_obs, pts) by the any-length pairwise kernel,
+        # then alpha^T K on the matrix cores
+        n_obs, n = len(pobs), len(pts)
+        for lo in range(0, n, 1 << 16):
+            hi = min(n, lo + (1 << 16))
+            sub = pts.rows(lo, hi)
+            KX = torch.empty(n_obs, hi - lo, dtype=torch.float64, device=out.device)
+            nat.pairwise(kind, pobs.data, pobs.norm, sub.data, sub.norm, None, hi - lo, pts.dt, spec.outputscale, KX)
+            row = torch.empty(1, hi - lo, dtype=torch.float64, device=out.device)
+            nat.dgemm(spec.alpha.reshape(1, -1).contiguous(), KX, row)
+            out[lo:hi] = row[0] + spec.mean_const
+        return out
     nat.kernel_matvec(kind, pobs.data, pobs.norm, spec.alpha, pts.data, pts.norm, pts.dt,
                       spec.outputscale, spec.mean_const, out)
     return out

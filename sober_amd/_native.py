@@ -58,6 +58,7 @@ SIGNATURES = {
     "sober_cholesky_inv": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
     "sober_trsm_blocks": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sober_cholesky_probe": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "sober_cholesky_probe_piv": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_jitter_ladder": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "sober_jitter_ladder_auto": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
@@ -99,6 +100,8 @@ class LevelJob(C.Structure):
         ("idx", _vp), ("pos0", _i64), ("count", _i64), ("E", _i64), ("mu", _vp),
         ("phase", _i32),
     ]
+
+E_DIM = -2
 
 _lib: Optional[C.CDLL] = None
 
@@ -156,16 +159,30 @@ def _req(t: torch.Tensor, dtype, name: str):
 # --------------------------------------------------------------------------- #
 # thin typed wrappers (torch tensors in, nothing allocated inside the library)
 # --------------------------------------------------------------------------- #
-def padded_dim(d: int) -> int:
+def padded_dim(d: int, generic: bool = False) -> int:
+    """Padded row length of scaled points.  The register-tiled kernels (level reduction, kernel-matvec) exist for
+    d <= 32; `generic=True` returns the next multiple of 4 beyond that (sober_pairwise and sober_scale_points take
+    any row length)."""
     r = load().sober_padded_dim(d)
+    if r == E_DIM and generic and d > 0:
+        return (d + 3) // 4 * 4
     _check(min(r, 0), f"padded_dim({d})")
     return r
 
 
-def bit_words(d: int) -> int:
+def bit_words(d: int, generic: bool = False) -> int:
+    """64-bit words per bit-packed fingerprint (tiled kernels: <= 32 words = 2048 bits; generic: any count)."""
     r = load().sober_bit_words(d)
+    if r == E_DIM and generic and d > 0:
+        return (d + 63) // 64
     _check(min(r, 0), f"bit_words({d})")
     return r
+
+
+def fused_dim_supported(kind: int, d: int) -> bool:
+    """True iff the fused level kernels have an instantiation for this input dimension."""
+    r = load().sober_bit_words(d) if kind == KIND_TANIMOTO else load().sober_padded_dim(d)
+    return r > 0
 
 
 def scale_points(X, lengthscale, out):
@@ -349,10 +366,11 @@ def trsm_blocks(Y, L, xinv, Q):
                                     Q.data_ptr(), Q.stride(0), _stream(Y)), "sober_trsm_blocks")
 
 
-def cholesky_probe(src, shifts, work, info):
+def cholesky_probe(src, shifts, work, info, min_pivot=None):
     n = src.shape[0]
-    _check(load().sober_cholesky_probe(src.data_ptr(), n, src.stride(0), shifts.data_ptr(), shifts.numel(),
-                                       work.data_ptr(), info.data_ptr(), _stream(src)), "sober_cholesky_probe")
+    _check(load().sober_cholesky_probe_piv(src.data_ptr(), n, src.stride(0), shifts.data_ptr(), shifts.numel(),
+                                           work.data_ptr(), info.data_ptr(), _ptr(min_pivot), _stream(src)),
+           "sober_cholesky_probe_piv")
 
 
 def abs_sym(C_, out, flag):

@@ -137,7 +137,10 @@ class HipOps:
             shifts = self._pin[key] = torch.tensor([1e-5 * (2 ** k - 1) for k in range(n_r)], dtype=torch.float64,
                                                    device=dev)
         work = self._buf(p, "chol_work", n_r * M * M)
-        nat.cholesky_probe(C, shifts, work, flags[2:])
+        # (smallest pivot of every rung + the largest diagonal entry: the borderline test below)
+        pivots = torch.empty(n_r + 1, dtype=torch.float64, device=dev)
+        pivots[n_r:] = C.diagonal().amax()
+        nat.cholesky_probe(C, shifts, work, flags[2:], pivots)
         nat.jitter_ladder_auto(C, flags[2:], flags[1:2])
         # svd_lowrank's randn comes from the CPU generator (it is the next consumer of the generator in the
         # reference too: make_cov_psd draws nothing), drawn while the probes run.  Should the input turn out
@@ -145,12 +148,33 @@ class HipOps:
         # generator is put back and the literal host route decides.
         rng_state = torch.get_rng_state()
         R = torch.randn(M, s, dtype=torch.float64)
-        U, flags_h = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=flags)
-        if int(flags_h[0]) == 0 or U is None:
+        U, (flags_h, piv_h) = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=(flags, pivots))
+        if int(flags_h[0]) == 0 or U is None or self.ladder_borderline(flags_h[2:], piv_h[:n_r], float(piv_h[n_r])):
             torch.set_rng_state(rng_state)                 # the host route draws the same randn again
             return None
         warnings.warn("Estimated covariance matrix was not positive semi-definite. Conveting...")
         return U, G
+
+    # is_psd (SOBER/_utils.py:117-129) = LAPACK's Cholesky succeeds AND linalg.eig >= 0.  k_chol's verdict on a rung
+    # can only differ from that where the rung is numerically singular: its smallest pivot (the failing one, <= 0,
+    # for a rejected rung) within LADDER_GUARD x the largest diagonal entry of zero.  Only the two deciding rungs
+    # matter (the first accepted one and the rejected one in front of it); a borderline ladder goes to the host's
+    # LAPACK, as the host twin does (sober_amd/_utils.py:make_cov_psd).
+    LADDER_GUARD = 1e-9
+
+    @classmethod
+    def ladder_borderline(cls, info, min_pivot, dmax) -> bool:
+        thr = cls.LADDER_GUARD * max(dmax, 0.0)
+        ok = [int(v) == 0 for v in info]
+        piv = [float(v) for v in min_pivot]
+        if not (dmax == dmax) or any(v != v for v in piv):
+            return True
+        k = ok.index(True) if any(ok) else len(ok)
+        if k < len(ok) and piv[k] < thr:                    # accepted, but numerically singular
+            return True
+        if k > 0 and piv[k - 1] > -thr:                     # rejected by a hair
+            return True
+        return False
 
     def _orth(self, Y, infos, pivs, slot, passes: int = 2):
         """CholeskyQR2: orthonormal basis of range(Y) with the flag of Householder QR.
@@ -216,6 +240,8 @@ class HipOps:
         if extra is None:
             infos_h, pivs_h = self.to_host(infos, pivs, before_sync=overlap)
             extra_h = None
+        elif isinstance(extra, tuple):
+            infos_h, pivs_h, *extra_h = self.to_host(infos, pivs, *extra, before_sync=overlap)
         else:
             infos_h, pivs_h, extra_h = self.to_host(infos, pivs, extra, before_sync=overlap)
         # a second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1

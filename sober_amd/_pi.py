@@ -13,7 +13,7 @@ import math
 import torch
 
 from . import _native as nat
-from ._kernel import posterior_mean, prepare_points, spec_from_model, woodbury
+from ._kernel import KernelSpec, posterior_mean, prepare_points, same_device, spec_from_model, woodbury
 
 CHUNK = 1 << 18
 
@@ -74,8 +74,12 @@ class PI:
         self.eta = None
 
     def _prepare(self, device):
-        if self._spec is None or self._spec.X_obs.device != torch.device(device):
-            self._spec = spec_from_model(self.model).to(device)
+        """A live model is read again on every call (the reference evaluates `self.model` each time, :20-38); a
+        KernelSpec snapshot is prepared once per device."""
+        dev = same_device(device)
+        live = not isinstance(self.model, KernelSpec)
+        if live or self._spec is None or same_device(self._spec.X_obs.device) != dev:
+            self._spec = spec_from_model(self.model).to(dev)
             m_obs, _, _ = _predict(self._spec, self._spec.X_obs)
             self.eta = float(m_obs.max().item())          # current maximum (:17)
         return self._spec

@@ -43,9 +43,15 @@ def recombination(pts_rec, pts_nys, num_pts, kernel, device=None, dtype=None, in
         raise ValueError('mode should be from ["predictive_covariance", '
                          '"weighted_predictive_covariance", "kernel"]')
     if _ops is None:
+        from . import _native as nat
         from ._ops_hip import CallableKernelOps, HipOps
         glob_dev, _ = setting_parameters()
         dev = _device_of(pts_rec, glob_dev)
+        if fused and not nat.fused_dim_supported(nat.KIND_BY_NAME[kernel.spec(dev).kind], pts_rec.shape[1]):
+            # beyond the fused level kernels' tile set (continuous inputs with d > 32, fingerprints with more than
+            # 2048 bits): the reference accepts any dimension, so the same Kernel is used as a plain callable -- its
+            # matrix K(X_cand, X_nys) is built once by the any-length pairwise kernel and stays in HBM
+            fused = False
         # raises when there is no HIP device / library.  A sober_amd.Kernel takes the fused path; any other
         # callable (the reference's kernel protocol, e.g. BASQ's gspace_kernel) is evaluated by the caller's
         # own torch code and only the kernel matrix itself is outside the HIP path

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
                     const double djj = ch_rdlane(d[j], j);
                     if (!(djj > 0.0)) {                   // also catches NaN
                         fail = kb + j + 1;
+                        minp = fmin(minp, djj);           // the failing pivot (<= 0): how far from positive definite
                     } else {
                         // multipliers through the reciprocal square root: one short dependent sequence per
                         // column instead of sqrt followed by a division (off-diagonal entries within 2 ulp)
@@ -451,8 +452,15 @@ extern "C" int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, con
     return 0;
 }
 
+extern "C" int sober_cholesky_probe_piv(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
+                                        double* work, int32_t* info, double* min_pivot, void* stream);
 extern "C" int sober_cholesky_probe(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
                                     double* work, int32_t* info, void* stream) {
+    return sober_cholesky_probe_piv(src, n, ld_src, shifts, n_shifts, work, info, nullptr, stream);
+}
+
+extern "C" int sober_cholesky_probe_piv(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
+                                        double* work, int32_t* info, double* min_pivot, void* stream) {
     if (!src || !shifts || !work || !info || n <= 0 || ld_src < n || n_shifts <= 0) return SOBER_E_ARG;
     if (n > sober::CH_MAXN) return SOBER_E_DIM;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
@@ -460,7 +468,7 @@ extern "C" int sober_cholesky_probe(const double* src, int n, int ld_src, const 
     HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 512));
     hipLaunchKernelGGL(sober::k_chol, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
-                       info, (double*)nullptr, src, ld_src, shifts, (double*)nullptr);
+                       info, min_pivot, src, ld_src, shifts, (double*)nullptr);
     LAUNCH_CHECK();
     return 0;
 }

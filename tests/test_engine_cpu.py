@@ -146,3 +146,18 @@ def test_wkde_fit_matches_reference():
         assert abs(float(kde.bw) - float(z[f"{tag}_bw"])) < 1e-15
         with pytest.raises(RuntimeError):
             kde.pdf(_t(z[f"{tag}_Xq"]))                       # CPU tensor: no fallback
+
+
+def test_ladder_borderline_rule():
+    """The rule that sends a numerically undecided jitter rung to the host's LAPACK (sober_amd/_ops_hip.py)."""
+    from sober_amd._ops_hip import HipOps
+    f = HipOps.ladder_borderline
+    ok3 = [1, 1, 1, 0, 0]
+    assert not f(ok3, [-1e-3, -5e-4, -1e-4, 2e-3, 5e-3], 1.0)            # clear
+    assert f(ok3, [-1e-3, -5e-4, -1e-4, 2e-12, 5e-3], 1.0)               # accepted rung numerically singular
+    assert f(ok3, [-1e-3, -5e-4, -3e-12, 2e-3, 5e-3], 1.0)               # rejected by a hair
+    assert not f([0, 0], [0.5, 0.6], 1.0)                                # PSD at rung 0
+    assert f([0, 0], [1e-13, 0.6], 1.0)
+    assert not f([1, 1], [-1e-2, -1e-3], 1.0)                            # no rung: diagonal fallback, clearly
+    assert f([1, 1], [-1e-2, -1e-12], 1.0)
+    assert f([1, 0], [float("nan"), 1.0], 1.0)

@@ -591,9 +591,8 @@ def test_cfg4_rbf_d20_vs_oracle(dev):
     # leftovers of every kind, R landing exactly on S or n + 1, pools below one level, one-dimensional inputs
     ("rbf", "predictive_covariance", 417, 60, 3, 7, 25),
     ("rbf", "predictive_covariance", 1000, 90, 2, 16, 40),          # R halves to exactly 2b several times
-    # (d = 1 is deliberately absent: 90 Nystrom points on a line give a Gram of numerical rank ~10, fewer than the
-    #  15 test functions, and the Caratheodory weights then amplify a 4e-12 input difference to 8e-4 -- same kept
-    #  sets, but no implementation can agree with another to 1e-4 there)
+    # (d = 1 has its own test, test_d1_within_reference_sensitivity: the reference's weights are not reproducible
+    #  to 1e-4 by the reference itself there)
     ("matern52", "predictive_covariance", 2311, 120, 5, 31, 50),
     ("rbf", "weighted_predictive_covariance", 1536, 80, 4, 12, 30),
     ("rbf", "kernel", 999, 70, 2, 9, 20),                            # symmetric Gram: host Nystrom route
@@ -606,6 +605,76 @@ def test_odd_shapes_vs_oracle(shape, dev):
     kind, mode, N, M, d, b, n_obs = shape
     kinds = {"rbf": O.RBF, "matern52": O.MATERN52}
     _vs_oracle(kinds[kind], mode, N, M, d, b, n_obs, 100 + N % 7, dev)
+
+
+def test_d1_within_reference_sensitivity(dev):
+    """One-dimensional inputs (tests/golden/make_golden.py::gen_d1_sensitivity): identical indices, and weights as
+    close to the reference as the reference is to itself when its inputs move by one ulp (recorded: ~1e-3)."""
+    from tests.golden import make_golden as MG
+    from tests.golden.synth import synth, build_spec
+    z = np.load(os.path.join(GOLD, "d1_sensitivity.npz"))
+    assert z["same_idx"].all()
+    tol = 2.0 * float(np.nanmax(z["rel_w_change"]))
+    assert 1e-4 < tol < 5e-2                                  # the point of the test: 1e-4 is not attainable here
+    case = MG.D1_CASE
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    mu = _t(inp["mu0"].copy()).to(dev)
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                         sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu)
+    assert np.array_equal(idx.cpu().numpy(), z["idx"])
+    np.testing.assert_allclose(w.cpu().numpy(), z["w"], rtol=tol)
+    assert abs(float(w.sum()) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("kind,mode,d", [
+    (O.RBF, "predictive_covariance", 30),                   # last dimension of the matrix-core level kernel (d + 2 <= 32)
+    (O.RBF, "predictive_covariance", 31),                   # register-tiled VALU level kernel (d <= 32)
+    (O.RBF, "predictive_covariance", 33),                   # beyond the tile set: matrix-resident route, any d
+    (O.MATERN52, "weighted_predictive_covariance", 40),
+    (O.TANIMOTO, "predictive_covariance", 2049),            # 33 words: beyond the 2048-bit tiles
+], ids=lambda v: str(v)[:6])
+def test_dimension_limits_vs_oracle(kind, mode, d, dev):
+    """The reference accepts any input dimension; the fused kernels are tiled for d <= 32 / <= 2048 bits and
+    `recombination` switches to the HBM-resident kernel matrix beyond that (sober_amd/_rchq.py) -- same results."""
+    _vs_oracle(kind, mode, 3000, 64, d, 10, 30, 50 + d % 11, dev, bit_p=0.02)
+
+
+def test_tile_set_error_codes(dev):
+    """The C ABI itself refuses shapes outside its compiled tile set with SOBER_E_DIM (-2), it never truncates."""
+    from sober_amd import _native as nat
+    with pytest.raises(nat.SoberHipError, match="dimension not supported"):
+        nat.padded_dim(33)
+    with pytest.raises(nat.SoberHipError, match="dimension not supported"):
+        nat.bit_words(2049)
+    assert nat.padded_dim(33, generic=True) == 36 and nat.bit_words(2049, generic=True) == 33
+    lib = nat.load()
+    assert lib.sober_aug_dim(30) == 32 and lib.sober_aug_dim(31) == nat.E_DIM
+    assert lib.sober_car_supported(449, 200) == 0 and lib.sober_car_supported(448, 257) == 0
+    assert lib.sober_car_supported(400, 200) == 1 and lib.sober_car_supported(200, 100) == 1
+
+
+def test_no_progress_is_an_error_not_a_hang(dev):
+    """Quirk Q6 (SOBER/_rchq.py:241-242): a pivot column without a positive entry ends the Caratheodory step early.
+    A NaN candidate makes every quotient NaN-free-of-positives, the step cancels nothing, and the reference's
+    `while True` (:71) would spin forever on the same list; here the level loop reports it (SOBER_E_NOPROGRESS)."""
+    from sober_amd import _native as nat
+    from tests.golden.synth import synth, build_spec
+    case = dict(kind=O.RBF, mode="predictive_covariance", N=3000, M=64, d=3, b=10, n_obs=20, seed=1)
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    X = _t(inp["X_cand"].copy())
+    X[5] = float("nan")
+    mu = _t(inp["mu0"].copy()).to(dev)
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises((RuntimeError, nat.SoberHipError), match="no progress|NOPROGRESS|code -"):
+            sober_amd.recombination(X.to(dev), _t(inp["X_nys"]).to(dev), 10,
+                                    sober_amd.Kernel(kspec(spec), "predictive_covariance"), init_weights=mu)
 
 
 # --------------------------------------------------------------------------- #
@@ -770,6 +839,49 @@ def test_device_and_host_nystrom_agree(dev):
         assert torch.equal(i1, i2), name
         np.testing.assert_allclose(w1.cpu().numpy(), w2.cpu().numpy(), rtol=W_RTOL)
         assert np.array_equal(i1.cpu().numpy(), z["idx"]), name
+
+
+def test_jitter_ladder_borderline_goes_to_host(dev):
+    """A Gram matrix whose |cov| sits ON a rung of make_cov_psd's jitter ladder (lambda_min + 7e-5 ~ 1e-15): LAPACK's
+    Cholesky/eig and k_chol may legitimately disagree there, so the device route must decline (the host's LAPACK then
+    decides like the reference, SOBER/_utils.py:117-157) and leave the CPU generator where it was; the same matrix
+    moved clear of the rung takes the device route with the rung the spectrum says."""
+    from sober_amd._ops_hip import HipOps
+    ops = HipOps(dev)
+    rng = np.random.default_rng(21)
+    M, s = 96, 20
+    B = rng.random((M, M)) * 0.2
+    B = 0.5 * (B + B.T)                                      # non-negative, symmetric: |B| = B elementwise
+    lam = np.linalg.eigvalsh(B)[0]
+    assert lam < -1e-3
+
+    class P:                                                 # the members nystrom_basis_device touches
+        pass
+
+    def basis_for(lam_min_target):
+        C = B + (lam_min_target - lam) * np.eye(M)
+        assert (C >= 0).all()
+        G = _t(C.copy())
+        G[0, 1] *= 1.0 + 4e-16                               # not exactly symmetric -> the device route's case
+        p = P()
+        p.M = M
+        ops.gram = lambda p_, G=G: G.to(dev)
+        ops._buf = lambda p_, name, n: torch.empty(n, dtype=torch.float64, device=dev)
+        st = torch.get_rng_state()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = ops.nystrom_basis_device(p, s, 10)
+        return res, torch.equal(st, torch.get_rng_state())
+
+    torch.manual_seed(3)
+    res, rng_kept = basis_for(-7e-5 + 2e-15)                 # on rung 3 (shift 1e-5 (2^3 - 1))
+    assert res is None and rng_kept
+    res, rng_kept = basis_for(-7e-5 - 3e-15)
+    assert res is None and rng_kept
+    res, rng_kept = basis_for(-6e-5)                          # clear of every rung: rung 3 it is, on the device
+    assert res is not None and not rng_kept
+    U = res[0].cpu().numpy()
+    np.testing.assert_allclose(U @ U.T, np.eye(s), atol=1e-10)
 
 
 def test_arbitrary_callable_kernel(dev):
