@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOBER_ABI_VERSION 1
+#define SOBER_ABI_VERSION 2
 
 /* kernel families: model.covar_module.forward behind SOBER/_gp.py:292-294 */
 #define SOBER_KIND_RBF       0   /* outputscale * exp(-0.5 * |x/l - y/l|^2)                      */
@@ -232,6 +232,24 @@ int sober_jitter_ladder(double* A, int n, int ld, int k, void* stream);
 int sober_jitter_ladder_auto(double* A, int n, int ld, const int32_t* info, int n_rungs, int32_t* k_out,
                              void* stream);
 
+/* Queued-level forms (see sober_level_loop): the same kernels with the level size read from device memory.
+ * sober_level_reduce_mfma_queued: leftover = 0: positions [0, *dR), set masses over [0, E S) (S = S_main);
+ * leftover = 1: the leftover positions [E S_main, *dR) over S pseudo-sets.  Launch sized for count_ub positions
+ * and n_chunks_ub chunks (the LARGEST count sober_level_chunks can return up to count_ub, not its value there). */
+int sober_level_reduce_mfma_queued(int kind, const double* rows, int n_rows, const double* cand, int da,
+                                   const int32_t* idx, int64_t count_ub, int S, int S_main, int leftover,
+                                   const double* mu, const double* wmul, double outputscale, int n_chunks_ub,
+                                   double* partG, int ldg, double* partTot, const int64_t* dR, void* stream);
+int sober_sum_partials_queued(const double* partG, const double* partTot, int n_rows, int ldg, int S,
+                              const double* extraG, const double* extraTot, int n_xcols, double* G, int ldo,
+                              double* tot, const int64_t* dR, void* stream);
+/* K7 (SOBER/_rchq.py:198-221) with R = *dR_cur and n_keep = keep_rank[S] read on the device; *dR_next = the next
+ * level's R, or -1 with mu and the list untouched when the host loop has to take over (R <= S, no progress,
+ * n_keep outside 1..S, more than R_ub_next survivors).                                                       */
+int sober_level_update_queued(const int32_t* idx_cur, int64_t R_ub, int S, const int32_t* keep_rank,
+                              const double* w_star, const double* tot, double* mu, int32_t* idx_new,
+                              const int64_t* dR_cur, int64_t* dR_next, int64_t R_ub_next, void* stream);
+
 /* KMeans of SOBER/_weights.py:100-126: Lloyd, centroids initialised to the first K rows, exactly
  * `iters` iterations, first-index argmin (a NaN distance wins like torch.argmin), empty cluster ->
  * NaN centroid.  X is (N, d) row-major raw points.  labels: N int32.  ws: sober_kmeans_ws_bytes.  */
@@ -319,7 +337,11 @@ typedef struct sober_level_job {
                                                    2 = projection only (Xtr = P G).  The set sums of the first level do
                                                    not depend on the Nystrom basis: they run while the host still works
                                                    on it.                                                                */
+    /* queued levels (optional, MFMA variant): SOBER_LEVEL_QUEUE + 1 int64 each -- dR device, h_dR pinned host.
+       NULL: every level is sized by the host after a stream synchronisation.                                  */
+    int64_t* dR; int64_t* h_dR;
 } sober_level_job;
+#define SOBER_LEVEL_QUEUE 24
 int sober_level_moments(const sober_level_job* job, void* stream);
 int sober_level_car(const sober_level_job* job, void* stream);
 /* The whole halving loop of an UNSHARDED pool (SOBER/_rchq.py:116-221, repeated while R > S) in one call: per level
@@ -331,6 +353,13 @@ int sober_level_car(const sober_level_job* job, void* stream);
  * *n_levels, *R_final (<= S), *in_b = 1 when the final live list is in idx_b.  Returns SOBER_E_NOPROGRESS when a
  * level cancels nothing (the reference would loop forever, :241-242), SOBER_E_WS when max_levels is too small.  */
 #define SOBER_E_NOPROGRESS -4
+/* With job->dR / job->h_dR set (and the MFMA variant) the loop first ENQUEUES every level that certainly exists
+ * (at most b of a level's 2b sets survive, so the number of live positions after a level is known up to its
+ * leftovers: R_new in [E b, E b + r]) without any host decision in between: the launches are sized from the upper
+ * bound, every kernel reads the exact R from dR[level] (written by the previous level's sober_level_update_queued),
+ * surplus workgroups exit.  One synchronisation for all of them; the last one or two levels, whose existence
+ * depends on the leftovers, and anything irregular (no progress, a step that kept more than b sets) fall back to
+ * the synchronised loop from the first level the chain did not complete.                                      */
 int sober_level_loop(sober_level_job* job, int64_t R, int32_t* idx_a, int32_t* idx_b, int first_sums_ready,
                      void** events, int max_levels, int64_t* level_R, int32_t* n_levels, int64_t* R_final,
                      int32_t* in_b, void* stream);

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SOBER_HIP_LIB: a diagnostic build of the same library, e.g. the in-kernel-stamp build `make stamps`)
 LIB_PATH = os.environ.get("SOBER_HIP_LIB") or os.path.join(_HERE, "libsober_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 KIND_RBF, KIND_MATERN52, KIND_TANIMOTO = 0, 1, 2
 KIND_BY_NAME = {"rbf": KIND_RBF, "matern52": KIND_MATERN52, "tanimoto": KIND_TANIMOTO}
@@ -73,6 +73,10 @@ SIGNATURES = {
     "sober_wkde_draw": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sober_level_moments": (_i32, [_vp, _vp]),
     "sober_level_car": (_i32, [_vp, _vp]),
+    "sober_level_reduce_mfma_queued": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _f64,
+                                              _i32, _vp, _i32, _vp, _vp, _vp]),
+    "sober_sum_partials_queued": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "sober_level_update_queued": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_record_event_pair": (_i32, [_vp, _vp, _vp]),
     "sober_gather_f64": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "sober_final_scatter": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -81,7 +85,7 @@ SIGNATURES = {
 }
 
 LEVEL_VALU, LEVEL_MFMA, LEVEL_GATHER = 0, 1, 2
-LEVEL_MAX_CHUNKS, LEVEL_XS = 64, 16
+LEVEL_MAX_CHUNKS, LEVEL_XS, LEVEL_QUEUE = 64, 16, 24
 
 
 class LevelJob(C.Structure):
@@ -99,6 +103,7 @@ class LevelJob(C.Structure):
         ("ev", _vp * 4),
         ("idx", _vp), ("pos0", _i64), ("count", _i64), ("E", _i64), ("mu", _vp),
         ("phase", _i32),
+        ("dR", _vp), ("h_dR", _vp),
     ]
 
 E_DIM = -2

@@ -29,6 +29,8 @@ class HipOps:
         self._pin = {}
         self.prof = None        # list -> (start_event, end_event, kernel entries) per level_reduce launch
         self.use_mfma = True    # False: VALU-only level kernel (direct differences), kept for A/B runs
+        # False (or SOBER_NO_QUEUE in the environment): every level sized by the host after a synchronisation (A/B runs)
+        self.queue_levels = os.environ.get("SOBER_NO_QUEUE") is None
 
     # ------------------------------------------------------------------ plan
     def build_plan(self, spec: KernelSpec, mode: str, X_nys, X_cand) -> Plan:
@@ -323,6 +325,11 @@ class HipOps:
         w["w_star"], w["mu_out"] = torch.empty(S, dtype=f64, device=dev), torch.empty(S, dtype=f64, device=dev)
         w["h_flags"] = torch.empty(S + 1, dtype=torch.int32, pin_memory=True)
         w["h_flags_np"] = w["h_flags"].numpy()
+        if job.variant == nat.LEVEL_MFMA and self.queue_levels:
+            # queued levels (csrc/level_exec.cpp): live positions per level, on the device and in pinned memory
+            w["dR"] = torch.zeros(nat.LEVEL_QUEUE + 1, dtype=torch.int64, device=dev)
+            w["h_dR"] = torch.zeros(nat.LEVEL_QUEUE + 1, dtype=torch.int64, pin_memory=True)
+            job.dR, job.h_dR = w["dR"].data_ptr(), w["h_dR"].data_ptr()
         for k in ("partG", "partTot", "extraG", "extraTot", "G", "Xtr", "tot", "X_tmp", "keep_rank", "w_star", "mu_out",
                   "h_flags"):
             setattr(job, k, w[k].data_ptr())

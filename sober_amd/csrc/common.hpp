@@ -21,6 +21,21 @@
 
 namespace sober {
 
+// Element chunks of one level launch (sober_level_chunks): ~4 workgroups per CU on 256 CUs, at most 64, no empty
+// chunk.  Host and device use the same formula: a launch sized from an upper bound of the live positions finds
+// its own chunk count from the exact number it reads on the device (level_exec.cpp: the queued loop).
+__host__ __device__ inline int level_chunks_for(int n_rows, int64_t e_total, int S) {
+    const int sb = (S + 15) / 16;
+    const int rb = (n_rows + 255) / 256;
+    int64_t n = 1024 / ((int64_t)sb * rb);
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    if (n > e_total) n = e_total;
+    if (n < 1) return 0;
+    const int64_t epc = (e_total + n - 1) / n;
+    return (int)((e_total + epc - 1) / epc);
+}
+
 // k(x, y) from the squared scaled distance (continuous kernels).
 // RBF:      gpytorch RBFKernel  -> exp(-sq / 2)                       [SURVEY App. D]
 // Matern52: gpytorch MaternKernel(nu=2.5): r = sqrt(max(sq, 1e-30)),

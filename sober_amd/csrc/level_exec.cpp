@@ -2,6 +2,8 @@
 // (optional) all-reduce.  Pure host code: it only sequences the library's own entry points on the caller's
 // stream, so a level costs two calls from the host language instead of ten.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 
 #include "../../include/sober_hip.h"
 
@@ -87,6 +89,102 @@ extern "C" int sober_level_car(const sober_level_job* j, void* stream) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// Largest chunk count sober_level_chunks can return for at most e_total elements per set.  (The count itself is
+// not monotone in e_total -- 64 elements give 64 chunks of one, 65 give 33 chunks of two -- so a launch sized from
+// an upper bound of the level takes the cap, not the count at the bound.)
+static int lx_chunks(int n_rows, int64_t e_total, int S) {
+    const int sb = (S + 15) / 16, rb = (n_rows + 255) / 256;
+    int64_t n = 1024 / ((int64_t)sb * rb);
+    if (n < 1) n = 1;
+    if (n > SOBER_LEVEL_MAX_CHUNKS) n = SOBER_LEVEL_MAX_CHUNKS;
+    if (n > e_total) n = e_total;
+    return (int)n;
+}
+
+// Phase A of sober_level_loop: every level that certainly exists, enqueued back to back with device-resident sizes.
+// -> *done = levels completed, *R_out = live positions after them (their list: idx_a if *done is even).
+static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_t* idx_b, int first_sums_ready,
+                          void** events, int max_levels, int64_t* level_R, int* done, int64_t* R_out, void* stream) {
+    const int S = j->S, n = j->n, b = n + 1;
+    *done = 0;
+    *R_out = R0;
+    int64_t Rlo[SOBER_LEVEL_QUEUE + 1], Rub[SOBER_LEVEL_QUEUE + 1];
+    Rlo[0] = Rub[0] = R0;
+    int L = 0;
+    while (L < SOBER_LEVEL_QUEUE && L < max_levels && Rlo[L] > S) {
+        Rlo[L + 1] = (Rlo[L] / S) * b;                                  // no leftovers kept, n_keep = b
+        Rub[L + 1] = (Rub[L] / S) * b + (S - 1);                        // the largest E with all leftovers kept
+        ++L;
+    }
+    if (const char* qm = getenv("SOBER_QUEUE_MAX")) { const int v = atoi(qm); if (v < L) L = v; }   // debugging aid
+    if (L < 2) return 0;                                                // nothing to gain: the synchronised loop
+    if (!sober_car_supported(S, b)) return SOBER_E_DIM;
+    hipStream_t st = (hipStream_t)stream;
+    j->h_dR[0] = R0;
+    hipError_t e = hipMemcpyAsync(j->dR, j->h_dR, sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    for (int l = 0; l < L; ++l) {
+        int32_t* cur = (l & 1) ? idx_b : idx_a;
+        int32_t* nxt = (l & 1) ? idx_a : idx_b;
+        for (int k = 0; k < 4; ++k) j->ev[k] = events ? events[4 * l + k] : nullptr;
+        if (!(l == 0 && first_sums_ready) && getenv("SOBER_QUEUE_CLASSIC_MOMENTS")) {
+            (void)hipMemcpyAsync(j->h_dR, j->dR, sizeof(int64_t) * (size_t)(l + 1), hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            const int64_t Rl = j->h_dR[l];
+            j->idx = cur; j->pos0 = 0; j->count = Rl; j->E = Rl / S; j->phase = 1;
+            LX_TRY(sober_level_moments(j, stream));
+        } else if (!(l == 0 && first_sums_ready)) {
+            const int nch = lx_chunks(j->n_rows, (Rub[l] + S - 1) / S, S);
+            const int nxch = lx_chunks(j->n_rows, (S - 1 + SOBER_LEVEL_XS - 1) / SOBER_LEVEL_XS, SOBER_LEVEL_XS);
+            if (nch <= 0 || nch > SOBER_LEVEL_MAX_CHUNKS || nxch <= 0 || nxch > SOBER_LEVEL_MAX_CHUNKS) return SOBER_E_WS;
+            LX_EVENT(0)
+            LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
+                                                  j->dim, cur, Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch,
+                                                  j->partG, S, j->partTot, j->dR + l, stream));
+            LX_EVENT(1)
+            LX_EVENT(2)
+            LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
+                                                  j->dim, cur, S - 1, SOBER_LEVEL_XS, S, 1, j->mu, j->wmul,
+                                                  j->outputscale, nxch, j->extraG, SOBER_LEVEL_XS, j->extraTot,
+                                                  j->dR + l, stream));
+            LX_EVENT(3)
+            if (getenv("SOBER_QUEUE_CLASSIC_SUM")) {
+                (void)hipMemcpyAsync(j->h_dR, j->dR, sizeof(int64_t) * (size_t)(l + 1), hipMemcpyDeviceToHost, st);
+                (void)hipStreamSynchronize(st);
+                const int64_t Rl = j->h_dR[l], left = Rl % S;
+                const int c1 = sober_level_chunks(j->n_rows, 0, Rl, S);
+                const int c2 = left > 0 ? sober_level_chunks(j->n_rows, 0, left, SOBER_LEVEL_XS) : 0;
+                fprintf(stderr, "level %d R %lld chunks %d xchunks %d (launched %d %d)\n", l, (long long)Rl, c1, c2, nch, nxch);
+                LX_TRY(sober_sum_partials(j->partG, j->partTot, c1, j->n_rows, S, S, left > 0 ? j->extraG : nullptr,
+                                          left > 0 ? j->extraTot : nullptr, c2, SOBER_LEVEL_XS, j->G, S, j->tot, stream));
+            } else
+            LX_TRY(sober_sum_partials_queued(j->partG, j->partTot, j->n_rows, S, S, j->extraG, j->extraTot,
+                                             SOBER_LEVEL_XS, j->G, S, j->tot, j->dR + l, stream));
+        }
+        LX_TRY(sober_dgemm(0, 0, n, S, j->n_rows, 1.0, j->P, j->n_rows, j->G, S, 0.0, j->Xtr, S, stream));
+        LX_TRY(sober_barycentres(j->Xtr, S, n, S, j->tot, j->X_tmp, stream));
+        LX_TRY(sober_car_device(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
+                                nullptr, j->car_ws, j->car_ws_bytes, stream));
+        LX_TRY(sober_level_update_queued(cur, Rub[l], S, j->keep_rank, j->w_star, j->tot, j->mu, nxt, j->dR + l,
+                                         j->dR + l + 1, Rub[l + 1], stream));
+    }
+    for (int k = 0; k < 4; ++k) j->ev[k] = nullptr;
+    e = hipMemcpyAsync(j->h_dR, j->dR, sizeof(int64_t) * (size_t)(L + 1), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamSynchronize(st);                                       // the one synchronisation of the chain
+    if (e != hipSuccess) return (int)e;
+    int d = 0;
+    while (d < L && j->h_dR[d + 1] >= 0) { level_R[d] = j->h_dR[d]; ++d; }
+    *done = d;
+    *R_out = j->h_dR[d];
+    if (getenv("SOBER_QUEUE_DEBUG")) {
+        fprintf(stderr, "queued levels %d, completed %d:", L, d);
+        for (int l = 0; l <= L; ++l) fprintf(stderr, " %lld[%lld..%lld]", (long long)j->h_dR[l], (long long)Rlo[l], (long long)Rub[l]);
+        fprintf(stderr, "\n");
+    }
+    return 0;
+}
+
 extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, int32_t* idx_b, int first_sums_ready,
                                 void** events, int max_levels, int64_t* level_R, int32_t* n_levels, int64_t* R_final,
                                 int32_t* in_b, void* stream) {
@@ -95,12 +193,23 @@ extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, i
     const int S = j->S;
     int32_t *cur = idx_a, *nxt = idx_b;
     int levels = 0;
+    if (j->dR && j->h_dR && j->variant == SOBER_LEVEL_MFMA) {
+        int done = 0;
+        int64_t R_after = R;
+        LX_TRY(lx_loop_queued(j, R, idx_a, idx_b, first_sums_ready, events, max_levels, level_R, &done, &R_after, stream));
+        if (done > 0) {
+            levels = done;
+            R = R_after;
+            first_sums_ready = 0;
+            if (done & 1) { cur = idx_b; nxt = idx_a; }
+        }
+    }
     while (R > S) {
         if (levels >= max_levels) return SOBER_E_WS;
         const int64_t E = R / S, r = R - E * S;
         j->idx = cur; j->pos0 = 0; j->count = R; j->E = E;
         j->phase = (levels == 0 && first_sums_ready) ? 2 : 0;
-        for (int k = 0; k < 4; ++k) j->ev[k] = events ? events[4 * levels + k] : nullptr;
+        for (int k = 0; k < 4; ++k) j->ev[k] = (events && levels < max_levels) ? events[4 * levels + k] : nullptr;
         LX_TRY(sober_level_moments(j, stream));
         LX_TRY(sober_level_car(j, stream));
         const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // the host decides the next level's size

@@ -162,14 +162,8 @@ using namespace sober;
 extern "C" int sober_level_chunks(int n_rows, int64_t pos0, int64_t count, int S) {
     if (n_rows <= 0 || pos0 < 0 || count <= 0 || S <= 0) return SOBER_E_ARG;
     const int64_t e_total = (pos0 + count + S - 1) / S - pos0 / S;
-    const int sb = (S + LR_SB - 1) / LR_SB;
-    const int rb = (n_rows + LR_RW * 64 - 1) / (LR_RW * 64);
-    int64_t n = 1024 / ((int64_t)sb * rb);          // ~4 workgroups per CU on 256 CUs
-    if (n < 1) n = 1;
-    if (n > 64) n = 64;
-    if (n > e_total) n = e_total;
-    const int64_t epc = (e_total + n - 1) / n;
-    return (int)((e_total + epc - 1) / epc);        // no empty chunks
+    static_assert(LR_SB == 16 && LR_RW == 4, "level_chunks_for assumes 16 sets x 256 rows per workgroup");
+    return sober::level_chunks_for(n_rows, e_total, S);
 }
 
 extern "C" int sober_level_reduce(int kind, const void* rows, const double* rows_norm, int n_rows,

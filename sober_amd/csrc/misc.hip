@@ -97,10 +97,19 @@ __global__ void k_sum_partials(const double* __restrict__ partG, const double* _
                                int n_chunks, int n_rows, int ldg, int S,
                                const double* __restrict__ extraG, const double* __restrict__ extraTot,
                                int n_xchunks, int n_xcols,
-                               double* __restrict__ G, int ldo, double* __restrict__ tot) {
+                               double* __restrict__ G, int ldo, double* __restrict__ tot,
+                               const int64_t* __restrict__ dR) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;            // row == n_rows -> the tot vector
     if (s >= S) return;
+    if (dR != nullptr) {                   // queued levels: the chunk counts follow from the exact level size
+        const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (R <= S) return;
+        const int64_t E = R / S, left = R - E * S;
+        n_chunks = level_chunks_for(n_rows, (R + S - 1) / S, S);
+        n_xchunks = left > 0 ? level_chunks_for(n_rows, (left + n_xcols - 1) / n_xcols, n_xcols) : 0;
+        if (left <= 0) { extraG = nullptr; extraTot = nullptr; }
+    }
     const bool fold = (extraG != nullptr) && (s == S - 1);
     if (row < n_rows) {
         double acc = 0.0;
@@ -159,6 +168,44 @@ __global__ void k_level_update(const int32_t* __restrict__ idx_cur, int64_t pos0
         const int k = keep_rank[s];
         mu[c] = (mu[c] * w_star[k]) / tot[s];   // multiply, then divide (:204-205, :212-213)
         idx_new[dst - new_pos0] = c;
+    } else {
+        mu[c] = 0.0;
+    }
+}
+
+// K7 for a queued level: everything the host of sober_level_loop decides between two levels, decided by every
+// workgroup for itself from device memory -- R = *dR_cur, E, the leftovers, n_keep = keep_rank[S], whether the last
+// set survived -- and R_new handed to the next level through *dR_next.  Anything the host loop would stop at (no
+// progress, a Caratheodory step that gave up, more survivors than the next launches were sized for, nothing left to
+// halve) leaves mu and the list UNTOUCHED and stops the chain (*dR_next = -1): the host redoes that level.
+__global__ void k_level_update_queued(const int32_t* __restrict__ idx_cur, int S, const int32_t* __restrict__ keep_rank,
+                                      const double* __restrict__ w_star, const double* __restrict__ tot,
+                                      double* __restrict__ mu, int32_t* __restrict__ idx_new,
+                                      const int64_t* __restrict__ dR_cur, int64_t* __restrict__ dR_next,
+                                      int64_t R_ub_next) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t R = __hip_atomic_load(dR_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t E = R > 0 ? R / S : 0, ES = E * S, r = R - ES;
+    const int n_keep = keep_rank[S];
+    const bool last_kept = keep_rank[S - 1] >= 0;
+    const int64_t R_new = E * (int64_t)n_keep + (last_kept ? r : 0);
+    const bool stop = R <= S || n_keep <= 0 || n_keep > S || R_new >= R || R_new > R_ub_next;
+    if (t == 0) *dR_next = stop ? -1 : R_new;
+    if (stop || t >= R) return;
+    const int c = idx_cur[t];
+    int s;
+    int64_t dst;
+    if (t < ES) {
+        s = (int)(t % S);
+        const int k = keep_rank[s];
+        dst = (k >= 0) ? (t / S) * n_keep + k : -1;
+    } else {                                   // leftovers ride on the last set (:208-218)
+        s = S - 1;
+        dst = last_kept ? E * n_keep + (t - ES) : -1;
+    }
+    if (dst >= 0) {
+        mu[c] = (mu[c] * w_star[keep_rank[s]]) / tot[s];   // multiply, then divide (:204-205, :212-213)
+        idx_new[dst] = c;
     } else {
         mu[c] = 0.0;
     }
@@ -413,6 +460,17 @@ extern "C" int sober_kernel_matvec(int kind, const void* a, const double* a_norm
 #undef MV_CASE
 }
 
+extern "C" int sober_level_update_queued(const int32_t* idx_cur, int64_t R_ub, int S, const int32_t* keep_rank,
+                                         const double* w_star, const double* tot, double* mu, int32_t* idx_new,
+                                         const int64_t* dR_cur, int64_t* dR_next, int64_t R_ub_next, void* stream) {
+    if (!idx_cur || !keep_rank || !w_star || !tot || !mu || !idx_new || !dR_cur || !dR_next || R_ub <= 0 || S <= 0)
+        return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_level_update_queued, dim3(nblk(R_ub, 256)), dim3(256), 0, (hipStream_t)stream, idx_cur, S,
+                       keep_rank, w_star, tot, mu, idx_new, dR_cur, dR_next, R_ub_next);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sober_sum_partials(const double* partG, const double* partTot, int n_chunks,
                                   int n_rows, int ldg, int S, const double* extraG,
                                   const double* extraTot, int n_xchunks, int n_xcols, double* G,
@@ -421,10 +479,24 @@ extern "C" int sober_sum_partials(const double* partG, const double* partTot, in
     if (extraG && (n_xchunks <= 0 || n_xcols <= 0)) return SOBER_E_ARG;
     dim3 grid(nblk(S, 64), (unsigned)(n_rows + 1));
     hipLaunchKernelGGL(k_sum_partials, grid, dim3(64), 0, (hipStream_t)stream, partG, partTot, n_chunks,
-                       n_rows, ldg, S, extraG, extraTot, n_xchunks, n_xcols, G, ldo, tot);
+                       n_rows, ldg, S, extraG, extraTot, n_xchunks, n_xcols, G, ldo, tot, (const int64_t*)nullptr);
     LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int sober_sum_partials_queued(const double* partG, const double* partTot, int n_rows, int ldg, int S,
+                                         const double* extraG, const double* extraTot, int n_xcols, double* G,
+                                         int ldo, double* tot, const int64_t* dR, void* stream) {
+    if (!partG || !partTot || !extraG || !extraTot || !G || !tot || !dR || n_rows <= 0 || S <= 0 || ldg < S || ldo < S ||
+        n_xcols <= 0)
+        return SOBER_E_ARG;
+    dim3 grid(nblk(S, 64), (unsigned)(n_rows + 1));
+    hipLaunchKernelGGL(k_sum_partials, grid, dim3(64), 0, (hipStream_t)stream, partG, partTot, 0, n_rows, ldg, S,
+                       extraG, extraTot, 0, n_xcols, G, ldo, tot, dR);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 
 extern "C" int sober_barycentres(const double* Xtr, int ldx, int n, int S, const double* tot,
                                  double* X_tmp, void* stream) {
