@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """Benchmark of the kernel-recombination step (BASELINE.json metric) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W          (N > 1)
+           --master-port P bench.py --gpus N --steps K --warmup W [--config C]          (N > 1)
 
-A "step" is ONE `sampling_recombination` call -- Gram + Nystrom basis + every halving level +
-the final direct level -- on a synthetic pool that is already resident in HBM:
-  N=1   BASELINE.json config 2: Ackley-shaped d=10, RBF, N_rec=100k, N_nys=500, batch=100,
-        n_obs=200 (inputs = tests/golden/synth.py seed 0, the cfg2 golden's inputs);
-  N>1   weak scaling: every rank owns a 100k-row shard of an N*100k pool; one recombination over
-        the whole pool, one small all-reduce (RCCL) per level.
+A "step" is ONE `sampling_recombination` call -- kernel build, Gram + Nystrom basis, every halving level, the final
+direct level -- on a synthetic pool that is already resident in HBM.  `--config` picks the BASELINE.json
+configuration (default 2, the one the metric is quoted on):
+  1  Branin-shaped   d=2  RBF (ARD)      N_rec=2k    N_nys=100  batch=10
+  2  Ackley-shaped   d=10 RBF            N_rec=100k  N_nys=500  batch=100
+  3  Hartmann-shaped d=6  Matern-5/2     N_rec=50k   N_nys=500  batch=200
+  4  Rosenbrock      d=20 RBF            N_rec=1M    N_nys=500  batch=100   (the 8-GPU configuration)
+  5  Malaria-shaped  2048-bit Tanimoto   N_rec=250k  N_nys=500  batch=100   (weighted posterior covariance)
+N > 1: one rank per GPU over RCCL, the pool row-sharded, one small all-reduce per level.  Configurations 1-3 and 5
+scale WEAKLY (every rank owns a full-size shard, one recombination over the N-fold pool); configuration 4 is the
+reference's 8-GPU case and scales STRONGLY (the 1M-row pool is split N ways: 125k rows per GPU at N = 8).
 Rank 0 prints ONE JSON line.  `value` = candidates reduced per second, whole job.
-`roofline` is for the dominant kernel (k_level_reduce): algorithmic FP64 flop (SURVEY.md 8d:
-(2d + 2 + C_k) per kernel entry, C_k = 28 for the software FP64 exp) / HIP-event time of the
-launches, against the FP64 peak.  `cpu_baseline` = the oracle (a torch-CPU port of the reference's
-own arithmetic, reference-shaped: it materialises the (E, M, S) tensor) on this box's host cores.
+`roofline` is for the dominant kernel (the level reduction): algorithmic FP64 flop ((2d + 2 + C_k)
+per kernel entry, C_k = 28 for the software FP64 exp, 40 for Matern-5/2) / HIP-event time of its launches, against
+the FP64 peak; for the Tanimoto kernel (integer work) the algorithmic bytes against the HBM peak.
+`cpu_baseline` = the oracle (a torch-CPU port of the reference's own arithmetic) on this box's host cores, on a
+bounded sample of the same workload: reference-shaped (materialises the (E, M, S) tensor of SOBER/_rchq.py:124) and
+streaming (the same sums over cache-sized element blocks); `value` is the faster of the two.
 """
 import argparse
 import json
@@ -33,14 +40,100 @@ sys.path.insert(0, ROOT)
 import sober_amd  # noqa: E402
 from tests.golden.synth import SEED_CALL, build_spec, synth  # noqa: E402
 
-CFG2 = dict(kind="rbf", mode="predictive_covariance", N=100000, M=500, d=10, b=100, n_obs=200, seed=0)
+CONFIGS = {
+    1: dict(kind="rbf", mode="predictive_covariance", N=2000, M=100, d=2, b=10, n_obs=30, seed=0, ard=True,
+            name="Branin-shaped d=2 RBF (ARD) posterior covariance", golden="recomb_cfg1_rbf_ard.npz"),
+    2: dict(kind="rbf", mode="predictive_covariance", N=100000, M=500, d=10, b=100, n_obs=200, seed=0,
+            name="Ackley-shaped d=10 RBF posterior covariance", golden="recomb_cfg2_rbf.npz"),
+    3: dict(kind="matern52", mode="predictive_covariance", N=50000, M=500, d=6, b=200, n_obs=200, seed=0,
+            name="Hartmann-shaped d=6 Matern-5/2 posterior covariance"),
+    4: dict(kind="rbf", mode="predictive_covariance", N=1000000, M=500, d=20, b=100, n_obs=200, seed=0,
+            name="Rosenbrock-shaped d=20 RBF posterior covariance", strong=True, cpu_sample_N=100000),
+    5: dict(kind="tanimoto", mode="weighted_predictive_covariance", N=250000, M=500, d=2048, b=100, n_obs=200,
+            seed=10, bit_p=0.04, mean_const=0.3, name="Malaria-shaped 2048-bit Tanimoto weighted posterior covariance",
+            cpu_sample_N=20000),
+}
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector = FP64 matrix (vendor)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
 CK = {"rbf": 28, "matern52": 40}
-PMC_TRAFFIC_BYTES_PER_LAUNCH = 23.4e6   # measured, see the comment at "traffic" below
+# HBM bytes per launch of the level kernel (mean over the launches of a step) from rocprofv3 PMC passes of the
+# configuration: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md; separate
+# --pmc passes; profiles/*_pmc_level_reduce.csv).  Algorithmic bytes at configuration 2 are ~1.7 MB/launch: the
+# excess is the per-chunk partial-sum buffers (n_chunks * Mtot * S * 8 B written, then re-read by k_sum_partials).
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {2: 23.4e6}
 
 
 def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def build_inputs(cfg, rank, world, dev):
+    """-> (X_cand, X_nys, mu0 on the device, spec, host inputs or None, rows on this rank)."""
+    case = {k: v for k, v in cfg.items() if k not in ("name", "golden", "strong", "cpu_sample_N")}
+    N_loc = case["N"] // world if cfg.get("strong") else case["N"]
+    if cfg["kind"] == "tanimoto":
+        # 250k x 2048 FP64 0/1 = 4 GB: built on the device; the GP side (observations, caches) from the small stream
+        small = dict(case, N=case["M"] + 1000)
+        base = synth(small)
+        spec = build_spec(small, base)
+        g0 = torch.Generator(device=dev)                             # rank 0's stream: its shard and the Nystrom points
+        g0.manual_seed(case["seed"])
+        X0 = (torch.rand(N_loc, case["d"], device=dev, generator=g0) < case["bit_p"]).to(torch.float64)
+        Xn = X0[torch.randperm(N_loc, device=dev, generator=g0)[:case["M"]]].clone()
+        g = torch.Generator(device=dev)
+        g.manual_seed(case["seed"] + 1000 + rank)
+        X = X0 if rank == 0 else (torch.rand(N_loc, case["d"], device=dev, generator=g) < case["bit_p"]).to(torch.float64)
+        del X0
+        mu0 = torch.rand(N_loc, device=dev, generator=g, dtype=torch.float64)
+        mu0 /= mu0.sum() * world
+        return X, Xn, mu0, spec, None, N_loc
+    shard = dict(case, N=N_loc, seed=case["seed"] + rank)            # every rank synthesises its own shard
+    inp = synth(shard)
+    base = synth(dict(case, N=N_loc)) if rank else inp               # X_nys / X_obs come from rank 0's stream
+    spec = build_spec(case, base)
+    return t(inp["X_cand"]).to(dev), t(base["X_nys"]).to(dev), t(inp["mu0"] / world).to(dev), spec, inp, N_loc
+
+
+def cpu_baseline_for(cfg, spec, inp, dev_inputs, cpu_steps):
+    """The oracle on the host cores, on a bounded sample (about 10-30 s of CPU work)."""
+    from oracle import sober_oracle as O
+    N_s = min(cfg.get("cpu_sample_N", cfg["N"]), cfg["N"])
+    if inp is not None:
+        Xc, Xn, m0 = t(inp["X_cand"][:N_s]), t(inp["X_nys"]), inp["mu0"][:N_s].copy()
+    else:
+        X_dev, Xn_dev, mu_dev = dev_inputs
+        Xc, Xn, m0 = X_dev[:N_s].cpu(), Xn_dev.cpu(), mu_dev[:N_s].cpu().numpy().copy()
+    m0 = m0 / m0.sum()
+    ok = O.Kernel(spec, cfg["mode"])
+
+    def cpu_step(stream):
+        m = t(m0.copy())
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return O.recombination(Xc, Xn, cfg["b"], ok, init_weights=m, stream_elements=stream)
+    # the reference-shaped CPU path barely scales with cores (memory-bound temporaries): time both variants at the
+    # host's thread count and at 8 threads, report the fastest
+    runs = {}
+    old = torch.get_num_threads()
+    for variant, stream in (("reference_shaped", None), ("streaming", 16)):
+        for th in sorted({os.cpu_count() // 2 or 1, 8}):
+            torch.set_num_threads(th)
+            cpu_step(stream)                                  # warm-up
+            c0 = time.perf_counter()
+            for _ in range(cpu_steps):
+                cpu_step(stream)
+            runs[(variant, th)] = (time.perf_counter() - c0) / cpu_steps
+    torch.set_num_threads(old)
+    best = min(runs, key=runs.get)
+    return {"value": N_s / runs[best], "unit": "candidates/s", "cores": best[1], "kind": "port", "variant": best[0],
+            "ms_per_step": runs[best] * 1e3,
+            "ms_per_step_by_variant_and_threads": {f"{v}@{th}": s * 1e3 for (v, th), s in runs.items()},
+            "sample": f"{cpu_steps} recombination steps after 1 warm-up on "
+                      + ("the full workload" if N_s == cfg["N"] else f"the first {N_s} candidates of the workload")
+                      + f" (N_nys={cfg['M']}, batch={cfg['b']}), oracle = torch CPU FP64 port of the reference: "
+                        "reference-shaped (materialised (E, M, S) tensor) and streaming (16-element blocks), each at "
+                        "8 threads and at half the host's hardware threads; fastest reported"}
 
 
 def main():
@@ -48,9 +141,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -72,22 +167,14 @@ def main():
             dist.init_process_group(backend)
         group = dist.group.WORLD
 
-    case = dict(CFG2)
-    case["seed"] = CFG2["seed"] + rank                 # every rank synthesises its own shard
-    inp = synth(case)
-    base = synth(CFG2) if rank else inp                # X_nys / X_obs come from rank 0's stream
-    spec = build_spec(CFG2, base)
+    X_cand, X_nys, mu0, spec, inp, N_loc = build_inputs(cfg, rank, world, dev)
     ks = sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs, spec.S_cache,
                               spec.noise, spec.mean_const, spec.alpha)
-    kernel = sober_amd.Kernel(ks, CFG2["mode"])
+    kernel = sober_amd.Kernel(ks, cfg["mode"])
     sober_amd.setting_parameters(device=dev, dtype=torch.double)
-    sampler = sober_amd.RecombinationSampler(kernel)
-
-    X_cand = t(inp["X_cand"]).to(dev)
-    X_nys = t(base["X_nys"]).to(dev)
-    mu0 = t(inp["mu0"] / world).to(dev)                # global weights sum to 1
     mu = mu0.clone()
-    N_loc, b = CFG2["N"], CFG2["b"]
+    b = cfg["b"]
+    N_total = N_loc * world
 
     from sober_amd._ops_hip import HipOps
     ops = HipOps(dev)
@@ -109,7 +196,7 @@ def main():
     # the warm-up steps run exactly what the timed steps run, event brackets included (their first use costs
     # tens of ms in a fresh process)
     ops.prof = []
-    ops.prof_reserve(16 * (args.steps + args.warmup + 1))    # event pairs for the level_reduce launches, created up front
+    ops.prof_reserve(24 * (args.steps + args.warmup + 1))    # event pairs for the level launches, created up front
     idx, w = step()                                      # initialisation (library load, workspaces, first-use paths)
     import gc
     gc.collect(); gc.disable()                           # no collector pauses inside the timed region
@@ -133,7 +220,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # dominant kernel: HIP-event time of every k_level_reduce launch in the timed region, minus the
+    # dominant kernel: HIP-event time of every level-reduction launch in the timed region, minus the
     # cost of an empty event pair on the same stream (calibrated here; ~5 us, comparable to the deep
     # levels' launches -- without it the event sum would not agree with rocprofv3's kernel durations)
     prof, ops.prof = ops.prof, None
@@ -148,15 +235,25 @@ def main():
     ev_overhead = float(np.median([a.elapsed_time(b_) for a, b_ in cal]))
     kern_ms = sum(max(a.elapsed_time(b_) - ev_overhead, 0.0) for a, b_, _ in prof)
     entries = sum(e for _, _, e in prof)
-    flop_per_entry = 2 * CFG2["d"] + 2 + CK[CFG2["kind"]]
-    achieved = entries * flop_per_entry / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+
+    # the step together with the Nystrom subsample that precedes it in the reference's funnel for a continuous
+    # prior (kmeans_resampling, SOBER/_weights.py:95-126, SOBER/_sampler.py:316-320); outside the timed region
+    kmeans_ms = None
+    if world == 1 and cfg["kind"] != "tanimoto":
+        sober_amd.KMeans(X_cand, cfg["M"])
+        torch.cuda.synchronize()
+        k0 = time.perf_counter()
+        for _ in range(3):
+            sober_amd.KMeans(X_cand, cfg["M"])
+        torch.cuda.synchronize()
+        kmeans_ms = (time.perf_counter() - k0) / 3 * 1e3
 
     if rank != 0:
         return
 
-    # parity of the timed configuration against the reference golden (N=1 only)
+    # parity of the timed configuration against the reference golden (N=1, configurations with a full-size golden)
     parity = None
-    gpath = os.path.join(ROOT, "tests", "golden", "recomb_cfg2_rbf.npz")
+    gpath = os.path.join(ROOT, "tests", "golden", cfg.get("golden", "-"))
     if world == 1 and os.path.exists(gpath):
         z = np.load(gpath)
         same = bool(np.array_equal(idx.cpu().numpy(), z["idx"]))
@@ -165,65 +262,55 @@ def main():
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import sober_oracle as O
-        Xc, Xn = t(inp["X_cand"]), t(inp["X_nys"])
-        ok = O.Kernel(spec, CFG2["mode"])
-
-        def cpu_step():
-            m = t(inp["mu0"].copy())
-            torch.manual_seed(SEED_CALL)
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                return O.recombination(Xc, Xn, b, ok, init_weights=m)
-        # the reference-shaped CPU path barely scales with cores (memory-bound temporaries): time it at the
-        # host's full thread count AND at 8 threads, report the faster one
-        runs = {}
-        for th in sorted({os.cpu_count() // 2 or 1, 8}):
-            torch.set_num_threads(th)
-            cpu_step()                                        # warm-up
-            c0 = time.perf_counter()
-            for _ in range(args.cpu_steps):
-                cpu_step()
-            runs[th] = (time.perf_counter() - c0) / args.cpu_steps
-        best = min(runs, key=runs.get)
-        cpu_s = runs[best]
-        cpu_baseline = {"value": N_loc / cpu_s, "unit": "candidates/s", "cores": best,
-                        "kind": "port", "ms_per_step": cpu_s * 1e3,
-                        "ms_per_step_by_threads": {str(k): v * 1e3 for k, v in runs.items()},
-                        "sample": f"{args.cpu_steps} full recombination steps of the same workload "
-                                  f"(N_rec=100k, N_nys=500, d=10, batch=100) after 1 warm-up, oracle "
-                                  f"(torch CPU FP64, reference-shaped), best of {sorted(runs)} threads"}
+        cpu_baseline = cpu_baseline_for(cfg, spec, inp, (X_cand, X_nys, mu0), args.cpu_steps)
 
     ms_per_step = elapsed / args.steps * 1e3
+    if cfg["kind"] == "tanimoto":
+        # integer work (AND + popcount over 32 words per entry): bounded by the LDS return path, reported against
+        # the HBM roofline with the algorithmic bytes of a launch = candidates * (words * 8 + 12)
+        words = (cfg["d"] + 63) // 64
+        n_rows = cfg["M"] + cfg["n_obs"]
+        cand = entries / n_rows
+        gbs = cand * (words * 8 + 12) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(args.config) if world == 1 else None,
+                    "kernel": "k_level_reduce<tanimoto>", "launches": len(prof),
+                    "kernel_ms_per_step": kern_ms / args.steps, "event_pair_overhead_ms": ev_overhead,
+                    "note": "bit-packed Tanimoto level kernel: the pool is read once per level (algorithmic bytes), "
+                            f"every candidate meets {n_rows} rows in registers; the kernel is bound by integer VALU / "
+                            "LDS-broadcast work, not by HBM -- the fraction says how far from the memory roofline"}
+    else:
+        flop_per_entry = 2 * cfg["d"] + 2 + CK[cfg["kind"]]
+        achieved = entries * flop_per_entry / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP64_PEAK_TFLOPS,
+                    "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(args.config) if world == 1 else None,
+                    "kernel": "k_level_reduce_mfma", "launches": len(prof), "kernel_ms_per_step": kern_ms / args.steps,
+                    "event_pair_overhead_ms": ev_overhead,
+                    "note": "FP64 compute-bound: -|x-y|^2/2 on v_mfma_f64_16x16x4 (augmented GEMM), "
+                            "table-driven FP64 exp on the VALU; MI355X FP64 vector and matrix peaks are "
+                            "both 78.6 TFLOP/s and share the DP units (scripts/fp64_pipes_probe.hip); "
+                            f"algorithmic flop = entries * (2d+2+C_k) = entries * {flop_per_entry}; all "
+                            "launches of a step are averaged (level 0 alone runs ~2x the average)"}
+    strong = bool(cfg.get("strong"))
+    n_rec = str(cfg["N"]) if (strong or world == 1) else "%dx%d" % (world, cfg["N"])
     out = {
-        "metric": "recombination-step candidates/sec (N_rec=100k, N_nys=500, d=10, batch=100)",
-        "value": world * N_loc / (elapsed / args.steps),
+        "metric": f"recombination-step candidates/sec (N_rec={n_rec}, N_nys={cfg['M']}, d={cfg['d']}, batch={cfg['b']})",
+        "value": N_total / (elapsed / args.steps),
         "unit": "candidates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "Ackley-shaped d=10 RBF posterior covariance, N_rec=100k per GPU, "
-                               "N_nys=500, batch=100, n_obs=200 (BASELINE.json configs[1])",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "u64" if cfg["kind"] == "tanimoto" else "f64", "data": "synthetic",
+        "config": {"workload": f"{cfg['name']}, N_rec={N_loc} per GPU ({N_total} in all), N_nys={cfg['M']}, "
+                               f"batch={cfg['b']}, n_obs={cfg['n_obs']} (BASELINE.json configs[{args.config - 1}])",
                    "parallelism": f"pool row-sharded x{world}, one all-reduce of (n*S+S) f64 per level"
                                   if world > 1 else "single GPU"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_PEAK_TFLOPS,
-                     # HBM bytes per launch (mean over the 11 launches of a step) from rocprofv3 PMC passes of
-                     # THIS workload: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction of
-                     # MI355X_MICROARCH.md; separate --pmc passes; profiles/r01_pmc_level_reduce.csv).
-                     # Algorithmic bytes are ~1.7 MB/launch: the excess is the per-chunk partial-sum
-                     # buffers (n_chunks * Mtot * S * 8 B written, then re-read by k_sum_partials).
-                     "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if world == 1 else None,
-                     "kernel": "k_level_reduce_mfma", "launches": len(prof), "kernel_ms_per_step": kern_ms / args.steps,
-                     "event_pair_overhead_ms": ev_overhead,
-                     "note": "FP64 compute-bound: -|x-y|^2/2 on v_mfma_f64_16x16x4 (augmented GEMM), "
-                             "table-driven FP64 exp on the VALU; MI355X FP64 vector and matrix peaks are "
-                             "both 78.6 TFLOP/s and share the DP units (scripts/fp64_pipes_probe.hip); "
-                             f"algorithmic flop = entries * (2d+2+C_k) = entries * {flop_per_entry}; all "
-                             "launches of a step are averaged (level 0 alone runs ~2x the average)"},
+        "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "parity": parity,
+        "kmeans_nystrom_subsample_ms": kmeans_ms,
+        "ms_per_step_incl_kmeans": None if kmeans_ms is None else ms_per_step + kmeans_ms,
         "phases_ms_per_step": {k: v / args.steps * 1e3 for k, v in timers.items()},
         "ms_each_step": [round(v * 1e3, 3) for v in per_step],
         "n_selected": int(idx.numel()),

@@ -315,11 +315,16 @@ def _second_elimination(Xp, obj_p, w_star, idx_star):
 
 
 def mod_tchernychova_lyons(samp, U_svd, pt_nys, kernel, mu=None, calc_obj=None,
-                           trace: Optional[list] = None):
+                           trace: Optional[list] = None, stream_elements: Optional[int] = None):
     """SOBER/_rchq.py:51-221, reference-shaped: materialises the (E, M, S) kernel
     tensor per level exactly like the reference.  ``mu`` is mutated (Q3).  If
     ``trace`` is a list, one dict per CAR call is appended (R, E, r, tot_weights,
-    X_tmp, idx_star, w_star)."""
+    X_tmp, idx_star, w_star).
+
+    ``stream_elements`` (bench.py's second CPU baseline, never the parity checker): the set sums of
+    :124-126 accumulated over blocks of that many elements, so that the kernel tensor of a block stays
+    in the cache instead of going through DRAM -- the same sums in a different association order
+    (results equal to rounding, not bit for bit)."""
     dt = samp.dtype
     N = len(samp)
     n, length = U_svd.shape
@@ -361,9 +366,14 @@ def mod_tchernychova_lyons(samp, U_svd, pt_nys, kernel, mu=None, calc_obj=None,
         idx = idx_story[:number_of_el * number_of_sets].reshape(number_of_el, -1)
         N_approx = number_of_sets * number_of_el
         _idx_tmp = idx_story[:N_approx].reshape(number_of_el, number_of_sets)
-        K = kernel(pt_nys, samp[_idx_tmp]) * mu[_idx_tmp].unsqueeze(1)   # :124
         X_for_nys = torch.zeros(length, number_of_sets, dtype=dt)
-        X_for_nys += K.sum(axis=0)
+        if stream_elements is None:
+            K = kernel(pt_nys, samp[_idx_tmp]) * mu[_idx_tmp].unsqueeze(1)   # :124
+            X_for_nys += K.sum(axis=0)
+        else:
+            for lo in range(0, number_of_el, stream_elements):
+                blk = _idx_tmp[lo:lo + stream_elements]
+                X_for_nys += (kernel(pt_nys, samp[blk]) * mu[blk].unsqueeze(1)).sum(axis=0)
 
         N_rest = len(idx_story) - N_approx
         if N_rest > 0:                                                   # Q1, :128-136
@@ -434,13 +444,14 @@ def mod_tchernychova_lyons(samp, U_svd, pt_nys, kernel, mu=None, calc_obj=None,
 
 
 def recombination(pts_rec, pts_nys, num_pts, kernel, init_weights=None, calc_obj=None,
-                  trace: Optional[dict] = None):
+                  trace: Optional[dict] = None, stream_elements: Optional[int] = None):
     """SOBER/_rchq.py:5-31 -> rc_kernel_svd (42-48).  Returns (idx_star, w_star)."""
     psd_trace = {} if trace is not None else None
     _, U = ker_svd_sparsify(pts_nys, num_pts - 1, kernel, trace=psd_trace)
     levels = [] if trace is not None else None
     w_star, idx_star = mod_tchernychova_lyons(
-        pts_rec, U, pts_nys, kernel, mu=init_weights, calc_obj=calc_obj, trace=levels)
+        pts_rec, U, pts_nys, kernel, mu=init_weights, calc_obj=calc_obj, trace=levels,
+        stream_elements=stream_elements)
     if trace is not None:
         trace.update(U=U, psd=psd_trace, levels=levels)
     return idx_star, w_star
