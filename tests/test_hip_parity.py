@@ -1171,3 +1171,133 @@ def test_sharded_device_path_two_ranks_one_gpu(name, cuts, dev):
     nz = np.flatnonzero(mu_all)
     assert np.array_equal(nz, z["mu_after_idx"])                      # Q3 across the shards
     np.testing.assert_allclose(mu_all[nz], z["mu_after_val"], rtol=W_RTOL)
+
+
+# --------------------------------------------------------------------------- #
+# BASELINE.json configurations 4 and 5 at FULL size: no CPU reference finishes in test time there, so the checks are
+# the size-independent properties of a recombination (positive weights, mass, support, Q3, the moment identity on a
+# variant without leftovers, run-to-run bit equality) -- the arithmetic itself is pinned at reduced size above
+# --------------------------------------------------------------------------- #
+CFG4 = dict(kind=O.RBF, mode="predictive_covariance", N=1000000, M=500, d=20, b=100, n_obs=200, seed=0)
+CFG5 = dict(kind=O.TANIMOTO, mode="weighted_predictive_covariance", N=250000, M=500, d=2048, b=100, n_obs=200,
+            seed=10, bit_p=0.04, mean_const=0.3)
+
+
+def _full_size_inputs(case, N, dev):
+    from tests.golden.synth import synth, build_spec
+    if case["kind"] == O.TANIMOTO:                          # 4 GB as FP64 0/1 on the host: built on the device
+        small = dict(case, N=case["M"] + 1000)
+        inp = synth(small)
+        spec = build_spec(small, inp)
+        g = torch.Generator(device=dev)
+        g.manual_seed(case["seed"])
+        X = (torch.rand(N, case["d"], device=dev, generator=g) < case["bit_p"]).to(torch.float64)
+        Xn = X[torch.randperm(N, device=dev, generator=g)[:case["M"]]].clone()
+        mu0 = torch.rand(N, device=dev, generator=g, dtype=torch.float64)
+        mu0 /= mu0.sum()
+        return X, Xn, mu0, spec
+    c = dict(case, N=N)
+    inp = synth(c)
+    return _t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), _t(inp["mu0"]).to(dev), build_spec(c, inp)
+
+
+def _recombine(X, Xn, mu0, spec, case, trace=None):
+    mu = mu0.clone()
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx, w = sober_amd.recombination(X, Xn, case["b"], sober_amd.Kernel(kspec(spec), case["mode"]),
+                                         init_weights=mu, _trace=trace)
+    return idx, w, mu
+
+
+def _check_full_size(case, N_noleft, dev):
+    b = case["b"]
+    X, Xn, mu0, spec = _full_size_inputs(case, case["N"], dev)
+    idx, w, mu = _recombine(X, Xn, mu0, spec, case)
+    assert 0 < len(idx) <= b and (w > 0).all()
+    assert abs(float(w.sum()) - float(mu0.sum())) < 1e-12
+    assert torch.equal(torch.nonzero(mu).flatten(), idx.sort().values)          # Q3: the caller's weights, in place
+    assert torch.equal(mu[idx], w) and len(idx.unique()) == len(idx)
+    idx2, w2, mu2 = _recombine(X, Xn, mu0, spec, case)
+    assert torch.equal(idx, idx2) and torch.equal(w, w2) and torch.equal(mu, mu2)   # bit-reproducible
+    del X, mu, mu2
+    # without leftovers (N = 2b 2^k: every level divides evenly) the Nystrom test functions' integrals are
+    # preserved exactly: U C(X_nys, pool) mu0 == U C(X_nys, selected) w
+    X, Xn, mu0, spec = _full_size_inputs(case, N_noleft, dev)
+    trace = {}
+    idx, w, mu = _recombine(X, Xn, mu0, spec, case, trace)
+    kern = sober_amd.Kernel(kspec(spec), case["mode"])
+    U = trace["U"].to(dev)
+    lhs = torch.zeros(U.shape[0], dtype=torch.float64, device=dev)
+    for lo in range(0, N_noleft, 1 << 17):
+        hi = min(N_noleft, lo + (1 << 17))
+        lhs += U @ (kern(Xn, X[lo:hi]) @ mu0[lo:hi])
+    rhs = U @ (kern(Xn, X[idx]) @ w)
+    assert float((lhs - rhs).norm() / lhs.norm()) < 1e-8
+    assert len(idx) <= b and abs(float(w.sum()) - 1.0) < 1e-12
+
+
+def test_cfg4_full_size_properties(dev):
+    """Rosenbrock-shaped d=20 RBF, N_rec = 1M on one GPU (BASELINE.json configs[3] before sharding)."""
+    _check_full_size(CFG4, 200 * 4096, dev)
+
+
+def test_cfg5_full_size_properties(dev):
+    """Malaria-shaped 2048-bit Tanimoto, weighted posterior covariance, N_rec = 250k (BASELINE.json configs[4])."""
+    _check_full_size(CFG5, 200 * 1024, dev)
+
+
+def _shard_worker_synth(rank, world, port, case, outq):
+    import torch.distributed as dist
+    from tests.golden.synth import synth, build_spec
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        inp = synth(case)
+        spec = build_spec(case, inp)
+        n = case["N"] // world
+        lo, hi = rank * n, (rank + 1) * n if rank < world - 1 else case["N"]
+        X = _t(inp["X_cand"][lo:hi].copy()).to(dev)
+        mu = _t(inp["mu0"][lo:hi].copy()).to(dev)
+        torch.manual_seed(SEED_CALL if rank == 0 else SEED_CALL + 17 * rank)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx, w = sober_amd.recombination(X, _t(inp["X_nys"]).to(dev), case["b"],
+                                             sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu,
+                                             group=dist.group.WORLD, row_offset=lo)
+        outq.put((rank, idx.cpu().numpy(), w.cpu().numpy(), int(torch.count_nonzero(mu))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg4_shape_eight_ranks_one_gpu(dev):
+    """BASELINE.json configs[3] as it is meant to run: the 1M-row pool split over 8 ranks (125k rows each), one
+    all-reduce per level -- eight processes share the test box's one GPU and talk through gloo.  Every rank must
+    return what ONE rank computes on the whole pool: identical global indices, weights to rounding."""
+    import socket
+    import torch.multiprocessing as mp
+    X, Xn, mu0, spec = _full_size_inputs(CFG4, CFG4["N"], dev)
+    idx1, w1, _ = _recombine(X, Xn, mu0, spec, CFG4)
+    idx1, w1 = idx1.cpu().numpy(), w1.cpu().numpy()
+    del X, mu0
+    torch.cuda.empty_cache()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker_synth, args=(r, world, port, CFG4, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, idx, w, _ in outs:
+        assert np.array_equal(idx, idx1), rank
+        np.testing.assert_allclose(w, w1, rtol=1e-9)
+    assert sum(o[3] for o in outs) == len(idx1)                       # Q3 across the eight shards
