@@ -1,23 +1,26 @@
-"""Per-segment cycle counts of k_car_pivot, waves 0 and 1 (build car.hip with -DCAR_STAMPS)."""
-import numpy as np, torch, sys, os
+"""Where a bidiagonalisation step of the one-CU Caratheodory kernel (csrc/car.hip) spends its cycles: run with the
+stamp build (`make -C sober_amd/csrc stamps`, SOBER_HIP_LIB=sober_amd/csrc/build/libsober_hip_stamps.so)."""
+import os, sys
+import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sober_amd import _native as nat
 dev = torch.device("cuda:0")
-z = np.load("tests/golden/recomb_matern_medium.npz")
+z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "recomb_matern_medium.npz"))
 X, mu = np.ascontiguousarray(z["L0_X_tmp"]), z["L0_tot_weights"]
-N, n = X.shape; m = n + 1
+N, n = X.shape
+m = n + 1
 Xd, mud = torch.from_numpy(X).to(dev), torch.from_numpy(mu).to(dev)
 kr = torch.empty(N, dtype=torch.int32, device=dev); ws = torch.empty(N, dtype=torch.float64, device=dev)
 nk = torch.empty(1, dtype=torch.int32, device=dev); mo = torch.empty(N, dtype=torch.float64, device=dev)
 for it in range(3):
     nat.car_device(Xd, mud, kr, ws, nk, mo)
-    torch.cuda.synchronize()
-    scratch = nat._CAR_WS[Xd.device]
-    Phi = scratch[m * 208 + 128:]
-    sub = Phi.view(torch.int64)[207 * 128 + 112: 207 * 128 + 128].cpu().numpy()
-    print("pivot kernel ticks per pivot [read+mu, owner ratio (avg), non-owner elim, barrier wait]: wave0", sub[:4] / 100.0, " wave1", sub[8:12] / 100.0,
-          " owner: iteration start -> published:", sub[4] / max(sub[5], 1), "ticks x", sub[5], " owner's own barrier wait:", sub[6] / max(sub[5], 1), " barrier wait + deferred block:", sub[7] / max(sub[5], 1))
-    arr = Phi.view(torch.int64)[206 * 128 + 64: 206 * 128 + 80].cpu().numpy()
-    print("per-wave mean arrival at the barrier (ticks after iteration start):", (arr / 100.0).round())
-    a50 = Phi.view(torch.int64)[205 * 128 + 64: 205 * 128 + 80].cpu().numpy()
-    print("arrival at step 50 (owner = wave 3):", a50)
+torch.cuda.synchronize()
+buf = nat._CAR_WS[Xd.device]
+off = m * 208 + 128 + 208 * 128
+d = buf[off:off + 512].cpu().numpy().view(np.uint64).astype(np.float64)[:4 * 8 * 10].reshape(4, 8, 10)
+names = ["loop", "A:reflector", "bar1", "B:apply G", "bar2", "C:H+zpart", "bar3", "D:colsum", "bar4", "update"]
+tot = d.sum(1)
+for w in range(4):
+    t = tot[w] / m
+    print("wave %d " % w + " ".join("%s %.0f" % (a, b) for a, b in zip(names, t)) + " | sum %.0f" % t.sum())
+print("by 16-step block (wave 0): " + " ".join("%.0f" % (d[0, s].sum() / 16) for s in range(7)))

@@ -162,13 +162,28 @@ struct CarLds {
     double* vbuf; double* colb; double* zsum; double* zpart; double* scal;
 };
 
+#ifdef CAR_BSTAMPS      // diagnostic build (`make stamps`): per-segment cycle sums of every wave -> behind the tau block
+#define CB_DECL unsigned long long cacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ctl_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ctl_) :: "memory");
+#define CB_STAMP(K) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    cacc_[K] += t_ - ctl_; ctl_ = t_; } while (0)
+#define CB_FLUSH(S_) do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 10; ++k_) \
+    ((unsigned long long*)(taup + 128 + CAR_NS * CAR_PC))[((threadIdx.x >> 6) * 8 + (S_)) * 10 + k_] = cacc_[k_]; } while (0)
+#else
+#define CB_DECL
+#define CB_STAMP(K) do { } while (0)
+#define CB_FLUSH(S_) do { } while (0)
+#endif
+
 template <int S>
 __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], int m, const CarLds& L,
                                                  double* __restrict__ vws, double* __restrict__ taup) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int R = tid >> 4, C = tid & 15;
     const int i_end = min(16 * S + 16, m);
+    CB_DECL
     for (int i = 16 * S; i < i_end; ++i) {
+        CB_STAMP(0);
         const int li = i & 15;                               // row i: DPP row li, slot S; column i: lane li, slot S
         if (R == li) {                                                 // (A)
             double ss0 = 0.0, ss1 = 0.0;
@@ -194,8 +209,10 @@ __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], in
             }
             if (C == 0) { taup[i] = tau; L.scal[1] = tau; }
         }
-        if (i == m - 1) return;
+        if (i == m - 1) { CB_FLUSH(S); return; }
+        CB_STAMP(1);
         CAR_LDS_BARRIER();
+        CB_STAMP(2);
         {                                                              // (B)
             const double tau = L.scal[1];
             double v[CAR_CQ];
@@ -216,7 +233,9 @@ __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], in
                 for (int k = S; k < CAR_MS; ++k) L.colb[R + 16 * k] = a[k][S];
             }
         }
+        CB_STAMP(3);
         CAR_LDS_BARRIER();
+        CB_STAMP(4);
         double u[CAR_MS], tauq;
         {                                                              // (C), redundantly in every wave
             const double x0 = L.colb[lane], x1 = L.colb[lane + 64];    // zero from row m on
@@ -239,7 +258,9 @@ __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], in
 #pragma unroll
             for (int q = S; q < CAR_CQ; ++q) L.zpart[R * CAR_NS + C + 16 * q] = zp[q];
         }
+        CB_STAMP(5);
         CAR_LDS_BARRIER();
+        CB_STAMP(6);
         if (tid >= 16 * S && tid < CAR_NS) {                           // (D): columns of the live slots
             double z0 = 0.0, z1 = 0.0;
 #pragma unroll
@@ -249,7 +270,9 @@ __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], in
             }
             L.zsum[tid] = z0 + z1;
         }
+        CB_STAMP(7);
         CAR_LDS_BARRIER();
+        CB_STAMP(8);
         {
             double zq[CAR_CQ];
 #pragma unroll
@@ -265,7 +288,9 @@ __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], in
             }
         }
         // (the next (A) touches registers, vbuf and scal[1] only; both were last read before the 2nd barrier)
+        CB_STAMP(9);
     }
+    CB_FLUSH(S);
 }
 
 __global__ __launch_bounds__(CAR_BT) void k_car_bidiag(const double* __restrict__ X, int ldx, int N, int m,
@@ -635,7 +660,7 @@ extern "C" int sober_car_supported(int N, int m) {
 // scratch: reflectors (m x 208), tau (m, padded to 128), Phi (208 x 128)
 // (a workspace sized for (N, m) also serves every (N' <= N, m): the final direct level)
 extern "C" int64_t sober_car_ws_bytes(int N, int m) {
-    const int64_t one = ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC) * (int64_t)sizeof(double);
+    const int64_t one = ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC + 512) * (int64_t)sizeof(double);   // (+512: stamp block)
     if (car_one_cu(N, m)) return one;
     const int64_t mc = sober_car_mc_ws_bytes(N, m);
     return mc > one ? mc : one;
