@@ -43,7 +43,7 @@ class HipOps:
         p.n_obs = spec.X_obs.shape[0] if corrected else 0
         stacked = torch.cat([X_nys.to(torch.float64), spec.X_obs], 0) if corrected else X_nys
         p.rows = prepare_points(spec, stacked)                    # [X_nys; X_obs]
-        p.cand = prepare_points(spec, X_cand)
+        p.cand = self._packed_pool(spec, X_cand)
         p.Mtot = len(p.rows)
         p.weighted = mode == "weighted_predictive_covariance"
         p.mean_nys = p.wmul = None
@@ -75,6 +75,25 @@ class HipOps:
         p.P = None
         p.ws = {}
         return p
+
+    def _packed_pool(self, spec, X_cand):
+        """prepare_points for the candidate pool.  A fingerprint pool (Tanimoto) arrives as an FP64 0/1 matrix --
+        4 GB at 250k x 2048 -- and a dataset prior hands over the SAME matrix at every BO iteration
+        (SOBER/_sampler.py:351-382): its bit-packed form (64x smaller) is kept across calls.  The key is the
+        tensor's storage, layout and in-place version counter; the cache holds a reference to the tensor, so its
+        memory cannot be handed to another tensor while the entry lives.  `clear_cache()` drops it."""
+        if spec.kind != "tanimoto":
+            return prepare_points(spec, X_cand)
+        key = (X_cand.data_ptr(), tuple(X_cand.shape), tuple(X_cand.stride()), X_cand.dtype, X_cand._version)
+        hit = getattr(self, "_pool_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[2]
+        pts = prepare_points(spec, X_cand)
+        self._pool_cache = (key, X_cand, pts)
+        return pts
+
+    def clear_cache(self):
+        self._pool_cache = None
 
     def gram(self, p: Plan):
         """kernel(pt, pt) of SOBER/_rchq.py:35 for the plan's mode."""

@@ -21,6 +21,20 @@ from ._kernel import MODES, Kernel
 from ._settings import setting_parameters
 
 
+_OPS = {}
+
+
+def _default_ops(dev, fused, HipOps, CallableKernelOps):
+    dev = torch.device(dev)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev, bool(fused))
+    ops = _OPS.get(key)
+    if ops is None:
+        ops = _OPS[key] = HipOps(dev) if fused else CallableKernelOps(dev)
+    return ops
+
+
 def _device_of(t, fallback):
     return t.device if t.is_cuda else fallback
 
@@ -55,7 +69,9 @@ def recombination(pts_rec, pts_nys, num_pts, kernel, device=None, dtype=None, in
         # raises when there is no HIP device / library.  A sober_amd.Kernel takes the fused path; any other
         # callable (the reference's kernel protocol, e.g. BASQ's gspace_kernel) is evaluated by the caller's
         # own torch code and only the kernel matrix itself is outside the HIP path
-        _ops = HipOps(dev) if fused else CallableKernelOps(dev)
+        # one backend object per device and kind, kept across calls: pinned staging buffers, event pools and the
+        # bit-packed form of a fingerprint pool that comes back unchanged at the next BO iteration
+        _ops = _default_ops(dev, fused, HipOps, CallableKernelOps)
     dev = _ops.device
 
     N = pts_rec.shape[0]
