@@ -183,6 +183,14 @@ int64_t sober_car_ws_bytes(int N, int m);
 int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
                      int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
                      double* phi_out, void* ws, int64_t ws_bytes, void* stream);
+/* The extra elimination of the acquisition-guided branch (SOBER/_rchq.py:87-106, :177-196) after a Caratheodory step
+ * with the objective as one more test function: the n1 surviving weights w1 (in rank order; rank1[0:Nsets] maps a
+ * set to its rank or -1) move along the null vector phi of [X_p; 1] -- the one-column phi_out of sober_car_device on
+ * the n1 survivors -- oriented so that sum w * objp does not decrease, until one more reaches zero.
+ * Out: keep_rank[0:Nsets] (new ranks, -1 = cancelled), w_star[0:n_keep], *n_keep.                               */
+int sober_second_elimination(const double* phi, const double* objp, const double* w1, const int32_t* rank1, int n1,
+                             int Nsets, int32_t* keep_rank, double* w_star, int32_t* n_keep, void* stream);
+
 /* The multi-CU implementation by itself (any size it covers, also the small ones: test and timing hook). */
 int sober_car_mc_supported(int N, int m);
 int64_t sober_car_mc_ws_bytes(int N, int m);

@@ -273,8 +273,9 @@ class RecombinationEngine:
         # vendor's gesdd/gesvd the null-space basis of [1 | X O]^T differs from that of [1 | X]^T.  So whenever the
         # Caratheodory steps of this run go to the host's LAPACK the literal route (U_B included) is taken and the
         # run reproduces the reference on the same machine whatever its LAPACK.
-        car_on_host = self.force_host_car or obj is not None or getattr(ops, "car_supported", None) is None \
-            or not ops.car_supported(S, n + 1)
+        n_fun = n + 1 + (1 if obj is not None else 0)
+        car_on_host = self.force_host_car or getattr(ops, "car_supported", None) is None \
+            or not ops.car_supported(S, n_fun) or (obj is not None and getattr(ops, "car_obj_device", None) is None)
         # (sharded runs keep the collectives in one fixed order on every rank: no overlap there, the ranks'
         # Nystrom routes may differ -- each draws its own randn -- and only rank 0's result is used)
         U = self.nystrom_basis(plan, n, overlap=head_once if comm.world == 1 else None, literal=car_on_host)
@@ -380,7 +381,22 @@ class RecombinationEngine:
         Np, n1 = X_dev.shape[0], X_dev.shape[1] + 1
         use_obj = getattr(self, "obj", None) is not None
         on_device = getattr(ops, "car_supported", None) is not None and ops.car_supported(Np, n1) \
-            and not self.force_host_car and not use_obj
+            and not self.force_host_car
+        if on_device and use_obj and getattr(ops, "car_obj_device", None) is not None:
+            # acquisition-guided branch: Caratheodory step with the objective as one more function + the extra
+            # elimination, both on the device (:84-106, :173-196)
+            res = ops.car_obj_device(X_dev, mu_dev, None if kind == "level" else self.obj_head)
+            if res is not None:
+                keep_rank_d, w_star_d, keep_rank, n_keep, (kr1_h, w1_d, n1k) = res
+                self._tick("levels_device", t0)
+                if levels is not None:
+                    X_h, mu_h, w1_h = ops.to_host(X_dev, mu_dev, w1_d)
+                    levels.append(dict(kind=kind, R=R, E=E, r=r, X_tmp=X_h, tot_weights=mu_h,
+                                       idx_star=torch.nonzero(kr1_h >= 0).flatten(), w_star=w1_h[:n1k].clone()))
+                return keep_rank_d, w_star_d, keep_rank, n_keep
+            on_device = False
+        elif use_obj:
+            on_device = False
         if on_device:
             keep_rank_d, w_star_d, n_keep_d, _ = ops.car_device(X_dev, mu_dev)
             if levels is not None:

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sober_car_supported": (_i32, [_i32, _i32]),
     "sober_car_ws_bytes": (_i64, [_i32, _i32]),
     "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sober_second_elimination": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sober_car_mc_supported": (_i32, [_i32, _i32]),
     "sober_car_mc_ws_bytes": (_i64, [_i32, _i32]),
     "sober_car_mc_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -337,6 +338,12 @@ def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None, multi_
     _check(fn(X.data_ptr(), X.stride(0), N, n + 1, mu_in.data_ptr(), keep_rank.data_ptr(),
               w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
               ws.data_ptr(), nbytes, _stream(X)), name)
+
+
+def second_elimination(phi, objp, w1, rank1, n1, keep_rank, w_star, n_keep):
+    _check(load().sober_second_elimination(phi.data_ptr(), objp.data_ptr(), w1.data_ptr(), rank1.data_ptr(), int(n1),
+                                           rank1.numel(), keep_rank.data_ptr(), w_star.data_ptr(), n_keep.data_ptr(),
+                                           _stream(phi)), "sober_second_elimination")
 
 
 def mc_selftest(x: torch.Tensor) -> torch.Tensor:

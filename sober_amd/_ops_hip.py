@@ -502,6 +502,35 @@ class HipOps:
         nat.car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out)
         return keep_rank, w_star, n_keep, mu_out
 
+    def car_obj_device(self, X, mu_in, obj_head=None):
+        """The Caratheodory step of the acquisition-guided branch on the device: X (N, n + 1) carries the objective
+        in its last column (SOBER/_rchq.py:79-81, :149-150), the step runs with n + 2 functions (:84, :173), then the
+        extra elimination along the null vector of [X_p; 1] (:87-106, :177-196) -- that vector is the one-column
+        null-space basis the same kernels produce for the n + 2 survivors.  `obj_head`: the final level's objective
+        values by LIST POSITION (the reference's indexing quirk, :89); None: the last column (:179).
+        -> (keep_rank_d, w_star_d, keep_rank host, n_keep, first-step trace) or None when the first step does not
+        leave exactly n + 2 points (the reference then takes a singular vector of a full-rank matrix: host route)."""
+        N, n1f = X.shape                                     # n1f = n + 1 functions incl. the objective
+        dev = self.device
+        kr1, w1, nk1, _ = self.car_device(X, mu_in)
+        (kr1_h, nk1_h) = self.to_host(kr1, nk1)
+        n1 = int(nk1_h[0])
+        if n1 != n1f + 1 or not nat.car_supported(n1, n1f):
+            return None
+        sel = torch.nonzero(kr1 >= 0).flatten()              # ascending set index = rank order
+        Xp = X[sel, :n1f - 1].contiguous()                    # (n1, n)
+        objp = (X[sel, n1f - 1] if obj_head is None else obj_head[sel]).contiguous()
+        phi = torch.empty(n1, 1, dtype=torch.float64, device=dev)
+        scratch = [torch.empty(n1, dtype=t_, device=dev) for t_ in (torch.int32, torch.float64, torch.float64)]
+        nkx = torch.empty(1, dtype=torch.int32, device=dev)
+        nat.car_device(Xp, w1[:n1].contiguous(), scratch[0], scratch[1], nkx, scratch[2], phi_out=phi)
+        keep_rank = torch.empty(N, dtype=torch.int32, device=dev)
+        w_star = torch.empty(N, dtype=torch.float64, device=dev)
+        n_keep = torch.empty(1, dtype=torch.int32, device=dev)
+        nat.second_elimination(phi, objp, w1, kr1, n1, keep_rank, w_star, n_keep)
+        (keep_h, nk_h) = self.to_host(keep_rank, n_keep)
+        return keep_rank, w_star, keep_h, int(nk_h[0]), (kr1_h, w1, n1)
+
     def level_update(self, idx_cur, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0):
         nat.level_update(idx_cur, 0, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0)
 

@@ -640,6 +640,72 @@ __global__ __launch_bounds__(CAR_PW * 64) void k_car_pivot(const double* __restr
 #undef CAR_MU_STEP
 }
 
+
+// ---------------- the extra elimination of the acquisition-guided branch (SOBER/_rchq.py:87-106, :177-196) ----------
+// After the Caratheodory step with one more test function (the objective), n1 = b + 1 points are left; their
+// weights move along the null vector w_null of [X_p; 1] (functions x points, a 1-dimensional null space) in the
+// direction that does not decrease sum w * calc_obj until one more weight reaches zero.  w_null arrives as the
+// one-column null-space basis of sober_car_device's phi_out (unit norm, sign arbitrary -- the reference fixes the
+// sign by the objective, :92-93, so ANY null vector gives its result).  One workgroup; n1 <= 512.
+//   in : phi[n1], objp[n1], w1[n1] (ranks of the first step), rank1[Nsets] (set -> rank or -1)
+//   out: keep_rank[Nsets] (new ranks), w_star[n_keep], *n_keep_out
+__global__ __launch_bounds__(512) void k_second_elim(const double* __restrict__ phi, const double* __restrict__ objp,
+                                                     const double* __restrict__ w1, const int32_t* __restrict__ rank1,
+                                                     int n1, int Nsets, int32_t* __restrict__ keep_rank,
+                                                     double* __restrict__ w_star, int32_t* __restrict__ n_keep_out) {
+    __shared__ double red[512];
+    __shared__ unsigned long long kmin[512];
+    __shared__ int kidx[512];
+    __shared__ int cnt[512];
+    const int t = threadIdx.x;
+    const double ph = t < n1 ? phi[t] : 0.0, ob = t < n1 ? objp[t] : 0.0, w = t < n1 ? w1[t] : 0.0;
+    red[t] = ob * ph;                                                   // torch.dot(obj_p, w_null): only its sign is used
+    __syncthreads();
+    for (int h = 256; h > 0; h >>= 1) {
+        if (t < h) red[t] += red[t + h];
+        __syncthreads();
+    }
+    const double wn = (red[0] < 0.0) ? -ph : ph;                        // :92-93
+    // alpha[plis] = w_star[plis] / w_null[plis]; first argmin (a NaN quotient wins like torch.argmin)
+    const bool ok = t < n1 && wn > 0.0;
+    const double al = w / wn;
+    kmin[t] = ok ? ratio_key(al) : ~0ull;
+    kidx[t] = t;
+    __syncthreads();
+    for (int h = 256; h > 0; h >>= 1) {
+        if (t < h) {
+            const unsigned long long a = kmin[t], b = kmin[t + h];
+            if (b < a || (b == a && kidx[t + h] < kidx[t])) { kmin[t] = b; kidx[t] = kidx[t + h]; }
+        }
+        __syncthreads();
+    }
+    const bool any = kmin[0] != ~0ull;
+    const int piv = kidx[0];
+    __shared__ double s_al;
+    if (t == piv) s_al = al;
+    __syncthreads();
+    // w_star = w_star - alpha[idx_sp] * w_null; w_star[idx_sp] = 0   (two roundings, :99-100)
+    double w2 = w;
+    if (any && t < n1) w2 = (t == piv) ? 0.0 : __dsub_rn(w, __dmul_rn(s_al, wn));
+    const bool keep = t < n1 && w2 > 0.0;
+    cnt[t] = keep ? 1 : 0;
+    __syncthreads();
+    for (int h = 1; h < 512; h <<= 1) {                                  // inclusive scan
+        const int v = (t >= h) ? cnt[t - h] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    if (keep) w_star[cnt[t] - 1] = w2;
+    red[t] = keep ? (double)(cnt[t] - 1) : -1.0;                        // new rank by old rank
+    __syncthreads();
+    for (int sidx = t; sidx < Nsets; sidx += 512) {
+        const int r1 = rank1[sidx];
+        keep_rank[sidx] = (r1 >= 0 && r1 < n1) ? (int)red[r1] : -1;
+    }
+    if (t == 0) *n_keep_out = cnt[511];
+}
+
 }  // namespace sober
 
 extern "C" int sober_car_mc_supported(int N, int m);
@@ -683,6 +749,17 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
     LAUNCH_CHECK();
     hipLaunchKernelGGL(sober::k_car_pivot, dim3(1), dim3(sober::CAR_PW * 64), 0, st, Phi, N, m, mu_in, keep_rank, w_star,
                        n_keep, mu_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_second_elimination(const double* phi, const double* objp, const double* w1, const int32_t* rank1,
+                                        int n1, int Nsets, int32_t* keep_rank, double* w_star, int32_t* n_keep,
+                                        void* stream) {
+    if (!phi || !objp || !w1 || !rank1 || !keep_rank || !w_star || !n_keep || n1 <= 0 || Nsets <= 0) return SOBER_E_ARG;
+    if (n1 > 512) return SOBER_E_DIM;
+    hipLaunchKernelGGL(sober::k_second_elim, dim3(1), dim3(512), 0, (hipStream_t)stream, phi, objp, w1, rank1, n1, Nsets,
+                       keep_rank, w_star, n_keep);
     LAUNCH_CHECK();
     return 0;
 }

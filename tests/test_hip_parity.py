@@ -547,7 +547,7 @@ def test_sharded_path_single_rank_rccl(dev):
 # --------------------------------------------------------------------------- #
 # BASELINE.json configs 3 and 5 (non-RBF kernels) against the oracle at / near full size
 # --------------------------------------------------------------------------- #
-def _vs_oracle(kind, mode, N, M, d, b, n_obs, seed, dev, bit_p=0.04, ard=True):
+def _vs_oracle(kind, mode, N, M, d, b, n_obs, seed, dev, bit_p=0.04, ard=True, calc_obj=None, timers=None):
     from tests.golden.synth import synth, build_spec
     case = dict(kind=kind, mode=mode, N=N, M=M, d=d, b=b, n_obs=n_obs, seed=seed, ard=ard, bit_p=bit_p,
                 mean_const=0.4)
@@ -558,15 +558,26 @@ def _vs_oracle(kind, mode, N, M, d, b, n_obs, seed, dev, bit_p=0.04, ard=True):
         warnings.simplefilter("ignore")
         torch.manual_seed(SEED_CALL)
         idx_ref, w_ref = O.recombination(_t(inp["X_cand"]), _t(inp["X_nys"]), b, O.Kernel(spec, mode),
-                                         init_weights=mu_ref)
+                                         init_weights=mu_ref, calc_obj=calc_obj)
         mu = _t(inp["mu0"].copy()).to(dev)
         torch.manual_seed(SEED_CALL)
         idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), b,
-                                         sober_amd.Kernel(kspec(spec), mode), init_weights=mu)
+                                         sober_amd.Kernel(kspec(spec), mode), init_weights=mu, calc_obj=calc_obj,
+                                         _timers=timers)
     assert np.array_equal(idx.cpu().numpy(), idx_ref.numpy())
     np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=W_RTOL)
     np.testing.assert_allclose(mu.cpu().numpy(), mu_ref.numpy(), rtol=W_RTOL, atol=0)
     assert abs(float(w.sum()) - 1.0) < 1e-12 and len(w) <= b
+
+
+@pytest.mark.parametrize("N,M,d,b", [(2000, 64, 3, 10), (6000, 150, 4, 50), (20000, 300, 6, 100), (9000, 300, 5, 120)])
+def test_calc_obj_levels_on_the_device(N, M, d, b, dev):
+    """The acquisition-guided branch (SOBER/_rchq.py:67-69, :79-106, :138-150, :168-196) with every Caratheodory
+    step (one more function: the objective) and every extra elimination on the device -- one-CU kernels up to batch
+    100, the multi-CU kernels beyond -- against the oracle's LAPACK route; no host Caratheodory step is taken."""
+    timers = {}
+    _vs_oracle(O.RBF, "predictive_covariance", N, M, d, b, 40, 300 + b, dev, calc_obj=calc_obj_fn, timers=timers)
+    assert "car_host" not in timers, timers
 
 
 def test_cfg3_matern_full_size_vs_oracle(dev):
