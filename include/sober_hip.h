@@ -371,6 +371,29 @@ int sober_level_car(const sober_level_job* job, void* stream);
 int sober_level_loop(sober_level_job* job, int64_t R, int32_t* idx_a, int32_t* idx_b, int first_sums_ready,
                      void** events, int max_levels, int64_t* level_R, int32_t* n_levels, int64_t* R_final,
                      int32_t* in_b, void* stream);
+/* The level loop of a ROW-SHARDED pool, native: rank `rank` of `world` owns the list positions
+ * [bounds[rank], bounds[rank+1]) (bounds: world + 1 int64, updated in place after every level from the replicated
+ * verdict: closed-form compaction, no candidate row moves).  Per level: local set sums -> ONE all-reduce of the flat
+ * (n S + S) double buffer job->Xtr (job->tot must follow it directly) through `allreduce(comm, buf, n, stream)` ->
+ * replicated Caratheodory step -> one synchronisation -> local sober_level_update.  Runs while the global number
+ * of live positions exceeds max(S, R_stop); the caller gathers the live rows once and finishes replicated
+ * (sober_level_loop + sober_level_final).  `allreduce` = sober_rccl_allreduce_f64 with an RCCL communicator from
+ * sober_rccl_comm_init in production; any function with that contract otherwise (the one-GPU tests run several ranks
+ * through a host transport).                                                                                    */
+typedef int (*sober_allreduce_fn)(void* comm, double* buf, int64_t n, void* stream);
+int sober_level_loop_sharded(sober_level_job* job, int rank, int world, int64_t* bounds, int32_t* idx_a,
+                             int32_t* idx_b, int first_sums_ready, sober_allreduce_fn allreduce, void* comm,
+                             int64_t R_stop, int max_levels, int64_t* level_R, int32_t* n_levels, int32_t* in_b,
+                             void* stream);
+/* RCCL bound at run time (csrc/rccl_link.cpp): dlopen of the library the host names (torch's own librccl.so), a
+ * communicator from a 128-byte unique id (rank 0 draws it, the host side distributes it), the in-place FP64 sum. */
+int sober_rccl_load(const char* path);
+int sober_rccl_unique_id(char* out128);
+int sober_rccl_comm_init(const char* id128, int rank, int world, void** comm);
+int sober_rccl_comm_destroy(void* comm);
+int sober_rccl_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
+int64_t sober_rccl_allreduce_ptr(void);     /* the address of sober_rccl_allreduce_f64, as an integer */
+
 /* The final direct level of an unsharded pool (n + 1 < R <= S, SOBER/_rchq.py:77-114) in one call: kernel columns of
  * the R live candidates (sober_pairwise on the SCALED points rows_sc / cand_sc, dt doubles or words per row), P K,
  * transpose, their weights, the Caratheodory step, mu[0:N] = 0 and the device-side write-back.  K: n_rows x R scratch,

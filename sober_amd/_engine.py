@@ -17,6 +17,7 @@ each level needs ONE all-reduce of the projected partial set sums (n x S doubles
 """
 from __future__ import annotations
 
+import os
 import time
 import warnings
 from typing import Optional
@@ -84,6 +85,31 @@ class DistComm:
         self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, 0) if self.group else 0,
                             group=self.group)
         return t
+
+    _RCCL = {}          # one RCCL communicator of our own per torch.distributed group
+
+    def native_allreduce(self, flat: torch.Tensor, device):
+        """-> (address of a sober_allreduce_fn, communicator pointer, keep-alive) for the level executor's sharded
+        loop.  Backend nccl: RCCL called from C on the stream (csrc/rccl_link.cpp).  Any other backend (gloo in the
+        one-GPU tests): a callback into this group's all_reduce on the flat buffer -- correct, not fast."""
+        import ctypes as C
+        dist, group = self.dist, self.group
+        if dist.get_backend(group) == "nccl":
+            key = id(group) if group is not None else 0
+            rc = DistComm._RCCL.get(key)
+            if rc is None:
+                rc = DistComm._RCCL[key] = nat.RcclComm(dist, group, device)
+            return rc.fn_ptr, rc.handle, rc
+
+        def cb(_comm, _buf, _n, _stream):
+            try:
+                torch.cuda.current_stream(device).synchronize()
+                dist.all_reduce(flat, group=group)
+                return 0
+            except Exception:                              # an exception must not unwind through the C caller
+                return -1
+        fn = nat.ALLREDUCE_FN(cb)
+        return C.cast(fn, C.c_void_p), None, fn
 
     def allgather_rows(self, t: torch.Tensor, counts):
         """Concatenate per-rank row blocks (rank r contributes counts[r] rows) in rank order."""
@@ -192,6 +218,14 @@ class RecombinationEngine:
         self.timers = {}                       # phase -> seconds (host wall clock, accumulated)
         self.force_host_car = False            # True: LAPACK null space + C++ pivots on the host
         self.force_host_nystrom = False        # True: make_cov_psd + svd_lowrank entirely on the host
+        self.basis_override = None             # a ready Nystrom basis (the replicated finish of a sharded run)
+        # sharded runs: once the global list is this short, the live rows are gathered and every rank finishes the
+        # remaining levels replicated -- a level's all-reduce (tens of us over xGMI) then costs more than the sharding
+        # of a level kernel that runs 30 us on one GPU saves.  An estimate from one-GPU kernel times; 0 disables.
+        self.cutover_R = int(os.environ.get("SOBER_CUTOVER_R", "32768"))
+        # a one-rank group normally runs as an unsharded pool; this sends it through the sharded loop and its
+        # collectives all the same (the RCCL path on a one-GPU box)
+        self.force_sharded = bool(os.environ.get("SOBER_FORCE_SHARDED"))
 
     def _tick(self, name, t0):
         t1 = time.perf_counter()
@@ -205,6 +239,8 @@ class RecombinationEngine:
         that enqueues device work independent of U; the device route calls it (once) while the host
         still works on the basis.  `literal`: take the host route (it returns svd_lowrank's U itself,
         final rotation U_B included)."""
+        if self.basis_override is not None:
+            return self.basis_override
         t0 = time.perf_counter()
         dev_route = getattr(self.ops, "nystrom_basis_device", None)
         if dev_route is not None and not self.force_host_nystrom and not literal:
@@ -291,13 +327,26 @@ class RecombinationEngine:
 
         if self.trace is not None:
             self.trace["levels"] = levels
-        if comm.world == 1 and obj is None and levels is None and not self.force_host_car and R > S \
+        sharded = comm.world > 1 or (self.force_sharded and getattr(comm, "native_allreduce", None) is not None)
+        if not sharded and obj is None and levels is None and not self.force_host_car and R > S \
                 and getattr(ops, "level_loop", None) is not None and ops.car_supported(S, n + 1):
             # unsharded pool, on-chip Caratheodory step: the whole loop below runs inside the level executor
             t0 = time.perf_counter()
             idx_cur, idx_new, R = ops.level_loop(plan, idx_cur, idx_new, R, S, mu, sums_ready)
             pos0, count, bounds, sums_ready = 0, R, [0, R], False
             self._tick("levels_device", t0)
+        elif sharded and obj is None and levels is None and not self.force_host_car and R > S \
+                and getattr(ops, "level_loop_sharded", None) is not None and ops.car_supported(S, n + 1) \
+                and getattr(comm, "native_allreduce", None) is not None:
+            # sharded pool: the levels run inside the level executor with the all-reduce issued from C; below
+            # cutover_R live positions the rows are gathered once and every rank finishes replicated
+            t0 = time.perf_counter()
+            idx_cur, idx_new, bounds = ops.level_loop_sharded(plan, idx_cur, idx_new, bounds, S, mu, sums_ready, comm,
+                                                              self.cutover_R)
+            R, pos0, count, sums_ready = bounds[-1], bounds[comm.rank], bounds[comm.rank + 1] - bounds[comm.rank], False
+            self._tick("levels_device", t0)
+            if R > S:
+                return self._finish_replicated(plan, idx_cur, bounds, mu, num_pts, U)
         while True:
             if R <= n + 1:                                  # :72-75
                 return self._finish_small(mu)
@@ -371,6 +420,31 @@ class RecombinationEngine:
         if n_left > 0:
             out[S - 1] += v[count - n_left:].sum()
         return out
+
+    def _finish_replicated(self, plan, idx_cur, bounds, mu, num_pts, U):
+        """The cut-over of a sharded run: every rank contributes the rows, weights and global indices of its live
+        positions (one all-gather each, in global list order), builds the plan of that short pool with the SAME
+        Nystrom basis and finishes the remaining levels as an unsharded run; the caller's shard of the weights is
+        then brought to the final state (Q3)."""
+        ops, comm = self.ops, self.comm
+        counts = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
+        loc = idx_cur[:counts[comm.rank]].long()
+        X_all = comm.allgather_rows(plan.X_cand_raw[loc].to(torch.float64).contiguous(), counts)
+        w_all = comm.allgather_rows(mu[loc].contiguous(), counts)
+        gid = comm.allgather_rows((loc + self.row_offset).contiguous(), counts)
+        plan2 = ops.build_plan(plan.spec, plan.mode, plan.X_nys_raw, X_all)
+        sub = RecombinationEngine(ops, SoloComm(), row_offset=0)
+        sub.basis_override = U
+        sub.force_host_nystrom, sub.force_host_car = self.force_host_nystrom, self.force_host_car
+        mu2 = w_all.clone().contiguous()
+        idx2, w2 = sub.run(plan2, mu2, num_pts)
+        for k, v in sub.timers.items():
+            self.timers[k] = self.timers.get(k, 0.0) + v
+        idx_glob = gid[idx2]
+        mu[loc] = 0.0                                                      # my cancelled rows
+        mine = (idx_glob >= self.row_offset) & (idx_glob < self.row_offset + mu.numel())
+        mu[idx_glob[mine] - self.row_offset] = w2[mine]
+        return idx_glob, w2
 
     # -- one Caratheodory step ---------------------------------------------------
     def _car(self, X_dev, mu_dev, R, E, r, levels, t0, kind="level"):

@@ -74,6 +74,13 @@ SIGNATURES = {
     "sober_wkde_draw": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sober_level_moments": (_i32, [_vp, _vp]),
     "sober_level_car": (_i32, [_vp, _vp]),
+    "sober_level_loop_sharded": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "sober_rccl_load": (_i32, [C.c_char_p]),
+    "sober_rccl_unique_id": (_i32, [_vp]),
+    "sober_rccl_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
+    "sober_rccl_comm_destroy": (_i32, [_vp]),
+    "sober_rccl_allreduce_f64": (_i32, [_vp, _vp, _i64, _vp]),
+    "sober_rccl_allreduce_ptr": (_i64, []),
     "sober_level_reduce_mfma_queued": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _f64,
                                               _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_sum_partials_queued": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
@@ -470,6 +477,55 @@ def level_loop(job: LevelJob, R: int, idx_a, idx_b, first_sums_ready: bool, even
                            "SOBER/_rchq.py:241-242); the reference would loop forever here")
     _check(rc, "sober_level_loop")
     return list(level_R[:n_levels.value]), int(R_final.value), bool(in_b.value)
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(_i32, _vp, _vp, _i64, _vp)      # sober_allreduce_fn(comm, buf, n, stream)
+
+
+def level_loop_sharded(job: LevelJob, rank: int, world: int, bounds, idx_a, idx_b, first_sums_ready: bool,
+                       allreduce_ptr, comm_ptr, R_stop: int, stream: int):
+    """sober_level_loop_sharded: -> (level_R list, new bounds list, final list is idx_b?).  allreduce_ptr: address of
+    a sober_allreduce_fn (sober_rccl_allreduce_ptr() or a ctypes callback cast to void*)."""
+    level_R = (_i64 * MAX_LEVELS)()
+    n_levels, in_b = _i32(0), _i32(0)
+    b = (_i64 * (world + 1))(*bounds)
+    rc = load().sober_level_loop_sharded(C.addressof(job), rank, world, b, idx_a.data_ptr(), idx_b.data_ptr(),
+                                         int(bool(first_sums_ready)), allreduce_ptr, comm_ptr, int(R_stop), MAX_LEVELS,
+                                         level_R, C.byref(n_levels), C.byref(in_b), stream)
+    if rc == E_NOPROGRESS:
+        raise RuntimeError("recombination made no progress (the Caratheodory step cancelled nothing, "
+                           "SOBER/_rchq.py:241-242); the reference would loop forever here")
+    _check(rc, "sober_level_loop_sharded")
+    return list(level_R[:n_levels.value]), list(b), bool(in_b.value)
+
+
+class RcclComm:
+    """An RCCL communicator of our own over the ranks of a torch.distributed group (csrc/rccl_link.cpp): rank 0
+    draws the unique id, the group's own collective carries it to the others."""
+
+    def __init__(self, dist, group, device):
+        import torch as _t
+        lib = load()
+        path = os.path.join(os.path.dirname(_t.__file__), "lib", "librccl.so")
+        _check(lib.sober_rccl_load(path.encode() if os.path.exists(path) else b""), "sober_rccl_load")
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = (C.c_char * 128)()
+        if rank == 0:
+            _check(lib.sober_rccl_unique_id(C.addressof(buf)), "sober_rccl_unique_id")
+        on_dev = dist.get_backend(group) == "nccl"
+        t = _t.frombuffer(bytearray(buf.raw), dtype=_t.uint8).clone()
+        t = t.to(device) if on_dev else t
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = bytes(t.cpu().numpy().tobytes())
+        self.handle = _vp()
+        with _t.cuda.device(device):
+            _check(lib.sober_rccl_comm_init(ident, rank, world, C.byref(self.handle)), "sober_rccl_comm_init")
+        self.fn_ptr = lib.sober_rccl_allreduce_ptr()
+
+    def close(self):
+        if self.handle:
+            load().sober_rccl_comm_destroy(self.handle)
+            self.handle = _vp()
 
 
 def level_final(job: LevelJob, rows, rows_norm, cand, cand_norm, dt, idx, R, N, row_offset, K, mu_live, out_idx,

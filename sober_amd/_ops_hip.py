@@ -36,6 +36,7 @@ class HipOps:
     def build_plan(self, spec: KernelSpec, mode: str, X_nys, X_cand) -> Plan:
         p = Plan()
         p.spec, p.mode = spec, mode
+        p.X_nys_raw, p.X_cand_raw = X_nys, X_cand                 # (the replicated finish of a sharded run rebuilds a plan)
         p.kind = nat.KIND_BY_NAME[spec.kind]
         p.M = X_nys.shape[0]
         dev = self.device
@@ -424,6 +425,20 @@ class HipOps:
                 else:
                     self._ev_pool.extend([a, b])
         return (idx_new, idx_cur, R_final) if in_b else (idx_cur, idx_new, R_final)
+
+    def level_loop_sharded(self, p: Plan, idx_cur, idx_new, bounds, S: int, mu, sums_ready: bool, comm, R_stop: int):
+        """The halving loop of a ROW-SHARDED pool in one call of the level executor (sober_level_loop_sharded): per
+        level one all-reduce of the flat (n S + S) buffer on the stream -- RCCL when the group's backend is nccl, the
+        group's own all_reduce through a callback otherwise (the one-GPU tests) -- and no Python in between.
+        Returns (idx_cur, idx_new, bounds) when the global list is down to max(S, R_stop)."""
+        job = self._job(p, S)
+        nat._req(mu, torch.float64, "mu"); nat._req(idx_cur, torch.int32, "idx"); nat._req(idx_new, torch.int32, "idx")
+        job.mu = mu.data_ptr()
+        fn_ptr, comm_ptr, keep = comm.native_allreduce(p.ws["XT"], self.device)
+        _, new_bounds, in_b = nat.level_loop_sharded(job, comm.rank, comm.world, bounds, idx_cur, idx_new, sums_ready,
+                                                     fn_ptr, comm_ptr, R_stop, nat._stream(mu))
+        del keep
+        return (idx_new, idx_cur, new_bounds) if in_b else (idx_cur, idx_new, new_bounds)
 
     def level_final(self, p: Plan, idx_cur, R: int, S: int, mu, row_offset: int):
         """The final direct level of an unsharded pool (n + 1 < R <= S, SOBER/_rchq.py:77-114) without leaving the

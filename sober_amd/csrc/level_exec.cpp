@@ -263,3 +263,71 @@ extern "C" int sober_record_event_pair(void* ev0, void* ev1, void* stream) {
     if (e == hipSuccess) e = hipEventRecord((hipEvent_t)ev1, (hipStream_t)stream);
     return e == hipSuccess ? 0 : (int)e;
 }
+
+// ---- the level loop of a ROW-SHARDED pool, native: no host language between the levels ------------
+// Rank `rank` of `world` owns the list positions [bounds[rank], bounds[rank + 1]) (contiguous ranges, kept in closed
+// form from the replicated verdicts).  Per level: the local set sums and masses (zeros for a rank without live
+// positions), ONE all-reduce of the flat (n S + S) buffer on the stream (`allreduce`: sober_rccl_allreduce_f64 in
+// production), the replicated Caratheodory step, one synchronisation for its verdict, the local weight update with the
+// closed-form compaction.  Runs while the global R exceeds max(S, R_stop): the caller finishes the rest replicated
+// after gathering the live rows once (the per-level all-reduce costs more than the sharding saves on short lists).
+static int64_t lx_survivors_before(int64_t p, int S, int64_t E, const int32_t* kept_prefix, int n_keep, bool last_kept) {
+    const int64_t ES = E * S;
+    if (p <= ES) return (p / S) * n_keep + kept_prefix[p % S];
+    return E * (int64_t)n_keep + (last_kept ? (p - ES) : 0);
+}
+
+extern "C" int sober_level_loop_sharded(sober_level_job* j, int rank, int world, int64_t* bounds, int32_t* idx_a,
+                                        int32_t* idx_b, int first_sums_ready, sober_allreduce_fn allreduce,
+                                        void* comm, int64_t R_stop, int max_levels, int64_t* level_R,
+                                        int32_t* n_levels, int32_t* in_b, void* stream) {
+    if (!j || !bounds || !idx_a || !idx_b || !allreduce || !level_R || !n_levels || !in_b || !j->h_flags || !j->mu ||
+        world <= 0 || rank < 0 || rank >= world || world > 1024)
+        return SOBER_E_ARG;
+    const int S = j->S, n = j->n;
+    if (j->Xtr + (size_t)n * S != j->tot) return SOBER_E_ARG;        // the flat all-reduce message: Xtr then tot
+    if (!sober_car_supported(S, n + 1)) return SOBER_E_DIM;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *cur = idx_a, *nxt = idx_b;
+    int levels = 0;
+    int32_t kept_prefix[1024 + 1];
+    if (S > 1024) return SOBER_E_DIM;
+    while (bounds[world] > S && bounds[world] > R_stop) {
+        if (levels >= max_levels) return SOBER_E_WS;
+        const int64_t R = bounds[world], E = R / S, r = R - E * S;
+        const int64_t pos0 = bounds[rank], count = bounds[rank + 1] - bounds[rank];
+        if (levels == 0 && first_sums_ready) {
+            // (the set sums of the first level are in G / tot already; only the projection is due)
+            j->phase = 2;
+            LX_TRY(sober_level_moments(j, stream));
+        } else if (count > 0) {
+            j->idx = cur; j->pos0 = pos0; j->count = count; j->E = E; j->phase = 0;
+            LX_TRY(sober_level_moments(j, stream));
+        } else {
+            hipError_t e = hipMemsetAsync(j->Xtr, 0, sizeof(double) * ((size_t)n * S + S), st);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (world > 1 || comm) LX_TRY(allreduce(comm, j->Xtr, (int64_t)n * S + S, stream));
+        LX_TRY(sober_level_car(j, stream));
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return (int)e;
+        const int n_keep = j->h_flags[S];
+        if (n_keep < 0) return SOBER_E_NOPROGRESS;
+        const bool last_kept = j->h_flags[S - 1] >= 0;
+        const int64_t R_new = E * n_keep + (last_kept ? r : 0);
+        level_R[levels++] = R;
+        if (R_new >= R) { *n_levels = levels; return SOBER_E_NOPROGRESS; }
+        kept_prefix[0] = 0;
+        for (int s = 0; s < S; ++s) kept_prefix[s + 1] = kept_prefix[s] + (j->h_flags[s] >= 0 ? 1 : 0);
+        int64_t nb_lo = lx_survivors_before(bounds[rank], S, E, kept_prefix, n_keep, last_kept);
+        if (count > 0)
+            LX_TRY(sober_level_update(cur, pos0, count, S, E, j->keep_rank, j->w_star, j->tot, n_keep, j->mu, nxt,
+                                      nb_lo, stream));
+        for (int q = 0; q <= world; ++q) bounds[q] = lx_survivors_before(bounds[q], S, E, kept_prefix, n_keep, last_kept);
+        int32_t* t = cur; cur = nxt; nxt = t;
+    }
+    j->phase = 0;
+    *n_levels = levels;
+    *in_b = (cur == idx_b) ? 1 : 0;
+    return 0;
+}

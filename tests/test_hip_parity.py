@@ -519,6 +519,42 @@ def test_host_and_device_car_agree(dev):
 # --------------------------------------------------------------------------- #
 # the distributed code path on the device (one rank: every collective still runs through RCCL)
 # --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("cutover", [0, 32768])
+def test_native_sharded_loop_over_rccl(cutover, dev, monkeypatch):
+    """sober_level_loop_sharded with the all-reduce issued from C through RCCL (csrc/rccl_link.cpp: our own
+    communicator from a unique id carried by the torch group) -- one rank on the one GPU of the test box, forced
+    through the sharded loop, the cut-over gather and the replicated finish; BASELINE configuration 2."""
+    import torch.distributed as dist
+    monkeypatch.setenv("SOBER_FORCE_SHARDED", "1")
+    monkeypatch.setenv("SOBER_CUTOVER_R", str(cutover))
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        path = os.path.join(GOLD, "recomb_cfg2_rbf.npz")
+        case, inp, spec, z = load_case(path)
+        mu = _t(inp["mu0"].copy()).to(dev)
+        timers = {}
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                             sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu,
+                                             group=dist.group.WORLD, row_offset=0, _timers=timers)
+        assert np.array_equal(idx.cpu().numpy(), z["idx"])
+        np.testing.assert_allclose(w.cpu().numpy(), z["w"], rtol=W_RTOL)
+        nz = torch.nonzero(mu).flatten().cpu().numpy()
+        assert np.array_equal(nz, z["mu_after_idx"])                      # Q3 through the gather / write-back
+        from sober_amd._engine import DistComm
+        assert len(DistComm._RCCL) >= 1                                   # the RCCL communicator was really made
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_sharded_path_single_rank_rccl(dev):
     import torch.distributed as dist
     created = False
@@ -1152,14 +1188,19 @@ def _shard_worker(rank, world, port, name, cuts, outq):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,cuts", [
-    ("rbf_medium", [0, 8100, 20000]),             # b = 50: on-chip Caratheodory steps, uneven ranges
-    ("rbf_b30", [0, 700, 1900, 3000]),            # three ranks
-    ("cfg2_rbf", [0, 50000, 100000]),             # BASELINE.json config 2, the shape the 2-GPU bench runs
+@pytest.mark.parametrize("name,cuts,cutover", [
+    ("rbf_medium", [0, 8100, 20000], 0),          # b = 50: on-chip Caratheodory steps, uneven ranges; sharded to the end
+    ("rbf_medium", [0, 8100, 20000], 4000),       # ... and with the replicated finish below 4000 live positions
+    ("rbf_b30", [0, 700, 1900, 3000], 0),         # three ranks
+    ("cfg2_rbf", [0, 50000, 100000], 32768),      # BASELINE.json config 2, the shape the 2-GPU bench runs
+    ("cfg2_rbf", [0, 30000, 100000], 0),
 ])
-def test_sharded_device_path_two_ranks_one_gpu(name, cuts, dev):
+def test_sharded_device_path_two_ranks_one_gpu(name, cuts, cutover, dev, monkeypatch):
+    """The native sharded level loop (sober_level_loop_sharded: all-reduce issued from C, here through the gloo
+    callback) and the cut-over to the replicated finish (cutover = live positions below which the rows are gathered)."""
     import socket
     import torch.multiprocessing as mp
+    monkeypatch.setenv("SOBER_CUTOVER_R", str(cutover))
     z = np.load(os.path.join(GOLD, f"recomb_{name}.npz"))
     assert cuts[-1] == int(z["N"])
     with socket.socket() as s:
