@@ -56,11 +56,13 @@ CONFIGS = {
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector = FP64 matrix (vendor)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
 CK = {"rbf": 28, "matern52": 40}
-# HBM bytes per launch of the level kernel (mean over the launches of a step) from rocprofv3 PMC passes of the
-# configuration: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md; separate
-# --pmc passes; profiles/*_pmc_level_reduce.csv).  Algorithmic bytes at configuration 2 are ~1.7 MB/launch: the
-# excess is the per-chunk partial-sum buffers (n_chunks * Mtot * S * 8 B written, then re-read by k_sum_partials).
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {2: 23.4e6}
+# HBM bytes per launch of the level kernel (mean over the launches of a step: 17 at configuration 2, the leftover
+# launches included) from rocprofv3 PMC passes of the configuration: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950
+# FETCH_SIZE correction of MI355X_MICROARCH.md; separate --pmc passes; profiles/r02_pmc_level_reduce.csv).
+# Algorithmic bytes at configuration 2 are ~1.3 MB/launch (every live candidate row, index and weight once per
+# level): the excess is the per-chunk partial-sum buffers (n_chunks * Mtot * S * 8 B written -- 14.6 MB at level 0
+# with 13 chunks -- then re-read by k_sum_partials).  Round 1 (26 chunks): 23.4 MB.
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {2: 11.6e6}
 
 
 def t(a):

@@ -19,6 +19,10 @@
         if (_e != hipSuccess) return (int)_e;           \
     } while (0)
 
+#ifndef SOBER_CHUNK_TARGET
+#define SOBER_CHUNK_TARGET 512      // workgroups a level launch aims for (~2 per CU): 1024 doubles the partial-sum traffic and is 9 % slower, 256 starves the 1M-row level (measured, scripts/_chunk_ab.py)
+#endif
+
 namespace sober {
 
 // Element chunks of one level launch (sober_level_chunks): ~4 workgroups per CU on 256 CUs, at most 64, no empty
@@ -27,7 +31,7 @@ namespace sober {
 __host__ __device__ inline int level_chunks_for(int n_rows, int64_t e_total, int S) {
     const int sb = (S + 15) / 16;
     const int rb = (n_rows + 255) / 256;
-    int64_t n = 1024 / ((int64_t)sb * rb);
+    int64_t n = SOBER_CHUNK_TARGET / ((int64_t)sb * rb);
     if (n < 1) n = 1;
     if (n > 64) n = 64;
     if (n > e_total) n = e_total;

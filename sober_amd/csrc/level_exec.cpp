@@ -94,7 +94,10 @@ extern "C" int sober_level_car(const sober_level_job* j, void* stream) {
 // an upper bound of the level takes the cap, not the count at the bound.)
 static int lx_chunks(int n_rows, int64_t e_total, int S) {
     const int sb = (S + 15) / 16, rb = (n_rows + 255) / 256;
-    int64_t n = 1024 / ((int64_t)sb * rb);
+#ifndef SOBER_CHUNK_TARGET
+#define SOBER_CHUNK_TARGET 512
+#endif
+    int64_t n = SOBER_CHUNK_TARGET / ((int64_t)sb * rb);
     if (n < 1) n = 1;
     if (n > SOBER_LEVEL_MAX_CHUNKS) n = SOBER_LEVEL_MAX_CHUNKS;
     if (n > e_total) n = e_total;
