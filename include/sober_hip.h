@@ -240,6 +240,15 @@ int sober_jitter_ladder(double* A, int n, int ld, int k, void* stream);
 int sober_jitter_ladder_auto(double* A, int n, int ld, const int32_t* info, int n_rungs, int32_t* k_out,
                              void* stream);
 
+/* K1-K3 for bit-packed fingerprints on the INT8 matrix cores (csrc/level_reduce_tani.hip): same contract as
+ * sober_level_reduce with kind = Tanimoto; dt = 64-bit words per fingerprint, 8 / 16 / 32 (512 .. 2048 bits)
+ * (sober_level_reduce_tani_supported); popcount(x & y) as v_mfma_i32_16x16x64_i8 on bits expanded to bytes.   */
+int sober_level_reduce_tani_supported(int dt);
+int sober_level_reduce_tani(const void* rows, const double* rows_norm, int n_rows, const void* cand,
+                            const double* cand_norm, int dt, const int32_t* idx, int64_t pos0, int64_t count, int S,
+                            const double* mu, const double* wmul, double outputscale, int n_chunks, double* partG,
+                            int ldg, int col0, double* partTot, int64_t tot_limit, void* stream);
+
 /* Queued-level forms (see sober_level_loop): the same kernels with the level size read from device memory.
  * sober_level_reduce_mfma_queued: leftover = 0: positions [0, *dR), set masses over [0, E S) (S = S_main);
  * leftover = 1: the leftover positions [E S_main, *dR) over S pseudo-sets.  Launch sized for count_ub positions
@@ -317,6 +326,7 @@ int sober_gspace_finish(double* K, const double* corr, int64_t n, int m, int64_t
 #define SOBER_LEVEL_VALU        0    /* sober_level_reduce      (rows/cand = scaled points or packed words) */
 #define SOBER_LEVEL_MFMA        1    /* sober_level_reduce_mfma (rows/cand = augmented points)              */
 #define SOBER_LEVEL_GATHER      2    /* sober_level_gather      (cand = Kmat, candidate-major, ld = kmat_ld) */
+#define SOBER_LEVEL_TANI        3    /* sober_level_reduce_tani (rows/cand = packed words, 512..2048 bits)   */
 #define SOBER_LEVEL_MAX_CHUNKS  64
 #define SOBER_LEVEL_XS          16   /* pseudo-sets of the leftover launch, folded into set S-1             */
 typedef struct sober_level_job {

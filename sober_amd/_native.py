@@ -74,6 +74,9 @@ SIGNATURES = {
     "sober_wkde_draw": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sober_level_moments": (_i32, [_vp, _vp]),
     "sober_level_car": (_i32, [_vp, _vp]),
+    "sober_level_reduce_tani_supported": (_i32, [_i32]),
+    "sober_level_reduce_tani": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _f64, _i32, _vp,
+                                       _i32, _i32, _vp, _i64, _vp]),
     "sober_level_loop_sharded": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sober_rccl_load": (_i32, [C.c_char_p]),
     "sober_rccl_unique_id": (_i32, [_vp]),
@@ -92,7 +95,7 @@ SIGNATURES = {
     "sober_level_loop": (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 
-LEVEL_VALU, LEVEL_MFMA, LEVEL_GATHER = 0, 1, 2
+LEVEL_VALU, LEVEL_MFMA, LEVEL_GATHER, LEVEL_TANI = 0, 1, 2, 3
 LEVEL_MAX_CHUNKS, LEVEL_XS, LEVEL_QUEUE = 64, 16, 24
 
 

@@ -30,6 +30,10 @@ static int lx_reduce(const sober_level_job* j, const int32_t* idx, int64_t pos0,
             return sober_level_reduce(j->kind, j->rows, j->rows_norm, j->n_rows, j->cand, j->cand_norm, j->dim, idx,
                                       pos0, count, S, j->mu, j->wmul, j->outputscale, n_chunks, partG, S, 0, partTot,
                                       tot_limit, stream);
+        case SOBER_LEVEL_TANI:
+            return sober_level_reduce_tani(j->rows, j->rows_norm, j->n_rows, j->cand, j->cand_norm, j->dim, idx, pos0, count,
+                                           S, j->mu, j->wmul, j->outputscale, n_chunks, partG, S, 0, partTot, tot_limit,
+                                           stream);
         case SOBER_LEVEL_GATHER:
             return sober_level_gather((const double*)j->cand, j->n_rows, j->kmat_ld, idx, pos0, count, S, j->mu,
                                       j->wmul, n_chunks, partG, S, 0, partTot, tot_limit, stream);

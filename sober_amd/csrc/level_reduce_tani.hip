@@ -1,0 +1,275 @@
+// K1-K3 for bit-packed fingerprints (Tanimoto kernel, SOBER/_drug_modelling.py:15-25,37) on the INT8 matrix cores.
+//
+//   k(x, y) = (<x, y> + eps) / (|x| + |y| - <x, y> + eps),   <x, y> = popcount(x & y) = sum_k x_k y_k,  x_k, y_k in {0, 1}
+//
+// The dot product of 0/1 vectors is an integer GEMM: with the bits expanded to bytes, v_mfma_i32_16x16x64_i8 does
+// 16 x 16 x 64 multiply-adds in 16 cycles per SIMD -- one 64-bit word of 16 rows against the same word of 16
+// candidates per instruction, exact in int32.  The VALU form (level_reduce.hip: AND + v_bcnt per 32 bits, operands
+// broadcast from LDS) needs ~130 integer instructions per (row, candidate) pair at 2048 bits; here a pair costs 1/8 of
+// an MFMA pass and the vector unit is left with the Tanimoto quotient and the weighted FP64 accumulation.
+//
+// Layout.  Workgroup = 4 waves x 32 rows (two 16-row MFMA tiles per wave) x 16 consecutive sets x one element chunk.
+// The rows' bits are expanded ONCE into registers (A fragments: 2 tiles x DT words x 16 bytes per lane = 256 VGPRs at
+// 2048 bits -- one wave per SIMD, the whole register file).  The 16 candidates of an element arrive bit-packed from
+// HBM (256 B each instead of 16 KB as the reference's FP64 0/1 matrix), are expanded to bytes by all 256 threads
+// (16 bits -> one ds_write_b128) into a double-buffered LDS tile with padded rows, and every wave reads its B
+// fragments with ds_read_b128.  A and B use the same bit -> byte position map, which is all a dot product needs.
+// C/D map (dtype independent on gfx950): col = lane & 15 (one candidate = one set), row = 4 (lane >> 4) + reg:
+// every lane owns 8 FP64 accumulators (2 tiles x 4 rows) of its set -- no atomics, fixed summation order.
+#include "common.hpp"
+
+namespace sober {
+
+typedef int int4_t __attribute__((ext_vector_type(4)));
+
+constexpr int LT_RW = 8;     // waves per workgroup (two per SIMD)
+constexpr int LT_RT = 1;     // 16-row MFMA tiles per wave: 128 VGPRs of A fragments at 2048 bits, nothing in AGPRs
+constexpr int LT_SB = 16;    // sets per workgroup = MFMA N
+constexpr int LT_TE = 2;     // elements (of 16 candidates) staged per tile
+constexpr int LT_ROWS = LT_RW * LT_RT * 16;   // 128 rows per workgroup
+
+// 16 bits -> 16 bytes of 0 / 1 (dword q holds bits 4q .. 4q+3, one per byte)
+__device__ __forceinline__ int4_t expand16(unsigned bits) {
+    int4_t r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = (int)((((bits >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u);
+    return r;
+}
+
+// (dot + eps) / (|x| + |y| - dot + eps) with a Newton-refined reciprocal (<= 1 ulp of the IEEE quotient, a third of its
+// instructions: eight quotients per lane and element are the vector unit's main load here); denominator >= eps > 0
+__device__ __forceinline__ double tani_fast(double dot, double nx, double ny, double os) {
+    const double eps = 1e-6;
+    const double den = ((eps + nx) + ny) - dot;
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    const double num = dot + eps;
+    double q = num * r;
+    q = fma(fma(-q, den, num), r, q);
+    return fmax(q, 0.0) * os;
+}
+
+template <int DT>      // 64-bit words per fingerprint
+__global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
+    const unsigned long long* __restrict__ rows, const double* __restrict__ rows_norm, int n_rows,
+    const unsigned long long* __restrict__ cand, const double* __restrict__ cand_norm,
+    const int32_t* __restrict__ idx, int64_t pos0, int64_t count, int S,
+    const double* __restrict__ mu, const double* __restrict__ wmul, double os,
+    int64_t e_first, int e_total, int e_per_chunk,
+    double* __restrict__ partG, int ldg, int col0,
+    double* __restrict__ partTot, int64_t tot_limit) {
+    constexpr int SB = LT_SB;
+    constexpr int ROWB = DT * 64 + 32;                 // bytes per candidate in LDS: row stride = 8 dwords mod 64 banks -> the four lane groups of a ds_read_b128 are conflict-free (a 16-byte pad leaves a 2-way conflict in each)
+    constexpr int TE = LT_TE;
+    constexpr int NC = TE * SB;                        // candidates per tile
+    constexpr int UNITS = NC * DT * 4;                 // 16-bit units per tile
+    constexpr int NTH = LT_RW * 64;                    // threads
+    constexpr int UPT = (UNITS + NTH - 1) / NTH;       // units per thread
+    // dynamic LDS (66 KB at 2048 bits: beyond the static limit): [2][SB * ROWB] candidate bytes, then [2][SB] weights
+    // and [2][SB] popcounts
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    unsigned char (*s_b)[NC * ROWB] = (unsigned char (*)[NC * ROWB])s_dyn;
+    double (*s_w)[NC] = (double (*)[NC])(s_dyn + 2 * NC * ROWB);
+    double (*s_ny)[NC] = (double (*)[NC])(s_dyn + 2 * NC * ROWB + 2 * NC * sizeof(double));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lj = lane & 15, lk = lane >> 4;
+    const int s0 = blockIdx.x * SB;
+    const int chunk = blockIdx.y;
+    const int row0 = blockIdx.z * LT_ROWS + wave * (LT_RT * 16);
+    const int e0 = chunk * e_per_chunk;
+    const int e1 = min(e0 + e_per_chunk, e_total);
+
+    // A fragments: lane holds bits [16 lk, 16 lk + 16) of every word of row (row0 + 16 t + lj), as bytes
+    int4_t afr[LT_RT][DT];
+#pragma unroll
+    for (int t = 0; t < LT_RT; ++t) {
+        const int r = row0 + 16 * t + lj;
+#pragma unroll
+        for (int ks = 0; ks < DT; ++ks) {
+            const unsigned long long wv = (r < n_rows) ? rows[(size_t)r * DT + ks] : 0ull;
+            afr[t][ks] = expand16((unsigned)(wv >> (16 * lk)) & 0xFFFFu);
+        }
+    }
+    double nxr[LT_RT][4];
+#pragma unroll
+    for (int t = 0; t < LT_RT; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = row0 + 16 * t + 4 * lk + v;
+            nxr[t][v] = (r < n_rows) ? rows_norm[r] : 0.0;
+        }
+    double acc[LT_RT][4];
+#pragma unroll
+    for (int t = 0; t < LT_RT; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[t][v] = 0.0;
+
+    // staging of one tile (TE elements of 16 consecutive list positions each): thread -> UPT 16-bit units.  The address
+    // chain idx -> candidate words is two global round trips, so the indices are fetched TWO tiles ahead and the words
+    // ONE ahead; every load is unconditional (clamped position, masked afterwards) so that the compiler counts
+    // outstanding loads instead of draining them; expansion and LDS writes follow the current tile's MFMAs.
+    // Positions are 32-bit offsets into this launch's index list (count < 2^31).
+    static_assert(UNITS % NTH == 0, "every thread stages the same number of units");
+    unsigned long long stw[UPT];
+    int cpre[UPT], cpre_w = 0;
+    bool okw[UPT];
+    double tot_acc = 0.0, m_raw = 0.0, wm_raw = 0.0, ny_raw = 0.0;
+    bool ok_w = false, ok_t = false;
+    const double* wm_ptr = wmul ? wmul : mu;
+    const int cnt32 = (int)count;
+    const int rel0 = (int)(e_first * S + s0 - pos0);                   // list offset of (element 0, set s0)
+    const int tl32 = (int)min(tot_limit - pos0, (int64_t)0x7fffffff);
+    // unit u of this thread: candidate q = (tid + 256 u) / (4 DT) of the tile (element q / SB, set s0 + q % SB)
+    int uq_e[UPT], uq_s[UPT], uq_w[UPT];
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+        const int unit = tid + NTH * u, q = unit / (4 * DT);
+        uq_e[u] = q / SB; uq_s[u] = q % SB; uq_w[u] = (unit / 4) % DT;
+    }
+    const int wq_e = (tid & (NC - 1)) / SB, wq_s = (tid & (NC - 1)) % SB;
+#define LT_REL(e_, qe_, qs_, R, OK)                                                        \
+    const int R = rel0 + ((e_) + (qe_)) * S + (qs_);                                       \
+    const bool OK = (s0 + (qs_) < S) & ((e_) + (qe_) < e1) & (R >= 0) & (R < cnt32);
+#define LT_PREFETCH_IDX(e_)                                                                \
+    {                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < UPT; ++u) {                                  \
+            LT_REL(e_, uq_e[u], uq_s[u], r_, okp_)                                         \
+            cpre[u] = idx[okp_ ? r_ : 0];                                                  \
+        }                                                                                  \
+        LT_REL(e_, wq_e, wq_s, rw_, okq_)                                                  \
+        cpre_w = idx[okq_ ? rw_ : 0];                                                      \
+    }
+#define LT_STAGE_LOAD(e_)                                                                  \
+    {                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < UPT; ++u) {                                  \
+            LT_REL(e_, uq_e[u], uq_s[u], r_, okl_)                                         \
+            okw[u] = okl_;                                                                 \
+            stw[u] = cand[(size_t)(okl_ ? cpre[u] : 0) * DT + uq_w[u]];                    \
+        }                                                                                  \
+        LT_REL(e_, wq_e, wq_s, rv_, okv_)                                                  \
+        const int cw_ = okv_ ? cpre_w : 0;                                                 \
+        m_raw = mu[cw_]; wm_raw = wm_ptr[cw_]; ny_raw = cand_norm[cw_];                    \
+        ok_w = okv_; ok_t = okv_ & (rv_ < tl32);                                           \
+    }
+#define LT_STAGE_WRITE(buf_)                                                               \
+    {                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < UPT; ++u) {                                  \
+            const int unit = tid + NTH * u;                                                \
+            const int q = unit / (4 * DT), part = unit & 3;                                \
+            *(int4_t*)(&s_b[buf_][q * ROWB + uq_w[u] * 64 + part * 16]) =                  \
+                expand16(okw[u] ? (unsigned)(stw[u] >> (16 * part)) & 0xFFFFu : 0u);       \
+        }                                                                                  \
+        if (tid < NC) {                                                                    \
+            s_w[buf_][tid] = ok_w ? (wmul ? m_raw * wm_raw : m_raw) : 0.0;                 \
+            s_ny[buf_][tid] = ok_w ? ny_raw : 0.0;                                         \
+            tot_acc += ok_t ? m_raw : 0.0;                                                 \
+        }                                                                                  \
+    }
+
+    int buf = 0;
+    LT_PREFETCH_IDX(e0)
+    __builtin_amdgcn_s_waitcnt(0);
+    LT_STAGE_LOAD(e0)
+    LT_PREFETCH_IDX(e0 + TE)
+    LT_STAGE_WRITE(0)
+    __syncthreads();
+    const bool rows_live = row0 < n_rows;
+    for (int e = e0; e < e1; e += TE) {
+        LT_STAGE_LOAD(e + TE)                                           // (padding when there is no next tile)
+        LT_PREFETCH_IDX(e + 2 * TE)
+        const int te_cnt = rows_live ? min(TE, e1 - e) : 0;
+        for (int te = 0; te < te_cnt; ++te) {
+            int4_t cc[LT_RT];
+#pragma unroll
+            for (int t = 0; t < LT_RT; ++t) cc[t] = (int4_t){0, 0, 0, 0};
+            const unsigned char* bp = &s_b[buf][(te * SB + lj) * ROWB + lk * 16];
+#pragma unroll
+            for (int ks = 0; ks < DT; ++ks) {
+                const int4_t bfr = *(const int4_t*)(bp + ks * 64);
+#pragma unroll
+                for (int t = 0; t < LT_RT; ++t)
+                    cc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[t][ks], bfr, cc[t], 0, 0, 0);
+            }
+            const double w = s_w[buf][te * SB + lj], ny = s_ny[buf][te * SB + lj];
+#pragma unroll
+            for (int t = 0; t < LT_RT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc[t][v] = fma(tani_fast((double)cc[t][v], nxr[t][v], ny, os), w, acc[t][v]);
+        }
+        LT_STAGE_WRITE(buf ^ 1)
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef LT_STAGE_LOAD
+#undef LT_STAGE_WRITE
+#undef LT_PREFETCH_IDX
+#undef LT_REL
+
+    if (s0 + lj < S) {
+#pragma unroll
+        for (int t = 0; t < LT_RT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = row0 + 16 * t + 4 * lk + v;
+                if (row < n_rows) partG[((size_t)chunk * n_rows + row) * ldg + col0 + s0 + lj] = acc[t][v];
+            }
+    }
+    if (partTot != nullptr && blockIdx.z == 0) {
+        __syncthreads();
+        if (tid < NC) s_w[0][tid] = tot_acc;                            // (the weight buffers are free now)
+        __syncthreads();
+        if (tid < SB && s0 + tid < S) {
+            double tt = 0.0;
+#pragma unroll
+            for (int te = 0; te < TE; ++te) tt += s_w[0][te * SB + tid];
+            partTot[(size_t)chunk * ldg + col0 + s0 + tid] = tt;
+        }
+    }
+}
+
+template <int DT>
+static int launch_lt(const void* rows, const double* rows_norm, int n_rows, const void* cand, const double* cand_norm,
+                     const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu, const double* wmul,
+                     double os, int n_chunks, double* partG, int ldg, int col0, double* partTot, int64_t tot_limit,
+                     hipStream_t st) {
+    const int64_t e_first = pos0 / S;
+    const int e_total = (int)((pos0 + count + S - 1) / S - e_first);
+    const int e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
+    dim3 grid((S + LT_SB - 1) / LT_SB, n_chunks, (n_rows + LT_ROWS - 1) / LT_ROWS);
+    const size_t lds = (size_t)2 * LT_TE * LT_SB * (DT * 64 + 32) + 4 * LT_TE * LT_SB * sizeof(double);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_level_reduce_tani<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_level_reduce_tani<DT>), grid, dim3(LT_RW * 64), lds, st, (const unsigned long long*)rows,
+                       rows_norm, n_rows, (const unsigned long long*)cand, cand_norm, idx, pos0, count, S, mu, wmul, os,
+                       e_first, e_total, e_per_chunk, partG, ldg, col0, partTot, tot_limit);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace sober
+
+using namespace sober;
+
+extern "C" int sober_level_reduce_tani_supported(int dt) { return (dt == 8 || dt == 16 || dt == 32) ? 1 : 0; }
+
+extern "C" int sober_level_reduce_tani(const void* rows, const double* rows_norm, int n_rows, const void* cand,
+                                       const double* cand_norm, int dt, const int32_t* idx, int64_t pos0,
+                                       int64_t count, int S, const double* mu, const double* wmul, double outputscale,
+                                       int n_chunks, double* partG, int ldg, int col0, double* partTot,
+                                       int64_t tot_limit, void* stream) {
+    if (!rows || !rows_norm || !cand || !cand_norm || !idx || !mu || !partG) return SOBER_E_ARG;
+    if (n_rows <= 0 || pos0 < 0 || count <= 0 || S <= 0 || n_chunks <= 0 || ldg < col0 + S) return SOBER_E_ARG;
+    if (n_chunks > (pos0 + count + S - 1) / S - pos0 / S) return SOBER_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dt) {
+        case 8: return launch_lt<8>(rows, rows_norm, n_rows, cand, cand_norm, idx, pos0, count, S, mu, wmul, outputscale,
+                                    n_chunks, partG, ldg, col0, partTot, tot_limit, st);
+        case 16: return launch_lt<16>(rows, rows_norm, n_rows, cand, cand_norm, idx, pos0, count, S, mu, wmul, outputscale,
+                                      n_chunks, partG, ldg, col0, partTot, tot_limit, st);
+        case 32: return launch_lt<32>(rows, rows_norm, n_rows, cand, cand_norm, idx, pos0, count, S, mu, wmul, outputscale,
+                                      n_chunks, partG, ldg, col0, partTot, tot_limit, st);
+        default: return SOBER_E_DIM;
+    }
+}

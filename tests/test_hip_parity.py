@@ -212,7 +212,8 @@ def test_dgemm_mfma_f64(dev):
     assert np.array_equal(Cd.cpu().numpy(), A @ B)
 
 
-@pytest.mark.parametrize("kind,d", [(O.RBF, 10), (O.MATERN52, 6), (O.TANIMOTO, 200), (O.RBF, 20), (O.RBF, 2)])
+@pytest.mark.parametrize("kind,d", [(O.RBF, 10), (O.MATERN52, 6), (O.TANIMOTO, 200), (O.RBF, 20), (O.RBF, 2),
+                                    (O.TANIMOTO, 500), (O.TANIMOTO, 1024), (O.TANIMOTO, 2048)])   # 8 / 16 / 32 words: INT8 MFMA kernel
 def test_level_moments_vs_test_double(kind, d, dev):
     """One level (with leftovers and a sharded position range) of the fused kernel against the CPU
     restatement of the same sums."""
