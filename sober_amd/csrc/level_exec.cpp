@@ -134,37 +134,18 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
         int32_t* cur = (l & 1) ? idx_b : idx_a;
         int32_t* nxt = (l & 1) ? idx_a : idx_b;
         for (int k = 0; k < 4; ++k) j->ev[k] = events ? events[4 * l + k] : nullptr;
-        if (!(l == 0 && first_sums_ready) && getenv("SOBER_QUEUE_CLASSIC_MOMENTS")) {
-            (void)hipMemcpyAsync(j->h_dR, j->dR, sizeof(int64_t) * (size_t)(l + 1), hipMemcpyDeviceToHost, st);
-            (void)hipStreamSynchronize(st);
-            const int64_t Rl = j->h_dR[l];
-            j->idx = cur; j->pos0 = 0; j->count = Rl; j->E = Rl / S; j->phase = 1;
-            LX_TRY(sober_level_moments(j, stream));
-        } else if (!(l == 0 && first_sums_ready)) {
+        if (!(l == 0 && first_sums_ready)) {
             const int nch = lx_chunks(j->n_rows, (Rub[l] + S - 1) / S, S);
             const int nxch = lx_chunks(j->n_rows, (S - 1 + SOBER_LEVEL_XS - 1) / SOBER_LEVEL_XS, SOBER_LEVEL_XS);
             if (nch <= 0 || nch > SOBER_LEVEL_MAX_CHUNKS || nxch <= 0 || nxch > SOBER_LEVEL_MAX_CHUNKS) return SOBER_E_WS;
             LX_EVENT(0)
             LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
-                                                  j->dim, cur, Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch,
-                                                  j->partG, S, j->partTot, j->dR + l, stream));
-            LX_EVENT(1)
-            LX_EVENT(2)
-            LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
-                                                  j->dim, cur, S - 1, SOBER_LEVEL_XS, S, 1, j->mu, j->wmul,
-                                                  j->outputscale, nxch, j->extraG, SOBER_LEVEL_XS, j->extraTot,
+                                                  j->dim, cur, Rub[l], S, j->mu, j->wmul, j->outputscale, nch,
+                                                  j->partG, j->partTot, SOBER_LEVEL_XS, nxch, j->extraG, j->extraTot,
                                                   j->dR + l, stream));
-            LX_EVENT(3)
-            if (getenv("SOBER_QUEUE_CLASSIC_SUM")) {
-                (void)hipMemcpyAsync(j->h_dR, j->dR, sizeof(int64_t) * (size_t)(l + 1), hipMemcpyDeviceToHost, st);
-                (void)hipStreamSynchronize(st);
-                const int64_t Rl = j->h_dR[l], left = Rl % S;
-                const int c1 = sober_level_chunks(j->n_rows, 0, Rl, S);
-                const int c2 = left > 0 ? sober_level_chunks(j->n_rows, 0, left, SOBER_LEVEL_XS) : 0;
-                fprintf(stderr, "level %d R %lld chunks %d xchunks %d (launched %d %d)\n", l, (long long)Rl, c1, c2, nch, nxch);
-                LX_TRY(sober_sum_partials(j->partG, j->partTot, c1, j->n_rows, S, S, left > 0 ? j->extraG : nullptr,
-                                          left > 0 ? j->extraTot : nullptr, c2, SOBER_LEVEL_XS, j->G, S, j->tot, stream));
-            } else
+            LX_EVENT(1)
+            LX_EVENT(2)                                                 // (the leftover pass rides in the same launch:
+            LX_EVENT(3)                                                 //  its bracket stays valid and empty)
             LX_TRY(sober_sum_partials_queued(j->partG, j->partTot, j->n_rows, S, S, j->extraG, j->extraTot,
                                              SOBER_LEVEL_XS, j->G, S, j->tot, j->dR + l, stream));
         }

@@ -584,7 +584,8 @@ def test_sharded_path_single_rank_rccl(dev):
 # --------------------------------------------------------------------------- #
 # BASELINE.json configs 3 and 5 (non-RBF kernels) against the oracle at / near full size
 # --------------------------------------------------------------------------- #
-def _vs_oracle(kind, mode, N, M, d, b, n_obs, seed, dev, bit_p=0.04, ard=True, calc_obj=None, timers=None):
+def _vs_oracle(kind, mode, N, M, d, b, n_obs, seed, dev, bit_p=0.04, ard=True, calc_obj=None, timers=None,
+               rtol=W_RTOL):
     from tests.golden.synth import synth, build_spec
     case = dict(kind=kind, mode=mode, N=N, M=M, d=d, b=b, n_obs=n_obs, seed=seed, ard=ard, bit_p=bit_p,
                 mean_const=0.4)
@@ -602,8 +603,8 @@ def _vs_oracle(kind, mode, N, M, d, b, n_obs, seed, dev, bit_p=0.04, ard=True, c
                                          sober_amd.Kernel(kspec(spec), mode), init_weights=mu, calc_obj=calc_obj,
                                          _timers=timers)
     assert np.array_equal(idx.cpu().numpy(), idx_ref.numpy())
-    np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=W_RTOL)
-    np.testing.assert_allclose(mu.cpu().numpy(), mu_ref.numpy(), rtol=W_RTOL, atol=0)
+    np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=rtol)
+    np.testing.assert_allclose(mu.cpu().numpy(), mu_ref.numpy(), rtol=rtol, atol=0)
     assert abs(float(w.sum()) - 1.0) < 1e-12 and len(w) <= b
 
 
@@ -613,7 +614,10 @@ def test_calc_obj_levels_on_the_device(N, M, d, b, dev):
     step (one more function: the objective) and every extra elimination on the device -- one-CU kernels up to batch
     100, the multi-CU kernels beyond -- against the oracle's LAPACK route; no host Caratheodory step is taken."""
     timers = {}
-    _vs_oracle(O.RBF, "predictive_covariance", N, M, d, b, 40, 300 + b, dev, calc_obj=calc_obj_fn, timers=timers)
+    # (two eliminations per level: the weights carry a few more rounding errors than the plain branch -- 1e-6 here,
+    #  the contract is 1e-4)
+    _vs_oracle(O.RBF, "predictive_covariance", N, M, d, b, 40, 300 + b, dev, calc_obj=calc_obj_fn, timers=timers,
+               rtol=1e-6)
     assert "car_host" not in timers, timers
 
 
