@@ -250,15 +250,13 @@ int sober_level_reduce_tani(const void* rows, const double* rows_norm, int n_row
                             int ldg, int col0, double* partTot, int64_t tot_limit, void* stream);
 
 /* Queued-level forms (see sober_level_loop): the same kernels with the level size read from device memory.
- * sober_level_reduce_mfma_queued: ONE launch per level -- chunk rows [0, n_chunks_ub) of the grid cover positions
- * [0, *dR) (set masses over [0, E S)), the n_xchunks_ub rows behind them the leftover positions [E S, *dR) over XS
- * pseudo-sets into extraG / extraTot.  Sized for count_ub positions; n_chunks_ub = the LARGEST count
- * sober_level_chunks can return up to count_ub, not its value there.                                          */
+ * sober_level_reduce_mfma_queued: leftover = 0: positions [0, *dR), set masses over [0, E S) (S = S_main);
+ * leftover = 1: the leftover positions [E S_main, *dR) over S pseudo-sets.  Launch sized for count_ub positions
+ * and n_chunks_ub chunks (the LARGEST count sober_level_chunks can return up to count_ub, not its value there). */
 int sober_level_reduce_mfma_queued(int kind, const double* rows, int n_rows, const double* cand, int da,
-                                   const int32_t* idx, int64_t count_ub, int S, const double* mu, const double* wmul,
-                                   double outputscale, int n_chunks_ub, double* partG, double* partTot, int XS,
-                                   int n_xchunks_ub, double* extraG, double* extraTot, const int64_t* dR,
-                                   void* stream);
+                                   const int32_t* idx, int64_t count_ub, int S, int S_main, int leftover,
+                                   const double* mu, const double* wmul, double outputscale, int n_chunks_ub,
+                                   double* partG, int ldg, double* partTot, const int64_t* dR, void* stream);
 int sober_sum_partials_queued(const double* partG, const double* partTot, int n_rows, int ldg, int S,
                               const double* extraG, const double* extraTot, int n_xcols, double* G, int ldo,
                               double* tot, const int64_t* dR, void* stream);

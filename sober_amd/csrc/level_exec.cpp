@@ -140,12 +140,15 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
             if (nch <= 0 || nch > SOBER_LEVEL_MAX_CHUNKS || nxch <= 0 || nxch > SOBER_LEVEL_MAX_CHUNKS) return SOBER_E_WS;
             LX_EVENT(0)
             LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
-                                                  j->dim, cur, Rub[l], S, j->mu, j->wmul, j->outputscale, nch,
-                                                  j->partG, j->partTot, SOBER_LEVEL_XS, nxch, j->extraG, j->extraTot,
-                                                  j->dR + l, stream));
+                                                  j->dim, cur, Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch,
+                                                  j->partG, S, j->partTot, j->dR + l, stream));
             LX_EVENT(1)
-            LX_EVENT(2)                                                 // (the leftover pass rides in the same launch:
-            LX_EVENT(3)                                                 //  its bracket stays valid and empty)
+            LX_EVENT(2)
+            LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
+                                                  j->dim, cur, S - 1, SOBER_LEVEL_XS, S, 1, j->mu, j->wmul,
+                                                  j->outputscale, nxch, j->extraG, SOBER_LEVEL_XS, j->extraTot,
+                                                  j->dR + l, stream));
+            LX_EVENT(3)
             LX_TRY(sober_sum_partials_queued(j->partG, j->partTot, j->n_rows, S, S, j->extraG, j->extraTot,
                                              SOBER_LEVEL_XS, j->G, S, j->tot, j->dR + l, stream));
         }

@@ -107,29 +107,22 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
     int64_t e_first, int e_total, int e_per_chunk,
     double* __restrict__ partG, int ldg, int col0,
     double* __restrict__ partTot, int64_t tot_limit,
-    const int64_t* __restrict__ dR, int y_main, int XS, double* __restrict__ extraG, double* __restrict__ extraTot) {
+    const int64_t* __restrict__ dR, int S_main, int leftover) {
     constexpr int DA = 4 * KT;
-    int chunk = blockIdx.y;
     // queued levels (level_exec.cpp): the launch was sized from an UPPER BOUND of the live positions; the exact
-    // number R sits in device memory (written by the previous level's update).  Chunk rows [0, y_main) of the grid
-    // are the main launch over positions [0, R); the rows behind them are the leftover pass over [E S, R) spread
-    // over XS pseudo-sets (one set block wide, partial sums into extraG / extraTot): one launch per level.
+    // number R sits in device memory (written by the previous level's update).  leftover = 0: the main launch over
+    // positions [0, R) (S = S_main); leftover = 1: positions [E S_main, R) spread over S pseudo-sets.
     if (dR != nullptr) {
         const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (not through the scalar cache)
-        if (R <= S) return;                               // nothing to halve (or the chain was stopped: R = -1)
-        const int64_t ES = (R / S) * S;
-        if (chunk < y_main) { count = R; tot_limit = ES; }
-        else {
-            if (blockIdx.x != 0) return;
-            chunk -= y_main;
-            idx += ES; count = R - ES; tot_limit = count;
-            S = XS; partG = extraG; partTot = extraTot; ldg = XS; col0 = 0;
-        }
+        if (R <= S_main) return;                          // nothing to halve (or the chain was stopped: R = -1)
+        const int64_t ES = (R / S_main) * S_main;
+        if (!leftover) { count = R; tot_limit = ES; }
+        else { idx += ES; count = R - ES; tot_limit = count; }
         if (count <= 0) return;
         pos0 = 0; e_first = 0;
         e_total = (int)((count + S - 1) / S);
         const int nch = level_chunks_for(n_rows, e_total, S);
-        if (chunk >= nch) return;
+        if ((int)blockIdx.y >= nch) return;
         e_per_chunk = (e_total + nch - 1) / nch;
     }
     constexpr int SB = LM_SB, TE = LM_TE, NT = TE * SB;
@@ -141,6 +134,7 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 15, lk = lane >> 4;
     const int s0 = blockIdx.x * SB;
+    const int chunk = blockIdx.y;
     const int row0 = blockIdx.z * (LM_RW * 64) + wave * 64;
     const int e0 = chunk * e_per_chunk;
     const int e1 = min(e0 + e_per_chunk, e_total);
@@ -342,15 +336,14 @@ template <int KIND, int KT>
 static int launch_lm(const double* rows, int n_rows, const double* cand, const int32_t* idx, int64_t pos0,
                      int64_t count, int S, const double* mu, const double* wmul, double os, int n_chunks,
                      double* partG, int ldg, int col0, double* partTot, int64_t tot_limit, hipStream_t st,
-                     const int64_t* dR = nullptr, int y_extra = 0, int XS = 0, double* extraG = nullptr,
-                     double* extraTot = nullptr) {
+                     const int64_t* dR = nullptr, int S_main = 0, int leftover = 0) {
     const int64_t e_first = pos0 / S;
     const int e_total = (int)((pos0 + count + S - 1) / S - e_first);
     const int e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
-    dim3 grid((S + LM_SB - 1) / LM_SB, n_chunks + y_extra, (n_rows + LM_RW * 64 - 1) / (LM_RW * 64));
+    dim3 grid((S + LM_SB - 1) / LM_SB, n_chunks, (n_rows + LM_RW * 64 - 1) / (LM_RW * 64));
     hipLaunchKernelGGL((k_level_reduce_mfma<KIND, KT>), grid, dim3(LM_RW * 64), 0, st, rows, n_rows, cand, idx,
                        pos0, count, S, mu, wmul, os, e_first, e_total, e_per_chunk, partG, ldg, col0, partTot,
-                       tot_limit, dR, n_chunks, XS, extraG, extraTot);
+                       tot_limit, dR, S_main, leftover);
     LAUNCH_CHECK();
     return 0;
 }
@@ -381,7 +374,7 @@ static int level_reduce_mfma_impl(int kind, const double* rows, int n_rows, cons
                                   const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu,
                                   const double* wmul, double outputscale, int n_chunks, double* partG,
                                   int ldg, int col0, double* partTot, int64_t tot_limit, void* stream,
-                                  const int64_t* dR, int y_extra, int XS, double* extraG, double* extraTot);
+                                  const int64_t* dR, int S_main, int leftover);
 
 extern "C" int sober_level_reduce_mfma(int kind, const double* rows, int n_rows, const double* cand, int da,
                                        const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu,
@@ -389,31 +382,31 @@ extern "C" int sober_level_reduce_mfma(int kind, const double* rows, int n_rows,
                                        int ldg, int col0, double* partTot, int64_t tot_limit, void* stream) {
     if (n_chunks > (pos0 + count + S - 1) / S - pos0 / S) return SOBER_E_ARG;
     return level_reduce_mfma_impl(kind, rows, n_rows, cand, da, idx, pos0, count, S, mu, wmul, outputscale, n_chunks,
-                                  partG, ldg, col0, partTot, tot_limit, stream, nullptr, 0, 0, nullptr, nullptr);
+                                  partG, ldg, col0, partTot, tot_limit, stream, nullptr, 0, 0);
 }
 
 extern "C" int sober_level_reduce_mfma_queued(int kind, const double* rows, int n_rows, const double* cand, int da,
-                                              const int32_t* idx, int64_t count_ub, int S, const double* mu,
-                                              const double* wmul, double outputscale, int n_chunks_ub, double* partG,
-                                              double* partTot, int XS, int n_xchunks_ub, double* extraG,
-                                              double* extraTot, const int64_t* dR, void* stream) {
-    if (!dR || !extraG || !extraTot || XS <= 0 || n_xchunks_ub <= 0) return SOBER_E_ARG;
+                                              const int32_t* idx, int64_t count_ub, int S, int S_main,
+                                              int leftover, const double* mu, const double* wmul,
+                                              double outputscale, int n_chunks_ub, double* partG, int ldg,
+                                              double* partTot, const int64_t* dR, void* stream) {
+    if (!dR || S_main <= 0 || (!leftover && S != S_main)) return SOBER_E_ARG;
     return level_reduce_mfma_impl(kind, rows, n_rows, cand, da, idx, 0, count_ub, S, mu, wmul, outputscale,
-                                  n_chunks_ub, partG, S, 0, partTot, 0, stream, dR, n_xchunks_ub, XS, extraG, extraTot);
+                                  n_chunks_ub, partG, ldg, 0, partTot, 0, stream, dR, S_main, leftover);
 }
 
 static int level_reduce_mfma_impl(int kind, const double* rows, int n_rows, const double* cand, int da,
                                   const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu,
                                   const double* wmul, double outputscale, int n_chunks, double* partG,
                                   int ldg, int col0, double* partTot, int64_t tot_limit, void* stream,
-                                  const int64_t* dR, int y_extra, int XS, double* extraG, double* extraTot) {
+                                  const int64_t* dR, int S_main, int leftover) {
     if (!rows || !cand || !idx || !mu || !partG) return SOBER_E_ARG;
     if (n_rows <= 0 || pos0 < 0 || count <= 0 || S <= 0 || n_chunks <= 0 || ldg < col0 + S) return SOBER_E_ARG;
     hipStream_t st = (hipStream_t)stream;
 #define LM_CASE(K, T)                                                                                          \
     case 4 * T:                                                                                                \
         return launch_lm<K, T>(rows, n_rows, cand, idx, pos0, count, S, mu, wmul, outputscale, n_chunks, partG, \
-                               ldg, col0, partTot, tot_limit, st, dR, y_extra, XS, extraG, extraTot);
+                               ldg, col0, partTot, tot_limit, st, dR, S_main, leftover);
     switch (kind) {
         case SOBER_KIND_RBF:
             switch (da) { LM_CASE(SOBER_KIND_RBF, 1) LM_CASE(SOBER_KIND_RBF, 2) LM_CASE(SOBER_KIND_RBF, 3)
