@@ -24,8 +24,9 @@
 //                 registers (16-lane DPP argmin with first-index tie break) straight after its own
 //                 elimination step.
 //
-// Limits: N <= 208, m <= 112, N - m <= 112 (batch <= 100).  Larger batches use the host LAPACK path
-// (sober_car_pivot_host_fast).
+// Limits of these one-CU kernels: N <= 208, m <= 112, N - m <= 112 (batch <= 100).  sober_car_device hands larger
+// steps (N <= 448, m <= 256: batch <= 224) to the multi-CU kernels of car_mc.hip; beyond those the engine takes the
+// host LAPACK route (sober_car_pivot_host).
 #include "common.hpp"
 
 namespace sober {

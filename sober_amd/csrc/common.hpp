@@ -20,7 +20,7 @@
     } while (0)
 
 #ifndef SOBER_CHUNK_TARGET
-#define SOBER_CHUNK_TARGET 512      // workgroups a level launch aims for (~2 per CU): 1024 doubles the partial-sum traffic and is 9 % slower, 256 starves the 1M-row level (measured, scripts/_chunk_ab.py)
+#define SOBER_CHUNK_TARGET 512      // workgroups a level launch aims for (~2 per CU): 1024 doubles the partial-sum traffic and is 9 % slower, 256 starves the 1M-row level (measured, scripts/chunk_target_ab.py)
 #endif
 
 namespace sober {
