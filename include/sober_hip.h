@@ -111,6 +111,11 @@ int sober_level_reduce_mfma(int kind, const double* rows, int n_rows, const doub
 
 /* chunk count the library would pick for a level of `count` positions in S sets.                 */
 int sober_level_chunks(int n_rows, int64_t pos0, int64_t count, int S);
+/* The same for sober_level_reduce_mfma (its workgroups are waves of one 64-row x 16-set tile that sum their element
+ * ranges on chip: 1-2 partial sums per tile), and the largest value it can take up to e_total_ub elements per set (what
+ * a launch sized ahead of time, sober_level_reduce_mfma_queued, is given). */
+int sober_level_parts_mfma(int n_rows, int64_t pos0, int64_t count, int S);
+int sober_level_parts_mfma_cap(int n_rows, int64_t e_total_ub, int S);
 
 /* G[row*ldo + s] = sum_chunk partG[chunk][row][s]  (s < S).  When extraG != NULL the leftover
  * partials extraG[xchunk][row][0:n_xcols] (and extraTot[xchunk][0:n_xcols]) -- a level_reduce run

@@ -34,6 +34,8 @@ SIGNATURES = {
     "sober_level_reduce": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp,
                                   _f64, _i32, _vp, _i32, _i32, _vp, _i64, _vp]),
     "sober_level_chunks": (_i32, [_i32, _i64, _i64, _i32]),
+    "sober_level_parts_mfma": (_i32, [_i32, _i64, _i64, _i32]),
+    "sober_level_parts_mfma_cap": (_i32, [_i32, _i64, _i32]),
     "sober_aug_dim": (_i32, [_i32]),
     "sober_augment_points": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "sober_level_reduce_mfma": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _f64, _i32,
@@ -232,6 +234,12 @@ def kernel_matvec(kind, a, a_norm, v, b, b_norm, dt, outputscale, c0, out):
 def level_chunks(n_rows, pos0, count, S) -> int:
     r = load().sober_level_chunks(n_rows, pos0, count, S)
     _check(min(r, 0), "sober_level_chunks")
+    return r
+
+
+def level_parts_mfma(n_rows, pos0, count, S) -> int:
+    r = load().sober_level_parts_mfma(n_rows, pos0, count, S)
+    _check(min(r, 0), "sober_level_parts_mfma")
     return r
 
 

@@ -40,6 +40,50 @@ __host__ __device__ inline int level_chunks_for(int n_rows, int64_t e_total, int
     return (int)((e_total + epc - 1) / epc);
 }
 
+// Split of one level launch of the wave-autonomous matrix-core kernel (level_reduce_mfma.hip: k_level_reduce_wave).
+// A wave owns a 64-row x 16-set tile over a contiguous range of elements.  All waves of a launch form ONE line, tile
+// after tile (row tiles of a set group adjacent), `wpt` waves per tile; a workgroup is SOBER_LW_W consecutive waves
+// of that line, so it may straddle two tiles: the waves of one tile inside a workgroup are summed through LDS in wave
+// order, and a tile leaves one partial sum per workgroup it touches -- at most level_wave_slots() of them.
+// At most SOBER_WAVE_TARGET waves per launch: two per SIMD on 1024 SIMDs, all resident at once (the kernel is
+// instruction-issue bound; a second round of workgroups would double its time).
+#ifndef SOBER_WAVE_TARGET
+#define SOBER_WAVE_TARGET 2048
+#endif
+#define SOBER_LW_W 4
+__host__ __device__ inline int64_t level_wave_tiles(int n_rows, int S) {
+    return (int64_t)((S + 15) / 16) * ((n_rows + 63) / 64);
+}
+// waves per tile: monotone in e_total (a launch sized from an upper bound of e_total covers the exact one)
+__host__ __device__ inline int level_wave_wpt(int n_rows, int64_t e_total, int S) {
+    int64_t wpt = SOBER_WAVE_TARGET / level_wave_tiles(n_rows, S);
+    if (wpt < 1) wpt = 1;
+    if (wpt > e_total) wpt = e_total;
+    return (int)wpt;
+}
+// partial-sum slots per tile = the most workgroups `wpt` consecutive waves can touch
+__host__ __device__ inline int level_wave_slots(int wpt) { return wpt <= 0 ? 0 : (wpt + SOBER_LW_W - 2) / SOBER_LW_W + 1; }
+
+// partial sums per tile of the matrix-core level kernel that is built in (SOBER_LM_BLOCK: the workgroup-staged one)
+__host__ __device__ inline int level_parts_mfma_for(int n_rows, int64_t e_total, int S) {
+#ifdef SOBER_LM_BLOCK
+    return level_chunks_for(n_rows, e_total, S);
+#else
+    return level_wave_slots(level_wave_wpt(n_rows, e_total, S));
+#endif
+}
+__host__ __device__ inline int level_parts_mfma_cap(int n_rows, int64_t e_total, int S) {
+#ifdef SOBER_LM_BLOCK
+    int64_t n = SOBER_CHUNK_TARGET / ((int64_t)((S + 15) / 16) * ((n_rows + 255) / 256));
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    if (n > e_total) n = e_total;
+    return (int)n;
+#else
+    return level_wave_slots(level_wave_wpt(n_rows, e_total, S));     // (monotone in e_total)
+#endif
+}
+
 // k(x, y) from the squared scaled distance (continuous kernels).
 // RBF:      gpytorch RBFKernel  -> exp(-sq / 2)                       [SURVEY App. D]
 // Matern52: gpytorch MaternKernel(nu=2.5): r = sqrt(max(sq, 1e-30)),

@@ -54,7 +54,9 @@ extern "C" int sober_level_moments(const sober_level_job* j, void* stream) {
         return SOBER_E_ARG;
     if (j->count <= 0 || j->pos0 < 0 || j->E < 0) return SOBER_E_ARG;
     const int64_t ES = j->E * S;
-    const int n_chunks = sober_level_chunks(j->n_rows, j->pos0, j->count, S);
+    const bool mfma = j->variant == SOBER_LEVEL_MFMA;
+    const int n_chunks = mfma ? sober_level_parts_mfma(j->n_rows, j->pos0, j->count, S)
+                              : sober_level_chunks(j->n_rows, j->pos0, j->count, S);
     if (n_chunks <= 0 || n_chunks > SOBER_LEVEL_MAX_CHUNKS) return n_chunks <= 0 ? n_chunks : SOBER_E_WS;
     // first placement: every live position, set = p mod S (leftovers land in sets 0..r-1, quirk Q1); tot over p < ES
     LX_EVENT(0)
@@ -67,7 +69,8 @@ extern "C" int sober_level_moments(const sober_level_job* j, void* stream) {
     int n_xchunks = 0;
     if (n_left > 0) {
         if (!j->extraG || !j->extraTot) return SOBER_E_ARG;
-        n_xchunks = sober_level_chunks(j->n_rows, 0, n_left, SOBER_LEVEL_XS);
+        n_xchunks = mfma ? sober_level_parts_mfma(j->n_rows, 0, n_left, SOBER_LEVEL_XS)
+                         : sober_level_chunks(j->n_rows, 0, n_left, SOBER_LEVEL_XS);
         if (n_xchunks <= 0 || n_xchunks > SOBER_LEVEL_MAX_CHUNKS) return n_xchunks <= 0 ? n_xchunks : SOBER_E_WS;
         LX_EVENT(2)
         LX_TRY(lx_reduce(j, j->idx + (lo - j->pos0), 0, n_left, SOBER_LEVEL_XS, n_xchunks, j->extraG, j->extraTot,
@@ -93,20 +96,9 @@ extern "C" int sober_level_car(const sober_level_job* j, void* stream) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
-// Largest chunk count sober_level_chunks can return for at most e_total elements per set.  (The count itself is
-// not monotone in e_total -- 64 elements give 64 chunks of one, 65 give 33 chunks of two -- so a launch sized from
-// an upper bound of the level takes the cap, not the count at the bound.)
-static int lx_chunks(int n_rows, int64_t e_total, int S) {
-    const int sb = (S + 15) / 16, rb = (n_rows + 255) / 256;
-#ifndef SOBER_CHUNK_TARGET
-#define SOBER_CHUNK_TARGET 512
-#endif
-    int64_t n = SOBER_CHUNK_TARGET / ((int64_t)sb * rb);
-    if (n < 1) n = 1;
-    if (n > SOBER_LEVEL_MAX_CHUNKS) n = SOBER_LEVEL_MAX_CHUNKS;
-    if (n > e_total) n = e_total;
-    return (int)n;
-}
+// Partial sums a queued launch of the matrix-core level kernel is sized for: an upper bound of the count the kernel
+// finds from the exact number of live positions (the count itself is not monotone in that number).
+static int lx_chunks(int n_rows, int64_t e_total, int S) { return sober_level_parts_mfma_cap(n_rows, e_total, S); }
 
 // Phase A of sober_level_loop: every level that certainly exists, enqueued back to back with device-resident sizes.
 // -> *done = levels completed, *R_out = live positions after them (their list: idx_a if *done is even).

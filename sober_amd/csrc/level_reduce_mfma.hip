@@ -16,6 +16,7 @@
 // one set) and rows (l >> 4) + 4*reg of each tile.  Workgroup = 4 waves = 256 rows sharing the staged
 // candidate tile.  Accumulators stay in VGPRs over the whole element chunk: fixed order, no atomics.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace sober {
 
@@ -28,39 +29,49 @@ constexpr int LM_TE = 8;     // elements staged per tile
 // exp of four independent arguments, written stage by stage so that the four dependency chains
 // interleave (one chain alone leaves the FP64 pipe idle for most of its latency).
 //
-// The argument arrives PRE-SCALED: y = a * 64/ln2 (the scale is folded into the augmented rows, so the
+// The argument arrives PRE-SCALED: y = a * 256/ln2 (the scale is folded into the augmented rows, so the
 // GEMM delivers y for free).  Then  n = rint(y)  via the 2^52 magic-number add (its low dword IS n),
-// r' = y - n exactly (no Cody-Waite split needed), exp(a) = 2^(n>>6) T[n&63] (1 + p(r')) with the
-// polynomial coefficients pre-multiplied by (ln2/64)^k, and the final scaling by 2^(n>>6) is an
-// integer add on the exponent field.  10 FP64 ops per value (libm: ~30).
+// r' = y - n exactly (no Cody-Waite split needed), exp(a) = 2^(n>>8) T[n&255] (1 + p(r')) with a 256-entry table,
+// a degree-4 polynomial (|r| <= ln2/512: truncation 3.8e-17) whose coefficients are pre-multiplied by (ln2/256)^k,
+// and the scaling by 2^(n>>8) as ONE integer add on the table value's high dword: the table stores 2^(j/256) with
+// (j << 12) subtracted from the high dword, so that adding (n << 12) = ((n>>8) << 20) + (j << 12) leaves exactly the
+// exponent increment.  8 FP64 + 4 integer instructions per value (libm: ~30): on gfx950 every vector instruction
+// of the SIMD -- integer ones too -- queues behind a running v_mfma_f64 (scripts/dp_rate_probe.hip), so the count
+// of instructions is what this kernel's time is made of.
+constexpr int EXP_TAB = 256;
+__device__ __forceinline__ double exp_tab_entry(int j) {
+    const double t = exp2((double)j * (1.0 / EXP_TAB));
+    return __hiloint2double(__double2hiint(t) - (j << 12), __double2loint(t));
+}
 __device__ __forceinline__ void exp_tab4(const double (&y)[4], const double* __restrict__ T, double (&out)[4]) {
     const double MAGIC = 6755399441055744.0;        // 1.5 * 2^52
-    const double K1 = 1.0830424696249145e-02;       // (ln2/64)^k / k!
-    const double K2 = 5.86490495505617e-05;
-    const double K3 = 2.1173137155464776e-07;
-    const double K4 = 5.732851688640402e-10;
-    const double K5 = 1.2417843701716925e-12;
+    const double K1 = 0.0027076061740622863;        // (ln2/256)^k / k!
+    const double K2 = 3.665565596910106e-06;
+    const double K3 = 3.308302680541371e-09;
+    const double K4 = 2.239395190875157e-12;
     double yc[4], u[4], r[4], t[4], q[4];
     int n[4];
-    // clamp at about -65000 (e^-704 ~ 1e-306 keeps 2^(n>>6) a normal number) as an UNSIGNED MIN ON THE HIGH DWORD:
+    // clamp at about -261000 (e^-706 ~ 1e-307 keeps 2^(n>>8) a normal number) as an UNSIGNED MIN ON THE HIGH DWORD:
     // for negative doubles a larger bit pattern is a more negative value, non-negative ones compare below any
-    // negative pattern and pass unchanged (NaN too).  An integer op: it does not take a slot of the FP64 units,
-    // which the exponentials and the MFMAs share.
+    // negative pattern and pass unchanged (NaN too).
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        yc[i] = __hiloint2double((int)min((unsigned)__double2hiint(y[i]), 0xC0EFBD00u), __double2loint(y[i]));
+        yc[i] = __hiloint2double((int)min((unsigned)__double2hiint(y[i]), 0xC10FDC40u), __double2loint(y[i]));
 #pragma unroll
     for (int i = 0; i < 4; ++i) u[i] = yc[i] + MAGIC;
 #pragma unroll
     for (int i = 0; i < 4; ++i) n[i] = __double2loint(u[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = T[n[i] & 63];
+    for (int i = 0; i < 4; ++i) {
+        const double tv = T[n[i] & (EXP_TAB - 1)];
+        int hi;                                                        // exponent field += n >> 8 (see above)
+        asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(hi) : "v"(n[i]), "v"(__double2hiint(tv)));
+        t[i] = __hiloint2double(hi, __double2loint(tv));
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = yc[i] - (u[i] - MAGIC);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = fma(r[i], K5, K4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = fma(r[i], q[i], K3);
+    for (int i = 0; i < 4; ++i) q[i] = fma(r[i], K4, K3);
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = fma(r[i], q[i], K2);
 #pragma unroll
@@ -68,23 +79,18 @@ __device__ __forceinline__ void exp_tab4(const double (&y)[4], const double* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = q[i] * r[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double v = fma(t[i], q[i], t[i]);                        // in [1, 2)
-        int hi;                                                        // exponent field += n >> 6: shift + fused shift-add
-        asm("v_lshl_add_u32 %0, %1, 20, %2" : "=v"(hi) : "v"(n[i] >> 6), "v"(__double2hiint(v)));
-        out[i] = __hiloint2double(hi, __double2loint(v));
-    }
+    for (int i = 0; i < 4; ++i) out[i] = fma(t[i], q[i], t[i]);
 }
 
 template <int KIND>
 __device__ __forceinline__ void kern_from_arg4(const double4_t& c, const double* __restrict__ T, double (&k)[4]) {
     if constexpr (KIND == SOBER_KIND_RBF) {
-        const double y[4] = {c[0], c[1], c[2], c[3]};                 // already -sq/2 * 64/ln2
+        const double y[4] = {c[0], c[1], c[2], c[3]};                 // already -sq/2 * 256/ln2
         exp_tab4(y, T, k);
     } else {
         const double s5 = 2.23606797749978969641;
-        const double INV_L = 1.0830424696249145e-02;                   // ln2/64: undo the pre-scaling
-        const double L = 92.33248261689366;
+        const double INV_L = 0.0027076061740622863;                    // ln2/256: undo the pre-scaling
+        const double L = 369.3299304675746;
         double sq[4], rr[4], a[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) sq[i] = fmax((-2.0 * INV_L) * c[i], 1e-30);   // clamp_min(1e-30) before sqrt
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
     __shared__ double s_pts[2][TE][DA][SB];      // k-major: a B fragment read is 512 contiguous bytes
     __shared__ double s_w[2][NT];
     __shared__ double s_tot[NT];
-    __shared__ double s_T[64];
+    __shared__ double s_T[EXP_TAB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 15, lk = lane >> 4;
@@ -139,7 +145,8 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
     const int e0 = chunk * e_per_chunk;
     const int e1 = min(e0 + e_per_chunk, e_total);
 
-    if (tid < 64) s_T[tid] = exp2((double)tid * (1.0 / 64.0));
+    static_assert(LM_RW * 64 >= EXP_TAB, "one table entry per thread");
+    if (tid < EXP_TAB) s_T[tid] = exp_tab_entry(tid);
 
     // A fragments: lane holds rows[row0 + 16*t + lj][4*ks + lk]
     double afr[4][KT];
@@ -288,8 +295,215 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
     }
 }
 
+// ---- wave-autonomous variant ----------------------------------------------------------------------------------
+// The same arithmetic without a workgroup in the inner loop.  A wave owns a 64-row x 16-set tile over a contiguous
+// range of elements and feeds its own B fragments straight from L2: lane (lj, lk) reads KT CONTIGUOUS doubles of its
+// candidate's augmented row (the contraction index is permuted, k = lk KT + ks, on both operands), its weight and its
+// list index -- index three elements ahead, row and weight two ahead, MFMAs one ahead of the exponentials.  No LDS
+// staging, no barrier in the loop.
+// On gfx950 v_mfma_f64 occupies the vector ALU for its 64 cycles -- neither FP64 nor integer vector instructions of
+// any wave of the SIMD overlap with it (scripts/dp_rate_probe.hip) -- so the kernel is bound by its instruction count
+// (12 MFMAs + ~270 vector instructions per element and wave at d = 10), not by latencies: two waves per SIMD are enough,
+// and what matters is that ALL waves of a launch are resident at once and evenly loaded.  Hence the split of
+// common.hpp: one line of waves, `wpt` per tile with element ranges that differ by at most one element, cut into
+// workgroups of 4 that may straddle two tiles; the waves of one tile inside a workgroup are summed through LDS in wave
+// order (fixed order: bit-reproducible) and leave ONE partial sum, so a tile leaves <= 5 in HBM instead of 13.
+// XCD-aware: consecutive workgroup ids go round the 8 XCDs, so id -> (xcd, slot) and XCD x takes the x-th CONTIGUOUS
+// eighth of the line -- the row tiles of at most three set groups: a candidate row is fetched by one or two L2s,
+// not by all eight.
+template <int KIND, int KT>
+__global__ __launch_bounds__(SOBER_LW_W * 64, 2) void k_level_reduce_wave(
+    const double* __restrict__ rows, int n_rows, const double* __restrict__ cand,
+    const int32_t* __restrict__ idx, int64_t pos0, int64_t count, int S,
+    const double* __restrict__ mu, const double* __restrict__ wmul, double os,
+    int64_t e_first, int e_total,
+    double* __restrict__ partG, int ldg, int col0,
+    double* __restrict__ partTot, int64_t tot_limit,
+    const int64_t* __restrict__ dR, int S_main, int leftover) {
+    constexpr int DA = 4 * KT;
+    constexpr int W = SOBER_LW_W;
+    __shared__ double s_T[EXP_TAB];              // 2^(j/256), exponent-adjusted (exp_tab_entry)
+    __shared__ double s_tot[W * 16];
+    __shared__ double s_red[W * 16 * 64];
+
+    if (dR != nullptr) {                        // queued level: sizes from device memory (see k_level_reduce_mfma)
+        const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (R <= S_main) return;
+        const int64_t ES = (R / S_main) * S_main;
+        if (!leftover) { count = R; tot_limit = ES; }
+        else { idx += ES; count = R - ES; tot_limit = count; }
+        if (count <= 0) return;
+        pos0 = 0; e_first = 0;
+        e_total = (int)((count + S - 1) / S);
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (scalar: the element loop is uniform)
+    const int lj = lane & 15, lk = lane >> 4;
+    const int G = (S + 15) >> 4, RT = (n_rows + 63) >> 6;
+    const int wpt = level_wave_wpt(n_rows, e_total, S);
+    const int n_slots = level_wave_slots(wpt);
+    const int n_waves = G * RT * wpt;
+    const int per_xcd = gridDim.x >> 3;                                 // (the grid is a multiple of 8)
+    const int q = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);       // my place in the line of workgroups
+    if (q * W >= n_waves) return;                                       // (whole workgroup)
+    const int v = q * W + wave;
+    const bool live = v < n_waves;
+    const int tile = live ? v / wpt : -1, sub = live ? v - tile * wpt : 0;
+    const int g = live ? tile / RT : 0, rt = live ? tile - g * RT : 0;
+    const int e_base = e_total / wpt, e_rem = e_total - e_base * wpt;   // element ranges differ by at most one
+    const int ea = live ? sub * e_base + min(sub, e_rem) : 0;
+    const int eb = live ? ea + e_base + (sub < e_rem ? 1 : 0) : 0;
+    const int row0 = rt * 64;
+    const int s = g * 16 + lj;
+    const bool s_ok = s < S;
+
+    static_assert(SOBER_LW_W * 64 >= EXP_TAB, "one table entry per thread");
+    if (tid < EXP_TAB) s_T[tid] = exp_tab_entry(tid);
+
+    double afr[4][KT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = min(row0 + 16 * t + lj, n_rows - 1);             // (rows past the table: computed, never stored)
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) afr[t][ks] = rows[(size_t)r * DA + lk * KT + ks];
+    }
+    double4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double tot_acc = 0.0;
+
+    const double* wm_ptr = wmul ? wmul : mu;
+    // list position of my candidate of element e, relative to the first position of this launch: 32-bit (the list
+    // holds int32 indices).  Without a candidate (set past S, element past my range, position outside the list) the
+    // loads go to a clamped position -- some valid candidate, whose finite kernel value meets a zero weight: every
+    // load is unconditional, so the compiler can count what is in flight.  (Lanes of a set past S compute on such
+    // stand-ins throughout and are never stored.)
+    const int rel0 = s - (int)(pos0 - e_first * S);
+    const int cnt32 = (int)count;
+    const int tl32 = (int)max((int64_t)INT32_MIN, min((int64_t)INT32_MAX, tot_limit - pos0));
+#define LW_REL(e, R, OK)                                                                   \
+    const int R = (e) * S + rel0;                                                          \
+    const bool OK = s_ok && (e) < eb && R >= 0 && R < cnt32;
+    // (addresses are clamped with integer min/max, not selected on OK: a select on a loaded value's address turns
+    // into a branch, and with control flow in the loop the waits degrade to "everything")
+#define LW_IDX(e, C) C = idx[min(max((e) * S + rel0, 0), cnt32 - 1)];
+#define LW_LOAD(e, C, Q)                                                                   \
+    {                                                                                      \
+        LW_REL(e, rl_, okl_)                                                               \
+        m[Q] = mu[C];                                                                      \
+        wv[Q] = wm_ptr[C];                                                                 \
+        const double* src_ = cand + (size_t)C * DA + lk * KT;                              \
+        _Pragma("unroll") for (int ks = 0; ks < KT; ++ks) b[Q][ks] = src_[ks];             \
+        ok[Q] = okl_;                                                                      \
+        okt[Q] = okl_ && rl_ < tl32;                                                       \
+    }
+    // matrix-core part of one element: its operands were loaded one half-step ago
+#define LW_MFMA(Q)                                                                         \
+    {                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) cc[Q][t] = (double4_t){0.0, 0.0, 0.0, 0.0}; \
+        _Pragma("unroll") for (int ks = 0; ks < KT; ++ks)                                  \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                  \
+                cc[Q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[t][ks], b[Q][ks], cc[Q][t], 0, 0, 0); \
+        w[Q] = ok[Q] ? (wmul ? m[Q] * wv[Q] : m[Q]) * os : 0.0;                            \
+        tot_acc += okt[Q] ? m[Q] : 0.0;                                                    \
+    }
+    // one element: operands of e + 2 requested, index of e + 3 requested, MFMAs of e + 1, exponentials of e
+#define LW_HALF(e, Q, QN)                                                                  \
+    {                                                                                      \
+        asm volatile("" : "+v"(cF));       /* the index is awaited HERE, not where it was requested */ \
+        int cG_;                                                                           \
+        LW_IDX((e) + 3, cG_)                                                               \
+        LW_LOAD((e) + 2, cF, Q)                                                            \
+        cF = cG_;                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        LW_MFMA(QN)                                                                        \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                    \
+            double k_[4];                                                                  \
+            const double4_t c_ = ccv[Q][t];                                                \
+            kern_from_arg4<KIND>(c_, s_T, k_);                                             \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[t][r] = fma(k_[r], wcv[Q], acc[t][r]); \
+        }                                                                                  \
+        LW_INTERLEAVE                                                                      \
+    }
+
+    // LW_SCHED = n: ask the scheduler for one MFMA per n vector instructions instead of its own order (which
+    // leaves the MFMAs of an element in two or three clumps)
+#if defined(LW_SCHED) && LW_SCHED > 0
+#define LW_INTERLEAVE                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4 * KT; ++i_) {                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x002, LW_SCHED, 0);                          \
+    }
+#else
+#define LW_INTERLEAVE
+#endif
+    double4_t cc[2][4];
+    double w[2];
+    double b[2][KT], m[2], wv[2];
+    bool ok[2], okt[2];
+    int cA = 0, cB = 0, cF = 0;
+    LW_IDX(ea, cA)
+    LW_IDX(ea + 1, cB)
+    LW_IDX(ea + 2, cF)
+    __syncthreads();                                   // the table (the only barrier before the final sum)
+    LW_LOAD(ea, cA, 0)
+    LW_LOAD(ea + 1, cB, 1)
+    LW_MFMA(0)
+    // (the exponentials of a half-step read cc / w of the element the PREVIOUS half-step multiplied)
+#define ccv cc
+#define wcv w
+    int e = ea;
+    for (; e + 1 < eb; e += 2) {
+        LW_HALF(e, 0, 1)
+        LW_HALF(e + 1, 1, 0)
+    }
+    if (e < eb) LW_HALF(e, 0, 1)
+#undef ccv
+#undef wcv
+#undef LW_REL
+#undef LW_IDX
+#undef LW_LOAD
+#undef LW_MFMA
+#undef LW_HALF
+#undef LW_INTERLEAVE
+
+    // the waves of one tile inside the workgroup hold consecutive element ranges: the first of them sums the run in
+    // wave order and stores it as the tile's partial sum number (this workgroup - the tile's first workgroup)
+    __shared__ int s_tile[W];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[(wave * 16 + t * 4 + r) * 64 + lane] = acc[t][r];
+    if (lk == 0) s_tot[wave * 16 + lj] = tot_acc;
+    if (lane == 0) s_tile[wave] = tile;
+    __syncthreads();
+    if (!live || (wave > 0 && s_tile[wave - 1] == tile)) return;       // not the first wave of its run
+    for (int w = wave + 1; w < W && s_tile[w] == tile; ++w) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += s_red[(w * 16 + t * 4 + r) * 64 + lane];
+        tot_acc += s_tot[w * 16 + lj];
+    }
+    const int slot = q - (tile * wpt) / W;
+    const int last_q = (tile * wpt + wpt - 1) / W;                     // the workgroup of the tile's last wave
+    if (!s_ok) return;
+    // (a tile whose waves touch fewer workgroups than n_slots: its last run also clears the slots nobody writes)
+    for (int sl = slot; sl < (q == last_q ? n_slots : slot + 1); ++sl) {
+        const bool mine = sl == slot;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * t + lk + 4 * r;
+                if (row < n_rows) partG[((size_t)sl * n_rows + row) * ldg + col0 + s] = mine ? acc[t][r] : 0.0;
+            }
+        if (partTot != nullptr && rt == 0 && lk == 0) partTot[(size_t)sl * ldg + col0 + s] = mine ? tot_acc : 0.0;
+    }
+}
+
 // points -> augmented, centred, scaled rows.  side 1 (pool): [y~, 1, -|y~|^2/2, 0..];
-// side 0 (row table): L * [x~, -|x~|^2/2, 1, 0..] with L = 64/ln2, so that X'.Y' = -|x~ - y~|^2/2 * L is
+// side 0 (row table): L * [x~, -|x~|^2/2, 1, 0..] with L = 256/ln2, so that X'.Y' = -|x~ - y~|^2/2 * L is
 // directly the table-exp's scaled argument
 // One 16-lane DPP row per point (lane l holds coordinates l and l + 16: DA <= 32): the row of X is read and the
 // augmented row written as contiguous 128-byte segments, |x~|^2 is an in-row DPP reduction.
@@ -308,7 +522,7 @@ __global__ __launch_bounds__(256) void k_augment_points(const double* __restrict
     const int l16 = threadIdx.x & 15;
     const bool live = i < n;
     const int64_t ir = live ? i : n - 1;
-    const double sc = (side == 0) ? 92.33248261689366 : 1.0;
+    const double sc = (side == 0) ? 369.3299304675746 : 1.0;       // 256/ln2: exp_tab4's pre-scaling
     double v[2], nrm = 0.0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -339,11 +553,21 @@ static int launch_lm(const double* rows, int n_rows, const double* cand, const i
                      const int64_t* dR = nullptr, int S_main = 0, int leftover = 0) {
     const int64_t e_first = pos0 / S;
     const int e_total = (int)((pos0 + count + S - 1) / S - e_first);
+#ifdef SOBER_LM_BLOCK
     const int e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
     dim3 grid((S + LM_SB - 1) / LM_SB, n_chunks, (n_rows + LM_RW * 64 - 1) / (LM_RW * 64));
     hipLaunchKernelGGL((k_level_reduce_mfma<KIND, KT>), grid, dim3(LM_RW * 64), 0, st, rows, n_rows, cand, idx,
                        pos0, count, S, mu, wmul, os, e_first, e_total, e_per_chunk, partG, ldg, col0, partTot,
                        tot_limit, dR, S_main, leftover);
+#else
+    const int wpt = level_wave_wpt(n_rows, e_total, S);
+    if (n_chunks != level_wave_slots(wpt)) return SOBER_E_ARG;         // (sober_level_parts_mfma: the slots per tile)
+    const int64_t n_waves = level_wave_tiles(n_rows, S) * wpt;
+    const int64_t n_wg = (n_waves + SOBER_LW_W - 1) / SOBER_LW_W;
+    hipLaunchKernelGGL((k_level_reduce_wave<KIND, KT>), dim3((unsigned)(8 * ((n_wg + 7) / 8))), dim3(SOBER_LW_W * 64), 0,
+                       st, rows, n_rows, cand, idx, pos0, count, S, mu, wmul, os, e_first, e_total, partG, ldg, col0,
+                       partTot, tot_limit, dR, S_main, leftover);
+#endif
     LAUNCH_CHECK();
     return 0;
 }
@@ -351,6 +575,16 @@ static int launch_lm(const double* rows, int n_rows, const double* cand, const i
 }  // namespace sober
 
 using namespace sober;
+
+extern "C" int sober_level_parts_mfma(int n_rows, int64_t pos0, int64_t count, int S) {
+    if (n_rows <= 0 || pos0 < 0 || count <= 0 || S <= 0) return SOBER_E_ARG;
+    return level_parts_mfma_for(n_rows, (pos0 + count + S - 1) / S - pos0 / S, S);
+}
+
+extern "C" int sober_level_parts_mfma_cap(int n_rows, int64_t e_total_ub, int S) {
+    if (n_rows <= 0 || e_total_ub <= 0 || S <= 0) return SOBER_E_ARG;
+    return level_parts_mfma_cap(n_rows, e_total_ub, S);
+}
 
 extern "C" int sober_aug_dim(int d) {
     if (d <= 0) return SOBER_E_ARG;
@@ -380,7 +614,9 @@ extern "C" int sober_level_reduce_mfma(int kind, const double* rows, int n_rows,
                                        const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu,
                                        const double* wmul, double outputscale, int n_chunks, double* partG,
                                        int ldg, int col0, double* partTot, int64_t tot_limit, void* stream) {
+#ifdef SOBER_LM_BLOCK
     if (n_chunks > (pos0 + count + S - 1) / S - pos0 / S) return SOBER_E_ARG;
+#endif
     return level_reduce_mfma_impl(kind, rows, n_rows, cand, da, idx, pos0, count, S, mu, wmul, outputscale, n_chunks,
                                   partG, ldg, col0, partTot, tot_limit, stream, nullptr, 0, 0);
 }

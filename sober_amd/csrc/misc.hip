@@ -106,8 +106,8 @@ __global__ void k_sum_partials(const double* __restrict__ partG, const double* _
         const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (R <= S) return;
         const int64_t E = R / S, left = R - E * S;
-        n_chunks = level_chunks_for(n_rows, (R + S - 1) / S, S);
-        n_xchunks = left > 0 ? level_chunks_for(n_rows, (left + n_xcols - 1) / n_xcols, n_xcols) : 0;
+        n_chunks = level_parts_mfma_for(n_rows, (R + S - 1) / S, S);
+        n_xchunks = left > 0 ? level_parts_mfma_for(n_rows, (left + n_xcols - 1) / n_xcols, n_xcols) : 0;
         if (left <= 0) { extraG = nullptr; extraTot = nullptr; }
     }
     const bool fold = (extraG != nullptr) && (s == S - 1);
