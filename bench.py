@@ -62,9 +62,9 @@ CK = {"rbf": 28, "matern52": 40}
 # launches included) from rocprofv3 PMC passes of the configuration: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950
 # FETCH_SIZE correction of MI355X_MICROARCH.md; separate --pmc passes; profiles/r02_pmc_level_reduce.csv).
 # Algorithmic bytes at configuration 2 are ~1.3 MB/launch (every live candidate row, index and weight once per
-# level): the excess is the per-chunk partial-sum buffers (n_chunks * Mtot * S * 8 B written -- 14.6 MB at level 0
-# with 13 chunks -- then re-read by k_sum_partials).  Round 1 (26 chunks): 23.4 MB.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {2: 11.6e6}
+# level).  The excess: the <= 5 partial sums per tile (5.6 MB written at level 0, re-read by k_sum_partials) and the
+# candidate rows that two XCDs' L2s both fetch.  Round 1: 23.4 MB; workgroup-staged kernel with 13 chunks: 11.6 MB.
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {2: 5.8e6}
 
 
 def t(a):
@@ -288,13 +288,16 @@ def main():
         roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS,
                     "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(args.config) if world == 1 else None,
-                    "kernel": "k_level_reduce_mfma", "launches": len(prof), "kernel_ms_per_step": kern_ms / args.steps,
+                    "kernel": "k_level_reduce_wave", "launches": len(prof), "kernel_ms_per_step": kern_ms / args.steps,
                     "event_pair_overhead_ms": ev_overhead,
                     "note": "FP64 compute-bound: -|x-y|^2/2 on v_mfma_f64_16x16x4 (augmented GEMM), "
                             "table-driven FP64 exp on the VALU; MI355X FP64 vector and matrix peaks are "
-                            "both 78.6 TFLOP/s and share the DP units (scripts/fp64_pipes_probe.hip); "
+                            "both 78.6 TFLOP/s at 2.4 GHz and share the vector ALU: on gfx950 no vector "
+                            "instruction of a SIMD overlaps with a running v_mfma_f64, and the clock under "
+                            "FP64 load is ~1.9 GHz (scripts/dp_rate_probe.hip: 63 TFLOP/s MFMA-only, "
+                            "61 FMA-only) -- the kernel is bound by its instruction count; "
                             f"algorithmic flop = entries * (2d+2+C_k) = entries * {flop_per_entry}; all "
-                            "launches of a step are averaged (level 0 alone runs ~2x the average)"}
+                            "launches of a step are averaged (level 0 alone runs ~1.35x the average)"}
     strong = bool(cfg.get("strong"))
     n_rec = str(cfg["N"]) if (strong or world == 1) else "%dx%d" % (world, cfg["N"])
     out = {

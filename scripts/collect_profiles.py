@@ -43,6 +43,32 @@ for pas, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             acc = per_kernel.setdefault(pas, [0.0, 0])
             acc[0] += val
             acc[1] += 1
+# SQ passes: one row per level-kernel dispatch of the LAST step, counters side by side
+for pas in ("sq", "sq2"):
+    cc = src / f"pmc_{pas}" / "run_counter_collection.csv"
+    if not cc.exists():
+        continue
+    per = {}
+    order = []
+    names = []
+    for r in csv.DictReader(cc.open()):
+        if "k_level_reduce" not in r["Kernel_Name"]:
+            continue
+        d = r["Dispatch_Id"]
+        if d not in per:
+            per[d] = {"grid": r["Grid_Size"], "dur": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])}
+            order.append(d)
+        per[d][r["Counter_Name"]] = float(r["Counter_Value"])
+        if r["Counter_Name"] not in names:
+            names.append(r["Counter_Name"])
+    # the last step = the dispatches after the last level-0 sized launch
+    big = max(int(per[d]["grid"]) for d in order)
+    last0 = max(i for i, d in enumerate(order) if int(per[d]["grid"]) == big)
+    with (dst / f"{name}_pmc_{pas}_level_reduce.csv").open("w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["dispatch", "grid", "duration_us"] + names)
+        for d in order[last0:]:
+            w.writerow([d, per[d]["grid"], f"{per[d]['dur'] / 1e3:.1f}"] + [f"{per[d].get(n, float('nan')):.6g}" for n in names])
 if rows:
     with (dst / f"{name}_pmc_level_reduce.csv").open("w", newline="") as f:
         w = csv.writer(f)

@@ -98,8 +98,16 @@ class DistComm:
             key = id(group) if group is not None else 0
             rc = DistComm._RCCL.get(key)
             if rc is None:
-                rc = DistComm._RCCL[key] = nat.RcclComm(dist, group, device)
-            return rc.fn_ptr, rc.handle, rc
+                try:
+                    rc = nat.RcclComm(dist, group, device)
+                except Exception as e:                     # (the same image on every rank: all of them land here)
+                    import warnings
+                    warnings.warn(f"sober_amd: RCCL could not be bound from C ({e}); the level loop's all-reduce goes "
+                                  "through torch.distributed instead")
+                    rc = False
+                DistComm._RCCL[key] = rc
+            if rc is not False:
+                return rc.fn_ptr, rc.handle, rc
 
         def cb(_comm, _buf, _n, _stream):
             try:

@@ -39,10 +39,10 @@ constexpr int LM_TE = 8;     // elements staged per tile
 // of the SIMD -- integer ones too -- queues behind a running v_mfma_f64 (scripts/dp_rate_probe.hip), so the count
 // of instructions is what this kernel's time is made of.
 constexpr int EXP_TAB = 256;
-__device__ __forceinline__ double exp_tab_entry(int j) {
-    const double t = exp2((double)j * (1.0 / EXP_TAB));
-    return __hiloint2double(__double2hiint(t) - (j << 12), __double2loint(t));
-}
+__device__ const unsigned long long c_exp_tab[EXP_TAB] = {
+#include "exp_table.inc"
+};
+__device__ __forceinline__ double exp_tab_entry(int j) { return __longlong_as_double((long long)c_exp_tab[j]); }
 __device__ __forceinline__ void exp_tab4(const double (&y)[4], const double* __restrict__ T, double (&out)[4]) {
     const double MAGIC = 6755399441055744.0;        // 1.5 * 2^52
     const double K1 = 0.0027076061740622863;        // (ln2/256)^k / k!

@@ -237,3 +237,27 @@ def test_adaptive_pruning_matches_reference():
         n_rec, n_nys = (int(v) for v in z[f"{tag}_args"])
         assert np.array_equal(O.adaptive_pruning(w, n_rec, n_nys).numpy(), z[f"{tag}_idx"]), tag
         assert np.array_equal(sober_amd.adaptive_pruning(w, n_rec, n_nys).numpy(), z[f"{tag}_idx"]), tag
+
+
+def test_d1_goldens_and_exact_moments():
+    """d = 1 (make_golden.py::gen_d1_sensitivity): the oracle reproduces the reference on both one-dimensional fixtures,
+    and on the pool without leftovers (N = 1024) the reduced measure integrates the step's own test functions exactly
+    -- the property the device result is held to on this ill-conditioned input (tests/test_hip_parity.py)."""
+    from tests.golden import make_golden as MG
+    from tests.golden.synth import synth, build_spec
+    for case, name in ((MG.D1_CASE, "d1_sensitivity.npz"), (MG.D1_EXACT_CASE, "d1_exact.npz")):
+        z = np.load(os.path.join(os.path.dirname(SMALL[0]), name))
+        inp = synth(case)
+        spec = build_spec(case, inp)
+        tr = {}
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx, w = O.recombination(_t(inp["X_cand"]), _t(inp["X_nys"]), case["b"], O.Kernel(spec, case["mode"]),
+                                     init_weights=_t(inp["mu0"].copy()), trace=tr)
+        assert np.array_equal(idx.numpy(), z["idx"]) and np.array_equal(w.numpy(), z["w"])
+        if case["N"] == 1024:
+            K = O.Kernel(spec, case["mode"])(_t(inp["X_nys"]), _t(inp["X_cand"])).numpy()
+            U = tr["U"].numpy()
+            m = U @ (K @ inp["mu0"])
+            assert np.linalg.norm(U @ (K[:, z["idx"]] @ z["w"]) - m) < 1e-12 * np.linalg.norm(m)
