@@ -110,6 +110,13 @@ int sober_level_reduce_mfma(int kind, const double* rows, int n_rows, const doub
                             double* partTot, int64_t tot_limit, void* stream);
 
 /* chunk count the library would pick for a level of `count` positions in S sets.                 */
+/* The live list idx_story = arange(N)[mu != 0] (SOBER/_rchq.py:63-65) as an ordered stream compaction whose count
+ * stays on the device (*count_out, int64): no synchronisation to size the output, unlike torch.nonzero.  idx_out holds
+ * N entries; ws from sober_nonzero_ws_bytes(N).                                                                      */
+int64_t sober_nonzero_ws_bytes(int64_t N);
+int sober_nonzero_i32(const double* mu, int64_t N, int32_t* idx_out, int64_t* count_out, void* ws, int64_t ws_bytes,
+                      void* stream);
+
 int sober_level_chunks(int n_rows, int64_t pos0, int64_t count, int S);
 /* The same for sober_level_reduce_mfma (its workgroups are waves of one 64-row x 16-set tile that sum their element
  * ranges on chip: 1-2 partial sums per tile), and the largest value it can take up to e_total_ub elements per set (what

@@ -295,9 +295,14 @@ class RecombinationEngine:
         # the live list and the first level's set sums do not depend on the Nystrom basis: on the device
         # route they are enqueued while the host runs the small SVD of svd_lowrank
         state = {}
+        # (the list itself is requested at once, behind whatever the plan has enqueued: its count is on the host long
+        #  before the first level wants it, with no synchronisation behind the Nystrom chain)
+        pending = ops.nonzero_start(mu) if getattr(ops, "nonzero_start", None) is not None \
+            and not os.environ.get("SOBER_SYNC_LIST") else None         # (the switch: A/B of the synchronised form)
 
         def first_sums():
-            idx_cur, count = ops.nonzero_i32(mu)           # idx_story = arange(N)[mu != 0]  (:63-65)
+            idx_cur, count = ops.nonzero_finish(pending) if pending is not None else ops.nonzero_i32(mu)
+            #                                                idx_story = arange(N)[mu != 0]  (:63-65)
             counts = comm.allgather_counts(count)
             bounds = [0]
             for c in counts:
@@ -325,6 +330,8 @@ class RecombinationEngine:
         U = self.nystrom_basis(plan, n, overlap=head_once if comm.world == 1 else None, literal=car_on_host)
         if comm.world > 1:                                  # rank 0's randn draw is the one that counts
             U = comm.broadcast0(ops.from_host(U.contiguous()) if U.device != ops.device else U.contiguous())
+            if hasattr(plan, "_proj_src"):
+                plan._proj_src = None                       # (the broadcast may have filled the very tensor a projection was enqueued for)
         ops.set_projection(plan, U)
         head_once()
         idx_cur, count, pos0, R = state["idx_cur"], state["count"], state["pos0"], state["R"]

@@ -33,6 +33,8 @@ SIGNATURES = {
     "sober_kernel_matvec": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _f64, _vp, _vp]),
     "sober_level_reduce": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp,
                                   _f64, _i32, _vp, _i32, _i32, _vp, _i64, _vp]),
+    "sober_nonzero_ws_bytes": (_i64, [_i64]),
+    "sober_nonzero_i32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "sober_level_chunks": (_i32, [_i32, _i64, _i64, _i32]),
     "sober_level_parts_mfma": (_i32, [_i32, _i64, _i64, _i32]),
     "sober_level_parts_mfma_cap": (_i32, [_i32, _i64, _i32]),
@@ -229,6 +231,18 @@ def kernel_matvec(kind, a, a_norm, v, b, b_norm, dt, outputscale, c0, out):
     _check(load().sober_kernel_matvec(kind, a.data_ptr(), _ptr(a_norm), v.data_ptr(), a.shape[0],
                                       b.data_ptr(), _ptr(b_norm), b.shape[0], dt, float(outputscale),
                                       float(c0), out.data_ptr(), _stream(out)), "sober_kernel_matvec")
+
+
+def nonzero_ws_bytes(N) -> int:
+    r = load().sober_nonzero_ws_bytes(N)
+    _check(min(int(r), 0), "sober_nonzero_ws_bytes")
+    return int(r)
+
+
+def nonzero_i32(mu, idx_out, count_out, ws):
+    _req(mu, torch.float64, "mu"); _req(idx_out, torch.int32, "idx_out"); _req(count_out, torch.int64, "count_out")
+    _check(load().sober_nonzero_i32(mu.data_ptr(), mu.numel(), idx_out.data_ptr(), count_out.data_ptr(), ws.data_ptr(),
+                                    ws.numel() * ws.element_size(), _stream(mu)), "sober_nonzero_i32")
 
 
 def level_chunks(n_rows, pos0, count, S) -> int:

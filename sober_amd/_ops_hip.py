@@ -115,6 +115,9 @@ class HipOps:
         """P = [U diag(mean), -(U diag(mean)) T]: phi(x) = P k([X_nys; X_obs], x) is the vector of
         Nystrom test functions U @ C(X_nys, x) (SOBER/_rchq.py:78,148,156) with the posterior
         correction of SOBER/_gp.py:295 folded in (it is linear)."""
+        if getattr(p, "_proj_src", None) is U:              # already enqueued for this very basis (nystrom_basis_device)
+            return
+        p._proj_src = U
         U = U.to(self.device, torch.float64).contiguous()
         p.n = U.shape[0]
         P1 = U * p.mean_nys.unsqueeze(0) if p.weighted else U
@@ -170,7 +173,7 @@ class HipOps:
         # generator is put back and the literal host route decides.
         rng_state = torch.get_rng_state()
         R = torch.randn(M, s, dtype=torch.float64)
-        U, (flags_h, piv_h) = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=(flags, pivots))
+        U, (flags_h, piv_h) = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=(flags, pivots), plan=p)
         if int(flags_h[0]) == 0 or U is None or self.ladder_borderline(flags_h[2:], piv_h[:n_r], float(piv_h[n_r])):
             torch.set_rng_state(rng_state)                 # the host route draws the same randn again
             return None
@@ -224,7 +227,7 @@ class HipOps:
     # matrix (~ cond(Y)^-2) stays above this: orthonormality then holds to ~1e-6 and the subspace to eps cond(Y)
     ORTH1_MIN_RATIO = 1e-10
 
-    def _svd_lowrank_device(self, A, q, R_host, niter: int = 2, overlap=None, extra=None):
+    def _svd_lowrank_device(self, A, q, R_host, niter: int = 2, overlap=None, extra=None, plan=None):
         """The range finder of torch.svd_lowrank(A, q) (Halko et al. Alg. 4.4, as in torch/_lowrank.py:64-79) for
         a square device matrix; returns an orthonormal basis of the same subspace as SOBER/_rchq.py:38's U, as
         rows (q, M) -- see the comment at the end for why the small SVD is not needed -- or None if CholeskyQR
@@ -259,6 +262,11 @@ class HipOps:
         # weights to 1e-12 on every golden level).  So any orthonormal basis of range(Q) serves, Q^T itself does,
         # and the q x M product, the second range finder for B^T, the host's LAPACK SVD (0.93 ms at q = 99), two
         # PCIe hops and a GEMM leave the step.  (The literal host route still computes U_B.)
+        # the projection P = [U, -U T] of this basis is enqueued BEFORE the flags are waited for: should they send the
+        # step to the host route, set_projection simply runs again with that route's basis
+        Ut = Q.T.contiguous()
+        if plan is not None and hasattr(plan, "weighted") and not os.environ.get("SOBER_SYNC_LIST"):
+            self.set_projection(plan, Ut)
         if extra is None:
             infos_h, pivs_h = self.to_host(infos, pivs, before_sync=overlap)
             extra_h = None
@@ -271,7 +279,6 @@ class HipOps:
         if bool((infos_h != 0).any()) or float(pivs_h[2 * last + 1]) < 0.5 \
                 or any(not (float(pivs_h[s + 1]) >= self.ORTH1_MIN_RATIO) for s in single):
             return (None, extra_h) if extra is not None else None
-        Ut = Q.T.contiguous()
         return (Ut, extra_h) if extra is not None else Ut
 
     # ------------------------------------------------------------------ levels
@@ -558,6 +565,31 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ plumbing
+    def nonzero_start(self, mu):
+        """Enqueue the live list idx_story = arange(N)[mu != 0] (SOBER/_rchq.py:63-65) NOW, as a compaction whose
+        count stays on the device and travels to pinned memory behind it; `nonzero_finish` waits for that copy only.
+        (torch.nonzero synchronises to size its output: called where the list is first needed, that wait sat behind the
+        whole Nystrom chain and the first level could not be enqueued until it was over.)"""
+        N = mu.numel()
+        key = ("nz", N)
+        bufs = self._pin.get(key)
+        if bufs is None:
+            ws = torch.empty(nat.nonzero_ws_bytes(N), dtype=torch.uint8, device=self.device)
+            bufs = self._pin[key] = (ws, torch.zeros(1, dtype=torch.int64, device=self.device),
+                                     torch.zeros(1, dtype=torch.int64).pin_memory())
+        ws, cnt, pin = bufs
+        out = torch.empty(N, dtype=torch.int32, device=self.device)
+        nat.nonzero_i32(mu, out, cnt, ws)
+        pin.copy_(cnt, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return out, pin, ev
+
+    def nonzero_finish(self, pending):
+        out, pin, ev = pending
+        ev.synchronize()
+        return out, int(pin[0])
+
     def nonzero_i32(self, mu):
         nz = torch.nonzero(mu != 0).flatten()
         out = torch.empty(max(nz.numel(), 1), dtype=torch.int32, device=self.device)

@@ -50,6 +50,11 @@ __device__ __forceinline__ double tani_fast(double dot, double nx, double ny, do
     return fmax(q, 0.0) * os;
 }
 
+#ifdef TANI_X_NOEXPAND
+#define LT_EXPAND(x) ((int4_t){(int)(x), (int)(x), (int)(x), (int)(x)})
+#else
+#define LT_EXPAND(x) expand16(x)
+#endif
 template <int DT>      // 64-bit words per fingerprint
 __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     const unsigned long long* __restrict__ rows, const double* __restrict__ rows_norm, int n_rows,
@@ -75,6 +80,8 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 15, lk = lane >> 4;
+    // (an XCD-aware one-dimensional grid -- the row blocks of one (set group, chunk) on ONE XCD, as in the FP64 level
+    //  kernel -- was measured 16 % SLOWER here: 809 vs 695 us at level 0 of configuration 5)
     const int s0 = blockIdx.x * SB;
     const int chunk = blockIdx.y;
     const int row0 = blockIdx.z * LT_ROWS + wave * (LT_RT * 16);
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
             const int unit = tid + NTH * u;                                                \
             const int q = unit / (4 * DT), part = unit & 3;                                \
             *(int4_t*)(&s_b[buf_][q * ROWB + uq_w[u] * 64 + part * 16]) =                  \
-                expand16(okw[u] ? (unsigned)(stw[u] >> (16 * part)) & 0xFFFFu : 0u);       \
+                LT_EXPAND(okw[u] ? (unsigned)(stw[u] >> (16 * part)) & 0xFFFFu : 0u);      \
         }                                                                                  \
         if (tid < NC) {                                                                    \
             s_w[buf_][tid] = ok_w ? (wmul ? m_raw * wm_raw : m_raw) : 0.0;                 \
@@ -187,17 +194,29 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
             const unsigned char* bp = &s_b[buf][(te * SB + lj) * ROWB + lk * 16];
 #pragma unroll
             for (int ks = 0; ks < DT; ++ks) {
+#ifdef TANI_X_NODSREAD          /* timing experiments only (scripts/tani_where.sh): results are wrong */
+                const int4_t bfr = afr[0][(ks + 1) % DT];
+#else
                 const int4_t bfr = *(const int4_t*)(bp + ks * 64);
+#endif
 #pragma unroll
                 for (int t = 0; t < LT_RT; ++t)
+#ifdef TANI_X_NOMFMA
+                    cc[t] += bfr;
+#else
                     cc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[t][ks], bfr, cc[t], 0, 0, 0);
+#endif
             }
             const double w = s_w[buf][te * SB + lj], ny = s_ny[buf][te * SB + lj];
 #pragma unroll
             for (int t = 0; t < LT_RT; ++t)
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
+#ifdef TANI_X_NOQUOT
+                    acc[t][v] = fma((double)cc[t][v] + ny, w, acc[t][v]);
+#else
                     acc[t][v] = fma(tani_fast((double)cc[t][v], nxr[t][v], ny, os), w, acc[t][v]);
+#endif
         }
         LT_STAGE_WRITE(buf ^ 1)
         __syncthreads();
