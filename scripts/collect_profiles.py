@@ -61,9 +61,9 @@ for pas in ("sq", "sq2"):
         per[d][r["Counter_Name"]] = float(r["Counter_Value"])
         if r["Counter_Name"] not in names:
             names.append(r["Counter_Name"])
-    # the last step = the dispatches after the last level-0 sized launch
-    big = max(int(per[d]["grid"]) for d in order)
-    last0 = max(i for i, d in enumerate(order) if int(per[d]["grid"]) == big)
+    # the last step = the dispatches from the last level-0 launch on (level 0 = the longest launches of the run)
+    big = max(per[d]["dur"] for d in order)
+    last0 = max(i for i, d in enumerate(order) if per[d]["dur"] >= 0.7 * big)
     with (dst / f"{name}_pmc_{pas}_level_reduce.csv").open("w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["dispatch", "grid", "duration_us"] + names)

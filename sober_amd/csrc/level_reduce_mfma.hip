@@ -562,6 +562,7 @@ static int launch_lm(const double* rows, int n_rows, const double* cand, const i
 #else
     const int wpt = level_wave_wpt(n_rows, e_total, S);
     if (n_chunks != level_wave_slots(wpt)) return SOBER_E_ARG;         // (sober_level_parts_mfma: the slots per tile)
+    if (count + 2 * (int64_t)S > 0x7fffffffLL) return SOBER_E_ARG;     // (positions inside a launch are 32-bit, like the list's entries)
     const int64_t n_waves = level_wave_tiles(n_rows, S) * wpt;
     const int64_t n_wg = (n_waves + SOBER_LW_W - 1) / SOBER_LW_W;
     hipLaunchKernelGGL((k_level_reduce_wave<KIND, KT>), dim3((unsigned)(8 * ((n_wg + 7) / 8))), dim3(SOBER_LW_W * 64), 0,
