@@ -143,9 +143,10 @@ class HipOps:
         then back where it was."""
         import warnings
         dev, M = self.device, p.M
-        G = self.gram(p)
         if M > nat.chol_max_n() or s > 256 or s >= M:
+            self.gram(p)
             return None
+        G = self.gram(p)
         # everything up to the basis is enqueued without a host decision in between: the symmetry flag of the input
         # and the rung the ladder took are read back together with the range finder's health flags at the end
         n_r = max_iter + 1
@@ -168,9 +169,15 @@ class HipOps:
         nat.cholesky_probe(C, shifts, work, flags[2:], pivots)
         nat.jitter_ladder_auto(C, flags[2:], flags[1:2])
         # svd_lowrank's randn comes from the CPU generator (it is the next consumer of the generator in the
-        # reference too: make_cov_psd draws nothing), drawn while the probes run.  Should the input turn out
-        # exactly symmetric (is_psd(cov) itself has to run, on the host) or the range finder lose rank, the
-        # generator is put back and the literal host route decides.
+        # reference too: make_cov_psd draws nothing).  torch.randn(500, 99) is 0.6 ms of host time -- as long as the
+        # Cholesky probe it hides behind: this phase is bound by the HOST.  Two ways of hiding it better were measured
+        # and made the step slower by 0.2 ms each: a helper thread for the draw (thread start, join and the GIL cost more
+        # than they hide) and enqueueing the first level's set sums in front of the draw (their host-side set-up delays
+        # the draw itself).  Should the input turn out exactly symmetric (is_psd(cov) itself has to run, on the host) or
+        # the range finder lose rank, the generator is put back and the literal host route decides.
+        if overlap is not None and os.environ.get("SOBER_EARLY_SUMS"):      # (measured: +0.2 ms at cfg-2, see above)
+            overlap()
+            overlap = None
         rng_state = torch.get_rng_state()
         R = torch.randn(M, s, dtype=torch.float64)
         U, (flags_h, piv_h) = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=(flags, pivots), plan=p)

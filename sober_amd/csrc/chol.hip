@@ -41,55 +41,15 @@ __device__ __forceinline__ double ch_rdlane(double v, int l) {
 //   (c) the panel below is L21 = A21 L11^-T as a small GEMM on the matrix cores (no per-row substitution chain);
 //   (d) the trailing update A22 -= L21 L21^T runs on the matrix cores from the LDS-resident panel, one 16 x 16
 //       tile per wave and trip, the next tile of A22 already in flight.
-__global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, int ld, double shift,
-                                              int32_t* __restrict__ info, double* __restrict__ min_pivot,
-                                              const double* __restrict__ src, int lds_src,
-                                              const double* __restrict__ shifts, double* __restrict__ xout) {
-    extern __shared__ double lds[];
-    if (src != nullptr) {                     // batched: copy the lower triangle into my slab first
-        A += (size_t)blockIdx.x * n * ld;
-        info += blockIdx.x;
-        if (min_pivot) min_pivot += blockIdx.x;
-        shift = shifts[blockIdx.x];
-        for (int i = threadIdx.x >> 6; i < n; i += CH_T / 64)
-            for (int j = threadIdx.x & 63; j <= i; j += 64) A[(size_t)i * ld + j] = src[(size_t)i * lds_src + j];
-        __threadfence_block();
-        __syncthreads();
-    }
+// (b) of k_chol, by ONE wave: Cholesky of the 32 x 32 diagonal block D (LDS, lower part, zero padded) in registers
+// (lane = row; pivots and multipliers are v_readlane broadcasts), L11 back to D, its inverse to Xs (and to xo).
+__device__ __forceinline__ void ch_diag_block(double* __restrict__ D, double* __restrict__ Xs, double* __restrict__ s_dinv,
+                                              int* __restrict__ s_fail_p, double* __restrict__ s_minp_p, int nb, int kb,
+                                              int lane, double* __restrict__ xout) {
     constexpr int LDP = CH_NB + 1;
-    double* D = lds;                         // NB x (NB+1): diagonal block / L11
-    double* Xs = lds + CH_NB * LDP;          // NB x (NB+1): L11^-1
-    constexpr int LDPP = CH_LDPP;
-    double* P = lds + 2 * CH_NB * LDP;       // (n - kb - nb) x LDPP panel
-    __shared__ int s_fail;
-    __shared__ double s_minp;
-    __shared__ double s_dinv[CH_NB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    if (tid == 0) { s_fail = 0; s_minp = __builtin_inf(); }
-    __syncthreads();
-#ifdef CH_STAMPS
-    long long st_t[5] = {0, 0, 0, 0, 0}, st_last = wall_clock64();
-#define CH_STAMP(K) { const long long now_ = wall_clock64(); st_t[K] += now_ - st_last; st_last = now_; }
-#else
-#define CH_STAMP(K)
-#endif
+    int& s_fail = *s_fail_p;
+    double& s_minp = *s_minp_p;
 
-    for (int kb = 0; kb < n; kb += CH_NB) {
-        const int nb = min(CH_NB, n - kb);
-        const int nr = n - kb - nb;                       // rows below the diagonal block
-        // ---- (a) diagonal block -> LDS (lower part), + shift; zero padded to 32 x 32
-#pragma unroll
-        for (int t = tid; t < CH_NB * CH_NB; t += CH_T) {
-            const int i = t >> 5, j = t & 31;
-            double v = (i < nb && j <= i) ? A[(size_t)(kb + i) * ld + kb + j] : 0.0;
-            if (i == j && i < nb) v += shift;
-            D[i * LDP + j] = v;
-        }
-        __syncthreads();
-        CH_STAMP(0)
-        // ---- (b) wave 0: Cholesky of D in registers, then its inverse
-        if (wave == 0) {
             const int i = lane;
             double d[CH_NB];
 #pragma unroll
@@ -107,7 +67,17 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
                     } else {
                         // multipliers through the reciprocal square root: one short dependent sequence per
                         // column instead of sqrt followed by a division (off-diagonal entries within 2 ulp)
-                        const double l = sqrt(djj), rinv = rsqrt(djj);
+                        // sqrt and 1/sqrt from ONE v_rsq_f64 seed + Newton steps (<= 1 ulp): the IEEE sqrt() and
+                        // rsqrt() sequences are ~60 dependent instructions on the critical path of every column
+                        double rinv = __builtin_amdgcn_rsq(djj);
+                        {
+                            double h = 0.5 * rinv, e = fma(-(djj * rinv), h, 0.5);
+                            rinv = fma(rinv, e, rinv);
+                            h = 0.5 * rinv; e = fma(-(djj * rinv), h, 0.5);
+                            rinv = fma(rinv, e, rinv);
+                        }
+                        double l = djj * rinv;
+                        l = fma(fma(-l, l, djj), 0.5 * rinv, l);
                         minp = fmin(minp, djj);
                         my_rinv = (i == j) ? rinv : my_rinv;
                         d[j] = (i == j) ? l : ((i > j) ? d[j] * rinv : 0.0);
@@ -152,8 +122,75 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
                 }
             }
         }
+
+// SMALL (n <= CH_SMALLN, one matrix): the matrix itself is staged into LDS and every phase works there -- the q x q Gram
+// matrices of CholeskyQR (q = batch - 1 ~ 100) spent most of their 86 us per call on global-memory round trips between
+// the phases of four panels, not on arithmetic.
+constexpr int CH_SMALLN = 120;      // 2 x 32 x 33 + (n - 32) x 36 + n (n + 1) doubles must fit in 160 KiB - 512
+template <bool SMALL>
+__global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, int ld, double shift,
+                                              int32_t* __restrict__ info, double* __restrict__ min_pivot,
+                                              const double* __restrict__ src, int lds_src,
+                                              const double* __restrict__ shifts, double* __restrict__ xout) {
+    extern __shared__ double lds[];
+    if (src != nullptr) {                     // batched: copy the lower triangle into my slab first
+        A += (size_t)blockIdx.x * n * ld;
+        info += blockIdx.x;
+        if (min_pivot) min_pivot += blockIdx.x;
+        shift = shifts[blockIdx.x];
+        for (int i = threadIdx.x >> 6; i < n; i += CH_T / 64)
+            for (int j = threadIdx.x & 63; j <= i; j += 64) A[(size_t)i * ld + j] = src[(size_t)i * lds_src + j];
+        __threadfence_block();
         __syncthreads();
-        CH_STAMP(1)
+    }
+    constexpr int LDP = CH_NB + 1;
+    double* D = lds;                         // NB x (NB+1): diagonal block / L11
+    double* Xs = lds + CH_NB * LDP;          // NB x (NB+1): L11^-1
+    constexpr int LDPP = CH_LDPP;
+    double* P = lds + 2 * CH_NB * LDP;       // (n - kb - nb) x LDPP panel
+    double* const A_glob = A;
+    const int ld_glob = ld;
+    if constexpr (SMALL) {                   // lower triangle -> LDS (odd row stride), and work there from here on
+        double* As = P + (size_t)(n > CH_NB ? n - CH_NB : 0) * LDPP;
+        for (int i = threadIdx.x >> 6; i < n; i += CH_T / 64)
+            for (int j = threadIdx.x & 63; j <= i; j += 64) As[i * (n + 1) + j] = A_glob[(size_t)i * ld_glob + j];
+        A = As;
+        ld = n + 1;
+    }
+    __shared__ int s_fail;
+    __shared__ double s_minp;
+    __shared__ double s_dinv[CH_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    if (tid == 0) { s_fail = 0; s_minp = __builtin_inf(); }
+    __syncthreads();
+#ifdef CH_STAMPS
+    long long st_t[5] = {0, 0, 0, 0, 0}, st_last = wall_clock64();
+#define CH_STAMP(K) { const long long now_ = wall_clock64(); st_t[K] += now_ - st_last; st_last = now_; }
+#else
+#define CH_STAMP(K)
+#endif
+
+    bool ahead = false;                                   // this panel's diagonal block was factorised by the previous (d)
+    for (int kb = 0; kb < n; kb += CH_NB) {
+        const int nb = min(CH_NB, n - kb);
+        const int nr = n - kb - nb;                       // rows below the diagonal block
+        if (!ahead) {
+            // ---- (a) diagonal block -> LDS (lower part), + shift; zero padded to 32 x 32
+#pragma unroll
+            for (int t = tid; t < CH_NB * CH_NB; t += CH_T) {
+                const int i = t >> 5, j = t & 31;
+                double v = (i < nb && j <= i) ? A[(size_t)(kb + i) * ld + kb + j] : 0.0;
+                if (i == j && i < nb) v += shift;
+                D[i * LDP + j] = v;
+            }
+            __syncthreads();
+            CH_STAMP(0)
+            // ---- (b) wave 0: Cholesky of D in registers, then its inverse
+            if (wave == 0) ch_diag_block(D, Xs, s_dinv, &s_fail, &s_minp, nb, kb, lane, xout);
+            __syncthreads();
+            CH_STAMP(1)
+        }
         if (s_fail != 0) break;                            // uniform
         // ---- write L_kk back
 #pragma unroll
@@ -214,19 +251,27 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
         // stores just issued are not waited for (loads and stores share vmcnt on gfx950).
         {
             const int nt = (nr + 15) / 16;                 // tiles per side
-            int ntr = 0, ntc = __builtin_amdgcn_readfirstlane(wave);       // cursor over this wave's tiles
+            // LOOK-AHEAD: wave 0 takes the (at most three) tiles of the NEXT diagonal block -- linear indices 0, 1, 2 --
+            // and then factorises that block (the ~13 us of (b): one wave's dependent chain) while waves 1..7 walk the
+            // rest of the update (linear index 3 + (wave - 1), + 7, ...); with fewer than 8 tiles there is nothing to hide
+            // behind and everybody walks as before.
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            const bool look = nt * (nt + 1) / 2 >= 8;
+            const int t_step = look ? (wv == 0 ? 1 : CH_T / 64 - 1) : CH_T / 64;
+            const int nt_mine = (look && wv == 0) ? min(nt, 2) : nt;       // wave 0 stops after tile row 1
+            int ntr = 0, ntc = look ? (wv == 0 ? 0 : 2 + wv) : wv;         // cursor over this wave's tiles
             while (ntc > ntr) { ntc -= ntr + 1; ++ntr; }
             int tr[CH_G], tc[CH_G], trn[CH_G], tcn[CH_G];
             double cv[CH_G][4], cn[CH_G][4];
             double* const a22 = A + (size_t)(kb + nb) * ld + kb + nb;
 #define CH_TAKE(R, C)                                                       \
-            { R = ntr; C = ntc; ntc += CH_T / 64; while (ntc > ntr) { ntc -= ntr + 1; ++ntr; } }
+            { R = ntr; C = ntc; ntc += t_step; while (ntc > ntr) { ntc -= ntr + 1; ++ntr; } }
 #define CH_LOAD(DST, R, C)                                                  \
             _Pragma("unroll") for (int e = 0; e < 4; ++e)                   \
                 DST[e] = a22[(size_t)min((R) * 16 + lk + 4 * e, nr - 1) * ld + min((C) * 16 + li, nr - 1)];
 #pragma unroll
             for (int g = 0; g < CH_G; ++g) { CH_TAKE(tr[g], tc[g]) CH_LOAD(cv[g], tr[g], tc[g]) }
-            while (tr[0] < nt) {
+            while (tr[0] < nt_mine) {
 #pragma unroll
                 for (int g = 0; g < CH_G; ++g) { CH_TAKE(trn[g], tcn[g]) CH_LOAD(cn[g], trn[g], tcn[g]) }
                 ch_double4 acc[CH_G][2];
@@ -248,7 +293,7 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int row = tr[g] * 16 + lk + 4 * e, col = tc[g] * 16 + li;
-                        double* dst = (row < nr && col <= row) ? a22 + (size_t)row * ld + col : ch_sink + tid;
+                        double* dst = (row < nr && col <= row && tr[g] < nt_mine) ? a22 + (size_t)row * ld + col : ch_sink + tid;
                         *dst = cv[g][e] - (acc[g][0][e] + acc[g][1][e]);
                     }
                 }
@@ -261,6 +306,22 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
             }
 #undef CH_TAKE
 #undef CH_LOAD
+            if (look && wave == 0) {
+                // the next diagonal block is final (my own stores: wait for them), so (a) and (b) of the next panel
+                // happen here, beside the other waves' share of the update
+                __builtin_amdgcn_s_waitcnt(0);
+                const int kb2 = kb + nb, nb2 = min(CH_NB, n - kb2);
+#pragma unroll
+                for (int t = lane; t < CH_NB * CH_NB; t += 64) {
+                    const int i = t >> 5, j = t & 31;
+                    double v = (i < nb2 && j <= i) ? A[(size_t)(kb2 + i) * ld + kb2 + j] : 0.0;
+                    if (i == j && i < nb2) v += shift;
+                    D[i * LDP + j] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                ch_diag_block(D, Xs, s_dinv, &s_fail, &s_minp, nb2, kb2, lane, xout);
+            }
+            ahead = look;
         }
         __threadfence_block();
         __syncthreads();
@@ -270,6 +331,11 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
     if (tid == 0 && n >= 16)                               // debugging build: ticks (100 MHz) in row 0's upper triangle
         for (int k = 0; k < 4; ++k) A[8 + k] = (double)st_t[k];
 #endif
+    if constexpr (SMALL) {                   // L back to the caller's matrix (rows finished before a failure included)
+        __syncthreads();
+        for (int i = tid >> 6; i < n; i += CH_T / 64)
+            for (int j = tid & 63; j <= i; j += 64) A_glob[(size_t)i * ld_glob + j] = A[i * (n + 1) + j];
+    }
     if (tid == 0) {
         *info = s_fail;
         if (min_pivot) *min_pivot = s_minp;
@@ -416,15 +482,23 @@ extern "C" int sober_cholesky_inv(double* A, int n, int ld, double shift, int32_
     if (!A || !info || n <= 0 || ld < n) return SOBER_E_ARG;
     if (n > sober::CH_MAXN) return SOBER_E_DIM;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
-    const size_t bytes = ((size_t)2 * sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * sober::CH_LDPP) * sizeof(double);
+    size_t bytes = ((size_t)2 * sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * sober::CH_LDPP) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 512));
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 512));
         attr_set = true;
     }
-    hipLaunchKernelGGL(sober::k_chol, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift, info,
-                       min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv);
+    if (n <= sober::CH_SMALLN) {
+        bytes += (size_t)n * (n + 1) * sizeof(double);
+        hipLaunchKernelGGL(sober::k_chol<true>, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift,
+                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv);
+    } else {
+        hipLaunchKernelGGL(sober::k_chol<false>, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift,
+                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv);
+    }
     LAUNCH_CHECK();
     return 0;
 }
@@ -465,9 +539,9 @@ extern "C" int sober_cholesky_probe_piv(const double* src, int n, int ld_src, co
     if (n > sober::CH_MAXN) return SOBER_E_DIM;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
     const size_t bytes = ((size_t)2 * sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * sober::CH_LDPP) * sizeof(double);
-    HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 512));
-    hipLaunchKernelGGL(sober::k_chol, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
+    hipLaunchKernelGGL(sober::k_chol<false>, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
                        info, min_pivot, src, ld_src, shifts, (double*)nullptr);
     LAUNCH_CHECK();
     return 0;

