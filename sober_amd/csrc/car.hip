@@ -28,6 +28,8 @@
 // steps (N <= 448, m <= 256: batch <= 224) to the multi-CU kernels of car_mc.hip; beyond those the engine takes the
 // host LAPACK route (sober_car_pivot_host).
 #include "common.hpp"
+#include <atomic>
+#include <cstdlib>
 
 namespace sober {
 
@@ -149,6 +151,36 @@ __device__ __forceinline__ void amin_take(double& best, int& piv, double ob, int
 }
 
 
+// ---- publishing the reflectors while the bidiagonalisation runs (fused launch, see k_car_bidiag_fused) ----------
+// A double travels as one 16-byte granule {lo, tag, hi, tag} written by ONE store; readers poll the granule itself
+// with L1-bypassing loads and accept it when both tags carry (epoch, reflector) -- no fence, no flag (the protocol of
+// car_mc.hip, where it is measured).  Producer and consumers sit on the same XCD, so the stores are plain ones.
+typedef unsigned int car_u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t car_rsrc_t;
+constexpr unsigned CARF_ERR = 0, CARF_XCD = 16, CARF_TICKET = 32, CARF_PROGRESS = 48;     // byte offsets in the comm block
+__host__ __device__ constexpr int64_t carf_bytes(int) { return 64; }
+constexpr unsigned CARF_SPIN_LIMIT = 1u << 22;
+__device__ __forceinline__ void carf_put(car_rsrc_t rs, unsigned off, double v, unsigned tag) {
+    car_u32x4 g;
+    g.x = (unsigned)__double2loint(v); g.y = tag; g.z = (unsigned)__double2hiint(v); g.w = tag;
+    __builtin_amdgcn_raw_buffer_store_b128(g, rs, off, 0, 0);
+}
+__device__ __forceinline__ car_u32x4 carf_load(car_rsrc_t rs, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);                    // sc1: past this CU's L1
+}
+__device__ __forceinline__ bool carf_ok(const car_u32x4& g, unsigned tag) { return (g.y == tag) & (g.w == tag); }
+__device__ __forceinline__ double carf_val(const car_u32x4& g) { return __hiloint2double((int)g.z, (int)g.x); }
+struct CarPub { car_rsrc_t rs; unsigned tag0; };
+// "reflectors 0 .. k-1 are complete in memory": the wave that STORED reflector k-1 says so one step later, when its
+// stores have long been acknowledged (the wait below is then free) -- nothing is added to the chain of the step itself
+__device__ __forceinline__ void car_publish_progress(const CarPub& pub, int k) {
+    const int tid = threadIdx.x;
+    if (k > 0 && (tid >> 6) == (((k - 1) & 15) >> 2)) {                // (wave-uniform: the wave of DPP row (k-1) & 15)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0) only
+        if ((tid & 63) == 0) __builtin_amdgcn_raw_buffer_store_b32(pub.tag0 + (unsigned)k, pub.rs, CARF_PROGRESS, 0, 0);
+    }
+}
+
 // ---------------- phase 1: Golub-Kahan bidiagonalisation (dgebd2, m < N), matrix in VGPRs ----------------
 // Thread (R = tid >> 4, C = tid & 15) holds A[R + 16 k][C + 16 q], k < 7, q < 13.
 // per step: (A) the owner DPP row builds G(i), publishes v~ (LDS + global)                         | barrier
@@ -176,9 +208,9 @@ struct CarLds {
 #define CB_FLUSH(S_) do { } while (0)
 #endif
 
-template <int S>
+template <int S, bool FUSED>
 __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], int m, const CarLds& L,
-                                                 double* __restrict__ vws, double* __restrict__ taup) {
+                                                 double* __restrict__ vws, double* __restrict__ taup, const CarPub& pub) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int R = tid >> 4, C = tid & 15;
     const int i_end = min(16 * S + 16, m);
@@ -186,6 +218,7 @@ __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], in
     for (int i = 16 * S; i < i_end; ++i) {
         CB_STAMP(0);
         const int li = i & 15;                               // row i: DPP row li, slot S; column i: lane li, slot S
+        if constexpr (FUSED) car_publish_progress(pub, i);   // reflector i - 1 is complete in memory by now
         if (R == li) {                                                 // (A)
             double ss0 = 0.0, ss1 = 0.0;
             {
@@ -294,8 +327,9 @@ __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], in
     CB_FLUSH(S);
 }
 
-__global__ __launch_bounds__(CAR_BT) void k_car_bidiag(const double* __restrict__ X, int ldx, int N, int m,
-                                                       double* __restrict__ vws, double* __restrict__ taup) {
+template <bool FUSED>
+__device__ __forceinline__ void car_bidiag_body(const double* __restrict__ X, int ldx, int N, int m,
+                                                double* __restrict__ vws, double* __restrict__ taup, const CarPub& pub) {
     __shared__ double vbuf[CAR_NS];
     __shared__ double colb[128];
     __shared__ double zsum[CAR_NS];
@@ -314,13 +348,138 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag(const double* __restrict_
     if (tid < 128) colb[tid] = 0.0;
     __syncthreads();
     const CarLds L{vbuf, colb, zsum, zpart, scal};
-    car_bidiag_block<0>(a, m, L, vws, taup);
-    if (m > 16) car_bidiag_block<1>(a, m, L, vws, taup);
-    if (m > 32) car_bidiag_block<2>(a, m, L, vws, taup);
-    if (m > 48) car_bidiag_block<3>(a, m, L, vws, taup);
-    if (m > 64) car_bidiag_block<4>(a, m, L, vws, taup);
-    if (m > 80) car_bidiag_block<5>(a, m, L, vws, taup);
-    if (m > 96) car_bidiag_block<6>(a, m, L, vws, taup);
+    car_bidiag_block<0, FUSED>(a, m, L, vws, taup, pub);
+    if (m > 16) car_bidiag_block<1, FUSED>(a, m, L, vws, taup, pub);
+    if (m > 32) car_bidiag_block<2, FUSED>(a, m, L, vws, taup, pub);
+    if (m > 48) car_bidiag_block<3, FUSED>(a, m, L, vws, taup, pub);
+    if (m > 64) car_bidiag_block<4, FUSED>(a, m, L, vws, taup, pub);
+    if (m > 80) car_bidiag_block<5, FUSED>(a, m, L, vws, taup, pub);
+    if (m > 96) car_bidiag_block<6, FUSED>(a, m, L, vws, taup, pub);
+}
+
+__global__ __launch_bounds__(CAR_BT) void k_car_bidiag(const double* __restrict__ X, int ldx, int N, int m,
+                                                       double* __restrict__ vws, double* __restrict__ taup) {
+    car_bidiag_body<false>(X, ldx, N, m, vws, taup, CarPub{});
+}
+
+// ---------------- phases 1 + 2 in one launch ----------------
+// Phi = G(0) ... G(m-1) [0; I] is also the last N - m columns of P = G(0) G(1) ... G(m-1) accumulated FORWARD, and in
+// that order every ROW of P is independent: p <- p - tau (p . v) v^T as each reflector appears.  So the 24 us that
+// k_car_phi spent after the bidiagonalisation (100 dependent steps per column, on an otherwise idle chip) move BESIDE
+// it: workgroup 0 is the bidiagonalisation and publishes every reflector as tagged granules; the other workgroups
+// that find themselves on ITS XCD (hardware id; the rest exit at once) take tickets for groups of four rows, one wave
+// per row, and follow the reflectors as they appear -- one step behind the producer, finished ~1 us after it.
+// Tags carry an epoch (one per launch), so nothing has to be cleared between launches; spins are bounded (error word:
+// k_car_pivot then reports n_keep = -1, the engine's signal for the host route).
+__global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __restrict__ X, int ldx, int N, int m,
+                                                             double* __restrict__ vws, double* __restrict__ taup,
+                                                             double* __restrict__ Phi, void* __restrict__ comm,
+                                                             unsigned cbytes, unsigned epoch) {
+    const car_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
+    const unsigned tag0 = epoch << 7;                                  // (m <= 112 < 128)
+    unsigned* words = (unsigned*)comm;
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;       // HW_REG_XCC_ID
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(words + CARF_ERR / 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(words + CARF_TICKET / 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(words + CARF_XCD / 4, (epoch << 4) | (xcc + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const CarPub pub{rs, tag0};
+        car_bidiag_body<true>(X, ldx, N, m, vws, taup, pub);
+        __syncthreads();
+        car_publish_progress(pub, m);                                  // the last reflector (this time the wait is real)
+        return;
+    }
+    // ---- consumers ----
+    __shared__ int s_group;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        unsigned spins = 0, w;
+        int grp = -1;
+        while (((w = __hip_atomic_load(words + CARF_XCD / 4, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 4) != epoch) {
+            if (++spins > CARF_SPIN_LIMIT) { w = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if ((w & 15u) == xcc + 1u) grp = 0;                            // on the producer's XCD: a worker
+        s_group = grp;
+    }
+    __syncthreads();
+    if (s_group < 0) return;
+    const int NC = N - m;
+    // TWO rows per wave, eight per workgroup: the launch's register budget is the producer's (one workgroup per CU), and
+    // the 26 row groups must all be resident on the ~31 free CUs of the producer's XCD while it runs
+    constexpr int RW = 2;
+    constexpr int n_groups = CAR_NS / (4 * RW);
+    for (;;) {
+        __syncthreads();
+        if (tid == 0)
+            s_group = (int)__hip_atomic_fetch_add(words + CARF_TICKET / 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int grp = s_group;
+        if (grp >= n_groups) return;
+        const int r0 = (4 * grp + wave) * RW;                          // my rows of P: r0, r0 + 1 (wave-uniform)
+        double p[RW][4];
+#pragma unroll
+        for (int w = 0; w < RW; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p[w][q] = (lane + 64 * q == r0 + w) ? 1.0 : 0.0;
+        const bool ok3 = lane + 192 < CAR_NS;
+        bool failed = false;
+        if (r0 < N) {
+            const car_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(vws, 0, (int)((size_t)(m * CAR_NS + 128) * sizeof(double)), 0x00020000);
+            int have = 0;                                              // reflectors known to be complete
+            for (int i = 0; i < m; ++i) {
+                unsigned spins = 0;
+                while (have <= i) {                                    // (one broadcast load per poll)
+                    const unsigned w = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, CARF_PROGRESS, 0, 16);
+                    if ((w >> 7) == epoch) have = (int)(w & 127u);
+                    if (have > i) break;
+                    if (++spins > CARF_SPIN_LIMIT ||
+                        ((spins & 255u) == 0u && __builtin_amdgcn_raw_buffer_load_b32(rs, CARF_ERR, 0, 16) != 0)) {
+                        __builtin_amdgcn_raw_buffer_store_b32(1, rs, CARF_ERR, 0, 16);
+                        failed = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                if (failed) break;
+                // (sc1 loads: tau's cache line also holds taus that are not written yet -- never through this CU's L1)
+                const unsigned base = (unsigned)(i * CAR_NS) * 8u;
+                double vv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const auto g2 = __builtin_amdgcn_raw_buffer_load_b64(rv, base + (unsigned)min(lane + 64 * q, CAR_NS - 1) * 8u, 0, 16);
+                    vv[q] = __hiloint2double((int)g2[1], (int)g2[0]);
+                }
+                const auto gt2 = __builtin_amdgcn_raw_buffer_load_b64(rv, (unsigned)(m * CAR_NS + i) * 8u, 0, 16);
+                const double tau = __hiloint2double((int)gt2[1], (int)gt2[0]);
+                const double v0 = vv[0], v1 = vv[1], v2 = vv[2], v3 = ok3 ? vv[3] : 0.0;
+                double d[RW];
+#pragma unroll
+                for (int w = 0; w < RW; ++w) d[w] = fma(v0, p[w][0], v1 * p[w][1]) + fma(v2, p[w][2], v3 * p[w][3]);
+#pragma unroll
+                for (int w = 0; w < RW; ++w) {
+                    const double t = tau * wave_sum(d[w]);
+                    p[w][0] = fma(-t, v0, p[w][0]); p[w][1] = fma(-t, v1, p[w][1]);
+                    p[w][2] = fma(-t, v2, p[w][2]); p[w][3] = fma(-t, v3, p[w][3]);
+                }
+            }
+        }
+        // rows of Phi: the last N - m entries of the rows of P, zero padded to CAR_PC columns (rows >= N: zeros)
+#pragma unroll
+        for (int w = 0; w < RW; ++w) {
+            const int r = r0 + w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = lane + 64 * q;                           // column of P
+                const int col = c - m;
+                if (c < CAR_NS && col >= 0 && col < CAR_PC) Phi[(size_t)r * CAR_PC + col] = (r < N && col < NC) ? p[w][q] : 0.0;
+            }
+            // (columns beyond what the lanes above cover)
+            for (int col = max(CAR_NS - m, 0) + lane; col < CAR_PC; col += 64) Phi[(size_t)r * CAR_PC + col] = 0.0;
+        }
+    }
 }
 
 // ---------------- phase 2: Phi = G(0) ... G(m-1) [0; I]  (N x NC) ----------------
@@ -424,7 +583,12 @@ __global__ __launch_bounds__(CAR_PW * 64) void k_car_pivot(const double* __restr
                                                            int32_t* __restrict__ keep_rank,
                                                            double* __restrict__ w_star,
                                                            int32_t* __restrict__ n_keep_out,
-                                                           double* __restrict__ mu_out) {
+                                                           double* __restrict__ mu_out,
+                                                           const unsigned* __restrict__ err) {
+    if (err != nullptr && *err != 0u) {    // the fused launch in front gave up on a reflector (bounded spins): no result
+        if (threadIdx.x == 0) *n_keep_out = -1;
+        return;
+    }
     __shared__ double colbuf[2 * 256];     // current / next pivot column (zero beyond N)
     __shared__ double pscal[2 * 4];        // (alpha, piv, 1/Phi[piv,0]) of the current / next step
     __shared__ double mubuf[256];          // the weights after the last finished update; -0.0 marks a dead row
@@ -727,7 +891,8 @@ extern "C" int sober_car_supported(int N, int m) {
 // scratch: reflectors (m x 208), tau (m, padded to 128), Phi (208 x 128)
 // (a workspace sized for (N, m) also serves every (N' <= N, m): the final direct level)
 extern "C" int64_t sober_car_ws_bytes(int N, int m) {
-    const int64_t one = ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC + 512) * (int64_t)sizeof(double);   // (+512: stamp block)
+    const int64_t one = ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC + 512) * (int64_t)sizeof(double)   // (+512: stamp block)
+                        + sober::carf_bytes(m);                                       // + the fused launch's granules
     if (car_one_cu(N, m)) return one;
     const int64_t mc = sober_car_mc_ws_bytes(N, m);
     return mc > one ? mc : one;
@@ -744,12 +909,28 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
     double* vws = (double*)ws;
     double* taup = vws + (size_t)m * sober::CAR_NS;
     double* Phi = taup + 128;
-    hipLaunchKernelGGL(sober::k_car_bidiag, dim3(1), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(sober::k_car_phi, dim3(sober::CAR_PC / 4), dim3(256), 0, st, vws, taup, N, m, Phi, phi_out);
+    static const bool unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;                // (A/B switch)
+    if (phi_out != nullptr || unfused) {
+        hipLaunchKernelGGL(sober::k_car_bidiag, dim3(1), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(sober::k_car_phi, dim3(sober::CAR_PC / 4), dim3(256), 0, st, vws, taup, N, m, Phi, phi_out);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(sober::k_car_pivot, dim3(1), dim3(sober::CAR_PW * 64), 0, st, Phi, N, m, mu_in, keep_rank,
+                           w_star, n_keep, mu_out, (const unsigned*)nullptr);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    // bidiagonalisation and Phi in ONE launch: workgroup 0 produces the reflectors, the workgroups that land on its XCD
+    // (an eighth of the rest: 26 are needed, 40 are offered) accumulate the rows of Phi as the reflectors appear
+    static std::atomic<unsigned> epoch_ctr{0};
+    const unsigned epoch = (epoch_ctr.fetch_add(1) + 1u) & 0x1FFFFFFu;
+    void* comm = (void*)(Phi + (size_t)sober::CAR_NS * sober::CAR_PC + 512);
+    static const int per_xcd = getenv("SOBER_CARF_PER_XCD") ? atoi(getenv("SOBER_CARF_PER_XCD")) : 40;    // (tuning aid)
+    hipLaunchKernelGGL(sober::k_car_bidiag_fused, dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup, Phi, comm,
+                       (unsigned)sober::carf_bytes(m), epoch);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(sober::k_car_pivot, dim3(1), dim3(sober::CAR_PW * 64), 0, st, Phi, N, m, mu_in, keep_rank, w_star,
-                       n_keep, mu_out);
+                       n_keep, mu_out, (const unsigned*)comm);
     LAUNCH_CHECK();
     return 0;
 }
