@@ -29,6 +29,7 @@
 // The communication area is zeroed by a hipMemsetAsync ahead of the launches of EVERY call; all spins are bounded
 // (a give-up writes an error word that makes the step report n_keep = -1).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace sober {
 namespace mc {
@@ -44,6 +45,11 @@ constexpr int PWAVES = 32;            // waves of the pivot kernel: N - m <= 256
 constexpr int KMAX = BC * PWAVES;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr int ELECT_GRID = 128;       // workgroups launched per kernel: some XCD gets >= 16 of them whatever the placement
+constexpr int FUSED_GRID = 8 * 32;    // bidiagonalisation + Phi in one launch: ONE workgroup per CU (forced by an LDS request that
+                                      // two do not fit: a producer that shares its SIMDs slows all nine down) -- on the winning
+                                      // XCD 9 producers and 23 consumers
+constexpr int FUSED_LDS_PAD = 88 * 1024;
+constexpr int PHI_RW = 5;             // rows of P per consumer wave (20 per workgroup: 23 groups for 448 rows)
 constexpr int DBG_WORDS = 8192;       // stamp block at the end of the workspace (diagnostic build)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -53,7 +59,9 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr unsigned OFF_ERR = 0;                                   // error word (+ padding)
 constexpr unsigned OFF_EL_B = 16;                                 // election of the bidiagonalisation: count[8], winner
 constexpr unsigned OFF_EL_P = 64;                                 // election of the pivot kernel: count[8], winner
-constexpr unsigned OFF_Q = 128;                                   // [2][GMAX][256] granules: per-CU partial row dots
+constexpr unsigned OFF_PROG = 128;                                // [GMAX] dwords: reflectors < k of this producer workgroup are in memory
+constexpr unsigned OFF_TICKET = 176;                              // row-group tickets of the Phi consumers (fused launch)
+constexpr unsigned OFF_Q = 192;                                   // [2][GMAX][256] granules: per-CU partial row dots
 constexpr unsigned OFF_C = OFF_Q + 2u * GMAX * 256u * 16u;        // [2][256]: column i
 constexpr unsigned OFF_S = OFF_C + 2u * 256u * 16u;               // [2][16]: per-CU partial |row_i|^2
 constexpr unsigned OFF_H = OFF_S + 2u * 16u * 16u;                // [KMAX][4]: pivot headers (alpha, 1/pivot, index)
@@ -193,6 +201,25 @@ __device__ __forceinline__ int elect(void* comm, unsigned base, int n, rsrc_t rs
     return (w == xcc + 1u) ? (int)t : -1;
 }
 
+// The same election for a launch in which the losers of the winning XCD stay on as CONSUMERS: -1 = exit (another
+// XCD), 0 .. n-1 = worker, >= n = consumer number (ticket - n).  Called by thread 0.
+__device__ __forceinline__ int elect_all(void* comm, unsigned base, int n, rsrc_t rs) {
+    unsigned* cnt = (unsigned*)((char*)comm + base);
+    unsigned* win = cnt + 8;
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;       // HW_REG_XCC_ID
+    const unsigned t = __hip_atomic_fetch_add(cnt + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (unsigned)n - 1u) {
+        unsigned expect = 0u;
+        __hip_atomic_compare_exchange_strong(win, &expect, xcc + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned spins = 0, w;
+    while ((w = __hip_atomic_load(win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+        if (spin_fail(rs, spins, 0x10u)) return -1;
+    }
+    return (w == xcc + 1u) ? (int)t : -1;
+}
+
 // in-kernel stamps (diagnostic build only, `make stamps`): per-segment cycle sums of every wave -> the debug block
 // at the end of the workspace, which nothing else reads
 #ifdef MC_STAMPS
@@ -220,6 +247,7 @@ struct BidiagLds {
     double lss[4];
     double lsc[2];                // |row_i|^2, A[i][i] after the exchange
     int ldead;
+    int lgrp;                     // row group of a Phi consumer
 };
 
 // BODY(j) for the live register slots j = 0 .. nlive-1, written out (an early exit inside `#pragma unroll` keeps the
@@ -243,6 +271,9 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], double (&r)[C
     MC_STAMP_DECL
     for (int i = 64 * SL; i < i_end; ++i) {
         MC_STAMP(0);
+#ifndef MC_X_NOWAIT
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): my entries of reflector i - 1 are in memory (stored a step ago: free)
+#endif
         const int li = i & 63;
         const unsigned tag = (unsigned)i + 1u;
         const unsigned par = (unsigned)i & 1u;
@@ -282,6 +313,9 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], double (&r)[C
         }
         MC_LDS_BARRIER();
         MC_STAMP(2);
+#ifndef MC_X_NOPROG
+        if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32((unsigned)i, rs, OFF_PROG + 4u * (unsigned)cu, 0, 0);   // (all four waves are past their wait)
+#endif
         // ---- 3. the exchange: thread t > i owns row t (publishes this CU's partial q_t, gathers the nine partials
         //         and column i's entry), thread i carries the partial norms in the slot of the (finished) row i and
         //         the diagonal entry A[i][i]; measured forms: scripts/xcd_exchange_probe.hip
@@ -414,18 +448,109 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], double (&r)[C
     return true;
 }
 
+// Phi beside the bidiagonalisation (fused launch): Phi = the last N - m columns of P = G(0) G(1) ... G(m-1) accumulated
+// FORWARD, where every ROW of P is independent: p <- p - tau (p . v) v^T as each reflector appears.  A consumer wave
+// holds PHI_RW rows, follows the nine producers' progress words (one line, one load per poll) and reads the reflectors
+// past its CU's L1.  PhiT[col][row] like k_mc_phi.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v);        // (phase 3 below)
+template <class LDS>
+__device__ __forceinline__ void phi_rows(const double* __restrict__ vws, int N, int m, double* __restrict__ PhiT,
+                                         void* comm, rsrc_t rs, LDS& L) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = N - m;
+    const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vws, 0, (int)(((size_t)64 * RS_MAX * NS + 256) * sizeof(double)), 0x00020000);
+    const unsigned tau_off = (unsigned)((size_t)64 * RS_MAX * NS * sizeof(double));
+    unsigned* ticket = (unsigned*)((char*)comm + OFF_TICKET);
+    constexpr int n_groups = (NS + 4 * PHI_RW - 1) / (4 * PHI_RW);
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) L.lgrp = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int grp = L.lgrp;
+        if (grp >= n_groups) return;
+        const int r0 = (4 * grp + wv) * PHI_RW;
+        double p[PHI_RW][NQ];
+#pragma unroll
+        for (int w = 0; w < PHI_RW; ++w)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) p[w][q] = (lane + 64 * q == r0 + w) ? 1.0 : 0.0;
+        if (r0 < N) {
+            int have = 0;
+            bool failed = false;
+            for (int i = 0; i < m && !failed; ++i) {
+                unsigned spins = 0;
+                while (have <= i) {
+                    const unsigned pw = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, OFF_PROG + 4u * (unsigned)min(lane, GMAX - 1), 0, 16);
+                    have = (int)wave_min_u32(pw);
+                    if (have > i) break;
+                    if (spin_fail(rs, spins, 0x400u + (unsigned)i)) { failed = true; break; }
+                    // (poll gently: the producers' exchange runs through the same L2 and is latency-bound, while a
+                    //  consumer has ~3 us per reflector to spare)
+                    __builtin_amdgcn_s_sleep(24);
+                }
+                if (failed) break;
+                double v[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const auto g2 = __builtin_amdgcn_raw_buffer_load_b64(rv, (unsigned)(i * NS + lane + 64 * q) * 8u, 0, 16);
+                    const double x = __hiloint2double((int)g2[1], (int)g2[0]);
+                    const int c = lane + 64 * q;
+                    v[q] = (c > i && c < N) ? x : ((c == i) ? 1.0 : 0.0);
+                }
+                const auto gt2 = __builtin_amdgcn_raw_buffer_load_b64(rv, tau_off + (unsigned)i * 8u, 0, 16);
+                const double tau = __hiloint2double((int)gt2[1], (int)gt2[0]);
+                double d[PHI_RW];
+#pragma unroll
+                for (int w = 0; w < PHI_RW; ++w) {
+                    d[w] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) d[w] = fma(v[q], p[w][q], d[w]);
+                }
+#pragma unroll
+                for (int w = 0; w < PHI_RW; ++w) {
+                    const double t = tau * wave_allsum(d[w]);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) p[w][q] = fma(-t, v[q], p[w][q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < PHI_RW; ++w) {
+            const int r = r0 + w;
+            if (r >= NS) continue;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int col = lane + 64 * q - m;
+#ifndef MC_X_NOSTORE
+                if (col >= 0 && col < K) PhiT[(size_t)col * NS + r] = (r < N) ? p[w][q] : 0.0;
+#else
+                if (col >= 0 && col < K && p[w][q] == 123.456) PhiT[(size_t)col * NS + r] = 0.0;
+#endif
+            }
+        }
+    }
+}
+
 template <int RS>
 __global__ __launch_bounds__(256) void k_mc_bidiag(const double* __restrict__ X, int ldx, int N, int m,
                                                    double* __restrict__ vws, double* __restrict__ taup, void* comm,
-                                                   unsigned cbytes, unsigned long long* dbg) {
+                                                   unsigned cbytes, unsigned long long* dbg, double* __restrict__ PhiT,
+                                                   int fused) {
     __shared__ BidiagLds<RS> L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
-    if (tid == 0) L.ldead = elect(comm, OFF_EL_B, GMAX, rs);
+    if (tid == 0) L.ldead = fused ? elect_all(comm, OFF_EL_B, GMAX, rs) : elect(comm, OFF_EL_B, GMAX, rs);
     __syncthreads();
     const int cu = __builtin_amdgcn_readfirstlane(L.ldead);
     if (cu < 0) return;
+    if (cu >= GMAX) {                                               // (fused launch) a consumer: rows of Phi
+#ifndef MC_X_NOCONSUMERS
+        phi_rows(vws, N, m, PhiT, comm, rs, L);
+#endif
+        return;
+    }
     __syncthreads();
     const int gw = cu * 4 + wv;
     double a[CPW][RS], r[CPW];
@@ -444,6 +569,10 @@ __global__ __launch_bounds__(256) void k_mc_bidiag(const double* __restrict__ X,
     if constexpr (RS > 1) { if (ok && m > 64) ok = bidiag_steps<RS, 1>(a, r, m, gw, cu, wv, L, rs, vws, taup, dbg); }
     if constexpr (RS > 2) { if (ok && m > 128) ok = bidiag_steps<RS, 2>(a, r, m, gw, cu, wv, L, rs, vws, taup, dbg); }
     if constexpr (RS > 3) { if (ok && m > 192) ok = bidiag_steps<RS, 3>(a, r, m, gw, cu, wv, L, rs, vws, taup, dbg); }
+    // the last reflector (this time the wait for the stores is a real one)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (ok && tid == 0) __builtin_amdgcn_raw_buffer_store_b32((unsigned)m, rs, OFF_PROG + 4u * (unsigned)cu, 0, 0);
 }
 
 // ================================================================================================================
@@ -814,23 +943,35 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
     double* PhiT = taup + 256;
     unsigned long long* dbg = (unsigned long long*)(PhiT + (size_t)KMAX * NS);
     HIP_TRY(hipMemsetAsync(ws, 0, (size_t)cbytes, st));
-    const int G = ELECT_GRID;
+    static const bool unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;                // (A/B switch)
+    const int fused = (phi_out == nullptr && !unfused) ? 1 : 0;
+    const int G = fused ? FUSED_GRID : ELECT_GRID;
+    const size_t pad = fused ? (size_t)FUSED_LDS_PAD : 0;             // (dynamic LDS nobody touches: one workgroup per CU)
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_mc_bidiag<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_PAD));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_mc_bidiag<3>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_PAD));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_mc_bidiag<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_PAD));
+        attr_set = true;
+    }
     const int RS = (m + 63) / 64;
     switch (RS) {
         case 1:
         case 2:
-            hipLaunchKernelGGL(k_mc_bidiag<2>, dim3(G), dim3(256), 0, st, X, ldx, N, m, vws, taup, ws, cbytes, dbg);
+            hipLaunchKernelGGL(k_mc_bidiag<2>, dim3(G), dim3(256), pad, st, X, ldx, N, m, vws, taup, ws, cbytes, dbg, PhiT, fused);
             break;
         case 3:
-            hipLaunchKernelGGL(k_mc_bidiag<3>, dim3(G), dim3(256), 0, st, X, ldx, N, m, vws, taup, ws, cbytes, dbg);
+            hipLaunchKernelGGL(k_mc_bidiag<3>, dim3(G), dim3(256), pad, st, X, ldx, N, m, vws, taup, ws, cbytes, dbg, PhiT, fused);
             break;
         default:
-            hipLaunchKernelGGL(k_mc_bidiag<4>, dim3(G), dim3(256), 0, st, X, ldx, N, m, vws, taup, ws, cbytes, dbg);
+            hipLaunchKernelGGL(k_mc_bidiag<4>, dim3(G), dim3(256), pad, st, X, ldx, N, m, vws, taup, ws, cbytes, dbg, PhiT, fused);
             break;
     }
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_mc_phi, dim3((K + 3) / 4), dim3(256), 0, st, vws, taup, N, m, PhiT, phi_out);
-    LAUNCH_CHECK();
+    if (!fused) {
+        hipLaunchKernelGGL(k_mc_phi, dim3((K + 3) / 4), dim3(256), 0, st, vws, taup, N, m, PhiT, phi_out);
+        LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_mc_pivot, dim3(ELECT_GRID), dim3(256), 0, st, PhiT, N, m, mu_in, keep_rank, w_star, n_keep,
                        mu_out, ws, cbytes, dbg);
     LAUNCH_CHECK();
