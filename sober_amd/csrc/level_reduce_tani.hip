@@ -36,21 +36,22 @@ __device__ __forceinline__ int4_t expand16(unsigned bits) {
     return r;
 }
 
-// (dot + eps) / (|x| + |y| - dot + eps) with a Newton-refined reciprocal (<= 1 ulp of the IEEE quotient, a third of its
-// instructions: eight quotients per lane and element are the vector unit's main load here); denominator >= eps > 0
-__device__ __forceinline__ double tani_fast(double dot, double nx, double ny, double os) {
+// (dot + eps) / (|x| + |y| - dot + eps): reciprocal seed + ONE Newton step (relative error ~2^-50), quotient, and one
+// correction step with the exact residual -- within 1 ulp of the IEEE quotient at a third of its instructions (four
+// quotients per lane and element are the vector unit's main arithmetic here).  Numerator and denominator are positive
+// (eps > 0), so the reference's clamp_min_(0) (SOBER/_drug_modelling.py:37) never acts; the output scale is folded into
+// the candidate's weight when the tile is staged.
+__device__ __forceinline__ double tani_fast(double dot, double nx, double ny) {
     const double eps = 1e-6;
     const double den = ((eps + nx) + ny) - dot;
     double r = __builtin_amdgcn_rcp(den);
     r = fma(fma(-den, r, 1.0), r, r);
-    r = fma(fma(-den, r, 1.0), r, r);
     const double num = dot + eps;
-    double q = num * r;
-    q = fma(fma(-q, den, num), r, q);
-    return fmax(q, 0.0) * os;
+    const double q = num * r;
+    return fma(fma(-q, den, num), r, q);
 }
 
-#ifdef TANI_X_NOEXPAND
+#ifdef TANI_X_NOEXPAND      /* timing experiments only (scripts/tani_where.sh): results are wrong */
 #define LT_EXPAND(x) ((int4_t){(int)(x), (int)(x), (int)(x), (int)(x)})
 #else
 #define LT_EXPAND(x) expand16(x)
@@ -113,64 +114,56 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[t][v] = 0.0;
 
-    // staging of one tile (TE elements of 16 consecutive list positions each): thread -> UPT 16-bit units.  The address
-    // chain idx -> candidate words is two global round trips, so the indices are fetched TWO tiles ahead and the words
-    // ONE ahead; every load is unconditional (clamped position, masked afterwards) so that the compiler counts
-    // outstanding loads instead of draining them; expansion and LDS writes follow the current tile's MFMAs.
-    // Positions are 32-bit offsets into this launch's index list (count < 2^31).
-    static_assert(UNITS % NTH == 0, "every thread stages the same number of units");
+    // staging of one tile (TE elements of 16 consecutive list positions each).  TPC = 16 threads share a candidate:
+    // ONE list position, one validity flag and one base address per thread and tile, then UPT 16-bit units of that
+    // candidate at fixed strides (unit j * TPC + cp: word 4 j + cp / 4, quarter cp % 4) -- loads and LDS writes with
+    // immediate offsets.  (A first form spread a thread's units over UPT different candidates: their positions, flags
+    // and addresses were more than half of the kernel's instruction stream.)  The address chain idx -> candidate words is
+    // two global round trips, so the index is fetched TWO tiles ahead and the words ONE ahead; every load is
+    // unconditional (clamped position, masked afterwards) so that the compiler counts outstanding loads instead of
+    // draining them; expansion and LDS writes follow the current tile's MFMAs.  Positions are 32-bit offsets into this
+    // launch's index list (count < 2^31).
+    constexpr int TPC = NTH / NC;                      // threads per candidate
+    static_assert(NTH % NC == 0 && TPC % 4 == 0 && (DT * 4) % TPC == 0 && UPT == DT * 4 / TPC, "unit map");
     unsigned long long stw[UPT];
-    int cpre[UPT], cpre_w = 0;
-    bool okw[UPT];
-    double tot_acc = 0.0, m_raw = 0.0, wm_raw = 0.0, ny_raw = 0.0;
+    int cpre = 0;
     bool ok_w = false, ok_t = false;
+    double tot_acc = 0.0, m_raw = 0.0, wm_raw = 0.0, ny_raw = 0.0;
     const double* wm_ptr = wmul ? wmul : mu;
     const int cnt32 = (int)count;
     const int rel0 = (int)(e_first * S + s0 - pos0);                   // list offset of (element 0, set s0)
     const int tl32 = (int)min(tot_limit - pos0, (int64_t)0x7fffffff);
-    // unit u of this thread: candidate q = (tid + 256 u) / (4 DT) of the tile (element q / SB, set s0 + q % SB)
-    int uq_e[UPT], uq_s[UPT], uq_w[UPT];
-#pragma unroll
-    for (int u = 0; u < UPT; ++u) {
-        const int unit = tid + NTH * u, q = unit / (4 * DT);
-        uq_e[u] = q / SB; uq_s[u] = q % SB; uq_w[u] = (unit / 4) % DT;
-    }
-    const int wq_e = (tid & (NC - 1)) / SB, wq_s = (tid & (NC - 1)) % SB;
-#define LT_REL(e_, qe_, qs_, R, OK)                                                        \
-    const int R = rel0 + ((e_) + (qe_)) * S + (qs_);                                       \
-    const bool OK = (s0 + (qs_) < S) & ((e_) + (qe_) < e1) & (R >= 0) & (R < cnt32);
+    const int cq = tid / TPC, cp = tid % TPC;                           // my candidate of the tile, my share of it
+    const int qe = cq / SB, qs = cq % SB;
+    const int wsel = cp / 4, part = cp % 4;
+    const bool qs_ok = s0 + qs < S;
+    unsigned char* const wr_base = &s_b[0][0] + cq * ROWB + wsel * 64 + part * 16;
+#define LT_REL(e_, R, OK)                                                                  \
+    const int R = rel0 + ((e_) + qe) * S + qs;                                             \
+    const bool OK = qs_ok & ((e_) + qe < e1) & (R >= 0) & (R < cnt32);
 #define LT_PREFETCH_IDX(e_)                                                                \
     {                                                                                      \
-        _Pragma("unroll") for (int u = 0; u < UPT; ++u) {                                  \
-            LT_REL(e_, uq_e[u], uq_s[u], r_, okp_)                                         \
-            cpre[u] = idx[okp_ ? r_ : 0];                                                  \
-        }                                                                                  \
-        LT_REL(e_, wq_e, wq_s, rw_, okq_)                                                  \
-        cpre_w = idx[okq_ ? rw_ : 0];                                                      \
+        LT_REL(e_, r_, okp_)                                                               \
+        cpre = idx[okp_ ? r_ : 0];                                                         \
     }
 #define LT_STAGE_LOAD(e_)                                                                  \
     {                                                                                      \
-        _Pragma("unroll") for (int u = 0; u < UPT; ++u) {                                  \
-            LT_REL(e_, uq_e[u], uq_s[u], r_, okl_)                                         \
-            okw[u] = okl_;                                                                 \
-            stw[u] = cand[(size_t)(okl_ ? cpre[u] : 0) * DT + uq_w[u]];                    \
-        }                                                                                  \
-        LT_REL(e_, wq_e, wq_s, rv_, okv_)                                                  \
-        const int cw_ = okv_ ? cpre_w : 0;                                                 \
-        m_raw = mu[cw_]; wm_raw = wm_ptr[cw_]; ny_raw = cand_norm[cw_];                    \
-        ok_w = okv_; ok_t = okv_ & (rv_ < tl32);                                           \
+        LT_REL(e_, r_, okl_)                                                               \
+        const int c_ = okl_ ? cpre : 0;                                                    \
+        const unsigned long long* src_ = cand + (size_t)c_ * DT + wsel;                    \
+        _Pragma("unroll") for (int u = 0; u < UPT; ++u) stw[u] = src_[u * (TPC / 4)];      \
+        m_raw = mu[c_]; wm_raw = wm_ptr[c_]; ny_raw = cand_norm[c_];                       \
+        ok_w = okl_; ok_t = okl_ & (r_ < tl32);                                            \
     }
 #define LT_STAGE_WRITE(buf_)                                                               \
     {                                                                                      \
-        _Pragma("unroll") for (int u = 0; u < UPT; ++u) {                                  \
-            const int unit = tid + NTH * u;                                                \
-            const int q = unit / (4 * DT), part = unit & 3;                                \
-            *(int4_t*)(&s_b[buf_][q * ROWB + uq_w[u] * 64 + part * 16]) =                  \
-                LT_EXPAND(okw[u] ? (unsigned)(stw[u] >> (16 * part)) & 0xFFFFu : 0u);      \
-        }                                                                                  \
-        if (tid < NC) {                                                                    \
-            s_w[buf_][tid] = ok_w ? (wmul ? m_raw * wm_raw : m_raw) : 0.0;                 \
-            s_ny[buf_][tid] = ok_w ? ny_raw : 0.0;                                         \
+        unsigned char* dst_ = wr_base + (buf_) * (NC * ROWB);                              \
+        _Pragma("unroll") for (int u = 0; u < UPT; ++u)                                    \
+            *(int4_t*)(dst_ + u * (TPC / 4) * 64) =                                        \
+                LT_EXPAND(ok_w ? (unsigned)(stw[u] >> (16 * part)) & 0xFFFFu : 0u);        \
+        if (cp == 0) {                                                                     \
+            s_w[buf_][cq] = ok_w ? (wmul ? m_raw * wm_raw : m_raw) * os : 0.0;             \
+            s_ny[buf_][cq] = ok_w ? ny_raw : 0.0;                                          \
             tot_acc += ok_t ? m_raw : 0.0;                                                 \
         }                                                                                  \
     }
@@ -188,25 +181,48 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
         LT_PREFETCH_IDX(e + 2 * TE)
         const int te_cnt = rows_live ? min(TE, e1 - e) : 0;
         for (int te = 0; te < te_cnt; ++te) {
-            int4_t cc[LT_RT];
+            // B fragments LT_BD k-steps ahead of their MFMAs and two accumulators per tile: with a single accumulator and
+            // the compiler's own order (two reads, wait, two dependent MFMAs) an element was a chain of 16 LDS round trips
+            int4_t cc[LT_RT], cd[LT_RT];
 #pragma unroll
-            for (int t = 0; t < LT_RT; ++t) cc[t] = (int4_t){0, 0, 0, 0};
+            for (int t = 0; t < LT_RT; ++t) { cc[t] = (int4_t){0, 0, 0, 0}; cd[t] = cc[t]; }
+            __builtin_amdgcn_sched_barrier(0);
             const unsigned char* bp = &s_b[buf][(te * SB + lj) * ROWB + lk * 16];
+            constexpr int LT_BD = 8;
+            int4_t bq[LT_BD];
+#pragma unroll
+            for (int j = 0; j < LT_BD && j < DT; ++j) bq[j] = *(const int4_t*)(bp + j * 64);
 #pragma unroll
             for (int ks = 0; ks < DT; ++ks) {
 #ifdef TANI_X_NODSREAD          /* timing experiments only (scripts/tani_where.sh): results are wrong */
                 const int4_t bfr = afr[0][(ks + 1) % DT];
 #else
-                const int4_t bfr = *(const int4_t*)(bp + ks * 64);
+                const int4_t bfr = bq[ks % LT_BD];
+                if (ks + LT_BD < DT) bq[ks % LT_BD] = *(const int4_t*)(bp + (ks + LT_BD) * 64);
 #endif
 #pragma unroll
                 for (int t = 0; t < LT_RT; ++t)
 #ifdef TANI_X_NOMFMA
                     cc[t] += bfr;
 #else
-                    cc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[t][ks], bfr, cc[t], 0, 0, 0);
+                {
+                    if (ks & 1) cd[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[t][ks], bfr, cd[t], 0, 0, 0);
+                    else cc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[t][ks], bfr, cc[t], 0, 0, 0);
+                }
 #endif
             }
+            // (the scheduler would pull every read back to just in front of its MFMA: pin the order -- LT_BD reads, then
+            //  one MFMA per further read)
+            __builtin_amdgcn_sched_group_barrier(0x100, LT_BD, 0);
+#pragma unroll
+            for (int ks = 0; ks < DT - LT_BD; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, LT_RT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, LT_RT * LT_BD, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < LT_RT; ++t) cc[t] += cd[t];
             const double w = s_w[buf][te * SB + lj], ny = s_ny[buf][te * SB + lj];
 #pragma unroll
             for (int t = 0; t < LT_RT; ++t)
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
 #ifdef TANI_X_NOQUOT
                     acc[t][v] = fma((double)cc[t][v] + ny, w, acc[t][v]);
 #else
-                    acc[t][v] = fma(tani_fast((double)cc[t][v], nxr[t][v], ny, os), w, acc[t][v]);
+                    acc[t][v] = fma(tani_fast((double)cc[t][v], nxr[t][v], ny), w, acc[t][v]);
 #endif
         }
         LT_STAGE_WRITE(buf ^ 1)
@@ -238,7 +254,7 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     }
     if (partTot != nullptr && blockIdx.z == 0) {
         __syncthreads();
-        if (tid < NC) s_w[0][tid] = tot_acc;                            // (the weight buffers are free now)
+        if (cp == 0) s_w[0][cq] = tot_acc;                              // (the weight buffers are free now)
         __syncthreads();
         if (tid < SB && s0 + tid < S) {
             double tt = 0.0;
