@@ -426,8 +426,10 @@ def abs_sym(C_, out, flag):
 def kmeans_lloyd(X, K, iters, centroids, labels):
     N, d = X.shape
     _req(X, torch.float64, "X"); _req(centroids, torch.float64, "centroids"); _req(labels, torch.int32, "labels")
+    nbytes = int(load().sober_kmeans_ws_bytes(N, d, K))
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=X.device)     # cluster sizes, sorted order, sort scratch
     _check(load().sober_kmeans_lloyd(X.data_ptr(), N, d, K, iters, centroids.data_ptr(), labels.data_ptr(),
-                                     None, 0, _stream(X)), "sober_kmeans_lloyd")
+                                     ws.data_ptr(), nbytes, _stream(X)), "sober_kmeans_lloyd")
 
 
 def predict_finish(KX, V, mean, kxx_const, norms, outputscale, noise, var_out, eta=0.0, lfi_out=None, log=False):
