@@ -225,6 +225,10 @@ int sober_cholesky(double* A, int n, int ld, double shift, int32_t* info, double
  * blocks of L (identity-padded in the last block) -- the operands of sober_trsm_blocks.                       */
 int sober_cholesky_inv(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, double* xinv,
                        void* stream);
+/* The same, also leaving *ratio_out = smallest pivot / largest diagonal entry of the input (~cond^-2 of a Gram matrix:
+ * what decides whether one CholeskyQR pass is enough) -- on the device, no reduction kernels around the call. */
+int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, double* xinv,
+                             double* ratio_out, void* stream);
 /* Q[r, 0:q] = Y[r, 0:q] L^-T (L lower triangular q x q, q <= 256: the Q factor of Y when L L^T = Y^T Y), blocked
  * on the matrix cores with the inverted diagonal blocks of sober_cholesky_inv: block-to-block dependency only.                                                          */
 int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl, const double* Xinv,

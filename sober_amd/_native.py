@@ -61,6 +61,7 @@ SIGNATURES = {
     "sober_chol_max_n": (_i32, []),
     "sober_cholesky": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp]),
     "sober_cholesky_inv": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
+    "sober_cholesky_inv_ratio": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp]),
     "sober_trsm_blocks": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sober_cholesky_probe": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_cholesky_probe_piv": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
@@ -395,13 +396,14 @@ def cholesky(A, shift, info, min_pivot=None):
                                  _stream(A)), "sober_cholesky")
 
 
-def cholesky_inv(A, shift, info, min_pivot, xinv):
-    """cholesky() that also leaves the inverted 32 x 32 diagonal blocks of L in xinv (ceil(n/32) * 1024 doubles)."""
+def cholesky_inv(A, shift, info, min_pivot, xinv, ratio=None):
+    """cholesky() that also leaves the inverted 32 x 32 diagonal blocks of L in xinv (ceil(n/32) * 1024 doubles) and,
+    with `ratio`, smallest pivot / largest diagonal entry of the input there."""
     n = A.shape[0]
     if xinv.numel() < ((n + 31) // 32) * 1024:
         raise SoberHipError("cholesky_inv: xinv too small")
-    _check(load().sober_cholesky_inv(A.data_ptr(), n, A.stride(0), float(shift), info.data_ptr(), _ptr(min_pivot),
-                                     xinv.data_ptr(), _stream(A)), "sober_cholesky_inv")
+    _check(load().sober_cholesky_inv_ratio(A.data_ptr(), n, A.stride(0), float(shift), info.data_ptr(), _ptr(min_pivot),
+                                           xinv.data_ptr(), _ptr(ratio), _stream(A)), "sober_cholesky_inv")
 
 
 def trsm_blocks(Y, L, xinv, Q):

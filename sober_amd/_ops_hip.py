@@ -217,14 +217,13 @@ class HipOps:
         for it in range(passes):
             Gm = torch.empty(q, q, dtype=torch.float64, device=self.device)
             nat.dgemm(Y, Y, Gm, transa=True)
-            dmax = Gm.diagonal().amax() if passes == 1 else None
             # one-workgroup blocked Cholesky, in place; it leaves the inverted 32 x 32 diagonal blocks behind,
-            # which turn Q = Y R^-1 into block-to-block MFMA work (sober_trsm_blocks)
+            # which turn Q = Y R^-1 into block-to-block MFMA work (sober_trsm_blocks) -- and, for a single pass,
+            # min pivot / max diagonal of the Gram matrix in pivs[slot + 1]
             Lc = Gm
             xinv = torch.empty(((q + 31) // 32) * 1024, dtype=torch.float64, device=self.device)
-            nat.cholesky_inv(Lc, 0.0, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1], xinv)
-            if passes == 1:
-                pivs[slot + 1] = pivs[slot] / dmax
+            nat.cholesky_inv(Lc, 0.0, infos[slot + it:slot + it + 1], pivs[slot + it:slot + it + 1], xinv,
+                             ratio=pivs[slot + 1:slot + 2] if passes == 1 else None)
             Q = torch.empty_like(Y)
             nat.trsm_blocks(Y, Lc, xinv, Q)                     # Q = Y R^-1
             Y = Q

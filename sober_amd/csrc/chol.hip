@@ -131,7 +131,8 @@ template <bool SMALL>
 __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, int ld, double shift,
                                               int32_t* __restrict__ info, double* __restrict__ min_pivot,
                                               const double* __restrict__ src, int lds_src,
-                                              const double* __restrict__ shifts, double* __restrict__ xout) {
+                                              const double* __restrict__ shifts, double* __restrict__ xout,
+                                              double* __restrict__ ratio_out) {
     extern __shared__ double lds[];
     if (src != nullptr) {                     // batched: copy the lower triangle into my slab first
         A += (size_t)blockIdx.x * n * ld;
@@ -163,6 +164,15 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     if (tid == 0) { s_fail = 0; s_minp = __builtin_inf(); }
+    // largest diagonal entry of the input (ratio_out = smallest pivot / this: ~cond^-2 for a Gram matrix)
+    __shared__ double s_dm[CH_T / 64];
+    if (ratio_out != nullptr) {
+        double dl = -__builtin_inf();
+        for (int i = tid; i < n; i += CH_T) dl = fmax(dl, A_glob[(size_t)i * ld_glob + i] + shift);   // (the caller's matrix: the LDS copy is not synchronised yet)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dl = fmax(dl, __shfl_xor(dl, o, 64));
+        if (lane == 0) s_dm[wave] = dl;
+    }
     __syncthreads();
 #ifdef CH_STAMPS
     long long st_t[5] = {0, 0, 0, 0, 0}, st_last = wall_clock64();
@@ -339,6 +349,12 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
     if (tid == 0) {
         *info = s_fail;
         if (min_pivot) *min_pivot = s_minp;
+        if (ratio_out) {
+            double dm = s_dm[0];
+#pragma unroll
+            for (int w = 1; w < CH_T / 64; ++w) dm = fmax(dm, s_dm[w]);
+            *ratio_out = s_minp / dm;
+        }
     }
 }
 
@@ -477,8 +493,15 @@ __global__ void k_jitter_ladder_auto(double* __restrict__ A, int n, int ld, cons
 
 extern "C" int sober_chol_max_n(void) { return sober::CH_MAXN; }
 
+extern "C" int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
+                                        double* xinv, double* ratio_out, void* stream);
 extern "C" int sober_cholesky_inv(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
                                   double* xinv, void* stream) {
+    return sober_cholesky_inv_ratio(A, n, ld, shift, info, min_pivot, xinv, nullptr, stream);
+}
+
+extern "C" int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
+                                        double* xinv, double* ratio_out, void* stream) {
     if (!A || !info || n <= 0 || ld < n) return SOBER_E_ARG;
     if (n > sober::CH_MAXN) return SOBER_E_DIM;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
@@ -494,10 +517,10 @@ extern "C" int sober_cholesky_inv(double* A, int n, int ld, double shift, int32_
     if (n <= sober::CH_SMALLN) {
         bytes += (size_t)n * (n + 1) * sizeof(double);
         hipLaunchKernelGGL(sober::k_chol<true>, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift,
-                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv);
+                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv, ratio_out);
     } else {
         hipLaunchKernelGGL(sober::k_chol<false>, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift,
-                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv);
+                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv, ratio_out);
     }
     LAUNCH_CHECK();
     return 0;
@@ -542,7 +565,7 @@ extern "C" int sober_cholesky_probe_piv(const double* src, int n, int ld_src, co
     HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 512));
     hipLaunchKernelGGL(sober::k_chol<false>, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
-                       info, min_pivot, src, ld_src, shifts, (double*)nullptr);
+                       info, min_pivot, src, ld_src, shifts, (double*)nullptr, (double*)nullptr);
     LAUNCH_CHECK();
     return 0;
 }
