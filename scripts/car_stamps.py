@@ -1,6 +1,7 @@
 """Where a bidiagonalisation step of the one-CU Caratheodory kernel (csrc/car.hip) spends its cycles: run with the
 stamp build (`make -C sober_amd/csrc stamps`, SOBER_HIP_LIB=sober_amd/csrc/build/libsober_hip_stamps.so)."""
 import os, sys
+os.environ.setdefault("SOBER_CAR_UNFUSED", "1")     # the stamps live in the stand-alone bidiagonalisation kernel
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sober_amd import _native as nat

@@ -175,9 +175,6 @@ class HipOps:
         # than they hide) and enqueueing the first level's set sums in front of the draw (their host-side set-up delays
         # the draw itself).  Should the input turn out exactly symmetric (is_psd(cov) itself has to run, on the host) or
         # the range finder lose rank, the generator is put back and the literal host route decides.
-        if overlap is not None and os.environ.get("SOBER_EARLY_SUMS"):      # (measured: +0.2 ms at cfg-2, see above)
-            overlap()
-            overlap = None
         rng_state = torch.get_rng_state()
         R = torch.randn(M, s, dtype=torch.float64)
         U, (flags_h, piv_h) = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=(flags, pivots), plan=p)
