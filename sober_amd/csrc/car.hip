@@ -806,6 +806,220 @@ __global__ __launch_bounds__(CAR_PW * 64) void k_car_pivot(const double* __restr
 }
 
 
+// ---------------- phase 3, streaming form ----------------
+// The same pivots without a workgroup barrier per pivot (the design of car_mc.hip's k_mc_pivot, through LDS instead of
+// L2).  A wave owns SP_BC CONSECUTIVE columns and keeps its own copy of the weights.  While a column of its block is the
+// pivot column it runs the ratio test on its registers, publishes (column, index, alpha, 1/pivot) in an LDS ring and goes
+// straight on to its next column -- seven of eight pivots need no hand-over at all; every other wave applies the
+// published pivots to its columns as they arrive, at low priority, in the issue slots the owner's dependent chain
+// leaves empty.  k_car_pivot above rotates the ownership with every pivot (column c -> wave c mod 16): one barrier,
+// one hand-over of the weights and one LDS round trip of the pivot column per pivot, 1.14 us each.
+constexpr int SP_W = 16, SP_BC = 7, SP_RING = 32;
+struct SpSlot { double col[256]; double alpha, rpp; int piv; int tag; };
+struct SpState { double mu[4]; bool dead[4], inr[4]; };
+
+__device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpState& st, int& piv, double& al, double& rp) {
+    double rt[4], rc[4];
+    unsigned kh[4], kl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { rt[q] = st.mu[q] / col[q]; rc[q] = 1.0 / col[q]; }
+    unsigned hmin = 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned long long k = ratio_key(rt[q]);
+        const bool ok = st.inr[q] & (col[q] > 0.0) & !st.dead[q];
+        kh[q] = ok ? (unsigned)(k >> 32) : 0xffffffffu;
+        kl[q] = ok ? (unsigned)k : 0xffffffffu;
+        hmin = min(hmin, kh[q]);
+    }
+    const unsigned H = wave_min_u32(hmin);
+    piv = -1; al = 0.0; rp = 1.0;
+    if (H == 0xffffffffu) return;                                     // uniform: no candidate (:241-242)
+    unsigned long long mb[4];
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mb[q] = __ballot(kh[q] == H); cnt += __popcll(mb[q]); }
+    if (cnt != 1) {                                                   // rare: several quotients share the high word
+        unsigned lmin = 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lmin = min(lmin, (kh[q] == H) ? kl[q] : 0xffffffffu);
+        const unsigned Lw = wave_min_u32(lmin);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mb[q] = __ballot((kh[q] == H) & (kl[q] == Lw));
+    }
+    bool found = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!found && mb[q] != 0ull) {                                // uniform
+            const int f = __ffsll((long long)mb[q]) - 1;
+            piv = f + 64 * q;
+            al = rdlane(rt[q], f);
+            rp = rdlane(rc[q], f);
+            found = true;
+        }
+    }
+}
+// mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (two roundings like the tensor expression, :253-254)
+__device__ __forceinline__ void sp_mu_step(SpState& st, const double (&col)[4], double alpha, int piv, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        st.dead[q] = st.dead[q] | (lane + 64 * q == piv);
+        st.mu[q] = st.dead[q] ? 0.0 : __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q]));
+    }
+}
+//   Phi[:, c] -= Phi[:, 0] * (Phi[idx, c] / Phi[idx, 0])   (:260-266), my columns J0 .. SP_BC-1
+template <int KP, int J0>
+__device__ __forceinline__ void sp_elim_kp(double (&phi)[SP_BC][4], const double (&col)[4], int lp, double rpp) {
+#pragma unroll
+    for (int j = J0; j < SP_BC; ++j) {
+        const double qv = rdlane(phi[j][KP], lp) * rpp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) phi[j][q] = fma(-qv, col[q], phi[j][q]);
+    }
+}
+template <int J0>
+__device__ __forceinline__ void sp_elim(double (&phi)[SP_BC][4], const double (&col)[4], int piv, double rpp) {
+    const int kp = piv >> 6, lp = piv & 63;
+    switch (kp) {                                                     // uniform
+        case 0: sp_elim_kp<0, J0>(phi, col, lp, rpp); break;
+        case 1: sp_elim_kp<1, J0>(phi, col, lp, rpp); break;
+        case 2: sp_elim_kp<2, J0>(phi, col, lp, rpp); break;
+        default: sp_elim_kp<3, J0>(phi, col, lp, rpp); break;
+    }
+}
+// wait for pivot s in the ring; false = give up (bounded)
+__device__ __forceinline__ bool sp_consume(SpSlot* ring, int s, int lane, double (&col)[4], double& alpha, double& rpp, int& piv) {
+    SpSlot& e = ring[s % SP_RING];
+    volatile int* tg = &e.tag;
+    unsigned spins = 0;
+    while (*tg != s + 1) {
+        if (++spins > (1u << 24)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    alpha = e.alpha; rpp = e.rpp; piv = e.piv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) col[q] = e.col[lane + 64 * q];
+    return true;
+}
+
+__global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __restrict__ Phi, int N, int m,
+                                                                const double* __restrict__ mu_in,
+                                                                int32_t* __restrict__ keep_rank,
+                                                                double* __restrict__ w_star,
+                                                                int32_t* __restrict__ n_keep_out,
+                                                                double* __restrict__ mu_out,
+                                                                const unsigned* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
+    SpSlot* ring = (SpSlot*)sp_lds;
+    volatile int* prog = (volatile int*)(sp_lds + sizeof(SpSlot) * SP_RING);    // [SP_W]: pivots consumed so far
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = N - m;
+    const int c0 = w * SP_BC;
+    if (tid < SP_RING) ring[tid].tag = 0;
+    if (tid < SP_W) prog[tid] = 0;
+    const bool broken = err != nullptr && *err != 0u;                 // the fused launch in front gave up on a reflector
+    __syncthreads();                                                  // (the only workgroup barrier)
+    if (broken) { if (tid == 0) *n_keep_out = -1; return; }
+    if (c0 >= K && w != 0) return;
+    double phi[SP_BC][4];
+    SpState st;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = lane + 64 * q;
+        st.inr[q] = row < N;
+        st.dead[q] = false;
+        st.mu[q] = st.inr[q] ? mu_in[row] + 0.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < SP_BC; ++j)
+            phi[j][q] = (c0 + j < K && row < N) ? Phi[(size_t)row * CAR_PC + c0 + j] : 0.0;
+    }
+    bool fail = false, stop = false;
+    double col[4] = {0.0, 0.0, 0.0, 0.0};
+    // the pivots before my block: apply them to all my columns as they arrive
+    const int s_mine = min(c0, K);
+    for (int s = 0; s < s_mine && !fail && !stop; ++s) {
+        double al, rp;
+        int piv;
+        if (!sp_consume(ring, s, lane, col, al, rp, piv)) { fail = true; break; }
+        if (lane == 0) prog[w] = s + 1;
+        if (piv < 0) { stop = true; break; }
+        sp_mu_step(st, col, al, piv, lane);
+        sp_elim<0>(phi, col, piv, rp);
+    }
+    // my block
+    if (!fail && !stop && c0 < K) {
+        __builtin_amdgcn_s_setprio(3);                                // the critical chain of the whole kernel
+        const int s_end = min(c0 + SP_BC, K);
+        // a ring slot is reused SP_RING pivots later: everybody who still follows must be past what I overwrite
+        if (s_end > SP_RING) {
+            const int need = s_end - SP_RING;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                for (int o = 0; o < SP_W; ++o) {
+                    const bool follows = (o > w && o * SP_BC < K) || (o == 0 && w != 0);
+                    if (follows && prog[o] < need) ok = false;
+                }
+                if (ok) break;
+                if (++spins > (1u << 22)) { fail = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        for (int sp = c0; sp < s_end && !fail && !stop; ++sp) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[0][q];
+            int piv;
+            double al, rp;
+            sp_ratio_test(col, st, piv, al, rp);
+            SpSlot& e = ring[sp % SP_RING];
+            if (piv >= 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e.col[lane + 64 * q] = col[q];
+            }
+            if (lane == 0) { e.alpha = al; e.rpp = rp; e.piv = piv; }
+            asm volatile("" ::: "memory");                            // (program order; a wave's LDS operations execute in order:
+            if (lane == 0) *(volatile int*)&e.tag = sp + 1;           //  the tag lands after the data it releases -- no wait)
+            if (piv < 0) { stop = true; break; }                      // Q6: the loop ends here (:241-242)
+            sp_mu_step(st, col, al, piv, lane);
+            sp_elim<1>(phi, col, piv, rp);                            // (consumed slots hold zeros and stay zero)
+#pragma unroll
+            for (int j = 0; j + 1 < SP_BC; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) phi[j][q] = phi[j + 1][q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) phi[SP_BC - 1][q] = 0.0;
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    if (w != 0) return;
+    // wave 0 follows the remaining pivots for the weights and writes the result
+    for (int s = c0 + SP_BC; s < K && !fail && !stop; ++s) {
+        double al, rp;
+        int piv;
+        if (!sp_consume(ring, s, lane, col, al, rp, piv)) { fail = true; break; }
+        if (lane == 0) prog[0] = s + 1;
+        if (piv < 0) { stop = true; break; }
+        sp_mu_step(st, col, al, piv, lane);
+    }
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = lane + 64 * q;
+        const double v = (row < N) ? st.mu[q] + 0.0 : 0.0;           // -0.0 -> +0.0
+        const bool keep = (row < N) && (v > 0.0);
+        const unsigned long long bal = __ballot(keep);
+        const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (row < N) {
+            keep_rank[row] = keep ? rank : -1;
+            mu_out[row] = v;
+            if (keep) w_star[rank] = v;
+        }
+        base += __popcll(bal);
+    }
+    if (lane == 0) *n_keep_out = fail ? -1 : base;
+}
+
 // ---------------- the extra elimination of the acquisition-guided branch (SOBER/_rchq.py:87-106, :177-196) ----------
 // After the Caratheodory step with one more test function (the objective), n1 = b + 1 points are left; their
 // weights move along the null vector w_null of [X_p; 1] (functions x points, a 1-dimensional null space) in the
@@ -909,14 +1123,28 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
     double* vws = (double*)ws;
     double* taup = vws + (size_t)m * sober::CAR_NS;
     double* Phi = taup + 128;
-    static const bool unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;                // (A/B switch)
+    static const bool unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;                // (A/B switches)
+    static const bool barrier_pivot = getenv("SOBER_CAR_PIVOT_BARRIER") != nullptr;
+    const size_t sp_bytes = sizeof(sober::SpSlot) * sober::SP_RING + sober::SP_W * sizeof(int);
+    static bool sp_attr = false;
+    if (!sp_attr) {
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_stream, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sp_bytes));
+        sp_attr = true;
+    }
+#define CAR_LAUNCH_PIVOT(ERR)                                                                                          \
+    if (barrier_pivot)                                                                                                 \
+        hipLaunchKernelGGL(sober::k_car_pivot, dim3(1), dim3(sober::CAR_PW * 64), 0, st, Phi, N, m, mu_in, keep_rank,   \
+                           w_star, n_keep, mu_out, (const unsigned*)(ERR));                                            \
+    else                                                                                                               \
+        hipLaunchKernelGGL(sober::k_car_pivot_stream, dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m, mu_in,  \
+                           keep_rank, w_star, n_keep, mu_out, (const unsigned*)(ERR));
     if (phi_out != nullptr || unfused) {
         hipLaunchKernelGGL(sober::k_car_bidiag, dim3(1), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(sober::k_car_phi, dim3(sober::CAR_PC / 4), dim3(256), 0, st, vws, taup, N, m, Phi, phi_out);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(sober::k_car_pivot, dim3(1), dim3(sober::CAR_PW * 64), 0, st, Phi, N, m, mu_in, keep_rank,
-                           w_star, n_keep, mu_out, (const unsigned*)nullptr);
+        CAR_LAUNCH_PIVOT(nullptr)
         LAUNCH_CHECK();
         return 0;
     }
@@ -929,10 +1157,10 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
     hipLaunchKernelGGL(sober::k_car_bidiag_fused, dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup, Phi, comm,
                        (unsigned)sober::carf_bytes(m), epoch);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(sober::k_car_pivot, dim3(1), dim3(sober::CAR_PW * 64), 0, st, Phi, N, m, mu_in, keep_rank, w_star,
-                       n_keep, mu_out, (const unsigned*)comm);
+    CAR_LAUNCH_PIVOT(comm)
     LAUNCH_CHECK();
     return 0;
+#undef CAR_LAUNCH_PIVOT
 }
 
 extern "C" int sober_second_elimination(const double* phi, const double* objp, const double* w1, const int32_t* rank1,
