@@ -224,7 +224,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # dominant kernel: HIP-event time of every level-reduction launch in the timed region, minus the
+    # dominant kernel: HIP-event time of every level's MAIN reduction launch in the timed region (the leftover launch
+    # behind it -- at most S - 1 positions, ~3.6 us, 0.1 % of the kernel's work -- is not bracketed: a hipEventRecord
+    # costs the stream ~5 us, and four per level were 0.1 ms of the step), minus the
     # cost of an empty event pair on the same stream (calibrated here; ~5 us, comparable to the deep
     # levels' launches -- without it the event sum would not agree with rocprofv3's kernel durations)
     prof, ops.prof = ops.prof, None
@@ -237,8 +239,9 @@ def main():
         nat.record_event_pair(e0, e1, st); cal.append((e0, e1))
     torch.cuda.synchronize()
     ev_overhead = float(np.median([a.elapsed_time(b_) for a, b_ in cal]))
-    kern_ms = sum(max(a.elapsed_time(b_) - ev_overhead, 0.0) for a, b_, _ in prof)
-    entries = sum(e for _, _, e in prof)
+    kern_ms = sum(max(a.elapsed_time(b_) - ev_overhead, 0.0) for a, b_, _, _ in prof)
+    entries = sum(e for _, _, e, _ in prof)
+    n_launches = sum(n for _, _, _, n in prof)
 
     # the step together with the Nystrom subsample that precedes it in the reference's funnel for a continuous
     # prior (kmeans_resampling, SOBER/_weights.py:95-126, SOBER/_sampler.py:316-320); outside the timed region
@@ -276,7 +279,7 @@ def main():
         tops = entries * 2 * bits / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         roofline = {"bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tops / INT8_PEAK_TOPS,
                     "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(args.config) if world == 1 else None,
-                    "kernel": "k_level_reduce_tani", "launches": len(prof),
+                    "kernel": "k_level_reduce_tani", "launches": n_launches,
                     "kernel_ms_per_step": kern_ms / args.steps, "event_pair_overhead_ms": ev_overhead,
                     "note": "bit-packed fingerprints, bits expanded to bytes in LDS, v_mfma_i32_16x16x64_i8 (integer "
                             "operations counted in the TFLOP/s unit); the matrix pipe, the LDS (fragment reads + the "
@@ -288,7 +291,7 @@ def main():
         roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS,
                     "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(args.config) if world == 1 else None,
-                    "kernel": "k_level_reduce_wave", "launches": len(prof), "kernel_ms_per_step": kern_ms / args.steps,
+                    "kernel": "k_level_reduce_wave", "launches": n_launches, "kernel_ms_per_step": kern_ms / args.steps,
                     "event_pair_overhead_ms": ev_overhead,
                     "note": "FP64 compute-bound: -|x-y|^2/2 on v_mfma_f64_16x16x4 (augmented GEMM), "
                             "table-driven FP64 exp on the VALU; MI355X FP64 vector and matrix peaks are "
@@ -297,7 +300,8 @@ def main():
                             "FP64 load is ~1.9 GHz (scripts/dp_rate_probe.hip: 63 TFLOP/s MFMA-only, "
                             "61 FMA-only) -- the kernel is bound by its instruction count; "
                             f"algorithmic flop = entries * (2d+2+C_k) = entries * {flop_per_entry}; all "
-                            "launches of a step are averaged (level 0 alone runs ~1.35x the average)"}
+                            "main launches of a step are averaged (level 0 alone runs ~1.35x the average); the leftover launches "
+                            "(<= S-1 positions each) are not timed"}
     strong = bool(cfg.get("strong"))
     n_rec = str(cfg["N"]) if (strong or world == 1) else "%dx%d" % (world, cfg["N"])
     out = {

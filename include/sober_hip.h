@@ -38,6 +38,7 @@ extern "C" {
 #define SOBER_E_ARG      -1      /* null pointer / non-positive size / bad enum                  */
 #define SOBER_E_DIM      -2      /* dimension not supported by the compiled tile set             */
 #define SOBER_E_WS       -3      /* workspace too small                                           */
+#define SOBER_E_EXCHANGE -5      /* a multi-workgroup kernel gave up waiting for a partner (bounded spins); no result */
 
 int sober_abi_version(void);
 

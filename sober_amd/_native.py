@@ -156,7 +156,8 @@ def _check(rc: int, what: str):
         return
     if rc < 0:
         msg = {-1: "bad argument", -2: "dimension not supported by the compiled tile set",
-               -3: "workspace too small"}.get(rc, "error")
+               -3: "workspace too small",
+               -5: "a multi-workgroup Caratheodory kernel gave up waiting for a partner workgroup (no result)"}.get(rc, "error")
         raise SoberHipError(f"{what}: {msg} (code {rc})")
     raise SoberHipError(f"{what}: hipError_t {rc}")
 

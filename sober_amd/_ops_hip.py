@@ -27,7 +27,9 @@ class HipOps:
                                     f"{self.device}.  There is no CPU fallback.")
         nat.load()
         self._pin = {}
-        self.prof = None        # list -> (start_event, end_event, kernel entries) per level_reduce launch
+        self.prof = None        # list -> (start_event, end_event, kernel entries, launches) per level: ONE bracket, around the
+        #                         main launch (every hipEventRecord costs the step ~5 us; the leftover launch -- at most
+        #                         S - 1 positions, ~3.6 us -- is not timed)
         self.use_mfma = True    # False: VALU-only level kernel (direct differences), kept for A/B runs
         # False (or SOBER_NO_QUEUE in the environment): every level sized by the host after a synchronisation (A/B runs)
         self.queue_levels = os.environ.get("SOBER_NO_QUEUE") is None
@@ -391,18 +393,14 @@ class HipOps:
             return p.ws["Xtr"], p.ws["tot"]
         nat._req(idx, torch.int32, "idx"); nat._req(mu, torch.float64, "mu")
         job.idx, job.pos0, job.count, job.E, job.mu = idx.data_ptr(), pos0, count, E, mu.data_ptr()
-        pairs = None
+        pair = None
         if self.prof is not None:
-            n_left = pos0 + count - max(pos0, E * S)
-            pairs = [self._prof_pair(), self._prof_pair() if n_left > 0 else None]
-            for k, pr in enumerate(pairs):
-                job.ev[2 * k] = pr[0].cuda_event if pr else None
-                job.ev[2 * k + 1] = pr[1].cuda_event if pr else None
+            n_left = max(pos0 + count - max(pos0, E * S), 0)
+            pair = self._prof_pair()
+            job.ev[0], job.ev[1], job.ev[2], job.ev[3] = pair[0].cuda_event, pair[1].cuda_event, None, None
         nat.level_moments(job, nat._stream(mu))
-        if pairs is not None:
-            self.prof.append((pairs[0][0], pairs[0][1], int(count * job.n_rows)))
-            if pairs[1] is not None:
-                self.prof.append((pairs[1][0], pairs[1][1], int(n_left * job.n_rows)))
+        if pair is not None:
+            self.prof.append((pair[0], pair[1], int(count * job.n_rows), 1))
             for k in range(4):
                 job.ev[k] = None
         return p.ws["Xtr"], p.ws["tot"]
@@ -418,24 +416,20 @@ class HipOps:
         events = pairs = None
         if self.prof is not None:
             n_max = min(nat.MAX_LEVELS, int(math.log2(max(R / S, 1.0))) + 3)
-            pairs = [(self._prof_pair(), self._prof_pair()) for _ in range(n_max)]
+            pairs = [self._prof_pair() for _ in range(n_max)]
             events = [None] * (4 * nat.MAX_LEVELS)
-            for l, (a, b) in enumerate(pairs):
-                events[4 * l:4 * l + 4] = [a[0].cuda_event, a[1].cuda_event, b[0].cuda_event, b[1].cuda_event]
+            for l, a in enumerate(pairs):
+                events[4 * l:4 * l + 4] = [a[0].cuda_event, a[1].cuda_event, None, None]
         level_R, R_final, in_b = nat.level_loop(job, R, idx_cur, idx_new, sums_ready, events, nat._stream(mu))
         if pairs is not None:
-            for l, (a, b) in enumerate(pairs):
+            for l, a in enumerate(pairs):
                 if l == 0 and sums_ready:                   # (that level's launches were bracketed by the phase-1 call)
-                    self._ev_pool.extend([a, b])
+                    self._ev_pool.append(a)
                 elif l < len(level_R):
                     Rl = level_R[l]
-                    self.prof.append((a[0], a[1], int(Rl * job.n_rows)))
-                    if Rl % S:
-                        self.prof.append((b[0], b[1], int((Rl % S) * job.n_rows)))
-                    else:
-                        self._ev_pool.append(b)
+                    self.prof.append((a[0], a[1], int(Rl * job.n_rows), 1))
                 else:
-                    self._ev_pool.extend([a, b])
+                    self._ev_pool.append(a)
         return (idx_new, idx_cur, R_final) if in_b else (idx_cur, idx_new, R_final)
 
     def level_loop_sharded(self, p: Plan, idx_cur, idx_new, bounds, S: int, mu, sums_ready: bool, comm, R_stop: int):
@@ -472,6 +466,8 @@ class HipOps:
                         row_offset, K, mu_live, out_idx, out_w, st.cuda_stream)
         st.synchronize()
         n_keep = int(p.ws["h_flags_np"][S])
+        if n_keep < 0:
+            raise nat.SoberHipError("Caratheodory step: a multi-workgroup kernel gave up waiting for a partner workgroup")
         return out_idx[:n_keep], out_w[:n_keep]
 
     def level_flat(self, p: Plan):
@@ -487,6 +483,8 @@ class HipOps:
         nat.level_car(job, st.cuda_stream)
         st.synchronize()
         flags = p.ws["h_flags_np"]
+        if int(flags[S]) < 0:
+            raise nat.SoberHipError("Caratheodory step: a multi-workgroup kernel gave up waiting for a partner workgroup")
         return p.ws["keep_rank"][:S], p.ws["w_star"], flags[:S].copy(), int(flags[S])
 
     def level_trace(self, p: Plan):

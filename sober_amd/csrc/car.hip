@@ -157,7 +157,7 @@ __device__ __forceinline__ void amin_take(double& best, int& piv, double ob, int
 // car_mc.hip, where it is measured).  Producer and consumers sit on the same XCD, so the stores are plain ones.
 typedef unsigned int car_u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t car_rsrc_t;
-constexpr unsigned CARF_ERR = 0, CARF_XCD = 16, CARF_TICKET = 32, CARF_PROGRESS = 48;     // byte offsets in the comm block
+constexpr unsigned CARF_ERR = 0, CARF_XCD = 16, CARF_TICKET = 32, CARF_PROGRESS = 48, CARF_DONE = 56;   // byte offsets in the comm block
 __host__ __device__ constexpr int64_t carf_bytes(int) { return 64; }
 constexpr unsigned CARF_SPIN_LIMIT = 1u << 22;
 __device__ __forceinline__ void carf_put(car_rsrc_t rs, unsigned off, double v, unsigned tag) {
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
         if (threadIdx.x == 0) {
             __hip_atomic_store(words + CARF_ERR / 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(words + CARF_TICKET / 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(words + CARF_DONE / 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(words + CARF_XCD / 4, (epoch << 4) | (xcc + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         const CarPub pub{rs, tag0};
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
     // the 26 row groups must all be resident on the ~31 free CUs of the producer's XCD while it runs
     constexpr int RW = 2;
     constexpr int n_groups = CAR_NS / (4 * RW);
+    static_assert(n_groups == CAR_NS / 8, "the pivot kernels check CARF_DONE against CAR_NS / 8");
     for (;;) {
         __syncthreads();
         if (tid == 0)
@@ -479,6 +481,11 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
             // (columns beyond what the lanes above cover)
             for (int col = max(CAR_NS - m, 0) + lane; col < CAR_PC; col += 64) Phi[(size_t)r * CAR_PC + col] = 0.0;
         }
+        // this group of rows is in memory: the pivot kernel refuses to run on a Phi with a group missing
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (tid == 0 && !failed)
+            __hip_atomic_fetch_add(words + CARF_DONE / 4, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -585,7 +592,8 @@ __global__ __launch_bounds__(CAR_PW * 64) void k_car_pivot(const double* __restr
                                                            int32_t* __restrict__ n_keep_out,
                                                            double* __restrict__ mu_out,
                                                            const unsigned* __restrict__ err) {
-    if (err != nullptr && *err != 0u) {    // the fused launch in front gave up on a reflector (bounded spins): no result
+    if (err != nullptr && (err[CARF_ERR / 4] != 0u || err[CARF_DONE / 4] != (unsigned)(CAR_NS / 8))) {
+        // the fused launch in front gave up on a reflector (bounded spins) or left a group of Phi's rows out: no result
         if (threadIdx.x == 0) *n_keep_out = -1;
         return;
     }
@@ -918,7 +926,8 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
     const int c0 = w * SP_BC;
     if (tid < SP_RING) ring[tid].tag = 0;
     if (tid < SP_W) prog[tid] = 0;
-    const bool broken = err != nullptr && *err != 0u;                 // the fused launch in front gave up on a reflector
+    // the fused launch in front gave up on a reflector, or not every group of Phi's rows found a consumer
+    const bool broken = err != nullptr && (err[CARF_ERR / 4] != 0u || err[CARF_DONE / 4] != (unsigned)(CAR_NS / 8));
     __syncthreads();                                                  // (the only workgroup barrier)
     if (broken) { if (tid == 0) *n_keep_out = -1; return; }
     if (c0 >= K && w != 0) return;

@@ -61,6 +61,7 @@ constexpr unsigned OFF_EL_B = 16;                                 // election of
 constexpr unsigned OFF_EL_P = 64;                                 // election of the pivot kernel: count[8], winner
 constexpr unsigned OFF_PROG = 128;                                // [GMAX] dwords: reflectors < k of this producer workgroup are in memory
 constexpr unsigned OFF_TICKET = 176;                              // row-group tickets of the Phi consumers (fused launch)
+constexpr unsigned OFF_DONE = 180;                                // row groups of Phi completed (fused launch)
 constexpr unsigned OFF_Q = 192;                                   // [2][GMAX][256] granules: per-CU partial row dots
 constexpr unsigned OFF_C = OFF_Q + 2u * GMAX * 256u * 16u;        // [2][256]: column i
 constexpr unsigned OFF_S = OFF_C + 2u * 256u * 16u;               // [2][16]: per-CU partial |row_i|^2
@@ -529,6 +530,12 @@ __device__ __forceinline__ void phi_rows(const double* __restrict__ vws, int N, 
 #endif
             }
         }
+        // this group of rows is in memory (a spin that gave up has set the error word): the pivot kernel refuses to run
+        // on a Phi with a group missing
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_fetch_add((unsigned*)((char*)comm + OFF_DONE), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -826,7 +833,7 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
                                                   const double* __restrict__ mu_in, int32_t* __restrict__ keep_rank,
                                                   double* __restrict__ w_star, int32_t* __restrict__ n_keep_out,
                                                   double* __restrict__ mu_out, void* comm, unsigned cbytes,
-                                                  unsigned long long* dbg) {
+                                                  unsigned long long* dbg, int phi_groups) {
     __shared__ int lcu;
     const int lane = threadIdx.x & 63;
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
@@ -850,6 +857,8 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
         for (int j = 0; j < BC; ++j) phi[j][q] = (c0 + j < K && row < N) ? PhiT[(size_t)(c0 + j) * NS + row] : 0.0;
     }
     bool fail = load_err(rs) != 0u;                                   // the bidiagonalisation gave up
+    if (phi_groups > 0)                                               // (fused launch) ... or a group of Phi's rows found no consumer
+        fail |= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, OFF_DONE, 0, 16) != (unsigned)phi_groups;
     bool stop = false;
     MC_STAMP_DECL
     double col[NQ];
@@ -973,7 +982,7 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_mc_pivot, dim3(ELECT_GRID), dim3(256), 0, st, PhiT, N, m, mu_in, keep_rank, w_star, n_keep,
-                       mu_out, ws, cbytes, dbg);
+                       mu_out, ws, cbytes, dbg, fused ? (NS + 4 * PHI_RW - 1) / (4 * PHI_RW) : 0);
     LAUNCH_CHECK();
     return 0;
 }

@@ -112,7 +112,8 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
     int L = 0;
     while (L < SOBER_LEVEL_QUEUE && L < max_levels && Rlo[L] > S) {
         Rlo[L + 1] = (Rlo[L] / S) * b;                                  // no leftovers kept, n_keep = b
-        Rub[L + 1] = (Rub[L] / S) * b + (S - 1);                        // the largest E with all leftovers kept
+        // the largest E with all leftovers kept; a level whose size is known exactly has exactly R mod S leftovers
+        Rub[L + 1] = (Rub[L] / S) * b + (Rlo[L] == Rub[L] ? Rub[L] % S : S - 1);
         ++L;
     }
     if (const char* qm = getenv("SOBER_QUEUE_MAX")) { const int v = atoi(qm); if (v < L) L = v; }   // debugging aid
@@ -135,12 +136,16 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
                                                   j->dim, cur, Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch,
                                                   j->partG, S, j->partTot, j->dR + l, stream));
             LX_EVENT(1)
-            LX_EVENT(2)
-            LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
-                                                  j->dim, cur, S - 1, SOBER_LEVEL_XS, S, 1, j->mu, j->wmul,
-                                                  j->outputscale, nxch, j->extraG, SOBER_LEVEL_XS, j->extraTot,
-                                                  j->dR + l, stream));
-            LX_EVENT(3)
+            // (the leftover launch of a level whose size is known exactly and leaves none is not made: the sums
+            //  kernel finds the same zero from dR)
+            if (!(Rlo[l] == Rub[l] && Rub[l] % S == 0)) {
+                LX_EVENT(2)
+                LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
+                                                      j->dim, cur, S - 1, SOBER_LEVEL_XS, S, 1, j->mu, j->wmul,
+                                                      j->outputscale, nxch, j->extraG, SOBER_LEVEL_XS, j->extraTot,
+                                                      j->dR + l, stream));
+                LX_EVENT(3)
+            }
             LX_TRY(sober_sum_partials_queued(j->partG, j->partTot, j->n_rows, S, S, j->extraG, j->extraTot,
                                              SOBER_LEVEL_XS, j->G, S, j->tot, j->dR + l, stream));
         }
@@ -198,6 +203,7 @@ extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, i
         const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // the host decides the next level's size
         if (e != hipSuccess) return (int)e;
         const int n_keep = j->h_flags[S];
+        if (n_keep < 0) { *n_levels = levels; return SOBER_E_EXCHANGE; }   // the Caratheodory kernels' exchange gave up
         const bool last_kept = j->h_flags[S - 1] >= 0;
         const int64_t R_new = E * n_keep + (last_kept ? r : 0);             // :198-221
         level_R[levels++] = R;
@@ -295,7 +301,7 @@ extern "C" int sober_level_loop_sharded(sober_level_job* j, int rank, int world,
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) return (int)e;
         const int n_keep = j->h_flags[S];
-        if (n_keep < 0) return SOBER_E_NOPROGRESS;
+        if (n_keep < 0) return SOBER_E_EXCHANGE;
         const bool last_kept = j->h_flags[S - 1] >= 0;
         const int64_t R_new = E * n_keep + (last_kept ? r : 0);
         level_R[levels++] = R;

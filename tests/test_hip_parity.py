@@ -1271,9 +1271,9 @@ def test_sharded_device_path_two_ranks_one_gpu(name, cuts, cutover, dev, monkeyp
     procs = [ctx.Process(target=_shard_worker, args=(r, world, port, name, cuts, q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    outs = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
     for p in procs:
-        p.join(120)
+        p.join(30)
         assert p.exitcode == 0
     mu_all = np.concatenate([o[3] for o in outs])
     for rank, idx, w, _ in outs:
@@ -1404,9 +1404,9 @@ def test_cfg4_shape_eight_ranks_one_gpu(dev):
     procs = [ctx.Process(target=_shard_worker_synth, args=(r, world, port, CFG4, q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    outs = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
     for p in procs:
-        p.join(120)
+        p.join(30)
         assert p.exitcode == 0
     for rank, idx, w, _ in outs:
         assert np.array_equal(idx, idx1), rank
