@@ -58,13 +58,13 @@ FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector = FP64 matrix (vendor; SUR
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
 INT8_PEAK_TOPS = 5000.0          # dense INT8 MFMA = 2 x the bf16 rate (MI355X_MICROARCH.md, matrix cores)
 CK = {"rbf": 28, "matern52": 40}
-# HBM bytes per launch of the level kernel (mean over the launches of a step: 17 at configuration 2, the leftover
+# HBM bytes per launch of the level kernel (mean over the launches of a step: 15 at configuration 2, the leftover
 # launches included) from rocprofv3 PMC passes of the configuration: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950
 # FETCH_SIZE correction of MI355X_MICROARCH.md; separate --pmc passes; profiles/r02_pmc_level_reduce.csv).
-# Algorithmic bytes at configuration 2 are ~1.3 MB/launch (every live candidate row, index and weight once per
+# Algorithmic bytes at configuration 2 are ~1.4 MB/launch (every live candidate row, index and weight once per
 # level).  The excess: the <= 5 partial sums per tile (5.6 MB written at level 0, re-read by k_sum_partials) and the
 # candidate rows that two XCDs' L2s both fetch.  Round 1: 23.4 MB; workgroup-staged kernel with 13 chunks: 11.6 MB.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {2: 5.8e6}
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {2: 6.6e6}
 
 
 def t(a):
