@@ -144,6 +144,10 @@ int sober_dgemm(int transa, int transb, int m, int n, int k, double alpha,
  * division: the final direct level, :78).                                                        */
 int sober_barycentres(const double* Xtr, int ldx, int n, int S, const double* tot,
                       double* X_tmp, void* stream);
+/* Projection and barycentres in one launch: Ct[j][i] = (A B)[i][j] / coldiv[j] (A: m x k, B: k x n, row-major; coldiv may
+ * be null) -- bit-identical to sober_dgemm followed by sober_barycentres. */
+int sober_dgemm_coldiv_t(int m, int n, int k, const double* A, int lda, const double* B, int ldb, const double* coldiv,
+                         double* Ct, int ldct, void* stream);
 
 /* K7 (SOBER/_rchq.py:198-221): rescale the kept sets' weights, zero the cancelled ones and write
  * the compacted survivor list (element-major, kept sets in ascending order, leftovers appended iff

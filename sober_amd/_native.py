@@ -35,6 +35,7 @@ SIGNATURES = {
                                   _f64, _i32, _vp, _i32, _i32, _vp, _i64, _vp]),
     "sober_nonzero_ws_bytes": (_i64, [_i64]),
     "sober_nonzero_i32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "sober_dgemm_coldiv_t": (_i32, [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sober_level_chunks": (_i32, [_i32, _i64, _i64, _i32]),
     "sober_level_parts_mfma": (_i32, [_i32, _i64, _i64, _i32]),
     "sober_level_parts_mfma_cap": (_i32, [_i32, _i64, _i32]),

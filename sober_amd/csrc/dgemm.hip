@@ -30,7 +30,8 @@ template <int SPLIT>
 __global__ __launch_bounds__(256) void k_dgemm(int transa, int transb, int m, int n, int k,
                                                double alpha, const double* __restrict__ A, int lda,
                                                const double* __restrict__ B, int ldb, double beta,
-                                               double* __restrict__ C, int ldc) {
+                                               double* __restrict__ C, int ldc,
+                                               const double* __restrict__ coldiv, double* __restrict__ Ct, int ldct) {
     __shared__ double red[SPLIT == 4 ? 3 * 256 : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int i0, j0, kbeg, kend;
@@ -81,9 +82,13 @@ __global__ __launch_bounds__(256) void k_dgemm(int transa, int transb, int m, in
         const int row = i0 + lk + 4 * r;
         const int col = j0 + li;
         if (row < m && col < n) {
-            double* c = C + (size_t)row * ldc + col;
             const double v = alpha * acc[r];
-            *c = (beta == 0.0) ? v : fma(beta, *c, v);
+            if (Ct != nullptr) {                                       // transposed, column j divided by coldiv[j]
+                Ct[(size_t)col * ldct + row] = coldiv ? v / coldiv[col] : v;
+            } else {
+                double* c = C + (size_t)row * ldc + col;
+                *c = (beta == 0.0) ? v : fma(beta, *c, v);
+            }
         }
     }
 }
@@ -99,11 +104,31 @@ extern "C" int sober_dgemm(int transa, int transb, int m, int n, int k, double a
     if (tiles <= 2048 && k >= 64) {                  // few tiles: cut the K chain in four
         dim3 grid((n + 15) / 16, (m + 15) / 16);
         hipLaunchKernelGGL(sober::k_dgemm<4>, grid, dim3(256), 0, (hipStream_t)stream, transa, transb, m, n, k,
-                           alpha, A, lda, B, ldb, beta, C, ldc);
+                           alpha, A, lda, B, ldb, beta, C, ldc, (const double*)nullptr, (double*)nullptr, 0);
     } else {
         dim3 grid((n + 31) / 32, (m + 31) / 32);
         hipLaunchKernelGGL(sober::k_dgemm<1>, grid, dim3(256), 0, (hipStream_t)stream, transa, transb, m, n, k,
-                           alpha, A, lda, B, ldb, beta, C, ldc);
+                           alpha, A, lda, B, ldb, beta, C, ldc, (const double*)nullptr, (double*)nullptr, 0);
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// Ct[j][i] = (A B)[i][j] / coldiv[j]  (A: m x k, B: k x n, both row-major; coldiv may be null): the projection P G and the
+// barycentres of SOBER/_rchq.py:151,166 -- division by the set masses, transposed store -- in one launch; the value
+// divided is the same alpha = 1 product sober_dgemm would have stored, so the result is bit-identical to the two steps.
+extern "C" int sober_dgemm_coldiv_t(int m, int n, int k, const double* A, int lda, const double* B, int ldb,
+                                    const double* coldiv, double* Ct, int ldct, void* stream) {
+    if (!A || !B || !Ct || m <= 0 || n <= 0 || k <= 0 || lda < k || ldb < n || ldct < m) return SOBER_E_ARG;
+    const long tiles = (long)((n + 15) / 16) * ((m + 15) / 16);
+    if (tiles <= 2048 && k >= 64) {
+        dim3 grid((n + 15) / 16, (m + 15) / 16);
+        hipLaunchKernelGGL(sober::k_dgemm<4>, grid, dim3(256), 0, (hipStream_t)stream, 0, 0, m, n, k, 1.0, A, lda, B, ldb,
+                           0.0, (double*)nullptr, 0, coldiv, Ct, ldct);
+    } else {
+        dim3 grid((n + 31) / 32, (m + 31) / 32);
+        hipLaunchKernelGGL(sober::k_dgemm<1>, grid, dim3(256), 0, (hipStream_t)stream, 0, 0, m, n, k, 1.0, A, lda, B, ldb,
+                           0.0, (double*)nullptr, 0, coldiv, Ct, ldct);
     }
     LAUNCH_CHECK();
     return 0;

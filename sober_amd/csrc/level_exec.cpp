@@ -149,8 +149,8 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
             LX_TRY(sober_sum_partials_queued(j->partG, j->partTot, j->n_rows, S, S, j->extraG, j->extraTot,
                                              SOBER_LEVEL_XS, j->G, S, j->tot, j->dR + l, stream));
         }
-        LX_TRY(sober_dgemm(0, 0, n, S, j->n_rows, 1.0, j->P, j->n_rows, j->G, S, 0.0, j->Xtr, S, stream));
-        LX_TRY(sober_barycentres(j->Xtr, S, n, S, j->tot, j->X_tmp, stream));
+        // projection and barycentres in one launch (X_tmp = (P G)^T / tot: bit-identical to the two steps)
+        LX_TRY(sober_dgemm_coldiv_t(n, S, j->n_rows, j->P, j->n_rows, j->G, S, j->tot, j->X_tmp, n, stream));
         LX_TRY(sober_car_device(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
                                 nullptr, j->car_ws, j->car_ws_bytes, stream));
         LX_TRY(sober_level_update_queued(cur, Rub[l], S, j->keep_rank, j->w_star, j->tot, j->mu, nxt, j->dR + l,
