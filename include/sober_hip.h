@@ -47,6 +47,14 @@ int sober_padded_dim(int d);
 /* number of 64-bit words per point for a d-bit Tanimoto fingerprint.                             */
 int sober_bit_words(int d);
 
+/* The random test matrix of torch.svd_lowrank (SOBER/_rchq.py:37; torch.randn(M, q, dtype=float64) on the CPU
+ * generator) in two halves.  sober_mt19937_uniform53 (HOST function, no GPU work) steps the generator state `state`
+ * (the bytes of torch.get_rng_state(), updated in place: afterwards it is what torch.randn would have left) and
+ * writes the uniforms the normal fill consumes: numel of them, plus 16 when numel % 16 != 0 (out holds numel + 16
+ * doubles).  sober_box_muller turns them into numel normals on the device, paired like ATen's fill.            */
+int sober_mt19937_uniform53(uint8_t* state, int64_t state_bytes, int64_t numel, double* out);
+int sober_box_muller(const double* u, int64_t numel, double* out, void* stream);
+
 /* x[i, 0:d] / lengthscale -> out[i, 0:dt] (zero padded).  ls_len is 1 (isotropic) or d (ARD).
  * Replaces the `x1.div(lengthscale)` prologue of gpytorch's RBF/Matern forward that
  * SOBER/_gp.py:292-294 calls on every kernel evaluation.                                         */

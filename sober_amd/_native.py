@@ -29,6 +29,8 @@ SIGNATURES = {
     "sober_bit_words": (_i32, [_i32]),
     "sober_scale_points": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
     "sober_pack_bits": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "sober_mt19937_uniform53": (_i32, [_vp, _i64, _i64, _vp]),
+    "sober_box_muller": (_i32, [_vp, _i64, _vp, _vp]),
     "sober_pairwise": (_i32, [_i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _f64, _vp, _i64, _vp]),
     "sober_kernel_matvec": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _f64, _vp, _vp]),
     "sober_level_reduce": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp,
@@ -214,6 +216,23 @@ def scale_points(X, lengthscale, out):
     _check(load().sober_scale_points(X.data_ptr(), n, d, X.stride(0), lengthscale.data_ptr(),
                                      lengthscale.numel(), out.data_ptr(), out.shape[1], _stream(X)),
            "sober_scale_points")
+
+
+def mt19937_uniform53(state, numel, out):
+    """HOST: step the CPU generator state `state` (uint8 bytes of torch.get_rng_state(), in place) through the draws
+    of torch.randn(numel, dtype=float64) and leave their uniforms in `out` (host float64, numel + 16)."""
+    _req(state, torch.uint8, "state"); _req(out, torch.float64, "out")
+    if state.is_cuda or out.is_cuda or out.numel() < numel + 16:
+        raise ValueError("mt19937_uniform53 takes host tensors, out of numel + 16 doubles")
+    _check(load().sober_mt19937_uniform53(state.data_ptr(), state.numel(), numel, out.data_ptr()),
+           "sober_mt19937_uniform53")
+
+
+def box_muller(u, numel, out):
+    _req(u, torch.float64, "u"); _req(out, torch.float64, "out")
+    if u.numel() < numel + 16 or out.numel() < numel:
+        raise ValueError("box_muller: u holds numel + 16 uniforms, out numel normals")
+    _check(load().sober_box_muller(u.data_ptr(), numel, out.data_ptr(), _stream(out)), "sober_box_muller")
 
 
 def pack_bits(X, words, norms, bad_flag):

@@ -9,6 +9,7 @@ import os
 import torch
 
 from . import _native as nat
+from . import _rng
 from ._kernel import KernelSpec, PointSet, posterior_mean, prepare_points, woodbury
 
 
@@ -171,14 +172,13 @@ class HipOps:
         nat.cholesky_probe(C, shifts, work, flags[2:], pivots)
         nat.jitter_ladder_auto(C, flags[2:], flags[1:2])
         # svd_lowrank's randn comes from the CPU generator (it is the next consumer of the generator in the
-        # reference too: make_cov_psd draws nothing).  torch.randn(500, 99) is 0.6 ms of host time -- as long as the
-        # Cholesky probe it hides behind: this phase is bound by the HOST.  Two ways of hiding it better were measured
-        # and made the step slower by 0.2 ms each: a helper thread for the draw (thread start, join and the GIL cost more
-        # than they hide) and enqueueing the first level's set sums in front of the draw (their host-side set-up delays
-        # the draw itself).  Should the input turn out exactly symmetric (is_psd(cov) itself has to run, on the host) or
-        # the range finder lose rank, the generator is put back and the literal host route decides.
+        # reference too: make_cov_psd draws nothing).  torch.randn(500, 99) itself is 0.6 ms of host time -- longer than
+        # the Cholesky probe it hides behind, which left the GPU idle for 0.2 ms; the host now only steps the Mersenne
+        # twister and the Box-Muller transform runs on the device (_rng.py).  Should the input turn out exactly
+        # symmetric (is_psd(cov) itself has to run, on the host) or the range finder lose rank, the generator is put
+        # back and the literal host route decides.
         rng_state = torch.get_rng_state()
-        R = torch.randn(M, s, dtype=torch.float64)
+        R = _rng.device_randn(M, s, dev)
         U, (flags_h, piv_h) = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=(flags, pivots), plan=p)
         if int(flags_h[0]) == 0 or U is None or self.ladder_borderline(flags_h[2:], piv_h[:n_r], float(piv_h[n_r])):
             torch.set_rng_state(rng_state)                 # the host route draws the same randn again
@@ -238,7 +238,7 @@ class HipOps:
         rows (q, M) -- see the comment at the end for why the small SVD is not needed -- or None if CholeskyQR
         lost rank."""
         dev, M = self.device, A.shape[0]
-        R = R_host.to(dev)                                           # CPU generator: the reference's draw
+        R = R_host.to(dev)                                           # CPU generator: the reference's draw (already there: _rng.py)
         n_orth = 1 + 2 * niter
         infos = torch.zeros(2 * n_orth, dtype=torch.int32, device=dev)
         pivs = torch.zeros(2 * n_orth, dtype=torch.float64, device=dev)

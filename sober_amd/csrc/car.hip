@@ -950,6 +950,7 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
     for (int s = 0; s < s_mine && !fail && !stop; ++s) {
         double al, rp;
         int piv;
+        if (s == s_mine - SP_BC) __builtin_amdgcn_s_setprio(2);      // on deck: the hand-over is on the critical chain
         if (!sp_consume(ring, s, lane, col, al, rp, piv)) { fail = true; break; }
         if (lane == 0) prog[w] = s + 1;
         if (piv < 0) { stop = true; break; }

@@ -373,6 +373,42 @@ extern "C" int sober_bit_words(int d) {
     return SOBER_E_DIM;
 }
 
+// Box-Muller exactly as ATen's CPU normal fill arranges it for a contiguous double tensor (groups of 16: element j < 8
+// pairs with element j + 8; u1 = 1 - u[j], u2 = u[j + 8]; radius sqrt(-2 log u1), angle 2 pi u2; cos to j, sin to
+// j + 8), the last 16 elements recomputed from 16 further uniforms when numel is not a multiple of 16.  u holds the
+// uniforms of sober_mt19937_uniform53 (numel, + 16 for that tail).  The values agree with torch.randn's to the last
+// ulp or two of the device's log / sincos -- the test matrix of a randomised range finder, nothing downstream
+// resolves that.
+__global__ void k_box_muller(const double* __restrict__ u, int64_t numel, double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one pair per thread
+    const int64_t full = numel / 16;                                      // complete groups
+    const bool tail = (numel % 16) != 0;
+    const int64_t npairs = (full + (tail ? 1 : 0)) * 8;
+    if (t >= npairs) return;
+    const int64_t g = t >> 3;
+    const int j = (int)(t & 7);
+    // the tail group reads its own 16 uniforms and lands on the last 16 elements; a complete group that overlaps
+    // them leaves those elements to it
+    const bool is_tail = g == full;
+    const int64_t ub = is_tail ? numel : g * 16, ob = is_tail ? numel - 16 : g * 16;
+    const double u1 = 1.0 - u[ub + j], u2 = u[ub + j + 8];
+    const double radius = sqrt(-2.0 * log(u1));
+    const double theta = 6.283185307179586 * u2;
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    const int64_t keep_below = tail ? numel - 16 : numel;
+    if (is_tail || ob + j < keep_below) out[ob + j] = radius * cs;
+    if (is_tail || ob + j + 8 < keep_below) out[ob + j + 8] = radius * sn;
+}
+
+extern "C" int sober_box_muller(const double* u, int64_t numel, double* out, void* stream) {
+    if (!u || !out || numel < 16) return SOBER_E_ARG;
+    const int64_t npairs = ((numel + 15) / 16) * 8;
+    hipLaunchKernelGGL(k_box_muller, dim3(nblk(npairs, 256)), dim3(256), 0, (hipStream_t)stream, u, numel, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sober_scale_points(const double* X, int64_t n, int d, int64_t ldx,
                                   const double* lengthscale, int ls_len, double* out, int dt,
                                   void* stream) {
