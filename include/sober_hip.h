@@ -256,6 +256,15 @@ int sober_cholesky_probe(const double* src, int n, int ld_src, const double* shi
  * LAPACK decide (sober_amd/_ops_hip.py:nystrom_basis_device).                                                    */
 int sober_cholesky_probe_piv(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
                              double* work, int32_t* info, double* min_pivot, void* stream);
+
+/* The same probes with 8 workgroups per rung (block rows dealt round-robin; the workgroups of a rung on one XCD):
+ * 0.49 -> ~0.2 ms at n = 500.  n_shifts <= 16; ws of sober_cholesky_probe_mc_ws_bytes bytes (scratch).  info[r] = -7:
+ * the rung's workgroups lost each other (bounded spins) and the rung has NO verdict -- probe again with
+ * sober_cholesky_probe_piv.  Same info / min_pivot otherwise.                                                  */
+int64_t sober_cholesky_probe_mc_ws_bytes(int n, int n_shifts);
+int sober_cholesky_probe_mc(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
+                            double* work, int32_t* info, double* min_pivot, void* ws, int64_t ws_bytes,
+                            void* stream);
 /* out = sqrt(nan_to_num(C) * nan_to_num(C)^T) elementwise (quirk Q2, SOBER/_utils.py:143-144);
  * flag[0] |= 1 when C is not exactly symmetric (:127).  Zero flag first.                            */
 int sober_abs_sym(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, void* stream);

@@ -68,6 +68,8 @@ SIGNATURES = {
     "sober_trsm_blocks": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sober_cholesky_probe": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_cholesky_probe_piv": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "sober_cholesky_probe_mc_ws_bytes": (_i64, [_i32, _i32]),
+    "sober_cholesky_probe_mc": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_jitter_ladder": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "sober_jitter_ladder_auto": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
@@ -438,6 +440,22 @@ def cholesky_probe(src, shifts, work, info, min_pivot=None):
     _check(load().sober_cholesky_probe_piv(src.data_ptr(), n, src.stride(0), shifts.data_ptr(), shifts.numel(),
                                            work.data_ptr(), info.data_ptr(), _ptr(min_pivot), _stream(src)),
            "sober_cholesky_probe_piv")
+
+
+PROBE_NO_VERDICT = -7      # info of a rung whose workgroups lost each other in cholesky_probe_mc
+
+
+def cholesky_probe_mc_ws_bytes(n: int, n_shifts: int) -> int:
+    return int(load().sober_cholesky_probe_mc_ws_bytes(n, n_shifts))
+
+
+def cholesky_probe_mc(src, shifts, work, info, min_pivot, ws):
+    """cholesky_probe with 8 workgroups per rung; info == PROBE_NO_VERDICT for a rung means: probe again with
+    cholesky_probe (or decide on the host)."""
+    n = src.shape[0]
+    _check(load().sober_cholesky_probe_mc(src.data_ptr(), n, src.stride(0), shifts.data_ptr(), shifts.numel(),
+                                          work.data_ptr(), info.data_ptr(), _ptr(min_pivot), ws.data_ptr(),
+                                          ws.numel() * ws.element_size(), _stream(src)), "sober_cholesky_probe_mc")
 
 
 def abs_sym(C_, out, flag):

@@ -34,6 +34,8 @@ class HipOps:
         self.use_mfma = True    # False: VALU-only level kernel (direct differences), kept for A/B runs
         # False (or SOBER_NO_QUEUE in the environment): every level sized by the host after a synchronisation (A/B runs)
         self.queue_levels = os.environ.get("SOBER_NO_QUEUE") is None
+        # the jitter ladder's probes on eight workgroups per rung (SOBER_PROBE_ONE_WG: one each, A/B runs)
+        self._probe_mc = os.environ.get("SOBER_PROBE_ONE_WG") is None
 
     # ------------------------------------------------------------------ plan
     def build_plan(self, spec: KernelSpec, mode: str, X_nys, X_cand) -> Plan:
@@ -169,7 +171,13 @@ class HipOps:
         # (smallest pivot of every rung + the largest diagonal entry: the borderline test below)
         pivots = torch.empty(n_r + 1, dtype=torch.float64, device=dev)
         pivots[n_r:] = C.diagonal().amax()
-        nat.cholesky_probe(C, shifts, work, flags[2:], pivots)
+        # (eight workgroups per rung from a few panels on: 0.49 -> 0.25 ms at M = 500; a rung whose workgroups lost each
+        #  other reports PROBE_NO_VERDICT and the step goes to the host route, this process then stays with one each)
+        if M >= self.PROBE_MC_MIN and n_r <= 16 and self._probe_mc:
+            ws = self._buf_u8(p, "chol_mc_ws", nat.cholesky_probe_mc_ws_bytes(M, n_r))
+            nat.cholesky_probe_mc(C, shifts, work, flags[2:], pivots, ws)
+        else:
+            nat.cholesky_probe(C, shifts, work, flags[2:], pivots)
         nat.jitter_ladder_auto(C, flags[2:], flags[1:2])
         # svd_lowrank's randn comes from the CPU generator (it is the next consumer of the generator in the
         # reference too: make_cov_psd draws nothing).  torch.randn(500, 99) itself is 0.6 ms of host time -- longer than
@@ -180,6 +188,12 @@ class HipOps:
         rng_state = torch.get_rng_state()
         R = _rng.device_randn(M, s, dev)
         U, (flags_h, piv_h) = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=(flags, pivots), plan=p)
+        if any(int(v) == nat.PROBE_NO_VERDICT for v in flags_h[2:]):
+            self._probe_mc = False
+            warnings.warn("sober_amd: the multi-CU Cholesky probe lost contact between its workgroups; "
+                          "falling back to one workgroup per rung")
+            torch.set_rng_state(rng_state)
+            return None
         if int(flags_h[0]) == 0 or U is None or self.ladder_borderline(flags_h[2:], piv_h[:n_r], float(piv_h[n_r])):
             torch.set_rng_state(rng_state)                 # the host route draws the same randn again
             return None
@@ -192,6 +206,7 @@ class HipOps:
     # matter (the first accepted one and the rejected one in front of it); a borderline ladder goes to the host's
     # LAPACK, as the host twin does (sober_amd/_utils.py:make_cov_psd).
     LADDER_GUARD = 1e-9
+    PROBE_MC_MIN = 160         # Gram matrices from this size on are probed by eight workgroups per rung
 
     @classmethod
     def ladder_borderline(cls, info, min_pivot, dmax) -> bool:
@@ -309,6 +324,13 @@ class HipOps:
         t = p.ws.get(name)
         if t is None or t.numel() < numel:
             t = torch.empty(numel, dtype=torch.float64, device=self.device)
+            p.ws[name] = t
+        return t
+
+    def _buf_u8(self, p, name, nbytes):
+        t = p.ws.get(name)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=self.device)
             p.ws[name] = t
         return t
 

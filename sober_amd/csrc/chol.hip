@@ -21,7 +21,10 @@ constexpr int CH_MAXN = 536;         // panel (n - NB) x LDPP doubles + two NB x
 typedef double ch_double4 __attribute__((ext_vector_type(4)));
 
 constexpr int CH_G = 4;              // tiles of the trailing update per wave and trip
-__device__ double ch_sink[CH_T];     // where the stores of lanes outside the lower triangle go (never read)
+__device__ double ch_sink[CH_T];
+#ifdef CM_STAMPS
+__device__ double ch_dbg[2];        // diagnostic build: ticks of the last ch_diag_block (factorisation, inversion)
+#endif     // where the stores of lanes outside the lower triangle go (never read)
 
 __device__ __forceinline__ double ch_rdlane(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
@@ -43,84 +46,75 @@ __device__ __forceinline__ double ch_rdlane(double v, int l) {
 //       tile per wave and trip, the next tile of A22 already in flight.
 // (b) of k_chol, by ONE wave: Cholesky of the 32 x 32 diagonal block D (LDS, lower part, zero padded) in registers
 // (lane = row; pivots and multipliers are v_readlane broadcasts), L11 back to D, its inverse to Xs (and to xo).
-__device__ __forceinline__ void ch_diag_block(double* __restrict__ D, double* __restrict__ Xs, double* __restrict__ s_dinv,
+__device__ __attribute__((noinline)) void ch_diag_block(double* __restrict__ D, double* __restrict__ Xs, double* __restrict__ s_dinv,
                                               int* __restrict__ s_fail_p, double* __restrict__ s_minp_p, int nb, int kb,
                                               int lane, double* __restrict__ xout) {
     constexpr int LDP = CH_NB + 1;
     int& s_fail = *s_fail_p;
     double& s_minp = *s_minp_p;
 
-            const int i = lane;
-            double d[CH_NB];
+            // One straight-line block (no branch per column): the factorisation's column j and step j of the
+            // column-oriented substitution for X = L^-1 (lane = column of X) use the SAME broadcast multipliers
+            // L[c][j], and the scheduler can put the independent updates of column j beside the dependent
+            // rsq / Newton sequence of column j + 1.  (Measured before: factorisation with a branch per column 7.8 us,
+            // then the substitution with its multipliers read back from LDS 7.0 us -- the whole launch's critical path.)
+            // A failed pivot only records itself; what is computed after it is never used.  Rows and columns >= nb are
+            // an identity block (pivots 1, not counted).
+            // Both halves of the wave do the same 32 rows (i = lane & 31): every lane stays active, there is no
+            // exec juggling around the LDS writes (the twin lanes write the same values to the same places), and
+            // column j of L and row j of X leave the registers as soon as they are final -- 64 doubles live at the
+            // start, fewer with every column (all 64 of d[] and x[] held to the end spilled to scratch).
+            const int i = lane & (CH_NB - 1);
+            double d[CH_NB], x[CH_NB];
+#ifdef CM_STAMPS
+            const long long dbg0 = wall_clock64();
+#endif
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) d[c] = (i < CH_NB) ? D[min(i, CH_NB - 1) * LDP + c] : 0.0;
+            for (int c = 0; c < CH_NB; ++c) {
+                const double dv = D[i * LDP + c];             // (rows >= nb are zero padded: read, then replaced)
+                d[c] = (i < nb) ? dv : ((c == i) ? 1.0 : 0.0);
+                x[c] = (c == i) ? 1.0 : 0.0;
+            }
+            double* xo = xout != nullptr ? xout + (size_t)(kb / CH_NB) * CH_NB * CH_NB : ch_sink;
+            const int xo_ld = xout != nullptr ? CH_NB : 0, xo_i = xout != nullptr ? i : lane;
             int fail = 0;
             double minp = s_minp;
-            double my_rinv = 1.0;                         // lane j: 1 / L[j][j] (identity padding: 1)
 #pragma unroll
             for (int j = 0; j < CH_NB; ++j) {
-                if (j < nb && fail == 0) {                // uniform
-                    const double djj = ch_rdlane(d[j], j);
-                    if (!(djj > 0.0)) {                   // also catches NaN
-                        fail = kb + j + 1;
-                        minp = fmin(minp, djj);           // the failing pivot (<= 0): how far from positive definite
-                    } else {
-                        // multipliers through the reciprocal square root: one short dependent sequence per
-                        // column instead of sqrt followed by a division (off-diagonal entries within 2 ulp)
-                        // sqrt and 1/sqrt from ONE v_rsq_f64 seed + Newton steps (<= 1 ulp): the IEEE sqrt() and
-                        // rsqrt() sequences are ~60 dependent instructions on the critical path of every column
-                        double rinv = __builtin_amdgcn_rsq(djj);
-                        {
-                            double h = 0.5 * rinv, e = fma(-(djj * rinv), h, 0.5);
-                            rinv = fma(rinv, e, rinv);
-                            h = 0.5 * rinv; e = fma(-(djj * rinv), h, 0.5);
-                            rinv = fma(rinv, e, rinv);
-                        }
-                        double l = djj * rinv;
-                        l = fma(fma(-l, l, djj), 0.5 * rinv, l);
-                        minp = fmin(minp, djj);
-                        my_rinv = (i == j) ? rinv : my_rinv;
-                        d[j] = (i == j) ? l : ((i > j) ? d[j] * rinv : 0.0);
+                const double djj = ch_rdlane(d[j], j);
+                const bool live = (j < nb) & (fail == 0);     // uniform
+                minp = live ? fmin(minp, djj) : minp;         // (the failing pivot, <= 0, included: how far from positive definite)
+                fail = (live & !(djj > 0.0)) ? kb + j + 1 : fail;       // also catches NaN
+                // sqrt and 1/sqrt from ONE v_rsq_f64 seed + Newton steps (<= 1 ulp): the IEEE sqrt() and rsqrt()
+                // sequences are ~60 dependent instructions on the critical path of every column; multipliers through
+                // the reciprocal square root (off-diagonal entries within 2 ulp)
+                double rinv = __builtin_amdgcn_rsq(djj);
+                {
+                    double h = 0.5 * rinv, e = fma(-(djj * rinv), h, 0.5);
+                    rinv = fma(rinv, e, rinv);
+                    h = 0.5 * rinv; e = fma(-(djj * rinv), h, 0.5);
+                    rinv = fma(rinv, e, rinv);
+                }
+                double l = djj * rinv;
+                l = fma(fma(-l, l, djj), 0.5 * rinv, l);
+                d[j] = (i == j) ? l : ((i > j) ? d[j] * rinv : 0.0);
+                x[j] *= rinv;                                 // x[j] / L[j][j]
+                D[i * LDP + j] = d[j];                        // L[i][j], final   (rows >= nb: the identity row)
+                Xs[j * LDP + i] = x[j];                       // X[j][i], final
+                xo[j * xo_ld + xo_i] = x[j];                  // (the inverted diagonal blocks feed k_trsm_blocks)
+                // (the multipliers L[c][j] read back from the column just written to LDS -- one wave-uniform ds_read per
+                //  two of them instead of two v_readlane each -- measured 9.3 us against 8.2 us for this form)
 #pragma unroll
-                        for (int c = j + 1; c < CH_NB; ++c)
-                            d[c] = fma(-d[j], ch_rdlane(d[j], c), d[c]);   // rows i < c: unused upper-triangle values
-                    }
+                for (int c = j + 1; c < CH_NB; ++c) {
+                    const double lcj = ch_rdlane(d[j], c);    // L[c][j]
+                    d[c] = fma(-d[j], lcj, d[c]);             // rows i < c: unused upper-triangle values
+                    x[c] = fma(-lcj, x[j], x[c]);
                 }
             }
-            if (i == 0) { s_fail = fail; s_minp = minp; }
-            if (fail == 0) {
-                // L11 -> LDS (padding rows >= nb become identity rows so that the inverse exists)
-                if (i < CH_NB) {
-#pragma unroll
-                    for (int c = 0; c < CH_NB; ++c)
-                        D[i * LDP + c] = (i < nb) ? ((c <= i) ? d[c] : 0.0) : ((c == i) ? 1.0 : 0.0);
-                    s_dinv[i] = my_rinv;
-                }
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // X = L11^-1 by columns, lane = column jx of X, column-oriented substitution: once x[k] is final,
-                // the updates of the rows below are independent of one another; L[r][k] and 1/L[k][k] are
-                // wave-uniform LDS reads (broadcasts) that do not depend on x
-                const int jx = lane;
-                double x[CH_NB];
-#pragma unroll
-                for (int r = 0; r < CH_NB; ++r) x[r] = (r == jx) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < CH_NB; ++k) {
-                    x[k] *= s_dinv[k];
-#pragma unroll
-                    for (int r = k + 1; r < CH_NB; ++r) x[r] = fma(-D[r * LDP + k], x[k], x[r]);
-                }
-                if (i < CH_NB) {
-#pragma unroll
-                    for (int c = 0; c < CH_NB; ++c) Xs[c * LDP + jx] = x[c];                 // X[c][jx]
-                    if (xout != nullptr) {                    // the inverted diagonal blocks feed k_trsm_blocks
-                        double* xo = xout + (size_t)(kb / CH_NB) * CH_NB * CH_NB;
-#pragma unroll
-                        for (int c = 0; c < CH_NB; ++c) xo[c * CH_NB + jx] = x[c];
-                    }
-                }
-            }
+            if (lane == 0) { s_fail = fail; s_minp = minp; }
+#ifdef CM_STAMPS
+            if (lane == 0) { ch_dbg[0] = (double)(wall_clock64() - dbg0); ch_dbg[1] = 0.0; }
+#endif
         }
 
 // SMALL (n <= CH_SMALLN, one matrix): the matrix itself is staged into LDS and every phase works there -- the q x q Gram
@@ -358,6 +352,361 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
     }
 }
 
+// ---------------- the ladder's probes, several compute units per rung ----------------
+// k_chol<false> probes every rung of the jitter ladder in one launch, one workgroup each: 0.49 ms at n = 500, bound by
+// the trailing update's read-modify-write traffic through ONE compute unit's memory path (22 MB per rung), with
+// 245 CUs idle.  Here CM_G workgroups share a rung: block row j (32 rows) belongs to ONE workgroup (cm_owner), which alone
+// reads and writes it.  Per panel k:
+//   owner(k)  factorises and inverts the diagonal block (ch_diag_block, one wave) and publishes the inverse X_k;
+//   everybody forms its rows of the panel L21 = A21 X_k^T, stores them (they stay where they are in the slab) and
+//             raises its flag; then fetches the panel rows of the others (up to its own last block row) into LDS;
+//   everybody updates its own block rows -- the owner of block k + 1 its diagonal tile first, then one wave factorises
+//             that block while the rest of the workgroup (and all other workgroups) finish the update.
+// The workgroups of a rung sit on ONE XCD (hardware XCC id + a ticket per XCD, as in car_mc.hip): a plain store is in
+// that XCD's L2 once vmcnt says so, and an L1-bypassing (sc1) load of a neighbour sees it -- no fences, no
+// cross-XCD round trips.  XCD x serves rungs x and x + 8.  Tile arithmetic is k_chol's (same MFMA order, same split
+// accumulators): info and pivots equal the one-workgroup kernel's.
+constexpr int CM_G = 8;
+constexpr int CM_MAXB = (CH_MAXN + CH_NB - 1) / CH_NB;
+constexpr unsigned CM_SPIN = 1u << 19;
+constexpr unsigned CM_OFF_TICKET = 0, CM_OFF_ERR = 64, CM_HDR = 128;
+constexpr unsigned CM_RUNG_BYTES = 1024;                                  // FX[MAXB] u32 | FP[MAXB][G] u32 | MP[MAXB] f64
+constexpr unsigned CM_OFF_FX = 0, CM_OFF_FP = CM_MAXB * 4, CM_OFF_MP = 768;
+static_assert(CM_OFF_FP + CM_MAXB * CM_G * 4 <= CM_OFF_MP && CM_OFF_MP + CM_MAXB * 8 <= CM_RUNG_BYTES, "flag layout");
+// block row -> workgroup, dealt back and forth (0 1 .. 7 7 6 .. 0 0 1 ..): a workgroup's rows j and 15 - j carry
+// (j - k) + (15 - j - k) tiles' worth of update at step k -- the same for every workgroup while both are active, where
+// plain round robin left the owner of rows 7 and 15 with 1.7x the average (and every step waits for the slowest)
+__device__ __forceinline__ int cm_owner(int j) { const int r = j % (2 * CM_G); return r < CM_G ? r : 2 * CM_G - 1 - r; }
+__device__ __forceinline__ int cm_row(int g, int idx) { return (idx >> 1) * 2 * CM_G + ((idx & 1) ? 2 * CM_G - 1 - g : g); }
+constexpr int CM_INFO_EXCHANGE = -7;                                      // info of a rung whose workgroups lost each other
+typedef __amdgpu_buffer_rsrc_t ch_rsrc_t;
+typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CM_POLL = 16 | (int)0x80000000;                             // sc1 + volatile: a fresh L2 read every time
+__device__ __forceinline__ unsigned cm_poll(ch_rsrc_t rs, unsigned off) {          // thread-level: wait for a non-zero word
+    unsigned spins = 0, v;
+    while ((v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, CM_POLL)) == 0u) {
+        if (++spins > CM_SPIN) return 0xffu;
+        if ((spins & 255u) == 0u && (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, CM_OFF_ERR, 0, CM_POLL) != 0u) return 0xffu;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(CH_T) void k_chol_mc(double* __restrict__ work, int n, int ld, int32_t* __restrict__ info,
+                                                  double* __restrict__ min_pivot, const double* __restrict__ src,
+                                                  int lds_src, const double* __restrict__ shifts, int n_rungs,
+                                                  unsigned char* ws, unsigned ws_bytes, unsigned x_off) {
+    extern __shared__ double lds[];
+    constexpr int LDP = CH_NB + 1, LDPP = CH_LDPP;
+    double* D = lds;
+    double* Xs = lds + CH_NB * LDP;
+    double* P = lds + 2 * CH_NB * LDP;                                    // rows below block k, relative, x LDPP
+    __shared__ int s_role, s_fail;
+    __shared__ double s_minp;
+    __shared__ double s_dinv[CH_NB];
+    __shared__ unsigned s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const ch_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)ws_bytes, 0x00020000);
+    if (tid == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;          // HW_REG_XCC_ID
+        const unsigned t = __hip_atomic_fetch_add((unsigned*)(ws + CM_OFF_TICKET) + xcc, 1u, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned rung = xcc + 8u * (t / CM_G);
+        s_role = rung < (unsigned)n_rungs ? (int)(rung * CM_G + t % CM_G) : -1;
+        s_fail = 0;
+        s_flag = 0u;
+        s_minp = __builtin_inf();
+    }
+    __syncthreads();
+    if (s_role < 0) return;
+    const int rung = s_role / CM_G, g = s_role % CM_G;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+    if (g >= nblk) return;
+    int jmax = g;                                                         // my last block row
+    for (int q = 1; cm_row(g, q) < nblk; ++q) jmax = cm_row(g, q);
+    double* const A = work + (size_t)rung * n * ld;
+    const ch_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(A, 0, (int)((size_t)n * ld * sizeof(double)), 0x00020000);
+    const double shift = shifts[rung];
+    const unsigned fbase = CM_HDR + (unsigned)rung * CM_RUNG_BYTES;
+    const unsigned xbase = x_off + (unsigned)rung * CM_MAXB * (CH_NB * CH_NB * 8);
+    // my block rows of the lower triangle -> my slab
+    for (int q = 0; cm_row(g, q) < nblk; ++q) {
+        const int j = cm_row(g, q);
+        const int r1 = min(n, CH_NB * (j + 1));
+        for (int i = CH_NB * j + (tid >> 6); i < r1; i += CH_T / 64)
+            for (int c = lane; c <= i; c += 64) A[(size_t)i * ld + c] = src[(size_t)i * lds_src + c];
+    }
+    __threadfence_block();
+    __syncthreads();
+
+#ifdef CM_STAMPS
+    long long cs_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs_last = wall_clock64();
+#define CM_STAMP(K) { const long long now_ = wall_clock64(); cs_t[K] += now_ - cs_last; cs_last = now_; if (tid == 0 && n >= 480 && k < 16) A[(size_t)g * ld + 300 + 6 * k + K] = (double)now_; }
+#else
+#define CM_STAMP(K)
+#endif
+    bool ahead = false;
+    int verdict = -1;                                                     // >= 0: I write the rung's result
+    for (int k = 0; k <= jmax; ++k) {
+        const int kb = CH_NB * k, nb = min(CH_NB, n - kb);
+        const bool own_k = cm_owner(k) == g;
+        if (own_k) {
+            if (!ahead) {
+#pragma unroll
+                for (int t = tid; t < CH_NB * CH_NB; t += CH_T) {
+                    const int i = t >> 5, j = t & 31;
+                    double v = (i < nb && j <= i) ? A[(size_t)(kb + i) * ld + kb + j] : 0.0;
+                    if (i == j && i < nb) v += shift;
+                    D[i * LDP + j] = v;
+                }
+                __syncthreads();
+                if (wave == 0) ch_diag_block(D, Xs, s_dinv, &s_fail, &s_minp, nb, kb, lane, nullptr);
+                __syncthreads();
+            }
+            if (tid == 0) {
+                const double mp = s_minp;
+                __builtin_amdgcn_raw_buffer_store_b32(__double2loint(mp), rs, fbase + CM_OFF_MP + 8 * k, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__double2hiint(mp), rs, fbase + CM_OFF_MP + 8 * k + 4, 0, 0);
+            }
+            if (s_fail != 0 || k == nblk - 1) {                           // uniform: the rung is decided here
+                if (tid == 0) {
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_raw_buffer_store_b32(2, rs, fbase + CM_OFF_FX + 4 * k, 0, 0);
+                }
+                verdict = k;
+                break;
+            }
+            // publish X_k
+            for (int t = tid; t < CH_NB * CH_NB / 2; t += CH_T) {
+                const int i = t >> 4, j = (t & 15) * 2;
+                ch_u32x4 v;
+                v.x = (unsigned)__double2loint(Xs[i * LDP + j]);     v.y = (unsigned)__double2hiint(Xs[i * LDP + j]);
+                v.z = (unsigned)__double2loint(Xs[i * LDP + j + 1]); v.w = (unsigned)__double2hiint(Xs[i * LDP + j + 1]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, xbase + (unsigned)k * (CH_NB * CH_NB * 8) + (unsigned)t * 16, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(1, rs, fbase + CM_OFF_FX + 4 * k, 0, 0);
+        } else {
+            if (tid == 0) s_flag = cm_poll(rs, fbase + CM_OFF_FX + 4 * k);
+            __syncthreads();
+            if (s_flag != 1u) {                                            // 2: the rung is decided; 0xff: lost contact
+                if (s_flag == 0xffu && tid == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b32(1, rs, CM_OFF_ERR, 0, 16);
+                    info[rung] = CM_INFO_EXCHANGE;
+                }
+                break;
+            }
+            for (int t = tid; t < CH_NB * CH_NB / 2; t += CH_T) {
+                const int i = t >> 4, j = (t & 15) * 2;
+                const ch_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xbase + (unsigned)k * (CH_NB * CH_NB * 8) + (unsigned)t * 16, 0, 16);
+                Xs[i * LDP + j] = __hiloint2double((int)v.y, (int)v.x);
+                Xs[i * LDP + j + 1] = __hiloint2double((int)v.w, (int)v.z);
+            }
+            __syncthreads();
+        }
+        CM_STAMP(0)
+        ahead = false;
+        if (k == jmax) break;                                              // no rows of mine below block k
+        // ---- my rows of the panel: L21 = A21 X^T (16 x 32 per wave and trip) -> LDS and the slab
+        int i_first = 0;                                                   // index of my first block row below k
+        while (cm_row(g, i_first) <= k) ++i_first;
+        int n_own = 0;
+        while (cm_row(g, i_first + n_own) < nblk) ++n_own;
+        for (int t = wave; t < 2 * n_own; t += CH_T / 64) {
+            const int j = cm_row(g, i_first + (t >> 1)), r0 = CH_NB * j + 16 * (t & 1);  // global rows r0 .. r0 + 15
+            const double* arow = A + (size_t)min(r0 + li, n - 1) * ld + kb;
+            double af[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) af[u] = arow[min(4 * u + lk, nb - 1)];
+            ch_double4 acc0 = (ch_double4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = 4 * u + lk;
+                const double a = (kk < nb) ? af[u] : 0.0;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xs[li * LDP + kk], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xs[(16 + li) * LDP + kk], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + lk + 4 * r;
+                if (row < n) {
+                    double* pr = P + (size_t)(row - kb - CH_NB) * LDPP;
+                    pr[li] = acc0[r];
+                    pr[16 + li] = acc1[r];
+                    if (li < nb) A[(size_t)row * ld + kb + li] = acc0[r];
+                    if (16 + li < nb) A[(size_t)row * ld + kb + 16 + li] = acc1[r];
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        CM_STAMP(1)
+        if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(1, rs, fbase + CM_OFF_FP + 4 * (k * CM_G + g), 0, 0);
+        // ---- the panel rows of the others, block rows k + 1 .. jmax
+        if (tid < CM_G && tid != g) {
+            int q = 0;
+            while (cm_row(tid, q) <= k) ++q;
+            const int jf = cm_row(tid, q);                                  // that workgroup's first block row below k
+            unsigned v = 1u;
+            if (jf <= jmax) v = cm_poll(rs, fbase + CM_OFF_FP + 4 * (k * CM_G + tid));
+            if (v != 1u) s_flag = 0xffu;
+        }
+        __syncthreads();
+        CM_STAMP(2)
+        if (s_flag == 0xffu) {
+            if (tid == 0) {
+                __builtin_amdgcn_raw_buffer_store_b32(1, rs, CM_OFF_ERR, 0, 16);
+                info[rung] = CM_INFO_EXCHANGE;
+            }
+            break;
+        }
+        // (512 x 16 bytes = one 32 x 32 block; eight blocks' loads in flight before the first LDS write)
+        for (int cb = k + 1; cb <= jmax; cb += 8) {
+            const int i = tid >> 4, j = (tid & 15) * 2;
+            ch_u32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = cb + q, row = min(CH_NB * c + i, n - 1);
+                if (c <= jmax && cm_owner(c) != g)
+                    v[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)(((size_t)row * ld + kb + j) * 8), 0, 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = cb + q, row = CH_NB * c + i;
+                if (c <= jmax && cm_owner(c) != g && row < n) {
+                    double* pr = P + (size_t)(row - kb - CH_NB) * LDPP + j;
+                    pr[0] = __hiloint2double((int)v[q].y, (int)v[q].x);
+                    pr[1] = __hiloint2double((int)v[q].w, (int)v[q].z);
+                }
+            }
+        }
+        __syncthreads();
+        CM_STAMP(3)
+        // ---- update of my block rows: 16 x 16 tiles (j; c; a, b), k < c <= j, lower triangle of the diagonal tile only
+        {
+            const bool look = cm_owner(k + 1) == g;                       // I own the next diagonal block
+            // wave 0 of the next owner: diagonal tile + factorisation.  Its dependent chain wants the SIMD to itself --
+            // no vector instruction issues beside a running v_mfma_f64 -- so wave 4, which shares SIMD 0
+            // with it, sits the update out (measured: the factorisation took 22 us beside wave 4's MFMAs)
+            const int nwalk = look ? CH_T / 64 - 2 : CH_T / 64;
+            const int wslot = look ? (wave < 4 ? wave - 1 : wave - 2) : wave;
+            const int nr = n - kb - CH_NB;                                 // rows below block k (P's extent)
+            double* const a22 = A + (size_t)(kb + CH_NB) * ld + kb + CH_NB;
+            // my 16-row strips below block k: strip s = rows of block row jfirst + CM_G (s >> 1), half s & 1; its tiles
+            // are the 16-wide columns 0 .. R0 / 16 of P (up to the diagonal).  A wave walks the tiles (linear over
+            // strips) with a cursor, CH_G at a time, the next batch's loads in flight during this batch's MFMAs;
+            // stores of unused slots go to a sink (k_chol's (d), same arithmetic per tile).
+            const int n_strips = 2 * n_own;
+            auto strip_r0 = [&](int sidx) { return CH_NB * (cm_row(g, i_first + (sidx >> 1)) - k - 1) + 16 * (sidx & 1); };
+            if (look && wave == 4) {
+            } else if (look && wave == 0) {
+                __builtin_amdgcn_s_setprio(3);
+                // block row k + 1's diagonal tile (strips 0 and 1: three tiles), then its factorisation
+                const int R0[3] = {0, 16, 16}, C0[3] = {0, 0, 16};
+                double cv[3][4];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        cv[q][e] = a22[(size_t)min(R0[q] + lk + 4 * e, nr - 1) * ld + min(C0[q] + li, nr - 1)];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    ch_double4 acc0 = (ch_double4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+                    const int pa = min(R0[q] + li, nr - 1), pb = min(C0[q] + li, nr - 1);
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[pa * LDPP + 4 * u + lk], P[pb * LDPP + 4 * u + lk], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[pa * LDPP + 4 * u + 4 + lk], P[pb * LDPP + 4 * u + 4 + lk], acc1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = R0[q] + lk + 4 * e, col = C0[q] + li;
+                        double* dst = (row < nr && col <= row) ? a22 + (size_t)row * ld + col : ch_sink + tid;
+                        *dst = cv[q][e] - (acc0[e] + acc1[e]);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                const int kb2 = kb + CH_NB, nb2 = min(CH_NB, n - kb2);
+#pragma unroll
+                for (int t = lane; t < CH_NB * CH_NB; t += 64) {
+                    const int i = t >> 5, j = t & 31;
+                    double v = (i < nb2 && j <= i) ? A[(size_t)(kb2 + i) * ld + kb2 + j] : 0.0;
+                    if (i == j && i < nb2) v += shift;
+                    D[i * LDP + j] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                ch_diag_block(D, Xs, s_dinv, &s_fail, &s_minp, nb2, kb2, lane, nullptr);
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                int cs = look ? 2 : 0, ct = wslot;                         // cursor: strip, tile within the strip
+                int tr[CH_G], tc[CH_G], trn[CH_G], tcn[CH_G];
+                double cv[CH_G][4], cn[CH_G][4];
+#define CM_TAKE(R, C)                                                                           \
+                { while (cs < n_strips && ct > strip_r0(cs) / 16) { ct -= strip_r0(cs) / 16 + 1; ++cs; }   \
+                  R = cs < n_strips ? strip_r0(cs) : -1; C = cs < n_strips ? 16 * ct : 0; ct += nwalk; }
+#define CM_LOAD(DST, R, C)                                                                      \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                   \
+                    DST[e] = a22[(size_t)min(max(R, 0) + lk + 4 * e, nr - 1) * ld + min((C) + li, nr - 1)];
+#pragma unroll
+                for (int q = 0; q < CH_G; ++q) { CM_TAKE(tr[q], tc[q]) CM_LOAD(cv[q], tr[q], tc[q]) }
+                while (tr[0] >= 0) {
+#pragma unroll
+                    for (int q = 0; q < CH_G; ++q) { CM_TAKE(trn[q], tcn[q]) CM_LOAD(cn[q], trn[q], tcn[q]) }
+                    ch_double4 acc[CH_G][2];
+#pragma unroll
+                    for (int q = 0; q < CH_G; ++q) {
+                        acc[q][0] = (ch_double4){0.0, 0.0, 0.0, 0.0};
+                        acc[q][1] = acc[q][0];
+                        const int pa = min(max(tr[q], 0) + li, nr - 1), pb = min(tc[q] + li, nr - 1);
+#pragma unroll
+                        for (int u = 0; u < 8; u += 2) {
+                            acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(P[pa * LDPP + 4 * u + lk], P[pb * LDPP + 4 * u + lk], acc[q][0], 0, 0, 0);
+                            acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(P[pa * LDPP + 4 * u + 4 + lk], P[pb * LDPP + 4 * u + 4 + lk], acc[q][1], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < CH_G; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = tr[q] + lk + 4 * e, col = tc[q] + li;
+                            double* dst = (tr[q] >= 0 && row < nr && col <= row) ? a22 + (size_t)row * ld + col : ch_sink + tid;
+                            *dst = cv[q][e] - (acc[q][0][e] + acc[q][1][e]);
+                        }
+#pragma unroll
+                    for (int q = 0; q < CH_G; ++q) {
+                        tr[q] = trn[q]; tc[q] = tcn[q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cv[q][e] = cn[q][e];
+                    }
+                }
+#undef CM_TAKE
+#undef CM_LOAD
+            }
+            CM_STAMP(4)
+            ahead = look;
+        }
+        __threadfence_block();
+        __syncthreads();
+        CM_STAMP(5)
+    }
+#ifdef CM_STAMPS
+    if (tid == 0 && n >= 480) { for (int q = 0; q < 6; ++q) A[(size_t)g * ld + 400 + q] = (double)cs_t[q]; A[(size_t)g * ld + 410] = ch_dbg[0]; A[(size_t)g * ld + 411] = ch_dbg[1]; }
+#endif
+    if (verdict >= 0 && tid == 0) {
+        double mp = s_minp;                                                // every block's owner left its running minimum
+        for (int q = 0; q < verdict; ++q) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, fbase + CM_OFF_MP + 8 * q, 0, 16);
+            const unsigned hi = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, fbase + CM_OFF_MP + 8 * q + 4, 0, 16);
+            mp = fmin(mp, __hiloint2double((int)hi, (int)lo));
+        }
+        info[rung] = s_fail;
+        if (min_pivot) min_pivot[rung] = mp;
+    }
+}
+
 // Q = Y L^-T (the Q factor of CholeskyQR) on the matrix cores, from the INVERTED 32 x 32 diagonal blocks that
 // k_chol leaves behind (xinv): for column block jb
 //     Q_jb = (Y_jb - sum_{kb < jb} Q_kb L[jb][kb]^T) X_jb^T ,      X_jb = L[jb][jb]^-1 ,
@@ -566,6 +915,41 @@ extern "C" int sober_cholesky_probe_piv(const double* src, int n, int ld_src, co
                                 160 * 1024 - 512));
     hipLaunchKernelGGL(sober::k_chol<false>, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
                        info, min_pivot, src, ld_src, shifts, (double*)nullptr, (double*)nullptr);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// workspace of the multi-CU probe: header + flags (zeroed per call) | the published inverses
+extern "C" int64_t sober_cholesky_probe_mc_ws_bytes(int n, int n_shifts) {
+    if (n <= 0 || n_shifts <= 0 || n_shifts > 16 || n > sober::CH_MAXN) return 0;
+    const int64_t flags = ((int64_t)sober::CM_HDR + (int64_t)n_shifts * sober::CM_RUNG_BYTES + 255) / 256 * 256;
+    return flags + (int64_t)n_shifts * sober::CM_MAXB * sober::CH_NB * sober::CH_NB * 8;
+}
+
+// sober_cholesky_probe_piv with CM_G workgroups per rung (n_shifts <= 16).  info[r] = -7: the rung's workgroups lost each
+// other (bounded spins; e.g. a dispatcher that does not spread 256 workgroups evenly over the XCDs) -- no verdict
+// for that rung, the caller falls back to sober_cholesky_probe_piv or the host.
+extern "C" int sober_cholesky_probe_mc(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
+                                       double* work, int32_t* info, double* min_pivot, void* ws, int64_t ws_bytes,
+                                       void* stream) {
+    if (!src || !shifts || !work || !info || !ws || n <= 0 || ld_src < n || n_shifts <= 0) return SOBER_E_ARG;
+    if (n > sober::CH_MAXN || n_shifts > 16) return SOBER_E_DIM;
+    const int64_t need = sober_cholesky_probe_mc_ws_bytes(n, n_shifts);
+    if (ws_bytes < need || need > 0x7fffffff) return SOBER_E_WS;
+    const int64_t flags = ((int64_t)sober::CM_HDR + (int64_t)n_shifts * sober::CM_RUNG_BYTES + 255) / 256 * 256;
+    const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
+    const size_t bytes = ((size_t)2 * sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * sober::CH_LDPP) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol_mc, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 512));
+        attr_set = true;
+    }
+    HIP_TRY(hipMemsetAsync(ws, 0, (size_t)flags, (hipStream_t)stream));
+    // one workgroup per CU (the LDS request sees to that), 32 per XCD: 16 of them find a seat (two rungs x CM_G)
+    const size_t lds_bytes = bytes > (size_t)84 * 1024 ? bytes : (size_t)84 * 1024;
+    hipLaunchKernelGGL(sober::k_chol_mc, dim3(256), dim3(sober::CH_T), lds_bytes, (hipStream_t)stream, work, n, n, info,
+                       min_pivot, src, ld_src, shifts, n_shifts, (unsigned char*)ws, (unsigned)need, (unsigned)flags);
     LAUNCH_CHECK();
     return 0;
 }

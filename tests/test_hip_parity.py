@@ -1431,3 +1431,47 @@ def test_device_randn_is_the_cpu_generators_draw():
         err = (got.cpu() - want).abs()
         assert float(err.max()) <= 4e-15, float(err.max())
         assert float((err == 0).double().mean()) > 0.5
+
+
+@pytest.mark.gpu
+def test_ladder_probe_on_eight_workgroups_equals_one_workgroup_probe():
+    """sober_cholesky_probe_mc (block rows dealt over eight workgroups per rung) against sober_cholesky_probe_piv:
+    same info and the same smallest pivots, bit for bit, for rungs that pass, fail early and fail late, sizes with
+    a ragged last block and sizes below one panel per workgroup (SOBER/_utils.py:117-157: only success / failure of
+    torch.linalg.cholesky(cov + jitter I) is used)."""
+    from sober_amd import _native as nat
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    n_r = 11
+    shifts = torch.tensor([1e-5 * (2 ** k - 1) for k in range(n_r)], dtype=torch.float64, device=dev)
+    for M, ls, neg in ((500, 0.6, 0.0), (500, 0.6, 3e-4), (536, 1.0, 1e-3), (257, 2.0, 0.0), (100, 1.0, 0.0),
+                       (33, 1.0, 1e-4), (32, 1.0, 0.0), (480, 5.0, 1e-2), (7, 1.0, 0.0)):
+        X = rng.random((M, 10))
+        K = np.exp(-0.5 * ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1) / ls)
+        if neg:
+            v = rng.standard_normal(M)
+            K = K - neg * np.outer(v, v) / (v @ v)
+        C = torch.from_numpy(K).to(dev)
+        i1 = torch.zeros(n_r, dtype=torch.int32, device=dev)
+        p1 = torch.zeros(n_r, dtype=torch.float64, device=dev)
+        i2 = torch.full((n_r,), 99, dtype=torch.int32, device=dev)
+        p2 = torch.zeros(n_r, dtype=torch.float64, device=dev)
+        w1 = torch.empty(n_r * M * M, dtype=torch.float64, device=dev)
+        w2 = torch.empty_like(w1)
+        ws = torch.empty(nat.cholesky_probe_mc_ws_bytes(M, n_r), dtype=torch.uint8, device=dev)
+        nat.cholesky_probe(C, shifts, w1, i1, p1)
+        for _ in range(3):                                     # (the workspace is reused: flags are cleared per call)
+            nat.cholesky_probe_mc(C, shifts, w2, i2, p2, ws)
+        torch.cuda.synchronize()
+        assert i1.cpu().tolist() == i2.cpu().tolist(), (M, i1.cpu().tolist(), i2.cpu().tolist())
+        assert np.array_equal(p1.cpu().numpy(), p2.cpu().numpy()), M
+        # against LAPACK: info == 0 exactly where numpy's Cholesky succeeds (these matrices are not borderline)
+        for k in range(n_r):
+            try:
+                np.linalg.cholesky(K + float(shifts[k]) * np.eye(M))
+                ok = True
+            except np.linalg.LinAlgError:
+                ok = False
+            piv = float(p1[k])
+            if abs(piv) > 1e-9 * K.diagonal().max():
+                assert (int(i1[k]) == 0) == ok, (M, k, int(i1[k]), piv)
