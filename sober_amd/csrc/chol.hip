@@ -21,7 +21,7 @@ constexpr int CH_MAXN = 536;         // panel (n - NB) x LDPP doubles + two NB x
 typedef double ch_double4 __attribute__((ext_vector_type(4)));
 
 constexpr int CH_G = 4;              // tiles of the trailing update per wave and trip
-__device__ double ch_sink[CH_T];
+__device__ double ch_sink[CH_T];     // where the stores of lanes outside the lower triangle go (never read)
 #ifdef CM_STAMPS
 __device__ double ch_dbg[2];        // diagnostic build: ticks of the last ch_diag_block (factorisation, inversion)
 #endif     // where the stores of lanes outside the lower triangle go (never read)
@@ -60,28 +60,34 @@ __device__ __attribute__((noinline)) void ch_diag_block(double* __restrict__ D, 
             // then the substitution with its multipliers read back from LDS 7.0 us -- the whole launch's critical path.)
             // A failed pivot only records itself; what is computed after it is never used.  Rows and columns >= nb are
             // an identity block (pivots 1, not counted).
-            // Both halves of the wave do the same 32 rows (i = lane & 31): every lane stays active, there is no
-            // exec juggling around the LDS writes (the twin lanes write the same values to the same places), and
-            // column j of L and row j of X leave the registers as soon as they are final -- 64 doubles live at the
-            // start, fewer with every column (all 64 of d[] and x[] held to the end spilled to scratch).
+            // The two halves of the wave split the work: lane i < 32 holds row i of the block being factorised
+            // (v = L's row), lane 32 + i holds column i of the inverse being built (v = X's column).  Both obey the SAME
+            // update v[c] -= v[j] L[c][j] with the same broadcast multipliers, so one fma per (j, c) serves both;
+            // only the scaling of column j differs (a select).  Column j of L and row j of X leave the registers as soon
+            // as they are final (every lane writes, none is masked off).
             const int i = lane & (CH_NB - 1);
-            double d[CH_NB], x[CH_NB];
+            const bool xh = lane >= CH_NB;                   // the inverse's half
+            double v[CH_NB];
 #ifdef CM_STAMPS
             const long long dbg0 = wall_clock64();
 #endif
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) {
-                const double dv = D[i * LDP + c];             // (rows >= nb are zero padded: read, then replaced)
-                d[c] = (i < nb) ? dv : ((c == i) ? 1.0 : 0.0);
-                x[c] = (c == i) ? 1.0 : 0.0;
+                double dv = D[i * LDP + c];                   // (rows >= nb are zero padded: read, then replaced)
+                asm volatile("" : "+v"(dv));                  // (an unconditional load: no branch around it per column)
+                v[c] = (xh | (i >= nb)) ? ((c == i) ? 1.0 : 0.0) : dv;      // identity: X's start, and the padding rows
             }
-            double* xo = xout != nullptr ? xout + (size_t)(kb / CH_NB) * CH_NB * CH_NB : ch_sink;
-            const int xo_ld = xout != nullptr ? CH_NB : 0, xo_i = xout != nullptr ? i : lane;
+            const bool xw = xout != nullptr && xh;           // this lane's X entries also go to the caller's xout
+            double* xo = xw ? xout + (size_t)(kb / CH_NB) * CH_NB * CH_NB : ch_sink;
+            const int xo_ld = xw ? CH_NB : 0, xo_i = xw ? i : lane;
+            // where a final entry goes: L[i][j] -> D[i][j]; X[j][i] -> Xs[j][i]  (Xs = D + NB * LDP by construction)
+            double* const o_base = xh ? Xs + i : D + i * LDP;
+            const int o_step = xh ? LDP : 1;
             int fail = 0;
             double minp = s_minp;
 #pragma unroll
             for (int j = 0; j < CH_NB; ++j) {
-                const double djj = ch_rdlane(d[j], j);
+                const double djj = ch_rdlane(v[j], j);
                 const bool live = (j < nb) & (fail == 0);     // uniform
                 minp = live ? fmin(minp, djj) : minp;         // (the failing pivot, <= 0, included: how far from positive definite)
                 fail = (live & !(djj > 0.0)) ? kb + j + 1 : fail;       // also catches NaN
@@ -97,18 +103,16 @@ __device__ __attribute__((noinline)) void ch_diag_block(double* __restrict__ D, 
                 }
                 double l = djj * rinv;
                 l = fma(fma(-l, l, djj), 0.5 * rinv, l);
-                d[j] = (i == j) ? l : ((i > j) ? d[j] * rinv : 0.0);
-                x[j] *= rinv;                                 // x[j] / L[j][j]
-                D[i * LDP + j] = d[j];                        // L[i][j], final   (rows >= nb: the identity row)
-                Xs[j * LDP + i] = x[j];                       // X[j][i], final
-                xo[j * xo_ld + xo_i] = x[j];                  // (the inverted diagonal blocks feed k_trsm_blocks)
+                const double sc = v[j] * rinv;                // L[i][j] = a / L[j][j];  x[j] / L[j][j]
+                v[j] = xh ? sc : ((i == j) ? l : ((i > j) ? sc : 0.0));
+                o_base[j * o_step] = v[j];
+                xo[j * xo_ld + xo_i] = v[j];                  // (the inverted diagonal blocks feed k_trsm_blocks)
                 // (the multipliers L[c][j] read back from the column just written to LDS -- one wave-uniform ds_read per
                 //  two of them instead of two v_readlane each -- measured 9.3 us against 8.2 us for this form)
 #pragma unroll
                 for (int c = j + 1; c < CH_NB; ++c) {
-                    const double lcj = ch_rdlane(d[j], c);    // L[c][j]
-                    d[c] = fma(-d[j], lcj, d[c]);             // rows i < c: unused upper-triangle values
-                    x[c] = fma(-lcj, x[j], x[c]);
+                    const double lcj = ch_rdlane(v[j], c);    // L[c][j]  (lane c < 32: the factor's half)
+                    v[c] = fma(-v[j], lcj, v[c]);             // rows i < c: unused upper-triangle values
                 }
             }
             if (lane == 0) { s_fail = fail; s_minp = minp; }
