@@ -41,7 +41,7 @@ for n in (99, 128, 198, 500):
     run(); torch.cuda.synchronize()
     Wh = W.cpu().numpy()
     err = np.abs(np.tril(Wh) - np.linalg.cholesky(S)).max()
-    print("k_chol n=%d: %.1f us (copy %.1f us subtracted), err %.2e, stamps(ticks a/b-inverse/c/d/b-factorisation) %s" % (n, t - tc, tc, err, Wh[0, 8:13].tolist()))
+    print("k_chol n=%d: %.1f us (copy %.1f us subtracted), err %.2e, stamps(ticks: (a) load D, (b) diagonal block, (c) panel, (d) update + look-ahead, copy back) %s" % (n, t - tc, tc, err, Wh[0, 8:13].tolist()))
 
 for m, q in ((500, 99), (500, 199)):
     Y = torch.from_numpy(rng.standard_normal((m, q))).to(dev)

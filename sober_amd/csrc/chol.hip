@@ -46,7 +46,8 @@ __device__ __forceinline__ double ch_rdlane(double v, int l) {
 //       tile per wave and trip, the next tile of A22 already in flight.
 // (b) of k_chol, by ONE wave: Cholesky of the 32 x 32 diagonal block D (LDS, lower part, zero padded) in registers
 // (lane = row; pivots and multipliers are v_readlane broadcasts), L11 back to D, its inverse to Xs (and to xo).
-__device__ __attribute__((noinline)) void ch_diag_block(double* __restrict__ D, double* __restrict__ Xs, double* __restrict__ s_dinv,
+template <int NC>      // NC = 8 / 16 / 32 columns are factorised (nb <= NC); the rest of the block is identity
+__device__ __attribute__((noinline)) void ch_diag_block_n(double* __restrict__ D, double* __restrict__ Xs, double* __restrict__ s_dinv,
                                               int* __restrict__ s_fail_p, double* __restrict__ s_minp_p, int nb, int kb,
                                               int lane, double* __restrict__ xout) {
     constexpr int LDP = CH_NB + 1;
@@ -86,7 +87,7 @@ __device__ __attribute__((noinline)) void ch_diag_block(double* __restrict__ D, 
             int fail = 0;
             double minp = s_minp;
 #pragma unroll
-            for (int j = 0; j < CH_NB; ++j) {
+            for (int j = 0; j < NC; ++j) {
                 const double djj = ch_rdlane(v[j], j);
                 const bool live = (j < nb) & (fail == 0);     // uniform
                 minp = live ? fmin(minp, djj) : minp;         // (the failing pivot, <= 0, included: how far from positive definite)
@@ -110,16 +111,27 @@ __device__ __attribute__((noinline)) void ch_diag_block(double* __restrict__ D, 
                 // (the multipliers L[c][j] read back from the column just written to LDS -- one wave-uniform ds_read per
                 //  two of them instead of two v_readlane each -- measured 9.3 us against 8.2 us for this form)
 #pragma unroll
-                for (int c = j + 1; c < CH_NB; ++c) {
+                for (int c = j + 1; c < NC; ++c) {            // (columns >= NC >= nb: identity, their multipliers are zero)
                     const double lcj = ch_rdlane(v[j], c);    // L[c][j]  (lane c < 32: the factor's half)
                     v[c] = fma(-v[j], lcj, v[c]);             // rows i < c: unused upper-triangle values
                 }
             }
+#pragma unroll
+            for (int j = NC; j < CH_NB; ++j) { o_base[j * o_step] = v[j]; xo[j * xo_ld + xo_i] = v[j]; }   // the identity part
             if (lane == 0) { s_fail = fail; s_minp = minp; }
 #ifdef CM_STAMPS
             if (lane == 0) { ch_dbg[0] = (double)(wall_clock64() - dbg0); ch_dbg[1] = 0.0; }
 #endif
         }
+
+// a ragged last block (nb = 3 at q = 99, 7 at q = 199) pays for the columns it has, rounded up to 8 or 16
+__device__ __forceinline__ void ch_diag_block(double* __restrict__ D, double* __restrict__ Xs, double* __restrict__ s_dinv,
+                                              int* __restrict__ s_fail_p, double* __restrict__ s_minp_p, int nb, int kb,
+                                              int lane, double* __restrict__ xout) {
+    if (nb <= 8) ch_diag_block_n<8>(D, Xs, s_dinv, s_fail_p, s_minp_p, nb, kb, lane, xout);
+    else if (nb <= 16) ch_diag_block_n<16>(D, Xs, s_dinv, s_fail_p, s_minp_p, nb, kb, lane, xout);
+    else ch_diag_block_n<CH_NB>(D, Xs, s_dinv, s_fail_p, s_minp_p, nb, kb, lane, xout);
+}
 
 // SMALL (n <= CH_SMALLN, one matrix): the matrix itself is staged into LDS and every phase works there -- the q x q Gram
 // matrices of CholeskyQR (q = batch - 1 ~ 100) spent most of their 86 us per call on global-memory round trips between
@@ -335,15 +347,18 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
         __syncthreads();
         CH_STAMP(3)
     }
-#ifdef CH_STAMPS
-    if (tid == 0 && n >= 16)                               // debugging build: ticks (100 MHz) in row 0's upper triangle
-        for (int k = 0; k < 4; ++k) A[8 + k] = (double)st_t[k];
-#endif
     if constexpr (SMALL) {                   // L back to the caller's matrix (rows finished before a failure included)
         __syncthreads();
         for (int i = tid >> 6; i < n; i += CH_T / 64)
             for (int j = tid & 63; j <= i; j += 64) A_glob[(size_t)i * ld_glob + j] = A[i * (n + 1) + j];
     }
+#ifdef CH_STAMPS
+    {
+        CH_STAMP(4)                                        // (the copy back)
+        if (tid == 0 && n >= 16)                           // debugging build: ticks (100 MHz) in row 0's upper triangle
+            for (int k = 0; k < 5; ++k) A_glob[8 + k] = (double)st_t[k];
+    }
+#endif
     if (tid == 0) {
         *info = s_fail;
         if (min_pivot) *min_pivot = s_minp;
