@@ -425,6 +425,8 @@ __global__ __launch_bounds__(CH_T) void k_chol_mc(double* __restrict__ work, int
     __shared__ double s_minp;
     __shared__ double s_dinv[CH_NB];
     __shared__ unsigned s_flag;
+    __shared__ int s_sub;                                                  // arrivals at the barrier of waves 1 .. 7
+    int sub_epoch = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const ch_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)ws_bytes, 0x00020000);
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(CH_T) void k_chol_mc(double* __restrict__ work, int
         s_role = rung < (unsigned)n_rungs ? (int)(rung * CM_G + t % CM_G) : -1;
         s_fail = 0;
         s_flag = 0u;
+        s_sub = 0;
         s_minp = __builtin_inf();
     }
     __syncthreads();
@@ -564,103 +567,62 @@ __global__ __launch_bounds__(CH_T) void k_chol_mc(double* __restrict__ work, int
         __syncthreads();
         CM_STAMP(1)
         if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(1, rs, fbase + CM_OFF_FP + 4 * (k * CM_G + g), 0, 0);
+        // I own the next diagonal block: its tile needs my own panel rows only, so wave 0 goes straight on to that tile and
+        // the factorisation -- the chain of the whole launch -- while waves 1 .. 7 wait for the other workgroups' panel rows,
+        // fetch them and update the rest of my rows behind a barrier of their own (an LDS counter: s_barrier counts all
+        // eight waves).  Everybody else does the three phases with workgroup barriers.
+        const bool look = cm_owner(k + 1) == g;
+        const int nr = n - kb - CH_NB;                                     // rows below block k (P's extent)
+        double* const a22 = A + (size_t)(kb + CH_NB) * ld + kb + CH_NB;
+        const int n_strips = 2 * n_own;
+        // my 16-row strips below block k: strip s = half s & 1 of my (s >> 1)-th block row below k; its tiles are the
+        // 16-wide columns 0 .. R0 / 16 of P (up to the diagonal)
+        auto strip_r0 = [&](int sidx) { return CH_NB * (cm_row(g, i_first + (sidx >> 1)) - k - 1) + 16 * (sidx & 1); };
+        auto sub_barrier = [&]() {                                         // waves 1 .. 7 of this workgroup
+            ++sub_epoch;
+            if (lane == 0) __hip_atomic_fetch_add(&s_sub, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&s_sub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 7 * sub_epoch)
+                __builtin_amdgcn_s_sleep(1);
+        };
         // ---- the panel rows of the others, block rows k + 1 .. jmax
-        if (tid < CM_G && tid != g) {
-            int q = 0;
-            while (cm_row(tid, q) <= k) ++q;
-            const int jf = cm_row(tid, q);                                  // that workgroup's first block row below k
-            unsigned v = 1u;
-            if (jf <= jmax) v = cm_poll(rs, fbase + CM_OFF_FP + 4 * (k * CM_G + tid));
-            if (v != 1u) s_flag = 0xffu;
-        }
-        __syncthreads();
-        CM_STAMP(2)
-        if (s_flag == 0xffu) {
-            if (tid == 0) {
-                __builtin_amdgcn_raw_buffer_store_b32(1, rs, CM_OFF_ERR, 0, 16);
-                info[rung] = CM_INFO_EXCHANGE;
+        auto poll_others = [&](int o) {                                    // o: the other workgroup this lane asks
+            if (o < CM_G && o != g) {
+                int q = 0;
+                while (cm_row(o, q) <= k) ++q;
+                const int jf = cm_row(o, q);                               // that workgroup's first block row below k
+                unsigned v = 1u;
+                if (jf <= jmax) v = cm_poll(rs, fbase + CM_OFF_FP + 4 * (k * CM_G + o));
+                if (v != 1u) s_flag = 0xffu;
             }
-            break;
-        }
+        };
         // (512 x 16 bytes = one 32 x 32 block; eight blocks' loads in flight before the first LDS write)
-        for (int cb = k + 1; cb <= jmax; cb += 8) {
-            const int i = tid >> 4, j = (tid & 15) * 2;
-            ch_u32x4 v[8];
+        auto gather = [&](int t0, int nthr) {
+            for (int cb = k + 1; cb <= jmax; cb += 8)
+                for (int gi = t0; gi < CH_NB * CH_NB / 2; gi += nthr) {
+                    const int i = gi >> 4, j = (gi & 15) * 2;
+                    ch_u32x4 v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int c = cb + q, row = min(CH_NB * c + i, n - 1);
-                if (c <= jmax && cm_owner(c) != g)
-                    v[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)(((size_t)row * ld + kb + j) * 8), 0, 16);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int c = cb + q, row = CH_NB * c + i;
-                if (c <= jmax && cm_owner(c) != g && row < n) {
-                    double* pr = P + (size_t)(row - kb - CH_NB) * LDPP + j;
-                    pr[0] = __hiloint2double((int)v[q].y, (int)v[q].x);
-                    pr[1] = __hiloint2double((int)v[q].w, (int)v[q].z);
-                }
-            }
-        }
-        __syncthreads();
-        CM_STAMP(3)
-        // ---- update of my block rows: 16 x 16 tiles (j; c; a, b), k < c <= j, lower triangle of the diagonal tile only
-        {
-            const bool look = cm_owner(k + 1) == g;                       // I own the next diagonal block
-            // wave 0 of the next owner: diagonal tile + factorisation.  Its dependent chain wants the SIMD to itself --
-            // no vector instruction issues beside a running v_mfma_f64 -- so wave 4, which shares SIMD 0
-            // with it, sits the update out (measured: the factorisation took 22 us beside wave 4's MFMAs)
-            const int nwalk = look ? CH_T / 64 - 2 : CH_T / 64;
-            const int wslot = look ? (wave < 4 ? wave - 1 : wave - 2) : wave;
-            const int nr = n - kb - CH_NB;                                 // rows below block k (P's extent)
-            double* const a22 = A + (size_t)(kb + CH_NB) * ld + kb + CH_NB;
-            // my 16-row strips below block k: strip s = rows of block row jfirst + CM_G (s >> 1), half s & 1; its tiles
-            // are the 16-wide columns 0 .. R0 / 16 of P (up to the diagonal).  A wave walks the tiles (linear over
-            // strips) with a cursor, CH_G at a time, the next batch's loads in flight during this batch's MFMAs;
-            // stores of unused slots go to a sink (k_chol's (d), same arithmetic per tile).
-            const int n_strips = 2 * n_own;
-            auto strip_r0 = [&](int sidx) { return CH_NB * (cm_row(g, i_first + (sidx >> 1)) - k - 1) + 16 * (sidx & 1); };
-            if (look && wave == 4) {
-            } else if (look && wave == 0) {
-                __builtin_amdgcn_s_setprio(3);
-                // block row k + 1's diagonal tile (strips 0 and 1: three tiles), then its factorisation
-                const int R0[3] = {0, 16, 16}, C0[3] = {0, 0, 16};
-                double cv[3][4];
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        cv[q][e] = a22[(size_t)min(R0[q] + lk + 4 * e, nr - 1) * ld + min(C0[q] + li, nr - 1)];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    ch_double4 acc0 = (ch_double4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-                    const int pa = min(R0[q] + li, nr - 1), pb = min(C0[q] + li, nr - 1);
-#pragma unroll
-                    for (int u = 0; u < 8; u += 2) {
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[pa * LDPP + 4 * u + lk], P[pb * LDPP + 4 * u + lk], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[pa * LDPP + 4 * u + 4 + lk], P[pb * LDPP + 4 * u + 4 + lk], acc1, 0, 0, 0);
+                    for (int q = 0; q < 8; ++q) {
+                        const int c = cb + q, row = min(CH_NB * c + i, n - 1);
+                        if (c <= jmax && cm_owner(c) != g)
+                            v[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)(((size_t)row * ld + kb + j) * 8), 0, 16);
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int row = R0[q] + lk + 4 * e, col = C0[q] + li;
-                        double* dst = (row < nr && col <= row) ? a22 + (size_t)row * ld + col : ch_sink + tid;
-                        *dst = cv[q][e] - (acc0[e] + acc1[e]);
+                    for (int q = 0; q < 8; ++q) {
+                        const int c = cb + q, row = CH_NB * c + i;
+                        if (c <= jmax && cm_owner(c) != g && row < n) {
+                            double* pr = P + (size_t)(row - kb - CH_NB) * LDPP + j;
+                            pr[0] = __hiloint2double((int)v[q].y, (int)v[q].x);
+                            pr[1] = __hiloint2double((int)v[q].w, (int)v[q].z);
+                        }
                     }
                 }
-                __builtin_amdgcn_s_waitcnt(0);
-                const int kb2 = kb + CH_NB, nb2 = min(CH_NB, n - kb2);
-#pragma unroll
-                for (int t = lane; t < CH_NB * CH_NB; t += 64) {
-                    const int i = t >> 5, j = t & 31;
-                    double v = (i < nb2 && j <= i) ? A[(size_t)(kb2 + i) * ld + kb2 + j] : 0.0;
-                    if (i == j && i < nb2) v += shift;
-                    D[i * LDP + j] = v;
-                }
-                __builtin_amdgcn_wave_barrier();
-                ch_diag_block(D, Xs, s_dinv, &s_fail, &s_minp, nb2, kb2, lane, nullptr);
-                __builtin_amdgcn_s_setprio(0);
-            } else {
-                int cs = look ? 2 : 0, ct = wslot;                         // cursor: strip, tile within the strip
+        };
+        // ---- update of my block rows: a wave walks the 16 x 16 tiles (linear over strips from strip cs0) with a cursor,
+        // CH_G at a time, the next batch's loads in flight during this batch's MFMAs; stores of unused slots go to a sink
+        // (k_chol's (d), same arithmetic per tile)
+        auto walk = [&](int cs0, int wslot, int nwalk) {
+            int cs = cs0, ct = wslot;                                      // cursor: strip, tile within the strip
                 int tr[CH_G], tc[CH_G], trn[CH_G], tcn[CH_G];
                 double cv[CH_G][4], cn[CH_G][4];
 #define CM_TAKE(R, C)                                                                           \
@@ -703,13 +665,72 @@ __global__ __launch_bounds__(CH_T) void k_chol_mc(double* __restrict__ work, int
                 }
 #undef CM_TAKE
 #undef CM_LOAD
+        };
+        if (!look) {
+            poll_others(tid);
+            __syncthreads();
+            CM_STAMP(2)
+            if (s_flag != 0xffu) gather(tid, CH_T);
+            __syncthreads();
+            CM_STAMP(3)
+            if (s_flag != 0xffu) walk(0, wave, CH_T / 64);
+        } else if (wave == 0) {
+            __builtin_amdgcn_s_setprio(3);
+            // block row k + 1's diagonal tile (strips 0 and 1: three tiles), then its factorisation
+            const int R0[3] = {0, 16, 16}, C0[3] = {0, 0, 16};
+            double cv[3][4];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    cv[q][e] = a22[(size_t)min(R0[q] + lk + 4 * e, nr - 1) * ld + min(C0[q] + li, nr - 1)];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                ch_double4 acc0 = (ch_double4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+                const int pa = min(R0[q] + li, nr - 1), pb = min(C0[q] + li, nr - 1);
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[pa * LDPP + 4 * u + lk], P[pb * LDPP + 4 * u + lk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[pa * LDPP + 4 * u + 4 + lk], P[pb * LDPP + 4 * u + 4 + lk], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = R0[q] + lk + 4 * e, col = C0[q] + li;
+                    double* dst = (row < nr && col <= row) ? a22 + (size_t)row * ld + col : ch_sink + tid;
+                    *dst = cv[q][e] - (acc0[e] + acc1[e]);
+                }
             }
-            CM_STAMP(4)
-            ahead = look;
+            __builtin_amdgcn_s_waitcnt(0);
+            const int kb2 = kb + CH_NB, nb2 = min(CH_NB, n - kb2);
+#pragma unroll
+            for (int t = lane; t < CH_NB * CH_NB; t += 64) {
+                const int i = t >> 5, j = t & 31;
+                double v = (i < nb2 && j <= i) ? A[(size_t)(kb2 + i) * ld + kb2 + j] : 0.0;
+                if (i == j && i < nb2) v += shift;
+                D[i * LDP + j] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            ch_diag_block(D, Xs, s_dinv, &s_fail, &s_minp, nb2, kb2, lane, nullptr);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            if (wave == 1) poll_others(lane);
+            sub_barrier();
+            if (s_flag != 0xffu) gather(tid - 64, CH_T - 64);
+            sub_barrier();
+            if (s_flag != 0xffu) walk(2, wave - 1, CH_T / 64 - 1);      // (strips 0 and 1, the next diagonal tile, are wave 0's)
         }
+        CM_STAMP(4)
+        ahead = look;
         __threadfence_block();
         __syncthreads();
         CM_STAMP(5)
+        if (s_flag == 0xffu) {
+            if (tid == 0) {
+                __builtin_amdgcn_raw_buffer_store_b32(1, rs, CM_OFF_ERR, 0, 16);
+                info[rung] = CM_INFO_EXCHANGE;
+            }
+            break;
+        }
     }
 #ifdef CM_STAMPS
     if (tid == 0 && n >= 480) { for (int q = 0; q < 6; ++q) A[(size_t)g * ld + 400 + q] = (double)cs_t[q]; A[(size_t)g * ld + 410] = ch_dbg[0]; A[(size_t)g * ld + 411] = ch_dbg[1]; }
