@@ -830,7 +830,11 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
     double rt[4], rc[4];
     unsigned kh[4], kl[4];
 #pragma unroll
+#ifdef SP_X_NODIV      // timing-only builds (wrong results): what each part of the producer's loop costs
+    for (int q = 0; q < 4; ++q) { rt[q] = st.mu[q] * col[q]; rc[q] = col[q]; }
+#else
     for (int q = 0; q < 4; ++q) { rt[q] = st.mu[q] / col[q]; rc[q] = 1.0 / col[q]; }
+#endif
     unsigned hmin = 0xffffffffu;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -840,7 +844,11 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
         kl[q] = ok ? (unsigned)k : 0xffffffffu;
         hmin = min(hmin, kh[q]);
     }
+#ifdef SP_X_NOMIN
+    const unsigned H = (unsigned)__builtin_amdgcn_readfirstlane((int)hmin);
+#else
     const unsigned H = wave_min_u32(hmin);
+#endif
     piv = -1; al = 0.0; rp = 1.0;
     if (H == 0xffffffffu) return;                                     // uniform: no candidate (:241-242)
     unsigned long long mb[4];
@@ -910,6 +918,32 @@ __device__ __forceinline__ bool sp_consume(SpSlot* ring, int s, int lane, double
     return true;
 }
 
+// pivot `sp` from column JJ of my block: ratio test, publish, update of my weights and of my columns behind JJ
+template <int JJ>
+__device__ __forceinline__ void sp_produce_step(double (&phi)[SP_BC][4], SpState& st, SpSlot* ring, int sp, int lane,
+                                                double (&col)[4], bool& stop) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[JJ][q];
+    int piv;
+    double al, rp;
+    sp_ratio_test(col, st, piv, al, rp);
+    SpSlot& e = ring[sp % SP_RING];
+#ifndef SP_X_NOPUB
+    if (piv >= 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e.col[lane + 64 * q] = col[q];
+    }
+#endif
+    if (lane == 0) { e.alpha = al; e.rpp = rp; e.piv = piv; }
+    asm volatile("" ::: "memory");                            // (program order; a wave's LDS operations execute in order:
+    if (lane == 0) *(volatile int*)&e.tag = sp + 1;           //  the tag lands after the data it releases -- no wait)
+    if (piv < 0) { stop = true; return; }                     // Q6: the loop ends here (:241-242)
+    sp_mu_step(st, col, al, piv, lane);
+#ifndef SP_X_NOELIM
+    sp_elim<JJ + 1>(phi, col, piv, rp);
+#endif
+}
+
 __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __restrict__ Phi, int N, int m,
                                                                 const double* __restrict__ mu_in,
                                                                 int32_t* __restrict__ keep_rank,
@@ -976,30 +1010,13 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
                 __builtin_amdgcn_s_sleep(2);
             }
         }
-        for (int sp = c0; sp < s_end && !fail && !stop; ++sp) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[0][q];
-            int piv;
-            double al, rp;
-            sp_ratio_test(col, st, piv, al, rp);
-            SpSlot& e = ring[sp % SP_RING];
-            if (piv >= 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e.col[lane + 64 * q] = col[q];
-            }
-            if (lane == 0) { e.alpha = al; e.rpp = rp; e.piv = piv; }
-            asm volatile("" ::: "memory");                            // (program order; a wave's LDS operations execute in order:
-            if (lane == 0) *(volatile int*)&e.tag = sp + 1;           //  the tag lands after the data it releases -- no wait)
-            if (piv < 0) { stop = true; break; }                      // Q6: the loop ends here (:241-242)
-            sp_mu_step(st, col, al, piv, lane);
-            sp_elim<1>(phi, col, piv, rp);                            // (consumed slots hold zeros and stay zero)
-#pragma unroll
-            for (int j = 0; j + 1 < SP_BC; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) phi[j][q] = phi[j + 1][q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) phi[SP_BC - 1][q] = 0.0;
-        }
+        // one instance of the step per column of my block: the columns keep their registers (rotating them down after
+        // every pivot -- 24 doubles moved behind the elimination they depend on -- cost 15 % of the kernel)
+        int sp = c0;
+#define SP_STEP(JJ) if (sp < s_end && !stop) { sp_produce_step<JJ>(phi, st, ring, sp, lane, col, stop); ++sp; }
+        SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6)
+#undef SP_STEP
+        static_assert(SP_BC == 7, "one SP_STEP per column of a block");
         __builtin_amdgcn_s_setprio(0);
     }
     if (w != 0) return;
