@@ -247,25 +247,30 @@ __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], in
         CB_STAMP(1);
         CAR_LDS_BARRIER();
         CB_STAMP(2);
+        double tG[CAR_MS], vG[CAR_CQ];
         {                                                              // (B)
             const double tau = L.scal[1];
             double v[CAR_CQ];
 #pragma unroll
             for (int q = S; q < CAR_CQ; ++q) v[q] = L.vbuf[C + 16 * q];
+            // the row sums first, then column slot S alone -- it holds column i, which H(i) is built from -- and its
+            // publication; the rest of the rank-1 update waits until after the barrier, where it shares a basic block
+            // with H(i)'s dependent reflector chain (same operations, same results: only the order moved)
 #pragma unroll
             for (int k = S; k < CAR_MS; ++k) {
                 double w0 = 0.0, w1 = 0.0;
 #pragma unroll
                 for (int q = S; q < CAR_CQ; ++q) { if (q & 1) w1 = fma(a[k][q], v[q], w1); else w0 = fma(a[k][q], v[q], w0); }
                 double t = tau * row16_sum(w0 + w1);
-                t = (R + 16 * k > i) ? t : 0.0;                        // rows <= i stay (rows >= m are zero)
-#pragma unroll
-                for (int q = S; q < CAR_CQ; ++q) a[k][q] = fma(-t, v[q], a[k][q]);
+                tG[k] = (R + 16 * k > i) ? t : 0.0;                    // rows <= i stay (rows >= m are zero)
+                a[k][S] = fma(-tG[k], v[S], a[k][S]);
             }
             if (C == li) {                                             // publish column i
 #pragma unroll
                 for (int k = S; k < CAR_MS; ++k) L.colb[R + 16 * k] = a[k][S];
             }
+#pragma unroll
+            for (int q = S + 1; q < CAR_CQ; ++q) vG[q] = v[q];
         }
         CB_STAMP(3);
         CAR_LDS_BARRIER();
@@ -278,9 +283,15 @@ __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], in
             double beta2, sc2;
             larfg(L.colb[i + 1], s2, beta2, tauq, sc2);
 #pragma unroll
+            for (int k = S; k < CAR_MS; ++k)                           // (the rest of G(i)'s update)
+#pragma unroll
+                for (int q = S + 1; q < CAR_CQ; ++q) a[k][q] = fma(-tG[k], vG[q], a[k][q]);
+#pragma unroll
             for (int k = S; k < CAR_MS; ++k) {
                 const int r = R + 16 * k;
-                u[k] = (r <= i) ? 0.0 : ((r == i + 1) ? 1.0 : L.colb[r] * sc2);
+                double cr = L.colb[r];                                 // (r < 128: read unconditionally, then select --
+                asm volatile("" : "+v"(cr));                           //  a conditional read is a branch per row slot)
+                u[k] = (r <= i) ? 0.0 : ((r == i + 1) ? 1.0 : cr * sc2);
             }
             double zp[CAR_CQ];
 #pragma unroll
