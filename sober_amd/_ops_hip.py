@@ -35,7 +35,8 @@ class HipOps:
         # False (or SOBER_NO_QUEUE in the environment): every level sized by the host after a synchronisation (A/B runs)
         self.queue_levels = os.environ.get("SOBER_NO_QUEUE") is None
         # the jitter ladder's probes on eight workgroups per rung (SOBER_PROBE_ONE_WG: one each, A/B runs)
-        self._probe_mc = os.environ.get("SOBER_PROBE_ONE_WG") is None
+        self._probe_mc = os.environ.get("SOBER_PROBE_ONE_WG") is None \
+            and torch.cuda.get_device_properties(self.device).multi_processor_count >= 256   # (8 XCDs x 32 CUs: unpartitioned)
 
     # ------------------------------------------------------------------ plan
     def build_plan(self, spec: KernelSpec, mode: str, X_nys, X_cand) -> Plan:

@@ -986,6 +986,9 @@ extern "C" int sober_cholesky_probe_mc(const double* src, int n, int ld_src, con
         attr_set = true;
     }
     HIP_TRY(hipMemsetAsync(ws, 0, (size_t)flags, (hipStream_t)stream));
+    // every rung starts as "no verdict": a rung that finds no workgroups at all (a device whose XCC ids do not run over
+    // 0..7, e.g. a partitioned one) must not read as info = 0
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)info, sober::CM_INFO_EXCHANGE, (size_t)n_shifts, (hipStream_t)stream));
     // one workgroup per CU (the LDS request sees to that), 32 per XCD: 16 of them find a seat (two rungs x CM_G)
     const size_t lds_bytes = bytes > (size_t)84 * 1024 ? bytes : (size_t)84 * 1024;
     hipLaunchKernelGGL(sober::k_chol_mc, dim3(256), dim3(sober::CH_T), lds_bytes, (hipStream_t)stream, work, n, n, info,
