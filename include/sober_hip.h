@@ -268,6 +268,9 @@ int sober_cholesky_probe_mc(const double* src, int n, int ld_src, const double* 
 /* out = sqrt(nan_to_num(C) * nan_to_num(C)^T) elementwise (quirk Q2, SOBER/_utils.py:143-144);
  * flag[0] |= 1 when C is not exactly symmetric (:127).  Zero flag first.                            */
 int sober_abs_sym(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, void* stream);
+/* ... and max_i out[i][i] into *dmax (device double, ZERO it first; cov.diag().max() of the ladder's borderline test) */
+int sober_abs_sym_dmax(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, double* dmax,
+                       void* stream);
 
 /* k rungs of make_cov_psd's jitter ladder (SOBER/_utils.py:151-152) with the reference's sequence of
  * roundings: jitter = 1e-5; repeat k times { diag(A) += jitter; jitter *= 2 }.                        */

@@ -71,6 +71,7 @@ SIGNATURES = {
     "sober_cholesky_probe_mc_ws_bytes": (_i64, [_i32, _i32]),
     "sober_cholesky_probe_mc": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_abs_sym": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "sober_abs_sym_dmax": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_jitter_ladder": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "sober_jitter_ladder_auto": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_kmeans_ws_bytes": (_i64, [_i64, _i32, _i32]),
@@ -458,10 +459,11 @@ def cholesky_probe_mc(src, shifts, work, info, min_pivot, ws):
                                           ws.numel() * ws.element_size(), _stream(src)), "sober_cholesky_probe_mc")
 
 
-def abs_sym(C_, out, flag):
+def abs_sym(C_, out, flag, dmax=None):
+    """|C| = sqrt(C * C^T) elementwise + the symmetry flag; dmax (one zeroed device double): max diagonal of the result."""
     n = C_.shape[0]
-    _check(load().sober_abs_sym(C_.data_ptr(), n, C_.stride(0), out.data_ptr(), out.stride(0), flag.data_ptr(),
-                                _stream(C_)), "sober_abs_sym")
+    _check(load().sober_abs_sym_dmax(C_.data_ptr(), n, C_.stride(0), out.data_ptr(), out.stride(0), flag.data_ptr(),
+                                     _ptr(dmax), _stream(C_)), "sober_abs_sym")
 
 
 def kmeans_lloyd(X, K, iters, centroids, labels):

@@ -156,9 +156,16 @@ class HipOps:
         # everything up to the basis is enqueued without a host decision in between: the symmetry flag of the input
         # and the rung the ladder took are read back together with the range finder's health flags at the end
         n_r = max_iter + 1
-        flags = torch.zeros(2 + n_r, dtype=torch.int32, device=dev)      # [0] not symmetric, [1] rung taken, [2:] info
+        # one zero-fill for every flag and pivot of this phase (they were four fills, a reduction and a copy):
+        #   pivots[n_r + 1] f64 | range finder's pivs[2 * 5] f64 | flags[2 + n_r] i32 | range finder's infos[2 * 5] i32
+        n_orth2 = 2 * (1 + 2 * 2)
+        zb = torch.zeros(8 * (n_r + 1 + n_orth2) + 4 * (2 + n_r + n_orth2), dtype=torch.uint8, device=dev)
+        f64s = zb[:8 * (n_r + 1 + n_orth2)].view(torch.float64)
+        i32s = zb[8 * (n_r + 1 + n_orth2):].view(torch.int32)
+        pivots, pivs_rf = f64s[:n_r + 1], f64s[n_r + 1:]
+        flags, infos_rf = i32s[:2 + n_r], i32s[2 + n_r:]                 # [0] not symmetric, [1] rung taken, [2:] info
         C = torch.empty_like(G)
-        nat.abs_sym(G, C, flags[:1])
+        nat.abs_sym(G, C, flags[:1], pivots[n_r:])                       # (+ the largest diagonal entry: the borderline test)
         # every rung of the ladder (after k = 0 .. max_iter jitter additions) is probed at once: one
         # workgroup per rung, one launch; the first positive definite rung is applied on the device with the
         # reference's own sequence of diagonal additions -- or, when none is, the diagonal fallback
@@ -169,9 +176,7 @@ class HipOps:
             shifts = self._pin[key] = torch.tensor([1e-5 * (2 ** k - 1) for k in range(n_r)], dtype=torch.float64,
                                                    device=dev)
         work = self._buf(p, "chol_work", n_r * M * M)
-        # (smallest pivot of every rung + the largest diagonal entry: the borderline test below)
-        pivots = torch.empty(n_r + 1, dtype=torch.float64, device=dev)
-        pivots[n_r:] = C.diagonal().amax()
+        # (pivots: smallest pivot of every rung + the largest diagonal entry: the borderline test below)
         # (eight workgroups per rung from a few panels on: 0.49 -> 0.25 ms at M = 500; a rung whose workgroups lost each
         #  other reports PROBE_NO_VERDICT and the step goes to the host route, this process then stays with one each)
         if M >= self.PROBE_MC_MIN and n_r <= 16 and self._probe_mc:
@@ -188,7 +193,8 @@ class HipOps:
         # back and the literal host route decides.
         rng_state = torch.get_rng_state()
         R = _rng.device_randn(M, s, dev)
-        U, (flags_h, piv_h) = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=(flags, pivots), plan=p)
+        U, (flags_h, piv_h) = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=(flags, pivots), plan=p,
+                                                       zeroed=(infos_rf, pivs_rf))
         if any(int(v) == nat.PROBE_NO_VERDICT for v in flags_h[2:]):
             self._probe_mc = False
             warnings.warn("sober_amd: the multi-CU Cholesky probe lost contact between its workgroups; "
@@ -248,7 +254,7 @@ class HipOps:
     # matrix (~ cond(Y)^-2) stays above this: orthonormality then holds to ~1e-6 and the subspace to eps cond(Y)
     ORTH1_MIN_RATIO = 1e-10
 
-    def _svd_lowrank_device(self, A, q, R_host, niter: int = 2, overlap=None, extra=None, plan=None):
+    def _svd_lowrank_device(self, A, q, R_host, niter: int = 2, overlap=None, extra=None, plan=None, zeroed=None):
         """The range finder of torch.svd_lowrank(A, q) (Halko et al. Alg. 4.4, as in torch/_lowrank.py:64-79) for
         a square device matrix; returns an orthonormal basis of the same subspace as SOBER/_rchq.py:38's U, as
         rows (q, M) -- see the comment at the end for why the small SVD is not needed -- or None if CholeskyQR
@@ -256,8 +262,11 @@ class HipOps:
         dev, M = self.device, A.shape[0]
         R = R_host.to(dev)                                           # CPU generator: the reference's draw (already there: _rng.py)
         n_orth = 1 + 2 * niter
-        infos = torch.zeros(2 * n_orth, dtype=torch.int32, device=dev)
-        pivs = torch.zeros(2 * n_orth, dtype=torch.float64, device=dev)
+        if zeroed is not None and zeroed[0].numel() == 2 * n_orth:        # (the caller's zero-filled flags and pivots)
+            infos, pivs = zeroed
+        else:
+            infos = torch.zeros(2 * n_orth, dtype=torch.int32, device=dev)
+            pivs = torch.zeros(2 * n_orth, dtype=torch.float64, device=dev)
         Y = torch.empty(M, q, dtype=torch.float64, device=dev)
         nat.dgemm(A, R, Y)
         # torch/_lowrank.py orthonormalises after every product; only range(Q) of the LAST block enters the
