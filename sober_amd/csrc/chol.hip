@@ -39,13 +39,13 @@ __device__ __forceinline__ double ch_rdlane(double v, int l) {
 // SOBER/_utils.py:145-156 in ONE launch (the rungs are independent).
 //
 // Right-looking, panel width 32, per panel:
-//   (b) wave 0 factorises the 32 x 32 diagonal block IN REGISTERS (lane = row; pivots and multipliers are
-//       v_readlane broadcasts) and inverts it (lane = column of the inverse);
+//   (b) wave 0 factorises the 32 x 32 diagonal block IN REGISTERS and builds its inverse in the same pass (lanes 0..31:
+//       rows of L, lanes 32..63: columns of the inverse; pivots and multipliers are v_readlane broadcasts);
 //   (c) the panel below is L21 = A21 L11^-T as a small GEMM on the matrix cores (no per-row substitution chain);
 //   (d) the trailing update A22 -= L21 L21^T runs on the matrix cores from the LDS-resident panel, one 16 x 16
 //       tile per wave and trip, the next tile of A22 already in flight.
-// (b) of k_chol, by ONE wave: Cholesky of the 32 x 32 diagonal block D (LDS, lower part, zero padded) in registers
-// (lane = row; pivots and multipliers are v_readlane broadcasts), L11 back to D, its inverse to Xs (and to xo).
+// (b) of k_chol, by ONE wave: Cholesky of the 32 x 32 diagonal block D (LDS, lower part, zero padded) in registers,
+// L11 back to D, its inverse to Xs (and to xout).  s_dinv is unused (kept for the call sites' signature).
 template <int NC>      // NC = 8 / 16 / 32 columns are factorised (nb <= NC); the rest of the block is identity
 __device__ __attribute__((noinline)) void ch_diag_block_n(double* __restrict__ D, double* __restrict__ Xs, double* __restrict__ s_dinv,
                                               int* __restrict__ s_fail_p, double* __restrict__ s_minp_p, int nb, int kb,
