@@ -1475,3 +1475,30 @@ def test_ladder_probe_on_eight_workgroups_equals_one_workgroup_probe():
             piv = float(p1[k])
             if abs(piv) > 1e-9 * K.diagonal().max():
                 assert (int(i1[k]) == 0) == ok, (M, k, int(i1[k]), piv)
+
+
+@pytest.mark.gpu
+def test_abs_sym_leaves_the_largest_diagonal_entry():
+    """sober_abs_sym_dmax: |C| = sqrt(C * C^T) (SOBER/_utils.py:131-143), the symmetry flag, and max_i |C|[i][i] in the
+    same launch (cov.diag().max() of the jitter ladder's borderline test) -- against torch, NaN entries included."""
+    from sober_amd import _native as nat
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    for n in (5, 32, 33, 257, 500):
+        A = torch.randn(n, n, dtype=torch.float64, generator=g)
+        A = A @ A.T / n + 1e-3 * torch.randn(n, n, dtype=torch.float64, generator=g)   # slightly asymmetric
+        if n == 33:
+            A[3, 3] = float("nan")
+        Cd = A.to(dev)
+        out = torch.empty_like(Cd)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        dmax = torch.zeros(1, dtype=torch.float64, device=dev)
+        nat.abs_sym(Cd, out, flag, dmax)
+        An = torch.nan_to_num(A)
+        want = torch.sqrt(An * An.T)
+        # to the last place: the device's sqrt is the correctly rounded one; torch's vectorised CPU sqrt is an ulp off
+        # it in ~1 % of the entries on some hosts (AVX-512 path), none on others.  Entries of opposite sign across the
+        # diagonal give sqrt(negative) = NaN on both sides.
+        assert torch.allclose(out.cpu(), want, rtol=2.3e-16, atol=0, equal_nan=True)
+        assert int(flag) == 1
+        assert float(dmax) == float(want.diagonal().max())
