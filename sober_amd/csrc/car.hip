@@ -228,7 +228,9 @@ __device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], in
 #pragma unroll
             for (int q = S + 1; q < CAR_CQ; ++q) { if (q & 1) ss1 = fma(a[S][q], a[S][q], ss1); else ss0 = fma(a[S][q], a[S][q], ss0); }
             const double ss = row16_sum(ss0 + ss1);
-            const double al = row16_sum((C == li) ? a[S][S] : 0.0);
+            // the diagonal entry of the owner row sits in lane 17 li of its wave (R = li, C = li): one broadcast
+            // instead of a masked 16-lane sum (+ 0.0: a negative zero reads as the sum read it)
+            const double al = rdlane(a[S][S], (17 * li) & 63) + 0.0;
             double beta, tau, sc;
             larfg(al, ss, beta, tau, sc);
 #pragma unroll
