@@ -857,11 +857,7 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
         kl[q] = ok ? (unsigned)k : 0xffffffffu;
         hmin = min(hmin, kh[q]);
     }
-#ifdef SP_X_NOMIN
-    const unsigned H = (unsigned)__builtin_amdgcn_readfirstlane((int)hmin);
-#else
     const unsigned H = wave_min_u32(hmin);
-#endif
     piv = -1; al = 0.0; rp = 1.0;
     if (H == 0xffffffffu) return;                                     // uniform: no candidate (:241-242)
     unsigned long long mb[4];
