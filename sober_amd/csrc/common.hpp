@@ -50,7 +50,9 @@ __host__ __device__ inline int level_chunks_for(int n_rows, int64_t e_total, int
 #ifndef SOBER_WAVE_TARGET
 #define SOBER_WAVE_TARGET 2048
 #endif
+#ifndef SOBER_LW_W
 #define SOBER_LW_W 4
+#endif
 __host__ __device__ inline int64_t level_wave_tiles(int n_rows, int S) {
     return (int64_t)((S + 15) / 16) * ((n_rows + 63) / 64);
 }

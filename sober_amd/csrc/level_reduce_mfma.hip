@@ -312,7 +312,7 @@ __global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
 // eighth of the line -- the row tiles of at most three set groups: a candidate row is fetched by one or two L2s,
 // not by all eight.
 template <int KIND, int KT>
-__global__ __launch_bounds__(SOBER_LW_W * 64, 2) void k_level_reduce_wave(
+__global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduce_wave(
     const double* __restrict__ rows, int n_rows, const double* __restrict__ cand,
     const int32_t* __restrict__ idx, int64_t pos0, int64_t count, int S,
     const double* __restrict__ mu, const double* __restrict__ wmul, double os,
