@@ -18,3 +18,9 @@ print("torch A.add_(1.0)                           %.2f us" % per(lambda: A.add_
 print("torch.empty(64,64)                          %.2f us" % per(lambda: torch.empty(64, 64, dtype=torch.float64, device=dev)))
 C = torch.empty(64, 64, dtype=torch.float64, device=dev)
 print("nat.dgemm 64^3                              %.2f us" % per(lambda: nat.dgemm(A, B, C)))
+raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+if raw is not None:
+    print("torch._C._cuda_getCurrentRawStream(0)           %.2f us" % per(lambda: raw(0)), "same handle:", raw(0) == torch.cuda.current_stream(dev).cuda_stream)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        print("   inside a stream context: same handle:", raw(0) == side.cuda_stream)
