@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOBER_ABI_VERSION 2
+#define SOBER_ABI_VERSION 3
 
 /* kernel families: model.covar_module.forward behind SOBER/_gp.py:292-294 */
 #define SOBER_KIND_RBF       0   /* outputscale * exp(-0.5 * |x/l - y/l|^2)                      */
@@ -177,6 +177,10 @@ int sober_gather_f64(const double* src, const int32_t* idx, int64_t n, double* o
  * with rank k = keep_rank[t] >= 0 gives mu[idx[t]] = w_star[k], out_idx[k] = idx[t] + row_offset, out_w[k] = w_star[k]. */
 int sober_final_scatter(const int32_t* idx, int n, const int32_t* keep_rank, const double* w_star,
                         int64_t row_offset, double* mu, int64_t* out_idx, double* out_w, void* stream);
+/* mu[0:N] = 0 (SOBER/_rchq.py:109) followed by that write-back, both skipped when the device word *n_keep is negative
+ * (the Caratheodory step in front reported no result: the weights stay as they were for the caller's other route). */
+int sober_final_commit(const int32_t* idx, int n, const int32_t* keep_rank, const double* w_star, const int32_t* n_keep,
+                       int64_t row_offset, double* mu, int64_t N, int64_t* out_idx, double* out_w, void* stream);
 
 /* idx[p] = p-th index with mu != 0 is the caller's job (torch.nonzero); helper: int64 -> int32.   */
 int sober_i64_to_i32(const int64_t* in, int64_t n, int32_t* out, void* stream);
@@ -208,6 +212,27 @@ int64_t sober_car_ws_bytes(int N, int m);
 int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
                      int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
                      double* phi_out, void* ws, int64_t ws_bytes, void* stream);
+/* The same step with the choice of launches in the caller's hand (SOBER/_rchq.py:224-270 never fails, so a give-up
+ * must be recoverable):
+ *   SOBER_CAR_DEFAULT  what sober_car_device runs: launches whose workgroups wait for partner workgroups (the fused
+ *                      bidiagonalisation + Phi of csrc/car.hip, every kernel of csrc/car_mc.hip).  All waits are
+ *                      bounded; a give-up (partners not co-resident: a shared or partitioned device) reports
+ *                      *n_keep = -1 and leaves keep_rank / w_star unwritten.
+ *   SOBER_CAR_SAFE     only launches in which no workgroup depends on another one (stand-alone bidiagonalisation,
+ *                      one wave per column of Phi, the one-workgroup pivot stream): cannot give up; exists for the
+ *                      one-CU sizes (sober_car_safe_supported), SOBER_E_DIM beyond -- the host route is next.
+ * The level loops below redo a level that came back with n_keep = -1 in SOBER_CAR_SAFE mode, set job->car_mode so
+ * that the rest of the run (and, through the caller, the following steps) stay there, and only return
+ * SOBER_E_EXCHANGE when that mode does not cover the size.
+ * sober_car_giveup_forced() = 1 while the environment variable SOBER_CAR_FORCE_GIVEUP is set: the test switch that
+ * makes every SOBER_CAR_DEFAULT launch give up (spin limit of one poll / reported give-up).                      */
+#define SOBER_CAR_DEFAULT 0
+#define SOBER_CAR_SAFE 1
+int sober_car_safe_supported(int N, int m);
+int sober_car_giveup_forced(void);
+int sober_car_device_ex(const double* X, int ldx, int N, int m, const double* mu_in,
+                        int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
+                        double* phi_out, void* ws, int64_t ws_bytes, int mode, void* stream);
 /* The extra elimination of the acquisition-guided branch (SOBER/_rchq.py:87-106, :177-196) after a Caratheodory step
  * with the objective as one more test function: the n1 surviving weights w1 (in rank order; rank1[0:Nsets] maps a
  * set to its rank or -1) move along the null vector phi of [X_p; 1] -- the one-column phi_out of sober_car_device on
@@ -399,10 +424,16 @@ typedef struct sober_level_job {
     /* queued levels (optional, MFMA variant): SOBER_LEVEL_QUEUE + 1 int64 each -- dR device, h_dR pinned host.
        NULL: every level is sized by the host after a stream synchronisation.                                  */
     int64_t* dR; int64_t* h_dR;
+    int32_t car_mode;                           /* SOBER_CAR_DEFAULT / SOBER_CAR_SAFE for the Caratheodory steps; the loops
+                                                   raise it to SOBER_CAR_SAFE after a give-up (in/out)                   */
 } sober_level_job;
 #define SOBER_LEVEL_QUEUE 24
 int sober_level_moments(const sober_level_job* job, void* stream);
 int sober_level_car(const sober_level_job* job, void* stream);
+/* After a sober_level_car whose verdict was n_keep = -1 (job->h_flags[S] < 0 once the stream is synchronised): the step
+ * alone is redone in SOBER_CAR_SAFE mode on the barycentres that are still in place, synchronised, and job->car_mode
+ * stays SOBER_CAR_SAFE.  0 = a fresh verdict is in h_flags; SOBER_E_EXCHANGE = that mode does not cover the size.    */
+int sober_level_car_retry(sober_level_job* job, void* stream);
 /* The whole halving loop of an UNSHARDED pool (SOBER/_rchq.py:116-221, repeated while R > S) in one call: per level
  * sober_level_moments, sober_level_car, a stream synchronisation (the host has to know how many sets survived
  * before it can size the next level), sober_level_update, buffer swap -- without a round trip through the host
@@ -449,7 +480,8 @@ int64_t sober_rccl_allreduce_ptr(void);     /* the address of sober_rccl_allredu
  * the R live candidates (sober_pairwise on the SCALED points rows_sc / cand_sc, dt doubles or words per row), P K,
  * transpose, their weights, the Caratheodory step, mu[0:N] = 0 and the device-side write-back.  K: n_rows x R scratch,
  * mu_live: R scratch.  out_idx / out_w: R entries, the first n_keep valid; n_keep arrives in job->h_flags[S] (pinned)
- * once the stream has been synchronised.                                                                        */
+ * once the stream has been synchronised.  n_keep = -1 (a give-up of the step, job->car_mode = SOBER_CAR_DEFAULT): mu
+ * has NOT been touched -- call again with job->car_mode = SOBER_CAR_SAFE or take the host route.               */
 int sober_level_final(const sober_level_job* job, const void* rows_sc, const double* rows_norm, const void* cand_sc,
                       const double* cand_norm, int dt, const int32_t* idx, int R, int64_t N, int64_t row_offset,
                       double* K, double* mu_live, int64_t* out_idx, double* out_w, void* stream);

@@ -19,7 +19,7 @@ torch.cuda.synchronize()
 buf = nat._CAR_WS[Xd.device]
 off = m * 208 + 128 + 208 * 128
 d = buf[off:off + 512].cpu().numpy().view(np.uint64).astype(np.float64)[:4 * 8 * 10].reshape(4, 8, 10)
-names = ["loop", "A:reflector", "bar1", "B:apply G", "bar2", "C:H+zpart", "bar3", "D:colsum", "bar4", "update"]
+names = ["top", "larfg2", "z,x,ss", "larfg", "q->tG", "G-upd+store+publish", "Y+writes", "bar1", "D", "bar2"]   # merged form (round 3)
 tot = d.sum(1)
 for w in range(4):
     t = tot[w] / m

@@ -389,13 +389,19 @@ class RecombinationEngine:
             if obj is None and not self.force_host_car and getattr(ops, "level_car", None) is not None \
                     and ops.car_supported(S, n + 1):
                 # barycentres + on-chip Caratheodory step + flags to the host: one executor call (:151,166,173-175)
-                keep_rank_d, w_star_d, keep_np, n_keep = ops.level_car(plan, S)
-                self._tick("levels_device", t0)
-                if levels is not None:
-                    X_h, mu_h, w_h = ops.level_trace(plan)
-                    levels.append(dict(kind="level", R=R, E=E, r=r, X_tmp=X_h, tot_weights=mu_h,
-                                       idx_star=torch.from_numpy(np.flatnonzero(keep_np >= 0)),
-                                       w_star=w_h[:n_keep].clone()))
+                res = ops.level_car(plan, S)
+                if res is None:                             # the launches gave up and no device rung is left for this size
+                    X_tmp, tot = ops.level_barycentres(plan)
+                    keep_rank_d, w_star_d, keep_rank, n_keep = self._car(X_tmp, tot, R, E, r, levels, t0)
+                    keep_np = keep_rank.numpy()
+                else:
+                    keep_rank_d, w_star_d, keep_np, n_keep = res
+                    self._tick("levels_device", t0)
+                    if levels is not None:
+                        X_h, mu_h, w_h = ops.level_trace(plan)
+                        levels.append(dict(kind="level", R=R, E=E, r=r, X_tmp=X_h, tot_weights=mu_h,
+                                           idx_star=torch.from_numpy(np.flatnonzero(keep_np >= 0)),
+                                           w_star=w_h[:n_keep].clone()))
             else:
                 X_tmp = ops.barycentres(Xtr, tot)           # :151,166
                 keep_rank_d, w_star_d, keep_rank, n_keep = self._car(X_tmp, tot, R, E, r, levels, t0)  # :173-175
@@ -487,17 +493,16 @@ class RecombinationEngine:
         elif use_obj:
             on_device = False
         if on_device:
-            keep_rank_d, w_star_d, n_keep_d, _ = ops.car_device(X_dev, mu_dev)
-            if levels is not None:
-                keep_rank, nk, X_h, mu_h, w_h = ops.to_host(keep_rank_d, n_keep_d, X_dev, mu_dev, w_star_d)
-            else:
-                keep_rank, nk = ops.to_host(keep_rank_d, n_keep_d)
-            n_keep = int(nk[0])
-            self._tick("levels_device", t0)
-            if levels is not None:
-                levels.append(dict(kind=kind, R=R, E=E, r=r, X_tmp=X_h, tot_weights=mu_h,
-                                   idx_star=torch.nonzero(keep_rank >= 0).flatten(), w_star=w_h[:n_keep].clone()))
-            return keep_rank_d, w_star_d, keep_rank, n_keep
+            # (a step whose launches gave up comes back redone on the single-workgroup kernels, or as None: host route)
+            res = ops.car_device_checked(X_dev, mu_dev, also=(X_dev, mu_dev) if levels is not None else ())
+            if res is not None:
+                keep_rank_d, w_star_d, keep_rank, n_keep, extra = res
+                self._tick("levels_device", t0)
+                if levels is not None:
+                    (w_h,) = ops.to_host(w_star_d)
+                    levels.append(dict(kind=kind, R=R, E=E, r=r, X_tmp=extra[0], tot_weights=extra[1],
+                                       idx_star=torch.nonzero(keep_rank >= 0).flatten(), w_star=w_h[:n_keep].clone()))
+                return keep_rank_d, w_star_d, keep_rank, n_keep
         X_h, mu_h = ops.to_host(X_dev, mu_dev)
         t0 = self._tick("levels_device", t0)
         w_star, idx_star = car_host(X_h, mu_h.clone())

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SOBER_HIP_LIB: a diagnostic build of the same library, e.g. the in-kernel-stamp build `make stamps`)
 LIB_PATH = os.environ.get("SOBER_HIP_LIB") or os.path.join(_HERE, "libsober_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 KIND_RBF, KIND_MATERN52, KIND_TANIMOTO = 0, 1, 2
 KIND_BY_NAME = {"rbf": KIND_RBF, "matern52": KIND_MATERN52, "tanimoto": KIND_TANIMOTO}
@@ -60,6 +60,11 @@ SIGNATURES = {
     "sober_car_mc_supported": (_i32, [_i32, _i32]),
     "sober_car_mc_ws_bytes": (_i64, [_i32, _i32]),
     "sober_car_mc_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sober_car_device_ex": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "sober_car_safe_supported": (_i32, [_i32, _i32]),
+    "sober_car_giveup_forced": (_i32, []),
+    "sober_final_commit": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "sober_level_car_retry": (_i32, [_vp, _vp]),
     "sober_mc_selftest": (_i32, [_vp, _vp, _vp]),
     "sober_chol_max_n": (_i32, []),
     "sober_cholesky": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp]),
@@ -126,9 +131,12 @@ class LevelJob(C.Structure):
         ("idx", _vp), ("pos0", _i64), ("count", _i64), ("E", _i64), ("mu", _vp),
         ("phase", _i32),
         ("dR", _vp), ("h_dR", _vp),
+        ("car_mode", _i32),
     ]
 
 E_DIM = -2
+E_EXCHANGE = -5
+CAR_DEFAULT, CAR_SAFE, CAR_HOST = 0, 1, 2     # (CAR_HOST: the host side's own third rung, never passed to the library)
 
 _lib: Optional[C.CDLL] = None
 
@@ -388,11 +396,25 @@ def car_supported(N: int, m: int) -> bool:
     return bool(load().sober_car_supported(N, m))
 
 
-def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None, multi_cu=False):
+def car_safe_supported(N: int, m: int) -> bool:
+    return bool(load().sober_car_safe_supported(N, m))
+
+
+def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None, multi_cu=False, mode=CAR_DEFAULT):
     """X (N, m-1) float64 device (unit inner stride), mu_in (N).  multi_cu=True: the multi-CU kernels of
-    csrc/car_mc.hip whatever the size (test and timing hook; sober_car_device picks by size)."""
+    csrc/car_mc.hip whatever the size (test and timing hook; sober_car_device picks by size).  mode: CAR_DEFAULT or
+    CAR_SAFE (sober_car_device_ex: only launches that cannot give up; one-CU sizes)."""
     N, n = X.shape
     lib = load()
+    if mode != CAR_DEFAULT and not multi_cu:
+        nbytes = lib.sober_car_ws_bytes(N, n + 1)
+        ws = _CAR_WS.get(X.device)
+        if ws is None or ws.numel() * 8 < nbytes:
+            ws = _CAR_WS[X.device] = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=X.device)
+        _check(lib.sober_car_device_ex(X.data_ptr(), X.stride(0), N, n + 1, mu_in.data_ptr(), keep_rank.data_ptr(),
+                                       w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
+                                       ws.data_ptr(), nbytes, int(mode), _stream(X)), "sober_car_device_ex")
+        return
     nbytes = max(lib.sober_car_ws_bytes(N, n + 1), lib.sober_car_mc_ws_bytes(N, n + 1) if multi_cu else 0)
     ws = _CAR_WS.get(X.device)
     if ws is None or ws.numel() * 8 < nbytes:
@@ -535,6 +557,16 @@ def level_car(job: LevelJob, stream: int):
     _check(load().sober_level_car(C.addressof(job), stream), "sober_level_car")
 
 
+def level_car_retry(job: LevelJob, stream: int) -> bool:
+    """sober_level_car_retry: the step of the last sober_level_car again in CAR_SAFE mode (synchronised).  False: that
+    mode does not cover the size."""
+    rc = load().sober_level_car_retry(C.addressof(job), stream)
+    if rc == E_EXCHANGE:
+        return False
+    _check(rc, "sober_level_car_retry")
+    return True
+
+
 E_NOPROGRESS = -4
 MAX_LEVELS = 64
 
@@ -552,8 +584,11 @@ def level_loop(job: LevelJob, R: int, idx_a, idx_b, first_sums_ready: bool, even
     if rc == E_NOPROGRESS:
         raise RuntimeError("recombination made no progress (the Caratheodory step cancelled nothing, "
                            "SOBER/_rchq.py:241-242); the reference would loop forever here")
-    _check(rc, "sober_level_loop")
-    return list(level_R[:n_levels.value]), int(R_final.value), bool(in_b.value)
+    if rc != E_EXCHANGE:
+        _check(rc, "sober_level_loop")
+    # (E_EXCHANGE: the level at R_final is still due -- its Caratheodory step gave up and the safe launches do not
+    #  cover its size; the state handed back is consistent and the caller goes on from there on the host route)
+    return list(level_R[:n_levels.value]), int(R_final.value), bool(in_b.value), rc == E_EXCHANGE
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(_i32, _vp, _vp, _i64, _vp)      # sober_allreduce_fn(comm, buf, n, stream)

@@ -5,6 +5,7 @@ kernels on the current stream.  The level logic lives in `_engine.py`."""
 from __future__ import annotations
 
 import os
+import warnings
 
 import torch
 
@@ -37,6 +38,10 @@ class HipOps:
         # the jitter ladder's probes on eight workgroups per rung (SOBER_PROBE_ONE_WG: one each, A/B runs)
         self._probe_mc = os.environ.get("SOBER_PROBE_ONE_WG") is None \
             and torch.cuda.get_device_properties(self.device).multi_processor_count >= 256   # (8 XCDs x 32 CUs: unpartitioned)
+        # the rung of the Caratheodory step on this device: CAR_DEFAULT (launches whose workgroups wait for partner
+        # workgroups: fused / multi-CU), CAR_SAFE after one of them gave up (single-workgroup kernels, batch <= 100),
+        # CAR_HOST beyond those (host LAPACK + C++ pivots) -- SOBER/_rchq.py:224-270 never fails, so neither may this
+        self.car_mode = nat.CAR_DEFAULT
 
     # ------------------------------------------------------------------ plan
     def build_plan(self, spec: KernelSpec, mode: str, X_nys, X_cand) -> Plan:
@@ -355,6 +360,7 @@ class HipOps:
                 if p.P.stride(0) != p.Mtot or p.P.stride(1) != 1:
                     p.P = p.P.contiguous()
                 job.P = p.P.data_ptr()
+            job.car_mode = min(self.car_mode, nat.CAR_SAFE)
             return job
         dev, f64 = self.device, torch.float64
         job = nat.LevelJob()
@@ -403,8 +409,19 @@ class HipOps:
             nbytes = nat.car_ws_bytes(S, n + 1)
             w["car_ws"] = torch.empty(max(nbytes // 8, 1), dtype=f64, device=dev)
             job.car_ws, job.car_ws_bytes = w["car_ws"].data_ptr(), nbytes
+        job.car_mode = min(self.car_mode, nat.CAR_SAFE)
         w["job"] = job
         return job
+
+    def _car_downgrade(self, mode: int, why: str):
+        """Remember that the Caratheodory launches which depend on partner workgroups gave up on this device (another
+        stream or process shares it, or it is partitioned): the following steps start on the rung that worked."""
+        if mode > self.car_mode:
+            self.car_mode = mode
+            warnings.warn("sober_amd: a multi-workgroup Caratheodory launch gave up waiting for its partner workgroups "
+                          f"({why}); this and the following steps use "
+                          + ("the single-workgroup kernels" if mode == nat.CAR_SAFE else "the host LAPACK route")
+                          + " for that step -- same result, slower")
 
     def level_moments(self, p: Plan, idx, pos0, count, S, E, mu, phase: int = 0, n: int = None):
         """Partial (n, S) projected set sums and (S,) set masses over the local list positions
@@ -452,7 +469,11 @@ class HipOps:
             events = [None] * (4 * nat.MAX_LEVELS)
             for l, a in enumerate(pairs):
                 events[4 * l:4 * l + 4] = [a[0].cuda_event, a[1].cuda_event, None, None]
-        level_R, R_final, in_b = nat.level_loop(job, R, idx_cur, idx_new, sums_ready, events, nat._stream(mu))
+        level_R, R_final, in_b, gave_up = nat.level_loop(job, R, idx_cur, idx_new, sums_ready, events, nat._stream(mu))
+        if job.car_mode > min(self.car_mode, nat.CAR_SAFE):
+            self._car_downgrade(nat.CAR_SAFE, "level loop")
+        if gave_up:                                          # beyond the single-workgroup kernels: the host route is next
+            self._car_downgrade(nat.CAR_HOST, "level loop")
         if pairs is not None:
             for l, a in enumerate(pairs):
                 if l == 0 and sums_ready:                   # (that level's launches were bracketed by the phase-1 call)
@@ -476,13 +497,16 @@ class HipOps:
         _, new_bounds, in_b = nat.level_loop_sharded(job, comm.rank, comm.world, bounds, idx_cur, idx_new, sums_ready,
                                                      fn_ptr, comm_ptr, R_stop, nat._stream(mu))
         del keep
+        if job.car_mode > min(self.car_mode, nat.CAR_SAFE):
+            self._car_downgrade(nat.CAR_SAFE, "sharded level loop")
         return (idx_new, idx_cur, new_bounds) if in_b else (idx_cur, idx_new, new_bounds)
 
     def level_final(self, p: Plan, idx_cur, R: int, S: int, mu, row_offset: int):
         """The final direct level of an unsharded pool (n + 1 < R <= S, SOBER/_rchq.py:77-114) without leaving the
         device: one executor call, one synchronisation (for the number of survivors).  -> (idx int64, w) or None
         when this plan needs the step-by-step route (weighted mode, resident kernel matrix, size)."""
-        if p.weighted or getattr(p, "Kmat", None) is not None or not nat.car_supported(R, p.n + 1):
+        if p.weighted or getattr(p, "Kmat", None) is not None or not nat.car_supported(R, p.n + 1) \
+                or self.car_mode == nat.CAR_HOST or (self.car_mode == nat.CAR_SAFE and not nat.car_safe_supported(R, p.n + 1)):
             return None
         job = self._job(p, S)
         if not job.car_ws:
@@ -499,7 +523,13 @@ class HipOps:
         st.synchronize()
         n_keep = int(p.ws["h_flags_np"][S])
         if n_keep < 0:
-            raise nat.SoberHipError("Caratheodory step: a multi-workgroup kernel gave up waiting for a partner workgroup")
+            # the step gave up; the weights are untouched (sober_final_commit): once more on the next rung, or the
+            # engine's step-by-step route with the host's LAPACK
+            if job.car_mode == nat.CAR_DEFAULT and nat.car_safe_supported(R, p.n + 1):
+                self._car_downgrade(nat.CAR_SAFE, "final level")
+                return self.level_final(p, idx_cur, R, S, mu, row_offset)
+            self._car_downgrade(nat.CAR_HOST, "final level")
+            return None
         return out_idx[:n_keep], out_w[:n_keep]
 
     def level_flat(self, p: Plan):
@@ -516,8 +546,17 @@ class HipOps:
         st.synchronize()
         flags = p.ws["h_flags_np"]
         if int(flags[S]) < 0:
-            raise nat.SoberHipError("Caratheodory step: a multi-workgroup kernel gave up waiting for a partner workgroup")
+            # the launches gave up: the step alone again on the single-workgroup kernels; None = the size is beyond
+            # them, the engine takes the barycentres (still in the plan's workspace) to the host route
+            if not nat.level_car_retry(job, st.cuda_stream):
+                self._car_downgrade(nat.CAR_HOST, "level")
+                return None
+            self._car_downgrade(nat.CAR_SAFE, "level")
         return p.ws["keep_rank"][:S], p.ws["w_star"], flags[:S].copy(), int(flags[S])
+
+    def level_barycentres(self, p: Plan):
+        """The barycentres and set masses the last `level_car` worked on (device)."""
+        return p.ws["X_tmp"], p.ws["tot"]
 
     def level_trace(self, p: Plan):
         """Host copies of the last level's barycentres, set masses and kept weights (test traces)."""
@@ -545,19 +584,40 @@ class HipOps:
         return out
 
     def car_supported(self, N, m):
-        return nat.car_supported(N, m)
+        """The step runs on the device: a kernel covers the size AND the rung this device is on still has one."""
+        if not nat.car_supported(N, m) or self.car_mode == nat.CAR_HOST:
+            return False
+        return self.car_mode == nat.CAR_DEFAULT or nat.car_safe_supported(N, m)
 
-    def car_device(self, X, mu_in):
+    def car_device(self, X, mu_in, phi_out=None):
         """Tchernychova_Lyons_CAR on the device -> (keep_rank int32 (N,), w_star (N,), n_keep int32
-        (1,), mu_out (N,)); nothing leaves the GPU."""
+        (1,), mu_out (N,)); nothing leaves the GPU.  n_keep = -1: the launches gave up (SOBER_CAR_DEFAULT only) and
+        keep_rank / w_star are unwritten -- `car_device_checked` is the form that recovers."""
         N = X.shape[0]
         dev = self.device
         keep_rank = torch.empty(N, dtype=torch.int32, device=dev)
         w_star = torch.empty(N, dtype=torch.float64, device=dev)
         n_keep = torch.empty(1, dtype=torch.int32, device=dev)
         mu_out = torch.empty(N, dtype=torch.float64, device=dev)
-        nat.car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out)
+        nat.car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=phi_out, mode=min(self.car_mode, nat.CAR_SAFE))
         return keep_rank, w_star, n_keep, mu_out
+
+    def car_device_checked(self, X, mu_in, phi_out=None, also=()):
+        """`car_device` + the verdict on the host (one synchronisation, which every caller needs anyway) + recovery:
+        a step that gave up is redone on the single-workgroup kernels when they cover the size.
+        -> (keep_rank_d, w_star_d, keep_rank host, n_keep, host copies of `also`) or None: host route."""
+        N, m = X.shape[0], X.shape[1] + 1
+        for _ in range(2):
+            if not self.car_supported(N, m):
+                return None
+            keep_rank, w_star, n_keep_d, _mu = self.car_device(X, mu_in, phi_out)
+            host = self.to_host(keep_rank, n_keep_d, *also)
+            n_keep = int(host[1][0])
+            if n_keep >= 0:
+                return keep_rank, w_star, host[0], n_keep, host[2:]
+            self._car_downgrade(nat.CAR_SAFE if nat.car_safe_supported(N, m) and self.car_mode == nat.CAR_DEFAULT
+                                else nat.CAR_HOST, "Caratheodory step")
+        return None
 
     def car_obj_device(self, X, mu_in, obj_head=None):
         """The Caratheodory step of the acquisition-guided branch on the device: X (N, n + 1) carries the objective
@@ -569,10 +629,11 @@ class HipOps:
         leave exactly n + 2 points (the reference then takes a singular vector of a full-rank matrix: host route)."""
         N, n1f = X.shape                                     # n1f = n + 1 functions incl. the objective
         dev = self.device
-        kr1, w1, nk1, _ = self.car_device(X, mu_in)
-        (kr1_h, nk1_h) = self.to_host(kr1, nk1)
-        n1 = int(nk1_h[0])
-        if n1 != n1f + 1 or not nat.car_supported(n1, n1f):
+        first = self.car_device_checked(X, mu_in)
+        if first is None:
+            return None
+        kr1, w1, kr1_h, n1, _ = first
+        if n1 != n1f + 1 or not self.car_supported(n1, n1f):
             return None
         sel = torch.nonzero(kr1 >= 0).flatten()              # ascending set index = rank order
         Xp = X[sel, :n1f - 1].contiguous()                    # (n1, n)
@@ -580,6 +641,7 @@ class HipOps:
         phi = torch.empty(n1, 1, dtype=torch.float64, device=dev)
         scratch = [torch.empty(n1, dtype=t_, device=dev) for t_ in (torch.int32, torch.float64, torch.float64)]
         nkx = torch.empty(1, dtype=torch.int32, device=dev)
+        # (phi_out is filled by the stand-alone bidiagonalisation + Phi launches: nothing here can give up)
         nat.car_device(Xp, w1[:n1].contiguous(), scratch[0], scratch[1], nkx, scratch[2], phi_out=phi)
         keep_rank = torch.empty(N, dtype=torch.int32, device=dev)
         w_star = torch.empty(N, dtype=torch.float64, device=dev)

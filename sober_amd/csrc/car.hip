@@ -8,21 +8,18 @@
 // (dgebrd, lower-bidiagonal case m < N, dlarfg sign convention) -- checked against
 // torch.linalg.svd on the reference's own per-level inputs in tests/test_car_algorithm.py (CPU) and
 // tests/test_hip_parity.py (GPU).  That product is a deterministic function of A, so it can be
-// recomputed here.  Three launches on one stream, each shaped by what bounds its phase:
+// recomputed here.  Launches on one stream, each shaped by what bounds its phase:
 //
-//   k_car_bidiag  1 workgroup x 256 threads.  The m bidiagonalisation steps are a chain of workgroup-wide
-//                 reductions (two norms, two matrix-vector products per step): latency, not arithmetic.
-//                 Four waves -- one per SIMD -- keep the barriers and the LDS exchanges cheap; the matrix
-//                 lives in VGPRs (7 x 13 doubles per thread), a matrix row inside ONE 16-lane DPP row so
-//                 that row dot products never leave the wave.  Reflectors v_i, tau_i -> global scratch.
-//   k_car_phi     Phi = P [0; I] by backward accumulation.  The columns of Phi are independent, so this
-//                 phase is spread over ceil((N-m)/8) workgroups of one wave (8 columns each, 16 lanes x 13
-//                 rows per column): ~10 us instead of >100 us inside a single workgroup.
-//   k_car_pivot   1 workgroup x 512 threads, Phi in VGPRs (4 columns x 13 rows per thread): the N-m
-//                 pivots of :237-266, one barrier per pivot.  Every DPP row carries its own copy of the
-//                 weights, so the DPP row that owns the next pivot column runs the ratio test on its
-//                 registers (16-lane DPP argmin with first-index tie break) straight after its own
-//                 elimination step.
+//   k_car_bidiag_fused  workgroup 0 (256 threads, one wave per SIMD) is the bidiagonalisation: the matrix lives in
+//                 VGPRs (7 x 13 doubles per thread), a matrix row inside ONE 16-lane DPP row so that row dot
+//                 products never leave the wave; two workgroup barriers per step (merged form, see
+//                 car_bidiag2_block).  The other workgroups on its XCD accumulate the rows of Phi = P [0; I] as the
+//                 reflectors appear (forward accumulation, row by row independent).
+//   k_car_bidiag + k_car_phi  the same two phases as separate launches with NO dependence between workgroups
+//                 (backward accumulation, one wave per column of Phi): the test hook for phi_out and the route a
+//                 fused launch that gave up is redone on (sober_car_device_ex, SOBER_CAR_SAFE).
+//   k_car_pivot_stream  1 workgroup x 16 waves, Phi in VGPRs: the N-m pivots of :237-266 as a barrier-free stream
+//                 through an LDS ring.
 //
 // Limits of these one-CU kernels: N <= 208, m <= 112, N - m <= 112 (batch <= 100).  sober_car_device hands larger
 // steps (N <= 448, m <= 256: batch <= 224) to the multi-CU kernels of car_mc.hip; beyond those the engine takes the
@@ -51,8 +48,8 @@ __device__ __forceinline__ double dpp(double v) {
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);          // (no `old` operand: every lane is written)
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 #endif
@@ -103,10 +100,7 @@ __device__ __forceinline__ unsigned long long ratio_key(double x) {
     return (x != x) ? 0ull : k;
 }
 
-// dlarfg: reflector H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2, v = x * scal.
-// v_rsq_f64 / v_rcp_f64 seeds + Newton steps (<= 1 ulp) instead of the IEEE sqrt and the two IEEE divisions: a third
-// of the dependent chain that sits on the critical path of every step, and no branch (a taken branch costs a single
-// resident wave 50-80 cycles of instruction fetch); operands far outside the normal range are rescaled with selects
+// v_rcp_f64 seed + Newton steps (<= 1 ulp) instead of an IEEE division: a third of its dependent chain, no branch
 __device__ __forceinline__ double car_rcp(double c) {
     double r = __builtin_amdgcn_rcp(c);
     double e = fma(-c, r, 1.0);
@@ -114,10 +108,14 @@ __device__ __forceinline__ double car_rcp(double c) {
     e = fma(-c, r, 1.0);
     return fma(r, e, r);
 }
-__device__ __forceinline__ void larfg(double alpha, double ss, double& beta, double& tau, double& scal) {
+// dlarfg: reflector H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2, v = x * scal -- computed
+// from 1 / norm alone (beta itself is never needed here):
+//   tau = (beta - alpha) / beta = 1 + |alpha| / norm,   scal = 1 / (alpha - beta) = sign(alpha) / (norm tau)
+// -- one refined rsq, one fma, one refined rcp of a number in [1, 2]: 15 dependent operations instead of 23
+__device__ __forceinline__ void larfg_vt(double alpha, double ss, double& tau, double& scal) {
     const double n2r = fma(alpha, alpha, ss);
     const bool tiny = n2r < 1e-200, huge = n2r > 1e200;
-    const double f = tiny ? 0x1p300 : (huge ? 0x1p-300 : 1.0), fi = tiny ? 0x1p-300 : (huge ? 0x1p300 : 1.0);
+    const double f = tiny ? 0x1p300 : (huge ? 0x1p-300 : 1.0);
     const double al = alpha * f;
     const double n2 = fma(al, al, (ss * f) * f);
     double r = __builtin_amdgcn_rsq(n2);
@@ -127,16 +125,15 @@ __device__ __forceinline__ void larfg(double alpha, double ss, double& beta, dou
     h = 0.5 * r;
     e = fma(-(n2 * r), h, 0.5);
     r = fma(r, e, r);
-    double nr = n2 * r;
-    nr = fma(fma(-nr, nr, n2), 0.5 * r, nr);
-    const double bs = -copysign(nr, al);
-    const double ib = car_rcp(bs);
-    double t = (bs - al) * ib;
-    t = fma(fma(-t, bs, bs - al), ib, t);
+    const double t = fma(fabs(al), r, 1.0);
+    double y = __builtin_amdgcn_rcp(t);
+    e = fma(-t, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-t, y, 1.0);
+    y = fma(y, e, y);
     const bool none = ss == 0.0;
-    beta = none ? alpha : bs * fi;
     tau = none ? 0.0 : t;
-    scal = none ? 0.0 : car_rcp(al - bs) * f;
+    scal = none ? 0.0 : copysign((r * f) * y, al);
 }
 
 // ratio-test combine, branch-free (selects only): first argmin, a NaN ratio wins (torch.argmin);
@@ -156,6 +153,7 @@ __device__ __forceinline__ void amin_take(double& best, int& piv, double ob, int
 // with L1-bypassing loads and accept it when both tags carry (epoch, reflector) -- no fence, no flag (the protocol of
 // car_mc.hip, where it is measured).  Producer and consumers sit on the same XCD, so the stores are plain ones.
 typedef unsigned int car_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int car_u32x2 __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t car_rsrc_t;
 constexpr unsigned CARF_ERR = 0, CARF_XCD = 16, CARF_TICKET = 32, CARF_PROGRESS = 48, CARF_DONE = 56;   // byte offsets in the comm block
 __host__ __device__ constexpr int64_t carf_bytes(int) { return 64; }
@@ -181,20 +179,6 @@ __device__ __forceinline__ void car_publish_progress(const CarPub& pub, int k) {
     }
 }
 
-// ---------------- phase 1: Golub-Kahan bidiagonalisation (dgebd2, m < N), matrix in VGPRs ----------------
-// Thread (R = tid >> 4, C = tid & 15) holds A[R + 16 k][C + 16 q], k < 7, q < 13.
-// per step: (A) the owner DPP row builds G(i), publishes v~ (LDS + global)                         | barrier
-//           (B) everyone applies it to its rows > i; column i is published                          | barrier
-//           (C) every wave builds H(i) from column i for itself; partial column sums u~^T A -> LDS   | barrier
-//           (D) 208 threads finish the sums                                                         | barrier
-//           then the rank-1 update with H(i)
-// Steps 16 S .. 16 S + 15 only touch row slots k >= S and column slots q >= S: the step body is instantiated
-// once per S so that the finished part of the matrix costs no instructions (the kernel is bound by the
-// instruction count of its one wave per SIMD, ~6 cycles per FP64 VALU op).
-struct CarLds {
-    double* vbuf; double* colb; double* zsum; double* zpart; double* scal;
-};
-
 #ifdef CAR_BSTAMPS      // diagnostic build (`make stamps`): per-segment cycle sums of every wave -> behind the tau block
 #define CB_DECL unsigned long long cacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ctl_; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ctl_) :: "memory");
@@ -208,171 +192,314 @@ struct CarLds {
 #define CB_FLUSH(S_) do { } while (0)
 #endif
 
+// ---------------- phase 1, merged form (round 3): two barriers per step, nobody waits for an owner ----------------
+// The step above is a relay: the owner row builds G(i) while three waves wait (A), everyone applies it (B), every wave
+// builds H(i) from the published column (C), the column sums are finished (D), H(i) is applied -- four barriers, and the
+// owner's 130 dependent instructions are paid by all.  Here every thread rebuilds what it needs from what the PREVIOUS
+// step left in LDS, the same reflectors in exact arithmetic (tests/test_car_algorithm.py::bidiag_merged):
+//   * row i+1 and column i+1 of A' = A G(i) are published by their holders right after G(i)'s update (rowg, colg);
+//     the next step's row x = rowg - tauq z and column cur = colg - f z_i follow from them in every thread, so G(i+1)'s
+//     scalars (dlarfg on x) are computed redundantly by all 256 threads -- phase (A) and its barrier are gone;
+//   * column i after G(i), col' = cur - tau w, is known to every thread for its own rows, so the column sums
+//     Y = col'[i+2:]^T A' and |col'[i+2:]|^2 start without H(i)'s scalars; H(i)'s dlarfg runs AFTER the sums, redundantly,
+//     at the top of the next iteration, where z = rowg + sc2 Y -- phase (C)'s wave-wide norm and its barrier are gone.
+// One iteration = [H(i-1)'s scalars, z, update | row, column, G(i), w = A v, update, publish, partial column sums]
+// barrier [16 partial sums -> Y] barrier.  Dead rows and columns are never written (masks on the block's own slot only).
+struct CarLds2 {
+    double* rowg; double* colg; double* zpart; double* s2part; double* zsum; double* scal;
+};
+
+// timing-only switches (wrong results): what each part of the step costs  (scripts/bidiag_where.sh)
+#ifdef CB2_X_NORSUM
+#define CB2_RSUM(v) (v)
+#else
+#define CB2_RSUM(v) row16_sum(v)
+#endif
+#ifdef CB2_X_NOHUPD
+#define CB2_HUPD(n, o) (o)
+#else
+#define CB2_HUPD(n, o) (n)
+#endif
+#ifdef CB2_X_NOGUPD
+#define CB2_GUPD(n, o) (o)
+#else
+#define CB2_GUPD(n, o) (n)
+#endif
+#ifdef CB2_X_NOBAR
+#define CB2_BARRIER() do { } while (0)
+#else
+#define CB2_BARRIER() CAR_LDS_BARRIER()
+#endif
+#ifdef CB2_X_NOVSTORE
+#define CB2_VSTORE(e) do { } while (0)
+#else
+#define CB2_VSTORE(e) e
+#endif
+#ifdef CAR_BSTAMPS
+#define CB2_STAMP(K, VAL) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(VAL) :: "memory"); \
+    cacc_[K] += t_ - ctl_; ctl_ = t_; } while (0)
+#else
+#define CB2_STAMP(K, VAL) do { } while (0)
+#endif
 template <int S, bool FUSED>
-__device__ __forceinline__ void car_bidiag_block(double (&a)[CAR_MS][CAR_CQ], int m, const CarLds& L,
-                                                 double* __restrict__ vws, double* __restrict__ taup, const CarPub& pub) {
-    const int tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], double (&colp)[CAR_MS], int m, const CarLds2& L,
+                                                  double* __restrict__ vws, double* __restrict__ taup, const CarPub& pub) {
+    const int tid = threadIdx.x;
     const int R = tid >> 4, C = tid & 15;
-    const int i_end = min(16 * S + 16, m);
+    const int i_end = min(16 * S + 16, m - 1);
+    constexpr int S1 = (S + 1 < CAR_MS) ? S + 1 : S;         // row slot of row i+1 when i is the block's last step
+    const car_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(vws, 0, (int)((size_t)m * CAR_NS * sizeof(double)), 0x00020000);
     CB_DECL
     for (int i = 16 * S; i < i_end; ++i) {
-        CB_STAMP(0);
-        const int li = i & 15;                               // row i: DPP row li, slot S; column i: lane li, slot S
+        const int li = i & 15, p = i & 1, pp = p ^ 1;
         if constexpr (FUSED) car_publish_progress(pub, i);   // reflector i - 1 is complete in memory by now
-        if (R == li) {                                                 // (A)
-            double ss0 = 0.0, ss1 = 0.0;
-            {
-                const double x = a[S][S];
-                ss0 = (C > li) ? x * x : 0.0;
-            }
+        // ---- H(i-1): scalars from the finished sums, z, the rank-1 update (rows >= i, columns >= i)
+        double z[CAR_CQ], x[CAR_CQ], f[CAR_MS], cur[CAR_MS];
+        CB_STAMP(0);
+        double tauq, sc2;
+        const double al2 = L.scal[pp], s2 = L.zsum[CAR_NS];
+        // (every LDS read of the block is issued before the scalar chain of H(i-1) starts: x and z wait in registers)
 #pragma unroll
-            for (int q = S + 1; q < CAR_CQ; ++q) { if (q & 1) ss1 = fma(a[S][q], a[S][q], ss1); else ss0 = fma(a[S][q], a[S][q], ss0); }
-            const double ss = row16_sum(ss0 + ss1);
-            // the diagonal entry of the owner row sits in lane 17 li of its wave (R = li, C = li): one broadcast
-            // instead of a masked 16-lane sum (+ 0.0: a negative zero reads as the sum read it)
-            const double al = rdlane(a[S][S], (17 * li) & 63) + 0.0;
-            double beta, tau, sc;
-            larfg(al, ss, beta, tau, sc);
+        for (int q = S; q < CAR_CQ; ++q) { x[q] = L.rowg[pp * CAR_NS + C + 16 * q]; z[q] = L.zsum[C + 16 * q]; }
+        const double rgi = L.rowg[pp * CAR_NS + i];
+#pragma unroll
+        for (int k = S; k < CAR_MS; ++k) cur[k] = L.colg[pp * 128 + R + 16 * k];
+        if constexpr (S > 0) __builtin_amdgcn_sched_barrier(0);      // (block 0 has no registers to hold them)
+        {
+            double beta2;
+#ifdef CB2_X_NOLARFG
+            beta2 = al2; tauq = s2; sc2 = beta2 + tauq;
+#else
+            larfg_vt(al2, s2, tauq, sc2); (void)beta2;
+#endif
+        }
+        CB2_STAMP(1, tauq);
+#pragma unroll
+        for (int q = S; q < CAR_CQ; ++q) {
+            z[q] = fma(sc2, z[q], x[q]);
+            x[q] = fma(-tauq, z[q], x[q]);                  // row i of the updated matrix (u_i = 1)
+        }
+        z[S] = (C >= li) ? z[S] : 0.0;
+        x[S] = (C > li) ? x[S] : 0.0;
+#pragma unroll
+        for (int k = S; k < CAR_MS; ++k) f[k] = tauq * (sc2 * colp[k]);
+        f[S] = (R == li) ? tauq : f[S];
+        const double zi = rdlane(z[S], li);                 // z at column i (lane li of every wave holds C == li)
+        const double alpha = fma(-tauq, zi, rgi);
+#pragma unroll
+        for (int k = S; k < CAR_MS; ++k) cur[k] = fma(-f[k], zi, cur[k]);                            // column i, my rows
+#pragma unroll
+        for (int q = S; q < CAR_CQ; ++q)
+#pragma unroll
+            for (int k = S; k < CAR_MS; ++k) a[k][q] = CB2_HUPD(fma(-f[k], z[q], a[k][q]), a[k][q]);
+        // ---- G(i) from row i
+        double ss0 = 0.0, ss1 = 0.0;
+#pragma unroll
+        for (int q = S; q < CAR_CQ; ++q) { if (q & 1) ss1 = fma(x[q], x[q], ss1); else ss0 = fma(x[q], x[q], ss0); }
+        double ss = CB2_RSUM(ss0 + ss1);
+        CB2_STAMP(2, ss);
+        double beta, tau, sc;
+#ifdef CB2_X_NOLARFG
+        beta = alpha; tau = ss; sc = alpha + ss;
+#else
+        larfg_vt(alpha, ss, tau, sc); (void)beta;
+#endif
+        CB2_STAMP(3, tau);
+        // w = A v = column i + sc * (A x) over my rows
+        double tG[CAR_MS];
+#pragma unroll
+        for (int k = S; k < CAR_MS; ++k) {
+            double w0 = 0.0, w1 = 0.0;
+#ifndef CB2_X_NOQ
+#pragma unroll
+            for (int q = S; q < CAR_CQ; ++q) { if (q & 1) w1 = fma(a[k][q], x[q], w1); else w0 = fma(a[k][q], x[q], w0); }
+#else
+            w0 = a[k][S]; w1 = x[S];
+#endif
+            tG[k] = tau * fma(sc, CB2_RSUM(w0 + w1), cur[k]);
+        }
+        tG[S] = (R > li) ? tG[S] : 0.0;                      // rows <= i stay
+        CB2_STAMP(4, tG[S]);
+#pragma unroll
+        for (int k = S; k < CAR_MS; ++k) colp[k] = cur[k] - tG[k];      // column i after G(i)  (v_i = 1)
+        colp[S] = (R > li) ? colp[S] : 0.0;
+#pragma unroll
+        for (int q = S; q < CAR_CQ; ++q) x[q] *= sc;         // x becomes v
+        if (R == li) {                                       // the reflector goes to the scratch (Phi follows it)
+            const unsigned so = (unsigned)i * (unsigned)(CAR_NS * 8);
 #pragma unroll
             for (int q = 0; q < CAR_CQ; ++q) {
-                const int c = C + 16 * q;
                 double v;
                 if (q < S) v = 0.0;
-                else if (q == S) v = (C < li) ? 0.0 : ((C == li) ? 1.0 : a[S][S] * sc);
-                else v = a[S][q] * sc;
-                L.vbuf[c] = v;
-                vws[(size_t)i * CAR_NS + c] = v;
+                else if (q == S) v = (C < li) ? 0.0 : ((C == li) ? 1.0 : x[S]);
+                else v = x[q];
+                car_u32x2 g;
+                g.x = (unsigned)__double2loint(v); g.y = (unsigned)__double2hiint(v);
+                CB2_VSTORE(__builtin_amdgcn_raw_buffer_store_b64(g, vrs, (unsigned)(C * 8 + 128 * q), so, 0));
             }
-            if (C == 0) { taup[i] = tau; L.scal[1] = tau; }
+            if (C == 0) taup[i] = tau;
         }
-        if (i == m - 1) { CB_FLUSH(S); return; }
-        CB_STAMP(1);
-        CAR_LDS_BARRIER();
-        CB_STAMP(2);
-        double tG[CAR_MS], vG[CAR_CQ];
-        {                                                              // (B)
-            const double tau = L.scal[1];
-            double v[CAR_CQ];
 #pragma unroll
-            for (int q = S; q < CAR_CQ; ++q) v[q] = L.vbuf[C + 16 * q];
-            // the row sums first, then column slot S alone -- it holds column i, which H(i) is built from -- and its
-            // publication; the rest of the rank-1 update waits until after the barrier, where it shares a basic block
-            // with H(i)'s dependent reflector chain (same operations, same results: only the order moved)
+        for (int k = S; k < CAR_MS; ++k)
 #pragma unroll
-            for (int k = S; k < CAR_MS; ++k) {
-                double w0 = 0.0, w1 = 0.0;
+            for (int q = S; q < CAR_CQ; ++q) a[k][q] = CB2_GUPD(fma(-tG[k], x[q], a[k][q]), a[k][q]);
+        // ---- what the next step is built from: row i+1 and column i+1 of A', and col'[i+1]
+        const bool last = li == 15;
+        const int n1 = (li + 1) & 15;
+        if (!last) {                                         // (uniform)
+            if (R == n1) {
 #pragma unroll
-                for (int q = S; q < CAR_CQ; ++q) { if (q & 1) w1 = fma(a[k][q], v[q], w1); else w0 = fma(a[k][q], v[q], w0); }
-                double t = tau * row16_sum(w0 + w1);
-                tG[k] = (R + 16 * k > i) ? t : 0.0;                    // rows <= i stay (rows >= m are zero)
-                a[k][S] = fma(-tG[k], v[S], a[k][S]);
+                for (int q = S; q < CAR_CQ; ++q) L.rowg[p * CAR_NS + C + 16 * q] = a[S][q];
+                if (C == 0) L.scal[p] = colp[S];
             }
-            if (C == li) {                                             // publish column i
+            if (C == n1) {
 #pragma unroll
-                for (int k = S; k < CAR_MS; ++k) L.colb[R + 16 * k] = a[k][S];
+                for (int k = S; k < CAR_MS; ++k) L.colg[p * 128 + R + 16 * k] = a[k][S];
             }
+        } else {
+            if (R == 0) {
 #pragma unroll
-            for (int q = S + 1; q < CAR_CQ; ++q) vG[q] = v[q];
+                for (int q = S; q < CAR_CQ; ++q) L.rowg[p * CAR_NS + C + 16 * q] = a[S1][q];
+                if (C == 0) L.scal[p] = colp[S1];
+            }
+            if (C == 0) {
+#pragma unroll
+                for (int k = S; k < CAR_MS; ++k) L.colg[p * 128 + R + 16 * k] = a[k][S + 1];
+            }
         }
-        CB_STAMP(3);
-        CAR_LDS_BARRIER();
-        CB_STAMP(4);
-        double u[CAR_MS], tauq;
-        {                                                              // (C), redundantly in every wave
-            const double x0 = L.colb[lane], x1 = L.colb[lane + 64];    // zero from row m on
-            double s2 = ((lane >= i + 2) ? x0 * x0 : 0.0) + ((lane + 64 >= i + 2) ? x1 * x1 : 0.0);
-            s2 = wave_sum(s2);
-            double beta2, sc2;
-            larfg(L.colb[i + 1], s2, beta2, tauq, sc2);
+        CB2_STAMP(5, a[S][S]);
+        // ---- partial column sums of H(i): rows >= i + 2 of col' against A'
+        double cm[CAR_MS];
 #pragma unroll
-            for (int k = S; k < CAR_MS; ++k)                           // (the rest of G(i)'s update)
+        for (int k = S; k < CAR_MS; ++k) cm[k] = colp[k];
+        cm[S] = (R > li + 1) ? cm[S] : 0.0;
+        if constexpr (S + 1 < CAR_MS) cm[S + 1] = (last && R == 0) ? 0.0 : cm[S + 1];
+        double yp[CAR_CQ], s2p = 0.0;
 #pragma unroll
-                for (int q = S + 1; q < CAR_CQ; ++q) a[k][q] = fma(-tG[k], vG[q], a[k][q]);
+        for (int q = S; q < CAR_CQ; ++q) yp[q] = cm[S] * a[S][q];
+#ifndef CB2_X_NOY
 #pragma unroll
-            for (int k = S; k < CAR_MS; ++k) {
-                const int r = R + 16 * k;
-                double cr = L.colb[r];                                 // (r < 128: read unconditionally, then select --
-                asm volatile("" : "+v"(cr));                           //  a conditional read is a branch per row slot)
-                u[k] = (r <= i) ? 0.0 : ((r == i + 1) ? 1.0 : cr * sc2);
-            }
-            double zp[CAR_CQ];
+        for (int k = S + 1; k < CAR_MS; ++k)
 #pragma unroll
-            for (int q = S; q < CAR_CQ; ++q) zp[q] = u[S] * a[S][q];
+            for (int q = S; q < CAR_CQ; ++q) yp[q] = fma(cm[k], a[k][q], yp[q]);
+#endif
 #pragma unroll
-            for (int k = S + 1; k < CAR_MS; ++k)
+        for (int k = S; k < CAR_MS; ++k) s2p = fma(cm[k], cm[k], s2p);
 #pragma unroll
-                for (int q = S; q < CAR_CQ; ++q) zp[q] = fma(u[k], a[k][q], zp[q]);
-#pragma unroll
-            for (int q = S; q < CAR_CQ; ++q) L.zpart[R * CAR_NS + C + 16 * q] = zp[q];
-        }
-        CB_STAMP(5);
-        CAR_LDS_BARRIER();
+        for (int q = S; q < CAR_CQ; ++q) L.zpart[R * CAR_NS + C + 16 * q] = yp[q];
+        if (C == 0) L.s2part[R] = s2p;
         CB_STAMP(6);
-        if (tid >= 16 * S && tid < CAR_NS) {                           // (D): columns of the live slots
+        CB2_BARRIER();
+        CB_STAMP(7);
+#ifndef CB2_X_NOD
+        if (tid >= 16 * S && tid <= CAR_NS) {                // thread CAR_NS: the norm
+            const double* src = (tid == CAR_NS) ? L.s2part : L.zpart + tid;
+            const int str = (tid == CAR_NS) ? 1 : CAR_NS;
             double z0 = 0.0, z1 = 0.0;
 #pragma unroll
             for (int w = 0; w < 16; w += 2) {
-                z0 += L.zpart[w * CAR_NS + tid];
-                z1 += L.zpart[(w + 1) * CAR_NS + tid];
+                z0 += src[w * str];
+                z1 += src[(w + 1) * str];
             }
             L.zsum[tid] = z0 + z1;
         }
-        CB_STAMP(7);
-        CAR_LDS_BARRIER();
+#endif
         CB_STAMP(8);
-        {
-            double zq[CAR_CQ];
-#pragma unroll
-            for (int q = S; q < CAR_CQ; ++q) {
-                const int c = C + 16 * q;
-                zq[q] = (c > i) ? L.zsum[c] : 0.0;                     // H(i) acts on columns i+1 .. N-1 only
-            }
-#pragma unroll
-            for (int k = S; k < CAR_MS; ++k) {
-                const double f = tauq * u[k];
-#pragma unroll
-                for (int q = S; q < CAR_CQ; ++q) a[k][q] = fma(-f, zq[q], a[k][q]);
-            }
-        }
-        // (the next (A) touches registers, vbuf and scal[1] only; both were last read before the 2nd barrier)
+        CB2_BARRIER();
         CB_STAMP(9);
     }
     CB_FLUSH(S);
 }
 
-template <bool FUSED>
-__device__ __forceinline__ void car_bidiag_body(const double* __restrict__ X, int ldx, int N, int m,
-                                                double* __restrict__ vws, double* __restrict__ taup, const CarPub& pub) {
-    __shared__ double vbuf[CAR_NS];
-    __shared__ double colb[128];
-    __shared__ double zsum[CAR_NS];
-    __shared__ double zpart[16 * CAR_NS];
-    __shared__ double scal[4];
+// the last reflector, G(m-1): row m-1 after H(m-2) -- no matrix work at all
+template <int S, bool FUSED>
+__device__ __forceinline__ void car_bidiag2_last(int m, const CarLds2& L, double* __restrict__ vws, double* __restrict__ taup,
+                                                 const CarPub& pub) {
     const int tid = threadIdx.x;
     const int R = tid >> 4, C = tid & 15;
-    double a[CAR_MS][CAR_CQ];
+    const int i = m - 1, li = i & 15, pp = (i & 1) ^ 1;
+    if constexpr (FUSED) car_publish_progress(pub, i);
+    double x[CAR_CQ], zS = 0.0;
+    double tauq, sc2, beta2;
+    larfg_vt(L.scal[pp], L.zsum[CAR_NS], tauq, sc2); (void)beta2;
 #pragma unroll
-    for (int k = 0; k < CAR_MS; ++k)
+    for (int q = S; q < CAR_CQ; ++q) {
+        const double rg = L.rowg[pp * CAR_NS + C + 16 * q];
+        const double zq = fma(sc2, L.zsum[C + 16 * q], rg);
+        if (q == S) zS = zq;
+        x[q] = fma(-tauq, zq, rg);
+    }
+    x[S] = (C > li) ? x[S] : 0.0;
+    const double zi = rdlane(zS, li);
+    const double alpha = fma(-tauq, zi, L.rowg[pp * CAR_NS + i]);
+    double ss0 = 0.0, ss1 = 0.0;
+#pragma unroll
+    for (int q = S; q < CAR_CQ; ++q) { if (q & 1) ss1 = fma(x[q], x[q], ss1); else ss0 = fma(x[q], x[q], ss0); }
+    const double ss = row16_sum(ss0 + ss1);
+    double beta, tau, sc;
+    larfg_vt(alpha, ss, tau, sc); (void)beta;
+    if (R == li) {
+#pragma unroll
+        for (int q = 0; q < CAR_CQ; ++q) {
+            double v;
+            if (q < S) v = 0.0;
+            else if (q == S) v = (C < li) ? 0.0 : ((C == li) ? 1.0 : x[S] * sc);
+            else v = x[q] * sc;
+            vws[(size_t)i * CAR_NS + C + 16 * q] = v;
+        }
+        if (C == 0) taup[i] = tau;
+    }
+}
+
+template <bool FUSED>
+__device__ __forceinline__ void car_bidiag2_body(const double* __restrict__ X, int ldx, int N, int m,
+                                                 double* __restrict__ vws, double* __restrict__ taup, const CarPub& pub) {
+    __shared__ double rowg[2 * CAR_NS];
+    __shared__ double colg[2 * 128];
+    __shared__ double zpart[16 * CAR_NS];
+    __shared__ double s2part[16];
+    __shared__ double zsum[CAR_NS + 8];
+    __shared__ double scal[2];
+    const int tid = threadIdx.x;
+    const int R = tid >> 4, C = tid & 15;
+    double a[CAR_MS][CAR_CQ], colp[CAR_MS];
+#pragma unroll
+    for (int k = 0; k < CAR_MS; ++k) {
+        colp[k] = 0.0;
 #pragma unroll
         for (int q = 0; q < CAR_CQ; ++q) {
             const int r = R + 16 * k, c = C + 16 * q;
             a[k][q] = (c < N && r < m) ? ((r == 0) ? 1.0 : X[(size_t)c * ldx + (r - 1)]) : 0.0;
         }
-    if (tid < 128) colb[tid] = 0.0;
+    }
+    // "step -1" left the matrix untouched: its row 0 and column 0, no H
+    if (tid < CAR_NS) { rowg[CAR_NS + tid] = (tid < N) ? 1.0 : 0.0; zsum[tid] = 0.0; }
+    if (tid < 128) colg[128 + tid] = (tid < m && N > 0) ? ((tid == 0) ? 1.0 : X[tid - 1]) : 0.0;
+    if (tid < 8) zsum[CAR_NS + tid] = 0.0;
+    if (tid < 2) scal[tid] = 0.0;
     __syncthreads();
-    const CarLds L{vbuf, colb, zsum, zpart, scal};
-    car_bidiag_block<0, FUSED>(a, m, L, vws, taup, pub);
-    if (m > 16) car_bidiag_block<1, FUSED>(a, m, L, vws, taup, pub);
-    if (m > 32) car_bidiag_block<2, FUSED>(a, m, L, vws, taup, pub);
-    if (m > 48) car_bidiag_block<3, FUSED>(a, m, L, vws, taup, pub);
-    if (m > 64) car_bidiag_block<4, FUSED>(a, m, L, vws, taup, pub);
-    if (m > 80) car_bidiag_block<5, FUSED>(a, m, L, vws, taup, pub);
-    if (m > 96) car_bidiag_block<6, FUSED>(a, m, L, vws, taup, pub);
+    const CarLds2 L{rowg, colg, zpart, s2part, zsum, scal};
+    car_bidiag2_block<0, FUSED>(a, colp, m, L, vws, taup, pub);
+    if (m > 17) car_bidiag2_block<1, FUSED>(a, colp, m, L, vws, taup, pub);
+    if (m > 33) car_bidiag2_block<2, FUSED>(a, colp, m, L, vws, taup, pub);
+    if (m > 49) car_bidiag2_block<3, FUSED>(a, colp, m, L, vws, taup, pub);
+    if (m > 65) car_bidiag2_block<4, FUSED>(a, colp, m, L, vws, taup, pub);
+    if (m > 81) car_bidiag2_block<5, FUSED>(a, colp, m, L, vws, taup, pub);
+    if (m > 97) car_bidiag2_block<6, FUSED>(a, colp, m, L, vws, taup, pub);
+    switch ((m - 1) >> 4) {
+        case 0: car_bidiag2_last<0, FUSED>(m, L, vws, taup, pub); break;
+        case 1: car_bidiag2_last<1, FUSED>(m, L, vws, taup, pub); break;
+        case 2: car_bidiag2_last<2, FUSED>(m, L, vws, taup, pub); break;
+        case 3: car_bidiag2_last<3, FUSED>(m, L, vws, taup, pub); break;
+        case 4: car_bidiag2_last<4, FUSED>(m, L, vws, taup, pub); break;
+        case 5: car_bidiag2_last<5, FUSED>(m, L, vws, taup, pub); break;
+        default: car_bidiag2_last<6, FUSED>(m, L, vws, taup, pub); break;
+    }
 }
 
 __global__ __launch_bounds__(CAR_BT) void k_car_bidiag(const double* __restrict__ X, int ldx, int N, int m,
                                                        double* __restrict__ vws, double* __restrict__ taup) {
-    car_bidiag_body<false>(X, ldx, N, m, vws, taup, CarPub{});
+    car_bidiag2_body<false>(X, ldx, N, m, vws, taup, CarPub{});
 }
 
 // ---------------- phases 1 + 2 in one launch ----------------
@@ -383,11 +510,12 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag(const double* __restrict_
 // that find themselves on ITS XCD (hardware id; the rest exit at once) take tickets for groups of four rows, one wave
 // per row, and follow the reflectors as they appear -- one step behind the producer, finished ~1 us after it.
 // Tags carry an epoch (one per launch), so nothing has to be cleared between launches; spins are bounded (error word:
-// k_car_pivot then reports n_keep = -1, the engine's signal for the host route).
+// the pivot kernel then reports n_keep = -1 and the caller redoes the step with the launches that do not depend on
+// partner workgroups: sober_car_device_ex, SOBER_CAR_SAFE).
 __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __restrict__ X, int ldx, int N, int m,
                                                              double* __restrict__ vws, double* __restrict__ taup,
                                                              double* __restrict__ Phi, void* __restrict__ comm,
-                                                             unsigned cbytes, unsigned epoch) {
+                                                             unsigned cbytes, unsigned epoch, unsigned spin_limit) {
     const car_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
     const unsigned tag0 = epoch << 7;                                  // (m <= 112 < 128)
     unsigned* words = (unsigned*)comm;
@@ -400,7 +528,7 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
             __hip_atomic_store(words + CARF_XCD / 4, (epoch << 4) | (xcc + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         const CarPub pub{rs, tag0};
-        car_bidiag_body<true>(X, ldx, N, m, vws, taup, pub);
+        car_bidiag2_body<true>(X, ldx, N, m, vws, taup, pub);
         __syncthreads();
         car_publish_progress(pub, m);                                  // the last reflector (this time the wait is real)
         return;
@@ -412,7 +540,7 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
         unsigned spins = 0, w;
         int grp = -1;
         while (((w = __hip_atomic_load(words + CARF_XCD / 4, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 4) != epoch) {
-            if (++spins > CARF_SPIN_LIMIT) { w = 0; break; }
+            if (++spins > CARF_SPIN_LIMIT) { w = 0; break; }      // (the election is not what the test switch shortens)
             __builtin_amdgcn_s_sleep(2);
         }
         if ((w & 15u) == xcc + 1u) grp = 0;                            // on the producer's XCD: a worker
@@ -450,7 +578,7 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
                     const unsigned w = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, CARF_PROGRESS, 0, 16);
                     if ((w >> 7) == epoch) have = (int)(w & 127u);
                     if (have > i) break;
-                    if (++spins > CARF_SPIN_LIMIT ||
+                    if (++spins > spin_limit ||
                         ((spins & 255u) == 0u && __builtin_amdgcn_raw_buffer_load_b32(rs, CARF_ERR, 0, 16) != 0)) {
                         __builtin_amdgcn_raw_buffer_store_b32(1, rs, CARF_ERR, 0, 16);
                         failed = true;
@@ -561,28 +689,6 @@ __global__ __launch_bounds__(256) void k_car_phi(const double* __restrict__ vws,
 }
 
 // ---------------- phase 3: the pivots of SOBER/_rchq.py:237-266 ----------------
-// Wave w owns columns w, w + 16, ...; lane l holds rows l + 64 q (q < 4) of each.  One barrier per pivot.
-// A dependent FP64 operation costs ~15 ns on one wave, so the kernel is shaped around the length of the
-// dependency chain from "pivot s known" to "pivot s+1 known":
-//   * the weights travel from owner to owner through LDS (only the wave that runs the ratio test needs them; a
-//     dead row -- Phi[idx, :] = 0 of :266 -- is marked by -0.0); the wave that owns column s+1 has that column in a FIXED
-//     register set (its columns are consumed in order; the array is rotated after each ownership), eliminates
-//     it first and runs the ratio test of step s+1 (:239-247) on its registers, while its other columns are
-//     updated by independent instructions the scheduler interleaves into the same block;
-//   * the 4 quotients AND the 4 reciprocals of a lane are issued together (IEEE division, interleaved chains);
-//   * quotients become order-preserving 64-bit keys; the 64-lane minimum is taken on the high and then the low
-//     word with single-instruction DPP steps, the first index then comes from ballots on the scalar unit;
-//   * the slot of the pivot row is picked by selects (no register-indexed branches) and the pivot row is not
-//     zeroed in the registers (:266) but marked dead: every later reader of that row goes through the mask.
-#ifndef CAR_PW_
-#define CAR_PW_ 16
-#endif
-constexpr int CAR_PW = CAR_PW_;            // waves in k_car_pivot
-#ifndef CAR_PJW_
-#define CAR_PJW_ 7                        // 8 spills at 1024 threads (128 VGPRs); 7 x 16 = 112 columns cover batch 100
-#endif
-constexpr int CAR_PJW = CAR_PJW_;          // columns per wave: N - m <= CAR_PW * CAR_PJW
-
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned dpp_min_u32(unsigned v) {
     const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
@@ -598,243 +704,14 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {        // total i
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-__global__ __launch_bounds__(CAR_PW * 64) void k_car_pivot(const double* __restrict__ Phi, int N, int m,
-                                                           const double* __restrict__ mu_in,
-                                                           int32_t* __restrict__ keep_rank,
-                                                           double* __restrict__ w_star,
-                                                           int32_t* __restrict__ n_keep_out,
-                                                           double* __restrict__ mu_out,
-                                                           const unsigned* __restrict__ err) {
-    if (err != nullptr && (err[CARF_ERR / 4] != 0u || err[CARF_DONE / 4] != (unsigned)(CAR_NS / 8))) {
-        // the fused launch in front gave up on a reflector (bounded spins) or left a group of Phi's rows out: no result
-        if (threadIdx.x == 0) *n_keep_out = -1;
-        return;
-    }
-    __shared__ double colbuf[2 * 256];     // current / next pivot column (zero beyond N)
-    __shared__ double pscal[2 * 4];        // (alpha, piv, 1/Phi[piv,0]) of the current / next step
-    __shared__ double mubuf[256];          // the weights after the last finished update; -0.0 marks a dead row
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NC = N - m;
-    double phi[CAR_PJW][4];                // phi[0] = my next column to become the pivot column
-    bool inr[4];
-#pragma unroll
-    for (int j = 0; j < CAR_PJW; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = lane + 64 * q;
-            phi[j][q] = (r < CAR_NS && wave + CAR_PW * j < CAR_PC) ? Phi[(size_t)r * CAR_PC + wave + CAR_PW * j] : 0.0;
-        }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) inr[q] = lane + 64 * q < N;
-    if (tid < 512) colbuf[tid] = 0.0;
-    __syncthreads();
-    int nlive = (NC > wave) ? (NC - wave + CAR_PW - 1) / CAR_PW : 0;   // my columns not yet consumed as pivot columns
-
-    // publish column phi[0] as the pivot column of buffer nb and run the ratio test on it: first argmin of
-    // mu/Phi over Phi > 0, a NaN quotient wins (:239-247)
-#define CAR_RATIO_TEST(nb)                                                                \
-    {                                                                                     \
-        double rt_[4], rc_[4];                                                            \
-        unsigned kh_[4], kl_[4];                                                          \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                   \
-            colbuf[(nb) * 256 + lane + 64 * q] = phi[0][q];       /* zero beyond N */     \
-            rt_[q] = mu4[q] / phi[0][q];                                                  \
-            rc_[q] = 1.0 / phi[0][q];                                                     \
-        }                                                                                 \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                   \
-            const unsigned long long k_ = ratio_key(rt_[q]);                              \
-            const bool ok_ = inr[q] & (phi[0][q] > 0.0) & !dead[q];                       \
-            kh_[q] = ok_ ? (unsigned)(k_ >> 32) : 0xffffffffu;                            \
-            kl_[q] = ok_ ? (unsigned)k_ : 0xffffffffu;                                    \
-        }                                                                                 \
-        const unsigned h01_ = min(kh_[0], kh_[1]), h23_ = min(kh_[2], kh_[3]);            \
-        const unsigned H_ = wave_min_u32(min(h01_, h23_));                                \
-        const unsigned long long m0_ = __ballot(kh_[0] == H_), m1_ = __ballot(kh_[1] == H_); \
-        const unsigned long long m2_ = __ballot(kh_[2] == H_), m3_ = __ballot(kh_[3] == H_); \
-        unsigned L_ = 0;                                                                  \
-        const bool single_ = (__popcll(m0_) + __popcll(m1_) + __popcll(m2_) + __popcll(m3_)) == 1; \
-        if (!single_) {                      /* rare: several quotients share the high word */ \
-            unsigned l_[4];                                                               \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) l_[q] = (kh_[q] == H_) ? kl_[q] : 0xffffffffu; \
-            L_ = wave_min_u32(min(min(l_[0], l_[1]), min(l_[2], l_[3])));                 \
-        }                                                                                 \
-        int piv_ = -1;                                                                    \
-        double al_ = 0.0, rp_ = 1.0;                                                      \
-        if (H_ != 0xffffffffu) {         /* uniform; an all-ones high word = no candidate (or masked) */ \
-            const unsigned long long b0_ = single_ ? m0_ : __ballot((kh_[0] == H_) & (kl_[0] == L_)); \
-            const unsigned long long b1_ = single_ ? m1_ : __ballot((kh_[1] == H_) & (kl_[1] == L_)); \
-            const unsigned long long b2_ = single_ ? m2_ : __ballot((kh_[2] == H_) & (kl_[2] == L_)); \
-            const unsigned long long b3_ = single_ ? m3_ : __ballot((kh_[3] == H_) & (kl_[3] == L_)); \
-            if (b0_)      { const int f_ = __ffsll((long long)b0_) - 1; piv_ = f_;       al_ = rdlane(rt_[0], f_); rp_ = rdlane(rc_[0], f_); } \
-            else if (b1_) { const int f_ = __ffsll((long long)b1_) - 1; piv_ = f_ + 64;  al_ = rdlane(rt_[1], f_); rp_ = rdlane(rc_[1], f_); } \
-            else if (b2_) { const int f_ = __ffsll((long long)b2_) - 1; piv_ = f_ + 128; al_ = rdlane(rt_[2], f_); rp_ = rdlane(rc_[2], f_); } \
-            else          { const int f_ = __ffsll((long long)b3_) - 1; piv_ = f_ + 192; al_ = rdlane(rt_[3], f_); rp_ = rdlane(rc_[3], f_); } \
-        }                                                                                 \
-        if (lane == 0) { pscal[(nb) * 4] = al_; pscal[(nb) * 4 + 1] = (double)piv_;       \
-                         pscal[(nb) * 4 + 2] = rp_; }                                     \
-    }
-    // rank-1 elimination of column J: Phi[:,c] -= Phi[:,0] * (Phi[idx,c] / Phi[idx,0])  (:260-266)
-#define CAR_ELIM(J)                                                                       \
-    {                                                                                     \
-        const double lo_ = kp0 ? phi[J][0] : phi[J][1], hi_ = kp2 ? phi[J][2] : phi[J][3]; \
-        const double qv_ = rdlane(kplo ? lo_ : hi_, lp) * rpp_;                           \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) phi[J][q] = fma(-qv_, pc[q], phi[J][q]); \
-    }
-    // eliminate live columns FROM .. nlive-1 (consumed columns are zero; uniform branches)
-#define CAR_ELIM_IF(J, FROM) if ((J) >= (FROM) && (J) < CAR_PJW && (J) < nlive) CAR_ELIM((J) < CAR_PJW ? (J) : 0)
-#define CAR_ELIM_LIVE(FROM)                                                               \
-    CAR_ELIM_IF(0, FROM) CAR_ELIM_IF(1, FROM) CAR_ELIM_IF(2, FROM) CAR_ELIM_IF(3, FROM)   \
-    CAR_ELIM_IF(4, FROM) CAR_ELIM_IF(5, FROM) CAR_ELIM_IF(6, FROM) CAR_ELIM_IF(7, FROM)   \
-    CAR_ELIM_IF(8, FROM) CAR_ELIM_IF(9, FROM) CAR_ELIM_IF(10, FROM) CAR_ELIM_IF(11, FROM) \
-    CAR_ELIM_IF(12, FROM) CAR_ELIM_IF(13, FROM) CAR_ELIM_IF(14, FROM) CAR_ELIM_IF(15, FROM)
-    // weights after pivot `PIV` (alpha A, pivot column PCOL) from the weights in mubuf; -0.0 = dead row
-#define CAR_MU_STEP(A, PIV, PCOL)                                                         \
-    double mu4[4];                                                                        \
-    bool dead[4];                                                                         \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                       \
-        const double mp_ = mubuf[lane + 64 * q];                                          \
-        dead[q] = ((__double2hiint(mp_) == (int)0x80000000) & (__double2loint(mp_) == 0)) | (lane + 64 * q == (PIV)); \
-        mu4[q] = dead[q] ? -0.0 : __dsub_rn(mp_, __dmul_rn((A), (PCOL)[q]));              \
-    }
-    if (wave == 0) {                                                   // column 0 is the first pivot column
-        double mu4[4];
-        bool dead[4] = {false, false, false, false};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            mu4[q] = inr[q] ? mu_in[lane + 64 * q] + 0.0 : 0.0;         // (+ 0.0: an input -0.0 is not a dead row)
-            mubuf[lane + 64 * q] = mu4[q];
-        }
-        CAR_RATIO_TEST(0)
-#pragma unroll
-        for (int j = 0; j + 1 < CAR_PJW; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) phi[j][q] = phi[j + 1][q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) phi[CAR_PJW - 1][q] = 0.0;
-        --nlive;
-    }
-    __syncthreads();
-#ifdef CAR_STAMPS
-    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime(), arr_ = 0;
-#define CAR_SUB(K) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_[K] += t_ - tl_; tl_ = t_; } while (0)
-#else
-#define CAR_SUB(K) do { } while (0)
-#endif
-
-    int cur = 0, s = 0;
-    for (; s < NC; ++s, cur ^= 1) {
-#ifdef CAR_STAMPS
-        const unsigned long long it0_ = tl_;
-#endif
-        const double alpha = pscal[cur * 4];
-        const int piv = (int)pscal[cur * 4 + 1];
-        const double rpp = pscal[cur * 4 + 2];
-        double rpp_ = rpp;
-        if (piv < 0) break;                                             // Q6 (:241-242), uniform
-        const int kp = piv >> 6, lp = piv & 63;
-        const bool kp0 = kp == 0, kp2 = kp == 2, kplo = kp < 2;
-        double pc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pc[q] = colbuf[cur * 256 + lane + 64 * q];
-        CAR_SUB(0);
-        const int nxt = s + 1;
-        const bool owner = nxt < NC && (nxt % CAR_PW) == wave;          // phi[0] is the next pivot column
-        if (owner) {
-            __builtin_amdgcn_s_setprio(3);                              // the critical chain of the step
-            // mu[:] = mu - alpha * Phi[:,0]; mu[idx] = 0   (two roundings like the tensor expression, :253-254)
-            CAR_MU_STEP(alpha, piv, pc)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) mubuf[lane + 64 * q] = mu4[q];
-            CAR_ELIM(0)
-            CAR_RATIO_TEST(cur ^ 1)
-            __builtin_amdgcn_s_setprio(0);
-            CAR_SUB(1);
-#ifdef CAR_STAMPS
-            acc_[4] += tl_ - it0_; acc_[5] += 1;
-#endif
-        } else {
-            CAR_ELIM_LIVE(0)
-            CAR_SUB(2);
-        }
-#ifdef CAR_STAMPS
-        arr_ += __builtin_amdgcn_s_memtime() - it0_;
-        if (s == 50 && lane == 0) ((unsigned long long*)Phi)[(size_t)205 * CAR_PC + 64 + wave] = __builtin_amdgcn_s_memtime() - it0_;
-#endif
-        __syncthreads();
-#ifdef CAR_STAMPS
-        if (owner) { acc_[6] += __builtin_amdgcn_s_memtime() - tl_; }
-#endif
-        if (owner) {
-            // off the critical path: the owner catches up with its other columns while the next owner (another
-            // wave) is already working on step s+1; then its next column moves to slot 0.  (The empty asm pins
-            // this register-only code behind the barrier: the compiler is otherwise free to hoist it.)
-            asm volatile("" : "+v"(rpp_));
-            CAR_ELIM_LIVE(1)
-#pragma unroll
-            for (int j = 0; j + 1 < CAR_PJW; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) phi[j][q] = phi[j + 1][q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) phi[CAR_PJW - 1][q] = 0.0;
-            --nlive;
-#ifdef CAR_STAMPS
-            acc_[7] += __builtin_amdgcn_s_memtime() - tl_;
-#endif
-        }
-        CAR_SUB(3);
-    }
-#ifdef CAR_STAMPS
-    if (lane == 0) ((unsigned long long*)Phi)[(size_t)206 * CAR_PC + 64 + wave] = arr_;
-    if (lane == 0 && wave < 2) for (int q_ = 0; q_ < 8; ++q_) ((unsigned long long*)Phi)[(size_t)207 * CAR_PC + 112 + 8 * wave + q_] = acc_[q_];
-#endif
-#undef CAR_RATIO_TEST
-#undef CAR_ELIM
-#undef CAR_ELIM_LIVE
-#undef CAR_ELIM_IF
-
-    // ---------------- output: w_star = mu[mu > 0], idx_star as ranks ----------------
-    if (wave == 0) {
-        double fin[4];
-        if (s == NC && NC > 0) {                                        // the update of the last pivot is still due
-            const int lc = (NC - 1) & 1;
-            const double* pcl = colbuf + lc * 256;
-            const double pcv[4] = {pcl[lane], pcl[lane + 64], pcl[lane + 128], pcl[lane + 192]};
-            CAR_MU_STEP(pscal[lc * 4], (int)pscal[lc * 4 + 1], pcv)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fin[q] = mu4[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fin[q] = mubuf[lane + 64 * q];
-        }
-        int base = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = lane + 64 * q;
-            const double v = (r < N) ? fin[q] + 0.0 : 0.0;              // -0.0 (dead) -> +0.0
-            const bool keep = (r < N) && (v > 0.0);
-            const unsigned long long bal = __ballot(keep);
-            const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if (r < N) {
-                keep_rank[r] = keep ? rank : -1;
-                mu_out[r] = v;
-                if (keep) w_star[rank] = v;
-            }
-            base += __popcll(bal);
-        }
-        if (lane == 0) *n_keep_out = base;
-    }
-#undef CAR_MU_STEP
-}
-
-
 // ---------------- phase 3, streaming form ----------------
 // The same pivots without a workgroup barrier per pivot (the design of car_mc.hip's k_mc_pivot, through LDS instead of
 // L2).  A wave owns SP_BC CONSECUTIVE columns and keeps its own copy of the weights.  While a column of its block is the
 // pivot column it runs the ratio test on its registers, publishes (column, index, alpha, 1/pivot) in an LDS ring and goes
 // straight on to its next column -- seven of eight pivots need no hand-over at all; every other wave applies the
 // published pivots to its columns as they arrive, at low priority, in the issue slots the owner's dependent chain
-// leaves empty.  k_car_pivot above rotates the ownership with every pivot (column c -> wave c mod 16): one barrier,
-// one hand-over of the weights and one LDS round trip of the pivot column per pivot, 1.14 us each.
+// leaves empty.  (The round-1 kernel rotated the ownership with every pivot -- column c -> wave c mod 16 --: one barrier,
+// one hand-over of the weights and one LDS round trip of the pivot column per pivot, 1.14 us each.)
 constexpr int SP_W = 16, SP_BC = 7, SP_RING = 32;
 struct SpSlot { double col[256]; double alpha, rpp; int piv; int tag; };
 struct SpState { double mu[4]; bool dead[4], inr[4]; };
@@ -1131,7 +1008,7 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
 
 // one compute unit (batch <= 100)
 static int car_one_cu(int N, int m) {
-    return (m >= 2 && N > m && N <= sober::CAR_NS && m <= 16 * sober::CAR_MS && N - m <= sober::CAR_PW * sober::CAR_PJW) ? 1 : 0;
+    return (m >= 2 && N > m && N <= sober::CAR_NS && m <= 16 * sober::CAR_MS && N - m <= sober::SP_W * sober::SP_BC) ? 1 : 0;
 }
 
 extern "C" int sober_car_supported(int N, int m) {
@@ -1148,39 +1025,49 @@ extern "C" int64_t sober_car_ws_bytes(int N, int m) {
     return mc > one ? mc : one;
 }
 
-extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
-                                int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
-                                double* phi_out, void* ws, int64_t ws_bytes, void* stream) {
+// the per-device function attribute of the streaming pivot kernel (dynamic LDS beyond 64 KB)
+static int car_pivot_attr(size_t sp_bytes) {
+    static std::atomic<unsigned long long> done{0};
+    if (sober_attr_needed(done)) {
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_stream, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sp_bytes));
+        sober_attr_done(done);
+    }
+    return 0;
+}
+
+// SOBER_CAR_FORCE_GIVEUP (any value, read at every call): the test switch that makes the launches which depend on
+// partner workgroups give up -- the fused launch's consumers get a spin limit of one poll, the multi-CU route reports
+// n_keep = -1 -- so that the recovery of the callers can be exercised (tests/test_hip_parity.py).
+extern "C" int sober_car_giveup_forced(void) { return getenv("SOBER_CAR_FORCE_GIVEUP") != nullptr ? 1 : 0; }
+
+extern "C" int sober_car_safe_supported(int N, int m) { return car_one_cu(N, m); }
+
+extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const double* mu_in,
+                                   int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
+                                   double* phi_out, void* ws, int64_t ws_bytes, int mode, void* stream) {
     if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || !ws || ldx < m - 1) return SOBER_E_ARG;
-    if (!car_one_cu(N, m))                                  // beyond one compute unit: car_mc.hip
+    if (mode != SOBER_CAR_DEFAULT && mode != SOBER_CAR_SAFE) return SOBER_E_ARG;
+    if (!car_one_cu(N, m)) {                                // beyond one compute unit: car_mc.hip
+        if (mode == SOBER_CAR_SAFE) return SOBER_E_DIM;     // (every launch there depends on partner workgroups)
         return sober_car_mc_device(X, ldx, N, m, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out, ws, ws_bytes, stream);
+    }
     if (ws_bytes < sober_car_ws_bytes(N, m)) return SOBER_E_WS;
     hipStream_t st = (hipStream_t)stream;
     double* vws = (double*)ws;
     double* taup = vws + (size_t)m * sober::CAR_NS;
     double* Phi = taup + 128;
-    static const bool unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;                // (A/B switches)
-    static const bool barrier_pivot = getenv("SOBER_CAR_PIVOT_BARRIER") != nullptr;
+    static const bool unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;                // (same-box A/B of the fused launch)
     const size_t sp_bytes = sizeof(sober::SpSlot) * sober::SP_RING + sober::SP_W * sizeof(int);
-    static bool sp_attr = false;
-    if (!sp_attr) {
-        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_stream, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)sp_bytes));
-        sp_attr = true;
-    }
-#define CAR_LAUNCH_PIVOT(ERR)                                                                                          \
-    if (barrier_pivot)                                                                                                 \
-        hipLaunchKernelGGL(sober::k_car_pivot, dim3(1), dim3(sober::CAR_PW * 64), 0, st, Phi, N, m, mu_in, keep_rank,   \
-                           w_star, n_keep, mu_out, (const unsigned*)(ERR));                                            \
-    else                                                                                                               \
-        hipLaunchKernelGGL(sober::k_car_pivot_stream, dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m, mu_in,  \
-                           keep_rank, w_star, n_keep, mu_out, (const unsigned*)(ERR));
-    if (phi_out != nullptr || unfused) {
+    { const int rc = car_pivot_attr(sp_bytes); if (rc != 0) return rc; }
+    if (phi_out != nullptr || unfused || mode == SOBER_CAR_SAFE) {
+        // three launches, no workgroup waits for another one: nothing here can give up
         hipLaunchKernelGGL(sober::k_car_bidiag, dim3(1), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(sober::k_car_phi, dim3(sober::CAR_PC / 4), dim3(256), 0, st, vws, taup, N, m, Phi, phi_out);
         LAUNCH_CHECK();
-        CAR_LAUNCH_PIVOT(nullptr)
+        hipLaunchKernelGGL(sober::k_car_pivot_stream, dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m, mu_in,
+                           keep_rank, w_star, n_keep, mu_out, (const unsigned*)nullptr);
         LAUNCH_CHECK();
         return 0;
     }
@@ -1190,13 +1077,21 @@ extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const do
     const unsigned epoch = (epoch_ctr.fetch_add(1) + 1u) & 0x1FFFFFFu;
     void* comm = (void*)(Phi + (size_t)sober::CAR_NS * sober::CAR_PC + 512);
     static const int per_xcd = getenv("SOBER_CARF_PER_XCD") ? atoi(getenv("SOBER_CARF_PER_XCD")) : 40;    // (tuning aid)
+    const unsigned spin_limit = sober_car_giveup_forced() ? 1u : sober::CARF_SPIN_LIMIT;
     hipLaunchKernelGGL(sober::k_car_bidiag_fused, dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup, Phi, comm,
-                       (unsigned)sober::carf_bytes(m), epoch);
+                       (unsigned)sober::carf_bytes(m), epoch, spin_limit);
     LAUNCH_CHECK();
-    CAR_LAUNCH_PIVOT(comm)
+    hipLaunchKernelGGL(sober::k_car_pivot_stream, dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m, mu_in,
+                       keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm);
     LAUNCH_CHECK();
     return 0;
-#undef CAR_LAUNCH_PIVOT
+}
+
+extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
+                                int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
+                                double* phi_out, void* ws, int64_t ws_bytes, void* stream) {
+    return sober_car_device_ex(X, ldx, N, m, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out, ws, ws_bytes,
+                               SOBER_CAR_DEFAULT, stream);
 }
 
 extern "C" int sober_second_elimination(const double* phi, const double* objp, const double* w1, const int32_t* rank1,

@@ -913,6 +913,7 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
 }
 
 // lane-swap self test: out[l] = wave_allsum(in[l]), out[64 + l] = xrow_allsum(in[l])
+__global__ void k_mc_report_giveup(int32_t* __restrict__ n_keep) { if (threadIdx.x == 0) *n_keep = -1; }
 __global__ void k_mc_selftest(const double* __restrict__ in, double* __restrict__ out) {
     const int l = threadIdx.x;
     out[l] = wave_allsum(in[l]);
@@ -922,6 +923,7 @@ __global__ void k_mc_selftest(const double* __restrict__ in, double* __restrict_
 }  // namespace mc
 }  // namespace sober
 
+extern "C" int sober_car_giveup_forced(void);
 extern "C" int sober_car_mc_supported(int N, int m) {
     using namespace sober::mc;
     return (m >= 2 && N > m && N <= NS && m <= 64 * RS_MAX && N - m <= KMAX) ? 1 : 0;
@@ -956,12 +958,12 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
     const int fused = (phi_out == nullptr && !unfused) ? 1 : 0;
     const int G = fused ? FUSED_GRID : ELECT_GRID;
     const size_t pad = fused ? (size_t)FUSED_LDS_PAD : 0;             // (dynamic LDS nobody touches: one workgroup per CU)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};             // (one bit per device)
+    if (sober_attr_needed(attr_set)) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_mc_bidiag<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_PAD));
         HIP_TRY(hipFuncSetAttribute((const void*)k_mc_bidiag<3>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_PAD));
         HIP_TRY(hipFuncSetAttribute((const void*)k_mc_bidiag<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_PAD));
-        attr_set = true;
+        sober_attr_done(attr_set);
     }
     const int RS = (m + 63) / 64;
     switch (RS) {
@@ -984,6 +986,10 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
     hipLaunchKernelGGL(k_mc_pivot, dim3(ELECT_GRID), dim3(256), 0, st, PhiT, N, m, mu_in, keep_rank, w_star, n_keep,
                        mu_out, ws, cbytes, dbg, fused ? (NS + 4 * PHI_RW - 1) / (4 * PHI_RW) : 0);
     LAUNCH_CHECK();
+    if (sober_car_giveup_forced()) {                        // (test switch: what a give-up of the exchange reports)
+        hipLaunchKernelGGL(k_mc_report_giveup, dim3(1), dim3(64), 0, st, n_keep);
+        LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -900,13 +900,13 @@ extern "C" int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, 
     if (n > sober::CH_MAXN) return SOBER_E_DIM;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
     size_t bytes = ((size_t)2 * sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * sober::CH_LDPP) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};             // (one bit per device)
+    if (sober_attr_needed(attr_set)) {
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 512));
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 512));
-        attr_set = true;
+        sober_attr_done(attr_set);
     }
     if (n <= sober::CH_SMALLN) {
         bytes += (size_t)n * (n + 1) * sizeof(double);
@@ -930,11 +930,11 @@ extern "C" int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, con
     if (!Y || !L || !Xinv || !Q || m <= 0 || q <= 0 || q > 256 || ldy < q || ldl < q || ldq < q) return SOBER_E_ARG;
     const int qpad = ((q + 31) / 32) * 32;
     const size_t bytes = (size_t)sober::TB_WAVES * (16 * (qpad + 4) + 16 * 36) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};             // (one bit per device)
+    if (sober_attr_needed(attr_set)) {
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_trsm_blocks, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     120 * 1024));
-        attr_set = true;
+        sober_attr_done(attr_set);
     }
     const int64_t row_blocks = (m + 15) / 16;
     hipLaunchKernelGGL(sober::k_trsm_blocks, dim3((unsigned)((row_blocks + sober::TB_WAVES - 1) / sober::TB_WAVES)),
@@ -984,11 +984,11 @@ extern "C" int sober_cholesky_probe_mc(const double* src, int n, int ld_src, con
     const int64_t flags = ((int64_t)sober::CM_HDR + (int64_t)n_shifts * sober::CM_RUNG_BYTES + 255) / 256 * 256;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
     const size_t bytes = ((size_t)2 * sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * sober::CH_LDPP) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};             // (one bit per device)
+    if (sober_attr_needed(attr_set)) {
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol_mc, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 512));
-        attr_set = true;
+        sober_attr_done(attr_set);
     }
     HIP_TRY(hipMemsetAsync(ws, 0, (size_t)flags, (hipStream_t)stream));
     // every rung starts as "no verdict": a rung that finds no workgroups at all (a device whose XCC ids do not run over

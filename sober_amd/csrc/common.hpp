@@ -13,6 +13,20 @@
         if (_e != hipSuccess) return (int)_e;           \
     } while (0)
 
+// Function attributes (dynamic LDS beyond 64 KB) are per DEVICE: one bit per device ordinal, set after the attribute
+// calls for that device went through.  Usage:  static std::atomic<unsigned long long> done{0};
+//   if (sober_attr_needed(done)) { HIP_TRY(hipFuncSetAttribute(...)); sober_attr_done(done); }
+#include <atomic>
+static inline bool sober_attr_needed(std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    return (done.load(std::memory_order_acquire) & (1ull << (dev & 63))) == 0;
+}
+static inline void sober_attr_done(std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+}
+
 #define LAUNCH_CHECK()                                  \
     do {                                                \
         hipError_t _e = hipGetLastError();              \

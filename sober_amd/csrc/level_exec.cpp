@@ -89,11 +89,29 @@ extern "C" int sober_level_car(const sober_level_job* j, void* stream) {
     const int S = j->S, n = j->n;
     if (!sober_car_supported(S, n + 1)) return SOBER_E_DIM;
     LX_TRY(sober_barycentres(j->Xtr, S, n, S, j->tot, j->X_tmp, stream));
-    LX_TRY(sober_car_device(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
-                            nullptr, j->car_ws, j->car_ws_bytes, stream));
+    LX_TRY(sober_car_device_ex(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
+                               nullptr, j->car_ws, j->car_ws_bytes, j->car_mode, stream));
     const hipError_t e = hipMemcpyAsync(j->h_flags, j->keep_rank, sizeof(int32_t) * (size_t)(S + 1),
                                         hipMemcpyDeviceToHost, (hipStream_t)stream);
     return e == hipSuccess ? 0 : (int)e;
+}
+
+// A level whose Caratheodory step came back with n_keep = -1 (its launches gave up waiting for partner workgroups):
+// the barycentres and masses are still in place, so the step alone is redone with the launches that depend on nobody
+// (SOBER_CAR_SAFE, one-CU sizes) and the job stays in that mode.  -> 0 with a fresh verdict in h_flags, or
+// SOBER_E_EXCHANGE when that mode does not cover the size (the caller's host route is next).
+extern "C" int sober_level_car_retry(sober_level_job* j, void* stream) {
+    if (!j || !j->X_tmp || !j->tot || !j->keep_rank || !j->w_star || !j->mu_out || !j->car_ws || !j->h_flags) return SOBER_E_ARG;
+    const int S = j->S, n = j->n;
+    if (j->car_mode == SOBER_CAR_SAFE || !sober_car_safe_supported(S, n + 1)) return SOBER_E_EXCHANGE;
+    j->car_mode = SOBER_CAR_SAFE;
+    LX_TRY(sober_car_device_ex(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
+                               nullptr, j->car_ws, j->car_ws_bytes, SOBER_CAR_SAFE, stream));
+    hipError_t e = hipMemcpyAsync(j->h_flags, j->keep_rank, sizeof(int32_t) * (size_t)(S + 1), hipMemcpyDeviceToHost,
+                                  (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return j->h_flags[S] < 0 ? SOBER_E_EXCHANGE : 0;
 }
 
 // Partial sums a queued launch of the matrix-core level kernel is sized for: an upper bound of the count the kernel
@@ -151,8 +169,8 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
         }
         // projection and barycentres in one launch (X_tmp = (P G)^T / tot: bit-identical to the two steps)
         LX_TRY(sober_dgemm_coldiv_t(n, S, j->n_rows, j->P, j->n_rows, j->G, S, j->tot, j->X_tmp, n, stream));
-        LX_TRY(sober_car_device(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
-                                nullptr, j->car_ws, j->car_ws_bytes, stream));
+        LX_TRY(sober_car_device_ex(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
+                                   nullptr, j->car_ws, j->car_ws_bytes, j->car_mode, stream));
         LX_TRY(sober_level_update_queued(cur, Rub[l], S, j->keep_rank, j->w_star, j->tot, j->mu, nxt, j->dR + l,
                                          j->dR + l + 1, Rub[l + 1], stream));
     }
@@ -202,8 +220,16 @@ extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, i
         LX_TRY(sober_level_car(j, stream));
         const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // the host decides the next level's size
         if (e != hipSuccess) return (int)e;
+        if (j->h_flags[S] < 0) {                                            // the Caratheodory launches gave up
+            const int rc = sober_level_car_retry(j, stream);
+            if (rc != 0) {                                                  // (state handed back: this level is still due)
+                *n_levels = levels; *R_final = R; *in_b = (cur == idx_b) ? 1 : 0;
+                for (int k = 0; k < 4; ++k) j->ev[k] = nullptr;
+                j->phase = 0;
+                return rc;
+            }
+        }
         const int n_keep = j->h_flags[S];
-        if (n_keep < 0) { *n_levels = levels; return SOBER_E_EXCHANGE; }   // the Caratheodory kernels' exchange gave up
         const bool last_kept = j->h_flags[S - 1] >= 0;
         const int64_t R_new = E * n_keep + (last_kept ? r : 0);             // :198-221
         level_R[levels++] = R;
@@ -235,12 +261,12 @@ extern "C" int sober_level_final(const sober_level_job* j, const void* rows_sc, 
     LX_TRY(sober_dgemm(0, 0, n, R, j->n_rows, 1.0, j->P, j->n_rows, K, R, 0.0, j->Xtr, R, stream));
     LX_TRY(sober_barycentres(j->Xtr, R, n, R, nullptr, j->X_tmp, stream));          // (U K)^T, no division
     LX_TRY(sober_gather_f64(j->mu, idx, R, mu_live, stream));                       // :84
-    LX_TRY(sober_car_device(j->X_tmp, n, R, n + 1, mu_live, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
-                            nullptr, j->car_ws, j->car_ws_bytes, stream));          // :85
-    hipError_t e = hipMemsetAsync(j->mu, 0, sizeof(double) * (size_t)N, (hipStream_t)stream);   // mu[:] = 0  (:109)
-    if (e != hipSuccess) return (int)e;
-    LX_TRY(sober_final_scatter(idx, R, j->keep_rank, j->w_star, row_offset, j->mu, out_idx, out_w, stream));
-    e = hipMemcpyAsync(j->h_flags + S, j->keep_rank + S, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    LX_TRY(sober_car_device_ex(j->X_tmp, n, R, n + 1, mu_live, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
+                               nullptr, j->car_ws, j->car_ws_bytes, j->car_mode, stream));   // :85
+    // mu[:] = 0 (:109) and the write-back -- both skipped on the device when the step reported no result
+    LX_TRY(sober_final_commit(idx, R, j->keep_rank, j->w_star, j->keep_rank + S, row_offset, j->mu, N, out_idx, out_w,
+                              stream));
+    hipError_t e = hipMemcpyAsync(j->h_flags + S, j->keep_rank + S, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
     return e == hipSuccess ? 0 : (int)e;
 }
 
@@ -300,8 +326,11 @@ extern "C" int sober_level_loop_sharded(sober_level_job* j, int rank, int world,
         LX_TRY(sober_level_car(j, stream));
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) return (int)e;
+        if (j->h_flags[S] < 0) {                                            // (a rank-local event: the redone step gives
+            const int rc = sober_level_car_retry(j, stream);                    //  this rank the other ranks' verdict; beyond
+            if (rc != 0) { *n_levels = levels; *in_b = (cur == idx_b) ? 1 : 0; j->phase = 0; return rc; }   //  the safe sizes the run ends here)
+        }
         const int n_keep = j->h_flags[S];
-        if (n_keep < 0) return SOBER_E_EXCHANGE;
         const bool last_kept = j->h_flags[S - 1] >= 0;
         const int64_t R_new = E * n_keep + (last_kept ? r : 0);
         level_R[levels++] = R;

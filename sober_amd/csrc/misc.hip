@@ -245,6 +245,28 @@ __global__ void k_final_scatter(const int32_t* __restrict__ idx, int n, const in
     out_w[k] = w;
 }
 
+// mu[:] = 0 (SOBER/_rchq.py:109) -- unless the Caratheodory step in front reported no result (*n_keep < 0): the caller
+// then redoes the step on another route with the weights intact
+__global__ void k_zero_unless_failed(double* __restrict__ mu, int64_t N, const int32_t* __restrict__ n_keep) {
+    if (*n_keep < 0) return;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N; t += (int64_t)gridDim.x * blockDim.x) mu[t] = 0.0;
+}
+__global__ void k_final_scatter_guarded(const int32_t* __restrict__ idx, int n, const int32_t* __restrict__ keep_rank,
+                                        const double* __restrict__ w_star, const int32_t* __restrict__ n_keep,
+                                        int64_t row_offset, double* __restrict__ mu, int64_t* __restrict__ out_idx,
+                                        double* __restrict__ out_w) {
+    if (*n_keep < 0) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int k = keep_rank[t];
+    if (k < 0) return;
+    const int c = idx[t];
+    const double w = w_star[k];
+    mu[c] = w;
+    out_idx[k] = (int64_t)c + row_offset;
+    out_w[k] = w;
+}
+
 __global__ void k_i64_to_i32(const int64_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) out[t] = (int32_t)in[t];
@@ -577,6 +599,20 @@ extern "C" int sober_final_scatter(const int32_t* idx, int n, const int32_t* kee
     if (!idx || !keep_rank || !w_star || !mu || !out_idx || !out_w || n <= 0) return SOBER_E_ARG;
     hipLaunchKernelGGL(k_final_scatter, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, idx, n, keep_rank, w_star,
                        row_offset, mu, out_idx, out_w);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_final_commit(const int32_t* idx, int n, const int32_t* keep_rank, const double* w_star,
+                                  const int32_t* n_keep, int64_t row_offset, double* mu, int64_t N, int64_t* out_idx,
+                                  double* out_w, void* stream) {
+    if (!idx || !keep_rank || !w_star || !n_keep || !mu || !out_idx || !out_w || n <= 0 || N <= 0) return SOBER_E_ARG;
+    int64_t nb = nblk(N, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_zero_unless_failed, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, mu, N, n_keep);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_final_scatter_guarded, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, idx, n, keep_rank,
+                       w_star, n_keep, row_offset, mu, out_idx, out_w);
     LAUNCH_CHECK();
     return 0;
 }

@@ -621,10 +621,115 @@ def test_calc_obj_levels_on_the_device(N, M, d, b, dev):
     assert "car_host" not in timers, timers
 
 
+# --------------------------------------------------------------------------- #
+# a give-up of the multi-workgroup Caratheodory launches is recovered, not raised (SOBER/_rchq.py:224-270 never fails)
+# --------------------------------------------------------------------------- #
+@pytest.fixture
+def forced_giveup(monkeypatch, dev):
+    """SOBER_CAR_FORCE_GIVEUP: every launch that waits for partner workgroups gives up (the fused launch's consumers
+    poll once, the multi-CU route reports n_keep = -1).  A fresh HipOps per test: the downgrade is remembered per
+    instance, the process-wide one stays on the fast rung."""
+    from sober_amd import _native as nat
+    from sober_amd._ops_hip import HipOps
+    monkeypatch.setenv("SOBER_CAR_FORCE_GIVEUP", "1")
+    assert nat.load().sober_car_giveup_forced() == 1
+    return HipOps(dev)
+
+
+def _golden_with_ops(path, dev, ops, timers=None):
+    case, inp, spec, z = load_case(path)
+    mu = _t(inp["mu0"].copy()).to(dev)
+    torch.manual_seed(SEED_CALL)
+    idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                     sober_amd.Kernel(kspec(spec), case["mode"]), dev, torch.double, init_weights=mu,
+                                     _ops=ops, _timers=timers)
+    return z, idx, w
+
+
+@pytest.mark.parametrize("name", ["rbf_medium", "matern_medium", "rbf_tiny_direct"])
+def test_giveup_is_recovered_on_the_single_workgroup_kernels(name, dev, forced_giveup):
+    """One-CU sizes: the level whose fused launch gave up is redone with the stand-alone bidiagonalisation + Phi +
+    pivot launches (queued chain -> synchronised loop -> sober_level_car_retry; final level -> level_final again);
+    the result is the golden's, the instance stays on that rung, one warning."""
+    from sober_amd import _native as nat
+    ops = forced_giveup
+    path = os.path.join(GOLD, f"recomb_{name}.npz")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        z, idx, w = _golden_with_ops(path, dev, ops)
+    assert np.array_equal(idx.cpu().numpy(), z["idx"])
+    np.testing.assert_allclose(w.cpu().numpy(), z["w"], rtol=W_RTOL)
+    assert ops.car_mode == nat.CAR_SAFE
+    assert sum("gave up" in str(r.message) for r in rec) == 1
+    # the next step starts on the safe rung: no further give-up, no further warning
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        z, idx, w = _golden_with_ops(path, dev, ops)
+    assert np.array_equal(idx.cpu().numpy(), z["idx"])
+    assert not any("gave up" in str(r.message) for r in rec)
+
+
+def test_giveup_beyond_one_cu_goes_to_the_host_route(dev, forced_giveup):
+    """batch 120 (S = 240: the multi-CU kernels, every one of which depends on partner workgroups): the levels and the
+    final level go to host LAPACK + the C++ pivots; same indices as the undisturbed run, weights to 1e-8."""
+    from sober_amd import _native as nat
+    from sober_amd._ops_hip import HipOps
+    from tests.golden.synth import synth, build_spec
+    case = dict(kind=O.MATERN52, mode="predictive_covariance", N=9000, M=300, d=5, b=120, n_obs=60, seed=77, ard=True,
+                bit_p=0.04, mean_const=0.4)
+    inp = synth(case)
+    spec = build_spec(case, inp)
+
+    def run(ops, timers):
+        mu = _t(inp["mu0"].copy()).to(dev)
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), 120,
+                                             sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu, _ops=ops,
+                                             _timers=timers)
+        return idx.cpu().numpy(), w.cpu().numpy(), mu.cpu().numpy()
+    t_forced = {}
+    i1, w1, m1 = run(forced_giveup, t_forced)
+    assert forced_giveup.car_mode == nat.CAR_HOST and "car_host" in t_forced
+    os.environ.pop("SOBER_CAR_FORCE_GIVEUP")
+    t_plain = {}
+    i0, w0, m0 = run(HipOps(dev), t_plain)
+    assert "car_host" not in t_plain
+    assert np.array_equal(i0, i1)
+    np.testing.assert_allclose(w1, w0, rtol=1e-8)
+    np.testing.assert_allclose(m1, m0, rtol=1e-8, atol=0)
+
+
+def test_car_safe_mode_equals_default_mode(dev):
+    """sober_car_device_ex: SOBER_CAR_SAFE (stand-alone launches) against SOBER_CAR_DEFAULT (fused launch) on a
+    reference level input -- same sets, weights to 1e-12; SOBER_E_DIM beyond the one-CU sizes."""
+    from sober_amd import _native as nat
+    z = np.load(os.path.join(GOLD, "recomb_matern_medium.npz"))
+    X, mu = _t(z["L0_X_tmp"]).to(dev), _t(z["L0_tot_weights"]).to(dev)
+    N = X.shape[0]
+    out = []
+    for mode in (nat.CAR_DEFAULT, nat.CAR_SAFE):
+        kr = torch.empty(N, dtype=torch.int32, device=dev); ws = torch.empty(N, dtype=torch.float64, device=dev)
+        nk = torch.empty(1, dtype=torch.int32, device=dev); mo = torch.empty(N, dtype=torch.float64, device=dev)
+        nat.car_device(X, mu, kr, ws, nk, mo, mode=mode)
+        out.append((kr.cpu().numpy(), ws.cpu().numpy(), int(nk.item())))
+    assert out[0][2] == out[1][2] > 0 and np.array_equal(out[0][0], out[1][0])
+    np.testing.assert_allclose(out[1][1][:out[1][2]], out[0][1][:out[0][2]], rtol=1e-12)
+    assert not nat.car_safe_supported(400, 200) and nat.car_supported(400, 200)
+    Xb = torch.randn(400, 199, dtype=torch.float64, device=dev)
+    with pytest.raises(nat.SoberHipError, match="dimension"):
+        nat.car_device(Xb, torch.rand(400, dtype=torch.float64, device=dev), torch.empty(400, dtype=torch.int32, device=dev),
+                       torch.empty(400, dtype=torch.float64, device=dev), torch.empty(1, dtype=torch.int32, device=dev),
+                       torch.empty(400, dtype=torch.float64, device=dev), mode=nat.CAR_SAFE)
+
+
 def test_cfg3_matern_full_size_vs_oracle(dev):
-    """Hartmann-shaped: d=6, Matern-5/2, N_rec=50k, N_nys=500, batch=200 (batch > 100: the
-    Caratheodory steps take the LAPACK route)."""
-    _vs_oracle(O.MATERN52, "predictive_covariance", 50000, 500, 6, 200, 200, 3, dev)
+    """Hartmann-shaped: d=6, Matern-5/2, N_rec=50k, N_nys=500, batch=200 -- every Caratheodory step (400 x 200) on the
+    multi-CU kernels of csrc/car_mc.hip, none on the host's LAPACK."""
+    timers = {}
+    _vs_oracle(O.MATERN52, "predictive_covariance", 50000, 500, 6, 200, 200, 3, dev, timers=timers)
+    assert "car_host" not in timers and "nystrom_host" not in timers, timers
 
 
 def test_cfg5_tanimoto_weighted_vs_oracle(dev):
