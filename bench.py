@@ -18,12 +18,15 @@ scale WEAKLY (every rank owns a full-size shard, one recombination over the N-fo
 reference's 8-GPU case and scales STRONGLY (the 1M-row pool is split N ways: 125k rows per GPU at N = 8).
 Rank 0 prints ONE JSON line.  `value` = candidates reduced per second, whole job.
 `roofline` is for the dominant kernel (the level reduction): algorithmic FP64 flop ((2d + 2 + C_k)
-per kernel entry, C_k = 28 for the software FP64 exp, 40 for Matern-5/2) / HIP-event time of its launches, against
-the FP64 peak; for the Tanimoto kernel the integer operations of popcount(x & y) as an INT8 GEMM (2 per bit and
-(row, candidate) pair) against the dense INT8 matrix peak.
+per kernel entry, C_k = 28 for the software FP64 exp, 40 for Matern-5/2) / the summed durations of ALL its launches in
+the timed region (main and leftover launches; HIP events carried in the dispatches themselves, i.e. the kernels' own
+begin / end timestamps -- calls x AverageNs of a rocprofv3 --kernel-trace --stats run of the same command), against the
+FP64 peak; for the Tanimoto kernel the integer operations of popcount(x & y) as an INT8 GEMM (2 per bit and (row,
+candidate) pair) against the dense INT8 matrix peak.  `roofline.step_frac` is the whole step's algorithmic flop
+(SURVEY.md 8d F_alg) / ms_per_step against the same peak; `hbm` = algorithmic bytes / time (small by construction).
 `cpu_baseline` = the oracle (a torch-CPU port of the reference's own arithmetic) on this box's host cores, on a
 bounded sample of the same workload: reference-shaped (materialises the (E, M, S) tensor of SOBER/_rchq.py:124) and
-streaming (the same sums over cache-sized element blocks); `value` is the faster of the two.
+streaming (the same sums over cache-sized element blocks); median of 3 each, `value` is the faster of the two.
 """
 import argparse
 import json
@@ -58,13 +61,38 @@ FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector = FP64 matrix (vendor; SUR
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
 INT8_PEAK_TOPS = 5000.0          # dense INT8 MFMA = 2 x the bf16 rate (MI355X_MICROARCH.md, matrix cores)
 CK = {"rbf": 28, "matern52": 40}
-# HBM bytes per launch of the level kernel (mean over the launches of a step: 15 at configuration 2, the leftover
-# launches included) from rocprofv3 PMC passes of the configuration: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950
-# FETCH_SIZE correction of MI355X_MICROARCH.md; separate --pmc passes; profiles/r02_pmc_level_reduce.csv).
-# Algorithmic bytes at configuration 2 are ~1.4 MB/launch (every live candidate row, index and weight once per
-# level).  The excess: the <= 5 partial sums per tile (5.6 MB written at level 0, re-read by k_sum_partials) and the
-# candidate rows that two XCDs' L2s both fetch.  Round 1: 23.4 MB; workgroup-staged kernel with 13 chunks: 11.6 MB.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {2: 6.6e6}
+# What the FP64 units of an MI355X sustain chip-wide (scripts/dp_rate_probe.hip, wall clock, all 256 CUs; committed
+# output: profiles/r03_dp_rate.txt): the clock under FP64 load is ~1.9 GHz, not the 2.4 GHz of the vendor figure.
+FP64_MEASURED_TFLOPS = {"v_fma_f64": 61.0, "v_mfma_f64_16x16x4": 63.0, "level-kernel mix (12 MFMA + 160 FMA)": 69.0,
+                        "source": "profiles/r03_dp_rate.txt"}
+
+
+def pmc_traffic(config):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS configuration
+    (profiles/rNN_pmc_traffic.json, newest round; written by scripts/collect_profiles.py from separate FETCH_SIZE and
+    WRITE_SIZE runs of `bench.py --config C`: mean over the kernel's launches of (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+    -- the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md).  None when no pass is committed for it."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1])).get(str(config))
+    except Exception:
+        return None, None
+    return (d["bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if d else (None, None)
+
+
+def host_cpu():
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"model": model, "logical_cpus": os.cpu_count()}
 
 
 def t(a):
@@ -124,16 +152,18 @@ def cpu_baseline_for(cfg, spec, inp, dev_inputs, cpu_steps):
         for th in sorted({os.cpu_count() // 2 or 1, 8}):
             torch.set_num_threads(th)
             cpu_step(stream)                                  # warm-up
-            c0 = time.perf_counter()
+            each = []
             for _ in range(cpu_steps):
+                c0 = time.perf_counter()
                 cpu_step(stream)
-            runs[(variant, th)] = (time.perf_counter() - c0) / cpu_steps
+                each.append(time.perf_counter() - c0)
+            runs[(variant, th)] = float(np.median(each))
     torch.set_num_threads(old)
     best = min(runs, key=runs.get)
     return {"value": N_s / runs[best], "unit": "candidates/s", "cores": best[1], "kind": "port", "variant": best[0],
-            "ms_per_step": runs[best] * 1e3,
+            "host": host_cpu(), "ms_per_step": runs[best] * 1e3, "statistic": f"median of {cpu_steps}",
             "ms_per_step_by_variant_and_threads": {f"{v}@{th}": s * 1e3 for (v, th), s in runs.items()},
-            "sample": f"{cpu_steps} recombination steps after 1 warm-up on "
+            "sample": f"median of {cpu_steps} recombination steps after 1 warm-up on "
                       + ("the full workload" if N_s == cfg["N"] else f"the first {N_s} candidates of the workload")
                       + f" (N_nys={cfg['M']}, batch={cfg['b']}), oracle = torch CPU FP64 port of the reference: "
                         "reference-shaped (materialised (E, M, S) tensor) and streaming (16-element blocks), each at "
@@ -147,7 +177,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-sweep", action="store_true", help="skip the n_obs sweep of SURVEY.md 8(d) (configuration 2, one GPU)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -200,7 +231,7 @@ def main():
     # the warm-up steps run exactly what the timed steps run, event brackets included (their first use costs
     # tens of ms in a fresh process)
     ops.prof = []
-    ops.prof_reserve(24 * (args.steps + args.warmup + 1))    # event pairs for the level launches, created up front
+    ops.prof_reserve(48 * (args.steps + args.warmup + 1))    # event pairs for the level launches, created up front
     idx, w = step()                                      # initialisation (library load, workspaces, first-use paths)
     import gc
     gc.collect(); gc.disable()                           # no collector pauses inside the timed region
@@ -224,22 +255,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # dominant kernel: HIP-event time of every level's MAIN reduction launch in the timed region (the leftover launch
-    # behind it -- at most S - 1 positions, ~3.6 us, 0.1 % of the kernel's work -- is not bracketed: a hipEventRecord
-    # costs the stream ~5 us, and four per level were 0.1 ms of the step), minus the
-    # cost of an empty event pair on the same stream (calibrated here; ~5 us, comparable to the deep
-    # levels' launches -- without it the event sum would not agree with rocprofv3's kernel durations)
+    # dominant kernel: the durations of ALL its launches in the timed region (main and leftover launch of every level).
+    # The event pairs ride in the dispatches (hipExtLaunchKernelGGL, sober_set_launch_events): elapsed_time is the
+    # kernel's own begin -> end, the figure rocprofv3 --kernel-trace reports; no marker packet enters the stream and
+    # nothing is subtracted.  kernel_ms_per_step = calls x AverageNs / steps of profiles/r03_cfgN_kernel_stats.csv.
     prof, ops.prof = ops.prof, None
-    cal = []
-    from sober_amd import _native as nat
-    ops.prof_reserve(200)
-    st = torch.cuda.current_stream(dev).cuda_stream
-    for _ in range(200):                               # same mechanism as the executor's brackets
-        e0, e1 = ops._prof_pair()
-        nat.record_event_pair(e0, e1, st); cal.append((e0, e1))
-    torch.cuda.synchronize()
-    ev_overhead = float(np.median([a.elapsed_time(b_) for a, b_ in cal]))
-    kern_ms = sum(max(a.elapsed_time(b_) - ev_overhead, 0.0) for a, b_, _, _ in prof)
+    kern_ms = sum(a.elapsed_time(b_) for a, b_, _, _ in prof)
     entries = sum(e for _, _, e, _ in prof)
     n_launches = sum(n for _, _, _, n in prof)
 
@@ -272,36 +293,79 @@ def main():
         cpu_baseline = cpu_baseline_for(cfg, spec, inp, (X_cand, X_nys, mu0), args.cpu_steps)
 
     ms_per_step = elapsed / args.steps * 1e3
+    traffic, traffic_src = pmc_traffic(args.config) if world == 1 else (None, None)
+    n_rows = cfg["M"] + (cfg["n_obs"] if cfg["mode"] != "kernel" else 0)
+    V = entries / n_rows / args.steps                      # visited list positions per step (sum of the levels' sizes)
+    n_levels = sum(1 for _, _, e, _ in prof if e > 0 and e >= 2 * b * n_rows) / args.steps   # main launches per step
+    S2, n1 = 2 * b, b - 1
+    common = {"launches": n_launches, "launches_per_step": n_launches / args.steps,
+              "kernel_ms_per_step": kern_ms / args.steps,
+              "timing": "HIP events carried in the kernels' dispatches (their own begin/end timestamps), all launches of "
+                        "the kernel in the timed region, nothing subtracted",
+              "traffic": traffic, "traffic_unit": "HBM bytes per launch, mean over the kernel's launches of a step",
+              "traffic_source": traffic_src, "V_per_step": V, "entries_per_step": entries / args.steps}
     if cfg["kind"] == "tanimoto":
         # popcount(x & y) as an INT8 GEMM on the matrix cores (csrc/level_reduce_tani.hip): 2 * bits integer operations
         # per (row, candidate) pair, against the dense INT8 MFMA peak (2 x the bf16 rate, MI355X_MICROARCH.md)
         bits = 64 * ((cfg["d"] + 63) // 64)
+        ops_step = entries / args.steps * 2 * bits
         tops = entries * 2 * bits / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tops / INT8_PEAK_TOPS,
-                    "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(args.config) if world == 1 else None,
-                    "kernel": "k_level_reduce_tani", "launches": n_launches,
-                    "kernel_ms_per_step": kern_ms / args.steps, "event_pair_overhead_ms": ev_overhead,
-                    "note": "bit-packed fingerprints, bits expanded to bytes in LDS, v_mfma_i32_16x16x64_i8 (integer "
-                            "operations counted in the TFLOP/s unit); the matrix pipe, the LDS (fragment reads + the "
-                            "expanded tile's writes) and the vector unit (bit expansion, Tanimoto quotient, FP64 "
-                            "accumulation) are each ~1/3 busy -- none of them is the single bound"}
+        alg_bytes = V * (bits / 8 + 16) + n_levels * (n_rows * S2 + S2) * 8
+        roofline = dict(common, bound="mfma", achieved=tops, peak=INT8_PEAK_TOPS, unit="TFLOP/s", frac=tops / INT8_PEAK_TOPS,
+                        step_frac=ops_step / (ms_per_step * 1e-3) / 1e12 / INT8_PEAK_TOPS, kernel="k_level_reduce_tani",
+                        note="bit-packed fingerprints, bits expanded to bytes in LDS, v_mfma_i32_16x16x64_i8 (integer "
+                             "operations counted in the TFLOP/s unit); the matrix pipe, the LDS (fragment reads + the "
+                             "expanded tile's writes) and the vector unit (bit expansion, Tanimoto quotient, FP64 "
+                             "accumulation) are each ~1/3 busy -- none of them is the single bound")
     else:
         flop_per_entry = 2 * cfg["d"] + 2 + CK[cfg["kind"]]
         achieved = entries * flop_per_entry / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_PEAK_TFLOPS,
-                    "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(args.config) if world == 1 else None,
-                    "kernel": "k_level_reduce_wave", "launches": n_launches, "kernel_ms_per_step": kern_ms / args.steps,
-                    "event_pair_overhead_ms": ev_overhead,
-                    "note": "FP64 compute-bound: -|x-y|^2/2 on v_mfma_f64_16x16x4 (augmented GEMM), "
-                            "table-driven FP64 exp on the VALU; MI355X FP64 vector and matrix peaks are "
-                            "both 78.6 TFLOP/s at 2.4 GHz and share the vector ALU: on gfx950 no vector "
-                            "instruction of a SIMD overlaps with a running v_mfma_f64, and the clock under "
-                            "FP64 load is ~1.9 GHz (scripts/dp_rate_probe.hip: 63 TFLOP/s MFMA-only, "
-                            "61 FMA-only) -- the kernel is bound by its instruction count; "
-                            f"algorithmic flop = entries * (2d+2+C_k) = entries * {flop_per_entry}; all "
-                            "main launches of a step are averaged (level 0 alone runs ~1.35x the average); the leftover launches "
-                            "(<= S-1 positions each) are not timed"}
+        # F_alg = entries (2d + 2 + C_k) + L (2 M n_obs S + 2 n M S)
+        f_alg = entries / args.steps * flop_per_entry + n_levels * (2.0 * cfg["M"] * cfg["n_obs"] * S2 + 2.0 * n1 * cfg["M"] * S2)
+        alg_bytes = V * (8 * cfg["d"] + 16) + n_levels * (n_rows * S2 + S2) * 8
+        roofline = dict(common, bound="mfma", achieved=achieved, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / FP64_PEAK_TFLOPS, peak_measured=FP64_MEASURED_TFLOPS,
+                        frac_of_measured_mix=achieved / FP64_MEASURED_TFLOPS["level-kernel mix (12 MFMA + 160 FMA)"],
+                        F_alg_per_step=f_alg, step_frac=f_alg / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                        kernel="k_level_reduce_wave",
+                        note="FP64 compute-bound: -|x-y|^2/2 on v_mfma_f64_16x16x4 (augmented GEMM), "
+                             "table-driven FP64 exp on the VALU; MI355X FP64 vector and matrix peaks are "
+                             "both 78.6 TFLOP/s at 2.4 GHz and share the vector ALU: on gfx950 no vector "
+                             "instruction of a SIMD overlaps with a running v_mfma_f64, and the clock under "
+                             "FP64 load is ~1.9 GHz (peak_measured) -- the kernel is bound by its instruction count; "
+                             f"algorithmic flop = entries * (2d+2+C_k) = entries * {flop_per_entry}; all launches of "
+                             "the kernel are counted (level 0 alone runs ~1.35x the average; the deep levels are "
+                             "launch-bound); step_frac: the step is a chain of ~200 dependent Caratheodory "
+                             "reflector/pivot steps per level, not a throughput problem")
+    hbm = {"alg_bytes_per_step": alg_bytes, "gbs_over_step": alg_bytes / (ms_per_step * 1e-3) / 1e9,
+           "gbs_over_kernel": alg_bytes / (kern_ms / args.steps * 1e-3) / 1e9 if kern_ms > 0 else None,
+           "peak_gbs": HBM_PEAK_GBS, "frac_over_step": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "note": "B_alg = V (8d + 16) + L (M_tot S + S) 8 (SURVEY.md 8d); a small fraction by construction: the path "
+                   "is FP64-compute and latency bound at ~300 flop/B"}
+
+    # n_obs sweep at the headline configuration (one GPU; outside the timed region)
+    sweep = None
+    if world == 1 and args.config == 2 and not args.no_sweep:
+        sweep = {}
+        for n_obs in (100, 200, 800, 1600):
+            c2 = dict(cfg, n_obs=n_obs)
+            Xc2, Xn2, mu02, spec2, _, _ = build_inputs(c2, 0, 1, dev)
+            k2 = sober_amd.Kernel(sober_amd.KernelSpec(spec2.kind, spec2.lengthscale, spec2.outputscale, spec2.X_obs,
+                                                       spec2.S_cache, spec2.noise, spec2.mean_const, spec2.alpha), cfg["mode"])
+            m2 = mu02.clone()
+            ts = []
+            for it in range(8):
+                m2.copy_(mu02)
+                torch.manual_seed(SEED_CALL)
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    sober_amd.recombination(Xc2, Xn2, b, k2, dev, torch.double, init_weights=m2, _ops=ops)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - c0) * 1e3)
+            sweep[str(n_obs)] = float(np.median(ts[3:]))
+            del Xc2, Xn2, mu02, m2, k2
     strong = bool(cfg.get("strong"))
     n_rec = str(cfg["N"]) if (strong or world == 1) else "%dx%d" % (world, cfg["N"])
     out = {
@@ -317,7 +381,9 @@ def main():
                    "parallelism": f"pool row-sharded x{world}, one all-reduce of (n*S+S) f64 per level"
                                   if world > 1 else "single GPU"},
         "roofline": roofline,
+        "hbm": hbm,
         "cpu_baseline": cpu_baseline,
+        "n_obs_sweep_ms_per_step": sweep,
         "parity": parity,
         "kmeans_nystrom_subsample_ms": kmeans_ms,
         "ms_per_step_incl_kmeans": None if kmeans_ms is None else ms_per_step + kmeans_ms,

@@ -412,8 +412,11 @@ typedef struct sober_level_job {
     double *w_star, *mu_out;                    /* S each                                                   */
     void* car_ws; int64_t car_ws_bytes;         /* sober_car_ws_bytes(S, n + 1)                             */
     int32_t* h_flags;                           /* pinned host, S + 1 int32                                 */
-    void* ev[4];                                /* optional hipEvent_t: recorded before / after the level_reduce
-                                                   launch (ev[0], ev[1]) and the leftover launch (ev[2], ev[3]) */
+    void* ev[4];                                /* optional hipEvent_t pairs for the level kernel's main launch (ev[0],
+                                                   ev[1]) and its leftover launch (ev[2], ev[3]).  Matrix-core variants:
+                                                   carried IN the dispatch (sober_set_launch_events: the kernel's own
+                                                   begin / end timestamps, what rocprofv3 reports); the others: recorded
+                                                   on the stream before / after the launch                          */
     /* per level */
     const int32_t* idx; int64_t pos0, count, E;
     double* mu;                                 /* read by the set sums; rescaled by sober_level_loop's updates */
@@ -426,6 +429,8 @@ typedef struct sober_level_job {
     int64_t* dR; int64_t* h_dR;
     int32_t car_mode;                           /* SOBER_CAR_DEFAULT / SOBER_CAR_SAFE for the Caratheodory steps; the loops
                                                    raise it to SOBER_CAR_SAFE after a give-up (in/out)                   */
+    uint64_t ev_used[2];                        /* out (sober_level_loop with events): bit l of [0] / [1] = the event pair of
+                                                   level l's main / leftover launch was attached to a launch          */
 } sober_level_job;
 #define SOBER_LEVEL_QUEUE 24
 int sober_level_moments(const sober_level_job* job, void* stream);
@@ -485,7 +490,12 @@ int64_t sober_rccl_allreduce_ptr(void);     /* the address of sober_rccl_allredu
 int sober_level_final(const sober_level_job* job, const void* rows_sc, const double* rows_norm, const void* cand_sc,
                       const double* cand_norm, int dt, const int32_t* idx, int R, int64_t N, int64_t row_offset,
                       double* K, double* mu_live, int64_t* out_idx, double* out_w, void* stream);
-/* ev0, ev1 (hipEvent_t) recorded back to back: the empty bracket, for calibrating the ev[] timings.       */
+/* Arms a pair of hipEvent_t for the NEXT level-kernel launch (matrix-core variants) made by the calling thread: the
+ * launch carries them in its dispatch (hipExtLaunchKernelGGL), so hipEventElapsedTime(start, stop) is the kernel's own
+ * duration -- the number rocprofv3 --kernel-trace reports for it -- and no marker packet enters the stream.
+ * (NULL, NULL) disarms.                                                                                              */
+int sober_set_launch_events(void* start, void* stop);
+/* ev0, ev1 (hipEvent_t) recorded back to back: the empty bracket (what two marker packets cost the stream).    */
 int sober_record_event_pair(void* ev0, void* ev1, void* stream);
 
 #ifdef __cplusplus

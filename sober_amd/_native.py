@@ -105,6 +105,7 @@ SIGNATURES = {
     "sober_sum_partials_queued": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_level_update_queued": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_record_event_pair": (_i32, [_vp, _vp, _vp]),
+    "sober_set_launch_events": (_i32, [_vp, _vp]),
     "sober_gather_f64": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "sober_final_scatter": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "sober_level_final": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
@@ -132,6 +133,7 @@ class LevelJob(C.Structure):
         ("phase", _i32),
         ("dR", _vp), ("h_dR", _vp),
         ("car_mode", _i32),
+        ("ev_used", C.c_uint64 * 2),
     ]
 
 E_DIM = -2

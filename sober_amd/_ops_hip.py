@@ -29,9 +29,10 @@ class HipOps:
                                     f"{self.device}.  There is no CPU fallback.")
         nat.load()
         self._pin = {}
-        self.prof = None        # list -> (start_event, end_event, kernel entries, launches) per level: ONE bracket, around the
-        #                         main launch (every hipEventRecord costs the step ~5 us; the leftover launch -- at most
-        #                         S - 1 positions, ~3.6 us -- is not timed)
+        self.prof = None        # list -> (start_event, stop_event, kernel entries, launches), one entry per launch of the
+        #                         level kernel (main and leftover): the events ride in the dispatch itself
+        #                         (sober_set_launch_events), so they hold the kernel's own duration -- rocprofv3's number --
+        #                         and cost the stream nothing
         self.use_mfma = True    # False: VALU-only level kernel (direct differences), kept for A/B runs
         # False (or SOBER_NO_QUEUE in the environment): every level sized by the host after a synchronisation (A/B runs)
         self.queue_levels = os.environ.get("SOBER_NO_QUEUE") is None
@@ -445,11 +446,14 @@ class HipOps:
         pair = None
         if self.prof is not None:
             n_left = max(pos0 + count - max(pos0, E * S), 0)
-            pair = self._prof_pair()
-            job.ev[0], job.ev[1], job.ev[2], job.ev[3] = pair[0].cuda_event, pair[1].cuda_event, None, None
+            pair, pair2 = self._prof_pair(), (self._prof_pair() if n_left > 0 else None)
+            job.ev[0], job.ev[1] = pair[0].cuda_event, pair[1].cuda_event
+            job.ev[2], job.ev[3] = (pair2[0].cuda_event, pair2[1].cuda_event) if pair2 else (None, None)
         nat.level_moments(job, nat._stream(mu))
         if pair is not None:
             self.prof.append((pair[0], pair[1], int(count * job.n_rows), 1))
+            if pair2 is not None:
+                self.prof.append((pair2[0], pair2[1], int(n_left * job.n_rows), 1))
             for k in range(4):
                 job.ev[k] = None
         return p.ws["Xtr"], p.ws["tot"]
@@ -465,24 +469,25 @@ class HipOps:
         events = pairs = None
         if self.prof is not None:
             n_max = min(nat.MAX_LEVELS, int(math.log2(max(R / S, 1.0))) + 3)
-            pairs = [self._prof_pair() for _ in range(n_max)]
+            pairs = [(self._prof_pair(), self._prof_pair()) for _ in range(n_max)]      # (main, leftover) per level
             events = [None] * (4 * nat.MAX_LEVELS)
-            for l, a in enumerate(pairs):
-                events[4 * l:4 * l + 4] = [a[0].cuda_event, a[1].cuda_event, None, None]
+            for l, (a, b) in enumerate(pairs):
+                events[4 * l:4 * l + 4] = [a[0].cuda_event, a[1].cuda_event, b[0].cuda_event, b[1].cuda_event]
         level_R, R_final, in_b, gave_up = nat.level_loop(job, R, idx_cur, idx_new, sums_ready, events, nat._stream(mu))
         if job.car_mode > min(self.car_mode, nat.CAR_SAFE):
             self._car_downgrade(nat.CAR_SAFE, "level loop")
         if gave_up:                                          # beyond the single-workgroup kernels: the host route is next
             self._car_downgrade(nat.CAR_HOST, "level loop")
         if pairs is not None:
-            for l, a in enumerate(pairs):
-                if l == 0 and sums_ready:                   # (that level's launches were bracketed by the phase-1 call)
-                    self._ev_pool.append(a)
-                elif l < len(level_R):
-                    Rl = level_R[l]
-                    self.prof.append((a[0], a[1], int(Rl * job.n_rows), 1))
-                else:
-                    self._ev_pool.append(a)
+            # which pairs a launch carried: job.ev_used (a queued level that the chain did not reach still launched --
+            # and left at once: counted as a launch without entries)
+            for l, (a, b) in enumerate(pairs):
+                Rl = level_R[l] if l < len(level_R) else 0
+                for which, pr, ent in ((0, a, Rl), (1, b, Rl % S)):
+                    if (job.ev_used[which] >> l) & 1 and not (l == 0 and sums_ready):
+                        self.prof.append((pr[0], pr[1], int(ent * job.n_rows), 1))
+                    else:
+                        self._ev_pool.append(pr)
         return (idx_new, idx_cur, R_final) if in_b else (idx_cur, idx_new, R_final)
 
     def level_loop_sharded(self, p: Plan, idx_cur, idx_new, bounds, S: int, mu, sums_ready: bool, comm, R_stop: int):

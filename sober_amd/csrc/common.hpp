@@ -27,6 +27,25 @@ static inline void sober_attr_done(std::atomic<unsigned long long>& done) {
     if (hipGetDevice(&dev) == hipSuccess) done.fetch_or(1ull << (dev & 63), std::memory_order_release);
 }
 
+// Kernel launches that can carry a pair of events IN THEIR DISPATCH (hipExtLaunchKernelGGL): start / stop then hold the
+// kernel's own begin / end timestamps -- the duration rocprofv3 reports for it -- with no marker packets on the stream.
+// sober_set_launch_events arms the pair for the NEXT such launch of the calling thread (the level kernels).
+#include <hip/hip_ext.h>
+namespace sober {
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+LaunchEvents& launch_events();                      // (thread-local, misc.hip)
+}
+#define SOBER_LAUNCH_TIMED(kernel, grid, block, shmem, stream, ...)                                        \
+    do {                                                                                                    \
+        sober::LaunchEvents& le_ = sober::launch_events();                                                  \
+        if (le_.start != nullptr && le_.stop != nullptr) {                                                  \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, le_.start, le_.stop, 0, __VA_ARGS__); \
+            le_ = sober::LaunchEvents{};                                                                    \
+        } else {                                                                                            \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                            \
+        }                                                                                                   \
+    } while (0)
+
 #define LAUNCH_CHECK()                                  \
     do {                                                \
         hipError_t _e = hipGetLastError();              \
@@ -80,24 +99,13 @@ __host__ __device__ inline int level_wave_wpt(int n_rows, int64_t e_total, int S
 // partial-sum slots per tile = the most workgroups `wpt` consecutive waves can touch
 __host__ __device__ inline int level_wave_slots(int wpt) { return wpt <= 0 ? 0 : (wpt + SOBER_LW_W - 2) / SOBER_LW_W + 1; }
 
-// partial sums per tile of the matrix-core level kernel that is built in (SOBER_LM_BLOCK: the workgroup-staged one)
+// partial sums per tile of the matrix-core level kernel (monotone in e_total: a launch sized from an upper bound covers
+// the exact one)
 __host__ __device__ inline int level_parts_mfma_for(int n_rows, int64_t e_total, int S) {
-#ifdef SOBER_LM_BLOCK
-    return level_chunks_for(n_rows, e_total, S);
-#else
     return level_wave_slots(level_wave_wpt(n_rows, e_total, S));
-#endif
 }
 __host__ __device__ inline int level_parts_mfma_cap(int n_rows, int64_t e_total, int S) {
-#ifdef SOBER_LM_BLOCK
-    int64_t n = SOBER_CHUNK_TARGET / ((int64_t)((S + 15) / 16) * ((n_rows + 255) / 256));
-    if (n < 1) n = 1;
-    if (n > 64) n = 64;
-    if (n > e_total) n = e_total;
-    return (int)n;
-#else
-    return level_wave_slots(level_wave_wpt(n_rows, e_total, S));     // (monotone in e_total)
-#endif
+    return level_wave_slots(level_wave_wpt(n_rows, e_total, S));
 }
 
 // k(x, y) from the squared scaled distance (continuous kernels).

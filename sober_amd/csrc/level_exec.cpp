@@ -13,10 +13,20 @@
         if (rc_ != 0) return rc_;    \
     } while (0)
 
-#define LX_EVENT(K)                                                                      \
-    if (j->ev[K]) {                                                                      \
-        const hipError_t e_ = hipEventRecord((hipEvent_t)j->ev[K], (hipStream_t)stream); \
-        if (e_ != hipSuccess) return (int)e_;                                            \
+// The event pair of a level-kernel launch: the matrix-core variants carry it in the dispatch (the kernel's own begin /
+// end timestamps: sober_set_launch_events), the others get a record on the stream either side of the launch.
+static inline bool lx_timed_in_dispatch(const sober_level_job* j) {
+    return j->variant == SOBER_LEVEL_MFMA || j->variant == SOBER_LEVEL_TANI;
+}
+#define LX_EVENTS_BEFORE(A, B)                                                                   \
+    if ((A) && (B)) {                                                                            \
+        if (lx_timed_in_dispatch(j)) { LX_TRY(sober_set_launch_events((A), (B))); }              \
+        else { const hipError_t e_ = hipEventRecord((hipEvent_t)(A), (hipStream_t)stream); if (e_ != hipSuccess) return (int)e_; } \
+    }
+#define LX_EVENTS_AFTER(A, B)                                                                    \
+    if ((A) && (B) && !lx_timed_in_dispatch(j)) {                                                \
+        const hipError_t e_ = hipEventRecord((hipEvent_t)(B), (hipStream_t)stream);              \
+        if (e_ != hipSuccess) return (int)e_;                                                    \
     }
 
 static int lx_reduce(const sober_level_job* j, const int32_t* idx, int64_t pos0, int64_t count, int S, int n_chunks,
@@ -59,9 +69,9 @@ extern "C" int sober_level_moments(const sober_level_job* j, void* stream) {
                               : sober_level_chunks(j->n_rows, j->pos0, j->count, S);
     if (n_chunks <= 0 || n_chunks > SOBER_LEVEL_MAX_CHUNKS) return n_chunks <= 0 ? n_chunks : SOBER_E_WS;
     // first placement: every live position, set = p mod S (leftovers land in sets 0..r-1, quirk Q1); tot over p < ES
-    LX_EVENT(0)
+    LX_EVENTS_BEFORE(j->ev[0], j->ev[1])
     LX_TRY(lx_reduce(j, j->idx, j->pos0, j->count, S, n_chunks, j->partG, j->partTot, ES, stream));
-    LX_EVENT(1)
+    LX_EVENTS_AFTER(j->ev[0], j->ev[1])
     // second placement of the leftovers (SOBER/_rchq.py:153-164): the same kernel over the leftover positions
     // alone, spread over XS pseudo-sets that sum_partials folds into set S-1
     const int64_t lo = j->pos0 > ES ? j->pos0 : ES;
@@ -72,10 +82,10 @@ extern "C" int sober_level_moments(const sober_level_job* j, void* stream) {
         n_xchunks = mfma ? sober_level_parts_mfma(j->n_rows, 0, n_left, SOBER_LEVEL_XS)
                          : sober_level_chunks(j->n_rows, 0, n_left, SOBER_LEVEL_XS);
         if (n_xchunks <= 0 || n_xchunks > SOBER_LEVEL_MAX_CHUNKS) return n_xchunks <= 0 ? n_xchunks : SOBER_E_WS;
-        LX_EVENT(2)
+        LX_EVENTS_BEFORE(j->ev[2], j->ev[3])
         LX_TRY(lx_reduce(j, j->idx + (lo - j->pos0), 0, n_left, SOBER_LEVEL_XS, n_xchunks, j->extraG, j->extraTot,
                          n_left, stream));
-        LX_EVENT(3)
+        LX_EVENTS_AFTER(j->ev[2], j->ev[3])
     }
     LX_TRY(sober_sum_partials(j->partG, j->partTot, n_chunks, j->n_rows, S, S, n_left > 0 ? j->extraG : nullptr,
                               n_left > 0 ? j->extraTot : nullptr, n_xchunks, SOBER_LEVEL_XS, j->G, S, j->tot, stream));
@@ -149,20 +159,20 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
             const int nch = lx_chunks(j->n_rows, (Rub[l] + S - 1) / S, S);
             const int nxch = lx_chunks(j->n_rows, (S - 1 + SOBER_LEVEL_XS - 1) / SOBER_LEVEL_XS, SOBER_LEVEL_XS);
             if (nch <= 0 || nch > SOBER_LEVEL_MAX_CHUNKS || nxch <= 0 || nxch > SOBER_LEVEL_MAX_CHUNKS) return SOBER_E_WS;
-            LX_EVENT(0)
+            LX_EVENTS_BEFORE(j->ev[0], j->ev[1])
+            if (j->ev[0] && j->ev[1]) j->ev_used[0] |= 1ull << l;
             LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
                                                   j->dim, cur, Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch,
                                                   j->partG, S, j->partTot, j->dR + l, stream));
-            LX_EVENT(1)
             // (the leftover launch of a level whose size is known exactly and leaves none is not made: the sums
             //  kernel finds the same zero from dR)
             if (!(Rlo[l] == Rub[l] && Rub[l] % S == 0)) {
-                LX_EVENT(2)
+                LX_EVENTS_BEFORE(j->ev[2], j->ev[3])
+                if (j->ev[2] && j->ev[3]) j->ev_used[1] |= 1ull << l;
                 LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
                                                       j->dim, cur, S - 1, SOBER_LEVEL_XS, S, 1, j->mu, j->wmul,
                                                       j->outputscale, nxch, j->extraG, SOBER_LEVEL_XS, j->extraTot,
                                                       j->dR + l, stream));
-                LX_EVENT(3)
             }
             LX_TRY(sober_sum_partials_queued(j->partG, j->partTot, j->n_rows, S, S, j->extraG, j->extraTot,
                                              SOBER_LEVEL_XS, j->G, S, j->tot, j->dR + l, stream));
@@ -199,6 +209,7 @@ extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, i
     const int S = j->S;
     int32_t *cur = idx_a, *nxt = idx_b;
     int levels = 0;
+    j->ev_used[0] = j->ev_used[1] = 0;
     if (j->dR && j->h_dR && j->variant == SOBER_LEVEL_MFMA) {
         int done = 0;
         int64_t R_after = R;
@@ -216,6 +227,10 @@ extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, i
         j->idx = cur; j->pos0 = 0; j->count = R; j->E = E;
         j->phase = (levels == 0 && first_sums_ready) ? 2 : 0;
         for (int k = 0; k < 4; ++k) j->ev[k] = (events && levels < max_levels) ? events[4 * levels + k] : nullptr;
+        if (j->phase != 2 && levels < 64) {
+            if (j->ev[0] && j->ev[1]) j->ev_used[0] |= 1ull << levels;
+            if (j->ev[2] && j->ev[3] && r > 0) j->ev_used[1] |= 1ull << levels;
+        }
         LX_TRY(sober_level_moments(j, stream));
         LX_TRY(sober_level_car(j, stream));
         const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // the host decides the next level's size

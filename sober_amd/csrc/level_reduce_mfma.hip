@@ -2,19 +2,19 @@
 //
 //   k(x, y) depends on  a = -1/2 |x~ - y~|^2  =  x~.y~ - 1/2|x~|^2 - 1/2|y~|^2        (x~ = (x - c)/l)
 //
-// With augmented points  X' = [x~, -1/2|x~|^2, 1, 0..]  and  Y' = [y~, 1, -1/2|y~|^2, 0..]  (the two
-// extra slots live in the zero padding of the 4-aligned dimension), a = X'.Y' is a plain GEMM with
-// K = DA = roundup4(d + 2): three v_mfma_f64_16x16x4_f64 per 16x16 tile at d = 10.  The matrix pipe
-// produces the exponent argument, the vector pipe only does the exponential and the weighted
-// accumulation -- the two pipes run concurrently across the waves of a SIMD.
+// With augmented points  X' = L [x~, -1/2|x~|^2, 1, 0..]  and  Y' = [y~, 1, -1/2|y~|^2, 0..]  (the two extra slots live
+// in the zero padding of the 4-aligned dimension; L = 256/ln2), X'.Y' = a L is a plain GEMM with
+// K = DA = roundup4(d + 2): three v_mfma_f64_16x16x4_f64 per 16x16 tile at d = 10.  The matrix pipe produces the
+// exponent argument already scaled for the table, the vector pipe does the exponential and the weighted accumulation.
 //
-// exp(): no v_exp_f64 exists.  a = n ln2/64 + r, |r| <= ln2/128; exp(a) = 2^(n>>6) * T[n&63] * e^r with
-// a 64-entry table in LDS and a degree-5 polynomial (truncation 3.5e-17): 11 FP64 + 4 int ops
-// (libm's exp is ~2.5x that).  Max relative error ~2.5e-16.
+// exp(): no v_exp_f64 exists.  n = rint(a L) by the magic-number add, 256-entry table 2^(j/256) (exp_table.inc,
+// correctly rounded constants), degree-4 polynomial, the power of two as one integer add on the table value's high
+// dword: 8 FP64 + 4 integer instructions per value, max relative error ~2e-16 (exp_tab4 below).
 //
-// Wave tile: 64 rows (4 MFMA row tiles) x 16 sets; lane l holds column j = l & 15 (one candidate ->
-// one set) and rows (l >> 4) + 4*reg of each tile.  Workgroup = 4 waves = 256 rows sharing the staged
-// candidate tile.  Accumulators stay in VGPRs over the whole element chunk: fixed order, no atomics.
+// Wave tile: 64 rows (4 MFMA row tiles) x 16 sets; lane l holds column j = l & 15 (one candidate -> one set) and rows
+// (l >> 4) + 4*reg of each tile.  A wave is autonomous (k_level_reduce_wave): it feeds its own B fragments from L2,
+// no LDS staging, no barrier in the element loop.  Accumulators stay in VGPRs over the wave's element range: fixed
+// order, no atomics.
 #include "common.hpp"
 #include <cstdlib>
 
@@ -22,9 +22,6 @@ namespace sober {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int LM_RW = 4;     // waves (64 rows each) per workgroup
-constexpr int LM_SB = 16;    // sets per workgroup = MFMA N
-constexpr int LM_TE = 8;     // elements staged per tile
 
 // exp of four independent arguments, written stage by stage so that the four dependency chains
 // interleave (one chain alone leaves the FP64 pipe idle for most of its latency).
@@ -104,197 +101,6 @@ __device__ __forceinline__ void kern_from_arg4(const double4_t& c, const double*
     }
 }
 
-template <int KIND, int KT>      // KT = DA / 4 k-steps
-__global__ __launch_bounds__(LM_RW * 64) void k_level_reduce_mfma(
-    const double* __restrict__ rows, int n_rows,          // n_rows x DA   (A side, augmented)
-    const double* __restrict__ cand,                      // N x DA        (B side, augmented)
-    const int32_t* __restrict__ idx, int64_t pos0, int64_t count, int S,
-    const double* __restrict__ mu, const double* __restrict__ wmul, double os,
-    int64_t e_first, int e_total, int e_per_chunk,
-    double* __restrict__ partG, int ldg, int col0,
-    double* __restrict__ partTot, int64_t tot_limit,
-    const int64_t* __restrict__ dR, int S_main, int leftover) {
-    constexpr int DA = 4 * KT;
-    // queued levels (level_exec.cpp): the launch was sized from an UPPER BOUND of the live positions; the exact
-    // number R sits in device memory (written by the previous level's update).  leftover = 0: the main launch over
-    // positions [0, R) (S = S_main); leftover = 1: positions [E S_main, R) spread over S pseudo-sets.
-    if (dR != nullptr) {
-        const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (not through the scalar cache)
-        if (R <= S_main) return;                          // nothing to halve (or the chain was stopped: R = -1)
-        const int64_t ES = (R / S_main) * S_main;
-        if (!leftover) { count = R; tot_limit = ES; }
-        else { idx += ES; count = R - ES; tot_limit = count; }
-        if (count <= 0) return;
-        pos0 = 0; e_first = 0;
-        e_total = (int)((count + S - 1) / S);
-        const int nch = level_chunks_for(n_rows, e_total, S);
-        if ((int)blockIdx.y >= nch) return;
-        e_per_chunk = (e_total + nch - 1) / nch;
-    }
-    constexpr int SB = LM_SB, TE = LM_TE, NT = TE * SB;
-    __shared__ double s_pts[2][TE][DA][SB];      // k-major: a B fragment read is 512 contiguous bytes
-    __shared__ double s_w[2][NT];
-    __shared__ double s_tot[NT];
-    __shared__ double s_T[EXP_TAB];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lj = lane & 15, lk = lane >> 4;
-    const int s0 = blockIdx.x * SB;
-    const int chunk = blockIdx.y;
-    const int row0 = blockIdx.z * (LM_RW * 64) + wave * 64;
-    const int e0 = chunk * e_per_chunk;
-    const int e1 = min(e0 + e_per_chunk, e_total);
-
-    static_assert(LM_RW * 64 >= EXP_TAB, "one table entry per thread");
-    if (tid < EXP_TAB) s_T[tid] = exp_tab_entry(tid);
-
-    // A fragments: lane holds rows[row0 + 16*t + lj][4*ks + lk]
-    double afr[4][KT];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int r = row0 + 16 * t + lj;
-#pragma unroll
-        for (int ks = 0; ks < KT; ++ks) afr[t][ks] = (r < n_rows) ? rows[(size_t)r * DA + 4 * ks + lk] : 0.0;
-    }
-    double4_t acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-    // staging: thread tid < NT stages candidate (te = tid / SB, i = tid % SB) of the NEXT tile while the
-    // current one is being consumed.  The address chain idx -> (mu, candidate row) is two global round
-    // trips, so the index is fetched TWO tiles ahead and the row ONE tile ahead.  Every load is
-    // unconditional (clamped position, zero weight for padding): with loads under a branch the compiler
-    // can no longer count outstanding loads and falls back to waiting for all of them before the MFMAs.
-    const bool stager = tid < NT;
-    const int st_te = tid / SB, st_i = tid % SB;
-    double st[DA];
-    double tot_acc = 0.0, m_raw = 0.0, wv_raw = 0.0;
-    bool ok_st = false, ok_tot = false;
-    const double* wm_ptr = wmul ? wmul : mu;
-    const int64_t p_last = pos0 + count - 1;
-    int c_pref = 0;                                   // idx of my candidate two tiles ahead
-
-#define LM_POS(e_tile, P, OK)                                                              \
-    const int e_##P = (e_tile) + st_te;                                                    \
-    const int s_##P = s0 + st_i;                                                           \
-    const int64_t P = (e_first + e_##P) * S + s_##P;                                       \
-    const bool OK = stager && (s_##P < S) && (e_##P < e1) && (P >= pos0) && (P <= p_last);
-#define LM_PREFETCH_IDX(e_tile)                                                            \
-    {                                                                                      \
-        LM_POS(e_tile, pp_, okp_)                                                          \
-        const int64_t pc_ = okp_ ? pp_ : pos0;                                             \
-        c_pref = idx[pc_ - pos0];                                                          \
-    }
-    // consume the prefetched index: ISSUE the loads of (weight, row) for that tile -- nothing here may touch
-    // the loaded values (their first use decides where the compiler waits): that happens in LM_STAGE_WRITE,
-    // after the tile in flight has been consumed
-#define LM_STAGE_LOAD(e_tile)                                                              \
-    {                                                                                      \
-        LM_POS(e_tile, pl_, okl_)                                                          \
-        const int c_ = okl_ ? c_pref : 0;                                                  \
-        m_raw = mu[c_];                                                                    \
-        wv_raw = wm_ptr[c_];                                                               \
-        const double* src_ = cand + (size_t)c_ * DA;                                       \
-        _Pragma("unroll") for (int j = 0; j < DA; ++j) st[j] = src_[j];                    \
-        ok_st = okl_;                                                                      \
-        ok_tot = okl_ && pl_ < tot_limit;                                                  \
-    }
-#define LM_STAGE_WRITE(buf)                                                                \
-    if (stager) {                                                                          \
-        _Pragma("unroll") for (int j = 0; j < DA; ++j) s_pts[buf][st_te][j][st_i] = ok_st ? st[j] : 0.0; \
-        s_w[buf][tid] = ok_st ? (wmul ? m_raw * wv_raw : m_raw) * os : 0.0;                \
-        tot_acc += ok_tot ? m_raw : 0.0;                                                   \
-    }
-
-    int buf = 0;
-    LM_PREFETCH_IDX(e0)
-    __builtin_amdgcn_s_waitcnt(0);                     // A fragments + first index: nothing pending at loop entry
-    LM_STAGE_LOAD(e0)
-    LM_PREFETCH_IDX(e0 + TE)
-    LM_STAGE_WRITE(0)
-    __syncthreads();
-
-    const bool rows_live = row0 < n_rows;               // a wave wholly past the row table only helps staging
-    for (int et = e0; et < e1; et += TE) {
-        LM_STAGE_LOAD(et + TE)                                          // (padding when there is no next tile)
-        LM_PREFETCH_IDX(et + 2 * TE)
-        const int te_cnt = rows_live ? min(TE, e1 - et) : 0;
-        // software pipeline over the elements of the tile: the MFMAs of element te+1 are issued
-        // before the exponentials of element te, so the matrix and vector pipes overlap in-wave
-        double4_t cc[4] = {};
-        double wc = 0.0;
-        if (rows_live) {
-            double bfr[KT];
-#pragma unroll
-            for (int ks = 0; ks < KT; ++ks) bfr[ks] = s_pts[buf][0][4 * ks + lk][lj];
-            wc = s_w[buf][lj];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                cc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < KT; ++ks)
-                    cc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[t][ks], bfr[ks], cc[t], 0, 0, 0);
-            }
-        }
-        for (int te = 0; te < te_cnt; ++te) {
-            double4_t cn[4];
-            double wn = 0.0;
-            const int tn = min(te + 1, TE - 1);                 // last iteration: harmless re-read
-            {
-                double bfr[KT];
-#pragma unroll
-                for (int ks = 0; ks < KT; ++ks) bfr[ks] = s_pts[buf][tn][4 * ks + lk][lj];
-                wn = s_w[buf][tn * SB + lj];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    cn[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int ks = 0; ks < KT; ++ks)
-                        cn[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[t][ks], bfr[ks], cn[t], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                double k[4];
-                kern_from_arg4<KIND>(cc[t], s_T, k);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] = fma(k[r], wc, acc[t][r]);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) cc[t] = cn[t];
-            wc = wn;
-        }
-        LM_STAGE_WRITE(buf ^ 1)                                         // (zeros when there is no next tile)
-        __syncthreads();
-        buf ^= 1;
-    }
-#undef LM_STAGE_LOAD
-#undef LM_STAGE_WRITE
-#undef LM_PREFETCH_IDX
-#undef LM_POS
-
-    // C/D map of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
-    if (s0 + lj < S) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 16 * t + lk + 4 * r;
-                if (row < n_rows) partG[((size_t)chunk * n_rows + row) * ldg + col0 + s0 + lj] = acc[t][r];
-            }
-    }
-    if (partTot != nullptr && blockIdx.z == 0) {
-        if (stager) s_tot[tid] = tot_acc;
-        __syncthreads();
-        if (tid < SB && s0 + tid < S) {
-            double t = 0.0;
-#pragma unroll
-            for (int te = 0; te < TE; ++te) t += s_tot[te * SB + tid];
-            partTot[(size_t)chunk * ldg + col0 + s0 + tid] = t;
-        }
-    }
-}
-
 // ---- wave-autonomous variant ----------------------------------------------------------------------------------
 // The same arithmetic without a workgroup in the inner loop.  A wave owns a 64-row x 16-set tile over a contiguous
 // range of elements and feeds its own B fragments straight from L2: lane (lj, lk) reads KT CONTIGUOUS doubles of its
@@ -326,7 +132,10 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
     __shared__ double s_tot[W * 16];
     __shared__ double s_red[W * 16 * 64];
 
-    if (dR != nullptr) {                        // queued level: sizes from device memory (see k_level_reduce_mfma)
+    if (dR != nullptr) {                        // queued level (level_exec.cpp): the launch was sized from an UPPER BOUND of
+        // the live positions; the exact number R sits in device memory (written by the previous level's update).
+        // leftover = 0: the main launch over positions [0, R) (S = S_main); leftover = 1: positions [E S_main, R)
+        // spread over S pseudo-sets.
         const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (R <= S_main) return;
         const int64_t ES = (R / S_main) * S_main;
@@ -553,22 +362,14 @@ static int launch_lm(const double* rows, int n_rows, const double* cand, const i
                      const int64_t* dR = nullptr, int S_main = 0, int leftover = 0) {
     const int64_t e_first = pos0 / S;
     const int e_total = (int)((pos0 + count + S - 1) / S - e_first);
-#ifdef SOBER_LM_BLOCK
-    const int e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
-    dim3 grid((S + LM_SB - 1) / LM_SB, n_chunks, (n_rows + LM_RW * 64 - 1) / (LM_RW * 64));
-    hipLaunchKernelGGL((k_level_reduce_mfma<KIND, KT>), grid, dim3(LM_RW * 64), 0, st, rows, n_rows, cand, idx,
-                       pos0, count, S, mu, wmul, os, e_first, e_total, e_per_chunk, partG, ldg, col0, partTot,
-                       tot_limit, dR, S_main, leftover);
-#else
     const int wpt = level_wave_wpt(n_rows, e_total, S);
     if (n_chunks != level_wave_slots(wpt)) return SOBER_E_ARG;         // (sober_level_parts_mfma: the slots per tile)
     if (count + 2 * (int64_t)S > 0x7fffffffLL) return SOBER_E_ARG;     // (positions inside a launch are 32-bit, like the list's entries)
     const int64_t n_waves = level_wave_tiles(n_rows, S) * wpt;
     const int64_t n_wg = (n_waves + SOBER_LW_W - 1) / SOBER_LW_W;
-    hipLaunchKernelGGL((k_level_reduce_wave<KIND, KT>), dim3((unsigned)(8 * ((n_wg + 7) / 8))), dim3(SOBER_LW_W * 64), 0,
+    SOBER_LAUNCH_TIMED((k_level_reduce_wave<KIND, KT>), dim3((unsigned)(8 * ((n_wg + 7) / 8))), dim3(SOBER_LW_W * 64), 0,
                        st, rows, n_rows, cand, idx, pos0, count, S, mu, wmul, os, e_first, e_total, partG, ldg, col0,
                        partTot, tot_limit, dR, S_main, leftover);
-#endif
     LAUNCH_CHECK();
     return 0;
 }
@@ -615,9 +416,6 @@ extern "C" int sober_level_reduce_mfma(int kind, const double* rows, int n_rows,
                                        const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu,
                                        const double* wmul, double outputscale, int n_chunks, double* partG,
                                        int ldg, int col0, double* partTot, int64_t tot_limit, void* stream) {
-#ifdef SOBER_LM_BLOCK
-    if (n_chunks > (pos0 + count + S - 1) / S - pos0 / S) return SOBER_E_ARG;
-#endif
     return level_reduce_mfma_impl(kind, rows, n_rows, cand, da, idx, pos0, count, S, mu, wmul, outputscale, n_chunks,
                                   partG, ldg, col0, partTot, tot_limit, stream, nullptr, 0, 0);
 }

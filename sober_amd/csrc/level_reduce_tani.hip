@@ -276,7 +276,7 @@ static int launch_lt(const void* rows, const double* rows_norm, int n_rows, cons
     dim3 grid((S + LT_SB - 1) / LT_SB, n_chunks, (n_rows + LT_ROWS - 1) / LT_ROWS);
     const size_t lds = (size_t)2 * LT_TE * LT_SB * (DT * 64 + 32) + 4 * LT_TE * LT_SB * sizeof(double);
     HIP_TRY(hipFuncSetAttribute((const void*)k_level_reduce_tani<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_level_reduce_tani<DT>), grid, dim3(LT_RW * 64), lds, st, (const unsigned long long*)rows,
+    SOBER_LAUNCH_TIMED((k_level_reduce_tani<DT>), grid, dim3(LT_RW * 64), lds, st, (const unsigned long long*)rows,
                        rows_norm, n_rows, (const unsigned long long*)cand, cand_norm, idx, pos0, count, S, mu, wmul, os,
                        e_first, e_total, e_per_chunk, partG, ldg, col0, partTot, tot_limit);
     LAUNCH_CHECK();

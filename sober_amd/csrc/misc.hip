@@ -378,6 +378,18 @@ static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / 
 
 extern "C" int sober_abi_version(void) { return SOBER_ABI_VERSION; }
 
+namespace sober {
+LaunchEvents& launch_events() {
+    static thread_local LaunchEvents le;
+    return le;
+}
+}  // namespace sober
+extern "C" int sober_set_launch_events(void* start, void* stop) {
+    if ((start == nullptr) != (stop == nullptr)) return SOBER_E_ARG;
+    sober::launch_events() = sober::LaunchEvents{(hipEvent_t)start, (hipEvent_t)stop};
+    return 0;
+}
+
 extern "C" int sober_padded_dim(int d) {
     if (d <= 0) return SOBER_E_ARG;
     const int dts[] = {4, 8, 12, 16, 20, 24, 32};
