@@ -490,6 +490,45 @@ int64_t sober_rccl_allreduce_ptr(void);     /* the address of sober_rccl_allredu
 int sober_level_final(const sober_level_job* job, const void* rows_sc, const double* rows_norm, const void* cand_sc,
                       const double* cand_norm, int dt, const int32_t* idx, int R, int64_t N, int64_t row_offset,
                       double* K, double* mu_live, int64_t* out_idx, double* out_w, void* stream);
+/* P = [U diag(mean), -(U diag(mean)) T]  (s x (M + n_obs), row-major): phi(x) = P k([X_nys; X_obs], x) is the vector of
+ * Nystrom test functions U C(X_nys, x) of SOBER/_rchq.py:78,148,156 with the posterior correction of SOBER/_gp.py:295
+ * folded in (it is linear).  Ut: s x M; mean (M, weighted mode: SOBER/_kernel.py:41) may be NULL; T = K(X_nys, X_obs) W
+ * (M x n_obs) may be NULL (mode "kernel": P = U diag(mean), s x M).                                                  */
+int sober_projection(const double* Ut, int s, int M, const double* mean, const double* T, int n_obs, double* P,
+                     void* stream);
+
+/* ker_svd_sparsify (SOBER/_rchq.py:34-39) from the Gram matrix on, in ONE call (csrc/nystrom_exec.cpp): make_cov_psd
+ * (SOBER/_utils.py:131-157: |cov| + symmetry test, every rung of the jitter ladder probed at once, the first positive
+ * definite rung or the diagonal fallback applied on the device), the range finder of torch.svd_lowrank on the matrix
+ * cores (A R, then `niter` times A^H Q and A Q, CholeskyQR after each product: one pass for the intermediate blocks,
+ * two for the last), U = Q^T, the projection P, and the copy of every flag to pinned memory.  No host decision inside.
+ * The flag block (sober_nystrom_flags_bytes; zeroed by the call):
+ *   pivots[n_rungs + 1] f64 (smallest pivot per rung, then the largest diagonal entry of |cov|) |
+ *   pivs_rf[2 (1 + 2 niter)] f64 | flags[2 + n_rungs] i32 ([0] != 0: not exactly symmetric, [1] rung taken, [2:] the
+ *   rungs' info) | infos_rf[2 (1 + 2 niter)] i32 -- read as sober_amd/_ops_hip.py:nystrom_basis_device does.          */
+typedef struct sober_nystrom_job {
+    int32_t M, s, n_rungs, niter, probe_mc;     /* Gram size, basis size, ladder rungs (max_iter + 1), power iterations,
+                                                   != 0: eight workgroups per rung (sober_cholesky_probe_mc)          */
+    const double* G;                            /* M x M Gram, row-major ld M: kernel(pt, pt) of SOBER/_rchq.py:35      */
+    const double* shifts;                       /* n_rungs jitter totals 1e-5 (2^k - 1), device                        */
+    const double* R;                            /* M x s standard normals, device: the CPU generator's draw            */
+    double* C;                                  /* M x M scratch: |cov|, then the repaired matrix                      */
+    double* chol_work;                          /* n_rungs x M x M scratch                                             */
+    void* probe_ws; int64_t probe_ws_bytes;     /* sober_cholesky_probe_mc_ws_bytes (probe_mc)                         */
+    double* Y[2];                               /* M x s each                                                          */
+    double* Gm;                                 /* s x s                                                               */
+    double* xinv;                               /* ceil(s / 32) x 1024                                                 */
+    void* flags_block; int64_t flags_bytes;     /* device, >= sober_nystrom_flags_bytes                                */
+    void* h_flags_block;                        /* pinned host copy of the block                                       */
+    double* Ut;                                 /* out: s x M, the basis as rows                                       */
+    const double* T; int32_t n_obs;             /* projection (P == NULL skips it): see sober_projection               */
+    const double* mean_nys; double* P;
+} sober_nystrom_job;
+int64_t sober_nystrom_flags_bytes(int n_rungs, int niter);
+/* phase 0: everything; 1: make_cov_psd only (flags zeroed, probes, ladder; R not needed yet -- the host steps its
+ * generator for R while the probes run); 2: the rest (range finder, U, projection, flag copy).                      */
+int sober_nystrom_basis(const sober_nystrom_job* job, int phase, void* stream);
+
 /* Arms a pair of hipEvent_t for the NEXT level-kernel launch (matrix-core variants) made by the calling thread: the
  * launch carries them in its dispatch (hipExtLaunchKernelGGL), so hipEventElapsedTime(start, stop) is the kernel's own
  * duration -- the number rocprofv3 --kernel-trace reports for it -- and no marker packet enters the stream.

@@ -5,11 +5,12 @@ of live positions into 2b sets, quirks Q1-Q6, the Caratheodor
 delegates every *bulk computation* to an `ops` backend.  The product has exactly one backend,
 `HipOps` (hand-written HIP kernels behind the C ABI); there is no CPU path.
 
-Parity-critical pieces stay on the host's LAPACK, exactly where the reference has them
-(SURVEY.md App. C): the PSD repair + randomised SVD of the Nystrom Gram (the `randn` draw comes
-from the CPU generator, so `torch.manual_seed` before the call reproduces the reference's U),
-and the null space of each Caratheodory step (`torch.linalg.svd`).  The device produces their
-inputs (Gram, barycentres) and consumes their outputs (U, kept sets and weights).
+The parity-critical pieces -- the PSD repair and randomised range finder of the Nystrom Gram (its `randn` draw is the
+CPU generator's, so `torch.manual_seed` before the call reproduces the reference's subspace) and the null space of
+each Caratheodory step -- run on the DEVICE (HipOps.nystrom_basis_device, the k_car_* / k_mc_* kernels) with the
+reference's decisions and random draw.  The literal host routes the reference has them on
+(`ker_svd_sparsify_host`, `car_host`: LAPACK) remain as the last rung: a symmetric Gram (mode "kernel"), a borderline
+jitter ladder, sizes beyond the kernels, or a device whose multi-workgroup launches gave up (HipOps.car_mode).
 
 Multi-GPU (SURVEY.md 8e): the live position list is sharded in contiguous ranges, one per rank;
 each level needs ONE all-reduce of the projected partial set sums (n x S doubles) and set masses
@@ -252,10 +253,8 @@ class RecombinationEngine:
         t0 = time.perf_counter()
         dev_route = getattr(self.ops, "nystrom_basis_device", None)
         if dev_route is not None and not self.force_host_nystrom and not literal:
-            with warnings.catch_warnings():
-                warnings.simplefilter("default")
-                res = dev_route(plan, s, self.tm.max_iter, overlap) if overlap is not None \
-                    else dev_route(plan, s, self.tm.max_iter)
+            res = dev_route(plan, s, self.tm.max_iter, overlap) if overlap is not None \
+                else dev_route(plan, s, self.tm.max_iter)
             if res is not None:
                 U, gram = res
                 self._tick("nystrom_device", t0)
@@ -266,18 +265,19 @@ class RecombinationEngine:
         gram = self.ops.gram(plan)
         (gram_h,) = self.ops.to_host(gram)
         t0 = self._tick("gram_device", t0)
-        with warnings.catch_warnings():
-            warnings.simplefilter("default")
-            _, U = ker_svd_sparsify_host(gram_h, s, self.tm)
+        _, U = ker_svd_sparsify_host(gram_h, s, self.tm)
         self._tick("nystrom_host", t0)
         if self.trace is not None:
             self.trace.update(gram=gram_h.clone(), U=U.clone())
         return U
 
     # -- the halving loop -------------------------------------------------------
-    def run(self, plan, mu: torch.Tensor, num_pts: int, obj: Optional[torch.Tensor] = None):
+    def run(self, plan, mu: torch.Tensor, num_pts: int, obj: Optional[torch.Tensor] = None, live=None):
         """Mod_Tchernychova_Lyons, SOBER/_rchq.py:51-221.  `mu` (local weights, device, float64)
         is modified in place (Q3).  `obj` = -calc_obj(samp) for the local candidates (or None).
+        `live`: the live list itself (int32, ascending) instead of arange(N)[mu != 0] -- the replicated finish of a
+        sharded run, whose list carries on from the levels before it (a survivor whose weight is exactly 0 keeps its
+        place there, as it does in an unsharded run after the first level).
         Returns (idx_star int64 global indices, w_star) on the device, identical on every rank."""
         ops, comm = self.ops, self.comm
         self.obj = obj
@@ -297,18 +297,24 @@ class RecombinationEngine:
         state = {}
         # (the list itself is requested at once, behind whatever the plan has enqueued: its count is on the host long
         #  before the first level wants it, with no synchronisation behind the Nystrom chain)
-        pending = ops.nonzero_start(mu) if getattr(ops, "nonzero_start", None) is not None \
+        pending = ops.nonzero_start(mu) if getattr(ops, "nonzero_start", None) is not None and live is None \
             and not os.environ.get("SOBER_SYNC_LIST") else None         # (the switch: A/B of the synchronised form)
+        sharded = comm.world > 1 or (self.force_sharded and getattr(comm, "native_allreduce", None) is not None)
 
         def first_sums():
-            idx_cur, count = ops.nonzero_finish(pending) if pending is not None else ops.nonzero_i32(mu)
+            if live is not None:
+                idx_cur, count = live, int(live.numel())
+            else:
+                idx_cur, count = ops.nonzero_finish(pending) if pending is not None else ops.nonzero_i32(mu)
             #                                                idx_story = arange(N)[mu != 0]  (:63-65)
             counts = comm.allgather_counts(count)
             bounds = [0]
             for c in counts:
                 bounds.append(bounds[-1] + c)              # every rank's range of list positions, kept in closed form
             state.update(idx_cur=idx_cur, count=count, pos0=bounds[comm.rank], R=bounds[-1], bounds=bounds)
-            if state["R"] > S and getattr(ops, "level_car", None) is not None and count > 0:
+            # (a sharded pool at or below the cut-over goes straight to the replicated finish: no level runs here)
+            cut = sharded and obj is None and self.cutover_R > 0 and state["R"] <= self.cutover_R
+            if state["R"] > S and getattr(ops, "level_car", None) is not None and count > 0 and not cut:
                 ops.level_moments(plan, idx_cur, state["pos0"], count, S, state["R"] // S, mu, phase=1, n=n)
                 state["sums_ready"] = True
 
@@ -342,7 +348,6 @@ class RecombinationEngine:
 
         if self.trace is not None:
             self.trace["levels"] = levels
-        sharded = comm.world > 1 or (self.force_sharded and getattr(comm, "native_allreduce", None) is not None)
         if not sharded and obj is None and levels is None and not self.force_host_car and R > S \
                 and getattr(ops, "level_loop", None) is not None and ops.car_supported(S, n + 1):
             # unsharded pool, on-chip Caratheodory step: the whole loop below runs inside the level executor
@@ -458,7 +463,8 @@ class RecombinationEngine:
         sub.basis_override = U
         sub.force_host_nystrom, sub.force_host_car = self.force_host_nystrom, self.force_host_car
         mu2 = w_all.clone().contiguous()
-        idx2, w2 = sub.run(plan2, mu2, num_pts)
+        live2 = torch.arange(mu2.numel(), dtype=torch.int32, device=mu2.device)   # the gathered list, every entry of it
+        idx2, w2 = sub.run(plan2, mu2, num_pts, live=live2)
         for k, v in sub.timers.items():
             self.timers[k] = self.timers.get(k, 0.0) + v
         idx_glob = gid[idx2]

@@ -106,6 +106,9 @@ SIGNATURES = {
     "sober_level_update_queued": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_record_event_pair": (_i32, [_vp, _vp, _vp]),
     "sober_set_launch_events": (_i32, [_vp, _vp]),
+    "sober_projection": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "sober_nystrom_flags_bytes": (_i64, [_i32, _i32]),
+    "sober_nystrom_basis": (_i32, [_vp, _i32, _vp]),
     "sober_gather_f64": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "sober_final_scatter": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "sober_level_final": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
@@ -114,6 +117,19 @@ SIGNATURES = {
 
 LEVEL_VALU, LEVEL_MFMA, LEVEL_GATHER, LEVEL_TANI = 0, 1, 2, 3
 LEVEL_MAX_CHUNKS, LEVEL_XS, LEVEL_QUEUE = 64, 16, 24
+
+
+class NystromJob(C.Structure):
+    """struct sober_nystrom_job of include/sober_hip.h (field for field)."""
+    _fields_ = [
+        ("M", _i32), ("s", _i32), ("n_rungs", _i32), ("niter", _i32), ("probe_mc", _i32),
+        ("G", _vp), ("shifts", _vp), ("R", _vp), ("C", _vp), ("chol_work", _vp),
+        ("probe_ws", _vp), ("probe_ws_bytes", _i64),
+        ("Y", _vp * 2), ("Gm", _vp), ("xinv", _vp),
+        ("flags_block", _vp), ("flags_bytes", _i64), ("h_flags_block", _vp),
+        ("Ut", _vp),
+        ("T", _vp), ("n_obs", _i32), ("mean_nys", _vp), ("P", _vp),
+    ]
 
 
 class LevelJob(C.Structure):
@@ -648,6 +664,20 @@ def level_final(job: LevelJob, rows, rows_norm, cand, cand_norm, dt, idx, R, N, 
                                     _ptr(cand_norm), dt, idx.data_ptr(), int(R), int(N), int(row_offset),
                                     K.data_ptr(), mu_live.data_ptr(), out_idx.data_ptr(), out_w.data_ptr(), stream),
            "sober_level_final")
+
+
+def nystrom_flags_bytes(n_rungs: int, niter: int) -> int:
+    return int(load().sober_nystrom_flags_bytes(n_rungs, niter))
+
+
+def nystrom_basis(job: NystromJob, phase: int, stream: int):
+    _check(load().sober_nystrom_basis(C.addressof(job), int(phase), stream), "sober_nystrom_basis")
+
+
+def projection(Ut, mean, T, P):
+    s_, M = Ut.shape
+    _check(load().sober_projection(Ut.data_ptr(), s_, M, _ptr(mean), _ptr(T), 0 if T is None else T.shape[1], P.data_ptr(),
+                                   _stream(P)), "sober_projection")
 
 
 def record_event_pair(ev0, ev1, stream: int):

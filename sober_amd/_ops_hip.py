@@ -91,18 +91,22 @@ class HipOps:
 
     def _packed_pool(self, spec, X_cand):
         """prepare_points for the candidate pool.  A fingerprint pool (Tanimoto) arrives as an FP64 0/1 matrix --
-        4 GB at 250k x 2048 -- and a dataset prior hands over the SAME matrix at every BO iteration
-        (SOBER/_sampler.py:351-382): its bit-packed form (64x smaller) is kept across calls.  The key is the
-        tensor's storage, layout and in-place version counter; the cache holds a reference to the tensor, so its
-        memory cannot be handed to another tensor while the entry lives.  `clear_cache()` drops it."""
+        4 GB at 250k x 2048 -- and a dataset prior without pruning hands over the SAME tensor object at every BO
+        iteration (SOBER/_sampler.py:351-382): its bit-packed form (64x smaller) is kept across calls.  Only the
+        packed words are held: the pool itself is referenced WEAKLY (a pruned prior builds a fresh tensor per
+        iteration -- that entry then simply misses and the old words are dropped; nothing pins the caller's 4 GB).
+        A hit needs the same tensor object, layout and in-place version counter; writes that bypass the counter
+        (`.data`, DLPack, foreign kernels) are the caller's to announce with `clear_cache()`."""
         if spec.kind != "tanimoto":
             return prepare_points(spec, X_cand)
+        import weakref
         key = (X_cand.data_ptr(), tuple(X_cand.shape), tuple(X_cand.stride()), X_cand.dtype, X_cand._version)
         hit = getattr(self, "_pool_cache", None)
-        if hit is not None and hit[0] == key:
+        if hit is not None and hit[0] == key and hit[1]() is X_cand:
             return hit[2]
+        self._pool_cache = None                                   # (a miss frees the previous pool's words first)
         pts = prepare_points(spec, X_cand)
-        self._pool_cache = (key, X_cand, pts)
+        self._pool_cache = (key, weakref.ref(X_cand), pts)
         return pts
 
     def clear_cache(self):
@@ -132,86 +136,125 @@ class HipOps:
         p._proj_src = U
         U = U.to(self.device, torch.float64).contiguous()
         p.n = U.shape[0]
-        P1 = U * p.mean_nys.unsqueeze(0) if p.weighted else U
-        if p.T is None:
-            p.P = P1.contiguous()
-            return
-        P = torch.empty(p.n, p.Mtot, dtype=torch.float64, device=self.device)
-        P[:, :p.M] = P1
-        nat.dgemm(P1.contiguous(), p.T, P[:, p.M:], alpha=-1.0)
+        P = torch.empty(p.n, p.Mtot if p.T is not None else p.M, dtype=torch.float64, device=self.device)
+        nat.projection(U, p.mean_nys if p.weighted else None, p.T, P)
         p.P = P
 
     # ------------------------------------------------------------------ Nystrom basis on the device
+    NITER = 2                    # torch.svd_lowrank's default number of power iterations
+
     def nystrom_basis_device(self, p: Plan, s: int, max_iter: int = 10, overlap=None):
-        """ker_svd_sparsify (SOBER/_rchq.py:34-39) with the N_nys x N_nys work on the GPU, no host decision inside:
+        """ker_svd_sparsify (SOBER/_rchq.py:34-39) with the N_nys x N_nys work on the GPU, no host decision inside, the
+        whole chain behind ONE native call (csrc/nystrom_exec.cpp: sober_nystrom_basis):
           make_cov_psd: |cov| and the symmetry test in one kernel; every rung of the jitter ladder probed by one
-                        launch of the one-workgroup Cholesky; the first positive definite rung (or the diagonal
-                        fallback) applied on the device with the reference's own sequence of additions;
-          svd_lowrank : randn from the CPU generator (same draw as the reference); range finder with MFMA GEMMs
-                        + CholeskyQR on the matrix cores; the result is an orthonormal basis of the reference's
-                        subspace (the final rotation U_B is invisible downstream, see _svd_lowrank_device).
-        Returns (U (s, M) on the device, the Gram matrix) or None when the literal host path must decide
-        (exactly symmetric Gram, sizes beyond the kernels, ill-conditioned range finder); the CPU generator is
-        then back where it was."""
-        import warnings
+                        launch; the first positive definite rung (or the diagonal fallback) applied on the device with
+                        the reference's own sequence of additions;
+          svd_lowrank : randn from the CPU generator (same draw as the reference: the host steps the Mersenne twister,
+                        Box-Muller runs on the device); range finder with MFMA GEMMs + CholeskyQR on the matrix cores;
+                        the result is an orthonormal basis of the reference's subspace;
+          projection  : P = [U, -U T] enqueued before the flags are waited for.
+        Returns (U (s, M) on the device, the Gram matrix) or None when the literal host path must decide (exactly
+        symmetric Gram, sizes beyond the kernels, a borderline ladder, an ill-conditioned range finder); the CPU
+        generator is then back where it was.
+
+        WHY NO SMALL SVD.  torch/_lowrank.py goes on with B = Q^H A, its SVD and U = Q U_B.  U_B is a q x q
+        ORTHOGONAL matrix, and nothing downstream can see it: the Caratheodory step (SOBER/_rchq.py:224-270) takes the
+        null space of A = [1 | X]^T from the right Householder reflectors of A's bidiagonalisation (csrc/car.hip), and
+        those depend on A only through its first row (the ones) and A^T A -- both unchanged when the remaining rows,
+        i.e. the Nystrom test functions U k(X_nys, .), are mixed by an orthogonal matrix.  Same kept sets, same weights
+        (tests/test_car_algorithm.py::test_car_invariant_under_orthogonal_mixing).  So any orthonormal basis of
+        range(Q) serves, Q^T itself does.  (The literal host route still computes U_B.)"""
         dev, M = self.device, p.M
         if M > nat.chol_max_n() or s > 256 or s >= M:
             self.gram(p)
             return None
         G = self.gram(p)
-        # everything up to the basis is enqueued without a host decision in between: the symmetry flag of the input
-        # and the rung the ladder took are read back together with the range finder's health flags at the end
-        n_r = max_iter + 1
-        # one zero-fill for every flag and pivot of this phase (they were four fills, a reduction and a copy):
-        #   pivots[n_r + 1] f64 | range finder's pivs[2 * 5] f64 | flags[2 + n_r] i32 | range finder's infos[2 * 5] i32
-        n_orth2 = 2 * (1 + 2 * 2)
-        zb = torch.zeros(8 * (n_r + 1 + n_orth2) + 4 * (2 + n_r + n_orth2), dtype=torch.uint8, device=dev)
-        f64s = zb[:8 * (n_r + 1 + n_orth2)].view(torch.float64)
-        i32s = zb[8 * (n_r + 1 + n_orth2):].view(torch.int32)
-        pivots, pivs_rf = f64s[:n_r + 1], f64s[n_r + 1:]
-        flags, infos_rf = i32s[:2 + n_r], i32s[2 + n_r:]                 # [0] not symmetric, [1] rung taken, [2:] info
-        C = torch.empty_like(G)
-        nat.abs_sym(G, C, flags[:1], pivots[n_r:])                       # (+ the largest diagonal entry: the borderline test)
-        # every rung of the ladder (after k = 0 .. max_iter jitter additions) is probed at once: one
-        # workgroup per rung, one launch; the first positive definite rung is applied on the device with the
-        # reference's own sequence of diagonal additions -- or, when none is, the diagonal fallback
-        # (SOBER/_utils.py:150-156)
-        key = ("shifts", n_r)
-        shifts = self._pin.get(key)
-        if shifts is None:
-            shifts = self._pin[key] = torch.tensor([1e-5 * (2 ** k - 1) for k in range(n_r)], dtype=torch.float64,
-                                                   device=dev)
+        n_r, niter = max_iter + 1, self.NITER
+        n_orth2 = 2 * (1 + 2 * niter)
+        if getattr(p, "ws", None) is None:
+            p.ws = {}
+        # (the chain's buffers and its job live with the backend, not with the plan: a plan is built per step, and the
+        #  pinned flag block alone costs more to allocate than the call it serves)
+        key = ("nys", M, s, n_r)
+        st = self._pin.get(key)
+        if st is None:
+            f64 = torch.float64
+            nbytes = nat.nystrom_flags_bytes(n_r, niter)
+            st = self._pin[key] = {
+                "job": nat.NystromJob(), "C": torch.empty(M, M, dtype=f64, device=dev),
+                "Y0": torch.empty(M, s, dtype=f64, device=dev), "Y1": torch.empty(M, s, dtype=f64, device=dev),
+                "Gm": torch.empty(s, s, dtype=f64, device=dev),
+                "xinv": torch.empty(((s + 31) // 32) * 1024, dtype=f64, device=dev),
+                "flags": torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                "h_flags": torch.empty(nbytes, dtype=torch.uint8, pin_memory=True),
+                "Ut": torch.empty(s, M, dtype=f64, device=dev),
+            }
+            skey = ("shifts", n_r)
+            if skey not in self._pin:
+                self._pin[skey] = torch.tensor([1e-5 * (2 ** k - 1) for k in range(n_r)], dtype=f64, device=dev)
+            j = st["job"]
+            j.M, j.s, j.n_rungs, j.niter = M, s, n_r, niter
+            j.shifts, j.C = self._pin[skey].data_ptr(), st["C"].data_ptr()
+            j.Y[0], j.Y[1], j.Gm, j.xinv = st["Y0"].data_ptr(), st["Y1"].data_ptr(), st["Gm"].data_ptr(), st["xinv"].data_ptr()
+            j.flags_block, j.flags_bytes, j.h_flags_block = st["flags"].data_ptr(), nbytes, st["h_flags"].data_ptr()
+            j.Ut = st["Ut"].data_ptr()
+        j = st["job"]
         work = self._buf(p, "chol_work", n_r * M * M)
-        # (pivots: smallest pivot of every rung + the largest diagonal entry: the borderline test below)
-        # (eight workgroups per rung from a few panels on: 0.49 -> 0.25 ms at M = 500; a rung whose workgroups lost each
+        j.G, j.chol_work = G.data_ptr(), work.data_ptr()
+        # (eight workgroups per rung from a few panels on: 0.49 -> 0.16 ms at M = 500; a rung whose workgroups lost each
         #  other reports PROBE_NO_VERDICT and the step goes to the host route, this process then stays with one each)
-        if M >= self.PROBE_MC_MIN and n_r <= 16 and self._probe_mc:
-            ws = self._buf_u8(p, "chol_mc_ws", nat.cholesky_probe_mc_ws_bytes(M, n_r))
-            nat.cholesky_probe_mc(C, shifts, work, flags[2:], pivots, ws)
+        j.probe_mc = 1 if (M >= self.PROBE_MC_MIN and n_r <= 16 and self._probe_mc) else 0
+        if j.probe_mc:
+            pws = self._buf_u8(p, "chol_mc_ws", nat.cholesky_probe_mc_ws_bytes(M, n_r))
+            j.probe_ws, j.probe_ws_bytes = pws.data_ptr(), pws.numel()
+        # the projection rides in the same call when the plan is a real one (it is simply redone should the flags
+        # send the step to the host route)
+        proj = hasattr(p, "weighted") and not os.environ.get("SOBER_SYNC_LIST")
+        if proj:
+            T = p.T
+            P = torch.empty(s, p.Mtot if T is not None else M, dtype=torch.float64, device=dev)
+            j.T, j.n_obs = nat._ptr(T), (T.shape[1] if T is not None else 0)
+            j.mean_nys, j.P = (p.mean_nys.data_ptr() if p.weighted else None), P.data_ptr()
         else:
-            nat.cholesky_probe(C, shifts, work, flags[2:], pivots)
-        nat.jitter_ladder_auto(C, flags[2:], flags[1:2])
+            j.P = None
         # svd_lowrank's randn comes from the CPU generator (it is the next consumer of the generator in the
-        # reference too: make_cov_psd draws nothing).  torch.randn(500, 99) itself is 0.6 ms of host time -- longer than
-        # the Cholesky probe it hides behind, which left the GPU idle for 0.2 ms; the host now only steps the Mersenne
-        # twister and the Box-Muller transform runs on the device (_rng.py).  Should the input turn out exactly
-        # symmetric (is_psd(cov) itself has to run, on the host) or the range finder lose rank, the generator is put
-        # back and the literal host route decides.
+        # reference too: make_cov_psd draws nothing); should the host route have to decide, the generator is put back
+        stream = torch.cuda.current_stream(dev)
+        nat.nystrom_basis(j, 1, stream.cuda_stream)         # the probes run while the host steps its generator
         rng_state = torch.get_rng_state()
         R = _rng.device_randn(M, s, dev)
-        U, (flags_h, piv_h) = self._svd_lowrank_device(C, s, R, overlap=overlap, extra=(flags, pivots), plan=p,
-                                                       zeroed=(infos_rf, pivs_rf))
+        j.R = R.data_ptr()
+        nat.nystrom_basis(j, 2, stream.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        Ut = st["Ut"]
+        if proj:
+            p.P, p.n, p._proj_src = P, s, Ut
+        if overlap is not None:
+            overlap()                                       # (device work independent of U, behind the chain)
+        ev.synchronize()
+        hb = st["h_flags"]
+        n8 = 8 * (n_r + 1 + n_orth2)
+        f64s, i32s = hb[:n8].view(torch.float64), hb[n8:].view(torch.int32)
+        piv_h, pivs_rf = f64s[:n_r + 1], f64s[n_r + 1:]
+        flags_h, infos_rf = i32s[:2 + n_r], i32s[2 + n_r:]
         if any(int(v) == nat.PROBE_NO_VERDICT for v in flags_h[2:]):
             self._probe_mc = False
             warnings.warn("sober_amd: the multi-CU Cholesky probe lost contact between its workgroups; "
                           "falling back to one workgroup per rung")
             torch.set_rng_state(rng_state)
             return None
-        if int(flags_h[0]) == 0 or U is None or self.ladder_borderline(flags_h[2:], piv_h[:n_r], float(piv_h[n_r])):
+        # a second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1; a single pass is accepted
+        # while min pivot / max diagonal of its Gram matrix (~ cond^-2) stays above ORTH1_MIN_RATIO
+        last = 2 * niter
+        single = [k for k in range(0, n_orth2, 2) if k // 2 != last]
+        rank_lost = bool((infos_rf != 0).any()) or float(pivs_rf[2 * last + 1]) < 0.5 \
+            or any(not (float(pivs_rf[k + 1]) >= self.ORTH1_MIN_RATIO) for k in single)
+        if int(flags_h[0]) == 0 or rank_lost or self.ladder_borderline(flags_h[2:], piv_h[:n_r], float(piv_h[n_r])):
             torch.set_rng_state(rng_state)                 # the host route draws the same randn again
             return None
         warnings.warn("Estimated covariance matrix was not positive semi-definite. Conveting...")
-        return U, G
+        return Ut, G
 
     # is_psd (SOBER/_utils.py:117-129) = LAPACK's Cholesky succeeds AND linalg.eig >= 0.  k_chol's verdict on a rung
     # can only differ from that where the rung is numerically singular: its smallest pivot (the failing one, <= 0,
@@ -236,7 +279,9 @@ class HipOps:
         return False
 
     def _orth(self, Y, infos, pivs, slot, passes: int = 2):
-        """CholeskyQR2: orthonormal basis of range(Y) with the flag of Householder QR.
+        """The CholeskyQR building block of the range finder, by itself (csrc/nystrom_exec.cpp runs the same three
+        calls per pass; this form serves the kernels' own tests).
+        CholeskyQR2: orthonormal basis of range(Y) with the flag of Householder QR.
         passes=1 (the intermediate blocks of the power iteration): the same subspace to the same accuracy
         (the first triangular solve decides it), orthonormal only to cond(Y)^2 eps -- which is all the next
         product A Q needs; pivs[slot + 1] then holds min pivot / max diagonal of the Gram matrix (~ cond^-2)."""
@@ -259,63 +304,6 @@ class HipOps:
     # single-pass CholeskyQR is accepted for an intermediate block while min pivot / max diagonal of its Gram
     # matrix (~ cond(Y)^-2) stays above this: orthonormality then holds to ~1e-6 and the subspace to eps cond(Y)
     ORTH1_MIN_RATIO = 1e-10
-
-    def _svd_lowrank_device(self, A, q, R_host, niter: int = 2, overlap=None, extra=None, plan=None, zeroed=None):
-        """The range finder of torch.svd_lowrank(A, q) (Halko et al. Alg. 4.4, as in torch/_lowrank.py:64-79) for
-        a square device matrix; returns an orthonormal basis of the same subspace as SOBER/_rchq.py:38's U, as
-        rows (q, M) -- see the comment at the end for why the small SVD is not needed -- or None if CholeskyQR
-        lost rank."""
-        dev, M = self.device, A.shape[0]
-        R = R_host.to(dev)                                           # CPU generator: the reference's draw (already there: _rng.py)
-        n_orth = 1 + 2 * niter
-        if zeroed is not None and zeroed[0].numel() == 2 * n_orth:        # (the caller's zero-filled flags and pivots)
-            infos, pivs = zeroed
-        else:
-            infos = torch.zeros(2 * n_orth, dtype=torch.int32, device=dev)
-            pivs = torch.zeros(2 * n_orth, dtype=torch.float64, device=dev)
-        Y = torch.empty(M, q, dtype=torch.float64, device=dev)
-        nat.dgemm(A, R, Y)
-        # torch/_lowrank.py orthonormalises after every product; only range(Q) of the LAST block enters the
-        # result, the earlier QRs are there for conditioning -- one CholeskyQR pass each does that
-        last = 2 * niter
-        Q = self._orth(Y, infos, pivs, 0, passes=1 if last > 0 else 2)
-        slot, k = 2, 0
-        for _ in range(niter):
-            k += 1
-            nat.dgemm(A, Q, Y, transa=True)                          # A^H Q
-            Q = self._orth(Y, infos, pivs, slot, passes=1); slot += 2
-            Y = torch.empty(M, q, dtype=torch.float64, device=dev)
-            k += 1
-            nat.dgemm(A, Q, Y)
-            Q = self._orth(Y, infos, pivs, slot, passes=2 if k == last else 1); slot += 2
-            Y = torch.empty(M, q, dtype=torch.float64, device=dev)
-        # torch/_lowrank.py goes on with B = Q^H A, its SVD and U = Q U_B.  U_B is a q x q ORTHOGONAL matrix, and
-        # nothing downstream can see it: the Caratheodory step (SOBER/_rchq.py:224-270) takes the null space of
-        # A = [1 | X]^T from the right Householder reflectors of A's bidiagonalisation (csrc/car.hip), and those
-        # depend on A only through its first row (the ones) and A^T A -- both unchanged when the remaining rows,
-        # i.e. the Nystrom test functions U k(X_nys, .), are mixed by an orthogonal matrix.  Same kept sets, same
-        # weights (tests/test_car_algorithm.py::test_car_invariant_under_orthogonal_mixing: identical indices,
-        # weights to 1e-12 on every golden level).  So any orthonormal basis of range(Q) serves, Q^T itself does,
-        # and the q x M product, the second range finder for B^T, the host's LAPACK SVD (0.93 ms at q = 99), two
-        # PCIe hops and a GEMM leave the step.  (The literal host route still computes U_B.)
-        # the projection P = [U, -U T] of this basis is enqueued BEFORE the flags are waited for: should they send the
-        # step to the host route, set_projection simply runs again with that route's basis
-        Ut = Q.T.contiguous()
-        if plan is not None and hasattr(plan, "weighted") and not os.environ.get("SOBER_SYNC_LIST"):
-            self.set_projection(plan, Ut)
-        if extra is None:
-            infos_h, pivs_h = self.to_host(infos, pivs, before_sync=overlap)
-            extra_h = None
-        elif isinstance(extra, tuple):
-            infos_h, pivs_h, *extra_h = self.to_host(infos, pivs, *extra, before_sync=overlap)
-        else:
-            infos_h, pivs_h, extra_h = self.to_host(infos, pivs, extra, before_sync=overlap)
-        # a second CholeskyQR pass works on a nearly orthonormal block: its pivots must be ~1
-        single = [s for s in range(0, 2 * n_orth, 2) if s // 2 != last]
-        if bool((infos_h != 0).any()) or float(pivs_h[2 * last + 1]) < 0.5 \
-                or any(not (float(pivs_h[s + 1]) >= self.ORTH1_MIN_RATIO) for s in single):
-            return (None, extra_h) if extra is not None else None
-        return (Ut, extra_h) if extra is not None else Ut
 
     # ------------------------------------------------------------------ levels
     def prof_reserve(self, n_pairs: int):

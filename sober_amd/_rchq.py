@@ -3,8 +3,8 @@
     idx_star, w_star = recombination(pts_rec, pts_nys, num_pts, kernel, device, dtype,
                                      init_weights=None, calc_obj=None)
 
-`calc_obj(samp) -> (N,)` (the acquisition-guided branch, :67-69) is supported: the extra objective row
-is summed on the device, the two small eliminations per level run on the host's LAPACK.
+`calc_obj(samp) -> (N,)` (the acquisition-guided branch, :67-69) is supported: the extra objective row is summed on
+the device and both eliminations of a level run there too (Caratheodory step with one more function, k_second_elim).
 `kernel` is a `sober_amd.Kernel` (RBF / Matern-5/2 / Tanimoto posterior covariance, weighted or
 raw): the whole step then runs on the fused HIP path -- the (E, M, S) kernel tensor of
 SOBER/_rchq.py:124 is never materialised.  As in the reference, `device`/`dtype` are accepted and

@@ -46,8 +46,11 @@ class EmpiricalSampler(RecombinationSampler):
         self.prior_updater = prior_updater
         self.flag = False
 
-    # ---- the sampled-prior path (SOBER/_sampler.py:163-323): the funnel's own logic; drawing from / refitting the
-    #      prior is the prior object's and the caller's `prior_updater`'s business
+    # ---- the sampled-prior path (SOBER/_sampler.py:163-323).  CONVENIENCE OUTSIDE THE SURVEY.md 8 CONTRACT: candidate
+    #      generation is not the hot path (SURVEY.md 2 marks the sampler's internals other than the funnel out of
+    #      scope); these few methods only keep `Sober.next_batch` callable with a sampled prior -- control flow as in
+    #      the reference, drawing from / refitting / resetting the prior delegated to the prior object and the
+    #      caller's hooks.  Of this block only `nystrom_subsample` (:316-320) is on the contract (row a10).
     def check_categorical(self):
         """SOBER/_sampler.py:163-176."""
         return self.label in ("mixedcategorical", "categorical")

@@ -3,8 +3,10 @@ path: pi = `sober_amd.PI` (LFI weights over the pool), kernel = `sober_amd.Kerne
 `sober_amd.EmpiricalSampler`, `sampling_recombination` -> HIP.  What the reference does AROUND the path stays with
 the reference: GP fitting, the FBGP / BQ model families (`PI_FBGP`, `PI_BQ`), prior updates and WKDE refits
 (`_prior_update.py`).  A continuous/mixed prior therefore needs the caller's `prior_updater` (any callable
-`(sampler, X, weights) -> None`, e.g. the reference's `update_prior` bound to its own prior classes); the dataset
-prior (`prior.type == "dataset"`) needs nothing else."""
+`(sampler, X, weights) -> None`, e.g. the reference's `update_prior` bound to its own prior classes) and
+`prior_initialiser` (`(sampler) -> None`: what the reference's `initialise_prior`, SOBER/_sampler.py:87-111, does with
+its own prior classes); WHEN the prior is reset is decided here exactly like the reference (`should_reset_prior`).
+The dataset prior (`prior.type == "dataset"`) needs neither."""
 import torch
 
 from ._kernel import Kernel
@@ -14,8 +16,9 @@ from ._sampler import EmpiricalSampler
 
 class Sober(EmpiricalSampler):
     def __init__(self, prior, model, thresh=5, sampler_type="lfi", kernel_type="predictive_covariance",
-                 dataset_pruning=True, prior_updater=None):
+                 dataset_pruning=True, prior_updater=None, prior_initialiser=None):
         """SOBER/_sober.py:10-39."""
+        self.prior_initialiser = prior_initialiser
         self.sampler_type = sampler_type
         self.kernel_type = kernel_type
         self.dataset_pruning = dataset_pruning
@@ -44,12 +47,47 @@ class Sober(EmpiricalSampler):
         """SOBER/_sober.py:74-82."""
         self.pi, self.kernel = self.initialisation(model)
 
+    def should_reset_prior(self, batch_size, recycle_prior):
+        """SOBER/_sober.py:84-123: the prior is reset when the running maximum of the observations has not moved for
+        `n_batches_until_reset` batches, or at every call when `recycle_prior` is False (never before the second
+        batch)."""
+        targets = self.pi.model.train_targets
+        n_targets = len(targets)
+        y_max = targets.max()
+        cummax = targets.cummax(0).values
+        learning_length = n_targets - self.n_init
+        if (learning_length == 0) or (learning_length == batch_size):
+            return False
+        hit = torch.where((cummax >= y_max).diff())[0]                      # first index whose successor reaches the maximum
+        idx_max = int(hit[0]) if hit.numel() else 0
+        n_iterations = -(-learning_length // batch_size)                    # ceil
+        for n_batches in range(1, n_iterations + 1):
+            if n_batches * batch_size >= idx_max:
+                break
+        n_nonimproved_batches = n_iterations - n_batches + 2
+        if n_nonimproved_batches >= self.n_batches_until_reset:
+            return True
+        return not recycle_prior
+
+    def initialise_prior(self):
+        """SOBER/_sampler.py:87-111 rebuilds the prior object of the sampler's label from the reference's own prior
+        classes -- candidate generation, outside this path: the caller's `prior_initialiser(sampler)` does it."""
+        if self.prior_initialiser is None:
+            raise NotImplementedError(
+                "the prior is due for a reset (SOBER/_sober.py:152-155: no improvement for "
+                f"{self.n_batches_until_reset} batches, or recycle_prior=False) and no `prior_initialiser` was given: "
+                "pass Sober(..., prior_initialiser=lambda sampler: ...) that puts a fresh prior into sampler.prior")
+        self.prior_initialiser(self)
+
     def next_batch(self, n_rec, n_nys, batch_size, calc_obj=None, return_weights=False, recycle_prior=True,
                    verbose=False):
         """SOBER/_sober.py:125-195: candidates + Nystrom sample + weights -> recombination -> one of the
         reference's three return shapes: (w_rchq, X_batch) | (idx_rchq, X_batch) for a dataset prior (indices
         into the prior's available rows when pruning is on) | X_batch."""
         if not self.label == "dataset":
+            if self.should_reset_prior(batch_size, recycle_prior):           # :152-155
+                print("The prior was initialised.")
+                self.initialise_prior()
             X_cand, X_nys, weights = self.sampling_candidates(n_rec, n_nys, verbose=verbose)
         else:
             empirical_measure = self.sampling_datasets(n_rec, n_nys)

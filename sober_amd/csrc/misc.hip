@@ -267,6 +267,15 @@ __global__ void k_final_scatter_guarded(const int32_t* __restrict__ idx, int n, 
     out_w[k] = w;
 }
 
+// left block of the projection: P[r][c] = Ut[r][c] * mean[c]  (c < M; ldp = M + n_obs)
+__global__ void k_projection_left(const double* __restrict__ Ut, int s, int M, const double* __restrict__ mean,
+                                  double* __restrict__ P, int ldp) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= s * M) return;
+    const int r = t / M, c = t - r * M;
+    P[(size_t)r * ldp + c] = mean ? Ut[t] * mean[c] : Ut[t];
+}
+
 __global__ void k_i64_to_i32(const int64_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) out[t] = (int32_t)in[t];
@@ -627,6 +636,17 @@ extern "C" int sober_final_commit(const int32_t* idx, int n, const int32_t* keep
                        w_star, n_keep, row_offset, mu, out_idx, out_w);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sober_projection(const double* Ut, int s, int M, const double* mean, const double* T, int n_obs, double* P,
+                                void* stream) {
+    if (!Ut || !P || s <= 0 || M <= 0 || (T && n_obs <= 0)) return SOBER_E_ARG;
+    const int ldp = M + (T ? n_obs : 0);
+    hipLaunchKernelGGL(k_projection_left, dim3(nblk((int64_t)s * M, 256)), dim3(256), 0, (hipStream_t)stream, Ut, s, M,
+                       mean, P, ldp);
+    LAUNCH_CHECK();
+    if (!T) return 0;
+    return sober_dgemm(0, 0, s, n_obs, M, -1.0, P, ldp, T, n_obs, 0.0, P + M, ldp, stream);
 }
 
 extern "C" int sober_i64_to_i32(const int64_t* in, int64_t n, int32_t* out, void* stream) {

@@ -1,0 +1,96 @@
+// Nystrom executor: the launch sequence of ker_svd_sparsify (SOBER/_rchq.py:34-39) from the Gram matrix on -- PSD
+// repair (make_cov_psd, SOBER/_utils.py:131-157) and the range finder of torch.svd_lowrank -- behind ONE C call, plus
+// the projection P = [U, -U T] and the copy of every flag to pinned memory.  Pure host code: it only sequences the
+// library's own entry points on the caller's stream (what sober_amd/_ops_hip.py issued one ctypes call at a time:
+// ~40 calls and a dozen allocations per step, "at the host's pace").  No host decision inside: the caller reads the
+// flags once, behind whatever it enqueues next.
+#include <hip/hip_runtime.h>
+
+#include "../../include/sober_hip.h"
+
+#define NX_TRY(call)                 \
+    do {                             \
+        const int rc_ = (call);      \
+        if (rc_ != 0) return rc_;    \
+    } while (0)
+#define NX_HIP(call)                                   \
+    do {                                               \
+        const hipError_t e_ = (call);                  \
+        if (e_ != hipSuccess) return (int)e_;          \
+    } while (0)
+
+extern "C" int64_t sober_nystrom_flags_bytes(int n_rungs, int niter) {
+    const int64_t n_orth2 = 2 * (1 + 2 * (int64_t)niter);
+    return 8 * (n_rungs + 1 + n_orth2) + 4 * (2 + n_rungs + n_orth2);
+}
+
+// CholeskyQR of the M x s block in *Y, in place over the two buffers (`passes` = 2: CholeskyQR2; 1: the intermediate
+// blocks of the power iteration, with min pivot / max diagonal of the Gram matrix in pivs[slot + 1]).  On return *Y
+// holds Q and *other is free.
+static int nx_orth(const sober_nystrom_job* j, double** Y, double** other, int32_t* infos, double* pivs, int slot,
+                   int passes, void* stream) {
+    const int M = j->M, s = j->s;
+    for (int it = 0; it < passes; ++it) {
+        NX_TRY(sober_dgemm(1, 0, s, s, M, 1.0, *Y, s, *Y, s, 0.0, j->Gm, s, stream));                   // Y^T Y
+        NX_TRY(sober_cholesky_inv_ratio(j->Gm, s, s, 0.0, infos + slot + it, pivs + slot + it, j->xinv,
+                                        passes == 1 ? pivs + slot + 1 : nullptr, stream));
+        NX_TRY(sober_trsm_blocks(*Y, M, s, s, j->Gm, s, j->xinv, *other, s, stream));                    // Q = Y R^-1
+        double* t = *Y; *Y = *other; *other = t;
+    }
+    return 0;
+}
+
+extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* stream) {
+    if (phase < 0 || phase > 2) return SOBER_E_ARG;
+    if (!j || !j->G || !j->shifts || (!j->R && phase != 1) || !j->C || !j->chol_work || !j->Y[0] || !j->Y[1] || !j->Gm ||
+        !j->xinv || !j->flags_block || !j->h_flags_block || !j->Ut)
+        return SOBER_E_ARG;
+    const int M = j->M, s = j->s, n_r = j->n_rungs, niter = j->niter;
+    if (M <= 0 || s <= 0 || s >= M || s > 256 || n_r <= 0 || n_r > 64 || niter < 0 || niter > 8) return SOBER_E_ARG;
+    if (M > sober_chol_max_n()) return SOBER_E_DIM;
+    if (j->flags_bytes < sober_nystrom_flags_bytes(n_r, niter)) return SOBER_E_WS;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_orth2 = 2 * (1 + 2 * niter);
+    // the flag block: pivots[n_r + 1] f64 | pivs_rf[n_orth2] f64 | flags[2 + n_r] i32 | infos_rf[n_orth2] i32
+    double* pivots = (double*)j->flags_block;
+    double* pivs_rf = pivots + n_r + 1;
+    int32_t* flags = (int32_t*)(pivs_rf + n_orth2);
+    int32_t* infos_rf = flags + 2 + n_r;
+    if (phase != 2) {
+        NX_HIP(hipMemsetAsync(j->flags_block, 0, (size_t)j->flags_bytes, st));
+        // ---- make_cov_psd: |cov| + symmetry flag + largest diagonal entry, every rung of the jitter ladder probed at once,
+        //      the first positive definite rung (or the diagonal fallback) applied with the reference's own additions
+        NX_TRY(sober_abs_sym_dmax(j->G, M, M, j->C, M, flags, pivots + n_r, stream));
+        if (j->probe_mc) {
+            if (!j->probe_ws) return SOBER_E_ARG;
+            NX_TRY(sober_cholesky_probe_mc(j->C, M, M, j->shifts, n_r, j->chol_work, flags + 2, pivots, j->probe_ws,
+                                           j->probe_ws_bytes, stream));
+        } else {
+            NX_TRY(sober_cholesky_probe_piv(j->C, M, M, j->shifts, n_r, j->chol_work, flags + 2, pivots, stream));
+        }
+        NX_TRY(sober_jitter_ladder_auto(j->C, M, M, flags + 2, n_r, flags + 1, stream));
+    }
+    if (phase == 1) return 0;       // (the caller's host work -- stepping the generator for R -- overlaps with the probes)
+    // ---- the range finder of torch.svd_lowrank (Halko et al. Alg. 4.4, torch/_lowrank.py:64-79): only range(Q) of the
+    //      LAST block enters the result, so the intermediate blocks take one CholeskyQR pass, the last one two
+    const int last = 2 * niter;
+    double *Q = j->Y[0], *free_buf = j->Y[1];
+    NX_TRY(sober_dgemm(0, 0, M, s, M, 1.0, j->C, M, j->R, s, 0.0, Q, s, stream));                         // A R
+    NX_TRY(nx_orth(j, &Q, &free_buf, infos_rf, pivs_rf, 0, last > 0 ? 1 : 2, stream));
+    int slot = 2, k = 0;
+    for (int it = 0; it < niter; ++it) {
+        for (int half = 0; half < 2; ++half) {
+            ++k;
+            NX_TRY(sober_dgemm(half == 0 ? 1 : 0, 0, M, s, M, 1.0, j->C, M, Q, s, 0.0, free_buf, s, stream));   // A^H Q, then A Q
+            double* t = Q; Q = free_buf; free_buf = t;                                                 // (Q is consumed)
+            NX_TRY(nx_orth(j, &Q, &free_buf, infos_rf, pivs_rf, slot, (half == 1 && k == last) ? 2 : 1, stream));
+            slot += 2;
+        }
+    }
+    NX_TRY(sober_barycentres(Q, s, M, s, nullptr, j->Ut, stream));                                      // U = Q^T (s x M)
+    // ---- P = [U diag(mean), -(U diag(mean)) T]: the Nystrom test functions with the posterior correction folded in
+    if (j->P) NX_TRY(sober_projection(j->Ut, s, M, j->mean_nys, j->T, j->n_obs, j->P, stream));
+    NX_HIP(hipMemcpyAsync(j->h_flags_block, j->flags_block, (size_t)sober_nystrom_flags_bytes(n_r, niter),
+                          hipMemcpyDeviceToHost, st));
+    return 0;
+}

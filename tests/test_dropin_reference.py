@@ -132,3 +132,52 @@ def test_reference_sober_next_batch_sampled_prior(ref):
     b = _next_batch(ref, prior, model, True, 321, **dict(kw))
     assert isinstance(a, torch.Tensor) and a.shape == (8, 3)
     assert torch.equal(a, b)
+
+
+def test_should_reset_prior_equals_the_reference(ref):
+    """SOBER/_sober.py:84-123 (when a sampled prior is reset) against `sober_amd.Sober.should_reset_prior` on random
+    observation histories; and `next_batch` asks for the caller's `prior_initialiser` instead of dropping
+    `recycle_prior` (SOBER/_sober.py:152-155)."""
+    import types
+    rng = np.random.default_rng(5)
+    RefSober = ref["_sober"].Sober
+    n_true = 0
+    for trial in range(300):
+        n_init = int(rng.integers(1, 12))
+        bs = int(rng.integers(1, 9))
+        n_batches = int(rng.integers(0, 7))
+        extra = int(rng.integers(0, bs)) if n_batches and rng.random() < 0.3 else 0
+        y = torch.from_numpy(rng.standard_normal(n_init + n_batches * bs + extra))
+        if rng.random() < 0.3:                                           # a maximum early in the history
+            y[int(rng.integers(0, n_init))] = 10.0
+        model = types.SimpleNamespace(train_targets=y)
+        for recycle in (True, False):
+            a = object.__new__(RefSober)
+            a.fbgp, a.is_bq, a.n_init, a.n_batches_until_reset = False, False, n_init, 3
+            a.pi = types.SimpleNamespace(model=model)
+            a.tensor = torch.tensor
+            b = object.__new__(sober_amd.Sober)
+            b.n_init, b.n_batches_until_reset, b.pi = n_init, 3, types.SimpleNamespace(model=model)
+            ra, rb = bool(a.should_reset_prior(bs, recycle)), bool(b.should_reset_prior(bs, recycle))
+            assert ra == rb, (trial, n_init, bs, n_batches, extra, recycle)
+            n_true += ra
+    assert 50 < n_true < 550                                             # (both verdicts occur)
+
+    # a reset that is due and no hook: an error that says so, not a silently recycled prior
+    s = object.__new__(sober_amd.Sober)
+    s.label, s.n_init, s.n_batches_until_reset, s.prior_initialiser = "continuous", 2, 3, None
+    s.pi = types.SimpleNamespace(model=types.SimpleNamespace(train_targets=torch.tensor([5.0, 1, 0, 0, 0, 0, 0, 0])))
+    assert s.should_reset_prior(2, True)
+    with pytest.raises(NotImplementedError, match="prior_initialiser"):
+        s.next_batch(100, 10, 2)
+    called = []
+    s.prior_initialiser = lambda smp: called.append(smp)
+    class _Stop(Exception):
+        pass
+
+    def _stop(*a, **k):                                                  # (stop right behind the reset)
+        raise _Stop()
+    s.sampling_candidates = _stop
+    with pytest.raises(_Stop):
+        s.next_batch(100, 10, 2)
+    assert called == [s]
