@@ -293,6 +293,39 @@ def test_kmeans_vs_golden(dev):
     np.testing.assert_allclose(c3.cpu().numpy(), z["c_c"], rtol=1e-11)
 
 
+@pytest.mark.parametrize("N,d,K", [(100000, 10, 500), (30011, 3, 77), (20000, 20, 500), (5000, 31, 64), (4096, 1, 33)])
+def test_kmeans_matrix_core_e_step_equals_the_valu_kernel(N, d, K, dev):
+    """The E step in GEMM form on the matrix cores + exact re-check against the (x - c)^2 kernel it replaces
+    (sober_kmeans_lloyd without a workspace runs that one): labels and centroids bit-equal -- on random pools, with
+    duplicated rows (exact ties between centroids: the first index wins), with an empty cluster (NaN centroid: every
+    point then takes the first NaN index, like torch.argmin) and with a NaN coordinate."""
+    from sober_amd import _native as nat
+    lib = nat.load()
+    rng = np.random.default_rng(N + d)
+    X = rng.random((N, d))
+    X[1] = X[0]                                               # centroids 0 and 1 start identical: exact ties
+    X[K + 5] = X[7]
+    variants = [X]
+    Xe = X.copy(); Xe[:K] = 2.0 + np.arange(K)[:, None] * 3.0; Xe[K:] = Xe[0] + 1e-3 * rng.random((N - K, d))
+    variants.append(Xe)                                       # everything lands in cluster 0: K - 1 empty clusters
+    Xn = X.copy(); Xn[N // 2, d // 2] = np.nan
+    variants.append(Xn)
+    for Xv in variants:
+        Xd = _t(Xv).to(dev)
+        out = []
+        for with_ws in (True, False):
+            c = torch.empty(K, d, dtype=torch.float64, device=dev)
+            cl = torch.empty(N, dtype=torch.int32, device=dev)
+            nbytes = int(lib.sober_kmeans_ws_bytes(N, d, K)) if with_ws else 0
+            ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
+            nat._check(lib.sober_kmeans_lloyd(Xd.data_ptr(), N, d, K, 10, c.data_ptr(), cl.data_ptr(),
+                                              ws.data_ptr() if with_ws else None, nbytes, nat._stream(Xd)), "kmeans")
+            out.append((cl.cpu().numpy(), c.cpu().numpy()))
+        assert np.array_equal(out[0][0], out[1][0])
+        # (the two M steps sum a cluster's points in different fixed orders: centroids agree to rounding)
+        np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12, equal_nan=True)
+
+
 def test_cleansing_weights_vs_golden(dev):
     z = np.load(os.path.join(GOLD, "weights.npz"))
     ws = sober_amd.WeightsStabiliser()
