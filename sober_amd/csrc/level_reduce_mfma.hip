@@ -91,8 +91,26 @@ __device__ __forceinline__ void kern_from_arg4(const double4_t& c, const double*
         double sq[4], rr[4], a[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) sq[i] = fmax((-2.0 * INV_L) * c[i], 1e-30);   // clamp_min(1e-30) before sqrt
+        // sqrt without the IEEE sequence (range checks, scaling, fix-up): sq >= 1e-30 is a normal number by the clamp
+        // above, so v_rsq_f64 (~2^-23) + ONE coupled Newton step on 1/sqrt (-> ~2^-45) + one residual correction of the
+        // root itself (quadratic again: rounding-limited, <= 1 ulp) -- the four chains written stage by stage so that
+        // they interleave
+        double rs[4], hh[4], ee[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rr[i] = sqrt(sq[i]);
+        for (int i = 0; i < 4; ++i) rs[i] = __builtin_amdgcn_rsq(sq[i]);
+#pragma unroll
+        for (int it = 0; it < 1; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hh[i] = 0.5 * rs[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ee[i] = fma(-(sq[i] * rs[i]), hh[i], 0.5);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs[i] = fma(rs[i], ee[i], rs[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rr[i] = sq[i] * rs[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rr[i] = fma(fma(-rr[i], rr[i], sq[i]), 0.5 * rs[i], rr[i]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = (-s5 * L) * rr[i];
         exp_tab4(a, T, k);
