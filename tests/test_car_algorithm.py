@@ -49,6 +49,45 @@ def nullspace_gebrd(A):
     return Phi
 
 
+def nullspace_merged(A):
+    """numpy restatement of the MERGED bidiagonalisation of csrc/car.hip (car_bidiag2_block, round 3): the same
+    reflectors as dgebd2 in exact arithmetic, in the operation order of the kernel -- row i+1 and column i+1 of
+    A' = A G(i) are kept aside (rowg, colg); the next step's row and column follow from them and from z without
+    touching the matrix; H(i)'s scalars come after the column sums Y = col'[i+2:]^T A'."""
+    A = A.copy()
+    m, N = A.shape
+    V, taup = np.zeros((m, N)), np.zeros(m)
+    rowg, colg = A[0].copy(), A[:, 0].copy()
+    z, f, tauq = np.zeros(N), np.zeros(m), 0.0
+    for i in range(m):
+        if i > 0:
+            A[i:, i:] -= np.outer(f[i:], z[i:])                      # H(i-1)'s update
+        x = rowg[i + 1:] - tauq * z[i + 1:]                          # row i, rebuilt (u_i = 1)
+        alpha = rowg[i] - tauq * z[i]
+        cur = colg - f * z[i]                                        # column i, rebuilt
+        beta, tau, v = larfg(alpha, x)
+        sc = 0.0 if not np.any(x) else 1.0 / (alpha - beta)
+        V[i, i], V[i, i + 1:], taup[i] = 1.0, v, tau
+        if i == m - 1:
+            break
+        tG = tau * (cur[i + 1:] + sc * (A[i + 1:, i + 1:] @ x))      # tau * A [1; v]
+        colp = cur[i + 1:] - tG                                      # column i after G(i)
+        A[i + 1:, i + 1:] -= np.outer(tG, v)
+        rowg, colg = A[i + 1].copy(), A[:, i + 1].copy()
+        Y = colp[1:] @ A[i + 2:, :]
+        beta2, tauq, u = larfg(colp[0], colp[1:])
+        sc2 = 0.0 if not np.any(colp[1:]) else 1.0 / (colp[0] - beta2)
+        z = np.zeros(N)
+        z[i + 1:] = rowg[i + 1:] + sc2 * Y[i + 1:]
+        f = np.zeros(m)
+        f[i + 1], f[i + 2:] = tauq, tauq * sc2 * colp[1:]
+    Phi = np.zeros((N, N - m))
+    Phi[m:, :] = np.eye(N - m)
+    for i in range(m - 1, -1, -1):
+        Phi -= taup[i] * np.outer(V[i], V[i] @ Phi)
+    return Phi
+
+
 def pivots(Phi, mu):
     """phase 3 of k_car (q = prow/pp then one FMA, instead of (prow*col)/pp)."""
     Phi, mu = Phi.copy(), mu.copy()
@@ -106,3 +145,20 @@ def test_car_invariant_under_orthogonal_mixing():
             np.testing.assert_allclose(w2.numpy(), w1.numpy(), rtol=1e-9)
             n_checked += 1
     assert n_checked >= 20
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[7:-4])
+def test_merged_bidiagonalisation_gives_the_dgebd2_basis(path):
+    """The merged two-barrier form of the device kernel (round 3) against dgebd2 on the reference's own level inputs:
+    the same null-space basis to rounding, the same kept sets, the same weights -- the parity bar of the contract
+    (identical indices, weights well inside 1e-7), not bit-equality with LAPACK's rounding."""
+    z = np.load(path)
+    for i in range(int(z["n_levels"])):
+        X, mu = z[f"L{i}_X_tmp"], z[f"L{i}_tot_weights"]
+        A = np.vstack([np.ones(len(X)), X.T])
+        P0, P1 = nullspace_gebrd(A), nullspace_merged(A)
+        assert np.abs(P0 - P1).max() < 1e-11, i
+        w0, k0 = pivots(P0, mu)
+        w1, k1 = pivots(P1, mu)
+        assert np.array_equal(k0, k1), i
+        np.testing.assert_allclose(w1, w0, rtol=1e-9)
