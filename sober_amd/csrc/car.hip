@@ -108,34 +108,6 @@ __device__ __forceinline__ double car_rcp(double c) {
     e = fma(-c, r, 1.0);
     return fma(r, e, r);
 }
-// dlarfg: reflector H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2, v = x * scal -- computed
-// from 1 / norm alone (beta itself is never needed here):
-//   tau = (beta - alpha) / beta = 1 + |alpha| / norm,   scal = 1 / (alpha - beta) = sign(alpha) / (norm tau)
-// -- one refined rsq, one fma, one refined rcp of a number in [1, 2]: 15 dependent operations instead of 23
-__device__ __forceinline__ void larfg_vt(double alpha, double ss, double& tau, double& scal) {
-    const double n2r = fma(alpha, alpha, ss);
-    const bool tiny = n2r < 1e-200, huge = n2r > 1e200;
-    const double f = tiny ? 0x1p300 : (huge ? 0x1p-300 : 1.0);
-    const double al = alpha * f;
-    const double n2 = fma(al, al, (ss * f) * f);
-    double r = __builtin_amdgcn_rsq(n2);
-    double h = 0.5 * r;
-    double e = fma(-(n2 * r), h, 0.5);
-    r = fma(r, e, r);
-    h = 0.5 * r;
-    e = fma(-(n2 * r), h, 0.5);
-    r = fma(r, e, r);
-    const double t = fma(fabs(al), r, 1.0);
-    double y = __builtin_amdgcn_rcp(t);
-    e = fma(-t, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-t, y, 1.0);
-    y = fma(y, e, y);
-    const bool none = ss == 0.0;
-    tau = none ? 0.0 : t;
-    scal = none ? 0.0 : copysign((r * f) * y, al);
-}
-
 // ratio-test combine, branch-free (selects only): first argmin, a NaN ratio wins (torch.argmin);
 // piv < 0 = no candidate yet
 __device__ __forceinline__ void amin_take(double& best, int& piv, double ob, int op) {

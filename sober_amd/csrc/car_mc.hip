@@ -73,8 +73,8 @@ __host__ __device__ constexpr unsigned comm_bytes(int K) { return OFF_P + (unsig
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);          // (no `old` operand: every lane is written)
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 constexpr int ROR1 = 0x121, ROR2 = 0x122, ROR4 = 0x124, ROR8 = 0x128;
@@ -119,34 +119,7 @@ __device__ __forceinline__ double fast_rcp(double c) {
     e = fma(-c, r, 1.0);
     return fma(r, e, r);
 }
-// dlarfg: H = I - tau [1; v][1; v]^T with H [alpha; x] = [beta; 0], ss = |x|^2, v = x * scal.
-// Branch-free (a taken branch costs a single resident wave 50-80 cycles of instruction fetch): operands far
-// outside the normal range are rescaled by 2^(+-300) with selects, ss = 0 gives the identity (tau = 0).
-__device__ __forceinline__ void larfg(double alpha, double ss, double& beta, double& tau, double& scal) {
-    const double n2r = fma(alpha, alpha, ss);
-    const bool tiny = n2r < 1e-200, huge = n2r > 1e200;
-    const double f = tiny ? 0x1p300 : (huge ? 0x1p-300 : 1.0), fi = tiny ? 0x1p-300 : (huge ? 0x1p300 : 1.0);
-    const double al = alpha * f;
-    const double n2 = fma(al, al, (ss * f) * f);
-    double r = __builtin_amdgcn_rsq(n2);                      // 1 / sqrt(n2)
-    double h = 0.5 * r;
-    double e = fma(-(n2 * r), h, 0.5);
-    r = fma(r, e, r);
-    h = 0.5 * r;
-    e = fma(-(n2 * r), h, 0.5);
-    r = fma(r, e, r);
-    double nr = n2 * r;                                       // sqrt(n2), one correction step
-    nr = fma(fma(-nr, nr, n2), 0.5 * r, nr);
-    const double bs = -copysign(nr, al);
-    const double ib = fast_rcp(bs);
-    double t = (bs - al) * ib;
-    t = fma(fma(-t, bs, bs - al), ib, t);                     // residual correction of the quotient
-    const bool none = ss == 0.0;
-    beta = none ? alpha : bs * fi;
-    tau = none ? 0.0 : t;
-    scal = none ? 0.0 : fast_rcp(al - bs) * f;
-}
-
+// (reflector scalars: larfg_vt of common.hpp -- tau and the scale of v from 1 / norm alone, beta is never needed)
 // workgroup barrier that waits for this wave's LDS traffic only (global stores and loads stay in flight)
 #define MC_LDS_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
@@ -361,8 +334,8 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], double (&r)[C
         if (L.ldead) return false;
         const double sst = L.lsc[0], alpha = L.lsc[1];
         // ---- 4. G(i): every wave for itself; r <- v = row_i * scal
-        double beta, tau, scal;
-        larfg(alpha, sst, beta, tau, scal);
+        double tau, scal;
+        larfg_vt(alpha, sst, tau, scal);
 #define MC_VSCALE(J) r[J] *= scal;
         MC_FOR_LIVE(nlive, MC_VSCALE);
 #undef MC_VSCALE
@@ -402,8 +375,8 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], double (&r)[C
         constexpr int SN = (SL + 1 < RS) ? SL + 1 : SL;
         const double alpha2 = rdlane(nxt ? nc[SN] : nc[SL], l1);
         const double w1 = rdlane(nxt ? w[SN] : w[SL], l1);
-        double beta2, tauq, sc2;
-        larfg(alpha2, p1, beta2, tauq, sc2);
+        double tauq, sc2;
+        larfg_vt(alpha2, p1, tauq, sc2);
         const double uw = fma(sc2, p2, w1);                         // u^T w
         double u[RS], tu[RS];
 #pragma unroll
