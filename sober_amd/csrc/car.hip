@@ -175,10 +175,10 @@ __device__ __forceinline__ void car_publish_progress(const CarPub& pub, int k) {
 //   * column i after G(i), col' = cur - tau w, is known to every thread for its own rows, so the column sums
 //     Y = col'[i+2:]^T A' and |col'[i+2:]|^2 start without H(i)'s scalars; H(i)'s dlarfg runs AFTER the sums, redundantly,
 //     at the top of the next iteration, where z = rowg + sc2 Y -- phase (C)'s wave-wide norm and its barrier are gone.
-// One iteration = [H(i-1)'s scalars, z, update | row, column, G(i), w = A v, update, publish, partial column sums]
-// barrier [16 partial sums -> Y] barrier.  Dead rows and columns are never written (masks on the block's own slot only).
+// One iteration = [z, H(i-1)'s update | row, column, G(i), w = A v, update, publish, partial column sums]
+// barrier [16 partial sums -> Y on waves 0-2; norm + H(i)'s scalars on wave 3] barrier.  Dead rows and columns are never written (masks on the block's own slot only).
 struct CarLds2 {
-    double* rowg; double* colg; double* zpart; double* s2part; double* zsum; double* scal;
+    double* rowg; double* colg; double* zpart; double* s2part; double* zsum; double* scal; double* hsc;
 };
 
 // timing-only switches (wrong results): what each part of the step costs  (scripts/bidiag_where.sh)
@@ -228,24 +228,12 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         // ---- H(i-1): scalars from the finished sums, z, the rank-1 update (rows >= i, columns >= i)
         double z[CAR_CQ], x[CAR_CQ], f[CAR_MS], cur[CAR_MS];
         CB_STAMP(0);
-        double tauq, sc2;
-        const double al2 = L.scal[pp], s2 = L.zsum[CAR_NS];
-        // (every LDS read of the block is issued before the scalar chain of H(i-1) starts: x and z wait in registers)
+        const double tauq = L.hsc[0], sc2 = L.hsc[1];        // H(i-1)'s scalars (wave 3 of the previous step's sums)
 #pragma unroll
         for (int q = S; q < CAR_CQ; ++q) { x[q] = L.rowg[pp * CAR_NS + C + 16 * q]; z[q] = L.zsum[C + 16 * q]; }
         const double rgi = L.rowg[pp * CAR_NS + i];
 #pragma unroll
         for (int k = S; k < CAR_MS; ++k) cur[k] = L.colg[pp * 128 + R + 16 * k];
-        if constexpr (S > 0) __builtin_amdgcn_sched_barrier(0);      // (block 0 has no registers to hold them)
-        {
-            double beta2;
-#ifdef CB2_X_NOLARFG
-            beta2 = al2; tauq = s2; sc2 = beta2 + tauq;
-#else
-            larfg_vt(al2, s2, tauq, sc2); (void)beta2;
-#endif
-        }
-        CB2_STAMP(1, tauq);
 #pragma unroll
         for (int q = S; q < CAR_CQ; ++q) {
             z[q] = fma(sc2, z[q], x[q]);
@@ -364,16 +352,37 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         CB2_BARRIER();
         CB_STAMP(7);
 #ifndef CB2_X_NOD
-        if (tid >= 16 * S && tid <= CAR_NS) {                // thread CAR_NS: the norm
-            const double* src = (tid == CAR_NS) ? L.s2part : L.zpart + tid;
-            const int str = (tid == CAR_NS) ? 1 : CAR_NS;
-            double z0 = 0.0, z1 = 0.0;
+        // the 16 partial sums per live column: column 16 S + t belongs to thread t of waves 0 .. 2 (192 threads cover the
+        // live columns from block 1 on).  WAVE 3 has no column of its own then: it sums the norm and runs H(i)'s scalar
+        // chain (dlarfg: ~35 dependent instructions) HERE, beside the column sums, instead of every thread running it at
+        // the top of the next iteration with nothing to overlap it (block 0: wave 3 also takes columns 192 .. 207)
+        if (tid < 192) {                                     // (wave-uniform)
+            const int c = 16 * S + tid;
+            if (c < CAR_NS) {
+                double z0 = 0.0, z1 = 0.0;
 #pragma unroll
-            for (int w = 0; w < 16; w += 2) {
-                z0 += src[w * str];
-                z1 += src[(w + 1) * str];
+                for (int w = 0; w < 16; w += 2) {
+                    z0 += L.zpart[w * CAR_NS + c];
+                    z1 += L.zpart[(w + 1) * CAR_NS + c];
+                }
+                L.zsum[c] = z0 + z1;
             }
-            L.zsum[tid] = z0 + z1;
+        } else {
+            if constexpr (S == 0) {
+                if (tid < CAR_NS) {
+                    double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 16; w += 2) {
+                        z0 += L.zpart[w * CAR_NS + tid];
+                        z1 += L.zpart[(w + 1) * CAR_NS + tid];
+                    }
+                    L.zsum[tid] = z0 + z1;
+                }
+            }
+            const double s2n = row16_sum(L.s2part[C]);       // (every 16-lane row of the wave: the same sum, same order)
+            double tq, s2c;
+            larfg_vt(L.scal[p], s2n, tq, s2c);
+            if (tid == 192) { L.hsc[0] = tq; L.hsc[1] = s2c; }
         }
 #endif
         CB_STAMP(8);
@@ -392,8 +401,7 @@ __device__ __forceinline__ void car_bidiag2_last(int m, const CarLds2& L, double
     const int i = m - 1, li = i & 15, pp = (i & 1) ^ 1;
     if constexpr (FUSED) car_publish_progress(pub, i);
     double x[CAR_CQ], zS = 0.0;
-    double tauq, sc2, beta2;
-    larfg_vt(L.scal[pp], L.zsum[CAR_NS], tauq, sc2); (void)beta2;
+    const double tauq = L.hsc[0], sc2 = L.hsc[1];
 #pragma unroll
     for (int q = S; q < CAR_CQ; ++q) {
         const double rg = L.rowg[pp * CAR_NS + C + 16 * q];
@@ -432,6 +440,7 @@ __device__ __forceinline__ void car_bidiag2_body(const double* __restrict__ X, i
     __shared__ double s2part[16];
     __shared__ double zsum[CAR_NS + 8];
     __shared__ double scal[2];
+    __shared__ double hsc[2];
     const int tid = threadIdx.x;
     const int R = tid >> 4, C = tid & 15;
     double a[CAR_MS][CAR_CQ], colp[CAR_MS];
@@ -448,9 +457,9 @@ __device__ __forceinline__ void car_bidiag2_body(const double* __restrict__ X, i
     if (tid < CAR_NS) { rowg[CAR_NS + tid] = (tid < N) ? 1.0 : 0.0; zsum[tid] = 0.0; }
     if (tid < 128) colg[128 + tid] = (tid < m && N > 0) ? ((tid == 0) ? 1.0 : X[tid - 1]) : 0.0;
     if (tid < 8) zsum[CAR_NS + tid] = 0.0;
-    if (tid < 2) scal[tid] = 0.0;
+    if (tid < 2) { scal[tid] = 0.0; hsc[tid] = 0.0; }    // (tau = 0: "H(-1)" is the identity)
     __syncthreads();
-    const CarLds2 L{rowg, colg, zpart, s2part, zsum, scal};
+    const CarLds2 L{rowg, colg, zpart, s2part, zsum, scal, hsc};
     car_bidiag2_block<0, FUSED>(a, colp, m, L, vws, taup, pub);
     if (m > 17) car_bidiag2_block<1, FUSED>(a, colp, m, L, vws, taup, pub);
     if (m > 33) car_bidiag2_block<2, FUSED>(a, colp, m, L, vws, taup, pub);
