@@ -1,4 +1,4 @@
-# per-kernel durations of scripts/kmeans_time.py (rocprofv3 kernel stats)
+# per-kernel durations of scripts/kmeans_time.py (rocprofv3 kernel stats); KM_SIZES="100000:10" restricts the sizes
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kmp
@@ -6,6 +6,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kmp -o run -- pytho
 cat /tmp/kmp.log | grep "per KMeans"
 python3 - <<PY
 import csv
+tot=0
 for r in csv.DictReader(open('/tmp/kmp/run_kernel_stats.csv')):
-    if float(r['Percentage']) > 0.5: print('  ', r['Name'][:70], r['Calls'], 'avg us %.1f' % (float(r['AverageNs'])/1e3), 'min %.1f' % (float(r['MinNs'])/1e3), 'max %.1f' % (float(r['MaxNs'])/1e3), r['Percentage'])
+    tot+=float(r['TotalDurationNs'])
+    if float(r['Percentage']) > ${KM_MINPCT:-0.5}: print('  ', r['Name'][:90], r['Calls'], 'avg us %.1f' % (float(r['AverageNs'])/1e3), 'total ms %.2f' % (float(r['TotalDurationNs'])/1e6), r['Percentage'])
+print('total kernel ms', tot/1e6)
 PY

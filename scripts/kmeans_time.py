@@ -4,7 +4,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sober_amd
 dev = torch.device("cuda")
-for N, d in ((100000, 10), (1000000, 20)):
+sizes = [tuple(int(v) for v in t.split(":")) for t in os.environ.get("KM_SIZES", "100000:10,1000000:20").split(",")]
+for N, d in sizes:
     g = torch.Generator().manual_seed(0)
     X = torch.rand(N, d, generator=g, dtype=torch.float64).to(dev)
     sober_amd.KMeans(X, 500); torch.cuda.synchronize()
