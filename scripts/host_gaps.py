@@ -27,8 +27,8 @@ def wrap(obj, name, sync=False):
         return r
     setattr(obj, name, g)
 
-for nm in ("build_plan", "gram", "set_projection", "nonzero_i32", "level_moments", "level_car", "level_update", "direct_columns",
-           "scatter_weights", "to_host", "_svd_lowrank_device", "nystrom_basis_device"):
+for nm in ("build_plan", "gram", "set_projection", "nonzero_start", "nonzero_finish", "level_moments", "level_loop", "level_final",
+           "level_car", "level_update", "direct_columns", "scatter_weights", "to_host", "nystrom_basis_device"):
     wrap(ops, nm)
 wrap(nat, "cholesky_probe"); wrap(torch.linalg, "svd")
 

@@ -45,8 +45,11 @@ class HipOps:
         self.car_mode = nat.CAR_DEFAULT
 
     # ------------------------------------------------------------------ plan
-    def build_plan(self, spec: KernelSpec, mode: str, X_nys, X_cand) -> Plan:
+    def build_plan(self, spec: KernelSpec, mode: str, X_nys, X_cand, pool_owner=None) -> Plan:
+        """`pool_owner`: the caller's own tensor object behind X_cand (recombination() hands the plan a detached view,
+        a fresh Python object per call): what the caches of `_packed_pool` / `_pool_mean` hold their weak reference to."""
         p = Plan()
+        pool_owner = X_cand if pool_owner is None else pool_owner
         p.spec, p.mode = spec, mode
         p.X_nys_raw, p.X_cand_raw = X_nys, X_cand                 # (the replicated finish of a sharded run rebuilds a plan)
         p.kind = nat.KIND_BY_NAME[spec.kind]
@@ -56,13 +59,13 @@ class HipOps:
         p.n_obs = spec.X_obs.shape[0] if corrected else 0
         stacked = torch.cat([X_nys.to(torch.float64), spec.X_obs], 0) if corrected else X_nys
         p.rows = prepare_points(spec, stacked)                    # [X_nys; X_obs]
-        p.cand = self._packed_pool(spec, X_cand)
+        p.cand = self._packed_pool(spec, X_cand, pool_owner)
         p.Mtot = len(p.rows)
         p.weighted = mode == "weighted_predictive_covariance"
         p.mean_nys = p.wmul = None
         if p.weighted:
             p.mean_nys = posterior_mean(spec, p.rows.rows(0, p.M))
-            p.wmul = self._pool_mean(spec, p.cand, X_cand)        # mu_y of SOBER/_kernel.py:41
+            p.wmul = self._pool_mean(spec, p.cand, X_cand, pool_owner)   # mu_y of SOBER/_kernel.py:41
         p.T = None
         if corrected:
             # T = KxX @ W with KxX = k(X_nys, X_obs) (SOBER/_gp.py:293,295)
@@ -89,27 +92,28 @@ class HipOps:
         p.ws = {}
         return p
 
-    def _packed_pool(self, spec, X_cand):
+    def _packed_pool(self, spec, X_cand, owner):
         """prepare_points for the candidate pool.  A fingerprint pool (Tanimoto) arrives as an FP64 0/1 matrix --
         4 GB at 250k x 2048 -- and a dataset prior without pruning hands over the SAME tensor object at every BO
         iteration (SOBER/_sampler.py:351-382): its bit-packed form (64x smaller) is kept across calls.  Only the
-        packed words are held: the pool itself is referenced WEAKLY (a pruned prior builds a fresh tensor per
-        iteration -- that entry then simply misses and the old words are dropped; nothing pins the caller's 4 GB).
-        A hit needs the same tensor object, layout and in-place version counter; writes that bypass the counter
+        packed words are held: the pool itself is referenced WEAKLY, through the caller's own tensor object `owner`
+        (a pruned prior builds a fresh tensor per iteration -- that entry then simply misses and the old words are
+        dropped; nothing pins the caller's 4 GB).  A hit needs the same owner object (alive), the same memory, layout
+        and in-place version counter (a detached view shares its base's counter); writes that bypass the counter
         (`.data`, DLPack, foreign kernels) are the caller's to announce with `clear_cache()`."""
         if spec.kind != "tanimoto":
             return prepare_points(spec, X_cand)
         import weakref
         key = (X_cand.data_ptr(), tuple(X_cand.shape), tuple(X_cand.stride()), X_cand.dtype, X_cand._version)
         hit = getattr(self, "_pool_cache", None)
-        if hit is not None and hit[0] == key and hit[1]() is X_cand:
+        if hit is not None and hit[0] == key and hit[1]() is owner:
             return hit[2]
         self._pool_cache = None                                   # (a miss frees the previous pool's words first)
         pts = prepare_points(spec, X_cand)
-        self._pool_cache = (key, weakref.ref(X_cand), pts)
+        self._pool_cache = (key, weakref.ref(owner), pts)
         return pts
 
-    def _pool_mean(self, spec, cand, X_cand):
+    def _pool_mean(self, spec, cand, X_cand, owner):
         """The posterior mean over the pool (the per-candidate factor of the weighted kernel, SOBER/_kernel.py:41): a
         kernel-matvec over all N candidates, 0.37 ms at 250k x 2048 bits.  Kept while BOTH the pool (same tensor object,
         layout, version: the packed-pool cache's rule) and the model's snapshot (the same KernelSpec tensors, unmodified)
@@ -119,12 +123,12 @@ class HipOps:
                id(spec.alpha), spec.alpha._version, id(spec.X_obs), spec.X_obs._version,
                id(spec.lengthscale), spec.lengthscale._version, spec.kind, float(spec.outputscale), float(spec.mean_const))
         hit = getattr(self, "_mean_cache", None)
-        if hit is not None and hit[0] == key and hit[1]() is X_cand and hit[2]() is spec.alpha and hit[3]() is spec.X_obs:
+        if hit is not None and hit[0] == key and hit[1]() is owner and hit[2]() is spec.alpha and hit[3]() is spec.X_obs:
             return hit[4]
         import weakref
         self._mean_cache = None
         out = posterior_mean(spec, cand)
-        self._mean_cache = (key, weakref.ref(X_cand), weakref.ref(spec.alpha), weakref.ref(spec.X_obs), out)
+        self._mean_cache = (key, weakref.ref(owner), weakref.ref(spec.alpha), weakref.ref(spec.X_obs), out)
         return out
 
     def clear_cache(self):
@@ -750,7 +754,7 @@ class MatrixKernelOps(HipOps):
 
     CHUNK_ROWS = 1 << 15       # candidates per call of a foreign callable
 
-    def build_plan(self, kernel_fn, mode, X_nys, X_cand) -> Plan:
+    def build_plan(self, kernel_fn, mode, X_nys, X_cand, pool_owner=None) -> Plan:
         p = Plan()
         p.kernel_fn, p.mode = kernel_fn, "matrix"
         p.X_nys, p.X_cand = X_nys, X_cand

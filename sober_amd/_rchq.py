@@ -88,8 +88,8 @@ def recombination(pts_rec, pts_nys, num_pts, kernel, device=None, dtype=None, in
     comm = DistComm(group) if group is not None else SoloComm()
     eng = RecombinationEngine(_ops, comm, row_offset=row_offset)
     eng.trace = _trace
-    plan = _ops.build_plan(kernel.spec(dev), kernel.mode, X_nys, X_cand) if fused else \
-        _ops.build_plan(kernel, "callable", X_nys, X_cand)
+    plan = _ops.build_plan(kernel.spec(dev), kernel.mode, X_nys, X_cand, pool_owner=pts_rec) if fused else \
+        _ops.build_plan(kernel, "callable", X_nys, X_cand, pool_owner=pts_rec)
     obj = None
     if calc_obj is not None:                                              # :67-69, once on all candidates
         obj = (-1 * calc_obj(X_cand)).detach().to(dev, torch.float64).reshape(-1).contiguous()

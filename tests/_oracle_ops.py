@@ -24,7 +24,7 @@ class OracleOps:
     def __init__(self):
         self.device = torch.device("cpu")
 
-    def build_plan(self, spec, mode, X_nys, X_cand):
+    def build_plan(self, spec, mode, X_nys, X_cand, pool_owner=None):
         p = _Plan()
         p.kernel = O.Kernel(to_oracle_spec(spec), mode)
         p.X_nys, p.X_cand = X_nys, X_cand

@@ -326,6 +326,56 @@ def test_kmeans_matrix_core_e_step_equals_the_valu_kernel(N, d, K, dev):
         np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12, equal_nan=True)
 
 
+def test_fingerprint_pool_caches_hit_and_do_not_pin(dev, monkeypatch):
+    """What HipOps keeps across calls (the bit-packed fingerprint pool, the pool's posterior mean): a hit when the
+    caller hands over the SAME pool tensor and model snapshot again (a dataset prior without pruning), a miss -- and
+    nothing kept alive -- for a fresh tensor (a pruned prior); `recombination` itself works on a detached view, so the
+    weak reference must be to the caller's object."""
+    import gc
+    import weakref
+    from sober_amd import _native as nat
+    from sober_amd import _kernel as K
+    from sober_amd._ops_hip import HipOps
+    path = os.path.join(GOLD, "recomb_tanimoto_weighted.npz")
+    case, inp, spec, z = load_case(path)
+    ops = HipOps(dev)
+    kernel = sober_amd.Kernel(kspec(spec), case["mode"])
+    n_pack = []
+    real_pack = nat.pack_bits
+    monkeypatch.setattr(nat, "pack_bits", lambda X, *a, **k: (n_pack.append(X.shape[0]), real_pack(X, *a, **k))[1])
+    n_mv = []
+    real_mv = nat.kernel_matvec
+    monkeypatch.setattr(nat, "kernel_matvec", lambda *a, **k: (n_mv.append(1), real_mv(*a, **k))[1])
+    N = inp["X_cand"].shape[0]
+    pool = _t(inp["X_cand"]).to(dev)
+    Xn = _t(inp["X_nys"]).to(dev)
+
+    def run(p):
+        mu = _t(inp["mu0"].copy()).to(dev)
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return sober_amd.recombination(p, Xn, case["b"], kernel, init_weights=mu, _ops=ops)
+    i0, w0 = run(pool)
+    packs_pool = sum(1 for n in n_pack if n == N)
+    mv0 = len(n_mv)
+    assert packs_pool == 1 and np.array_equal(i0.cpu().numpy(), z["idx"])
+    i1, w1 = run(pool)                                        # same tensor, same KernelSpec: both caches hit
+    assert sum(1 for n in n_pack if n == N) == 1
+    assert len(n_mv) - mv0 == mv0 - 1                         # (the Nystrom points' mean is recomputed, the pool's is not)
+    assert torch.equal(i0, i1) and torch.equal(w0, w1)
+    pool2 = pool.clone()                                      # a fresh tensor (pruned prior): a miss ...
+    wr = weakref.ref(pool)
+    del pool
+    i2, _ = run(pool2)
+    assert sum(1 for n in n_pack if n == N) == 2 and torch.equal(i0, i2)
+    gc.collect()
+    assert wr() is None                                       # ... and the old pool is not kept alive by the backend
+    pool2[0, 0] = 1.0 - pool2[0, 0]                           # an in-place write bumps the version counter: a miss
+    run(pool2)
+    assert sum(1 for n in n_pack if n == N) == 3
+
+
 def test_cleansing_weights_vs_golden(dev):
     z = np.load(os.path.join(GOLD, "weights.npz"))
     ws = sober_amd.WeightsStabiliser()
