@@ -41,6 +41,10 @@ extern "C" {
 #define SOBER_E_EXCHANGE -5      /* a multi-workgroup kernel gave up waiting for a partner (bounded spins); no result */
 
 int sober_abi_version(void);
+/* sizeof(sober_level_job) / sizeof(sober_nystrom_job) as the library was built: a binding that lays the structs out itself
+ * (ctypes, cgo, JNA ...) checks its own size against these before the first call.                                   */
+int sober_level_job_size(void);
+int sober_nystrom_job_size(void);
 
 /* DT for a d-dimensional continuous kernel (multiple of 4, >= d), or -2 if d > SOBER max.       */
 int sober_padded_dim(int d);

@@ -25,6 +25,8 @@ _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
 # name -> (restype, argtypes); mirrors include/sober_hip.h one to one
 SIGNATURES = {
     "sober_abi_version": (_i32, []),
+    "sober_level_job_size": (_i32, []),
+    "sober_nystrom_job_size": (_i32, []),
     "sober_padded_dim": (_i32, [_i32]),
     "sober_bit_words": (_i32, [_i32]),
     "sober_scale_points": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
@@ -179,6 +181,10 @@ def load() -> C.CDLL:
     got = lib.sober_abi_version()
     if got != ABI_VERSION:
         raise SoberHipError(f"libsober_hip ABI {got} != expected {ABI_VERSION}; rebuild")
+    for name, cls in (("sober_level_job_size", LevelJob), ("sober_nystrom_job_size", NystromJob)):
+        if getattr(lib, name)() != C.sizeof(cls):
+            raise SoberHipError(f"{cls.__name__}: {C.sizeof(cls)} bytes here, {getattr(lib, name)()} in libsober_hip; "
+                                "include/sober_hip.h and sober_amd/_native.py disagree")
     _lib = lib
     return lib
 

@@ -7,6 +7,8 @@
 
 #include "../../include/sober_hip.h"
 
+extern "C" int sober_level_job_size(void) { return (int)sizeof(sober_level_job); }
+
 #define LX_TRY(call)                 \
     do {                             \
         const int rc_ = (call);      \

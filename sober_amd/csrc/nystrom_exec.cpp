@@ -8,6 +8,8 @@
 
 #include "../../include/sober_hip.h"
 
+extern "C" int sober_nystrom_job_size(void) { return (int)sizeof(sober_nystrom_job); }
+
 #define NX_TRY(call)                 \
     do {                             \
         const int rc_ = (call);      \
