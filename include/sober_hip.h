@@ -327,6 +327,15 @@ int sober_level_reduce_mfma_queued(int kind, const double* rows, int n_rows, con
                                    const int32_t* idx, int64_t count_ub, int S, int S_main, int leftover,
                                    const double* mu, const double* wmul, double outputscale, int n_chunks_ub,
                                    double* partG, int ldg, double* partTot, const int64_t* dR, void* stream);
+/* Both placements in ONE launch: the workgroups of the leftover launch (n_xcols pseudo-sets, at most S - 1 positions,
+ * partial sums extraG / extraTot with row stride n_xcols, n_xchunks_ub = sober_level_parts_mfma_cap(n_rows,
+ * ceil((S - 1) / n_xcols), n_xcols)) ride behind the main launch's: the same arithmetic as the two launches
+ * (SOBER/_rchq.py:128-136 and :153-164), one dispatch less per level. */
+int sober_level_reduce_mfma_queued_pair(int kind, const double* rows, int n_rows, const double* cand, int da,
+                                        const int32_t* idx, int64_t count_ub, int S, int n_xcols, const double* mu,
+                                        const double* wmul, double outputscale, int n_chunks_ub, double* partG,
+                                        int ldg, double* partTot, int n_xchunks_ub, double* extraG, double* extraTot,
+                                        const int64_t* dR, void* stream);
 int sober_sum_partials_queued(const double* partG, const double* partTot, int n_rows, int ldg, int S,
                               const double* extraG, const double* extraTot, int n_xcols, double* G, int ldo,
                               double* tot, const int64_t* dR, void* stream);

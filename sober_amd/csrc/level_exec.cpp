@@ -163,18 +163,26 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
             if (nch <= 0 || nch > SOBER_LEVEL_MAX_CHUNKS || nxch <= 0 || nxch > SOBER_LEVEL_MAX_CHUNKS) return SOBER_E_WS;
             LX_EVENTS_BEFORE(j->ev[0], j->ev[1])
             if (j->ev[0] && j->ev[1]) j->ev_used[0] |= 1ull << l;
-            LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
-                                                  j->dim, cur, Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch,
-                                                  j->partG, S, j->partTot, j->dR + l, stream));
-            // (the leftover launch of a level whose size is known exactly and leaves none is not made: the sums
-            //  kernel finds the same zero from dR)
-            if (!(Rlo[l] == Rub[l] && Rub[l] % S == 0)) {
-                LX_EVENTS_BEFORE(j->ev[2], j->ev[3])
-                if (j->ev[2] && j->ev[3]) j->ev_used[1] |= 1ull << l;
+            // (a level whose size is known exactly and leaves no leftover carries no leftover workgroups: the sums
+            //  kernel finds the same zero from dR); otherwise both placements travel in one launch
+            const bool no_left = Rlo[l] == Rub[l] && Rub[l] % S == 0;
+            if (no_left || getenv("SOBER_LEVEL_TWO_LAUNCHES")) {
                 LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
-                                                      j->dim, cur, S - 1, SOBER_LEVEL_XS, S, 1, j->mu, j->wmul,
-                                                      j->outputscale, nxch, j->extraG, SOBER_LEVEL_XS, j->extraTot,
-                                                      j->dR + l, stream));
+                                                      j->dim, cur, Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch,
+                                                      j->partG, S, j->partTot, j->dR + l, stream));
+                if (!no_left) {
+                    LX_EVENTS_BEFORE(j->ev[2], j->ev[3])
+                    if (j->ev[2] && j->ev[3]) j->ev_used[1] |= 1ull << l;
+                    LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
+                                                          j->dim, cur, S - 1, SOBER_LEVEL_XS, S, 1, j->mu, j->wmul,
+                                                          j->outputscale, nxch, j->extraG, SOBER_LEVEL_XS, j->extraTot,
+                                                          j->dR + l, stream));
+                }
+            } else {
+                LX_TRY(sober_level_reduce_mfma_queued_pair(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
+                                                           j->dim, cur, Rub[l], S, SOBER_LEVEL_XS, j->mu, j->wmul,
+                                                           j->outputscale, nch, j->partG, S, j->partTot, nxch, j->extraG,
+                                                           j->extraTot, j->dR + l, stream));
             }
             LX_TRY(sober_sum_partials_queued(j->partG, j->partTot, j->n_rows, S, S, j->extraG, j->extraTot,
                                              SOBER_LEVEL_XS, j->G, S, j->tot, j->dR + l, stream));

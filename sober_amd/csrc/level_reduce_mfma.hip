@@ -143,26 +143,53 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
     int64_t e_first, int e_total,
     double* __restrict__ partG, int ldg, int col0,
     double* __restrict__ partTot, int64_t tot_limit,
-    const int64_t* __restrict__ dR, int S_main, int leftover) {
+    const int64_t* __restrict__ dR, int S_main, int leftover,
+    int S_x, double* __restrict__ partG_x, int ldg_x, double* __restrict__ partTot_x, int grid_main) {
     constexpr int DA = 4 * KT;
     constexpr int W = SOBER_LW_W;
+#ifdef LW_STAMPS      // diagnostic build (scripts/level_stamps.py): s_memrealtime (100 MHz, one origin for the whole chip) of every wave at eight points -> partG, slot 6 on
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long* const st_out_ = (unsigned long long*)(partG + (size_t)6 * n_rows * ldg) + ((size_t)blockIdx.x * W + (threadIdx.x >> 6)) * 8;
+#define LW_STAMP(K) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_[K] = t_; } while (0)
+#define LW_STAMP_V(K, VAL) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(VAL) :: "memory"); st_[K] = t_; } while (0)
+#define LW_STAMP_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; ++k_) st_out_[k_] = st_[k_]; } while (0)
+    LW_STAMP(0);
+#else
+#define LW_STAMP(K) do { } while (0)
+#define LW_STAMP_V(K, VAL) do { } while (0)
+#define LW_STAMP_FLUSH() do { } while (0)
+#endif
     __shared__ double s_T[EXP_TAB];              // 2^(j/256), exponent-adjusted (exp_tab_entry)
     __shared__ double s_tot[W * 16];
     __shared__ double s_red[W * 16 * 64];
 
+    int bid = blockIdx.x, gdim = gridDim.x;     // my place in my launch, and its size
     if (dR != nullptr) {                        // queued level (level_exec.cpp): the launch was sized from an UPPER BOUND of
         // the live positions; the exact number R sits in device memory (written by the previous level's update).
         // leftover = 0: the main launch over positions [0, R) (S = S_main); leftover = 1: positions [E S_main, R)
-        // spread over S pseudo-sets.
+        // spread over S pseudo-sets; leftover = 2: BOTH in one grid -- the workgroups behind the first grid_main are
+        // the leftover launch (S_x pseudo-sets, its own partial sums), same arithmetic as two launches.
         const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (R <= S_main) return;
         const int64_t ES = (R / S_main) * S_main;
+        if (leftover == 2) {
+            if (bid >= grid_main) {
+                leftover = 1; bid -= grid_main; gdim -= grid_main;
+                S = S_x; partG = partG_x; ldg = ldg_x; partTot = partTot_x;
+            } else {
+                leftover = 0; gdim = grid_main;
+            }
+        }
         if (!leftover) { count = R; tot_limit = ES; }
         else { idx += ES; count = R - ES; tot_limit = count; }
         if (count <= 0) return;
         pos0 = 0; e_first = 0;
         e_total = (int)((count + S - 1) / S);
     }
+#ifdef LW_STAMPS
+    { unsigned hw_, xc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc_));
+      st_[1] = ((unsigned long long)xc_ << 32) | hw_; }          // where the wave runs
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (scalar: the element loop is uniform)
     const int lj = lane & 15, lk = lane >> 4;
@@ -170,8 +197,8 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
     const int wpt = level_wave_wpt(n_rows, e_total, S);
     const int n_slots = level_wave_slots(wpt);
     const int n_waves = G * RT * wpt;
-    const int per_xcd = gridDim.x >> 3;                                 // (the grid is a multiple of 8)
-    const int q = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);       // my place in the line of workgroups
+    const int per_xcd = gdim >> 3;                                      // (the grid is a multiple of 8)
+    const int q = (bid & 7) * per_xcd + (bid >> 3);                     // my place in the line of workgroups
     if (q * W >= n_waves) return;                                       // (whole workgroup)
     const int v = q * W + wave;
     const bool live = v < n_waves;
@@ -273,8 +300,11 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
     LW_IDX(ea + 1, cB)
     LW_IDX(ea + 2, cF)
     __syncthreads();                                   // the table (the only barrier before the final sum)
+    LW_STAMP(2);
+    LW_STAMP_V(3, afr[3][KT - 1]);
     LW_LOAD(ea, cA, 0)
     LW_LOAD(ea + 1, cB, 1)
+    LW_STAMP_V(4, b[1][KT - 1]);
     LW_MFMA(0)
     // (the exponentials of a half-step read cc / w of the element the PREVIOUS half-step multiplied)
 #define ccv cc
@@ -285,6 +315,7 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
         LW_HALF(e + 1, 1, 0)
     }
     if (e < eb) LW_HALF(e, 0, 1)
+    LW_STAMP_V(5, acc[3][3]);
 #undef ccv
 #undef wcv
 #undef LW_REL
@@ -304,7 +335,8 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
     if (lk == 0) s_tot[wave * 16 + lj] = tot_acc;
     if (lane == 0) s_tile[wave] = tile;
     __syncthreads();
-    if (!live || (wave > 0 && s_tile[wave - 1] == tile)) return;       // not the first wave of its run
+    LW_STAMP(6);
+    if (!live || (wave > 0 && s_tile[wave - 1] == tile)) { LW_STAMP_FLUSH(); return; }      // not the first wave of its run
     for (int w = wave + 1; w < W && s_tile[w] == tile; ++w) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -314,7 +346,7 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
     }
     const int slot = q - (tile * wpt) / W;
     const int last_q = (tile * wpt + wpt - 1) / W;                     // the workgroup of the tile's last wave
-    if (!s_ok) return;
+    if (!s_ok) { LW_STAMP_FLUSH(); return; }
     // (a tile whose waves touch fewer workgroups than n_slots: its last run also clears the slots nobody writes)
     for (int sl = slot; sl < (q == last_q ? n_slots : slot + 1); ++sl) {
         const bool mine = sl == slot;
@@ -327,6 +359,8 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
             }
         if (partTot != nullptr && rt == 0 && lk == 0) partTot[(size_t)sl * ldg + col0 + s] = mine ? tot_acc : 0.0;
     }
+    LW_STAMP(7);
+    LW_STAMP_FLUSH();
 }
 
 // points -> augmented, centred, scaled rows.  side 1 (pool): [y~, 1, -|y~|^2/2, 0..];
@@ -377,7 +411,8 @@ template <int KIND, int KT>
 static int launch_lm(const double* rows, int n_rows, const double* cand, const int32_t* idx, int64_t pos0,
                      int64_t count, int S, const double* mu, const double* wmul, double os, int n_chunks,
                      double* partG, int ldg, int col0, double* partTot, int64_t tot_limit, hipStream_t st,
-                     const int64_t* dR = nullptr, int S_main = 0, int leftover = 0) {
+                     const int64_t* dR = nullptr, int S_main = 0, int leftover = 0, int S_x = 0, int n_xchunks = 0,
+                     double* partG_x = nullptr, int ldg_x = 0, double* partTot_x = nullptr) {
     const int64_t e_first = pos0 / S;
     const int e_total = (int)((pos0 + count + S - 1) / S - e_first);
     const int wpt = level_wave_wpt(n_rows, e_total, S);
@@ -385,9 +420,18 @@ static int launch_lm(const double* rows, int n_rows, const double* cand, const i
     if (count + 2 * (int64_t)S > 0x7fffffffLL) return SOBER_E_ARG;     // (positions inside a launch are 32-bit, like the list's entries)
     const int64_t n_waves = level_wave_tiles(n_rows, S) * wpt;
     const int64_t n_wg = (n_waves + SOBER_LW_W - 1) / SOBER_LW_W;
-    SOBER_LAUNCH_TIMED((k_level_reduce_wave<KIND, KT>), dim3((unsigned)(8 * ((n_wg + 7) / 8))), dim3(SOBER_LW_W * 64), 0,
+    const int grid_main = (int)(8 * ((n_wg + 7) / 8));
+    int grid_x = 0;
+    if (leftover == 2) {                                               // + the leftover launch's workgroups (at most S_main - 1 positions)
+        const int e_x = (S_main - 1 + S_x - 1) / S_x;
+        const int wpt_x = level_wave_wpt(n_rows, e_x, S_x);
+        if (dR == nullptr || S_x <= 0 || n_xchunks != level_wave_slots(wpt_x) || !partG_x || ldg_x < S_x) return SOBER_E_ARG;
+        const int64_t n_wg_x = (level_wave_tiles(n_rows, S_x) * wpt_x + SOBER_LW_W - 1) / SOBER_LW_W;
+        grid_x = (int)(8 * ((n_wg_x + 7) / 8));
+    }
+    SOBER_LAUNCH_TIMED((k_level_reduce_wave<KIND, KT>), dim3((unsigned)(grid_main + grid_x)), dim3(SOBER_LW_W * 64), 0,
                        st, rows, n_rows, cand, idx, pos0, count, S, mu, wmul, os, e_first, e_total, partG, ldg, col0,
-                       partTot, tot_limit, dR, S_main, leftover);
+                       partTot, tot_limit, dR, S_main, leftover, S_x, partG_x, ldg_x, partTot_x, grid_main);
     LAUNCH_CHECK();
     return 0;
 }
@@ -428,7 +472,8 @@ static int level_reduce_mfma_impl(int kind, const double* rows, int n_rows, cons
                                   const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu,
                                   const double* wmul, double outputscale, int n_chunks, double* partG,
                                   int ldg, int col0, double* partTot, int64_t tot_limit, void* stream,
-                                  const int64_t* dR, int S_main, int leftover);
+                                  const int64_t* dR, int S_main, int leftover, int S_x = 0, int n_xchunks = 0,
+                                  double* partG_x = nullptr, int ldg_x = 0, double* partTot_x = nullptr);
 
 extern "C" int sober_level_reduce_mfma(int kind, const double* rows, int n_rows, const double* cand, int da,
                                        const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu,
@@ -448,18 +493,33 @@ extern "C" int sober_level_reduce_mfma_queued(int kind, const double* rows, int 
                                   n_chunks_ub, partG, ldg, 0, partTot, 0, stream, dR, S_main, leftover);
 }
 
+// both placements of a queued level in ONE launch: the leftover launch's workgroups ride behind the main ones
+extern "C" int sober_level_reduce_mfma_queued_pair(int kind, const double* rows, int n_rows, const double* cand, int da,
+                                                   const int32_t* idx, int64_t count_ub, int S, int n_xcols,
+                                                   const double* mu, const double* wmul, double outputscale,
+                                                   int n_chunks_ub, double* partG, int ldg, double* partTot,
+                                                   int n_xchunks_ub, double* extraG, double* extraTot,
+                                                   const int64_t* dR, void* stream) {
+    if (!dR || S <= 1 || n_xcols <= 0 || !extraG || !extraTot) return SOBER_E_ARG;
+    return level_reduce_mfma_impl(kind, rows, n_rows, cand, da, idx, 0, count_ub, S, mu, wmul, outputscale,
+                                  n_chunks_ub, partG, ldg, 0, partTot, 0, stream, dR, S, 2, n_xcols, n_xchunks_ub, extraG,
+                                  n_xcols, extraTot);
+}
+
 static int level_reduce_mfma_impl(int kind, const double* rows, int n_rows, const double* cand, int da,
                                   const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu,
                                   const double* wmul, double outputscale, int n_chunks, double* partG,
                                   int ldg, int col0, double* partTot, int64_t tot_limit, void* stream,
-                                  const int64_t* dR, int S_main, int leftover) {
+                                  const int64_t* dR, int S_main, int leftover, int S_x, int n_xchunks,
+                                  double* partG_x, int ldg_x, double* partTot_x) {
     if (!rows || !cand || !idx || !mu || !partG) return SOBER_E_ARG;
     if (n_rows <= 0 || pos0 < 0 || count <= 0 || S <= 0 || n_chunks <= 0 || ldg < col0 + S) return SOBER_E_ARG;
     hipStream_t st = (hipStream_t)stream;
 #define LM_CASE(K, T)                                                                                          \
     case 4 * T:                                                                                                \
         return launch_lm<K, T>(rows, n_rows, cand, idx, pos0, count, S, mu, wmul, outputscale, n_chunks, partG, \
-                               ldg, col0, partTot, tot_limit, st, dR, S_main, leftover);
+                               ldg, col0, partTot, tot_limit, st, dR, S_main, leftover, S_x, n_xchunks, partG_x,   \
+                               ldg_x, partTot_x);
     switch (kind) {
         case SOBER_KIND_RBF:
             switch (da) { LM_CASE(SOBER_KIND_RBF, 1) LM_CASE(SOBER_KIND_RBF, 2) LM_CASE(SOBER_KIND_RBF, 3)

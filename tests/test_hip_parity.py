@@ -126,6 +126,19 @@ def test_bit_reproducible(dev):
     assert torch.equal(idx1, idx2) and torch.equal(w1, w2) and torch.equal(mu1, mu2)
 
 
+def test_leftover_workgroups_in_the_main_launch_equal_two_launches(dev, monkeypatch):
+    """Queued levels send the second placement of the leftovers (SOBER/_rchq.py:153-164) as extra workgroups of the
+    main launch; SOBER_LEVEL_TWO_LAUNCHES=1 makes the two launches of before: same arithmetic, bit for bit."""
+    for name in ("recomb_cfg2_rbf.npz", "recomb_rbf_medium.npz"):
+        path = os.path.join(GOLD, name)
+        monkeypatch.delenv("SOBER_LEVEL_TWO_LAUNCHES", raising=False)
+        _, _, z, idx1, w1, mu1 = run_hip(path, dev)
+        monkeypatch.setenv("SOBER_LEVEL_TWO_LAUNCHES", "1")
+        _, _, _, idx2, w2, mu2 = run_hip(path, dev)
+        assert torch.equal(idx1, idx2) and torch.equal(w1, w2) and torch.equal(mu1, mu2)
+        assert np.array_equal(idx1.cpu().numpy(), z["idx"])
+
+
 def test_moment_identity_without_leftovers(dev):
     path = os.path.join(GOLD, "recomb_rbf_noleft.npz")
     trace = {}
