@@ -19,9 +19,9 @@ reference's 8-GPU case and scales STRONGLY (the 1M-row pool is split N ways: 125
 Rank 0 prints ONE JSON line.  `value` = candidates reduced per second, whole job.
 `roofline` is for the dominant kernel (the level reduction): algorithmic FP64 flop ((2d + 2 + C_k)
 per kernel entry, C_k = 28 for the software FP64 exp, 40 for Matern-5/2) / the summed durations of ALL its launches in
-the timed region (main and leftover launches; HIP events carried in the dispatches themselves, i.e. the kernels' own
-begin / end timestamps -- calls x AverageNs of a rocprofv3 --kernel-trace --stats run of the same command), against the
-FP64 peak; for the Tanimoto kernel the integer operations of popcount(x & y) as an INT8 GEMM (2 per bit and (row,
+every --event-every-th step of the timed region (HIP events carried in the dispatches themselves, i.e. the kernels'
+own begin / end timestamps -- calls x AverageNs of a rocprofv3 --kernel-trace --stats run of the same command; a
+dispatch that carries events costs the stream 10-20 us, hence not every step), against the FP64 peak; for the Tanimoto kernel the integer operations of popcount(x & y) as an INT8 GEMM (2 per bit and (row,
 candidate) pair) against the dense INT8 matrix peak.  `roofline.step_frac` is the whole step's algorithmic flop
 (SURVEY.md 8d F_alg) / ms_per_step against the same peak; `hbm` = algorithmic bytes / time (small by construction).
 `cpu_baseline` = the oracle (a torch-CPU port of the reference's own arithmetic) on this box's host cores, on a
@@ -178,6 +178,10 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="the level launches of every n-th timed step carry the HIP event pairs behind roofline.achieved "
+                         "(an event-carrying dispatch costs the stream 10-20 us: on every step that is +0.1-0.2 ms at "
+                         "configuration 2, profiles/r03_event_cost.txt); 1 = every step")
     ap.add_argument("--no-sweep", action="store_true", help="skip the n_obs sweep of SURVEY.md 8(d) (configuration 2, one GPU)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -242,7 +246,13 @@ def main():
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     per_step = []
-    for _ in range(args.steps):
+    ev_every = max(1, int(os.environ.get("SOBER_BENCH_EVENTS_EVERY", args.event_every)))
+    prof_all = ops.prof
+    ev_steps = 0
+    for i_step in range(args.steps):
+        with_events = i_step % ev_every == 0                # (every n-th step of the timed region: --event-every)
+        ops.prof = prof_all if with_events else None
+        ev_steps += 1 if with_events else 0
         ts = time.perf_counter()
         idx, w = step(timers)
         per_step.append(time.perf_counter() - ts)          # (host clock at return: the result tensors are final)
@@ -259,7 +269,7 @@ def main():
     # The event pairs ride in the dispatches (hipExtLaunchKernelGGL, sober_set_launch_events): elapsed_time is the
     # kernel's own begin -> end, the figure rocprofv3 --kernel-trace reports; no marker packet enters the stream and
     # nothing is subtracted.  kernel_ms_per_step = calls x AverageNs / steps of profiles/r03_cfgN_kernel_stats.csv.
-    prof, ops.prof = ops.prof, None
+    prof, ops.prof = prof_all, None
     kern_ms = sum(a.elapsed_time(b_) for a, b_, _, _ in prof)
     entries = sum(e for _, _, e, _ in prof)
     n_launches = sum(n for _, _, _, n in prof)
@@ -295,20 +305,21 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     traffic, traffic_src = pmc_traffic(args.config) if world == 1 else (None, None)
     n_rows = cfg["M"] + (cfg["n_obs"] if cfg["mode"] != "kernel" else 0)
-    V = entries / n_rows / args.steps                      # visited list positions per step (sum of the levels' sizes)
-    n_levels = sum(1 for _, _, e, _ in prof if e > 0 and e >= 2 * b * n_rows) / args.steps   # main launches per step
+    V = entries / n_rows / ev_steps                      # visited list positions per step (sum of the levels' sizes)
+    n_levels = sum(1 for _, _, e, _ in prof if e > 0 and e >= 2 * b * n_rows) / ev_steps   # main launches per step
     S2, n1 = 2 * b, b - 1
-    common = {"launches": n_launches, "launches_per_step": n_launches / args.steps,
-              "kernel_ms_per_step": kern_ms / args.steps,
+    common = {"launches": n_launches, "launches_per_step": n_launches / ev_steps, "steps_with_events": ev_steps,
+              "kernel_ms_per_step": kern_ms / ev_steps,
               "timing": "HIP events carried in the kernels' dispatches (their own begin/end timestamps), all launches of "
-                        "the kernel in the timed region, nothing subtracted",
+                        f"the kernel in every {ev_every}-th step of the timed region ({ev_steps} of {args.steps} steps), "
+                        "nothing subtracted",
               "traffic": traffic, "traffic_unit": "HBM bytes per launch, mean over the kernel's launches of a step",
-              "traffic_source": traffic_src, "V_per_step": V, "entries_per_step": entries / args.steps}
+              "traffic_source": traffic_src, "V_per_step": V, "entries_per_step": entries / ev_steps}
     if cfg["kind"] == "tanimoto":
         # popcount(x & y) as an INT8 GEMM on the matrix cores (csrc/level_reduce_tani.hip): 2 * bits integer operations
         # per (row, candidate) pair, against the dense INT8 MFMA peak (2 x the bf16 rate, MI355X_MICROARCH.md)
         bits = 64 * ((cfg["d"] + 63) // 64)
-        ops_step = entries / args.steps * 2 * bits
+        ops_step = entries / ev_steps * 2 * bits
         tops = entries * 2 * bits / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         alg_bytes = V * (bits / 8 + 16) + n_levels * (n_rows * S2 + S2) * 8
         roofline = dict(common, bound="mfma", achieved=tops, peak=INT8_PEAK_TOPS, unit="TFLOP/s", frac=tops / INT8_PEAK_TOPS,
@@ -321,7 +332,7 @@ def main():
         flop_per_entry = 2 * cfg["d"] + 2 + CK[cfg["kind"]]
         achieved = entries * flop_per_entry / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         # F_alg = entries (2d + 2 + C_k) + L (2 M n_obs S + 2 n M S)
-        f_alg = entries / args.steps * flop_per_entry + n_levels * (2.0 * cfg["M"] * cfg["n_obs"] * S2 + 2.0 * n1 * cfg["M"] * S2)
+        f_alg = entries / ev_steps * flop_per_entry + n_levels * (2.0 * cfg["M"] * cfg["n_obs"] * S2 + 2.0 * n1 * cfg["M"] * S2)
         alg_bytes = V * (8 * cfg["d"] + 16) + n_levels * (n_rows * S2 + S2) * 8
         roofline = dict(common, bound="mfma", achieved=achieved, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=achieved / FP64_PEAK_TFLOPS, peak_measured=FP64_MEASURED_TFLOPS,
@@ -338,7 +349,7 @@ def main():
                              "launch-bound); step_frac: the step is a chain of ~200 dependent Caratheodory "
                              "reflector/pivot steps per level, not a throughput problem")
     hbm = {"alg_bytes_per_step": alg_bytes, "gbs_over_step": alg_bytes / (ms_per_step * 1e-3) / 1e9,
-           "gbs_over_kernel": alg_bytes / (kern_ms / args.steps * 1e-3) / 1e9 if kern_ms > 0 else None,
+           "gbs_over_kernel": alg_bytes / (kern_ms / ev_steps * 1e-3) / 1e9 if kern_ms > 0 else None,
            "peak_gbs": HBM_PEAK_GBS, "frac_over_step": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "note": "B_alg = V (8d + 16) + L (M_tot S + S) 8 (SURVEY.md 8d); a small fraction by construction: the path "
                    "is FP64-compute and latency bound at ~300 flop/B"}

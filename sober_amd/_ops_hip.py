@@ -496,7 +496,8 @@ class HipOps:
             # and left at once: counted as a launch without entries)
             for l, (a, b) in enumerate(pairs):
                 Rl = level_R[l] if l < len(level_R) else 0
-                for which, pr, ent in ((0, a, Rl), (1, b, Rl % S)):
+                both = not ((job.ev_used[1] >> l) & 1)       # (the leftover workgroups rode in the main launch)
+                for which, pr, ent in ((0, a, Rl + (Rl % S if both else 0)), (1, b, Rl % S)):
                     if (job.ev_used[which] >> l) & 1 and not (l == 0 and sums_ready):
                         self.prof.append((pr[0], pr[1], int(ent * job.n_rows), 1))
                     else:
