@@ -15,8 +15,20 @@ from ._kernel import KernelSpec, PointSet, posterior_mean, prepare_points, woodb
 
 
 class Plan:
-    """Per-step device state shared by all levels."""
-    pass
+    """Per-step device state shared by all levels.  The POOL's side of it (scaled / augmented candidates, the pool's
+    posterior mean) is prepared at first use: the Nystrom chain needs the row table only, so the host enqueues that
+    chain first and prepares the pool while the GPU is busy with it (build_plan: `_pool_prep`)."""
+    _POOL_FIELDS = ("cand", "cand_aug", "rows_aug", "wmul")
+
+    def __getattr__(self, name):                                  # (only reached when the attribute is not set yet)
+        if name in Plan._POOL_FIELDS:
+            prep = self.__dict__.get("_pool_prep")
+            if prep is not None:
+                self.__dict__["_pool_prep"] = None
+                prep()
+                if name in self.__dict__:
+                    return self.__dict__[name]
+        raise AttributeError(name)
 
 
 class HipOps:
@@ -59,13 +71,11 @@ class HipOps:
         p.n_obs = spec.X_obs.shape[0] if corrected else 0
         stacked = torch.cat([X_nys.to(torch.float64), spec.X_obs], 0) if corrected else X_nys
         p.rows = prepare_points(spec, stacked)                    # [X_nys; X_obs]
-        p.cand = self._packed_pool(spec, X_cand, pool_owner)
         p.Mtot = len(p.rows)
         p.weighted = mode == "weighted_predictive_covariance"
-        p.mean_nys = p.wmul = None
+        p.mean_nys = None
         if p.weighted:
             p.mean_nys = posterior_mean(spec, p.rows.rows(0, p.M))
-            p.wmul = self._pool_mean(spec, p.cand, X_cand, pool_owner)   # mu_y of SOBER/_kernel.py:41
         p.T = None
         if corrected:
             # T = KxX @ W with KxX = k(X_nys, X_obs) (SOBER/_gp.py:293,295)
@@ -77,17 +87,29 @@ class HipOps:
             W = woodbury(spec)
             p.T = torch.empty(p.M, p.n_obs, dtype=torch.float64, device=dev)
             nat.dgemm(Kall[p.M:], W, p.T, transa=True)            # K_Xn^T W == KxX W (k symmetric)
-        # matrix-core level kernel: augmented copies of the row table and the pool
         p.da = nat.aug_dim(X_nys.shape[1]) if (p.kind != nat.KIND_TANIMOTO and self.use_mfma) else -1
-        if p.da > 0:
-            Xn64 = X_nys.to(torch.float64)
-            center = Xn64.mean(0).contiguous()                    # any shift works; this one keeps |x~| small
-            p.rows_aug = torch.empty(p.Mtot, p.da, dtype=torch.float64, device=dev)
-            p.cand_aug = torch.empty(X_cand.shape[0], p.da, dtype=torch.float64, device=dev)
-            nat.augment_points(stacked.to(torch.float64).contiguous(), spec.lengthscale, center, 0, p.rows_aug)
-            Xc = X_cand if (X_cand.dtype == torch.float64 and X_cand.stride(-1) == 1) else \
-                X_cand.to(torch.float64).contiguous()
-            nat.augment_points(Xc, spec.lengthscale, center, 1, p.cand_aug)
+
+        def pool_prep():
+            # everything that reads the candidate pool -- first touched by the first level's set sums, which the engine
+            # enqueues behind the Nystrom chain: this host work then runs beside that chain, not in front of it
+            p.cand = self._packed_pool(spec, X_cand, pool_owner)
+            p.wmul = self._pool_mean(spec, p.cand, X_cand, pool_owner) if p.weighted else None   # mu_y of SOBER/_kernel.py:41
+            # matrix-core level kernel: augmented copies of the row table and the pool
+            if p.da > 0:
+                Xn64 = X_nys.to(torch.float64)
+                center = Xn64.mean(0).contiguous()                # any shift works; this one keeps |x~| small
+                p.rows_aug = torch.empty(p.Mtot, p.da, dtype=torch.float64, device=dev)
+                p.cand_aug = torch.empty(X_cand.shape[0], p.da, dtype=torch.float64, device=dev)
+                nat.augment_points(stacked.to(torch.float64).contiguous(), spec.lengthscale, center, 0, p.rows_aug)
+                Xc = X_cand if (X_cand.dtype == torch.float64 and X_cand.stride(-1) == 1) else \
+                    X_cand.to(torch.float64).contiguous()
+                nat.augment_points(Xc, spec.lengthscale, center, 1, p.cand_aug)
+            else:
+                p.rows_aug = p.cand_aug = None
+        p._pool_prep = pool_prep
+        if os.environ.get("SOBER_EAGER_PLAN"):                    # (A/B: everything in front of the Nystrom chain)
+            p._pool_prep = None
+            pool_prep()
         p.P = None
         p.ws = {}
         return p
