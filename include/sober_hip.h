@@ -503,6 +503,22 @@ int64_t sober_rccl_allreduce_ptr(void);     /* the address of sober_rccl_allredu
 int sober_level_final(const sober_level_job* job, const void* rows_sc, const double* rows_norm, const void* cand_sc,
                       const double* cand_norm, int dt, const int32_t* idx, int R, int64_t N, int64_t row_offset,
                       double* K, double* mu_live, int64_t* out_idx, double* out_w, void* stream);
+/* sober_level_loop followed -- without going back to the host language -- by sober_level_final when the loop ends on a
+ * list of n + 1 < R <= S positions that the Caratheodory kernels of job->car_mode cover (final->done = 1: the stream
+ * has been synchronised, n_keep is in job->h_flags[S], out_idx / out_w hold the result; done = 0: nothing beyond
+ * sober_level_loop happened).  The arguments of sober_level_final travel in `final` (NULL: sober_level_loop). */
+typedef struct sober_final_job {
+    const void* rows_sc; const double* rows_norm;
+    const void* cand_sc; const double* cand_norm;
+    int32_t dt, done;
+    int64_t N, row_offset;
+    double *K, *mu_live;
+    int64_t* out_idx; double* out_w;
+} sober_final_job;
+int sober_final_job_size(void);
+int sober_level_loop_final(sober_level_job* job, sober_final_job* final, int64_t R, int32_t* idx_a, int32_t* idx_b,
+                           int first_sums_ready, void** events, int max_levels, int64_t* level_R, int32_t* n_levels,
+                           int64_t* R_final, int32_t* in_b, void* stream);
 /* P = [U diag(mean), -(U diag(mean)) T]  (s x (M + n_obs), row-major): phi(x) = P k([X_nys; X_obs], x) is the vector of
  * Nystrom test functions U C(X_nys, x) of SOBER/_rchq.py:78,148,156 with the posterior correction of SOBER/_gp.py:295
  * folded in (it is linear).  Ut: s x M; mean (M, weighted mode: SOBER/_kernel.py:41) may be NULL; T = K(X_nys, X_obs) W

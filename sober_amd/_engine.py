@@ -352,7 +352,7 @@ class RecombinationEngine:
                 and getattr(ops, "level_loop", None) is not None and ops.car_supported(S, n + 1):
             # unsharded pool, on-chip Caratheodory step: the whole loop below runs inside the level executor
             t0 = time.perf_counter()
-            idx_cur, idx_new, R = ops.level_loop(plan, idx_cur, idx_new, R, S, mu, sums_ready)
+            idx_cur, idx_new, R = ops.level_loop(plan, idx_cur, idx_new, R, S, mu, sums_ready, self.row_offset)
             pos0, count, bounds, sums_ready = 0, R, [0, R], False
             self._tick("levels_device", t0)
         elif sharded and obj is None and levels is None and not self.force_host_car and R > S \

@@ -27,6 +27,8 @@ SIGNATURES = {
     "sober_abi_version": (_i32, []),
     "sober_level_job_size": (_i32, []),
     "sober_nystrom_job_size": (_i32, []),
+    "sober_final_job_size": (_i32, []),
+    "sober_level_loop_final": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sober_padded_dim": (_i32, [_i32]),
     "sober_bit_words": (_i32, [_i32]),
     "sober_scale_points": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
@@ -123,6 +125,15 @@ LEVEL_VALU, LEVEL_MFMA, LEVEL_GATHER, LEVEL_TANI = 0, 1, 2, 3
 LEVEL_MAX_CHUNKS, LEVEL_XS, LEVEL_QUEUE = 64, 16, 24
 
 
+class FinalJob(C.Structure):
+    """struct sober_final_job of include/sober_hip.h (field for field)."""
+    _fields_ = [
+        ("rows_sc", _vp), ("rows_norm", _vp), ("cand_sc", _vp), ("cand_norm", _vp),
+        ("dt", _i32), ("done", _i32), ("N", _i64), ("row_offset", _i64),
+        ("K", _vp), ("mu_live", _vp), ("out_idx", _vp), ("out_w", _vp),
+    ]
+
+
 class NystromJob(C.Structure):
     """struct sober_nystrom_job of include/sober_hip.h (field for field)."""
     _fields_ = [
@@ -183,7 +194,8 @@ def load() -> C.CDLL:
     got = lib.sober_abi_version()
     if got != ABI_VERSION:
         raise SoberHipError(f"libsober_hip ABI {got} != expected {ABI_VERSION}; rebuild")
-    for name, cls in (("sober_level_job_size", LevelJob), ("sober_nystrom_job_size", NystromJob)):
+    for name, cls in (("sober_level_job_size", LevelJob), ("sober_nystrom_job_size", NystromJob),
+                      ("sober_final_job_size", FinalJob)):
         if getattr(lib, name)() != C.sizeof(cls):
             raise SoberHipError(f"{cls.__name__}: {C.sizeof(cls)} bytes here, {getattr(lib, name)()} in libsober_hip; "
                                 "include/sober_hip.h and sober_amd/_native.py disagree")
@@ -597,16 +609,22 @@ E_NOPROGRESS = -4
 MAX_LEVELS = 64
 
 
-def level_loop(job: LevelJob, R: int, idx_a, idx_b, first_sums_ready: bool, events, stream: int):
-    """sober_level_loop: -> (level_R list, R_final, final list is idx_b?).  events: None or a flat list of
-    4 * MAX_LEVELS hipEvent_t handles (None entries allowed)."""
+def level_loop(job: LevelJob, R: int, idx_a, idx_b, first_sums_ready: bool, events, stream: int, final: "FinalJob" = None):
+    """sober_level_loop (sober_level_loop_final with `final`: the final direct level follows in the same call when the
+    loop ends on one, final.done says so): -> (level_R list, R_final, final list is idx_b?, gave up?).  events: None
+    or a flat list of 4 * MAX_LEVELS hipEvent_t handles (None entries allowed)."""
     level_R = (_i64 * MAX_LEVELS)()
     n_levels, in_b, R_final = _i32(0), _i32(0), _i64(0)
     ev = None
     if events is not None:
         ev = (_vp * (4 * MAX_LEVELS))(*events)
-    rc = load().sober_level_loop(C.addressof(job), R, idx_a.data_ptr(), idx_b.data_ptr(), int(bool(first_sums_ready)),
-                                 ev, MAX_LEVELS, level_R, C.byref(n_levels), C.byref(R_final), C.byref(in_b), stream)
+    if final is not None:
+        rc = load().sober_level_loop_final(C.addressof(job), C.addressof(final), R, idx_a.data_ptr(), idx_b.data_ptr(),
+                                           int(bool(first_sums_ready)), ev, MAX_LEVELS, level_R, C.byref(n_levels),
+                                           C.byref(R_final), C.byref(in_b), stream)
+    else:
+        rc = load().sober_level_loop(C.addressof(job), R, idx_a.data_ptr(), idx_b.data_ptr(), int(bool(first_sums_ready)),
+                                     ev, MAX_LEVELS, level_R, C.byref(n_levels), C.byref(R_final), C.byref(in_b), stream)
     if rc == E_NOPROGRESS:
         raise RuntimeError("recombination made no progress (the Caratheodory step cancelled nothing, "
                            "SOBER/_rchq.py:241-242); the reference would loop forever here")

@@ -493,7 +493,7 @@ class HipOps:
                 job.ev[k] = None
         return p.ws["Xtr"], p.ws["tot"]
 
-    def level_loop(self, p: Plan, idx_cur, idx_new, R: int, S: int, mu, sums_ready: bool):
+    def level_loop(self, p: Plan, idx_cur, idx_new, R: int, S: int, mu, sums_ready: bool, row_offset: int = 0):
         """The whole halving loop of an unsharded pool while R > S (SOBER/_rchq.py:116-221) in ONE call of the
         level executor (csrc/level_exec.cpp: sober_level_loop) -- no trip through Python between a level's
         verdict and the next level's launches.  Returns (idx_cur, idx_new, R) for the terminal branch."""
@@ -508,7 +508,19 @@ class HipOps:
             events = [None] * (4 * nat.MAX_LEVELS)
             for l, (a, b) in enumerate(pairs):
                 events[4 * l:4 * l + 4] = [a[0].cuda_event, a[1].cuda_event, b[0].cuda_event, b[1].cuda_event]
-        level_R, R_final, in_b, gave_up = nat.level_loop(job, R, idx_cur, idx_new, sums_ready, events, nat._stream(mu))
+        # the final direct level rides in the same call when the loop ends on one (no visit to Python between the
+        # loop's synchronisation and that level's launches); level_final() then finds its result waiting
+        fin = None
+        p.ws.pop("final_done", None)
+        if not p.weighted and getattr(p, "Kmat", None) is None and self.car_mode != nat.CAR_HOST and job.car_ws \
+                and not os.environ.get("SOBER_FINAL_FROM_PYTHON"):
+            fin = self._final_job(p, S, mu, row_offset)
+        level_R, R_final, in_b, gave_up = nat.level_loop(job, R, idx_cur, idx_new, sums_ready, events, nat._stream(mu), fin)
+        if fin is not None and fin.done:
+            n_keep = int(p.ws["h_flags_np"][S])
+            if n_keep >= 0:
+                lst = idx_new if in_b else idx_cur
+                p.ws["final_done"] = (lst.data_ptr(), R_final, row_offset, p._fin_out[0][:n_keep], p._fin_out[1][:n_keep])
         if job.car_mode > min(self.car_mode, nat.CAR_SAFE):
             self._car_downgrade(nat.CAR_SAFE, "level loop")
         if gave_up:                                          # beyond the single-workgroup kernels: the host route is next
@@ -542,6 +554,18 @@ class HipOps:
             self._car_downgrade(nat.CAR_SAFE, "sharded level loop")
         return (idx_new, idx_cur, new_bounds) if in_b else (idx_cur, idx_new, new_bounds)
 
+    def _final_job(self, p: Plan, S: int, mu, row_offset: int = 0):
+        """The arguments of sober_level_final as a struct (the buffers live with the plan)."""
+        dev = self.device
+        f = nat.FinalJob()
+        f.rows_sc, f.rows_norm = p.rows.data.data_ptr(), nat._ptr(p.rows.norm)
+        f.cand_sc, f.cand_norm = p.cand.data.data_ptr(), nat._ptr(p.cand.norm)
+        f.dt, f.done, f.N, f.row_offset = p.rows.dt, 0, mu.numel(), row_offset
+        p._fin_out = (torch.empty(S, dtype=torch.int64, device=dev), torch.empty(S, dtype=torch.float64, device=dev))
+        f.K, f.mu_live = self._buf(p, "K_final", p.Mtot * S).data_ptr(), self._buf(p, "mu_live", S).data_ptr()
+        f.out_idx, f.out_w = p._fin_out[0].data_ptr(), p._fin_out[1].data_ptr()
+        return f
+
     def level_final(self, p: Plan, idx_cur, R: int, S: int, mu, row_offset: int):
         """The final direct level of an unsharded pool (n + 1 < R <= S, SOBER/_rchq.py:77-114) without leaving the
         device: one executor call, one synchronisation (for the number of survivors).  -> (idx int64, w) or None
@@ -549,6 +573,11 @@ class HipOps:
         if p.weighted or getattr(p, "Kmat", None) is not None or not nat.car_supported(R, p.n + 1) \
                 or self.car_mode == nat.CAR_HOST or (self.car_mode == nat.CAR_SAFE and not nat.car_safe_supported(R, p.n + 1)):
             return None
+        done = p.ws.pop("final_done", None)
+        if done is not None:                                 # (level_loop ran it already: mu holds the result)
+            if done[:3] != (idx_cur.data_ptr(), R, row_offset):
+                raise nat.SoberHipError("level_final: the final level that rode in level_loop was another one")
+            return done[3], done[4]
         job = self._job(p, S)
         if not job.car_ws:
             return None

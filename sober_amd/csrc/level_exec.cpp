@@ -295,6 +295,32 @@ extern "C" int sober_level_final(const sober_level_job* j, const void* rows_sc, 
     return e == hipSuccess ? 0 : (int)e;
 }
 
+extern "C" int sober_final_job_size(void) { return (int)sizeof(sober_final_job); }
+
+// The loop and the final direct level behind one call: the host language is not visited between the loop's
+// synchronisation (which tells R) and the final level's launches.
+extern "C" int sober_level_loop_final(sober_level_job* j, sober_final_job* f, int64_t R, int32_t* idx_a, int32_t* idx_b,
+                                      int first_sums_ready, void** events, int max_levels, int64_t* level_R,
+                                      int32_t* n_levels, int64_t* R_final, int32_t* in_b, void* stream) {
+    if (f) f->done = 0;
+    const int rc = sober_level_loop(j, R, idx_a, idx_b, first_sums_ready, events, max_levels, level_R, n_levels, R_final,
+                                    in_b, stream);
+    if (rc != 0 || !f) return rc;
+    const int S = j->S, n = j->n;
+    const int64_t Rf = *R_final;
+    if (Rf <= n + 1 || Rf > S) return 0;
+    if (j->car_mode != SOBER_CAR_DEFAULT && j->car_mode != SOBER_CAR_SAFE) return 0;
+    if (!sober_car_supported((int)Rf, n + 1)) return 0;
+    if (j->car_mode == SOBER_CAR_SAFE && !sober_car_safe_supported((int)Rf, n + 1)) return 0;
+    if (!f->rows_sc || !f->cand_sc || !f->K || !f->mu_live || !f->out_idx || !f->out_w) return SOBER_E_ARG;
+    LX_TRY(sober_level_final(j, f->rows_sc, f->rows_norm, f->cand_sc, f->cand_norm, f->dt, *in_b ? idx_b : idx_a, (int)Rf,
+                             f->N, f->row_offset, f->K, f->mu_live, f->out_idx, f->out_w, stream));
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    f->done = 1;
+    return 0;
+}
+
 // Two events recorded back to back on the stream: what an empty ev[0]/ev[1] bracket of sober_level_moments
 // measures (the calibration of the caller's kernel timing).
 extern "C" int sober_record_event_pair(void* ev0, void* ev1, void* stream) {
