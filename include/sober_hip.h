@@ -319,6 +319,9 @@ int sober_level_reduce_tani(const void* rows, const double* rows_norm, int n_row
                             const double* mu, const double* wmul, double outputscale, int n_chunks, double* partG,
                             int ldg, int col0, double* partTot, int64_t tot_limit, void* stream);
 
+/* *dst = v, in stream order (device memory; a one-thread kernel). */
+int sober_set_i64(int64_t* dst, int64_t v, void* stream);
+
 /* Queued-level forms (see sober_level_loop): the same kernels with the level size read from device memory.
  * sober_level_reduce_mfma_queued: leftover = 0: positions [0, *dR), set masses over [0, E S) (S = S_main);
  * leftover = 1: the leftover positions [E S_main, *dR) over S pseudo-sets.  Launch sized for count_ub positions

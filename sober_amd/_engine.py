@@ -242,18 +242,19 @@ class RecombinationEngine:
         return t1
 
     # -- Nystrom basis --------------------------------------------------------
-    def nystrom_basis(self, plan, s: int, overlap=None, literal=False):
+    def nystrom_basis(self, plan, s: int, overlap=None, literal=False, early=None):
         """-> U (s, M).  Device route when the backend has one (HipOps.nystrom_basis_device); the
         literal host route (LAPACK) otherwise or when the device route declines.  `overlap`: callable
         that enqueues device work independent of U; the device route calls it (once) while the host
-        still works on the basis.  `literal`: take the host route (it returns svd_lowrank's U itself,
-        final rotation U_B included)."""
+        still works on the basis.  `early`: the same for short device work whose result the host wants soon -- the
+        device route calls it right behind the Cholesky probes.  `literal`: take the host route (it returns
+        svd_lowrank's U itself, final rotation U_B included)."""
         if self.basis_override is not None:
             return self.basis_override
         t0 = time.perf_counter()
         dev_route = getattr(self.ops, "nystrom_basis_device", None)
         if dev_route is not None and not self.force_host_nystrom and not literal:
-            res = dev_route(plan, s, self.tm.max_iter, overlap) if overlap is not None \
+            res = dev_route(plan, s, self.tm.max_iter, overlap, early) if (overlap is not None or early is not None) \
                 else dev_route(plan, s, self.tm.max_iter)
             if res is not None:
                 U, gram = res
@@ -297,15 +298,24 @@ class RecombinationEngine:
         state = {}
         # (the list itself is requested at once, behind whatever the plan has enqueued: its count is on the host long
         #  before the first level wants it, with no synchronisation behind the Nystrom chain)
-        pending = ops.nonzero_start(mu) if getattr(ops, "nonzero_start", None) is not None and live is None \
-            and not os.environ.get("SOBER_SYNC_LIST") else None         # (the switch: A/B of the synchronised form)
+        # (requested as soon as the Cholesky probes of the device Nystrom route are enqueued -- `early` below --: its
+        #  count then reaches the host long before the first level wants it, and the host's share of it is hidden
+        #  behind the probes instead of standing in front of the whole chain)
+        can_start = getattr(ops, "nonzero_start", None) is not None and live is None \
+            and not os.environ.get("SOBER_SYNC_LIST")                   # (the switch: A/B of the synchronised form)
+        pend = {}
+
+        def start_list():
+            if can_start and "p" not in pend:
+                pend["p"] = ops.nonzero_start(mu)
         sharded = comm.world > 1 or (self.force_sharded and getattr(comm, "native_allreduce", None) is not None)
 
         def first_sums():
             if live is not None:
                 idx_cur, count = live, int(live.numel())
             else:
-                idx_cur, count = ops.nonzero_finish(pending) if pending is not None else ops.nonzero_i32(mu)
+                start_list()
+                idx_cur, count = ops.nonzero_finish(pend["p"]) if "p" in pend else ops.nonzero_i32(mu)
             #                                                idx_story = arange(N)[mu != 0]  (:63-65)
             counts = comm.allgather_counts(count)
             bounds = [0]
@@ -333,7 +343,10 @@ class RecombinationEngine:
             or not ops.car_supported(S, n_fun) or (obj is not None and getattr(ops, "car_obj_device", None) is None)
         # (sharded runs keep the collectives in one fixed order on every rank: no overlap there, the ranks'
         # Nystrom routes may differ -- each draws its own randn -- and only rank 0's result is used)
-        U = self.nystrom_basis(plan, n, overlap=head_once if comm.world == 1 else None, literal=car_on_host)
+        if comm.world > 1 or os.environ.get("SOBER_LIST_FIRST"):   # (no hook on that route; the switch: A/B)
+            start_list()
+        U = self.nystrom_basis(plan, n, overlap=head_once if comm.world == 1 else None, literal=car_on_host,
+                               early=start_list if comm.world == 1 else None)
         if comm.world > 1:                                  # rank 0's randn draw is the one that counts
             U = comm.broadcast0(ops.from_host(U.contiguous()) if U.device != ops.device else U.contiguous())
             if hasattr(plan, "_proj_src"):

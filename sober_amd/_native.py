@@ -28,6 +28,7 @@ SIGNATURES = {
     "sober_level_job_size": (_i32, []),
     "sober_nystrom_job_size": (_i32, []),
     "sober_final_job_size": (_i32, []),
+    "sober_set_i64": (_i32, [_vp, _i64, _vp]),
     "sober_level_loop_final": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sober_padded_dim": (_i32, [_i32]),
     "sober_bit_words": (_i32, [_i32]),

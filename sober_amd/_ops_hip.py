@@ -190,7 +190,7 @@ class HipOps:
     # ------------------------------------------------------------------ Nystrom basis on the device
     NITER = 2                    # torch.svd_lowrank's default number of power iterations
 
-    def nystrom_basis_device(self, p: Plan, s: int, max_iter: int = 10, overlap=None):
+    def nystrom_basis_device(self, p: Plan, s: int, max_iter: int = 10, overlap=None, early=None):
         """ker_svd_sparsify (SOBER/_rchq.py:34-39) with the N_nys x N_nys work on the GPU, no host decision inside, the
         whole chain behind ONE native call (csrc/nystrom_exec.cpp: sober_nystrom_basis):
           make_cov_psd: |cov| and the symmetry test in one kernel; every rung of the jitter ladder probed by one
@@ -268,6 +268,8 @@ class HipOps:
         # reference too: make_cov_psd draws nothing); should the host route have to decide, the generator is put back
         stream = torch.cuda.current_stream(dev)
         nat.nystrom_basis(j, 1, stream.cuda_stream)         # the probes run while the host steps its generator
+        if early is not None:
+            early()                                         # (short device work whose result the host wants soon)
         rng_state = torch.get_rng_state()
         R = _rng.device_randn(M, s, dev)
         j.R = R.data_ptr()

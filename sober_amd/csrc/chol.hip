@@ -885,6 +885,14 @@ __global__ void k_jitter_ladder_auto(double* __restrict__ A, int n, int ld, cons
 
 }  // namespace sober
 
+namespace sober {
+__global__ void k_probe_mc_init(uint32_t* __restrict__ ws, int64_t n_words, int32_t* __restrict__ info, int n_info, int32_t value) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_words) ws[t] = 0u;
+    if (t < n_info) info[t] = value;
+}
+}  // namespace sober
+
 extern "C" int sober_chol_max_n(void) { return sober::CH_MAXN; }
 
 extern "C" int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
@@ -990,10 +998,12 @@ extern "C" int sober_cholesky_probe_mc(const double* src, int n, int ld_src, con
                                     160 * 1024 - 512));
         sober_attr_done(attr_set);
     }
-    HIP_TRY(hipMemsetAsync(ws, 0, (size_t)flags, (hipStream_t)stream));
-    // every rung starts as "no verdict": a rung that finds no workgroups at all (a device whose XCC ids do not run over
-    // 0..7, e.g. a partitioned one) must not read as info = 0
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)info, sober::CM_INFO_EXCHANGE, (size_t)n_shifts, (hipStream_t)stream));
+    // the flag area zeroed, and every rung starts as "no verdict": a rung that finds no workgroups at all (a device
+    // whose XCC ids do not run over 0..7, e.g. a partitioned one) must not read as info = 0 -- ONE launch (the two
+    // memsets this replaces were four fill kernels and 35 us of a host-paced stream in front of the probe)
+    hipLaunchKernelGGL(sober::k_probe_mc_init, dim3((unsigned)((flags / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (uint32_t*)ws, (int64_t)(flags / 4), info, n_shifts, (int32_t)sober::CM_INFO_EXCHANGE);
+    LAUNCH_CHECK();
     // one workgroup per CU (the LDS request sees to that), 32 per XCD: 16 of them find a seat (two rungs x CM_G)
     const size_t lds_bytes = bytes > (size_t)84 * 1024 ? bytes : (size_t)84 * 1024;
     hipLaunchKernelGGL(sober::k_chol_mc, dim3(256), dim3(sober::CH_T), lds_bytes, (hipStream_t)stream, work, n, n, info,

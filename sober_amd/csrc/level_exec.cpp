@@ -150,9 +150,8 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
     if (L < 2) return 0;                                                // nothing to gain: the synchronised loop
     if (!sober_car_supported(S, b)) return SOBER_E_DIM;
     hipStream_t st = (hipStream_t)stream;
-    j->h_dR[0] = R0;
-    hipError_t e = hipMemcpyAsync(j->dR, j->h_dR, sizeof(int64_t), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return (int)e;
+    LX_TRY(sober_set_i64(j->dR, R0, stream));
+    hipError_t e = hipSuccess;
     for (int l = 0; l < L; ++l) {
         int32_t* cur = (l & 1) ? idx_b : idx_a;
         int32_t* nxt = (l & 1) ? idx_a : idx_b;
@@ -283,8 +282,7 @@ extern "C" int sober_level_final(const sober_level_job* j, const void* rows_sc, 
     if (!sober_car_supported(R, n + 1)) return SOBER_E_DIM;
     LX_TRY(sober_pairwise(j->kind, rows_sc, rows_norm, j->n_rows, cand_sc, cand_norm, idx, R, dt, j->outputscale, K, R,
                           stream));                                                  // kernel(pt_nys, samp[idx])  (:78)
-    LX_TRY(sober_dgemm(0, 0, n, R, j->n_rows, 1.0, j->P, j->n_rows, K, R, 0.0, j->Xtr, R, stream));
-    LX_TRY(sober_barycentres(j->Xtr, R, n, R, nullptr, j->X_tmp, stream));          // (U K)^T, no division
+    LX_TRY(sober_dgemm_coldiv_t(n, R, j->n_rows, j->P, j->n_rows, K, R, nullptr, j->X_tmp, n, stream));   // (U K)^T, no division
     LX_TRY(sober_gather_f64(j->mu, idx, R, mu_live, stream));                       // :84
     LX_TRY(sober_car_device_ex(j->X_tmp, n, R, n + 1, mu_live, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
                                nullptr, j->car_ws, j->car_ws_bytes, j->car_mode, stream));   // :85

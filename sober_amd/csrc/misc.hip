@@ -624,6 +624,17 @@ extern "C" int sober_final_scatter(const int32_t* idx, int n, const int32_t* kee
     return 0;
 }
 
+__global__ void k_set_i64(int64_t* dst, int64_t v) { *dst = v; }
+
+// *dst = v on the stream, as a one-thread kernel: a hipMemcpyAsync of 8 host bytes goes through the copy path and
+// holds the stream for ~20 us in front of the first queued level
+extern "C" int sober_set_i64(int64_t* dst, int64_t v, void* stream) {
+    if (!dst) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, v);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sober_final_commit(const int32_t* idx, int n, const int32_t* keep_rank, const double* w_star,
                                   const int32_t* n_keep, int64_t row_offset, double* mu, int64_t N, int64_t* out_idx,
                                   double* out_w, void* stream) {
