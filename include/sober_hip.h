@@ -506,6 +506,16 @@ int64_t sober_rccl_allreduce_ptr(void);     /* the address of sober_rccl_allredu
 int sober_level_final(const sober_level_job* job, const void* rows_sc, const double* rows_norm, const void* cand_sc,
                       const double* cand_norm, int dt, const int32_t* idx, int R, int64_t N, int64_t row_offset,
                       double* K, double* mu_live, int64_t* out_idx, double* out_w, void* stream);
+/* The row table's side of a step's plan in one call (RBF / Matern-5/2): rows = [X_nys; X_obs] / lengthscale
+ * ((M + n_obs) x dt, dt = padded dimension of sober_scale_points), Kall = k(rows, X_nys) ((M + n_obs) x M),
+ * W = S_cache S_cache^T (SOBER/_gp.py:277), T = K(X_nys, X_obs) W (M x n_obs, SOBER/_gp.py:293-295) and the Gram matrix
+ * of SOBER/_rchq.py:35, G = K(X_nys, X_nys) - T K(X_obs, X_nys) (M x M).  n_obs = 0 (mode "kernel"): rows and
+ * G = k(X_nys, X_nys); X_obs, S_cache, Kall, W, T may then be NULL. */
+int sober_plan_rows(int kind, const double* X_nys, int M, int64_t ld_nys, const double* X_obs, int n_obs,
+                    int64_t ld_obs, int d, const double* lengthscale, int ls_len, double outputscale,
+                    const double* S_cache, int ld_s, double* rows, int dt, double* Kall, double* W, double* T,
+                    double* G, void* stream);
+
 /* sober_level_loop followed -- without going back to the host language -- by sober_level_final when the loop ends on a
  * list of n + 1 < R <= S positions that the Caratheodory kernels of job->car_mode cover (final->done = 1: the stream
  * has been synchronised, n_keep is in job->h_flags[S], out_idx / out_w hold the result; done = 0: nothing beyond

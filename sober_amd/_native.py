@@ -29,6 +29,8 @@ SIGNATURES = {
     "sober_nystrom_job_size": (_i32, []),
     "sober_final_job_size": (_i32, []),
     "sober_set_i64": (_i32, [_vp, _i64, _vp]),
+    "sober_plan_rows": (_i32, [_i32, _vp, _i32, _i64, _vp, _i32, _i64, _i32, _vp, _i32, _f64, _vp, _i32, _vp, _i32, _vp,
+                               _vp, _vp, _vp, _vp]),
     "sober_level_loop_final": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sober_padded_dim": (_i32, [_i32]),
     "sober_bit_words": (_i32, [_i32]),
@@ -298,6 +300,20 @@ def pack_bits(X, words, norms, bad_flag):
     _req(bad_flag, torch.int32, "bad_flag")
     _check(load().sober_pack_bits(X.data_ptr(), n, d, X.stride(0), words.data_ptr(), words.shape[1],
                                   norms.data_ptr(), bad_flag.data_ptr(), _stream(X)), "sober_pack_bits")
+
+
+def plan_rows(kind, X_nys, X_obs, lengthscale, outputscale, S_cache, rows, Kall, W, T, G):
+    """sober_plan_rows: the row table, Kall, W, T and the Gram matrix of a step in one call (X_obs None: mode "kernel")."""
+    M, d = X_nys.shape
+    n_obs = 0 if X_obs is None else X_obs.shape[0]
+    for t in (X_nys, X_obs, S_cache, rows, Kall, W, T, G):
+        if t is not None and (t.dtype != torch.float64 or t.stride(-1) != 1):
+            raise SoberHipError("plan_rows: float64 tensors with unit inner stride")
+    _check(load().sober_plan_rows(kind, X_nys.data_ptr(), M, X_nys.stride(0), _ptr(X_obs), n_obs,
+                                  X_obs.stride(0) if X_obs is not None else 0, d, lengthscale.data_ptr(),
+                                  lengthscale.numel(), float(outputscale), _ptr(S_cache),
+                                  S_cache.stride(0) if S_cache is not None else 0, rows.data_ptr(), rows.shape[1],
+                                  _ptr(Kall), _ptr(W), _ptr(T), G.data_ptr(), _stream(G)), "sober_plan_rows")
 
 
 def pairwise(kind, a, a_norm, b, b_norm, idx, n, dt, outputscale, out):

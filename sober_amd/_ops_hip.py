@@ -69,24 +69,49 @@ class HipOps:
         dev = self.device
         corrected = mode != "kernel"
         p.n_obs = spec.X_obs.shape[0] if corrected else 0
-        stacked = torch.cat([X_nys.to(torch.float64), spec.X_obs], 0) if corrected else X_nys
-        p.rows = prepare_points(spec, stacked)                    # [X_nys; X_obs]
-        p.Mtot = len(p.rows)
         p.weighted = mode == "weighted_predictive_covariance"
         p.mean_nys = None
-        if p.weighted:
-            p.mean_nys = posterior_mean(spec, p.rows.rows(0, p.M))
         p.T = None
-        if corrected:
-            # T = KxX @ W with KxX = k(X_nys, X_obs) (SOBER/_gp.py:293,295)
-            Kall = torch.empty(p.Mtot, p.M, dtype=torch.float64, device=dev)
-            nys = p.rows.rows(0, p.M)
-            nat.pairwise(p.kind, p.rows.data, p.rows.norm, nys.data, nys.norm, None, p.M, p.rows.dt,
-                         spec.outputscale, Kall)
-            p.Kall = Kall
-            W = woodbury(spec)
-            p.T = torch.empty(p.M, p.n_obs, dtype=torch.float64, device=dev)
-            nat.dgemm(Kall[p.M:], W, p.T, transa=True)            # K_Xn^T W == KxX W (k symmetric)
+        Xn64 = X_nys.to(torch.float64)
+        native_rows = (p.kind != nat.KIND_TANIMOTO and not p.weighted and Xn64.stride(-1) == 1
+                       and not os.environ.get("SOBER_PLAN_FROM_PYTHON")
+                       and (not corrected or (spec.X_obs.dtype == torch.float64 and spec.X_obs.stride(-1) == 1
+                                              and spec.S_cache.dtype == torch.float64 and spec.S_cache.stride(-1) == 1)))
+        if native_rows:
+            # the row table, Kall, W, T and the Gram matrix behind ONE native call (csrc/nystrom_exec.cpp: sober_plan_rows)
+            f64 = torch.float64
+            p.Mtot = p.M + p.n_obs
+            dt = nat.padded_dim(X_nys.shape[1], generic=True)
+            rows = torch.empty(p.Mtot, dt, dtype=f64, device=dev)
+            G = torch.empty(p.M, p.M, dtype=f64, device=dev)
+            Kall = W = T = None
+            if corrected:
+                Kall = torch.empty(p.Mtot, p.M, dtype=f64, device=dev)
+                W = torch.empty(p.n_obs, p.n_obs, dtype=f64, device=dev)
+                T = torch.empty(p.M, p.n_obs, dtype=f64, device=dev)
+            nat.plan_rows(p.kind, Xn64, spec.X_obs if corrected else None, spec.lengthscale, spec.outputscale,
+                          spec.S_cache if corrected else None, rows, Kall, W, T, G)
+            p.rows = PointSet(rows, None, dt)
+            p.T, p._gram = T, G
+            if corrected:
+                p.Kall = Kall
+            stacked = None                                        # (built by pool_prep, where the augmented rows want it)
+        else:
+            stacked = torch.cat([Xn64, spec.X_obs], 0) if corrected else X_nys
+            p.rows = prepare_points(spec, stacked)                # [X_nys; X_obs]
+            p.Mtot = len(p.rows)
+            if p.weighted:
+                p.mean_nys = posterior_mean(spec, p.rows.rows(0, p.M))
+            if corrected:
+                # T = KxX @ W with KxX = k(X_nys, X_obs) (SOBER/_gp.py:293,295)
+                Kall = torch.empty(p.Mtot, p.M, dtype=torch.float64, device=dev)
+                nys = p.rows.rows(0, p.M)
+                nat.pairwise(p.kind, p.rows.data, p.rows.norm, nys.data, nys.norm, None, p.M, p.rows.dt,
+                             spec.outputscale, Kall)
+                p.Kall = Kall
+                W = woodbury(spec)
+                p.T = torch.empty(p.M, p.n_obs, dtype=torch.float64, device=dev)
+                nat.dgemm(Kall[p.M:], W, p.T, transa=True)        # K_Xn^T W == KxX W (k symmetric)
         p.da = nat.aug_dim(X_nys.shape[1]) if (p.kind != nat.KIND_TANIMOTO and self.use_mfma) else -1
 
         def pool_prep():
@@ -96,11 +121,11 @@ class HipOps:
             p.wmul = self._pool_mean(spec, p.cand, X_cand, pool_owner) if p.weighted else None   # mu_y of SOBER/_kernel.py:41
             # matrix-core level kernel: augmented copies of the row table and the pool
             if p.da > 0:
-                Xn64 = X_nys.to(torch.float64)
+                st = stacked if stacked is not None else (torch.cat([Xn64, spec.X_obs], 0) if corrected else Xn64)
                 center = Xn64.mean(0).contiguous()                # any shift works; this one keeps |x~| small
                 p.rows_aug = torch.empty(p.Mtot, p.da, dtype=torch.float64, device=dev)
                 p.cand_aug = torch.empty(X_cand.shape[0], p.da, dtype=torch.float64, device=dev)
-                nat.augment_points(stacked.to(torch.float64).contiguous(), spec.lengthscale, center, 0, p.rows_aug)
+                nat.augment_points(st.to(torch.float64).contiguous(), spec.lengthscale, center, 0, p.rows_aug)
                 Xc = X_cand if (X_cand.dtype == torch.float64 and X_cand.stride(-1) == 1) else \
                     X_cand.to(torch.float64).contiguous()
                 nat.augment_points(Xc, spec.lengthscale, center, 1, p.cand_aug)
@@ -162,6 +187,10 @@ class HipOps:
     def gram(self, p: Plan):
         """kernel(pt, pt) of SOBER/_rchq.py:35 for the plan's mode."""
         dev = self.device
+        G = getattr(p, "_gram", None)
+        if G is not None:                                         # (sober_plan_rows computed it with the row table)
+            p._gram = None
+            return G
         if p.T is None:
             nys = p.rows
             G = torch.empty(p.M, p.M, dtype=torch.float64, device=dev)

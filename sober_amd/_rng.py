@@ -66,10 +66,27 @@ def device_randn(M: int, q: int, device):
             ev.synchronize()
     nat.mt19937_uniform53(state, numel, u)
     torch.set_rng_state(state)
-    ud = u.to(device, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(device))
+    # the upload travels on a stream of its own: on the caller's stream it would queue behind whatever is running
+    # there (the Cholesky probes of the Nystrom chain) and the 0.4 MB would cross the bus only afterwards
+    main = torch.cuda.current_stream(device)
+    side = _pin.get(("stream", device))
+    if side is None:
+        side = _pin[("stream", device)] = torch.cuda.Stream(device)
+    ud = _pin.get(("dev", numel, device))
+    if ud is None:
+        ud = _pin[("dev", numel, device)] = torch.empty(numel + 16, dtype=torch.float64, device=device)
+    used = _pin.get(("used", numel, device))
+    if used is not None:
+        side.wait_event(used)                                  # (the previous Box-Muller pass has read `ud`)
+    with torch.cuda.stream(side):
+        ud.copy_(u, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
     _pin[("ev", numel)] = ev
+    main.wait_event(ev)
     R = torch.empty(M, q, dtype=torch.float64, device=device)
     nat.box_muller(ud, numel, R)
+    used = torch.cuda.Event()
+    used.record(main)
+    _pin[("used", numel, device)] = used
     return R

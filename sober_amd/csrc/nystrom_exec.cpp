@@ -96,3 +96,27 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
                           hipMemcpyDeviceToHost, st));
     return 0;
 }
+
+// ---- the ROW TABLE's side of a step's plan behind one call (continuous kernels) -----------------------------------------
+// rows = [X_nys; X_obs] / lengthscale (two launches into one table: no concatenated copy), Kall = k(rows, X_nys)
+// ((M + n_obs) x M), W = S S^T (SOBER/_gp.py:277), T = K(X_nys, X_obs) W (M x n_obs; SOBER/_gp.py:293,295) and the Gram
+// matrix of SOBER/_rchq.py:35, G = K(X_nys, X_nys) - T K(X_obs, X_nys), in the reference's association order.  With
+// n_obs = 0 (mode "kernel"): rows and G = k(X_nys, X_nys) only.  The same launches the host language used to issue one
+// by one (~130 us of a host-paced stream in front of the Nystrom chain), same order, same bits.
+extern "C" int sober_plan_rows(int kind, const double* X_nys, int M, int64_t ld_nys, const double* X_obs, int n_obs,
+                               int64_t ld_obs, int d, const double* lengthscale, int ls_len, double outputscale,
+                               const double* S_cache, int ld_s, double* rows, int dt, double* Kall, double* W, double* T,
+                               double* G, void* stream) {
+    if (!X_nys || !lengthscale || !rows || !G || M <= 0 || d <= 0 || n_obs < 0 || dt < d) return SOBER_E_ARG;
+    if (kind != SOBER_KIND_RBF && kind != SOBER_KIND_MATERN52) return SOBER_E_ARG;
+    NX_TRY(sober_scale_points(X_nys, M, d, ld_nys, lengthscale, ls_len, rows, dt, stream));
+    if (n_obs == 0) return sober_pairwise(kind, rows, nullptr, M, rows, nullptr, nullptr, M, dt, outputscale, G, M, stream);
+    if (!X_obs || !S_cache || !Kall || !W || !T || ld_s < n_obs) return SOBER_E_ARG;
+    NX_TRY(sober_scale_points(X_obs, n_obs, d, ld_obs, lengthscale, ls_len, rows + (size_t)M * dt, dt, stream));
+    NX_TRY(sober_pairwise(kind, rows, nullptr, (int64_t)M + n_obs, rows, nullptr, nullptr, M, dt, outputscale, Kall, M, stream));
+    NX_TRY(sober_dgemm(0, 1, n_obs, n_obs, n_obs, 1.0, S_cache, ld_s, S_cache, ld_s, 0.0, W, n_obs, stream));
+    const double* KXn = Kall + (size_t)M * M;                              // k(X_obs, X_nys), n_obs x M
+    NX_TRY(sober_dgemm(1, 0, M, n_obs, n_obs, 1.0, KXn, M, W, n_obs, 0.0, T, n_obs, stream));
+    NX_HIP(hipMemcpyAsync(G, Kall, sizeof(double) * (size_t)M * M, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return sober_dgemm(0, 0, M, M, n_obs, -1.0, T, n_obs, KXn, M, 1.0, G, M, stream);
+}
