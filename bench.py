@@ -83,6 +83,16 @@ def pmc_traffic(config):
     return (d["bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if d else (None, None)
 
 
+def allreduce_route():
+    """Which all-reduce the sharded level loop used in this process (sober_amd/_engine.py: DistComm.native_allreduce)."""
+    from sober_amd._engine import DistComm
+    if any(pc not in (None, False) for pc in DistComm._PEER.values()):
+        return "one-shot direct-peer kernel, sums in rank order: csrc/peer_reduce.hip"
+    if any(rc not in (None, False) for rc in DistComm._RCCL.values()):
+        return "ncclAllReduce issued from C: csrc/rccl_link.cpp"
+    return "the group's own all_reduce"
+
+
 def host_cpu():
     model = None
     try:
@@ -389,7 +399,7 @@ def main():
         "dtype": "u64" if cfg["kind"] == "tanimoto" else "f64", "data": "synthetic",
         "config": {"workload": f"{cfg['name']}, N_rec={N_loc} per GPU ({N_total} in all), N_nys={cfg['M']}, "
                                f"batch={cfg['b']}, n_obs={cfg['n_obs']} (BASELINE.json configs[{args.config - 1}])",
-                   "parallelism": f"pool row-sharded x{world}, one all-reduce of (n*S+S) f64 per level"
+                   "parallelism": f"pool row-sharded x{world}, one all-reduce of (n*S+S) f64 per level ({allreduce_route()})"
                                   if world > 1 else "single GPU"},
         "roofline": roofline,
         "hbm": hbm,

@@ -497,6 +497,25 @@ int sober_rccl_comm_destroy(void* comm);
 int sober_rccl_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
 int64_t sober_rccl_allreduce_ptr(void);     /* the address of sober_rccl_allreduce_f64, as an integer */
 
+/* One-shot direct-peer all-reduce (csrc/peer_reduce.hip): every rank owns an exchange region in its own
+ * memory, maps its peers' regions (IPC handles between processes: sober_peer_create hands out the 64-byte handle of
+ * mine, sober_peer_connect takes all `world` of them in rank order; sober_peer_connect_ptrs: plain device pointers,
+ * ranks inside one process) and a call is ONE kernel per rank that publishes its message, waits for the peers' flags
+ * (bounded) and sums the `world` contributions in RANK ORDER -- the same bits on every rank, no ring steps.
+ * sober_peer_allreduce_f64 is a sober_allreduce_fn (n <= n_max doubles).  sober_peer_status, after the stream has been
+ * synchronised: 0, or SOBER_E_EXCHANGE when a wait ran out (a rank that never arrived) -- the rank's own message of
+ * that call is then copied back to `restore` (n doubles; may be NULL). */
+int64_t sober_peer_region_bytes(int64_t n_max);
+int sober_peer_create(int rank, int world, int64_t n_max, void** comm, char* handle64);
+int sober_peer_connect(void* comm, const char* handles);
+int sober_peer_connect_ptrs(void* comm, void* const* regions);
+int64_t sober_peer_region(void* comm);      /* the address of my region, as an integer */
+int sober_peer_set_spin_limit(void* comm, unsigned spin_limit);
+int sober_peer_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
+int64_t sober_peer_allreduce_ptr(void);      /* the address of sober_peer_allreduce_f64, as an integer */
+int sober_peer_status(void* comm, double* restore, int64_t n, void* stream);
+int sober_peer_destroy(void* comm);
+
 /* The final direct level of an unsharded pool (n + 1 < R <= S, SOBER/_rchq.py:77-114) in one call: kernel columns of
  * the R live candidates (sober_pairwise on the SCALED points rows_sc / cand_sc, dt doubles or words per row), P K,
  * transpose, their weights, the Caratheodory step, mu[0:N] = 0 and the device-side write-back.  K: n_rows x R scratch,

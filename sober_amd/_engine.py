@@ -88,6 +88,7 @@ class DistComm:
         return t
 
     _RCCL = {}          # one RCCL communicator of our own per torch.distributed group
+    _PEER = {}          # one direct-peer exchange (csrc/peer_reduce.hip) per group, sized for the largest message so far
 
     def native_allreduce(self, flat: torch.Tensor, device):
         """-> (address of a sober_allreduce_fn, communicator pointer, keep-alive) for the level executor's sharded
@@ -95,8 +96,28 @@ class DistComm:
         one-GPU tests): a callback into this group's all_reduce on the flat buffer -- correct, not fast."""
         import ctypes as C
         dist, group = self.dist, self.group
+        key = id(group) if group is not None else 0
+        peer_mode = os.environ.get("SOBER_PEER_ALLREDUCE", "1")     # "0": never; "force": also over a non-nccl group (tests)
+        if (dist.get_backend(group) == "nccl" and peer_mode != "0") or peer_mode == "force":
+            # SURVEY.md 8e: the one-shot direct-peer all-reduce (every rank reads its peers' messages over xGMI and sums
+            # in rank order: deterministic, one kernel) first; it checks itself on every rank when it is set up, and the
+            # group falls back to RCCL together when the node does not support it (SOBER_PEER_ALLREDUCE=0: never tried)
+            pc = DistComm._PEER.get(key)
+            if pc is None or (pc is not False and pc.n_max < flat.numel()):
+                if pc:
+                    pc.close()
+                try:
+                    pc = nat.PeerComm(dist, group, device, max(int(flat.numel()), 1 << 15))
+                    if pc.ok:
+                        pc.self_check(dist, group)
+                    if not pc.ok:
+                        pc = False
+                except Exception:
+                    pc = False
+                DistComm._PEER[key] = pc
+            if pc is not False:
+                return pc.fn_ptr, pc.handle, pc
         if dist.get_backend(group) == "nccl":
-            key = id(group) if group is not None else 0
             rc = DistComm._RCCL.get(key)
             if rc is None:
                 try:

@@ -107,6 +107,16 @@ SIGNATURES = {
     "sober_rccl_comm_destroy": (_i32, [_vp]),
     "sober_rccl_allreduce_f64": (_i32, [_vp, _vp, _i64, _vp]),
     "sober_rccl_allreduce_ptr": (_i64, []),
+    "sober_peer_region_bytes": (_i64, [_i64]),
+    "sober_peer_create": (_i32, [_i32, _i32, _i64, _vp, _vp]),
+    "sober_peer_connect": (_i32, [_vp, C.c_char_p]),
+    "sober_peer_connect_ptrs": (_i32, [_vp, _vp]),
+    "sober_peer_region": (_i64, [_vp]),
+    "sober_peer_set_spin_limit": (_i32, [_vp, C.c_uint]),
+    "sober_peer_allreduce_f64": (_i32, [_vp, _vp, _i64, _vp]),
+    "sober_peer_allreduce_ptr": (_i64, []),
+    "sober_peer_status": (_i32, [_vp, _vp, _i64, _vp]),
+    "sober_peer_destroy": (_i32, [_vp]),
     "sober_level_reduce_mfma_queued": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _f64,
                                               _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_level_reduce_mfma_queued_pair": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _f64, _i32,
@@ -698,6 +708,83 @@ class RcclComm:
     def close(self):
         if self.handle:
             load().sober_rccl_comm_destroy(self.handle)
+            self.handle = _vp()
+
+
+class PeerComm:
+    """The one-shot direct-peer all-reduce of csrc/peer_reduce.hip over the ranks of a torch.distributed group (one
+    process per GPU of ONE node): every rank creates its exchange region, the group's own all-gather carries the IPC
+    handles, every rank maps the others' regions.  `self_check` runs a few calls with known data on every rank and
+    lets the group agree on the verdict -- a node where peer mapping or cross-process visibility does not work ends
+    up on the RCCL route instead."""
+
+    def __init__(self, dist, group, device, n_max: int):
+        import torch as _t
+        lib = load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n_max, self.device, self.handle = int(n_max), device, _vp()
+        self.fn_ptr = lib.sober_peer_allreduce_ptr()
+        on_dev = dist.get_backend(group) == "nccl"
+        hbuf = (C.c_char * 64)()
+        with _t.cuda.device(device):
+            rc = lib.sober_peer_create(self.rank, self.world, self.n_max, C.byref(self.handle), C.addressof(hbuf))
+        mine = _t.frombuffer(bytearray(hbuf.raw), dtype=_t.uint8).clone()
+        mine = _t.cat([mine, _t.tensor([0 if rc == 0 else 1], dtype=_t.uint8)])        # handle + "my create failed"
+        mine = mine.to(device) if on_dev else mine
+        outs = [_t.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(outs, mine, group=group)
+        outs = [o.cpu() for o in outs]
+        ok = rc == 0 and all(int(o[64]) == 0 for o in outs)
+        if ok:
+            allh = b"".join(bytes(o[:64].numpy().tobytes()) for o in outs)
+            with _t.cuda.device(device):
+                ok = lib.sober_peer_connect(self.handle, allh) == 0
+        self.ok = self._agree(dist, group, on_dev, ok)
+        if not self.ok:
+            self.close()
+
+    def _agree(self, dist, group, on_dev, ok: bool) -> bool:
+        import torch as _t
+        t = _t.tensor([1 if ok else 0], dtype=_t.int32)
+        t = t.to(self.device) if on_dev else t
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()) == 1)
+
+    def allreduce(self, buf, stream: int):
+        _check(load().sober_peer_allreduce_f64(self.handle, buf.data_ptr(), buf.numel(), stream), "sober_peer_allreduce_f64")
+
+    def status(self) -> int:
+        return int(load().sober_peer_status(self.handle, None, 0, None))
+
+    def self_check(self, dist, group) -> bool:
+        """Four calls with rank- and round-dependent data, short waits; every rank must see the exact sums."""
+        import torch as _t
+        lib = load()
+        on_dev = dist.get_backend(group) == "nccl"
+        ok = True
+        try:
+            with _t.cuda.device(self.device):
+                lib.sober_peer_set_spin_limit(self.handle, 1 << 21)
+                n = min(self.n_max, 4096)
+                base = _t.arange(n, dtype=_t.float64, device=self.device)
+                st = _t.cuda.current_stream(self.device)
+                for rnd in range(4):
+                    x = (base + rnd) * float(self.rank + 1)
+                    self.allreduce(x, st.cuda_stream)
+                    st.synchronize()
+                    want = (base + rnd) * float(self.world * (self.world + 1) // 2)
+                    ok = ok and self.status() == 0 and bool(_t.equal(x, want))
+                lib.sober_peer_set_spin_limit(self.handle, 1 << 23)
+        except Exception:
+            ok = False
+        self.ok = self._agree(dist, group, on_dev, ok)
+        if not self.ok:
+            self.close()
+        return self.ok
+
+    def close(self):
+        if self.handle:
+            load().sober_peer_destroy(self.handle)
             self.handle = _vp()
 
 

@@ -375,6 +375,12 @@ extern "C" int sober_level_loop_sharded(sober_level_job* j, int rank, int world,
         LX_TRY(sober_level_car(j, stream));
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) return (int)e;
+        if ((void*)allreduce == (void*)&sober_peer_allreduce_f64 && comm) {
+            // the direct-peer all-reduce reports a rank that never arrived here, after the synchronisation (the list and
+            // the weights are still those of this level)
+            const int prc = sober_peer_status(comm, nullptr, 0, stream);
+            if (prc != 0) { *n_levels = levels; *in_b = (cur == idx_b) ? 1 : 0; j->phase = 0; return prc; }
+        }
         if (j->h_flags[S] < 0) {                                            // (a rank-local event: the redone step gives
             const int rc = sober_level_car_retry(j, stream);                    //  this rank the other ranks' verdict; beyond
             if (rc != 0) { *n_levels = levels; *in_b = (cur == idx_b) ? 1 : 0; j->phase = 0; return rc; }   //  the safe sizes the run ends here)
