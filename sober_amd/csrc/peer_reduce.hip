@@ -181,11 +181,13 @@ extern "C" int sober_peer_allreduce_f64(void* comm, double* buf, int64_t n, void
 extern "C" int64_t sober_peer_allreduce_ptr(void) { return (int64_t)(intptr_t)&sober_peer_allreduce_f64; }
 
 // after a synchronisation of the stream: 0 = every call so far met all its peers; SOBER_E_EXCHANGE = a wait ran out
-// (the rank's own contribution of the failed call is still in its slot: *restore != NULL gets it back, n doubles)
+// (the rank's own contribution of the failed call is still in its slot: *restore != NULL gets it back, n doubles);
+// the error is reported once
 extern "C" int sober_peer_status(void* comm, double* restore, int64_t n, void* stream) {
     PeerComm* c = (PeerComm*)comm;
     if (!c) return SOBER_E_ARG;
     if (*(volatile unsigned*)c->h_err == 0u) return 0;
+    *(volatile unsigned*)c->h_err = 0u;                                // (reported once; the flags themselves stay consistent)
     if (restore && n > 0 && n <= c->n_max) {
         const double* slot = (const double*)(c->mine + sober::PEER_HDR) + (size_t)(c->epoch & 1u) * (size_t)c->n_max;
         HIP_TRY(hipMemcpyAsync(restore, slot, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream));

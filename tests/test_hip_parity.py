@@ -1621,9 +1621,27 @@ def test_peer_allreduce_virtual_ranks_one_process(dev):
     regions = (C.c_void_p * W)(*[lib.sober_peer_region(c) for c in comms])
     for r in range(W):
         assert lib.sober_peer_connect_ptrs(comms[r], regions) == 0
-    streams = [torch.cuda.Stream(dev) for _ in range(W)]
     g = torch.Generator().manual_seed(3)
     try:
+        # the three kernels of a call wait for each other: they need three streams that the runtime has put on three
+        # different hardware queues (it multiplexes streams onto a handful of them) -- found by a short handshake
+        streams = None
+        for c in comms:
+            lib.sober_peer_set_spin_limit(c, 1 << 14)
+        for attempt in range(8):
+            cand = [torch.cuda.Stream(dev) for _ in range(W)]
+            xs = [torch.ones(8, dtype=torch.float64, device=dev) for _ in range(W)]
+            torch.cuda.synchronize()
+            for r in range(W):
+                assert lib.sober_peer_allreduce_f64(comms[r], xs[r].data_ptr(), 8, cand[r].cuda_stream) == 0
+            torch.cuda.synchronize()
+            if all(lib.sober_peer_status(comms[r], None, 0, None) == 0 for r in range(W)):
+                streams = cand
+                break
+        if streams is None:
+            pytest.skip("no three streams on three hardware queues in this process")
+        for c in comms:
+            lib.sober_peer_set_spin_limit(c, 1 << 23)
         for n in (7, 1024, 31999, 158400, 200000, 5):
             xs = [torch.randn(n, generator=g, dtype=torch.float64).to(dev) for _ in range(W)]
             want = (0.0 + xs[0]) + xs[1]
