@@ -1,0 +1,42 @@
+"""When every pivot of k_car_pivot_stream is published (diagnostic build -DSP_TSTAMPS: make -C sober_amd/csrc
+BUILD=build_sps EXTRA=-DSP_TSTAMPS OUT=build_sps/libsober_hip_sps.so), on the reference's level-0 input of the
+matern_medium golden (N = 200, m = 100): microseconds between consecutive publishes, in-block pivots against the first pivot
+of a block (the hand-over from the wave before)."""
+import ctypes as C, numpy as np, torch, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sober_amd import _native as nat
+dev = torch.device("cuda:0")
+z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "recomb_matern_medium.npz"))
+X, mu = np.ascontiguousarray(z["L0_X_tmp"]), z["L0_tot_weights"]
+N, n = X.shape
+Xd, mud = torch.from_numpy(X).to(dev), torch.from_numpy(mu).to(dev)
+kr = torch.empty(N, dtype=torch.int32, device=dev); ws = torch.empty(N, dtype=torch.float64, device=dev)
+nk = torch.empty(1, dtype=torch.int32, device=dev); mo = torch.empty(N, dtype=torch.float64, device=dev)
+lib = nat.load()
+lib.sober_debug_sp_stamps.restype = C.c_int
+acc = []
+for it in range(8):
+    nat.car_device(Xd, mud, kr, ws, nk, mo)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 260)()
+    assert lib.sober_debug_sp_stamps(buf) == 0
+    t = np.array(buf[:], dtype=np.int64)
+    K = N - (n + 1)
+    if it >= 3:
+        acc.append((t[:K] - t[256]) / 100.0)
+        tail = (t[257] - t[K - 1]) / 100.0
+a = np.mean(acc, 0)
+d = np.diff(np.concatenate([[0.0], a]))
+first = np.arange(len(d)) % 7 == 0
+print("pivots", len(d), "first publish after the barrier: %.2f us; last publish at %.2f us; tail (weights out) %.2f us" % (d[0], a[-1], tail))
+print("in-block pivots : mean %.3f us (min %.3f max %.3f)" % (d[~first].mean(), d[~first].min(), d[~first].max()))
+print("hand-over pivots: mean %.3f us (min %.3f max %.3f)  [%d of them]" % (d[first][1:].mean(), d[first][1:].min(), d[first][1:].max(), first.sum() - 1))
+print("by position in the block:", [round(float(d[(np.arange(len(d)) % 7 == j) & (np.arange(len(d)) >= 7)].mean()), 3) for j in range(7)])
+print("per block (us):", [round(float(d[b * 7:(b + 1) * 7].sum()), 2) for b in range((len(d) + 6) // 7)])
+seg = (C.c_ulonglong * 128)()
+if hasattr(lib, "sober_debug_sp_segments") and lib.sober_debug_sp_segments(seg) == 0:
+    sg = np.array(seg[:], dtype=np.float64).reshape(16, 8)[:14]           # the 14 full blocks
+    per = sg.sum(0) / (14 * 7) / 100.0
+    print("inside the ratio test: divisions %.3f | keys + lane minimum %.3f | wave minimum %.3f | ballots + winner %.3f" % (per[5], per[6], per[7], per[1]))
+    print("produce step by segment, us per pivot (each includes one stamp's own cost): elimination behind the previous pivot + column select %.3f | "
+          "ratio test %.3f | publish %.3f | weights %.3f | (block end) %.3f" % (per[0], per[1], per[2], per[3], per[4] * 7))

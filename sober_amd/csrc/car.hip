@@ -694,10 +694,24 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {        // total i
 // leaves empty.  (The round-1 kernel rotated the ownership with every pivot -- column c -> wave c mod 16 --: one barrier,
 // one hand-over of the weights and one LDS round trip of the pivot column per pivot, 1.14 us each.)
 constexpr int SP_W = 16, SP_BC = 7, SP_RING = 32;
+constexpr int SP_W_MAX_DBG = 16;
+#ifdef SP_TSTAMPS     // diagnostic build (scripts/pivot_stamps.py): s_memrealtime (100 MHz) of every publish, by pivot index
+__device__ unsigned long long g_sp_stamps[260];
+__device__ unsigned long long g_sp_seg[SP_W_MAX_DBG * 8];   // per wave: ticks summed by segment of the produce step
+#define SP_SEG(K, DEP_CONSTRAINT, DEP) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), DEP_CONSTRAINT(DEP) :: "memory"); \
+        sp_seg_[K] += t_ - sp_last_; sp_last_ = t_; } while (0)
+#else
+#define SP_SEG(K, DEP_CONSTRAINT, DEP) do { } while (0)
+#endif
 struct SpSlot { double col[256]; double alpha, rpp; int piv; int tag; };
 struct SpState { double mu[4]; bool dead[4], inr[4]; };
 
-__device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpState& st, int& piv, double& al, double& rp) {
+#ifdef SP_TSTAMPS
+#define SP_DBG_ARGS0 , unsigned long long (&sp_seg_)[8], unsigned long long& sp_last_
+#else
+#define SP_DBG_ARGS0
+#endif
+__device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpState& st, int& piv, double& al, double& rp SP_DBG_ARGS0) {
     double rt[4], rc[4];
     unsigned kh[4], kl[4];
 #pragma unroll
@@ -706,6 +720,7 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
 #else
     for (int q = 0; q < 4; ++q) { rt[q] = st.mu[q] / col[q]; rc[q] = 1.0 / col[q]; }
 #endif
+    SP_SEG(5, "+v", rt[3]);                                          // the eight divisions
     unsigned hmin = 0xffffffffu;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -715,7 +730,9 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
         kl[q] = ok ? (unsigned)k : 0xffffffffu;
         hmin = min(hmin, kh[q]);
     }
-    const unsigned H = wave_min_u32(hmin);
+    SP_SEG(6, "+v", hmin);                                           // keys, the lane's minimum
+    unsigned H = wave_min_u32(hmin);
+    SP_SEG(7, "+s", H);                                              // the wave's minimum
     piv = -1; al = 0.0; rp = 1.0;
     if (H == 0xffffffffu) return;                                     // uniform: no candidate (:241-242)
     unsigned long long mb[4];
@@ -751,6 +768,9 @@ __device__ __forceinline__ void sp_mu_step(SpState& st, const double (&col)[4], 
     }
 }
 //   Phi[:, c] -= Phi[:, 0] * (Phi[idx, c] / Phi[idx, 0])   (:260-266), my columns J0 .. SP_BC-1
+// (the row slot of the pivot entry by a uniform switch: picking it with three selects per column makes the compiler
+//  index a copy of phi in scratch memory -- 2x slower --, picking it arithmetically with four 0/1 weights measured
+//  3.5 us per step slower than the switch)
 template <int KP, int J0>
 __device__ __forceinline__ void sp_elim_kp(double (&phi)[SP_BC][4], const double (&col)[4], int lp, double rpp) {
 #pragma unroll
@@ -786,14 +806,23 @@ __device__ __forceinline__ bool sp_consume(SpSlot* ring, int s, int lane, double
 }
 
 // pivot `sp` from column JJ of my block: ratio test, publish, update of my weights and of my columns behind JJ
+#ifdef SP_TSTAMPS
+#define SP_DBG_ARGS , unsigned long long (&sp_seg_)[8], unsigned long long& sp_last_
+#define SP_DBG_PASS , sp_seg_, sp_last_
+#else
+#define SP_DBG_ARGS
+#define SP_DBG_PASS
+#endif
 template <int JJ>
 __device__ __forceinline__ void sp_produce_step(double (&phi)[SP_BC][4], SpState& st, SpSlot* ring, int sp, int lane,
-                                                double (&col)[4], bool& stop) {
+                                                double (&col)[4], bool& stop SP_DBG_ARGS) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[JJ][q];
+    SP_SEG(0, "+v", col[0]);                                  // (since the previous stamp: the elimination behind the last pivot)
     int piv;
     double al, rp;
-    sp_ratio_test(col, st, piv, al, rp);
+    sp_ratio_test(col, st, piv, al, rp SP_DBG_PASS);
+    SP_SEG(1, "+s", piv);                                     // ratio test: ballots, the winner's lane, its quotient
     SpSlot& e = ring[sp % SP_RING];
 #ifndef SP_X_NOPUB
     if (piv >= 0) {
@@ -802,10 +831,15 @@ __device__ __forceinline__ void sp_produce_step(double (&phi)[SP_BC][4], SpState
     }
 #endif
     if (lane == 0) { e.alpha = al; e.rpp = rp; e.piv = piv; }
+#ifdef SP_TSTAMPS
+    { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) g_sp_stamps[sp] = t_; }
+#endif
     asm volatile("" ::: "memory");                            // (program order; a wave's LDS operations execute in order:
     if (lane == 0) *(volatile int*)&e.tag = sp + 1;           //  the tag lands after the data it releases -- no wait)
+    SP_SEG(2, "+s", piv);                                     // publish
     if (piv < 0) { stop = true; return; }                     // Q6: the loop ends here (:241-242)
     sp_mu_step(st, col, al, piv, lane);
+    SP_SEG(3, "+v", st.mu[0]);                                // weights
 #ifndef SP_X_NOELIM
     sp_elim<JJ + 1>(phi, col, piv, rp);
 #endif
@@ -830,6 +864,9 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
     // the fused launch in front gave up on a reflector, or not every group of Phi's rows found a consumer
     const bool broken = err != nullptr && (err[CARF_ERR / 4] != 0u || err[CARF_DONE / 4] != (unsigned)(CAR_NS / 8));
     __syncthreads();                                                  // (the only workgroup barrier)
+#ifdef SP_TSTAMPS
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_sp_stamps[256] = t_; }
+#endif
     if (broken) { if (tid == 0) *n_keep_out = -1; return; }
     if (c0 >= K && w != 0) return;
     double phi[SP_BC][4];
@@ -866,13 +903,12 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
         if (s_end > SP_RING) {
             const int need = s_end - SP_RING;
             unsigned spins = 0;
+            // (lane o looks at wave o: one LDS read and a ballot -- sixteen dependent reads by every lane were 1 us of
+            //  every block's hand-over, 10 % of the kernel: scripts/pivot_stamps.py)
+            const int o = lane & (SP_W - 1);
+            const bool follows = (o > w && o * SP_BC < K) || (o == 0 && w != 0);
             for (;;) {
-                bool ok = true;
-                for (int o = 0; o < SP_W; ++o) {
-                    const bool follows = (o > w && o * SP_BC < K) || (o == 0 && w != 0);
-                    if (follows && prog[o] < need) ok = false;
-                }
-                if (ok) break;
+                if (__ballot(follows && prog[o] < need) == 0ull) break;
                 if (++spins > (1u << 22)) { fail = true; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -880,10 +916,18 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
         // one instance of the step per column of my block: the columns keep their registers (rotating them down after
         // every pivot -- 24 doubles moved behind the elimination they depend on -- cost 15 % of the kernel)
         int sp = c0;
-#define SP_STEP(JJ) if (sp < s_end && !stop) { sp_produce_step<JJ>(phi, st, ring, sp, lane, col, stop); ++sp; }
+#ifdef SP_TSTAMPS
+        unsigned long long sp_seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sp_last_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sp_last_) :: "memory");
+#endif
+#define SP_STEP(JJ) if (sp < s_end && !stop) { sp_produce_step<JJ>(phi, st, ring, sp, lane, col, stop SP_DBG_PASS); ++sp; }
         SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6)
 #undef SP_STEP
         static_assert(SP_BC == 7, "one SP_STEP per column of a block");
+#ifdef SP_TSTAMPS
+        SP_SEG(4, "+v", col[0]);                              // the elimination behind the block's last pivot (nothing left: ~ a stamp's own cost)
+        if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) g_sp_seg[w * 8 + k_] = sp_seg_[k_];
+#endif
         __builtin_amdgcn_s_setprio(0);
     }
     if (w != 0) return;
@@ -912,6 +956,9 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
         base += __popcll(bal);
     }
     if (lane == 0) *n_keep_out = fail ? -1 : base;
+#ifdef SP_TSTAMPS
+    if (lane == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_sp_stamps[257] = t_; }
+#endif
 }
 
 // ---------------- the extra elimination of the acquisition-guided branch (SOBER/_rchq.py:87-106, :177-196) ----------
@@ -1085,3 +1132,12 @@ extern "C" int sober_second_elimination(const double* phi, const double* objp, c
     LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef SP_TSTAMPS
+extern "C" int sober_debug_sp_stamps(unsigned long long* out260) {
+    return (int)hipMemcpyFromSymbol(out260, HIP_SYMBOL(sober::g_sp_stamps), sizeof(unsigned long long) * 260, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int sober_debug_sp_segments(unsigned long long* out128) {
+    return (int)hipMemcpyFromSymbol(out128, HIP_SYMBOL(sober::g_sp_seg), sizeof(unsigned long long) * 128, 0, hipMemcpyDeviceToHost);
+}
+#endif
