@@ -33,7 +33,8 @@ namespace sober {
 constexpr int CAR_MS = 7;           // matrix row slots per thread in the bidiagonalisation: m <= 16 * 7
 constexpr int CAR_CQ = 13;          // 16-lane slots along N: N <= 16 * 13
 constexpr int CAR_NS = 16 * CAR_CQ; // stride of a reflector / of the LDS columns
-constexpr int CAR_PC = 128;         // stride of a Phi row in the global scratch: N - m <= 128
+constexpr int CAR_PC = 128;         // columns of Phi in the global scratch (N - m <= 128), kept COLUMN by column: Phi[col * CAR_NS + row]
+//                                    (a pivot wave reads its seven columns as contiguous runs of rows)
 constexpr int CAR_BT = 256;         // threads of k_car_bidiag
 
 // ---- DPP cross-lane helpers (row = 16 lanes).  ds_bpermute-based __shfl costs an LDS round trip
@@ -598,10 +599,10 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
             for (int q = 0; q < 4; ++q) {
                 const int c = lane + 64 * q;                           // column of P
                 const int col = c - m;
-                if (c < CAR_NS && col >= 0 && col < CAR_PC) Phi[(size_t)r * CAR_PC + col] = (r < N && col < NC) ? p[w][q] : 0.0;
+                if (c < CAR_NS && col >= 0 && col < CAR_PC) Phi[(size_t)col * CAR_NS + r] = (r < N && col < NC) ? p[w][q] : 0.0;
             }
             // (columns beyond what the lanes above cover)
-            for (int col = max(CAR_NS - m, 0) + lane; col < CAR_PC; col += 64) Phi[(size_t)r * CAR_PC + col] = 0.0;
+            for (int col = max(CAR_NS - m, 0) + lane; col < CAR_PC; col += 64) Phi[(size_t)col * CAR_NS + r] = 0.0;
         }
         // this group of rows is in memory: the pivot kernel refuses to run on a Phi with a group missing
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(256) void k_car_phi(const double* __restrict__ vws,
     for (int q = 0; q < 4; ++q) {
         const int r = lane + 64 * q;
         if (r < CAR_NS) {
-            Phi[(size_t)r * CAR_PC + col] = (r < N) ? phi[q] : 0.0;
+            Phi[(size_t)col * CAR_NS + r] = (r < N) ? phi[q] : 0.0;
             if (phi_out != nullptr && col < NC && r < N) phi_out[(size_t)r * NC + col] = phi[q];
         }
     }
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
         st.mu[q] = st.inr[q] ? mu_in[row] + 0.0 : 0.0;
 #pragma unroll
         for (int j = 0; j < SP_BC; ++j)
-            phi[j][q] = (c0 + j < K && row < N) ? Phi[(size_t)row * CAR_PC + c0 + j] : 0.0;
+            phi[j][q] = (c0 + j < K && row < N) ? Phi[(size_t)(c0 + j) * CAR_NS + row] : 0.0;
     }
     bool fail = false, stop = false;
     double col[4] = {0.0, 0.0, 0.0, 0.0};
