@@ -776,6 +776,9 @@ __device__ __forceinline__ void publish(rsrc_t rs, int s, int lane, const double
 #define MC_PSTAMP_ARGS
 #define MC_PSTAMP_PASS
 #endif
+#ifdef MC_TSTAMPS      // diagnostic build (scripts/pivot_stamps.py mc): s_memrealtime (100 MHz) of every publish, by pivot index
+__device__ unsigned long long g_mc_stamps[260];
+#endif
 __device__ __forceinline__ bool produce(double (&phi)[BC][NQ], PivState& st, rsrc_t rs, int s, int lane MC_PSTAMP_ARGS) {
     double col[NQ];
     MC_STAMP(0);
@@ -788,6 +791,9 @@ __device__ __forceinline__ bool produce(double (&phi)[BC][NQ], PivState& st, rsr
     ratio_test(col, st, piv, al, rp);
     MC_STAMP(1);
     publish(rs, s, lane, col, al, rp, piv);
+#ifdef MC_TSTAMPS
+    { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0 && s < 256) g_mc_stamps[s] = t_; }
+#endif
     MC_STAMP(2);
     if (piv < 0) return false;                                        // Q6: the loop ends here (:241-242)
     mu_step(st, col, al, piv, lane);
@@ -815,6 +821,9 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
     const int cu = __builtin_amdgcn_readfirstlane(lcu);
     if (cu < 0) return;
     const int gw = cu * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef MC_TSTAMPS
+    if (gw == 0 && lane == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mc_stamps[256] = t_; }
+#endif
     const int K = N - m;
     const int c0 = gw * BC;
     if (c0 >= K && gw != 0) return;
@@ -883,6 +892,9 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
         base += __popcll(bal);
     }
     if (lane == 0) *n_keep_out = fail ? -1 : base;
+#ifdef MC_TSTAMPS
+    if (lane == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mc_stamps[257] = t_; }
+#endif
 }
 
 // lane-swap self test: out[l] = wave_allsum(in[l]), out[64 + l] = xrow_allsum(in[l])
@@ -972,3 +984,9 @@ extern "C" int sober_mc_selftest(const double* in, double* out, void* stream) {
     LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef MC_TSTAMPS
+extern "C" int sober_debug_mc_stamps(unsigned long long* out260) {
+    return (int)hipMemcpyFromSymbol(out260, HIP_SYMBOL(sober::mc::g_mc_stamps), sizeof(unsigned long long) * 260, 0, hipMemcpyDeviceToHost);
+}
+#endif
