@@ -40,3 +40,12 @@ if hasattr(lib, "sober_debug_sp_segments") and lib.sober_debug_sp_segments(seg) 
     print("inside the ratio test: divisions %.3f | keys + lane minimum %.3f | wave minimum %.3f | ballots + winner %.3f" % (per[5], per[6], per[7], per[1]))
     print("produce step by segment, us per pivot (each includes one stamp's own cost): elimination behind the previous pivot + column select %.3f | "
           "ratio test %.3f | publish %.3f | weights %.3f | (block end) %.3f" % (per[0], per[1], per[2], per[3], per[4] * 7))
+rt = (C.c_ulonglong * 8)()
+if hasattr(lib, "sober_debug_car_rt") and lib.sober_debug_car_rt(rt) == 0:
+    r = np.array(rt[:], dtype=np.int64)
+    t = np.array(buf[:], dtype=np.int64)
+    o = r[0]
+    f = lambda x: (x - o) / 100.0
+    print("timeline of the step's two launches (us, producer's entry = 0): last reflector computed %.2f | published, producer out %.2f | "
+          "last consumer (Phi) done %.2f | pivot kernel in %.2f | its barrier %.2f | first publish %.2f | last publish %.2f | weights out %.2f"
+          % (f(r[1]), f(r[2]), f(r[3]), f(t[258]), f(t[256]), f(t[0]), f(t[K - 1]), f(t[257])))

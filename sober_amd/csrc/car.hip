@@ -494,6 +494,14 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag(const double* __restrict_
 // Tags carry an epoch (one per launch), so nothing has to be cleared between launches; spins are bounded (error word:
 // the pivot kernel then reports n_keep = -1 and the caller redoes the step with the launches that do not depend on
 // partner workgroups: sober_car_device_ex, SOBER_CAR_SAFE).
+#ifdef SP_TSTAMPS     // diagnostic build: the launches' own timeline on the chip-wide 100 MHz clock (scripts/pivot_stamps.py)
+__device__ unsigned long long g_car_rt[8];   // 0 producer in, 1 last reflector out, 2 producer done, 3 last consumer done
+#define CAR_RT(K) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_car_rt[K] = t_; } while (0)
+#define CAR_RT_MAX(K) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); atomicMax(&g_car_rt[K], t_); } while (0)
+#else
+#define CAR_RT(K) do { } while (0)
+#define CAR_RT_MAX(K) do { } while (0)
+#endif
 __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __restrict__ X, int ldx, int N, int m,
                                                              double* __restrict__ vws, double* __restrict__ taup,
                                                              double* __restrict__ Phi, void* __restrict__ comm,
@@ -510,9 +518,12 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
             __hip_atomic_store(words + CARF_XCD / 4, (epoch << 4) | (xcc + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         const CarPub pub{rs, tag0};
+        if (threadIdx.x == 0) { CAR_RT(0); g_car_rt[3] = 0ull; }
         car_bidiag2_body<true>(X, ldx, N, m, vws, taup, pub);
         __syncthreads();
+        if (threadIdx.x == 0) CAR_RT(1);
         car_publish_progress(pub, m);                                  // the last reflector (this time the wait is real)
+        if (threadIdx.x == 0) CAR_RT(2);
         return;
     }
     // ---- consumers ----
@@ -609,6 +620,7 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
         __syncthreads();
         if (tid == 0 && !failed)
             __hip_atomic_fetch_add(words + CARF_DONE / 4, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) CAR_RT_MAX(3);
     }
 }
 
@@ -860,6 +872,9 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = N - m;
     const int c0 = w * SP_BC;
+#ifdef SP_TSTAMPS
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_sp_stamps[258] = t_; }
+#endif
     if (tid < SP_RING) ring[tid].tag = 0;
     if (tid < SP_W) prog[tid] = 0;
     // the fused launch in front gave up on a reflector, or not every group of Phi's rows found a consumer
@@ -1137,6 +1152,9 @@ extern "C" int sober_second_elimination(const double* phi, const double* objp, c
 #ifdef SP_TSTAMPS
 extern "C" int sober_debug_sp_stamps(unsigned long long* out260) {
     return (int)hipMemcpyFromSymbol(out260, HIP_SYMBOL(sober::g_sp_stamps), sizeof(unsigned long long) * 260, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int sober_debug_car_rt(unsigned long long* out8) {
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(sober::g_car_rt), sizeof(unsigned long long) * 8, 0, hipMemcpyDeviceToHost);
 }
 extern "C" int sober_debug_sp_segments(unsigned long long* out128) {
     return (int)hipMemcpyFromSymbol(out128, HIP_SYMBOL(sober::g_sp_seg), sizeof(unsigned long long) * 128, 0, hipMemcpyDeviceToHost);
