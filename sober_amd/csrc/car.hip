@@ -518,7 +518,9 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
             __hip_atomic_store(words + CARF_XCD / 4, (epoch << 4) | (xcc + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         const CarPub pub{rs, tag0};
+#ifdef SP_TSTAMPS
         if (threadIdx.x == 0) { CAR_RT(0); g_car_rt[3] = 0ull; }
+#endif
         car_bidiag2_body<true>(X, ldx, N, m, vws, taup, pub);
         __syncthreads();
         if (threadIdx.x == 0) CAR_RT(1);
