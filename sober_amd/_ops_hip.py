@@ -730,26 +730,39 @@ class HipOps:
         leave exactly n + 2 points (the reference then takes a singular vector of a full-rank matrix: host route)."""
         N, n1f = X.shape                                     # n1f = n + 1 functions incl. the objective
         dev = self.device
-        first = self.car_device_checked(X, mu_in)
-        if first is None:
-            return None
-        kr1, w1, kr1_h, n1, _ = first
-        if n1 != n1f + 1 or not self.car_supported(n1, n1f):
-            return None
-        sel = torch.nonzero(kr1 >= 0).flatten()              # ascending set index = rank order
-        Xp = X[sel, :n1f - 1].contiguous()                    # (n1, n)
-        objp = (X[sel, n1f - 1] if obj_head is None else obj_head[sel]).contiguous()
-        phi = torch.empty(n1, 1, dtype=torch.float64, device=dev)
-        scratch = [torch.empty(n1, dtype=t_, device=dev) for t_ in (torch.int32, torch.float64, torch.float64)]
-        nkx = torch.empty(1, dtype=torch.int32, device=dev)
-        # (phi_out is filled by the stand-alone bidiagonalisation + Phi launches: nothing here can give up)
-        nat.car_device(Xp, w1[:n1].contiguous(), scratch[0], scratch[1], nkx, scratch[2], phi_out=phi)
-        keep_rank = torch.empty(N, dtype=torch.int32, device=dev)
-        w_star = torch.empty(N, dtype=torch.float64, device=dev)
-        n_keep = torch.empty(1, dtype=torch.int32, device=dev)
-        nat.second_elimination(phi, objp, w1, kr1, n1, keep_rank, w_star, n_keep)
-        (keep_h, nk_h) = self.to_host(keep_rank, n_keep)
-        return keep_rank, w_star, keep_h, int(nk_h[0]), (kr1_h, w1, n1)
+        n1 = n1f + 1                                         # what the first step leaves when the branch is regular
+        for _ in range(2):
+            if not self.car_supported(N, n1f + 1) or not self.car_supported(n1, n1f):
+                return None
+            # BOTH steps are enqueued before anything is read back (one synchronisation per level instead of three): the
+            # second one assumes the regular outcome of the first -- exactly n + 2 survivors, whose rows go to their
+            # rank's place with plain indexed copies (ranks outside 0..n1-1 land in a spare row) -- and is simply
+            # discarded when the host then finds another count
+            kr1, w1, nk1_d, _mu = self.car_device(X, mu_in)
+            rk = kr1.long()
+            rk = torch.where((rk >= 0) & (rk < n1), rk, torch.full_like(rk, n1))
+            Xp = torch.zeros(n1 + 1, n1f - 1, dtype=torch.float64, device=dev).index_copy_(0, rk, X[:, :n1f - 1])[:n1]
+            ocol = X[:, n1f - 1] if obj_head is None else obj_head[:N]
+            objp = torch.zeros(n1 + 1, dtype=torch.float64, device=dev).index_copy_(0, rk, ocol.contiguous())[:n1]
+            phi = torch.empty(n1, 1, dtype=torch.float64, device=dev)
+            scratch = [torch.empty(n1, dtype=t_, device=dev) for t_ in (torch.int32, torch.float64, torch.float64)]
+            nkx = torch.empty(1, dtype=torch.int32, device=dev)
+            # (phi_out is filled by the stand-alone bidiagonalisation + Phi launches: nothing here can give up)
+            nat.car_device(Xp, w1[:n1].contiguous(), scratch[0], scratch[1], nkx, scratch[2], phi_out=phi)
+            keep_rank = torch.empty(N, dtype=torch.int32, device=dev)
+            w_star = torch.empty(N, dtype=torch.float64, device=dev)
+            n_keep = torch.empty(1, dtype=torch.int32, device=dev)
+            nat.second_elimination(phi, objp.contiguous(), w1, kr1, n1, keep_rank, w_star, n_keep)
+            (kr1_h, nk1_h, keep_h, nk_h) = self.to_host(kr1, nk1_d, keep_rank, n_keep)
+            nk1 = int(nk1_h[0])
+            if nk1 < 0:                                      # the first step gave up: once more on the next rung
+                self._car_downgrade(nat.CAR_SAFE if nat.car_safe_supported(N, n1f + 1) and self.car_mode == nat.CAR_DEFAULT
+                                    else nat.CAR_HOST, "Caratheodory step")
+                continue
+            if nk1 != n1:
+                return None
+            return keep_rank, w_star, keep_h, int(nk_h[0]), (kr1_h, w1, n1)
+        return None
 
     def level_update(self, idx_cur, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0):
         nat.level_update(idx_cur, 0, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0)
