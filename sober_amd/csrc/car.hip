@@ -214,13 +214,15 @@ struct CarLds2 {
 #else
 #define CB2_STAMP(K, VAL) do { } while (0)
 #endif
-template <int S, bool FUSED>
+// MS / CQ: row / column slots in use (m <= 16 MS, N <= 16 CQ): the instantiation is picked by the problem's size, so
+// a 20 x 10 step (batch 10) does not carry the 7 x 13 slots of a 200 x 100 one through every loop
+template <int S, bool FUSED, int MS, int CQ>
 __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], double (&colp)[CAR_MS], int m, const CarLds2& L,
                                                   double* __restrict__ vws, double* __restrict__ taup, const CarPub& pub) {
     const int tid = threadIdx.x;
     const int R = tid >> 4, C = tid & 15;
     const int i_end = min(16 * S + 16, m - 1);
-    constexpr int S1 = (S + 1 < CAR_MS) ? S + 1 : S;         // row slot of row i+1 when i is the block's last step
+    constexpr int S1 = (S + 1 < MS) ? S + 1 : S;         // row slot of row i+1 when i is the block's last step
     const car_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(vws, 0, (int)((size_t)m * CAR_NS * sizeof(double)), 0x00020000);
     CB_DECL
     for (int i = 16 * S; i < i_end; ++i) {
@@ -231,32 +233,32 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         CB_STAMP(0);
         const double tauq = L.hsc[0], sc2 = L.hsc[1];        // H(i-1)'s scalars (wave 3 of the previous step's sums)
 #pragma unroll
-        for (int q = S; q < CAR_CQ; ++q) { x[q] = L.rowg[pp * CAR_NS + C + 16 * q]; z[q] = L.zsum[C + 16 * q]; }
+        for (int q = S; q < CQ; ++q) { x[q] = L.rowg[pp * CAR_NS + C + 16 * q]; z[q] = L.zsum[C + 16 * q]; }
         const double rgi = L.rowg[pp * CAR_NS + i];
 #pragma unroll
-        for (int k = S; k < CAR_MS; ++k) cur[k] = L.colg[pp * 128 + R + 16 * k];
+        for (int k = S; k < MS; ++k) cur[k] = L.colg[pp * 128 + R + 16 * k];
 #pragma unroll
-        for (int q = S; q < CAR_CQ; ++q) {
+        for (int q = S; q < CQ; ++q) {
             z[q] = fma(sc2, z[q], x[q]);
             x[q] = fma(-tauq, z[q], x[q]);                  // row i of the updated matrix (u_i = 1)
         }
         z[S] = (C >= li) ? z[S] : 0.0;
         x[S] = (C > li) ? x[S] : 0.0;
 #pragma unroll
-        for (int k = S; k < CAR_MS; ++k) f[k] = tauq * (sc2 * colp[k]);
+        for (int k = S; k < MS; ++k) f[k] = tauq * (sc2 * colp[k]);
         f[S] = (R == li) ? tauq : f[S];
         const double zi = rdlane(z[S], li);                 // z at column i (lane li of every wave holds C == li)
         const double alpha = fma(-tauq, zi, rgi);
 #pragma unroll
-        for (int k = S; k < CAR_MS; ++k) cur[k] = fma(-f[k], zi, cur[k]);                            // column i, my rows
+        for (int k = S; k < MS; ++k) cur[k] = fma(-f[k], zi, cur[k]);                            // column i, my rows
 #pragma unroll
-        for (int q = S; q < CAR_CQ; ++q)
+        for (int q = S; q < CQ; ++q)
 #pragma unroll
-            for (int k = S; k < CAR_MS; ++k) a[k][q] = CB2_HUPD(fma(-f[k], z[q], a[k][q]), a[k][q]);
+            for (int k = S; k < MS; ++k) a[k][q] = CB2_HUPD(fma(-f[k], z[q], a[k][q]), a[k][q]);
         // ---- G(i) from row i
         double ss0 = 0.0, ss1 = 0.0;
 #pragma unroll
-        for (int q = S; q < CAR_CQ; ++q) { if (q & 1) ss1 = fma(x[q], x[q], ss1); else ss0 = fma(x[q], x[q], ss0); }
+        for (int q = S; q < CQ; ++q) { if (q & 1) ss1 = fma(x[q], x[q], ss1); else ss0 = fma(x[q], x[q], ss0); }
         double ss = CB2_RSUM(ss0 + ss1);
         CB2_STAMP(2, ss);
         double beta, tau, sc;
@@ -269,11 +271,11 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         // w = A v = column i + sc * (A x) over my rows
         double tG[CAR_MS];
 #pragma unroll
-        for (int k = S; k < CAR_MS; ++k) {
+        for (int k = S; k < MS; ++k) {
             double w0 = 0.0, w1 = 0.0;
 #ifndef CB2_X_NOQ
 #pragma unroll
-            for (int q = S; q < CAR_CQ; ++q) { if (q & 1) w1 = fma(a[k][q], x[q], w1); else w0 = fma(a[k][q], x[q], w0); }
+            for (int q = S; q < CQ; ++q) { if (q & 1) w1 = fma(a[k][q], x[q], w1); else w0 = fma(a[k][q], x[q], w0); }
 #else
             w0 = a[k][S]; w1 = x[S];
 #endif
@@ -282,16 +284,16 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         tG[S] = (R > li) ? tG[S] : 0.0;                      // rows <= i stay
         CB2_STAMP(4, tG[S]);
 #pragma unroll
-        for (int k = S; k < CAR_MS; ++k) colp[k] = cur[k] - tG[k];      // column i after G(i)  (v_i = 1)
+        for (int k = S; k < MS; ++k) colp[k] = cur[k] - tG[k];      // column i after G(i)  (v_i = 1)
         colp[S] = (R > li) ? colp[S] : 0.0;
 #pragma unroll
-        for (int q = S; q < CAR_CQ; ++q) x[q] *= sc;         // x becomes v
+        for (int q = S; q < CQ; ++q) x[q] *= sc;         // x becomes v
         if (R == li) {                                       // the reflector goes to the scratch (Phi follows it)
             const unsigned so = (unsigned)i * (unsigned)(CAR_NS * 8);
 #pragma unroll
-            for (int q = 0; q < CAR_CQ; ++q) {
+            for (int q = 0; q < CAR_CQ; ++q) {            // (whole reflectors: the consumers read every slot)
                 double v;
-                if (q < S) v = 0.0;
+                if (q < S || q >= CQ) v = 0.0;
                 else if (q == S) v = (C < li) ? 0.0 : ((C == li) ? 1.0 : x[S]);
                 else v = x[q];
                 car_u32x2 g;
@@ -301,53 +303,53 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
             if (C == 0) taup[i] = tau;
         }
 #pragma unroll
-        for (int k = S; k < CAR_MS; ++k)
+        for (int k = S; k < MS; ++k)
 #pragma unroll
-            for (int q = S; q < CAR_CQ; ++q) a[k][q] = CB2_GUPD(fma(-tG[k], x[q], a[k][q]), a[k][q]);
+            for (int q = S; q < CQ; ++q) a[k][q] = CB2_GUPD(fma(-tG[k], x[q], a[k][q]), a[k][q]);
         // ---- what the next step is built from: row i+1 and column i+1 of A', and col'[i+1]
         const bool last = li == 15;
         const int n1 = (li + 1) & 15;
         if (!last) {                                         // (uniform)
             if (R == n1) {
 #pragma unroll
-                for (int q = S; q < CAR_CQ; ++q) L.rowg[p * CAR_NS + C + 16 * q] = a[S][q];
+                for (int q = S; q < CQ; ++q) L.rowg[p * CAR_NS + C + 16 * q] = a[S][q];
                 if (C == 0) L.scal[p] = colp[S];
             }
             if (C == n1) {
 #pragma unroll
-                for (int k = S; k < CAR_MS; ++k) L.colg[p * 128 + R + 16 * k] = a[k][S];
+                for (int k = S; k < MS; ++k) L.colg[p * 128 + R + 16 * k] = a[k][S];
             }
         } else {
             if (R == 0) {
 #pragma unroll
-                for (int q = S; q < CAR_CQ; ++q) L.rowg[p * CAR_NS + C + 16 * q] = a[S1][q];
+                for (int q = S; q < CQ; ++q) L.rowg[p * CAR_NS + C + 16 * q] = a[S1][q];
                 if (C == 0) L.scal[p] = colp[S1];
             }
             if (C == 0) {
 #pragma unroll
-                for (int k = S; k < CAR_MS; ++k) L.colg[p * 128 + R + 16 * k] = a[k][S + 1];
+                for (int k = S; k < MS; ++k) L.colg[p * 128 + R + 16 * k] = a[k][S + 1];
             }
         }
         CB2_STAMP(5, a[S][S]);
         // ---- partial column sums of H(i): rows >= i + 2 of col' against A'
         double cm[CAR_MS];
 #pragma unroll
-        for (int k = S; k < CAR_MS; ++k) cm[k] = colp[k];
+        for (int k = S; k < MS; ++k) cm[k] = colp[k];
         cm[S] = (R > li + 1) ? cm[S] : 0.0;
-        if constexpr (S + 1 < CAR_MS) cm[S + 1] = (last && R == 0) ? 0.0 : cm[S + 1];
+        if constexpr (S + 1 < MS) cm[S + 1] = (last && R == 0) ? 0.0 : cm[S + 1];
         double yp[CAR_CQ], s2p = 0.0;
 #pragma unroll
-        for (int q = S; q < CAR_CQ; ++q) yp[q] = cm[S] * a[S][q];
+        for (int q = S; q < CQ; ++q) yp[q] = cm[S] * a[S][q];
 #ifndef CB2_X_NOY
 #pragma unroll
-        for (int k = S + 1; k < CAR_MS; ++k)
+        for (int k = S + 1; k < MS; ++k)
 #pragma unroll
-            for (int q = S; q < CAR_CQ; ++q) yp[q] = fma(cm[k], a[k][q], yp[q]);
+            for (int q = S; q < CQ; ++q) yp[q] = fma(cm[k], a[k][q], yp[q]);
 #endif
 #pragma unroll
-        for (int k = S; k < CAR_MS; ++k) s2p = fma(cm[k], cm[k], s2p);
+        for (int k = S; k < MS; ++k) s2p = fma(cm[k], cm[k], s2p);
 #pragma unroll
-        for (int q = S; q < CAR_CQ; ++q) L.zpart[R * CAR_NS + C + 16 * q] = yp[q];
+        for (int q = S; q < CQ; ++q) L.zpart[R * CAR_NS + C + 16 * q] = yp[q];
         if (C == 0) L.s2part[R] = s2p;
         CB_STAMP(6);
         CB2_BARRIER();
@@ -359,7 +361,7 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         // the top of the next iteration with nothing to overlap it (block 0: wave 3 also takes columns 192 .. 207)
         if (tid < 192) {                                     // (wave-uniform)
             const int c = 16 * S + tid;
-            if (c < CAR_NS) {
+            if (c < 16 * CQ) {
                 double z0 = 0.0, z1 = 0.0;
 #pragma unroll
                 for (int w = 0; w < 16; w += 2) {
@@ -370,7 +372,7 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
             }
         } else {
             if constexpr (S == 0) {
-                if (tid < CAR_NS) {
+                if (tid < 16 * CQ) {
                     double z0 = 0.0, z1 = 0.0;
 #pragma unroll
                     for (int w = 0; w < 16; w += 2) {
@@ -394,7 +396,7 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
 }
 
 // the last reflector, G(m-1): row m-1 after H(m-2) -- no matrix work at all
-template <int S, bool FUSED>
+template <int S, bool FUSED, int MS, int CQ>
 __device__ __forceinline__ void car_bidiag2_last(int m, const CarLds2& L, double* __restrict__ vws, double* __restrict__ taup,
                                                  const CarPub& pub) {
     const int tid = threadIdx.x;
@@ -404,7 +406,7 @@ __device__ __forceinline__ void car_bidiag2_last(int m, const CarLds2& L, double
     double x[CAR_CQ], zS = 0.0;
     const double tauq = L.hsc[0], sc2 = L.hsc[1];
 #pragma unroll
-    for (int q = S; q < CAR_CQ; ++q) {
+    for (int q = S; q < CQ; ++q) {
         const double rg = L.rowg[pp * CAR_NS + C + 16 * q];
         const double zq = fma(sc2, L.zsum[C + 16 * q], rg);
         if (q == S) zS = zq;
@@ -415,7 +417,7 @@ __device__ __forceinline__ void car_bidiag2_last(int m, const CarLds2& L, double
     const double alpha = fma(-tauq, zi, L.rowg[pp * CAR_NS + i]);
     double ss0 = 0.0, ss1 = 0.0;
 #pragma unroll
-    for (int q = S; q < CAR_CQ; ++q) { if (q & 1) ss1 = fma(x[q], x[q], ss1); else ss0 = fma(x[q], x[q], ss0); }
+    for (int q = S; q < CQ; ++q) { if (q & 1) ss1 = fma(x[q], x[q], ss1); else ss0 = fma(x[q], x[q], ss0); }
     const double ss = row16_sum(ss0 + ss1);
     double beta, tau, sc;
     larfg_vt(alpha, ss, tau, sc); (void)beta;
@@ -423,7 +425,7 @@ __device__ __forceinline__ void car_bidiag2_last(int m, const CarLds2& L, double
 #pragma unroll
         for (int q = 0; q < CAR_CQ; ++q) {
             double v;
-            if (q < S) v = 0.0;
+            if (q < S || q >= CQ) v = 0.0;
             else if (q == S) v = (C < li) ? 0.0 : ((C == li) ? 1.0 : x[S] * sc);
             else v = x[q] * sc;
             vws[(size_t)i * CAR_NS + C + 16 * q] = v;
@@ -432,7 +434,7 @@ __device__ __forceinline__ void car_bidiag2_last(int m, const CarLds2& L, double
     }
 }
 
-template <bool FUSED>
+template <bool FUSED, int MS, int CQ>
 __device__ __forceinline__ void car_bidiag2_body(const double* __restrict__ X, int ldx, int N, int m,
                                                  double* __restrict__ vws, double* __restrict__ taup, const CarPub& pub) {
     __shared__ double rowg[2 * CAR_NS];
@@ -451,7 +453,8 @@ __device__ __forceinline__ void car_bidiag2_body(const double* __restrict__ X, i
 #pragma unroll
         for (int q = 0; q < CAR_CQ; ++q) {
             const int r = R + 16 * k, c = C + 16 * q;
-            a[k][q] = (c < N && r < m) ? ((r == 0) ? 1.0 : X[(size_t)c * ldx + (r - 1)]) : 0.0;
+            a[k][q] = 0.0;                                   // (slots beyond MS / CQ: constants, never touched again)
+            if (k < MS && q < CQ) a[k][q] = (c < N && r < m) ? ((r == 0) ? 1.0 : X[(size_t)c * ldx + (r - 1)]) : 0.0;
         }
     }
     // "step -1" left the matrix untouched: its row 0 and column 0, no H
@@ -461,27 +464,27 @@ __device__ __forceinline__ void car_bidiag2_body(const double* __restrict__ X, i
     if (tid < 2) { scal[tid] = 0.0; hsc[tid] = 0.0; }    // (tau = 0: "H(-1)" is the identity)
     __syncthreads();
     const CarLds2 L{rowg, colg, zpart, s2part, zsum, scal, hsc};
-    car_bidiag2_block<0, FUSED>(a, colp, m, L, vws, taup, pub);
-    if (m > 17) car_bidiag2_block<1, FUSED>(a, colp, m, L, vws, taup, pub);
-    if (m > 33) car_bidiag2_block<2, FUSED>(a, colp, m, L, vws, taup, pub);
-    if (m > 49) car_bidiag2_block<3, FUSED>(a, colp, m, L, vws, taup, pub);
-    if (m > 65) car_bidiag2_block<4, FUSED>(a, colp, m, L, vws, taup, pub);
-    if (m > 81) car_bidiag2_block<5, FUSED>(a, colp, m, L, vws, taup, pub);
-    if (m > 97) car_bidiag2_block<6, FUSED>(a, colp, m, L, vws, taup, pub);
-    switch ((m - 1) >> 4) {
-        case 0: car_bidiag2_last<0, FUSED>(m, L, vws, taup, pub); break;
-        case 1: car_bidiag2_last<1, FUSED>(m, L, vws, taup, pub); break;
-        case 2: car_bidiag2_last<2, FUSED>(m, L, vws, taup, pub); break;
-        case 3: car_bidiag2_last<3, FUSED>(m, L, vws, taup, pub); break;
-        case 4: car_bidiag2_last<4, FUSED>(m, L, vws, taup, pub); break;
-        case 5: car_bidiag2_last<5, FUSED>(m, L, vws, taup, pub); break;
-        default: car_bidiag2_last<6, FUSED>(m, L, vws, taup, pub); break;
-    }
+    car_bidiag2_block<0, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 1) if (m > 17) car_bidiag2_block<1, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 2) if (m > 33) car_bidiag2_block<2, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 3) if (m > 49) car_bidiag2_block<3, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 4) if (m > 65) car_bidiag2_block<4, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 5) if (m > 81) car_bidiag2_block<5, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 6) if (m > 97) car_bidiag2_block<6, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    const int sl = (m - 1) >> 4;
+    if (sl == 0) car_bidiag2_last<0, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 1) if (sl == 1) car_bidiag2_last<1, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 2) if (sl == 2) car_bidiag2_last<2, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 3) if (sl == 3) car_bidiag2_last<3, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 4) if (sl == 4) car_bidiag2_last<4, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 5) if (sl == 5) car_bidiag2_last<5, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 6) if (sl >= 6) car_bidiag2_last<6, FUSED, MS, CQ>(m, L, vws, taup, pub);
 }
 
+template <int MS, int CQ>
 __global__ __launch_bounds__(CAR_BT) void k_car_bidiag(const double* __restrict__ X, int ldx, int N, int m,
                                                        double* __restrict__ vws, double* __restrict__ taup) {
-    car_bidiag2_body<false>(X, ldx, N, m, vws, taup, CarPub{});
+    car_bidiag2_body<false, MS, CQ>(X, ldx, N, m, vws, taup, CarPub{});
 }
 
 // ---------------- phases 1 + 2 in one launch ----------------
@@ -502,6 +505,7 @@ __device__ unsigned long long g_car_rt[8];   // 0 producer in, 1 last reflector 
 #define CAR_RT(K) do { } while (0)
 #define CAR_RT_MAX(K) do { } while (0)
 #endif
+template <int MS, int CQ>
 __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __restrict__ X, int ldx, int N, int m,
                                                              double* __restrict__ vws, double* __restrict__ taup,
                                                              double* __restrict__ Phi, void* __restrict__ comm,
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
 #ifdef SP_TSTAMPS
         if (threadIdx.x == 0) { CAR_RT(0); g_car_rt[3] = 0ull; }
 #endif
-        car_bidiag2_body<true>(X, ldx, N, m, vws, taup, pub);
+        car_bidiag2_body<true, MS, CQ>(X, ldx, N, m, vws, taup, pub);
         __syncthreads();
         if (threadIdx.x == 0) CAR_RT(1);
         car_publish_progress(pub, m);                                  // the last reflector (this time the wait is real)
@@ -567,7 +571,11 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
         if (r0 < N) {
             const car_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(vws, 0, (int)((size_t)(m * CAR_NS + 128) * sizeof(double)), 0x00020000);
             int have = 0;                                              // reflectors known to be complete
-            for (int i = 0; i < m; ++i) {
+            if (spin_limit == 0u) {                                    // (the test switch: give up at once, through the real path --
+                __builtin_amdgcn_raw_buffer_store_b32(1, rs, CARF_ERR, 0, 16);   //  a limit of one poll stopped being a give-up when
+                failed = true;                                         //  a small step's producer got ahead of its consumers)
+            }
+            for (int i = 0; i < m && !failed; ++i) {
                 unsigned spins = 0;
                 while (have <= i) {                                    // (one broadcast load per poll)
                     const unsigned w = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, CARF_PROGRESS, 0, 16);
@@ -1083,11 +1091,21 @@ static int car_pivot_attr(size_t sp_bytes) {
 }
 
 // SOBER_CAR_FORCE_GIVEUP (any value, read at every call): the test switch that makes the launches which depend on
-// partner workgroups give up -- the fused launch's consumers get a spin limit of one poll, the multi-CU route reports
+// partner workgroups give up -- the fused launch's consumers give up at once (spin limit 0), the multi-CU route reports
 // n_keep = -1 -- so that the recovery of the callers can be exercised (tests/test_hip_parity.py).
 extern "C" int sober_car_giveup_forced(void) { return getenv("SOBER_CAR_FORCE_GIVEUP") != nullptr ? 1 : 0; }
 
 extern "C" int sober_car_safe_supported(int N, int m) { return car_one_cu(N, m); }
+
+// the bidiagonalisation's instantiation by size: row / column slots in use (m <= 16 MS_, N <= 16 CQ_)
+#define CAR_BY_SIZE(m_, N_, LAUNCH)                                                                    \
+    do {                                                                                               \
+        if ((m_) <= 16 && (N_) <= 32) { constexpr int MS_ = 1, CQ_ = 2; LAUNCH; }                      \
+        else if ((m_) <= 32 && (N_) <= 64) { constexpr int MS_ = 2, CQ_ = 4; LAUNCH; }                 \
+        else if ((m_) <= 64 && (N_) <= 112) { constexpr int MS_ = 4, CQ_ = 7; LAUNCH; }                \
+        else if ((N_) <= 112) { constexpr int MS_ = sober::CAR_MS, CQ_ = 7; LAUNCH; }                  \
+        else { constexpr int MS_ = sober::CAR_MS, CQ_ = sober::CAR_CQ; LAUNCH; }                       \
+    } while (0)
 
 extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const double* mu_in,
                                    int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
@@ -1108,7 +1126,7 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
     { const int rc = car_pivot_attr(sp_bytes); if (rc != 0) return rc; }
     if (phi_out != nullptr || unfused || mode == SOBER_CAR_SAFE) {
         // three launches, no workgroup waits for another one: nothing here can give up
-        hipLaunchKernelGGL(sober::k_car_bidiag, dim3(1), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup);
+        CAR_BY_SIZE(m, N, hipLaunchKernelGGL((sober::k_car_bidiag<MS_, CQ_>), dim3(1), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup));
         LAUNCH_CHECK();
         hipLaunchKernelGGL(sober::k_car_phi, dim3(sober::CAR_PC / 4), dim3(256), 0, st, vws, taup, N, m, Phi, phi_out);
         LAUNCH_CHECK();
@@ -1123,9 +1141,9 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
     const unsigned epoch = (epoch_ctr.fetch_add(1) + 1u) & 0x1FFFFFFu;
     void* comm = (void*)(Phi + (size_t)sober::CAR_NS * sober::CAR_PC + 512);
     static const int per_xcd = getenv("SOBER_CARF_PER_XCD") ? atoi(getenv("SOBER_CARF_PER_XCD")) : 40;    // (tuning aid)
-    const unsigned spin_limit = sober_car_giveup_forced() ? 1u : sober::CARF_SPIN_LIMIT;
-    hipLaunchKernelGGL(sober::k_car_bidiag_fused, dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X, ldx, N, m, vws, taup, Phi, comm,
-                       (unsigned)sober::carf_bytes(m), epoch, spin_limit);
+    const unsigned spin_limit = sober_car_giveup_forced() ? 0u : sober::CARF_SPIN_LIMIT;
+    CAR_BY_SIZE(m, N, hipLaunchKernelGGL((sober::k_car_bidiag_fused<MS_, CQ_>), dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X, ldx,
+                                         N, m, vws, taup, Phi, comm, (unsigned)sober::carf_bytes(m), epoch, spin_limit));
     LAUNCH_CHECK();
     hipLaunchKernelGGL(sober::k_car_pivot_stream, dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m, mu_in,
                        keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm);
