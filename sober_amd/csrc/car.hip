@@ -734,19 +734,20 @@ struct SpState { double mu[4]; bool dead[4], inr[4]; };
 #else
 #define SP_DBG_ARGS0
 #endif
+template <int NQ>
 __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpState& st, int& piv, double& al, double& rp SP_DBG_ARGS0) {
     double rt[4], rc[4];
     unsigned kh[4], kl[4];
 #pragma unroll
 #ifdef SP_X_NODIV      // timing-only builds (wrong results): what each part of the producer's loop costs
-    for (int q = 0; q < 4; ++q) { rt[q] = st.mu[q] * col[q]; rc[q] = col[q]; }
+    for (int q = 0; q < NQ; ++q) { rt[q] = st.mu[q] * col[q]; rc[q] = col[q]; }
 #else
-    for (int q = 0; q < 4; ++q) { rt[q] = st.mu[q] / col[q]; rc[q] = 1.0 / col[q]; }
+    for (int q = 0; q < NQ; ++q) { rt[q] = st.mu[q] / col[q]; rc[q] = 1.0 / col[q]; }
 #endif
     SP_SEG(5, "+v", rt[3]);                                          // the eight divisions
     unsigned hmin = 0xffffffffu;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const unsigned long long k = ratio_key(rt[q]);
         const bool ok = st.inr[q] & (col[q] > 0.0) & !st.dead[q];
         kh[q] = ok ? (unsigned)(k >> 32) : 0xffffffffu;
@@ -761,18 +762,18 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
     unsigned long long mb[4];
     int cnt = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { mb[q] = __ballot(kh[q] == H); cnt += __popcll(mb[q]); }
+    for (int q = 0; q < NQ; ++q) { mb[q] = __ballot(kh[q] == H); cnt += __popcll(mb[q]); }
     if (cnt != 1) {                                                   // rare: several quotients share the high word
         unsigned lmin = 0xffffffffu;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lmin = min(lmin, (kh[q] == H) ? kl[q] : 0xffffffffu);
+        for (int q = 0; q < NQ; ++q) lmin = min(lmin, (kh[q] == H) ? kl[q] : 0xffffffffu);
         const unsigned Lw = wave_min_u32(lmin);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mb[q] = __ballot((kh[q] == H) & (kl[q] == Lw));
+        for (int q = 0; q < NQ; ++q) mb[q] = __ballot((kh[q] == H) & (kl[q] == Lw));
     }
     bool found = false;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         if (!found && mb[q] != 0ull) {                                // uniform
             const int f = __ffsll((long long)mb[q]) - 1;
             piv = f + 64 * q;
@@ -783,9 +784,10 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
     }
 }
 // mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (two roundings like the tensor expression, :253-254)
+template <int NQ>
 __device__ __forceinline__ void sp_mu_step(SpState& st, const double (&col)[4], double alpha, int piv, int lane) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         st.dead[q] = st.dead[q] | (lane + 64 * q == piv);
         st.mu[q] = st.dead[q] ? 0.0 : __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q]));
     }
@@ -794,26 +796,34 @@ __device__ __forceinline__ void sp_mu_step(SpState& st, const double (&col)[4], 
 // (the row slot of the pivot entry by a uniform switch: picking it with three selects per column makes the compiler
 //  index a copy of phi in scratch memory -- 2x slower --, picking it arithmetically with four 0/1 weights measured
 //  3.5 us per step slower than the switch)
-template <int KP, int J0>
+template <int KP, int J0, int NQ>
 __device__ __forceinline__ void sp_elim_kp(double (&phi)[SP_BC][4], const double (&col)[4], int lp, double rpp) {
 #pragma unroll
     for (int j = J0; j < SP_BC; ++j) {
         const double qv = rdlane(phi[j][KP], lp) * rpp;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) phi[j][q] = fma(-qv, col[q], phi[j][q]);
+        for (int q = 0; q < NQ; ++q) phi[j][q] = fma(-qv, col[q], phi[j][q]);
     }
 }
-template <int J0>
+template <int J0, int NQ>
 __device__ __forceinline__ void sp_elim(double (&phi)[SP_BC][4], const double (&col)[4], int piv, double rpp) {
     const int kp = piv >> 6, lp = piv & 63;
-    switch (kp) {                                                     // uniform
-        case 0: sp_elim_kp<0, J0>(phi, col, lp, rpp); break;
-        case 1: sp_elim_kp<1, J0>(phi, col, lp, rpp); break;
-        case 2: sp_elim_kp<2, J0>(phi, col, lp, rpp); break;
-        default: sp_elim_kp<3, J0>(phi, col, lp, rpp); break;
+    if constexpr (NQ == 1) {
+        sp_elim_kp<0, J0, NQ>(phi, col, lp, rpp);
+    } else if constexpr (NQ == 2) {
+        if (kp == 0) sp_elim_kp<0, J0, NQ>(phi, col, lp, rpp);        // uniform
+        else sp_elim_kp<1, J0, NQ>(phi, col, lp, rpp);
+    } else {
+        switch (kp) {                                                 // uniform
+            case 0: sp_elim_kp<0, J0, NQ>(phi, col, lp, rpp); break;
+            case 1: sp_elim_kp<1, J0, NQ>(phi, col, lp, rpp); break;
+            case 2: sp_elim_kp<2, J0, NQ>(phi, col, lp, rpp); break;
+            default: sp_elim_kp<3, J0, NQ>(phi, col, lp, rpp); break;
+        }
     }
 }
 // wait for pivot s in the ring; false = give up (bounded)
+template <int NQ>
 __device__ __forceinline__ bool sp_consume(SpSlot* ring, int s, int lane, double (&col)[4], double& alpha, double& rpp, int& piv) {
     SpSlot& e = ring[s % SP_RING];
     volatile int* tg = &e.tag;
@@ -824,7 +834,7 @@ __device__ __forceinline__ bool sp_consume(SpSlot* ring, int s, int lane, double
     }
     alpha = e.alpha; rpp = e.rpp; piv = e.piv;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) col[q] = e.col[lane + 64 * q];
+    for (int q = 0; q < NQ; ++q) col[q] = e.col[lane + 64 * q];
     return true;
 }
 
@@ -836,21 +846,21 @@ __device__ __forceinline__ bool sp_consume(SpSlot* ring, int s, int lane, double
 #define SP_DBG_ARGS
 #define SP_DBG_PASS
 #endif
-template <int JJ>
+template <int JJ, int NQ>
 __device__ __forceinline__ void sp_produce_step(double (&phi)[SP_BC][4], SpState& st, SpSlot* ring, int sp, int lane,
                                                 double (&col)[4], bool& stop SP_DBG_ARGS) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[JJ][q];
+    for (int q = 0; q < NQ; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[JJ][q];
     SP_SEG(0, "+v", col[0]);                                  // (since the previous stamp: the elimination behind the last pivot)
     int piv;
     double al, rp;
-    sp_ratio_test(col, st, piv, al, rp SP_DBG_PASS);
+    sp_ratio_test<NQ>(col, st, piv, al, rp SP_DBG_PASS);
     SP_SEG(1, "+s", piv);                                     // ratio test: ballots, the winner's lane, its quotient
     SpSlot& e = ring[sp % SP_RING];
 #ifndef SP_X_NOPUB
     if (piv >= 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) e.col[lane + 64 * q] = col[q];
+        for (int q = 0; q < NQ; ++q) e.col[lane + 64 * q] = col[q];
     }
 #endif
     if (lane == 0) { e.alpha = al; e.rpp = rp; e.piv = piv; }
@@ -861,13 +871,15 @@ __device__ __forceinline__ void sp_produce_step(double (&phi)[SP_BC][4], SpState
     if (lane == 0) *(volatile int*)&e.tag = sp + 1;           //  the tag lands after the data it releases -- no wait)
     SP_SEG(2, "+s", piv);                                     // publish
     if (piv < 0) { stop = true; return; }                     // Q6: the loop ends here (:241-242)
-    sp_mu_step(st, col, al, piv, lane);
+    sp_mu_step<NQ>(st, col, al, piv, lane);
     SP_SEG(3, "+v", st.mu[0]);                                // weights
 #ifndef SP_X_NOELIM
-    sp_elim<JJ + 1>(phi, col, piv, rp);
+    sp_elim<JJ + 1, NQ>(phi, col, piv, rp);
 #endif
 }
 
+// NQ: 64-row slots in use (N <= 64 NQ): a 20-point step does not run the ratio test of a 200-point one
+template <int NQ>
 __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __restrict__ Phi, int N, int m,
                                                                 const double* __restrict__ mu_in,
                                                                 int32_t* __restrict__ keep_rank,
@@ -898,7 +910,7 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
     double phi[SP_BC][4];
     SpState st;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int row = lane + 64 * q;
         st.inr[q] = row < N;
         st.dead[q] = false;
@@ -915,11 +927,11 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
         double al, rp;
         int piv;
         if (s == s_mine - SP_BC) __builtin_amdgcn_s_setprio(2);      // on deck: the hand-over is on the critical chain
-        if (!sp_consume(ring, s, lane, col, al, rp, piv)) { fail = true; break; }
+        if (!sp_consume<NQ>(ring, s, lane, col, al, rp, piv)) { fail = true; break; }
         if (lane == 0) prog[w] = s + 1;
         if (piv < 0) { stop = true; break; }
-        sp_mu_step(st, col, al, piv, lane);
-        sp_elim<0>(phi, col, piv, rp);
+        sp_mu_step<NQ>(st, col, al, piv, lane);
+        sp_elim<0, NQ>(phi, col, piv, rp);
     }
     // my block
     if (!fail && !stop && c0 < K) {
@@ -946,7 +958,7 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
         unsigned long long sp_seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sp_last_;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sp_last_) :: "memory");
 #endif
-#define SP_STEP(JJ) if (sp < s_end && !stop) { sp_produce_step<JJ>(phi, st, ring, sp, lane, col, stop SP_DBG_PASS); ++sp; }
+#define SP_STEP(JJ) if (sp < s_end && !stop) { sp_produce_step<JJ, NQ>(phi, st, ring, sp, lane, col, stop SP_DBG_PASS); ++sp; }
         SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6)
 #undef SP_STEP
         static_assert(SP_BC == 7, "one SP_STEP per column of a block");
@@ -961,14 +973,14 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
     for (int s = c0 + SP_BC; s < K && !fail && !stop; ++s) {
         double al, rp;
         int piv;
-        if (!sp_consume(ring, s, lane, col, al, rp, piv)) { fail = true; break; }
+        if (!sp_consume<NQ>(ring, s, lane, col, al, rp, piv)) { fail = true; break; }
         if (lane == 0) prog[0] = s + 1;
         if (piv < 0) { stop = true; break; }
-        sp_mu_step(st, col, al, piv, lane);
+        sp_mu_step<NQ>(st, col, al, piv, lane);
     }
     int base = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int row = lane + 64 * q;
         const double v = (row < N) ? st.mu[q] + 0.0 : 0.0;           // -0.0 -> +0.0
         const bool keep = (row < N) && (v > 0.0);
@@ -1083,8 +1095,9 @@ extern "C" int64_t sober_car_ws_bytes(int N, int m) {
 static int car_pivot_attr(size_t sp_bytes) {
     static std::atomic<unsigned long long> done{0};
     if (sober_attr_needed(done)) {
-        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_stream, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)sp_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_stream<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_stream<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_stream<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_bytes));
         sober_attr_done(done);
     }
     return 0;
@@ -1105,6 +1118,14 @@ extern "C" int sober_car_safe_supported(int N, int m) { return car_one_cu(N, m);
         else if ((m_) <= 64 && (N_) <= 112) { constexpr int MS_ = 4, CQ_ = 7; LAUNCH; }                \
         else if ((N_) <= 112) { constexpr int MS_ = sober::CAR_MS, CQ_ = 7; LAUNCH; }                  \
         else { constexpr int MS_ = sober::CAR_MS, CQ_ = sober::CAR_CQ; LAUNCH; }                       \
+    } while (0)
+
+// the pivot kernel's instantiation by size: 64-row slots in use
+#define CAR_PIVOT_BY_SIZE(N_, LAUNCH)                                  \
+    do {                                                               \
+        if ((N_) <= 64) { constexpr int NQ_ = 1; LAUNCH; }             \
+        else if ((N_) <= 128) { constexpr int NQ_ = 2; LAUNCH; }       \
+        else { constexpr int NQ_ = 4; LAUNCH; }                        \
     } while (0)
 
 extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const double* mu_in,
@@ -1130,8 +1151,8 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
         LAUNCH_CHECK();
         hipLaunchKernelGGL(sober::k_car_phi, dim3(sober::CAR_PC / 4), dim3(256), 0, st, vws, taup, N, m, Phi, phi_out);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(sober::k_car_pivot_stream, dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m, mu_in,
-                           keep_rank, w_star, n_keep, mu_out, (const unsigned*)nullptr);
+        CAR_PIVOT_BY_SIZE(N, hipLaunchKernelGGL((sober::k_car_pivot_stream<NQ_>), dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m,
+                                                mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)nullptr));
         LAUNCH_CHECK();
         return 0;
     }
@@ -1145,8 +1166,8 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
     CAR_BY_SIZE(m, N, hipLaunchKernelGGL((sober::k_car_bidiag_fused<MS_, CQ_>), dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X, ldx,
                                          N, m, vws, taup, Phi, comm, (unsigned)sober::carf_bytes(m), epoch, spin_limit));
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(sober::k_car_pivot_stream, dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m, mu_in,
-                       keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm);
+    CAR_PIVOT_BY_SIZE(N, hipLaunchKernelGGL((sober::k_car_pivot_stream<NQ_>), dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m,
+                                            mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm));
     LAUNCH_CHECK();
     return 0;
 }
