@@ -21,10 +21,18 @@ for case in range(n_cases):
     N = int(rng.integers(max(2 * b + 1, M + 1), 40 * b + 50))
     n_obs = int(rng.integers(8, 60))
     kind = [O.RBF, O.MATERN52][int(rng.integers(0, 2))] if hasattr(O, "MATERN52") else O.RBF
+    tani = os.environ.get("FUZZ_KIND") == "tanimoto"
+    if tani:                                                 # fingerprints: 0/1 rows of 64..2048 bits
+        kind, d = O.TANIMOTO, int(rng.choice([64, 100, 512, 1000, 2048]))
+        b = min(b, 64)                                       # (a pool of random fingerprints has no more structure than that)
+        M = int(rng.integers(b + 8, max(b + 9, 4 * b))); N = int(rng.integers(max(2 * b + 1, M + 1), 40 * b + 50))
     mode = ["predictive_covariance", "kernel", "weighted_predictive_covariance"][int(rng.integers(0, 3))]
     use_obj = bool(rng.random() < 0.25) and b <= 100
     obj = (lambda Z: (Z ** 2).sum(1)) if use_obj else None
     X = rng.random((N, d)); Xo = rng.random((n_obs, d)); mu0 = rng.random(N); mu0 /= mu0.sum()
+    if tani:
+        pbit = float(rng.choice([0.03, 0.1, 0.3]))
+        X = (X < pbit).astype(np.float64); Xo = (Xo < pbit).astype(np.float64)
     Xn = X[rng.permutation(N)[:M]].copy()
     spec = O.make_spec(kind, t(Xo), t((0.25 + 0.5 * rng.random(d)) * np.sqrt(d)), outputscale=float(0.5 + 2 * rng.random()),
                        noise=1e-2, y_obs=t(rng.standard_normal(n_obs)))
