@@ -1,7 +1,7 @@
 """d = 1 case (tests/golden/d1_sensitivity.npz): the device run level by level against the oracle's trace."""
 import os, sys, warnings
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import sober_amd
 from tests.golden import make_golden as MG

@@ -1,9 +1,9 @@
 """Random small recombinations on the device against the oracle (same seeded inputs): batch sizes across the size
 instantiations of the Caratheodory kernels, leftovers of every kind, both continuous kernels, with and without the
-posterior correction.  python scripts/fuzz_parity.py [n_cases=60] [seed=0]"""
+posterior correction.  python tests/tools/fuzz_parity.py [n_cases=60] [seed=0]"""
 import os, sys, warnings, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import sober_amd
 from oracle import sober_oracle as O

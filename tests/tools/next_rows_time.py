@@ -4,11 +4,11 @@ time against the oracle (the torch-CPU restatement of the reference) on this box
   f2  WKDE prior: pdf over the pool, sampling                     (SOBER/_wkde.py:109-145, 221-248)
   f3  recombination with calc_obj (acquisition-guided branch)     (SOBER/_rchq.py:67-69, 79-106)
   f4  BASQ g-space kernel: resident matrix + quadrature           (SOBER/BASQ/_scale_mmlt.py:256-275, _basq.py:59-81)
-Usage: python scripts/next_rows_time.py   (the oracle is test infrastructure: this script is measurement, like bench.py's
+Usage: python tests/tools/next_rows_time.py   (the oracle is test infrastructure: this script is measurement, like bench.py's
 cpu_baseline leg)"""
 import os, sys, time, warnings
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import sober_amd
 from oracle import sober_oracle as O

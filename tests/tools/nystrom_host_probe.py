@@ -1,7 +1,7 @@
 """Where does the host part of the Nystrom basis go (run on the GPU box)?"""
 import os, sys, time, warnings
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import sober_oracle as O
 from tests.golden.synth import synth, build_spec
 from sober_amd._utils import SafeTensorOperator
