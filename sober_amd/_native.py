@@ -757,14 +757,15 @@ class PeerComm:
         return int(load().sober_peer_status(self.handle, None, 0, None))
 
     def self_check(self, dist, group) -> bool:
-        """Four calls with rank- and round-dependent data, short waits; every rank must see the exact sums."""
+        """Four calls with rank- and round-dependent data; every rank must see the exact sums.  The ranks enter together
+        (a barrier of the group first: a rank that is still loading the library must not look like a dead peer)."""
         import torch as _t
         lib = load()
         on_dev = dist.get_backend(group) == "nccl"
         ok = True
         try:
+            dist.barrier(group=group)
             with _t.cuda.device(self.device):
-                lib.sober_peer_set_spin_limit(self.handle, 1 << 21)
                 n = min(self.n_max, 4096)
                 base = _t.arange(n, dtype=_t.float64, device=self.device)
                 st = _t.cuda.current_stream(self.device)
@@ -774,7 +775,6 @@ class PeerComm:
                     st.synchronize()
                     want = (base + rnd) * float(self.world * (self.world + 1) // 2)
                     ok = ok and self.status() == 0 and bool(_t.equal(x, want))
-                lib.sober_peer_set_spin_limit(self.handle, 1 << 23)
         except Exception:
             ok = False
         self.ok = self._agree(dist, group, on_dev, ok)
