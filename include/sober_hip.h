@@ -319,6 +319,10 @@ int sober_level_reduce_tani(const void* rows, const double* rows_norm, int n_row
                             const double* mu, const double* wmul, double outputscale, int n_chunks, double* partG,
                             int ldg, int col0, double* partTot, int64_t tot_limit, void* stream);
 
+/* Xp[rank[s]][0:n] = X[s][0:n], objp[rank[s]] = ocol[s] for the sets s with 0 <= rank[s] < n1: the survivors of a
+ * Caratheodory step in rank order (SOBER/_rchq.py:87-91, :177-181), without a host decision.  Xp: n1 x n, objp: n1. */
+int sober_rank_scatter(const double* X, int ldx, int N, int n, const double* ocol, const int32_t* rank, int n1,
+                       double* Xp, double* objp, void* stream);
 /* *dst = v, in stream order (device memory; a one-thread kernel). */
 int sober_set_i64(int64_t* dst, int64_t v, void* stream);
 

@@ -29,6 +29,7 @@ SIGNATURES = {
     "sober_nystrom_job_size": (_i32, []),
     "sober_final_job_size": (_i32, []),
     "sober_set_i64": (_i32, [_vp, _i64, _vp]),
+    "sober_rank_scatter": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sober_plan_rows": (_i32, [_i32, _vp, _i32, _i64, _vp, _i32, _i64, _i32, _vp, _i32, _f64, _vp, _i32, _vp, _i32, _vp,
                                _vp, _vp, _vp, _vp]),
     "sober_level_loop_final": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -310,6 +311,13 @@ def pack_bits(X, words, norms, bad_flag):
     _req(bad_flag, torch.int32, "bad_flag")
     _check(load().sober_pack_bits(X.data_ptr(), n, d, X.stride(0), words.data_ptr(), words.shape[1],
                                   norms.data_ptr(), bad_flag.data_ptr(), _stream(X)), "sober_pack_bits")
+
+
+def rank_scatter(X, n, ocol, rank, n1, Xp, objp):
+    """sober_rank_scatter: rows X[s, :n] and ocol[s] of the sets with rank 0 .. n1-1 to their rank's place."""
+    _req(X, torch.float64, "X"); _req(ocol, torch.float64, "ocol"); _req(rank, torch.int32, "rank")
+    _check(load().sober_rank_scatter(X.data_ptr(), X.stride(0), X.shape[0], n, ocol.data_ptr(), rank.data_ptr(), n1,
+                                     Xp.data_ptr(), objp.data_ptr(), _stream(X)), "sober_rank_scatter")
 
 
 def plan_rows(kind, X_nys, X_obs, lengthscale, outputscale, S_cache, rows, Kall, W, T, G):

@@ -736,14 +736,13 @@ class HipOps:
                 return None
             # BOTH steps are enqueued before anything is read back (one synchronisation per level instead of three): the
             # second one assumes the regular outcome of the first -- exactly n + 2 survivors, whose rows go to their
-            # rank's place with plain indexed copies (ranks outside 0..n1-1 land in a spare row) -- and is simply
+            # rank's place (sober_rank_scatter; ranks outside 0..n1-1 are dropped) -- and is simply
             # discarded when the host then finds another count
             kr1, w1, nk1_d, _mu = self.car_device(X, mu_in)
-            rk = kr1.long()
-            rk = torch.where((rk >= 0) & (rk < n1), rk, torch.full_like(rk, n1))
-            Xp = torch.zeros(n1 + 1, n1f - 1, dtype=torch.float64, device=dev).index_copy_(0, rk, X[:, :n1f - 1])[:n1]
-            ocol = X[:, n1f - 1] if obj_head is None else obj_head[:N]
-            objp = torch.zeros(n1 + 1, dtype=torch.float64, device=dev).index_copy_(0, rk, ocol.contiguous())[:n1]
+            Xp = torch.zeros(n1, n1f - 1, dtype=torch.float64, device=dev)
+            objp = torch.zeros(n1, dtype=torch.float64, device=dev)
+            ocol = (X[:, n1f - 1] if obj_head is None else obj_head[:N]).contiguous()
+            nat.rank_scatter(X, n1f - 1, ocol, kr1, n1, Xp, objp)
             phi = torch.empty(n1, 1, dtype=torch.float64, device=dev)
             scratch = [torch.empty(n1, dtype=t_, device=dev) for t_ in (torch.int32, torch.float64, torch.float64)]
             nkx = torch.empty(1, dtype=torch.int32, device=dev)
@@ -752,7 +751,7 @@ class HipOps:
             keep_rank = torch.empty(N, dtype=torch.int32, device=dev)
             w_star = torch.empty(N, dtype=torch.float64, device=dev)
             n_keep = torch.empty(1, dtype=torch.int32, device=dev)
-            nat.second_elimination(phi, objp.contiguous(), w1, kr1, n1, keep_rank, w_star, n_keep)
+            nat.second_elimination(phi, objp, w1, kr1, n1, keep_rank, w_star, n_keep)
             (kr1_h, nk1_h, keep_h, nk_h) = self.to_host(kr1, nk1_d, keep_rank, n_keep)
             nk1 = int(nk1_h[0])
             if nk1 < 0:                                      # the first step gave up: once more on the next rung

@@ -626,6 +626,29 @@ extern "C" int sober_final_scatter(const int32_t* idx, int n, const int32_t* kee
 
 __global__ void k_set_i64(int64_t* dst, int64_t v) { *dst = v; }
 
+// rows of X (N x n, ld) and entries of ocol whose rank is 0 .. n1-1 go to that rank's place (Xp: n1 x n, objp: n1)
+__global__ void k_rank_scatter(const double* __restrict__ X, int ldx, int N, int n, const double* __restrict__ ocol,
+                               const int32_t* __restrict__ rank, int n1, double* __restrict__ Xp, double* __restrict__ objp) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)N * (n + 1)) return;
+    const int s = (int)(t / (n + 1)), j = (int)(t - (int64_t)s * (n + 1));
+    const int r = rank[s];
+    if (r < 0 || r >= n1) return;
+    if (j < n) Xp[(size_t)r * n + j] = X[(size_t)s * ldx + j];
+    else objp[r] = ocol[s];
+}
+
+// the survivors of a Caratheodory step in rank order: Xp[rank[s]] = X[s, 0:n], objp[rank[s]] = ocol[s] for the sets s whose
+// rank is 0 .. n1-1 (the acquisition-guided branch's second step, SOBER/_rchq.py:87-91 / :177-181, without a host decision)
+extern "C" int sober_rank_scatter(const double* X, int ldx, int N, int n, const double* ocol, const int32_t* rank, int n1,
+                                  double* Xp, double* objp, void* stream) {
+    if (!X || !ocol || !rank || !Xp || !objp || N <= 0 || n <= 0 || n1 <= 0 || ldx < n) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_rank_scatter, dim3(nblk((int64_t)N * (n + 1), 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, N, n, ocol,
+                       rank, n1, Xp, objp);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // *dst = v on the stream, as a one-thread kernel: a hipMemcpyAsync of 8 host bytes goes through the copy path and
 // holds the stream for ~20 us in front of the first queued level
 extern "C" int sober_set_i64(int64_t* dst, int64_t v, void* stream) {
