@@ -106,14 +106,18 @@ class DistComm:
             if pc is None or (pc is not False and pc.n_max < flat.numel()):
                 if pc:
                     pc.close()
+                why = "its set-up or self-check did not pass on every rank"
                 try:
                     pc = nat.PeerComm(dist, group, device, max(int(flat.numel()), 1 << 15))
                     if pc.ok:
                         pc.self_check(dist, group)
                     if not pc.ok:
                         pc = False
-                except Exception:
-                    pc = False
+                except Exception as e:                      # (a collective inside may have failed on this rank only)
+                    pc, why = False, f"{type(e).__name__}: {e}"
+                if pc is False:
+                    warnings.warn("sober_amd: the direct-peer all-reduce is not used for this group (" + why + "); the level "
+                                  "loop's all-reduce goes through RCCL / torch.distributed")
                 DistComm._PEER[key] = pc
             if pc is not False:
                 return pc.fn_ptr, pc.handle, pc
