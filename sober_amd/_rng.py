@@ -56,12 +56,13 @@ def device_randn(M: int, q: int, device):
     state = torch.get_rng_state() if _verified and numel >= 16 and not host_only else None
     if state is None or state.numel() != _STATE_BYTES:
         return torch.randn(M, q, dtype=torch.float64).to(device)
-    u = _pin.get(numel)
+    device = torch.device(device)
+    u = _pin.get((numel, device))
     if u is None:
-        u = _pin[numel] = torch.empty(numel + 16, dtype=torch.float64, pin_memory=True)
+        u = _pin[(numel, device)] = torch.empty(numel + 16, dtype=torch.float64, pin_memory=True)
     else:
         # the previous copy out of this staging buffer must have left before it is overwritten
-        ev = _pin.get(("ev", numel))
+        ev = _pin.get(("ev", numel, device))
         if ev is not None:
             ev.synchronize()
     nat.mt19937_uniform53(state, numel, u)
@@ -82,7 +83,7 @@ def device_randn(M: int, q: int, device):
         ud.copy_(u, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(side)
-    _pin[("ev", numel)] = ev
+    _pin[("ev", numel, device)] = ev
     main.wait_event(ev)
     R = torch.empty(M, q, dtype=torch.float64, device=device)
     nat.box_muller(ud, numel, R)
