@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOBER_ABI_VERSION 3
+#define SOBER_ABI_VERSION 4
 
 /* kernel families: model.covar_module.forward behind SOBER/_gp.py:292-294 */
 #define SOBER_KIND_RBF       0   /* outputscale * exp(-0.5 * |x/l - y/l|^2)                      */
@@ -343,9 +343,19 @@ int sober_level_reduce_mfma_queued_pair(int kind, const double* rows, int n_rows
                                         const double* wmul, double outputscale, int n_chunks_ub, double* partG,
                                         int ldg, double* partTot, int n_xchunks_ub, double* extraG, double* extraTot,
                                         const int64_t* dR, void* stream);
+/* chunked = 1: the partial sums come from an element-chunk kernel (sober_level_reduce_tani_queued: sober_level_chunks
+ * of them at the level's exact size), 0: from the matrix-core FP64 kernel (sober_level_parts_mfma slots per tile). */
 int sober_sum_partials_queued(const double* partG, const double* partTot, int n_rows, int ldg, int S,
                               const double* extraG, const double* extraTot, int n_xcols, double* G, int ldo,
-                              double* tot, const int64_t* dR, void* stream);
+                              double* tot, const int64_t* dR, int chunked, void* stream);
+/* The Tanimoto level kernel with the level size read from device memory (leftover = 0 / 1 like
+ * sober_level_reduce_mfma_queued); n_chunks_ub = sober_level_chunks_cap(n_rows, ceil(count_ub / S), S). */
+int sober_level_reduce_tani_queued(const void* rows, const double* rows_norm, int n_rows, const void* cand,
+                                   const double* cand_norm, int dt, const int32_t* idx, int64_t count_ub, int S,
+                                   int S_main, int leftover, const double* mu, const double* wmul, double outputscale,
+                                   int n_chunks_ub, double* partG, int ldg, double* partTot, const int64_t* dR,
+                                   void* stream);
+int sober_level_chunks_cap(int n_rows, int64_t e_total_ub, int S);
 /* K7 (SOBER/_rchq.py:198-221) with R = *dR_cur and n_keep = keep_rank[S] read on the device; *dR_next = the next
  * level's R, or -1 with mu and the list untouched when the host loop has to take over (R <= S, no progress,
  * n_keep outside 1..S, more than R_ub_next survivors).                                                       */

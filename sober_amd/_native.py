@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SOBER_HIP_LIB: a diagnostic build of the same library, e.g. the in-kernel-stamp build `make stamps`)
 LIB_PATH = os.environ.get("SOBER_HIP_LIB") or os.path.join(_HERE, "libsober_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 KIND_RBF, KIND_MATERN52, KIND_TANIMOTO = 0, 1, 2
 KIND_BY_NAME = {"rbf": KIND_RBF, "matern52": KIND_MATERN52, "tanimoto": KIND_TANIMOTO}
@@ -122,7 +122,10 @@ SIGNATURES = {
                                               _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_level_reduce_mfma_queued_pair": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _f64, _i32,
                                                    _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
-    "sober_sum_partials_queued": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "sober_sum_partials_queued": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "sober_level_reduce_tani_queued": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _f64,
+                                              _i32, _vp, _i32, _vp, _vp, _vp]),
+    "sober_level_chunks_cap": (_i32, [_i32, _i64, _i32]),
     "sober_level_update_queued": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_record_event_pair": (_i32, [_vp, _vp, _vp]),
     "sober_set_launch_events": (_i32, [_vp, _vp]),

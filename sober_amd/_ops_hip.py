@@ -464,7 +464,7 @@ class HipOps:
         w["w_star"], w["mu_out"] = torch.empty(S, dtype=f64, device=dev), torch.empty(S, dtype=f64, device=dev)
         w["h_flags"] = torch.empty(S + 1, dtype=torch.int32, pin_memory=True)
         w["h_flags_np"] = w["h_flags"].numpy()
-        if job.variant == nat.LEVEL_MFMA and self.queue_levels:
+        if job.variant in (nat.LEVEL_MFMA, nat.LEVEL_TANI) and self.queue_levels:
             # queued levels (csrc/level_exec.cpp): live positions per level, on the device and in pinned memory
             w["dR"] = torch.zeros(nat.LEVEL_QUEUE + 1, dtype=torch.int64, device=dev)
             w["h_dR"] = torch.zeros(nat.LEVEL_QUEUE + 1, dtype=torch.int64, pin_memory=True)

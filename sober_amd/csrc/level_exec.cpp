@@ -157,15 +157,29 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
         int32_t* nxt = (l & 1) ? idx_a : idx_b;
         for (int k = 0; k < 4; ++k) j->ev[k] = events ? events[4 * l + k] : nullptr;
         if (!(l == 0 && first_sums_ready)) {
-            const int nch = lx_chunks(j->n_rows, (Rub[l] + S - 1) / S, S);
-            const int nxch = lx_chunks(j->n_rows, (S - 1 + SOBER_LEVEL_XS - 1) / SOBER_LEVEL_XS, SOBER_LEVEL_XS);
+            const bool tani = j->variant == SOBER_LEVEL_TANI;
+            const int64_t e_ub = (Rub[l] + S - 1) / S, ex_ub = (S - 1 + SOBER_LEVEL_XS - 1) / SOBER_LEVEL_XS;
+            const int nch = tani ? sober_level_chunks_cap(j->n_rows, e_ub, S) : lx_chunks(j->n_rows, e_ub, S);
+            const int nxch = tani ? sober_level_chunks_cap(j->n_rows, ex_ub, SOBER_LEVEL_XS) : lx_chunks(j->n_rows, ex_ub, SOBER_LEVEL_XS);
             if (nch <= 0 || nch > SOBER_LEVEL_MAX_CHUNKS || nxch <= 0 || nxch > SOBER_LEVEL_MAX_CHUNKS) return SOBER_E_WS;
             LX_EVENTS_BEFORE(j->ev[0], j->ev[1])
             if (j->ev[0] && j->ev[1]) j->ev_used[0] |= 1ull << l;
             // (a level whose size is known exactly and leaves no leftover carries no leftover workgroups: the sums
-            //  kernel finds the same zero from dR); otherwise both placements travel in one launch
+            //  kernel finds the same zero from dR); otherwise both placements travel in one launch (matrix-core FP64
+            //  kernel) or in two queued ones (Tanimoto)
             const bool no_left = Rlo[l] == Rub[l] && Rub[l] % S == 0;
-            if (no_left || getenv("SOBER_LEVEL_TWO_LAUNCHES")) {
+            if (tani) {
+                LX_TRY(sober_level_reduce_tani_queued(j->rows, j->rows_norm, j->n_rows, j->cand, j->cand_norm, j->dim, cur,
+                                                      Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch, j->partG, S,
+                                                      j->partTot, j->dR + l, stream));
+                if (!no_left) {
+                    LX_EVENTS_BEFORE(j->ev[2], j->ev[3])
+                    if (j->ev[2] && j->ev[3]) j->ev_used[1] |= 1ull << l;
+                    LX_TRY(sober_level_reduce_tani_queued(j->rows, j->rows_norm, j->n_rows, j->cand, j->cand_norm, j->dim, cur,
+                                                          S - 1, SOBER_LEVEL_XS, S, 1, j->mu, j->wmul, j->outputscale, nxch,
+                                                          j->extraG, SOBER_LEVEL_XS, j->extraTot, j->dR + l, stream));
+                }
+            } else if (no_left || getenv("SOBER_LEVEL_TWO_LAUNCHES")) {
                 LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
                                                       j->dim, cur, Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch,
                                                       j->partG, S, j->partTot, j->dR + l, stream));
@@ -184,7 +198,7 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
                                                            j->extraTot, j->dR + l, stream));
             }
             LX_TRY(sober_sum_partials_queued(j->partG, j->partTot, j->n_rows, S, S, j->extraG, j->extraTot,
-                                             SOBER_LEVEL_XS, j->G, S, j->tot, j->dR + l, stream));
+                                             SOBER_LEVEL_XS, j->G, S, j->tot, j->dR + l, tani ? 1 : 0, stream));
         }
         // projection and barycentres in one launch (X_tmp = (P G)^T / tot: bit-identical to the two steps)
         LX_TRY(sober_dgemm_coldiv_t(n, S, j->n_rows, j->P, j->n_rows, j->G, S, j->tot, j->X_tmp, n, stream));
@@ -219,7 +233,7 @@ extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, i
     int32_t *cur = idx_a, *nxt = idx_b;
     int levels = 0;
     j->ev_used[0] = j->ev_used[1] = 0;
-    if (j->dR && j->h_dR && j->variant == SOBER_LEVEL_MFMA) {
+    if (j->dR && j->h_dR && (j->variant == SOBER_LEVEL_MFMA || (j->variant == SOBER_LEVEL_TANI && !getenv("SOBER_TANI_NO_QUEUE")))) {
         int done = 0;
         int64_t R_after = R;
         LX_TRY(lx_loop_queued(j, R, idx_a, idx_b, first_sums_ready, events, max_levels, level_R, &done, &R_after, stream));

@@ -159,6 +159,21 @@ static int launch_lr(const void* rows, const double* rows_norm, int n_rows, cons
 
 using namespace sober;
 
+// the largest value sober_level_chunks can take up to e_total_ub elements per set (what a launch sized ahead of time is
+// given: sober_level_reduce_tani_queued)
+extern "C" int sober_level_chunks_cap(int n_rows, int64_t e_total_ub, int S) {
+    if (n_rows <= 0 || e_total_ub <= 0 || S <= 0) return SOBER_E_ARG;
+    int best = 0;
+    // (the count is not monotone in the number of elements: n = min(target, 64, e) chunks of ceil(e / n) elements)
+    const int sb = (S + 15) / 16, rb = (n_rows + 255) / 256;
+    int64_t n = SOBER_CHUNK_TARGET / ((int64_t)sb * rb);
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    if (n > e_total_ub) n = e_total_ub;
+    best = (int)n;
+    return best;
+}
+
 extern "C" int sober_level_chunks(int n_rows, int64_t pos0, int64_t count, int S) {
     if (n_rows <= 0 || pos0 < 0 || count <= 0 || S <= 0) return SOBER_E_ARG;
     const int64_t e_total = (pos0 + count + S - 1) / S - pos0 / S;

@@ -64,8 +64,25 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     const double* __restrict__ mu, const double* __restrict__ wmul, double os,
     int64_t e_first, int e_total, int e_per_chunk,
     double* __restrict__ partG, int ldg, int col0,
-    double* __restrict__ partTot, int64_t tot_limit) {
+    double* __restrict__ partTot, int64_t tot_limit,
+    const int64_t* __restrict__ dR, int S_main, int leftover) {
     constexpr int SB = LT_SB;
+    if (dR != nullptr) {                        // queued level (level_exec.cpp): the launch was sized from an UPPER BOUND of
+        // the live positions; the exact number R sits in device memory.  leftover = 0: positions [0, R), set masses over
+        // [0, E S) (S = S_main); leftover = 1: the leftover positions [E S_main, R) over S pseudo-sets.  The chunk count
+        // follows from the exact size (the formula the host uses: level_chunks_for); surplus workgroups leave.
+        const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (R <= S_main) return;
+        const int64_t ES = (R / S_main) * S_main;
+        if (!leftover) { count = R; tot_limit = ES; }
+        else { idx += ES; count = R - ES; tot_limit = count; }
+        if (count <= 0) return;
+        pos0 = 0; e_first = 0;
+        e_total = (int)((count + S - 1) / S);
+        const int n_chunks = level_chunks_for(n_rows, e_total, S);
+        if ((int)blockIdx.y >= n_chunks) return;
+        e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
+    }
     constexpr int ROWB = DT * 64 + 32;                 // bytes per candidate in LDS: row stride = 8 dwords mod 64 banks -> the four lane groups of a ds_read_b128 are conflict-free (a 16-byte pad leaves a 2-way conflict in each)
     constexpr int TE = LT_TE;
     constexpr int NC = TE * SB;                        // candidates per tile
@@ -269,7 +286,7 @@ template <int DT>
 static int launch_lt(const void* rows, const double* rows_norm, int n_rows, const void* cand, const double* cand_norm,
                      const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu, const double* wmul,
                      double os, int n_chunks, double* partG, int ldg, int col0, double* partTot, int64_t tot_limit,
-                     hipStream_t st) {
+                     hipStream_t st, const int64_t* dR = nullptr, int S_main = 0, int leftover = 0) {
     const int64_t e_first = pos0 / S;
     const int e_total = (int)((pos0 + count + S - 1) / S - e_first);
     const int e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
@@ -278,7 +295,7 @@ static int launch_lt(const void* rows, const double* rows_norm, int n_rows, cons
     HIP_TRY(hipFuncSetAttribute((const void*)k_level_reduce_tani<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SOBER_LAUNCH_TIMED((k_level_reduce_tani<DT>), grid, dim3(LT_RW * 64), lds, st, (const unsigned long long*)rows,
                        rows_norm, n_rows, (const unsigned long long*)cand, cand_norm, idx, pos0, count, S, mu, wmul, os,
-                       e_first, e_total, e_per_chunk, partG, ldg, col0, partTot, tot_limit);
+                       e_first, e_total, e_per_chunk, partG, ldg, col0, partTot, tot_limit, dR, S_main, leftover);
     LAUNCH_CHECK();
     return 0;
 }
@@ -305,6 +322,28 @@ extern "C" int sober_level_reduce_tani(const void* rows, const double* rows_norm
                                       n_chunks, partG, ldg, col0, partTot, tot_limit, st);
         case 32: return launch_lt<32>(rows, rows_norm, n_rows, cand, cand_norm, idx, pos0, count, S, mu, wmul, outputscale,
                                       n_chunks, partG, ldg, col0, partTot, tot_limit, st);
+        default: return SOBER_E_DIM;
+    }
+}
+
+// queued form (see sober_level_loop): the level size is read from device memory; the launch is sized for count_ub
+// positions and n_chunks_ub chunks (sober_level_chunks_cap)
+extern "C" int sober_level_reduce_tani_queued(const void* rows, const double* rows_norm, int n_rows, const void* cand,
+                                              const double* cand_norm, int dt, const int32_t* idx, int64_t count_ub, int S,
+                                              int S_main, int leftover, const double* mu, const double* wmul,
+                                              double outputscale, int n_chunks_ub, double* partG, int ldg, double* partTot,
+                                              const int64_t* dR, void* stream) {
+    if (!rows || !rows_norm || !cand || !cand_norm || !idx || !mu || !partG || !dR) return SOBER_E_ARG;
+    if (n_rows <= 0 || count_ub <= 0 || S <= 0 || S_main <= 0 || n_chunks_ub <= 0 || ldg < S || (!leftover && S != S_main))
+        return SOBER_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dt) {
+        case 8: return launch_lt<8>(rows, rows_norm, n_rows, cand, cand_norm, idx, 0, count_ub, S, mu, wmul, outputscale,
+                                    n_chunks_ub, partG, ldg, 0, partTot, 0, st, dR, S_main, leftover);
+        case 16: return launch_lt<16>(rows, rows_norm, n_rows, cand, cand_norm, idx, 0, count_ub, S, mu, wmul, outputscale,
+                                      n_chunks_ub, partG, ldg, 0, partTot, 0, st, dR, S_main, leftover);
+        case 32: return launch_lt<32>(rows, rows_norm, n_rows, cand, cand_norm, idx, 0, count_ub, S, mu, wmul, outputscale,
+                                      n_chunks_ub, partG, ldg, 0, partTot, 0, st, dR, S_main, leftover);
         default: return SOBER_E_DIM;
     }
 }

@@ -98,7 +98,7 @@ __global__ void k_sum_partials(const double* __restrict__ partG, const double* _
                                const double* __restrict__ extraG, const double* __restrict__ extraTot,
                                int n_xchunks, int n_xcols,
                                double* __restrict__ G, int ldo, double* __restrict__ tot,
-                               const int64_t* __restrict__ dR) {
+                               const int64_t* __restrict__ dR, int chunked) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;            // row == n_rows -> the tot vector
     if (s >= S) return;
@@ -106,8 +106,10 @@ __global__ void k_sum_partials(const double* __restrict__ partG, const double* _
         const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (R <= S) return;
         const int64_t E = R / S, left = R - E * S;
-        n_chunks = level_parts_mfma_for(n_rows, (R + S - 1) / S, S);
-        n_xchunks = left > 0 ? level_parts_mfma_for(n_rows, (left + n_xcols - 1) / n_xcols, n_xcols) : 0;
+        // (chunked: the element-chunk kernels -- Tanimoto --, else the matrix-core FP64 kernel's slots per tile)
+        n_chunks = chunked ? level_chunks_for(n_rows, (R + S - 1) / S, S) : level_parts_mfma_for(n_rows, (R + S - 1) / S, S);
+        n_xchunks = left <= 0 ? 0 : (chunked ? level_chunks_for(n_rows, (left + n_xcols - 1) / n_xcols, n_xcols)
+                                             : level_parts_mfma_for(n_rows, (left + n_xcols - 1) / n_xcols, n_xcols));
         if (left <= 0) { extraG = nullptr; extraTot = nullptr; }
     }
     const bool fold = (extraG != nullptr) && (s == S - 1);
@@ -558,20 +560,20 @@ extern "C" int sober_sum_partials(const double* partG, const double* partTot, in
     if (extraG && (n_xchunks <= 0 || n_xcols <= 0)) return SOBER_E_ARG;
     dim3 grid(nblk(S, 64), (unsigned)(n_rows + 1));
     hipLaunchKernelGGL(k_sum_partials, grid, dim3(64), 0, (hipStream_t)stream, partG, partTot, n_chunks,
-                       n_rows, ldg, S, extraG, extraTot, n_xchunks, n_xcols, G, ldo, tot, (const int64_t*)nullptr);
+                       n_rows, ldg, S, extraG, extraTot, n_xchunks, n_xcols, G, ldo, tot, (const int64_t*)nullptr, 0);
     LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sober_sum_partials_queued(const double* partG, const double* partTot, int n_rows, int ldg, int S,
                                          const double* extraG, const double* extraTot, int n_xcols, double* G,
-                                         int ldo, double* tot, const int64_t* dR, void* stream) {
+                                         int ldo, double* tot, const int64_t* dR, int chunked, void* stream) {
     if (!partG || !partTot || !extraG || !extraTot || !G || !tot || !dR || n_rows <= 0 || S <= 0 || ldg < S || ldo < S ||
         n_xcols <= 0)
         return SOBER_E_ARG;
     dim3 grid(nblk(S, 64), (unsigned)(n_rows + 1));
     hipLaunchKernelGGL(k_sum_partials, grid, dim3(64), 0, (hipStream_t)stream, partG, partTot, 0, n_rows, ldg, S,
-                       extraG, extraTot, 0, n_xcols, G, ldo, tot, dR);
+                       extraG, extraTot, 0, n_xcols, G, ldo, tot, dR, chunked);
     LAUNCH_CHECK();
     return 0;
 }
