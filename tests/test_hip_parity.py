@@ -139,6 +139,19 @@ def test_leftover_workgroups_in_the_main_launch_equal_two_launches(dev, monkeypa
         assert np.array_equal(idx1.cpu().numpy(), z["idx"])
 
 
+def test_fingerprint_levels_queued_equal_synchronised(dev, monkeypatch):
+    """Fingerprint pools (Tanimoto set sums on the INT8 matrix cores): the levels queued behind device-resident sizes
+    (sober_level_reduce_tani_queued) against the loop that synchronises after every level -- the same bits, and the
+    reference's result."""
+    path = os.path.join(GOLD, "recomb_tanimoto_weighted.npz")
+    monkeypatch.delenv("SOBER_TANI_NO_QUEUE", raising=False)
+    _, _, z, idx1, w1, mu1 = run_hip(path, dev)
+    monkeypatch.setenv("SOBER_TANI_NO_QUEUE", "1")
+    _, _, _, idx2, w2, mu2 = run_hip(path, dev)
+    assert torch.equal(idx1, idx2) and torch.equal(w1, w2) and torch.equal(mu1, mu2)
+    assert np.array_equal(idx1.cpu().numpy(), z["idx"])
+
+
 def test_moment_identity_without_leftovers(dev):
     path = os.path.join(GOLD, "recomb_rbf_noleft.npz")
     trace = {}
