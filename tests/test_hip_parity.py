@@ -140,16 +140,37 @@ def test_leftover_workgroups_in_the_main_launch_equal_two_launches(dev, monkeypa
 
 
 def test_fingerprint_levels_queued_equal_synchronised(dev, monkeypatch):
-    """Fingerprint pools (Tanimoto set sums on the INT8 matrix cores): the levels queued behind device-resident sizes
-    (sober_level_reduce_tani_queued) against the loop that synchronises after every level -- the same bits, and the
-    reference's result."""
-    path = os.path.join(GOLD, "recomb_tanimoto_weighted.npz")
-    monkeypatch.delenv("SOBER_TANI_NO_QUEUE", raising=False)
-    _, _, z, idx1, w1, mu1 = run_hip(path, dev)
-    monkeypatch.setenv("SOBER_TANI_NO_QUEUE", "1")
-    _, _, _, idx2, w2, mu2 = run_hip(path, dev)
-    assert torch.equal(idx1, idx2) and torch.equal(w1, w2) and torch.equal(mu1, mu2)
-    assert np.array_equal(idx1.cpu().numpy(), z["idx"])
+    """Fingerprint pools of 512+ bits (Tanimoto set sums on the INT8 matrix cores): the levels queued behind
+    device-resident sizes (sober_level_reduce_tani_queued) against the loop that synchronises after every level -- the
+    same bits, and the oracle's result on the same inputs."""
+    from tests.golden.synth import synth, build_spec
+    for d, mode in ((512, "predictive_covariance"), (2048, "weighted_predictive_covariance")):
+        case = dict(kind="tanimoto", mode=mode, N=9000, M=120, d=d, b=24, n_obs=30, seed=3, ard=False, bit_p=0.05,
+                    mean_const=0.4)
+        inp = synth(case)
+        spec = build_spec(case, inp)
+        outs = []
+        for sync in (False, True):
+            if sync:
+                monkeypatch.setenv("SOBER_TANI_NO_QUEUE", "1")
+            else:
+                monkeypatch.delenv("SOBER_TANI_NO_QUEUE", raising=False)
+            mu = _t(inp["mu0"].copy()).to(dev)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                torch.manual_seed(SEED_CALL)
+                idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                                 sober_amd.Kernel(kspec(spec), mode), init_weights=mu)
+            outs.append((idx, w, mu))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+        mu_ref = _t(inp["mu0"].copy())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.manual_seed(SEED_CALL)
+            idx_ref, w_ref = O.recombination(_t(inp["X_cand"]), _t(inp["X_nys"]), case["b"], O.Kernel(spec, mode),
+                                             init_weights=mu_ref)
+        assert np.array_equal(outs[0][0].cpu().numpy(), idx_ref.numpy())
+        np.testing.assert_allclose(outs[0][1].cpu().numpy(), w_ref.numpy(), rtol=W_RTOL)
 
 
 def test_moment_identity_without_leftovers(dev):
