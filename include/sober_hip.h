@@ -355,6 +355,11 @@ int sober_level_reduce_tani_queued(const void* rows, const double* rows_norm, in
                                    int S_main, int leftover, const double* mu, const double* wmul, double outputscale,
                                    int n_chunks_ub, double* partG, int ldg, double* partTot, const int64_t* dR,
                                    void* stream);
+int sober_level_reduce_tani_queued_pair(const void* rows, const double* rows_norm, int n_rows, const void* cand,
+                                        const double* cand_norm, int dt, const int32_t* idx, int64_t count_ub, int S,
+                                        int n_xcols, const double* mu, const double* wmul, double outputscale,
+                                        int n_chunks_ub, double* partG, int ldg, double* partTot, int n_xchunks_ub,
+                                        double* extraG, double* extraTot, const int64_t* dR, void* stream);
 int sober_level_chunks_cap(int n_rows, int64_t e_total_ub, int S);
 /* K7 (SOBER/_rchq.py:198-221) with R = *dR_cur and n_keep = keep_rank[S] read on the device; *dR_next = the next
  * level's R, or -1 with mu and the list untouched when the host loop has to take over (R <= S, no progress,

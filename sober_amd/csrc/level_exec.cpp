@@ -168,7 +168,12 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
             //  kernel finds the same zero from dR); otherwise both placements travel in one launch (matrix-core FP64
             //  kernel) or in two queued ones (Tanimoto)
             const bool no_left = Rlo[l] == Rub[l] && Rub[l] % S == 0;
-            if (tani) {
+            if (tani && !no_left && !getenv("SOBER_LEVEL_TWO_LAUNCHES")) {
+                LX_TRY(sober_level_reduce_tani_queued_pair(j->rows, j->rows_norm, j->n_rows, j->cand, j->cand_norm, j->dim, cur,
+                                                           Rub[l], S, SOBER_LEVEL_XS, j->mu, j->wmul, j->outputscale, nch,
+                                                           j->partG, S, j->partTot, nxch, j->extraG, j->extraTot, j->dR + l,
+                                                           stream));
+            } else if (tani) {
                 LX_TRY(sober_level_reduce_tani_queued(j->rows, j->rows_norm, j->n_rows, j->cand, j->cand_norm, j->dim, cur,
                                                       Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch, j->partG, S,
                                                       j->partTot, j->dR + l, stream));

@@ -65,8 +65,10 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     int64_t e_first, int e_total, int e_per_chunk,
     double* __restrict__ partG, int ldg, int col0,
     double* __restrict__ partTot, int64_t tot_limit,
-    const int64_t* __restrict__ dR, int S_main, int leftover) {
+    const int64_t* __restrict__ dR, int S_main, int leftover,
+    int S_x, double* __restrict__ partG_x, int ldg_x, double* __restrict__ partTot_x) {
     constexpr int SB = LT_SB;
+    int bx = blockIdx.x;                        // my set group
     if (dR != nullptr) {                        // queued level (level_exec.cpp): the launch was sized from an UPPER BOUND of
         // the live positions; the exact number R sits in device memory.  leftover = 0: positions [0, R), set masses over
         // [0, E S) (S = S_main); leftover = 1: the leftover positions [E S_main, R) over S pseudo-sets.  The chunk count
@@ -74,6 +76,11 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
         const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (R <= S_main) return;
         const int64_t ES = (R / S_main) * S_main;
+        if (leftover == 2) {                    // both placements in one grid: the set groups behind the main launch's are
+            const int g_main = (S_main + SB - 1) / SB;                 // the leftover launch's (S_x pseudo-sets, its own sums)
+            if (bx >= g_main) { leftover = 1; bx -= g_main; S = S_x; partG = partG_x; ldg = ldg_x; partTot = partTot_x; }
+            else leftover = 0;
+        }
         if (!leftover) { count = R; tot_limit = ES; }
         else { idx += ES; count = R - ES; tot_limit = count; }
         if (count <= 0) return;
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     const int lj = lane & 15, lk = lane >> 4;
     // (an XCD-aware one-dimensional grid -- the row blocks of one (set group, chunk) on ONE XCD, as in the FP64 level
     //  kernel -- was measured 16 % SLOWER here: 809 vs 695 us at level 0 of configuration 5)
-    const int s0 = blockIdx.x * SB;
+    const int s0 = bx * SB;
     const int chunk = blockIdx.y;
     const int row0 = blockIdx.z * LT_ROWS + wave * (LT_RT * 16);
     const int e0 = chunk * e_per_chunk;
@@ -286,16 +293,22 @@ template <int DT>
 static int launch_lt(const void* rows, const double* rows_norm, int n_rows, const void* cand, const double* cand_norm,
                      const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu, const double* wmul,
                      double os, int n_chunks, double* partG, int ldg, int col0, double* partTot, int64_t tot_limit,
-                     hipStream_t st, const int64_t* dR = nullptr, int S_main = 0, int leftover = 0) {
+                     hipStream_t st, const int64_t* dR = nullptr, int S_main = 0, int leftover = 0, int S_x = 0, int n_xchunks = 0,
+                     double* partG_x = nullptr, int ldg_x = 0, double* partTot_x = nullptr) {
     const int64_t e_first = pos0 / S;
     const int e_total = (int)((pos0 + count + S - 1) / S - e_first);
     const int e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
     dim3 grid((S + LT_SB - 1) / LT_SB, n_chunks, (n_rows + LT_ROWS - 1) / LT_ROWS);
+    if (leftover == 2) {                                               // + the leftover launch's set groups and chunks
+        grid.x += (unsigned)((S_x + LT_SB - 1) / LT_SB);
+        if ((unsigned)n_xchunks > grid.y) grid.y = (unsigned)n_xchunks;
+    }
     const size_t lds = (size_t)2 * LT_TE * LT_SB * (DT * 64 + 32) + 4 * LT_TE * LT_SB * sizeof(double);
     HIP_TRY(hipFuncSetAttribute((const void*)k_level_reduce_tani<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SOBER_LAUNCH_TIMED((k_level_reduce_tani<DT>), grid, dim3(LT_RW * 64), lds, st, (const unsigned long long*)rows,
                        rows_norm, n_rows, (const unsigned long long*)cand, cand_norm, idx, pos0, count, S, mu, wmul, os,
-                       e_first, e_total, e_per_chunk, partG, ldg, col0, partTot, tot_limit, dR, S_main, leftover);
+                       e_first, e_total, e_per_chunk, partG, ldg, col0, partTot, tot_limit, dR, S_main, leftover, S_x, partG_x,
+                       ldg_x, partTot_x);
     LAUNCH_CHECK();
     return 0;
 }
@@ -346,4 +359,25 @@ extern "C" int sober_level_reduce_tani_queued(const void* rows, const double* ro
                                       n_chunks_ub, partG, ldg, 0, partTot, 0, st, dR, S_main, leftover);
         default: return SOBER_E_DIM;
     }
+}
+
+// both placements of a queued level in ONE launch: the leftover launch's set groups ride behind the main ones
+extern "C" int sober_level_reduce_tani_queued_pair(const void* rows, const double* rows_norm, int n_rows, const void* cand,
+                                                   const double* cand_norm, int dt, const int32_t* idx, int64_t count_ub,
+                                                   int S, int n_xcols, const double* mu, const double* wmul,
+                                                   double outputscale, int n_chunks_ub, double* partG, int ldg,
+                                                   double* partTot, int n_xchunks_ub, double* extraG, double* extraTot,
+                                                   const int64_t* dR, void* stream) {
+    if (!rows || !rows_norm || !cand || !cand_norm || !idx || !mu || !partG || !dR || !extraG || !extraTot) return SOBER_E_ARG;
+    if (n_rows <= 0 || count_ub <= 0 || S <= 1 || n_xcols <= 0 || n_chunks_ub <= 0 || n_xchunks_ub <= 0 || ldg < S) return SOBER_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+#define LT_PAIR(T) launch_lt<T>(rows, rows_norm, n_rows, cand, cand_norm, idx, 0, count_ub, S, mu, wmul, outputscale, n_chunks_ub, \
+                                partG, ldg, 0, partTot, 0, st, dR, S, 2, n_xcols, n_xchunks_ub, extraG, n_xcols, extraTot)
+    switch (dt) {
+        case 8: return LT_PAIR(8);
+        case 16: return LT_PAIR(16);
+        case 32: return LT_PAIR(32);
+        default: return SOBER_E_DIM;
+    }
+#undef LT_PAIR
 }
