@@ -410,6 +410,7 @@ def main():
         "ms_per_step_incl_kmeans": None if kmeans_ms is None else ms_per_step + kmeans_ms,
         "phases_ms_per_step": {k: v / args.steps * 1e3 for k, v in timers.items()},
         "ms_each_step": [round(v * 1e3, 3) for v in per_step],
+        "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2] * 1e3, 3),    # (the steps without event pairs or host hiccups)
         "n_selected": int(idx.numel()),
     }
     print(json.dumps(out))
