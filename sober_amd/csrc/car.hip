@@ -999,568 +999,6 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
 #endif
 }
 
-// ---------------- phase 3, team form (round 4): N > 128 ----------------
-// The streaming kernel above runs the ratio test of a 200-point step on ONE wave: four row slots per lane, so every
-// element-wise operation of the chain -- two IEEE divisions, the order-preserving key, the selects, the weights, the
-// block's eliminations -- is issued four times, and the stamps (profiles/r03_pivot_stamps.txt) show the pivot's
-// 0.95 us to be that one wave's ~300 in-order instructions.  Splitting the rows of the pivot column across four waves
-// cuts the chain to ~130 instructions per wave -- and gains NOTHING while the eliminations of the other hundred columns
-// share the compute unit: one CU issues one vector instruction per SIMD every four cycles, the eliminations are ~7
-// instructions per live column and pivot, and a CU that runs chain and eliminations is issue-bound at ~0.9 us per pivot
-// whatever the layout (measured: the team alone 0.27 us per pivot, with the store beside it 0.95).  So the work is
-// spread over THREE compute units of one XCD, by how soon a column is needed:
-//   * CHAIN TEAM (workgroup 0, waves 0-3, one per SIMD): wave q holds rows 64 q + lane of the current block of seven
-//     columns and the weights of those rows.  Per pivot every wave finds its own winner (lane-local key, DPP minimum,
-//     ballot); the winner's LANE writes {key | tag, quotient, reciprocal of the pivot entry, its entries of the block's
-//     remaining columns} to LDS; the four waves read the four keys (one LDS round trip), pick the smallest (key, row) --
-//     torch.argmin's first minimum, a NaN wins --, read the winner's data and eliminate the block's remaining columns on
-//     their own rows.  No reduction crosses a wave, no barrier.  Every pivot is published twice: in the LDS ring (for
-//     the near store) and as data-tagged 16-byte granules in global memory (for the far store).
-//   * NEAR STORE (workgroup 0, waves 4-7): wave k holds ONE block at a time -- all 200 rows of its seven columns, four
-//     slots per lane like the streaming kernel's consumers: the pivot row's entry is a v_readlane away --, follows the LDS
-//     ring, and hands the block to the chain team through LDS right after the pivot BEFORE the last one of the block in
-//     front has been applied; the team picks it up inside that last step (behind its local ratio test, in front of the
-//     exchange), so the winner's lanes also carry their entries of the seven new columns and the last pivot is applied
-//     by the team itself: the hand-over costs the chain what the store is late by, not a round trip.  Then the wave takes
-//     its next block (four blocks further on) from the far store and catches up from the ring.
-//   * FAR STORE (two more workgroups, elected onto workgroup 0's XCD): one wave per block from the sixth on, fed by a
-//     FETCHER wave that mirrors the global pivot stream into the workgroup's own LDS ring (several pivots in flight per
-//     L2 round trip).  A far wave applies the pivots up to 40 before its block's turn, leaves the block in global memory
-//     as tagged granules and exits: the 1-2 us between compute units are never on the chain.
-// Same element-wise arithmetic as the streaming kernel (mu / col and 1 / col as IEEE divisions, multiplier times
-// reciprocal, one fma): keep_rank, w_star and mu_out are the same bits (scripts/pivot_team_check.py).  Every wait is
-// bounded: a far workgroup that is not resident makes the near store give up, n_keep = -1, and the caller redoes the step
-// on the streaming kernel (sober_car_device_ex, SOBER_CAR_SAFE).
-constexpr int TP_BC = 7, TP_RING = 32, TP_NEAR = 4, TP_FARW = 7;     // block width; LDS ring slots; near-store waves; far waves per workgroup
-constexpr int TP_FAR0 = 1 + TP_NEAR;                                 // blocks 0 .. 4 start on workgroup 0, the others in the far store
-constexpr int TP_LEAD = 40;                                          // a far block is left behind pivot 7 t - TP_LEAD
-constexpr int TP_KMAX = SP_W * SP_BC;                                // 112 columns: the one-CU limit
-constexpr int TP_NBLK = (TP_KMAX + TP_BC - 1) / TP_BC;               // 16 blocks
-constexpr int TP_FARG = (TP_NBLK - TP_FAR0 + TP_FARW - 1) / TP_FARW; // far workgroups (2)
-constexpr int TP_THREADS = 512;                                      // eight waves: 256 registers each
-constexpr int TP_BIG = 1 << 28;
-constexpr unsigned TP_SPIN_LIMIT = 1u << 22;
-struct alignas(16) TpSlot {             // one pivot as a store wave sees it; in workgroup 0 chain wave q fills its row slot's part
-    double col[256];
-    double rpp[4];                      // 1 / pivot entry (one copy per chain wave: each releases its own part)
-    int tp[4];                          // per row slot: (s + 1) | (pivot row + 1) << 16   (pivot row + 1 = 0: the loop ends, Q6)
-};
-struct alignas(16) TpX { car_u32x4 g0; double d[10]; };   // chain exchange: {key lo, tag, key hi, tag}; quotient, 1/col, <= 7 entries
-// A workgroup's LDS block, by byte offset (small hot structures first: their offsets fit the instructions' 16 bits).
-constexpr unsigned TP_O_PROG = 0, TP_O_CNT = 64, TP_O_ROLE = 80, TP_O_FAIL = 96, TP_O_X = 128, TP_O_DTAG = TP_O_X + (unsigned)sizeof(TpX) * 8,
-                   TP_O_DL = TP_O_DTAG + 64, TP_O_RING = TP_O_DL + 8u * 2 * TP_BC * 256,
-                   TP_LDS_BYTES = TP_O_RING + (unsigned)sizeof(TpSlot) * TP_RING;
-static_assert(TP_O_DL % 16 == 0 && TP_O_RING % 16 == 0, "16-byte granules");
-__host__ __device__ constexpr size_t tp_lds_bytes() { return TP_LDS_BYTES; }
-// The launch's block in global memory (the caller's workspace), by byte offset.  Nothing is ever cleared: every granule
-// {lo, tag, hi, tag} carries the launch's epoch.
-constexpr unsigned TP_G_XCD = 0, TP_G_TICKET = 4, TP_G_RING = 256, TP_G_PIVOT = 257u * 16u,      // a pivot: 256 column granules + 1 / pivot
-                   TP_G_H = TP_G_RING + TP_KMAX * TP_G_PIVOT, TP_G_BLOCK = TP_BC * 256u * 16u,
-                   TP_G_BYTES = TP_G_H + (TP_NBLK - TP_FAR0) * TP_G_BLOCK;
-__host__ __device__ constexpr int64_t tp_global_bytes() { return TP_G_BYTES; }
-__device__ __forceinline__ unsigned tp_ring_tag(unsigned epoch, int s, int piv) { return (epoch << 16) | ((unsigned)(s + 1) << 9) | (unsigned)(piv + 1); }
-__device__ __forceinline__ unsigned tp_block_tag(unsigned epoch, int t, int j) { return (epoch << 16) | 0x8000u | ((unsigned)t << 4) | (unsigned)j; }
-// Every LDS access goes through an explicit LDS pointer formed from the block's base address -- through generic
-// pointers the compiler turned the tag stores into FLAT stores, which are not ordered with the ds_write of the data they
-// release -- and every step takes the base through tp_fresh(): without it the compiler hoists two dozen lane-dependent
-// addresses out of the pivot loop and spills the columns to scratch to make room for them.
-#define TP_LDSQ __attribute__((address_space(3)))
-#define TP_P(T, b, off) ((TP_LDSQ T*)(unsigned)((b) + (off)))
-#define TP_VI(p) (*(volatile TP_LDSQ int*)&(p))
-__device__ __forceinline__ unsigned tp_fresh(unsigned b) { asm volatile("" : "+v"(b)); return b; }
-__device__ __forceinline__ bool tp_failed(unsigned b) { return __builtin_amdgcn_readfirstlane(*TP_P(volatile int, b, TP_O_FAIL)) != 0; }
-__device__ __forceinline__ void tp_fail(unsigned b) { *TP_P(volatile int, b, TP_O_FAIL) = 1; }
-#define TP_SPIN_OR(b, spins, ACTION) if (++(spins) > TP_SPIN_LIMIT || (((spins) & 255u) == 0u && tp_failed(b))) { tp_fail(b); ACTION; }
-#ifdef TP_STAMPS      // diagnostic build (scripts/pivot_team_stamps.py): s_memrealtime (100 MHz) of every publish, by pivot index
-__device__ unsigned long long g_tp_stamps[520];   // 0..: chain publishes; 256 result out, 257 kernel entry; 260 + t: block t reaches the near store; 300 + t: far wave done; 400 + s: fetcher commits
-#define TP_STAMP(K) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_tp_stamps[K] = t_; } while (0)
-#else
-#define TP_STAMP(K) do { } while (0)
-#endif
-struct TpG { car_rsrc_t rs; unsigned epoch; };
-#ifdef TP_STAMPS
-__device__ unsigned long long g_tp_phase[4 * 8];   // per chain wave: cycles by segment of the step, summed over the pivots
-#define TP_PH_DECL unsigned long long ph_t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_t_) :: "memory");
-#define TP_PH(K, CON, DEP) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), CON(DEP) :: "memory"); \
-        if (lane == 0) g_tp_phase[q * 8 + (K)] += t_ - ph_t_; ph_t_ = t_; } while (0)
-#else
-#define TP_PH_DECL
-#define TP_PH(K, CON, DEP) do { } while (0)
-#endif
-
-// the wave's minimum as an SGPR: v_min_u32 with the DPP modifier on its first operand (one instruction per stage where
-// the builtin form costs a move, the DPP move and the minimum)
-__device__ __forceinline__ unsigned tp_wave_min_u32(unsigned v) {
-    unsigned r;
-    asm volatile("s_nop 1\n\t"
-                 "v_min_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
-                 : "=&v"(r) : "v"(v));
-    return (unsigned)__builtin_amdgcn_readlane((int)r, 63);
-}
-
-// One pivot of the chain team: column JJ of its current block.  PICK (the block's last step, a block behind it): the
-// next block's nb1 columns are taken from the near store in front of the exchange and the pivot is applied to them too.
-// -> pivot row, -1 = no candidate (Q6), -2 = gave up
-template <int JJ, bool PICK>
-__device__ __forceinline__ int tp_chain_step(double (&blk)[TP_BC], double (&nxt)[TP_BC], double& mu, int& dead, const unsigned lds0,
-                                             const TpG& G, const int s, const int q, const int lane, const int nb1, const int blk1) {
-    const unsigned b = tp_fresh(lds0);
-    TP_PH_DECL
-    const double col = dead ? 0.0 : blk[JJ];                         // (dead: cancelled rows, and the rows beyond N from the start)
-    const double rt = mu / col;
-    double rc = 1.0 / col;
-    asm volatile("" : "+v"(rc));                                     // (beside the quotient, not behind the argmin: only the winner's lane stores it)
-    const bool ok = col > 0.0;
-    const unsigned long long k = ratio_key(rt);
-    unsigned kh = ok ? (unsigned)(k >> 32) : 0xffffffffu;           // (a key's high word never reaches 0xffffffff: +inf is 0xfff00000)
-    const unsigned kl = ok ? (unsigned)k : 0xffffffffu;
-    TP_PH(0, "+v", kh);                                 // divisions, keys
-    unsigned H = tp_wave_min_u32(kh);
-    TP_PH(1, "+s", H);                                               // the wave's minimum
-    const bool none = H == 0xffffffffu;                              // uniform: no candidate among my rows
-    int f = 0;
-    if (!none) {
-        unsigned long long mb = __ballot(kh == H);
-        if (__popcll(mb) != 1) {                                     // rare: several quotients share the high word
-            const unsigned Lw = tp_wave_min_u32((kh == H) ? kl : 0xffffffffu);
-            mb = __ballot((kh == H) & (kl == Lw));
-        }
-        f = __ffsll((long long)mb) - 1;
-    }
-    if constexpr (PICK) {                                            // the next block, as the near store left it behind pivot s - 1
-        volatile TP_LDSQ int* dt = TP_P(volatile int, b, TP_O_DTAG);
-        const TP_LDSQ double* dl = TP_P(double, b, TP_O_DL) + (blk1 & 1) * TP_BC * 256 + 64 * q + lane;
-        unsigned spins = 0;
-#ifndef TP_X_NONEAR
-        while (__builtin_amdgcn_readfirstlane(dt[blk1 & 1]) != blk1 + 1) {
-            TP_SPIN_OR(b, spins, return -2)
-        }
-#endif
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < TP_BC; ++j) nxt[j] = (j < nb1) ? dl[j * 256] : 0.0;
-    }
-    TP_PH(2, "+s", f);                                               // ballots, the winner's lane (and the next block's pick-up)
-    TP_LDSQ TpX* xb = TP_P(TpX, b, TP_O_X) + (s & 1) * 4;
-    unsigned tagl = (unsigned)(s + 1) | ((unsigned)f << 16);
-    asm volatile("" : "+s"(tagl));                                   // (kept scalar: inside the branch the compiler writes f as `lane`, hoists lane << 16 out of the loop and spills it)
-    if (lane == f) {                                                 // my winner's lane writes the record (lane 0: "none")
-        TP_LDSQ TpX& xr = xb[q];
-        xr.d[0] = rt; xr.d[1] = rc;
-        if constexpr (PICK) {
-#pragma unroll
-            for (int j = 0; j < TP_BC; ++j) xr.d[2 + j] = nxt[j];
-        } else {
-#pragma unroll
-            for (int j = JJ + 1; j < TP_BC; ++j) xr.d[2 + j - (JJ + 1)] = blk[j];
-        }
-        asm volatile("" ::: "memory");                               // (a wave's LDS operations execute in order: the key
-        car_u32x4 gk;                                                //  granule lands after the data it releases)
-        gk.x = none ? 0xffffffffu : kl; gk.y = tagl; gk.z = none ? 0xffffffffu : kh; gk.w = tagl;
-        *(volatile TP_LDSQ car_u32x4*)&xr.g0 = gk;
-    }
-    TP_PH(3, "+s", tagl);                                            // my record
-    // the four keys (uniform addresses: broadcast reads)
-    car_u32x4 r0, r1, r2, r3;
-    unsigned spins = 0;
-    const unsigned want = (unsigned)(s + 1);
-    for (;;) {
-        r0 = *(volatile TP_LDSQ car_u32x4*)&xb[0].g0; r1 = *(volatile TP_LDSQ car_u32x4*)&xb[1].g0;
-        r2 = *(volatile TP_LDSQ car_u32x4*)&xb[2].g0; r3 = *(volatile TP_LDSQ car_u32x4*)&xb[3].g0;
-        const bool all = ((r0.y & 0xffffu) == want) & (r0.y == r0.w) & ((r1.y & 0xffffu) == want) & (r1.y == r1.w) &
-                         ((r2.y & 0xffffu) == want) & (r2.y == r2.w) & ((r3.y & 0xffffu) == want) & (r3.y == r3.w);
-        if (__builtin_amdgcn_readfirstlane((int)all)) break;
-        TP_SPIN_OR(b, spins, return -2)
-    }
-    asm volatile("" ::: "memory");
-    const unsigned long long k0 = ((unsigned long long)r0.z << 32) | r0.x, k1 = ((unsigned long long)r1.z << 32) | r1.x;
-    const unsigned long long k2 = ((unsigned long long)r2.z << 32) | r2.x, k3 = ((unsigned long long)r3.z << 32) | r3.x;
-    unsigned long long kb = k0; int best = 0; unsigned tb = r0.y;    // smallest (key, row): ties go to the lower slot
-    if (k1 < kb) { kb = k1; best = 1; tb = r1.y; }
-    if (k2 < kb) { kb = k2; best = 2; tb = r2.y; }
-    if (k3 < kb) { kb = k3; best = 3; tb = r3.y; }
-    best = __builtin_amdgcn_readfirstlane(best);
-    tb = (unsigned)__builtin_amdgcn_readfirstlane((int)tb);
-    TP_PH(4, "+s", best);                                            // the four keys arrive, the smallest
-    TP_LDSQ TpSlot& e = TP_P(TpSlot, b, TP_O_RING)[s % TP_RING];
-    const unsigned goff = TP_G_RING + (unsigned)s * TP_G_PIVOT;
-    if (__builtin_amdgcn_readfirstlane((int)(kb == ~0ull))) {        // :241-242
-        if (lane == 0) TP_VI(e.tp[q]) = s + 1;
-        carf_put(G.rs, goff + (unsigned)(64 * q + lane) * 16u, 0.0, tp_ring_tag(G.epoch, s, -1));
-        if (q == 0 && lane == 0) carf_put(G.rs, goff + 256u * 16u, 0.0, tp_ring_tag(G.epoch, s, -1));
-        return -1;
-    }
-    const int piv = 64 * best + (int)(tb >> 16);
-    const TP_LDSQ TpX& wr = xb[best];
-    const double alpha = wr.d[0], rpp = wr.d[1];
-    // my row slot's part of the pivot: for the near store ...
-    e.col[64 * q + lane] = col;
-    if (lane == 0) e.rpp[q] = rpp;
-    asm volatile("" ::: "memory");
-    if (lane == 0) TP_VI(e.tp[q]) = (s + 1) | ((piv + 1) << 16);
-#ifdef TP_STAMPS
-    if (q == 0 && lane == 0) TP_STAMP(s);
-#endif
-    // ... and for the far one (a granule is its own release: no wait, no fence)
-#ifndef TP_X_NOGLOBAL    // timing-only build (the far store starves)
-    carf_put(G.rs, goff + (unsigned)(64 * q + lane) * 16u, col, tp_ring_tag(G.epoch, s, piv));
-    if (q == 0 && lane == 0) carf_put(G.rs, goff + 256u * 16u, rpp, tp_ring_tag(G.epoch, s, piv));
-#endif
-    TP_PH(5, "+v", dead);                                            // the winner's data, both publications
-    // mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (two roundings like the tensor expression, :253-254)
-    dead = dead | (int)(64 * q + lane == piv);
-    mu = dead ? 0.0 : __dsub_rn(mu, __dmul_rn(alpha, col));
-    if constexpr (PICK) {
-#pragma unroll
-        for (int j = 0; j < TP_BC; ++j) {
-            const double qv = wr.d[2 + j] * rpp;
-            nxt[j] = fma(-qv, col, nxt[j]);
-        }
-    } else {
-#pragma unroll
-        for (int j = JJ + 1; j < TP_BC; ++j) {
-            const double qv = wr.d[2 + j - (JJ + 1)] * rpp;
-            blk[j] = fma(-qv, col, blk[j]);
-        }
-    }
-    TP_PH(6, "+v", dead);                                            // weights, the block's eliminations
-    return piv;
-}
-
-// ---- a store wave: ONE block (seven columns, every row: four slots per lane) following its workgroup's LDS ring ----
-//   Phi[:, c] -= Phi[:, 0] * (Phi[idx, c] / Phi[idx, 0])   (:260-266); the row slot of the pivot entry by a uniform switch
-template <int KP>
-__device__ __forceinline__ void tp_elim_kp(double (&phi)[TP_BC][4], const double (&col)[4], const int lp, const double rpp) {
-#pragma unroll
-    for (int j = 0; j < TP_BC; ++j) {
-        const double qv = rdlane(phi[j][KP], lp) * rpp;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) phi[j][q] = fma(-qv, col[q], phi[j][q]);
-    }
-}
-// pivots s_from .. s_to of the ring applied to my block.  -> 0, 1 = the loop ended (Q6), 2 = gave up
-__device__ __forceinline__ int tp_store_follow(double (&phi)[TP_BC][4], const unsigned lds0, const int s_from, const int s_to,
-                                               const int w, const int lane) {
-    for (int s = s_from; s <= s_to; ++s) {
-        const unsigned b = tp_fresh(lds0);
-        TP_LDSQ TpSlot& e = TP_P(TpSlot, b, TP_O_RING)[s % TP_RING];
-        unsigned spins = 0;
-        int piv;
-        for (;;) {
-            const int t0 = TP_VI(e.tp[0]), t1 = TP_VI(e.tp[1]), t2 = TP_VI(e.tp[2]), t3 = TP_VI(e.tp[3]);
-            const bool all = ((t0 & 0xffff) == s + 1) & (t1 == t0) & (t2 == t0) & (t3 == t0);
-            piv = __builtin_amdgcn_readfirstlane(t0 >> 16) - 1;
-            if (__builtin_amdgcn_readfirstlane((int)all)) break;
-            TP_SPIN_OR(b, spins, return 2)
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (piv < 0) return 1;
-        asm volatile("" ::: "memory");
-        double col[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) col[q] = e.col[lane + 64 * q];
-        const double rpp = e.rpp[0];
-        const int lp = piv & 63;
-        switch (piv >> 6) {                                          // uniform
-            case 0: tp_elim_kp<0>(phi, col, lp, rpp); break;
-            case 1: tp_elim_kp<1>(phi, col, lp, rpp); break;
-            case 2: tp_elim_kp<2>(phi, col, lp, rpp); break;
-            default: tp_elim_kp<3>(phi, col, lp, rpp); break;
-        }
-        asm volatile("" ::: "memory");
-        if (lane == 0) TP_P(volatile int, b, TP_O_PROG)[w] = s + 1;
-    }
-    return 0;
-}
-__device__ __forceinline__ void tp_block_from_phi(double (&phi)[TP_BC][4], const double* __restrict__ Phi, const int t, const int K,
-                                                  const int N, const int lane) {
-#pragma unroll
-    for (int j = 0; j < TP_BC; ++j) {
-        const int c = TP_BC * t + j;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) phi[j][q] = (c < K && lane + 64 * q < N) ? Phi[(size_t)c * CAR_NS + lane + 64 * q] : 0.0;
-    }
-}
-
-__global__ __launch_bounds__(TP_THREADS) void k_car_pivot_team(const double* __restrict__ Phi, int N, int m,
-                                                               const double* __restrict__ mu_in,
-                                                               int32_t* __restrict__ keep_rank, double* __restrict__ w_star,
-                                                               int32_t* __restrict__ n_keep_out, double* __restrict__ mu_out,
-                                                               const unsigned* __restrict__ err, void* __restrict__ gws,
-                                                               unsigned epoch) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char tp_lds[];
-    const unsigned lds0 = (unsigned)(size_t)(TP_LDSQ unsigned char*)tp_lds;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = N - m;
-    const int nblk = (K + TP_BC - 1) / TP_BC;
-    TpG G;
-    G.rs = __builtin_amdgcn_make_buffer_rsrc(gws, 0, (int)TP_G_BYTES, 0x00020000);
-    G.epoch = epoch & 0xffffu;
-    unsigned* gwords = (unsigned*)gws;
-    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;       // HW_REG_XCC_ID
-    // the fused launch in front gave up on a reflector, or not every group of Phi's rows found a consumer
-    const bool broken = err != nullptr && (err[CARF_ERR / 4] != 0u || err[CARF_DONE / 4] != (unsigned)(CAR_NS / 8));
-    int role = 0;                                                    // 0: workgroup 0; 1 + g: far workgroup g; -1: nothing to do
-    if (blockIdx.x == 0) {
-        if (tid == 0) {
-            __hip_atomic_store(gwords + TP_G_TICKET / 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(gwords + TP_G_XCD / 4, (G.epoch << 4) | (xcc + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else {
-        if (tid == 0) {
-            unsigned spins = 0, wd = 0;
-            int r = -1;
-            if (!broken && nblk > TP_FAR0) {
-                while (((wd = __hip_atomic_load(gwords + TP_G_XCD / 4, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 4) != G.epoch) {
-                    if (++spins > CARF_SPIN_LIMIT) { wd = 0; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if ((wd & 15u) == xcc + 1u) {                        // on workgroup 0's XCD: a candidate
-                    const unsigned tk = __hip_atomic_fetch_add(gwords + TP_G_TICKET / 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((int)tk < TP_FARG && TP_FAR0 + TP_FARW * (int)tk < nblk) r = 1 + (int)tk;
-                }
-            }
-            *TP_P(volatile int, lds0, TP_O_ROLE) = r;
-        }
-        __syncthreads();
-        role = __builtin_amdgcn_readfirstlane(*TP_P(volatile int, lds0, TP_O_ROLE));
-        if (role < 0) return;
-    }
-    {
-        const unsigned b = lds0;
-        for (int i = tid; i < TP_RING * 4; i += TP_THREADS) TP_P(TpSlot, b, TP_O_RING)[i >> 2].tp[i & 3] = 0;
-        if (tid < 16) TP_P(volatile int, b, TP_O_DTAG)[tid] = 0;
-        if (tid < 8) { car_u32x4 z; z.x = z.y = z.z = z.w = 0u; TP_P(TpX, b, TP_O_X)[tid].g0 = z; }
-        // (where a store wave is in the pivot stream: from the start for one that will hold a block, nowhere otherwise)
-        if (tid < 16) {
-            const bool holds = role > 0 ? (tid < TP_FARW && TP_FAR0 + TP_FARW * (role - 1) + tid < nblk)
-                                        : (tid >= 4 && tid < 4 + TP_NEAR && 1 + (tid - 4) < nblk);
-            TP_P(volatile int, b, TP_O_PROG)[tid] = holds ? 0 : TP_BIG;
-        }
-        if (tid < 4) TP_P(volatile int, b, TP_O_CNT)[tid] = -1;
-        if (tid == 0) *TP_P(volatile int, b, TP_O_FAIL) = 0;
-    }
-#ifdef TP_STAMPS
-    if (blockIdx.x == 0 && tid == 0) TP_STAMP(257);
-#endif
-    __syncthreads();                                                 // (the only workgroup barrier of the pivots)
-    if (role > 0) {
-        // ================= a far workgroup: waves 0 .. 6 one block each, wave 7 the fetcher =================
-        const int g = role - 1;
-        int s_max = -1;                                              // the last pivot this workgroup follows
-        for (int v = 0; v < TP_FARW; ++v) {
-            const int t = TP_FAR0 + TP_FARW * g + v;
-            if (t < nblk) s_max = max(s_max, TP_BC * t - TP_LEAD);
-        }
-        if (w < TP_FARW) {
-            const int t = TP_FAR0 + TP_FARW * g + w;
-            if (t >= nblk) return;
-            const int s_to = TP_BC * t - TP_LEAD;                    // (< 0: the block is passed on as it is)
-            double phi[TP_BC][4];
-            tp_block_from_phi(phi, Phi, t, K, N, lane);
-            if (lane == 0) TP_P(volatile int, lds0, TP_O_PROG)[w] = 0;
-            const int r = __builtin_amdgcn_readfirstlane(tp_store_follow(phi, lds0, 0, s_to, w, lane));
-            if (lane == 0) TP_P(volatile int, lds0, TP_O_PROG)[w] = TP_BIG;
-            if (r != 0) return;                                      // (the loop ended, or the fetcher gave up: nobody takes this block)
-            const unsigned hoff = TP_G_H + (unsigned)(t - TP_FAR0) * TP_G_BLOCK;
-#pragma unroll
-            for (int j = 0; j < TP_BC; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    carf_put(G.rs, hoff + (unsigned)(j * 256 + lane + 64 * q) * 16u, phi[j][q], tp_block_tag(G.epoch, t, j));
-#ifdef TP_STAMPS
-            if (lane == 0) TP_STAMP(300 + t);
-#endif
-            return;
-        }
-        // the fetcher: the global pivot stream into this workgroup's LDS ring, up to four pivots per L2 round trip
-        int s = 0;
-        unsigned spins = 0;
-        while (s <= s_max) {
-            const unsigned b = tp_fresh(lds0);
-            car_u32x4 gc[4][4], gr[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned goff = TP_G_RING + (unsigned)min(s + u, TP_KMAX - 1) * TP_G_PIVOT;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) gc[u][q] = carf_load(G.rs, goff + (unsigned)(lane + 64 * q) * 16u);
-                gr[u] = carf_load(G.rs, goff + 256u * 16u);
-            }
-            bool progress = false, stop = false;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (stop || s > s_max) break;                        // (uniform)
-                const unsigned hi = (G.epoch << 7) | (unsigned)(s + 1);
-                bool okl = ((gr[u].y >> 9) == hi) & (gr[u].y == gr[u].w);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) okl = okl & (gc[u][q].y == gr[u].y) & (gc[u][q].w == gr[u].y);
-                if (__ballot(!okl) != 0ull) { stop = true; break; }  // pivot s is not (all) there yet
-                const int piv = (int)(__builtin_amdgcn_readfirstlane((int)gr[u].y) & 0x1ff) - 1;
-                // the slot's previous pivot has been consumed by every wave that holds a block
-                unsigned sp2 = 0;
-                const int need = s - TP_RING + 1;
-                bool gaveup = false;
-                while (need > 0 && __ballot(TP_P(volatile int, b, TP_O_PROG)[lane & 7] < need) != 0ull) {
-                    if (++sp2 > TP_SPIN_LIMIT) { gaveup = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (gaveup) { tp_fail(b); return; }
-                TP_LDSQ TpSlot& e = TP_P(TpSlot, b, TP_O_RING)[s % TP_RING];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e.col[lane + 64 * q] = carf_val(gc[u][q]);
-                if (lane == 0) e.rpp[0] = carf_val(gr[u]);
-                asm volatile("" ::: "memory");
-                if (lane < 4) TP_VI(e.tp[lane]) = (s + 1) | ((piv + 1) << 16);
-#ifdef TP_STAMPS
-                if (g == 0 && lane == 0) TP_STAMP(400 + s);
-#endif
-                ++s;
-                progress = true;
-                if (piv < 0) return;                                 // the loop ended (Q6): the store waves stop on this slot
-            }
-            if (progress) spins = 0;
-            else {
-                if (++spins > TP_SPIN_LIMIT) { tp_fail(b); return; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        return;
-    }
-    // ================= workgroup 0 =================
-    if (broken) { if (tid == 0) *n_keep_out = -1; return; }
-    if (w >= 4) {
-        // ---- the near store: wave k holds block 1 + k, then 5 + k, ... ; each handed to the chain team behind pivot 7 t - 2
-#ifdef TP_X_NONEAR       // timing-only build (wrong results): the chain team alone on its compute unit
-        if (lane == 0) TP_P(volatile int, lds0, TP_O_PROG)[w] = TP_BIG;
-        return;
-#endif
-        const int k = w - 4;
-        double phi[TP_BC][4];
-        for (int t = 1 + k; t < nblk; t += TP_NEAR) {
-            int s_from = 0;
-            if (t < TP_FAR0) {
-                tp_block_from_phi(phi, Phi, t, K, N, lane);
-                if (lane == 0) TP_P(volatile int, lds0, TP_O_PROG)[w] = 0;
-            } else {
-                // from the far store, as it was left behind pivot 7 t - TP_LEAD; the ring still holds what came since
-                s_from = max(TP_BC * t - TP_LEAD + 1, 0);
-                if (lane == 0) TP_P(volatile int, lds0, TP_O_PROG)[w] = s_from;
-                const unsigned hoff = TP_G_H + (unsigned)(t - TP_FAR0) * TP_G_BLOCK;
-                unsigned spins = 0;
-                for (;;) {
-                    bool okl = true;
-#pragma unroll
-                    for (int j = 0; j < TP_BC; ++j) {
-                        const unsigned tg = tp_block_tag(G.epoch, t, j);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const car_u32x4 gq = carf_load(G.rs, hoff + (unsigned)(j * 256 + lane + 64 * q) * 16u);
-                            okl = okl & carf_ok(gq, tg);
-                            phi[j][q] = carf_val(gq);
-                        }
-                    }
-                    if (__ballot(!okl) == 0ull) break;
-                    if (++spins > (1u << 16) || ((spins & 15u) == 0u && tp_failed(lds0))) { tp_fail(lds0); return; }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-#ifdef TP_STAMPS
-            if (lane == 0) TP_STAMP(260 + t);
-#endif
-            const int r = __builtin_amdgcn_readfirstlane(tp_store_follow(phi, lds0, s_from, TP_BC * t - 2, w, lane));
-            if (r != 0) break;
-            // to the chain team, row slot by row slot
-            const unsigned b = tp_fresh(lds0);
-            TP_LDSQ double* dl = TP_P(double, b, TP_O_DL) + (t & 1) * TP_BC * 256 + lane;
-#pragma unroll
-            for (int j = 0; j < TP_BC; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dl[j * 256 + 64 * q] = phi[j][q];
-            asm volatile("" ::: "memory");
-            if (lane == 0) TP_P(volatile int, b, TP_O_DTAG)[t & 1] = t + 1;
-        }
-        if (lane == 0) TP_P(volatile int, lds0, TP_O_PROG)[w] = TP_BIG;
-        return;
-    }
-    // ---- the chain team ----
-    const int q = w;                                                 // (consecutive waves go round the SIMDs: the four run side by side)
-    const int row = 64 * q + lane;
-    int dead = row < N ? 0 : 1;
-    double mu = row < N ? mu_in[row] + 0.0 : 0.0;
-    double blk[TP_BC], nxt[TP_BC];
-#pragma unroll
-    for (int j = 0; j < TP_BC; ++j) {
-        blk[j] = (j < K && row < N) ? Phi[(size_t)j * CAR_NS + row] : 0.0;
-        nxt[j] = 0.0;
-    }
-    __builtin_amdgcn_s_setprio(3);                                   // the critical chain of the whole kernel
-    int st = 0;                                                      // 0 running, 1 the loop ended (Q6), 2 gave up
-    for (int t = 0; t < nblk && st == 0; ++t) {
-        const int s0 = TP_BC * t, s1 = min(s0 + TP_BC, K);
-        if (s1 > TP_RING) {                                          // a ring slot is reused TP_RING pivots later
-            const unsigned b = tp_fresh(lds0);
-            const int need = s1 - TP_RING;
-            unsigned spins = 0;
-            for (;;) {
-                if (__ballot(TP_P(volatile int, b, TP_O_PROG)[lane & 15] < need) == 0ull) break;
-                TP_SPIN_OR(b, spins, st = 2; break)
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        const int nb1 = min(TP_BC, K - s1);                          // columns of the next block (<= 0: none)
-        int s = s0;
-#define TP_STEP(JJ) if (st == 0 && s < s1) { const int r_ = __builtin_amdgcn_readfirstlane(tp_chain_step<JJ, false>(blk, nxt, mu, dead, lds0, G, s, q, lane, 0, 0)); if (r_ < 0) st = (r_ == -1) ? 1 : 2; ++s; }
-        TP_STEP(0) TP_STEP(1) TP_STEP(2) TP_STEP(3) TP_STEP(4) TP_STEP(5)
-#undef TP_STEP
-        static_assert(TP_BC == 7, "one TP_STEP per column of a block");
-        if (st == 0 && s < s1) {                                     // the block's last column
-            int r_;
-            if (nb1 > 0) r_ = __builtin_amdgcn_readfirstlane(tp_chain_step<6, true>(blk, nxt, mu, dead, lds0, G, s, q, lane, nb1, t + 1));
-            else r_ = __builtin_amdgcn_readfirstlane(tp_chain_step<6, false>(blk, nxt, mu, dead, lds0, G, s, q, lane, 0, 0));
-            if (r_ < 0) st = (r_ == -1) ? 1 : 2;
-#pragma unroll
-            for (int j = 0; j < TP_BC; ++j) blk[j] = nxt[j];
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    const unsigned b = tp_fresh(lds0);
-    if (st == 2 || tp_failed(b)) { tp_fail(b); if (w == 0 && lane == 0) *n_keep_out = -1; return; }
-    // the result, row slot by row slot
-    const bool inr = row < N;
-    const double v = inr ? mu + 0.0 : 0.0;                           // -0.0 -> +0.0
-    const bool keep = inr && (v > 0.0);
-    const unsigned long long bal = __ballot(keep);
-    const int mine = __popcll(bal);
-    volatile TP_LDSQ int* cnt = TP_P(volatile int, b, TP_O_CNT);
-    if (lane == 0) cnt[q] = mine;
-    int rbase = 0;
-    for (int o = 0; o < q; ++o) {
-        unsigned spins = 0;
-        int c;
-        while ((c = __builtin_amdgcn_readfirstlane(cnt[o])) < 0) {
-            if (++spins > TP_SPIN_LIMIT || tp_failed(b)) { tp_fail(b); c = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        rbase += c;
-    }
-    const int rank = rbase + __popcll(bal & ((1ull << lane) - 1ull));
-    if (inr) {
-        keep_rank[row] = keep ? rank : -1;
-        mu_out[row] = v;
-        if (keep) w_star[rank] = v;
-    }
-    if (q == 3 && lane == 0) *n_keep_out = tp_failed(b) ? -1 : rbase + mine;
-#ifdef TP_STAMPS
-    if (q == 3 && lane == 0) TP_STAMP(256);
-#endif
-}
-
 // ---------------- the extra elimination of the acquisition-guided branch (SOBER/_rchq.py:87-106, :177-196) ----------
 // After the Caratheodory step with one more test function (the objective), n1 = b + 1 points are left; their
 // weights move along the null vector w_null of [X_p; 1] (functions x points, a 1-dimensional null space) in the
@@ -1647,8 +1085,7 @@ extern "C" int sober_car_supported(int N, int m) {
 // (a workspace sized for (N, m) also serves every (N' <= N, m): the final direct level)
 extern "C" int64_t sober_car_ws_bytes(int N, int m) {
     const int64_t one = ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC + 512) * (int64_t)sizeof(double)   // (+512: stamp block)
-                        + sober::carf_bytes(m)                                        // + the fused launch's granules
-                        + 256 + sober::tp_global_bytes();                             // + the team pivot kernel's pivot stream and far store
+                        + sober::carf_bytes(m);                                       // + the fused launch's granules
     if (car_one_cu(N, m)) return one;
     const int64_t mc = sober_car_mc_ws_bytes(N, m);
     return mc > one ? mc : one;
@@ -1661,7 +1098,6 @@ static int car_pivot_attr(size_t sp_bytes) {
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_stream<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_stream<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_stream<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_car_pivot_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sober::tp_lds_bytes()));
         sober_attr_done(done);
     }
     return 0;
@@ -1692,28 +1128,6 @@ extern "C" int sober_car_safe_supported(int N, int m) { return car_one_cu(N, m);
         else { constexpr int NQ_ = 4; LAUNCH; }                        \
     } while (0)
 
-// the pivots: beyond 128 points the rows of a column are split across four waves (k_car_pivot_team); up to 128 the
-// one-wave chain of k_car_pivot_stream (one or two row slots per lane) is the shorter one
-static int car_launch_pivots(const double* Phi, int N, int m, const double* mu_in, int32_t* keep_rank, double* w_star,
-                             int32_t* n_keep, double* mu_out, const unsigned* err, size_t sp_bytes, void* gws, bool safe,
-                             hipStream_t st) {
-    const bool stream_only = getenv("SOBER_CAR_PIVOT_STREAM") != nullptr;              // (read at every call: same-process A/B of the team kernel)
-    if (N > 128 && N - m <= sober::TP_KMAX && !stream_only && !safe) {
-        static std::atomic<unsigned> team_epoch{0};
-        const unsigned epoch = (team_epoch.fetch_add(1) + 1u) & 0xffffu;
-        static const int per_xcd = getenv("SOBER_TP_PER_XCD") ? atoi(getenv("SOBER_TP_PER_XCD")) : 4;      // (tuning aid: far workgroups offered per XCD; 2 are needed)
-        const int nblk = (N - m + sober::TP_BC - 1) / sober::TP_BC;
-        const int grid = nblk > sober::TP_FAR0 ? 1 + 8 * per_xcd : 1;
-        hipLaunchKernelGGL(sober::k_car_pivot_team, dim3(grid), dim3(sober::TP_THREADS), sober::tp_lds_bytes(), st, Phi, N, m, mu_in,
-                           keep_rank, w_star, n_keep, mu_out, err, gws, epoch);
-    } else {
-        CAR_PIVOT_BY_SIZE(N, hipLaunchKernelGGL((sober::k_car_pivot_stream<NQ_>), dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m,
-                                                mu_in, keep_rank, w_star, n_keep, mu_out, err));
-    }
-    LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const double* mu_in,
                                    int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
                                    double* phi_out, void* ws, int64_t ws_bytes, int mode, void* stream) {
@@ -1728,8 +1142,6 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
     double* vws = (double*)ws;
     double* taup = vws + (size_t)m * sober::CAR_NS;
     double* Phi = taup + 128;
-    // (the team pivot kernel's block in global memory: behind the fused launch's granules, 256-byte aligned)
-    void* gws = (void*)(((uintptr_t)(Phi + (size_t)sober::CAR_NS * sober::CAR_PC + 512) + sober::carf_bytes(m) + 255) & ~(uintptr_t)255);
     static const bool unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;                // (same-box A/B of the fused launch)
     const size_t sp_bytes = sizeof(sober::SpSlot) * sober::SP_RING + sober::SP_W * sizeof(int);
     { const int rc = car_pivot_attr(sp_bytes); if (rc != 0) return rc; }
@@ -1739,7 +1151,10 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
         LAUNCH_CHECK();
         hipLaunchKernelGGL(sober::k_car_phi, dim3(sober::CAR_PC / 4), dim3(256), 0, st, vws, taup, N, m, Phi, phi_out);
         LAUNCH_CHECK();
-        return car_launch_pivots(Phi, N, m, mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)nullptr, sp_bytes, gws, mode == SOBER_CAR_SAFE, st);
+        CAR_PIVOT_BY_SIZE(N, hipLaunchKernelGGL((sober::k_car_pivot_stream<NQ_>), dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m,
+                                                mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)nullptr));
+        LAUNCH_CHECK();
+        return 0;
     }
     // bidiagonalisation and Phi in ONE launch: workgroup 0 produces the reflectors, the workgroups that land on its XCD
     // (an eighth of the rest: 26 are needed, 40 are offered) accumulate the rows of Phi as the reflectors appear
@@ -1751,7 +1166,10 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
     CAR_BY_SIZE(m, N, hipLaunchKernelGGL((sober::k_car_bidiag_fused<MS_, CQ_>), dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X, ldx,
                                          N, m, vws, taup, Phi, comm, (unsigned)sober::carf_bytes(m), epoch, spin_limit));
     LAUNCH_CHECK();
-    return car_launch_pivots(Phi, N, m, mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm, sp_bytes, gws, false, st);
+    CAR_PIVOT_BY_SIZE(N, hipLaunchKernelGGL((sober::k_car_pivot_stream<NQ_>), dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m,
+                                            mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm));
+    LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
@@ -1772,15 +1190,6 @@ extern "C" int sober_second_elimination(const double* phi, const double* objp, c
     return 0;
 }
 
-#ifdef TP_STAMPS
-extern "C" int sober_debug_tp_phases(unsigned long long* out32, int reset) {
-    if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(sober::g_tp_phase), z, sizeof(z), 0, hipMemcpyHostToDevice); }
-    return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(sober::g_tp_phase), sizeof(unsigned long long) * 32, 0, hipMemcpyDeviceToHost);
-}
-extern "C" int sober_debug_tp_stamps(unsigned long long* out520) {
-    return (int)hipMemcpyFromSymbol(out520, HIP_SYMBOL(sober::g_tp_stamps), sizeof(unsigned long long) * 520, 0, hipMemcpyDeviceToHost);
-}
-#endif
 #ifdef SP_TSTAMPS
 extern "C" int sober_debug_sp_stamps(unsigned long long* out260) {
     return (int)hipMemcpyFromSymbol(out260, HIP_SYMBOL(sober::g_sp_stamps), sizeof(unsigned long long) * 260, 0, hipMemcpyDeviceToHost);
