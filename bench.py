@@ -86,9 +86,9 @@ def pmc_traffic(config):
 def allreduce_route():
     """Which all-reduce the sharded level loop used in this process (sober_amd/_engine.py: DistComm.native_allreduce)."""
     from sober_amd._engine import DistComm
-    if any(pc not in (None, False) for pc in DistComm._PEER.values()):
+    if any(ent[1] not in (None, False) for ent in DistComm._PEER.values()):
         return "one-shot direct-peer kernel, sums in rank order: csrc/peer_reduce.hip"
-    if any(rc not in (None, False) for rc in DistComm._RCCL.values()):
+    if any(ent[1] not in (None, False) for ent in DistComm._RCCL.values()):
         return "ncclAllReduce issued from C: csrc/rccl_link.cpp"
     return "the group's own all_reduce"
 
@@ -193,6 +193,10 @@ def main():
                          "(an event-carrying dispatch costs the stream 10-20 us: on every step that is +0.1-0.2 ms at "
                          "configuration 2, profiles/r03_event_cost.txt); 1 = every step")
     ap.add_argument("--no-sweep", action="store_true", help="skip the n_obs sweep of SURVEY.md 8(d) (configuration 2, one GPU)")
+    ap.add_argument("--check-unsharded", action="store_true",
+                    help="N > 1: rank 0 gathers every shard and repeats the step UNSHARDED on its one GPU (outside the timed "
+                         "region); the JSON then carries the comparison (identical indices, weights) -- the test hook of "
+                         "tests/test_hip_round4.py, not for pools that do not fit one GPU")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -295,6 +299,51 @@ def main():
             sober_amd.KMeans(X_cand, cfg["M"])
         torch.cuda.synchronize()
         kmeans_ms = (time.perf_counter() - k0) / 3 * 1e3
+
+    # fingerprint pools: the step as a default `Sober` sees it.  The timed region above hits the caches a dataset prior
+    # WITHOUT pruning allows (the same pool tensor every iteration: its packed words and the pool's posterior mean are
+    # kept); with `dataset_pruning=True` -- the reference's default, SOBER/_sober.py:10-39 -- X_cand = available[idx] is a
+    # fresh tensor per iteration: re-pack + posterior mean over the pool every time.  Both are reported.
+    fresh_ms = None
+    if cfg["kind"] == "tanimoto":
+        each = []
+        for _ in range(6):
+            ops.clear_cache()                                 # (what a fresh pool tensor amounts to, without a 4 GB copy)
+            barrier(); torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            each.append(time.perf_counter() - c0)
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([float(np.median(each[1:]))], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            fresh_ms = float(tt.item()) * 1e3
+        else:
+            fresh_ms = float(np.median(each[1:])) * 1e3
+
+    # N > 1, on request: the same step unsharded on rank 0's GPU, from the gathered shards
+    sharded_check = None
+    if world > 1 and args.check_unsharded:
+        import torch.distributed as dist
+        on_dev = backend == "nccl"
+        Xs, ms = (X_cand, mu0) if on_dev else (X_cand.cpu(), mu0.cpu())
+        Xg = [torch.empty_like(Xs) for _ in range(world)]
+        mg = [torch.empty_like(ms) for _ in range(world)]
+        dist.all_gather(Xg, Xs.contiguous())
+        dist.all_gather(mg, ms.contiguous())
+        ig = [torch.empty_like(idx if on_dev else idx.cpu()) for _ in range(world)]     # (every rank holds the global result)
+        dist.all_gather(ig, (idx if on_dev else idx.cpu()).contiguous())
+        if rank == 0:
+            X_all, mu_all = torch.cat(Xg).to(dev), torch.cat(mg).to(dev)
+            torch.manual_seed(SEED_CALL)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                idx1, w1 = sober_amd.recombination(X_all, X_nys, b, kernel, dev, torch.double, init_weights=mu_all, _ops=HipOps(dev))
+            same = bool(torch.equal(idx1.cpu(), idx.cpu()))
+            sharded_check = {"idx_equal_unsharded": same, "ranks_agree": all(bool(torch.equal(g_.cpu(), idx.cpu())) for g_ in ig),
+                             "max_rel_w_vs_unsharded": float(((w1 - w).abs() / w1.abs()).max()) if same else None}
+            del X_all, mu_all
 
     if rank != 0:
         return
@@ -406,6 +455,12 @@ def main():
         "cpu_baseline": cpu_baseline,
         "n_obs_sweep_ms_per_step": sweep,
         "parity": parity,
+        "parity_sharded_vs_unsharded": sharded_check,
+        "ms_per_step_fresh_pool": fresh_ms,
+        "ms_per_step_note": None if fresh_ms is None else
+        "ms_per_step / value: the pool tensor comes back unchanged (dataset prior without pruning: packed words and the pool's "
+        "posterior mean are kept); ms_per_step_fresh_pool: a fresh pool tensor per call (dataset_pruning=True, the reference's "
+        "default): re-pack + posterior mean every step",
         "kmeans_nystrom_subsample_ms": kmeans_ms,
         "ms_per_step_incl_kmeans": None if kmeans_ms is None else ms_per_step + kmeans_ms,
         "phases_ms_per_step": {k: v / args.steps * 1e3 for k, v in timers.items()},

@@ -41,6 +41,9 @@ extern "C" {
 #define SOBER_E_EXCHANGE -5      /* a multi-workgroup kernel gave up waiting for a partner (bounded spins); no result */
 
 int sober_abi_version(void);
+/* 1 = a diagnostic build (in-kernel time stamps, -DSOBER_DIAG_BUILD: `make stamps`); sober_amd refuses to load one
+ * unless SOBER_ALLOW_DIAG_LIB=1.  `make all` gives 0. */
+int sober_diag_build(void);
 /* sizeof(sober_level_job) / sizeof(sober_nystrom_job) as the library was built: a binding that lays the structs out itself
  * (ctypes, cgo, JNA ...) checks its own size against these before the first call.                                   */
 int sober_level_job_size(void);
@@ -522,8 +525,10 @@ int64_t sober_rccl_allreduce_ptr(void);     /* the address of sober_rccl_allredu
  * ranks inside one process) and a call is ONE kernel per rank that publishes its message, waits for the peers' flags
  * (bounded) and sums the `world` contributions in RANK ORDER -- the same bits on every rank, no ring steps.
  * sober_peer_allreduce_f64 is a sober_allreduce_fn (n <= n_max doubles).  sober_peer_status, after the stream has been
- * synchronised: 0, or SOBER_E_EXCHANGE when a wait ran out (a rank that never arrived) -- the rank's own message of
- * that call is then copied back to `restore` (n doubles; may be NULL). */
+ * synchronised: 0, or SOBER_E_EXCHANGE when a wait ran out (a rank that never arrived within ~30 s) -- the rank's own
+ * message of the FIRST failing call is then copied back to `restore` (n doubles; may be NULL).  The time-out is decided
+ * per rank and is fatal for the sharded run (sober_level_loop_sharded returns it): the group-wide fall-back to RCCL
+ * happens at set-up, when the self-check does not pass on every rank, not afterwards. */
 int64_t sober_peer_region_bytes(int64_t n_max);
 int sober_peer_create(int rank, int world, int64_t n_max, void** comm, char* handle64);
 int sober_peer_connect(void* comm, const char* handles);

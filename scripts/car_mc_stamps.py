@@ -1,6 +1,7 @@
 """Where a bidiagonalisation step of the multi-CU Caratheodory kernel spends its cycles: run with the stamp build
-(`make -C sober_amd/csrc stamps`, SOBER_HIP_LIB=sober_amd/csrc/build/libsober_hip_stamps.so).  Prints, per wave role,
+(`make -C sober_amd/csrc stamps`, SOBER_HIP_LIB=sober_amd/csrc/build_stamps/libsober_hip_stamps.so).  Prints, per wave role,
 the mean cycles per step of every segment (shares, not absolute times: the stamps serialise the LDS traffic)."""
+import os as _os; _os.environ.setdefault("SOBER_ALLOW_DIAG_LIB", "1")   # (a stamped library is a diagnostic build)
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,6 @@
 """Where a bidiagonalisation step of the one-CU Caratheodory kernel (csrc/car.hip) spends its cycles: run with the
-stamp build (`make -C sober_amd/csrc stamps`, SOBER_HIP_LIB=sober_amd/csrc/build/libsober_hip_stamps.so)."""
+stamp build (`make -C sober_amd/csrc stamps`, SOBER_HIP_LIB=sober_amd/csrc/build_stamps/libsober_hip_stamps.so)."""
+import os as _os; _os.environ.setdefault("SOBER_ALLOW_DIAG_LIB", "1")   # (a stamped library is a diagnostic build)
 import os, sys
 os.environ.setdefault("SOBER_CAR_UNFUSED", "1")     # the stamps live in the stand-alone bidiagonalisation kernel
 import numpy as np, torch

@@ -1,6 +1,7 @@
 """Per-phase and per-step ticks of the multi-CU ladder probe (k_chol_mc), from a -DCM_STAMPS build:
-  make -C sober_amd/csrc BUILD=build_cms EXTRA=-DCM_STAMPS OUT=build_cms/libsober_hip_cms.so
+  make -C sober_amd/csrc BUILD=build_cms EXTRA='-DSOBER_DIAG_BUILD -DCM_STAMPS' OUT=build_cms/libsober_hip_cms.so
   SOBER_HIP_LIB=.../build_cms/libsober_hip_cms.so python scripts/chol_mc_stamps.py"""
+import os as _os; _os.environ.setdefault("SOBER_ALLOW_DIAG_LIB", "1")   # (a stamped library is a diagnostic build)
 import numpy as np, torch, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sober_amd import _native as nat

@@ -1,5 +1,6 @@
 """Time the one-workgroup Cholesky kernels: the 11-rung probe of a 500 x 500 Gram, single factorisations at
 n = 99 / 198 / 500, the blocked TRSM; with a -DCH_STAMPS build also the per-phase ticks of k_chol."""
+import os as _os; _os.environ.setdefault("SOBER_ALLOW_DIAG_LIB", "1")   # (a stamped library is a diagnostic build)
 import numpy as np, torch, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sober_amd import _native as nat

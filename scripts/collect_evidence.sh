@@ -6,8 +6,8 @@ R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 bash scripts/car_ab.sh 2>&1 | grep -E "lib:|car" > $OUT/car_kernels.txt
-if [ -f sober_amd/csrc/build/libsober_hip_stamps.so ]; then
-  SOBER_HIP_LIB=sober_amd/csrc/build/libsober_hip_stamps.so python3 scripts/car_stamps.py 2>&1 | grep -E "wave|block" > $OUT/car_stamps.txt
+if [ -f sober_amd/csrc/build_stamps/libsober_hip_stamps.so ]; then
+  SOBER_HIP_LIB=sober_amd/csrc/build_stamps/libsober_hip_stamps.so python3 scripts/car_stamps.py 2>&1 | grep -E "wave|block" > $OUT/car_stamps.txt
 fi
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/mck && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/mck -o run -- python3 $R/scripts/car_mc_time.py > /tmp/mck.log 2>&1; grep -i "ms" /tmp/mck.log | head -5; python3 - <<PY
 import csv

@@ -3,7 +3,7 @@
 //   mfma  : v_mfma_f64_16x16x4 only, 4 independent accumulator tiles
 //   mix   : 12 MFMAs + 160 FMAs per iteration (the level kernel's DP mix at d = 10), same wave
 //   int   : mix + 104 integer VALU ops per iteration (its non-DP vector instructions)
-// at 1, 2 and 3 waves per SIMD on all 256 CUs.  Build: hipcc --offload-arch=gfx950 -O3 -o dp_rate_probe.bin dp_rate_probe.hip
+// at 1, 2 and 3 waves per SIMD on all 256 CUs.  Build: hipcc --offload-arch=gfx950 -O3 -o build/probes/dp_rate_probe scripts/dp_rate_probe.hip   (make -f scripts/probes.mk)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));

@@ -1,8 +1,9 @@
 """Where a level launch's time goes, by in-kernel s_memrealtime stamps (diagnostic build -DLW_STAMPS of
-level_reduce_mfma.hip: make -C sober_amd/csrc BUILD=build_lws EXTRA=-DLW_STAMPS OUT=build_lws/libsober_hip_lws.so):
+level_reduce_mfma.hip: make -C sober_amd/csrc BUILD=build_lws EXTRA='-DSOBER_DIAG_BUILD -DLW_STAMPS' OUT=build_lws/libsober_hip_lws.so):
    SOBER_HIP_LIB=.../libsober_hip_lws.so python scripts/level_stamps.py [d=10] [rows=700] [S=200] [pool=100000] -- n ...
 For every n (live positions of the launch): the stamps of all waves relative to the earliest wave's entry, in microseconds -- 0 entry | 1 after the queued-level block | 2 after the table barrier | 3 row fragments arrived |
 4 first two candidates arrived | 5 element loop done | 6 after the LDS barrier | 7 stores issued."""
+import os as _os; _os.environ.setdefault("SOBER_ALLOW_DIAG_LIB", "1")   # (a stamped library is a diagnostic build)
 import os, sys, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,6 @@
 """When every pivot of k_mc_pivot is published (diagnostic build -DMC_TSTAMPS: make -C sober_amd/csrc BUILD=build_mts
-EXTRA=-DMC_TSTAMPS OUT=build_mts/libsober_hip_mts.so) at N = 400, m = 200: microseconds between consecutive publishes."""
+EXTRA='-DSOBER_DIAG_BUILD -DMC_TSTAMPS' OUT=build_mts/libsober_hip_mts.so) at N = 400, m = 200: microseconds between consecutive publishes."""
+import os as _os; _os.environ.setdefault("SOBER_ALLOW_DIAG_LIB", "1")   # (a stamped library is a diagnostic build)
 import ctypes as C, numpy as np, torch, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sober_amd import _native as nat

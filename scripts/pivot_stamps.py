@@ -1,7 +1,8 @@
 """When every pivot of k_car_pivot_stream is published (diagnostic build -DSP_TSTAMPS: make -C sober_amd/csrc
-BUILD=build_sps EXTRA=-DSP_TSTAMPS OUT=build_sps/libsober_hip_sps.so), on the reference's level-0 input of the
+BUILD=build_sps EXTRA='-DSOBER_DIAG_BUILD -DSP_TSTAMPS' OUT=build_sps/libsober_hip_sps.so), on the reference's level-0 input of the
 matern_medium golden (N = 200, m = 100): microseconds between consecutive publishes, in-block pivots against the first pivot
 of a block (the hand-over from the wave before)."""
+import os as _os; _os.environ.setdefault("SOBER_ALLOW_DIAG_LIB", "1")   # (a stamped library is a diagnostic build)
 import ctypes as C, numpy as np, torch, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sober_amd import _native as nat

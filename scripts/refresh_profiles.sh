@@ -10,8 +10,8 @@ CFGS=${2:-"1 2 3 4 5"}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-if [ -x scripts/dp_rate_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/dp_rate_probe.bin scripts/dp_rate_probe.hip 2> "$OUT/dp_rate_build.log"; then
-  BIN=scripts/dp_rate_probe.bin; [ -x /tmp/dp_rate_probe.bin ] && BIN=/tmp/dp_rate_probe.bin
+if [ -x build/probes/dp_rate_probe ] || make -f scripts/probes.mk build/probes/dp_rate_probe 2> "$OUT/dp_rate_build.log"; then
+  BIN=build/probes/dp_rate_probe
   $BIN > "$OUT/dp_rate.txt" 2>&1
 fi
 for c in $CFGS; do

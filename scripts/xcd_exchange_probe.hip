@@ -1,6 +1,6 @@
 // Probe: cost of one all-to-all exchange of 256 doubles per workgroup among G workgroups that sit on ONE XCD
 // (elected by XCC id, as csrc/car_mc.hip does), in the forms the multi-CU Caratheodory kernel could use.
-//   hipcc -O3 --offload-arch=gfx950 scripts/xcd_exchange_probe.hip -o scripts/xcd_exchange_probe.bin
+//   hipcc -O3 --offload-arch=gfx950 scripts/xcd_exchange_probe.hip -o build/probes/xcd_exchange_probe   (make -f scripts/probes.mk)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

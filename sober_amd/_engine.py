@@ -102,9 +102,15 @@ class DistComm:
             # the one-shot direct-peer all-reduce (every rank reads its peers' messages over xGMI and sums
             # in rank order: deterministic, one kernel) first; it checks itself on every rank when it is set up, and the
             # group falls back to RCCL together when the node does not support it (SOBER_PEER_ALLREDUCE=0: never tried)
-            pc = DistComm._PEER.get(key)
+            ent = DistComm._PEER.get(key)
+            pc = ent[1] if (ent is not None and ent[0] is group) else None   # (id() of a destroyed group can come back: the entry holds the group itself)
             if pc is None or (pc is not False and pc.n_max < flat.numel()):
                 if pc:
+                    # a larger message: the region is rebuilt.  A peer's last kernel may still be reading this rank's slot
+                    # (my stream's synchronisation does not cover ITS kernels) -- everybody leaves the old region first
+                    dist.barrier(group=group)
+                    torch.cuda.synchronize(device)
+                    dist.barrier(group=group)
                     pc.close()
                 why = "its set-up or self-check did not pass on every rank"
                 try:
@@ -118,11 +124,12 @@ class DistComm:
                 if pc is False:
                     warnings.warn("sober_amd: the direct-peer all-reduce is not used for this group (" + why + "); the level "
                                   "loop's all-reduce goes through RCCL / torch.distributed")
-                DistComm._PEER[key] = pc
+                DistComm._PEER[key] = (group, pc)
             if pc is not False:
                 return pc.fn_ptr, pc.handle, pc
         if dist.get_backend(group) == "nccl":
-            rc = DistComm._RCCL.get(key)
+            ent = DistComm._RCCL.get(key)
+            rc = ent[1] if (ent is not None and ent[0] is group) else None
             if rc is None:
                 try:
                     rc = nat.RcclComm(dist, group, device)
@@ -131,7 +138,7 @@ class DistComm:
                     warnings.warn(f"sober_amd: RCCL could not be bound from C ({e}); the level loop's all-reduce goes "
                                   "through torch.distributed instead")
                     rc = False
-                DistComm._RCCL[key] = rc
+                DistComm._RCCL[key] = (group, rc)
             if rc is not False:
                 return rc.fn_ptr, rc.handle, rc
 
@@ -326,8 +333,7 @@ class RecombinationEngine:
         # (requested as soon as the Cholesky probes of the device Nystrom route are enqueued -- `early` below --: its
         #  count then reaches the host long before the first level wants it, and the host's share of it is hidden
         #  behind the probes instead of standing in front of the whole chain)
-        can_start = getattr(ops, "nonzero_start", None) is not None and live is None \
-            and not os.environ.get("SOBER_SYNC_LIST")                   # (the switch: A/B of the synchronised form)
+        can_start = getattr(ops, "nonzero_start", None) is not None and live is None
         pend = {}
 
         def start_list():
@@ -368,7 +374,12 @@ class RecombinationEngine:
             or not ops.car_supported(S, n_fun) or (obj is not None and getattr(ops, "car_obj_device", None) is None)
         # (sharded runs keep the collectives in one fixed order on every rank: no overlap there, the ranks'
         # Nystrom routes may differ -- each draws its own randn -- and only rank 0's result is used)
-        if comm.world > 1 or os.environ.get("SOBER_LIST_FIRST"):   # (no hook on that route; the switch: A/B)
+        if car_on_host and not self.force_host_car and getattr(ops, "size_cliff", None) is not None \
+                and getattr(ops, "car_supported", None) is not None and not ops.car_supported(S, n_fun):
+            ops.size_cliff("car", f"batch = {n + 1}: a Caratheodory step on 2 x batch = {S} points with {n_fun} test functions is beyond "
+                                  "the device kernels (one compute unit: batch <= 100, several: batch <= 224); every level's "
+                                  "step runs on host LAPACK + the C++ pivots instead -- several ms per level")
+        if comm.world > 1:                                  # (no hook on that route)
             start_list()
         U = self.nystrom_basis(plan, n, overlap=head_once if comm.world == 1 else None, literal=car_on_host,
                                early=start_list if comm.world == 1 else None)

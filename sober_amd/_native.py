@@ -25,6 +25,7 @@ _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
 # name -> (restype, argtypes); mirrors include/sober_hip.h one to one
 SIGNATURES = {
     "sober_abi_version": (_i32, []),
+    "sober_diag_build": (_i32, []),
     "sober_level_job_size": (_i32, []),
     "sober_nystrom_job_size": (_i32, []),
     "sober_final_job_size": (_i32, []),
@@ -210,6 +211,9 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype, fn.argtypes = res, args
+    if lib.sober_diag_build() and os.environ.get("SOBER_ALLOW_DIAG_LIB") != "1":
+        raise SoberHipError(f"{LIB_PATH} is a diagnostic build (in-kernel time stamps): not a library to compute with; "
+                            "`make -C sober_amd/csrc` builds the product (SOBER_ALLOW_DIAG_LIB=1: the stamp scripts)")
     got = lib.sober_abi_version()
     if got != ABI_VERSION:
         raise SoberHipError(f"libsober_hip ABI {got} != expected {ABI_VERSION}; rebuild")
@@ -239,7 +243,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 # the current stream's handle: torch.cuda.current_stream(dev).cuda_stream builds a Stream object per call (1.9 us of the
 # 7 us a native call costs the host, ~150 calls per step); the raw getter underneath it is 0.2 us
-_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) if not os.environ.get("SOBER_STREAM_OBJECT") else None
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def _stream(t: torch.Tensor) -> Optional[int]:
@@ -777,6 +781,7 @@ class PeerComm:
         on_dev = dist.get_backend(group) == "nccl"
         ok = True
         try:
+            lib.sober_peer_set_spin_limit(self.handle, 1 << 21)       # short waits here (~0.5 s): the ranks enter together
             dist.barrier(group=group)
             with _t.cuda.device(self.device):
                 n = min(self.n_max, 4096)
@@ -790,6 +795,8 @@ class PeerComm:
                     ok = ok and self.status() == 0 and bool(_t.equal(x, want))
         except Exception:
             ok = False
+        if self.handle:
+            lib.sober_peer_set_spin_limit(self.handle, 1 << 27)       # production: a late peer is waited for (~30 s), like RCCL would
         self.ok = self._agree(dist, group, on_dev, ok)
         if not self.ok:
             self.close()

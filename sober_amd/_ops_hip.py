@@ -46,11 +46,11 @@ class HipOps:
         #                         (sober_set_launch_events), so they hold the kernel's own duration -- rocprofv3's number --
         #                         and cost the stream nothing
         self.use_mfma = True    # False: VALU-only level kernel (direct differences), kept for A/B runs
-        # False (or SOBER_NO_QUEUE in the environment): every level sized by the host after a synchronisation (A/B runs)
+        # False (or SOBER_NO_QUEUE in the environment): every level sized by the host after a synchronisation
         self.queue_levels = os.environ.get("SOBER_NO_QUEUE") is None
-        # the jitter ladder's probes on eight workgroups per rung (SOBER_PROBE_ONE_WG: one each, A/B runs)
-        self._probe_mc = os.environ.get("SOBER_PROBE_ONE_WG") is None \
-            and torch.cuda.get_device_properties(self.device).multi_processor_count >= 256   # (8 XCDs x 32 CUs: unpartitioned)
+        # the jitter ladder's probes on eight workgroups per rung (False: one workgroup each -- where the process stays
+        # after a rung's workgroups lost each other)
+        self._probe_mc = torch.cuda.get_device_properties(self.device).multi_processor_count >= 256   # (8 XCDs x 32 CUs: unpartitioned)
         # the rung of the Caratheodory step on this device: CAR_DEFAULT (launches whose workgroups wait for partner
         # workgroups: fused / multi-CU), CAR_SAFE after one of them gave up (single-workgroup kernels, batch <= 100),
         # CAR_HOST beyond those (host LAPACK + C++ pivots) -- SOBER/_rchq.py:224-270 never fails, so neither may this
@@ -74,9 +74,12 @@ class HipOps:
         p.T = None
         Xn64 = X_nys.to(torch.float64)
         native_rows = (p.kind != nat.KIND_TANIMOTO and not p.weighted and Xn64.stride(-1) == 1
-                       and not os.environ.get("SOBER_PLAN_FROM_PYTHON")
                        and (not corrected or (spec.X_obs.dtype == torch.float64 and spec.X_obs.stride(-1) == 1
-                                              and spec.S_cache.dtype == torch.float64 and spec.S_cache.stride(-1) == 1)))
+                                              and spec.S_cache.dtype == torch.float64 and spec.S_cache.stride(-1) == 1
+                                              # sober_plan_rows forms W = S S^T for a SQUARE root (n_obs x n_obs); gpytorch's
+                                              # Lanczos root beyond max_cholesky_size is n_obs x k: the Python route (woodbury)
+                                              and spec.S_cache.dim() == 2
+                                              and spec.S_cache.shape[0] == spec.S_cache.shape[1] == spec.X_obs.shape[0])))
         if native_rows:
             # the row table, Kall, W, T and the Gram matrix behind ONE native call (csrc/nystrom_exec.cpp: sober_plan_rows)
             f64 = torch.float64
@@ -132,9 +135,6 @@ class HipOps:
             else:
                 p.rows_aug = p.cand_aug = None
         p._pool_prep = pool_prep
-        if os.environ.get("SOBER_EAGER_PLAN"):                    # (A/B: everything in front of the Nystrom chain)
-            p._pool_prep = None
-            pool_prep()
         p.P = None
         p.ws = {}
         return p
@@ -150,8 +150,15 @@ class HipOps:
         (`.data`, DLPack, foreign kernels) are the caller's to announce with `clear_cache()`."""
         if spec.kind != "tanimoto":
             return prepare_points(spec, X_cand)
+        if not self._shares_storage(X_cand, owner):
+            # a converted copy of the caller's pool (CPU / float32 / bool pool: recombination() made X_cand itself): its
+            # memory is freed after the call and the allocator may hand the same block to the next copy -- pointer, layout
+            # and a fresh version counter would then match a pool the caller has modified since.  Never kept.
+            self._pool_cache = None
+            return prepare_points(spec, X_cand)
         import weakref
-        key = (X_cand.data_ptr(), tuple(X_cand.shape), tuple(X_cand.stride()), X_cand.dtype, X_cand._version)
+        key = (X_cand.data_ptr(), tuple(X_cand.shape), tuple(X_cand.stride()), X_cand.dtype, X_cand._version,
+               owner.data_ptr(), owner._version)
         hit = getattr(self, "_pool_cache", None)
         if hit is not None and hit[0] == key and hit[1]() is owner:
             return hit[2]
@@ -166,7 +173,11 @@ class HipOps:
         layout, version: the packed-pool cache's rule) and the model's snapshot (the same KernelSpec tensors, unmodified)
         come back -- several batches drawn from one fitted model; a live gpytorch model is re-read per call and always
         misses."""
+        if not self._shares_storage(X_cand, owner):                # (a converted copy: see _packed_pool)
+            self._mean_cache = None
+            return posterior_mean(spec, cand)
         key = (X_cand.data_ptr(), tuple(X_cand.shape), tuple(X_cand.stride()), X_cand.dtype, X_cand._version,
+               owner.data_ptr(), owner._version,
                id(spec.alpha), spec.alpha._version, id(spec.X_obs), spec.X_obs._version,
                id(spec.lengthscale), spec.lengthscale._version, spec.kind, float(spec.outputscale), float(spec.mean_const))
         hit = getattr(self, "_mean_cache", None)
@@ -177,6 +188,22 @@ class HipOps:
         out = posterior_mean(spec, cand)
         self._mean_cache = (key, weakref.ref(owner), weakref.ref(spec.alpha), weakref.ref(spec.X_obs), out)
         return out
+
+    @staticmethod
+    def _shares_storage(X_cand, owner):
+        """True iff X_cand IS the caller's pool memory (the owner tensor itself or a view of it from its first element):
+        only then does the owner's liveness pin the block and its version counter see every in-place write."""
+        return (isinstance(owner, torch.Tensor) and owner.device == X_cand.device and owner.dtype == X_cand.dtype
+                and owner.data_ptr() == X_cand.data_ptr())
+
+    def size_cliff(self, which: str, message: str):
+        """A size beyond the compiled device kernels sends a phase to the host: correct, much slower -- said ONCE per
+        backend and phase, naming the limit (the reference takes any N_nys and batch: SOBER/_rchq.py:34-39, :224-270)."""
+        seen = self.__dict__.setdefault("_cliffs_seen", set())
+        if which not in seen:
+            seen.add(which)
+            import warnings
+            warnings.warn("sober_amd: " + message, RuntimeWarning, stacklevel=3)
 
     def clear_cache(self):
         """Drop what is kept across calls (the packed fingerprint pool, the pool's posterior mean): after writing into a
@@ -242,6 +269,10 @@ class HipOps:
         range(Q) serves, Q^T itself does.  (The literal host route still computes U_B.)"""
         dev, M = self.device, p.M
         if M > nat.chol_max_n() or s > 256 or s >= M:
+            if s < M:                                             # (s >= M is the reference's own degenerate case, not a size limit)
+                self.size_cliff("nystrom", f"N_nys = {M}, batch = {s + 1}: beyond the device Nystrom route (N_nys <= "
+                                           f"{nat.chol_max_n()}, batch <= 257); make_cov_psd and svd_lowrank run on host LAPACK "
+                                           "instead -- about 5-10x the device route's time for this phase")
             self.gram(p)
             return None
         G = self.gram(p)
@@ -285,7 +316,7 @@ class HipOps:
             j.probe_ws, j.probe_ws_bytes = pws.data_ptr(), pws.numel()
         # the projection rides in the same call when the plan is a real one (it is simply redone should the flags
         # send the step to the host route)
-        proj = hasattr(p, "weighted") and not os.environ.get("SOBER_SYNC_LIST")
+        proj = hasattr(p, "weighted")
         if proj:
             T = p.T
             P = torch.empty(s, p.Mtot if T is not None else M, dtype=torch.float64, device=dev)
@@ -543,8 +574,7 @@ class HipOps:
         # loop's synchronisation and that level's launches); level_final() then finds its result waiting
         fin = None
         p.ws.pop("final_done", None)
-        if not p.weighted and getattr(p, "Kmat", None) is None and self.car_mode != nat.CAR_HOST and job.car_ws \
-                and not os.environ.get("SOBER_FINAL_FROM_PYTHON"):
+        if not p.weighted and getattr(p, "Kmat", None) is None and self.car_mode != nat.CAR_HOST and job.car_ws:
             fin = self._final_job(p, S, mu, row_offset)
         level_R, R_final, in_b, gave_up = nat.level_loop(job, R, idx_cur, idx_new, sums_ready, events, nat._stream(mu), fin)
         if fin is not None and fin.done:

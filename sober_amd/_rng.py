@@ -52,8 +52,7 @@ def device_randn(M: int, q: int, device):
     numel = M * q
     if _verified is None:
         _verified = _self_check()
-    host_only = bool(os.environ.get("SOBER_HOST_RANDN"))          # A/B switch: torch.randn + copy
-    state = torch.get_rng_state() if _verified and numel >= 16 and not host_only else None
+    state = torch.get_rng_state() if _verified and numel >= 16 else None
     if state is None or state.numel() != _STATE_BYTES:
         return torch.randn(M, q, dtype=torch.float64).to(device)
     device = torch.device(device)

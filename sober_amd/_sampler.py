@@ -33,8 +33,10 @@ class EmpiricalSampler(RecombinationSampler):
     fingerprints): candidates are the prior's available rows, their weights come from `pi` (sober_amd.PI for the
     LFI sampler), the heaviest are kept (`adaptive_pruning`), scrubbed (`cleansing_weights`) and a Nystrom sample is
     drawn with probability ~ 1 / weight (`deweighted_resampling`) -- everything on the device; `sampling_recombination`
-    then takes (X_cand, X_nys, weights).  The continuous path (`sampling_candidates`: prior updates, WKDE refits) is
-    candidate GENERATION and stays with the reference."""
+    then takes (X_cand, X_nys, weights).  The sampled-prior path (`sampling_candidates`, SOBER/_sampler.py:163-323: draws
+    from the prior, prior updates, WKDE refits) is candidate GENERATION -- SURVEY.md section 2: out of scope -- and stays
+    with the reference; of that block only `nystrom_subsample` (:316-320, contract row a10) lives here.
+    `examples/sampled_prior.py` shows the few lines that connect a sampled prior to `Sober.next_batch`."""
 
     def __init__(self, prior, pi, kernel, thresh=5, label="dataset", dataset_pruning=True, prior_updater=None):
         super().__init__(kernel, thresh=thresh)
@@ -46,99 +48,12 @@ class EmpiricalSampler(RecombinationSampler):
         self.prior_updater = prior_updater
         self.flag = False
 
-    # ---- the sampled-prior path (SOBER/_sampler.py:163-323).  CONVENIENCE OUTSIDE THE SURVEY.md 8 CONTRACT: candidate
-    #      generation is not the hot path (SURVEY.md 2 marks the sampler's internals other than the funnel out of
-    #      scope); these few methods only keep `Sober.next_batch` callable with a sampled prior -- control flow as in
-    #      the reference, drawing from / refitting / resetting the prior delegated to the prior object and the
-    #      caller's hooks.  Of this block only `nystrom_subsample` (:316-320) is on the contract (row a10).
-    def check_categorical(self):
-        """SOBER/_sampler.py:163-176."""
-        return self.label in ("mixedcategorical", "categorical")
-
-    def update_prior(self, X_cand, weights, verbose=False):
-        """SOBER/_sampler.py:110-161 refits the prior on the weighted sample (`_prior_update.py`): outside the hot
-        path -- delegated to `prior_updater(sampler, X_cand, weights)`."""
-        if self.prior_updater is None:
-            raise NotImplementedError("updating a sampled prior needs `prior_updater` (see sober_amd/_sober.py)")
-        self.prior_updater(self, X_cand, weights)
-
-    def sampling(self, n_rec):
-        """SOBER/_sampler.py:178-192."""
-        X_cand = self.prior.sample(n_rec)
-        weights = self.pi(X_cand) / self.prior.pdf(X_cand)
-        return X_cand, self.cleansing_weights(weights.contiguous())
-
-    def categorical_sampling(self, n_rec):
-        """SOBER/_sampler.py:194-208."""
-        X_cand, X_indices = self.prior.sample_both(n_rec)
-        weights = self.pi(X_cand) / self.prior.pdf(X_indices)
-        return X_cand, X_indices, self.cleansing_weights(weights.contiguous())
-
-    def recursive_sampling(self, n_rec, n_repeat=5, verbose=False):
-        """SOBER/_sampler.py:210-262: repeat the weighted draw until more than `thresh` candidates carry weight;
-        none at all -> uniform weights (`flag`)."""
-        n_accepted, X_acc, I_acc, w_acc = 0, [], [], []
-        self.flag = False
-        cat = self.check_categorical()
-        for _ in range(n_repeat):
-            if cat:
-                X_cand, X_indices, weights = self.categorical_sampling(n_rec)
-            else:
-                X_cand, weights = self.sampling(n_rec)
-            idx = weights > 0
-            if not idx.sum() == 0:
-                X_acc.append(X_cand[idx])
-                w_acc.append(weights[idx])
-                n_accepted += int(idx.sum())
-                if cat:
-                    I_acc.append(X_indices[idx])
-            if n_accepted > self.thresh:
-                break
-        if n_accepted == 0:
-            self.flag = True
-            if cat:
-                X_cand, X_indices, weights = self.categorical_sampling(n_rec)
-                return X_cand, X_indices, torch.ones(n_rec, dtype=weights.dtype, device=weights.device) / n_rec
-            X_cand, weights = self.sampling(n_rec)
-            return X_cand, torch.ones(n_rec, dtype=weights.dtype, device=weights.device) / n_rec
-        X_cand = torch.vstack(X_acc)
-        weights = self.cleansing_weights(torch.cat(w_acc).contiguous())
-        if cat:
-            return X_cand, torch.vstack(I_acc), weights
-        return X_cand, weights
-
     def nystrom_subsample(self, X_cand, weights, n_nys):
         """SOBER/_sampler.py:316-320: KMeans centroids for a continuous prior (HIP Lloyd iterations), a draw with
         probability ~ 1 / weight otherwise."""
         if self.label == "continuous":
             return self.kmeans_resampling(X_cand, n_clusters=n_nys)
         return X_cand[self.deweighted_resampling(weights, n_nys)]
-
-    def sampling_candidates(self, n_rec, n_nys, verbose=False):
-        """SOBER/_sampler.py:264-323 -> (X_cand, X_nys, weights)."""
-        assert n_rec > n_nys
-        cat = self.check_categorical()
-        if cat:
-            X_cand, X_indices, weights = self.categorical_sampling(n_rec)
-        else:
-            X_cand, weights = self.sampling(n_rec)
-        if self.check_weights(weights):
-            self.update_prior(X_indices if cat else X_cand, weights, verbose=verbose)
-            self.thresh = n_nys
-            out = self.recursive_sampling(n_rec, n_repeat=self.thresh, verbose=verbose)
-            X_cand, weights = out[0], out[-1]
-        else:
-            out = self.recursive_sampling(n_rec, n_repeat=self.thresh, verbose=verbose)
-            X_cand, weights = out[0], out[-1]
-            if self.flag:
-                return X_cand, X_cand[:n_nys], weights
-            self.update_prior(out[1] if cat else X_cand, weights, verbose=verbose)
-            self.thresh = n_nys
-            out = self.recursive_sampling(n_rec, n_repeat=self.thresh, verbose=verbose)
-            X_cand, weights = out[0], out[-1]
-        X_nys = self.nystrom_subsample(X_cand, weights, n_nys)
-        self.thresh = self.thresh_initial
-        return X_cand, X_nys, weights
 
     def sampling_datasets(self, n_rec, n_nys):
         """SOBER/_sampler.py:351-382 -> (idx_sampled, X_cand, X_nys, weights) with pruning, else (X_cand, X_nys,

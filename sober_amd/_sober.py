@@ -2,11 +2,13 @@
 path: pi = `sober_amd.PI` (LFI weights over the pool), kernel = `sober_amd.Kernel`, the candidate funnel of
 `sober_amd.EmpiricalSampler`, `sampling_recombination` -> HIP.  What the reference does AROUND the path stays with
 the reference: GP fitting, the FBGP / BQ model families (`PI_FBGP`, `PI_BQ`), prior updates and WKDE refits
-(`_prior_update.py`).  A continuous/mixed prior therefore needs the caller's `prior_updater` (any callable
-`(sampler, X, weights) -> None`, e.g. the reference's `update_prior` bound to its own prior classes) and
-`prior_initialiser` (`(sampler) -> None`: what the reference's `initialise_prior`, SOBER/_sampler.py:87-111, does with
-its own prior classes); WHEN the prior is reset is decided here exactly like the reference (`should_reset_prior`).
-The dataset prior (`prior.type == "dataset"`) needs neither."""
+(`_prior_update.py`), and candidate GENERATION from a sampled prior (SOBER/_sampler.py:163-323).  A continuous/mixed
+prior therefore needs three hooks from the caller: `candidate_funnel` (`(sober, n_rec, n_nys, verbose) -> (X_cand, X_nys,
+weights)`: the reference's `sampling_candidates`; `examples/sampled_prior.py` is one), `prior_updater` (`(sampler, X,
+weights) -> None`, e.g. the reference's `update_prior` bound to its own prior classes) and `prior_initialiser`
+(`(sampler) -> None`: what the reference's `initialise_prior`, SOBER/_sampler.py:87-111, does with its own prior
+classes); WHEN the prior is reset is decided here exactly like the reference (`should_reset_prior`).  The dataset prior
+(`prior.type == "dataset"`) needs none of them."""
 import torch
 
 from ._kernel import Kernel
@@ -16,9 +18,10 @@ from ._sampler import EmpiricalSampler
 
 class Sober(EmpiricalSampler):
     def __init__(self, prior, model, thresh=5, sampler_type="lfi", kernel_type="predictive_covariance",
-                 dataset_pruning=True, prior_updater=None, prior_initialiser=None):
+                 dataset_pruning=True, prior_updater=None, prior_initialiser=None, candidate_funnel=None):
         """SOBER/_sober.py:10-39."""
         self.prior_initialiser = prior_initialiser
+        self.candidate_funnel = candidate_funnel
         self.sampler_type = sampler_type
         self.kernel_type = kernel_type
         self.dataset_pruning = dataset_pruning
@@ -78,6 +81,14 @@ class Sober(EmpiricalSampler):
                 f"{self.n_batches_until_reset} batches, or recycle_prior=False) and no `prior_initialiser` was given: "
                 "pass Sober(..., prior_initialiser=lambda sampler: ...) that puts a fresh prior into sampler.prior")
         self.prior_initialiser(self)
+
+    def sampling_candidates(self, n_rec, n_nys, verbose=False):
+        """SOBER/_sampler.py:264-323 is candidate generation: the caller's `candidate_funnel` does it."""
+        if getattr(self, "candidate_funnel", None) is None:
+            raise NotImplementedError(
+                "a sampled prior needs Sober(..., candidate_funnel=callable(sober, n_rec, n_nys, verbose) -> (X_cand, X_nys, "
+                "weights)): the reference's own sampling_candidates, or examples/sampled_prior.py")
+        return self.candidate_funnel(self, n_rec, n_nys, verbose)
 
     def next_batch(self, n_rec, n_nys, batch_size, calc_obj=None, return_weights=False, recycle_prior=True,
                    verbose=False):

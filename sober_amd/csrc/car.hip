@@ -39,13 +39,6 @@ constexpr int CAR_BT = 256;         // threads of k_car_bidiag
 
 // ---- DPP cross-lane helpers (row = 16 lanes).  ds_bpermute-based __shfl costs an LDS round trip
 // per step; these are plain VALU moves.
-#ifdef CAR_NO_DPP
-template <int CTRL>
-__device__ __forceinline__ double dpp(double v) {
-    const int l = threadIdx.x & 63;
-    return __shfl(v, (l & 0x30) | ((l - (CTRL & 15)) & 15), 64);
-}
-#else
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -53,7 +46,6 @@ __device__ __forceinline__ double dpp(double v) {
     hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-#endif
 constexpr int ROR1 = 0x121, ROR2 = 0x122, ROR4 = 0x124, ROR8 = 0x128;
 
 // workgroup barrier that waits for this wave's LDS traffic only: global stores (the reflector vectors
@@ -183,31 +175,11 @@ struct CarLds2 {
 };
 
 // timing-only switches (wrong results): what each part of the step costs  (scripts/bidiag_where.sh)
-#ifdef CB2_X_NORSUM
-#define CB2_RSUM(v) (v)
-#else
 #define CB2_RSUM(v) row16_sum(v)
-#endif
-#ifdef CB2_X_NOHUPD
-#define CB2_HUPD(n, o) (o)
-#else
 #define CB2_HUPD(n, o) (n)
-#endif
-#ifdef CB2_X_NOGUPD
-#define CB2_GUPD(n, o) (o)
-#else
 #define CB2_GUPD(n, o) (n)
-#endif
-#ifdef CB2_X_NOBAR
-#define CB2_BARRIER() do { } while (0)
-#else
 #define CB2_BARRIER() CAR_LDS_BARRIER()
-#endif
-#ifdef CB2_X_NOVSTORE
-#define CB2_VSTORE(e) do { } while (0)
-#else
 #define CB2_VSTORE(e) e
-#endif
 #ifdef CAR_BSTAMPS
 #define CB2_STAMP(K, VAL) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(VAL) :: "memory"); \
     cacc_[K] += t_ - ctl_; ctl_ = t_; } while (0)
@@ -262,23 +234,15 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         double ss = CB2_RSUM(ss0 + ss1);
         CB2_STAMP(2, ss);
         double beta, tau, sc;
-#ifdef CB2_X_NOLARFG
-        beta = alpha; tau = ss; sc = alpha + ss;
-#else
         larfg_vt(alpha, ss, tau, sc); (void)beta;
-#endif
         CB2_STAMP(3, tau);
         // w = A v = column i + sc * (A x) over my rows
         double tG[CAR_MS];
 #pragma unroll
         for (int k = S; k < MS; ++k) {
             double w0 = 0.0, w1 = 0.0;
-#ifndef CB2_X_NOQ
 #pragma unroll
             for (int q = S; q < CQ; ++q) { if (q & 1) w1 = fma(a[k][q], x[q], w1); else w0 = fma(a[k][q], x[q], w0); }
-#else
-            w0 = a[k][S]; w1 = x[S];
-#endif
             tG[k] = tau * fma(sc, CB2_RSUM(w0 + w1), cur[k]);
         }
         tG[S] = (R > li) ? tG[S] : 0.0;                      // rows <= i stay
@@ -340,12 +304,10 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         double yp[CAR_CQ], s2p = 0.0;
 #pragma unroll
         for (int q = S; q < CQ; ++q) yp[q] = cm[S] * a[S][q];
-#ifndef CB2_X_NOY
 #pragma unroll
         for (int k = S + 1; k < MS; ++k)
 #pragma unroll
             for (int q = S; q < CQ; ++q) yp[q] = fma(cm[k], a[k][q], yp[q]);
-#endif
 #pragma unroll
         for (int k = S; k < MS; ++k) s2p = fma(cm[k], cm[k], s2p);
 #pragma unroll
@@ -354,7 +316,6 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         CB_STAMP(6);
         CB2_BARRIER();
         CB_STAMP(7);
-#ifndef CB2_X_NOD
         // the 16 partial sums per live column: column 16 S + t belongs to thread t of waves 0 .. 2 (192 threads cover the
         // live columns from block 1 on).  WAVE 3 has no column of its own then: it sums the norm and runs H(i)'s scalar
         // chain (dlarfg: ~35 dependent instructions) HERE, beside the column sums, instead of every thread running it at
@@ -387,7 +348,6 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
             larfg_vt(L.scal[p], s2n, tq, s2c);
             if (tid == 192) { L.hsc[0] = tq; L.hsc[1] = s2c; }
         }
-#endif
         CB_STAMP(8);
         CB2_BARRIER();
         CB_STAMP(9);
@@ -717,7 +677,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {        // total i
 // leaves empty.  (The round-1 kernel rotated the ownership with every pivot -- column c -> wave c mod 16 --: one barrier,
 // one hand-over of the weights and one LDS round trip of the pivot column per pivot, 1.14 us each.)
 constexpr int SP_W = 16, SP_BC = 7, SP_RING = 32;
-constexpr int SP_W_MAX_DBG = 16;
+
 #ifdef SP_TSTAMPS     // diagnostic build (scripts/pivot_stamps.py): s_memrealtime (100 MHz) of every publish, by pivot index
 __device__ unsigned long long g_sp_stamps[260];
 __device__ unsigned long long g_sp_seg[SP_W_MAX_DBG * 8];   // per wave: ticks summed by segment of the produce step
@@ -739,11 +699,7 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
     double rt[4], rc[4];
     unsigned kh[4], kl[4];
 #pragma unroll
-#ifdef SP_X_NODIV      // timing-only builds (wrong results): what each part of the producer's loop costs
-    for (int q = 0; q < NQ; ++q) { rt[q] = st.mu[q] * col[q]; rc[q] = col[q]; }
-#else
     for (int q = 0; q < NQ; ++q) { rt[q] = st.mu[q] / col[q]; rc[q] = 1.0 / col[q]; }
-#endif
     SP_SEG(5, "+v", rt[3]);                                          // the eight divisions
     unsigned hmin = 0xffffffffu;
 #pragma unroll
@@ -857,12 +813,10 @@ __device__ __forceinline__ void sp_produce_step(double (&phi)[SP_BC][4], SpState
     sp_ratio_test<NQ>(col, st, piv, al, rp SP_DBG_PASS);
     SP_SEG(1, "+s", piv);                                     // ratio test: ballots, the winner's lane, its quotient
     SpSlot& e = ring[sp % SP_RING];
-#ifndef SP_X_NOPUB
     if (piv >= 0) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) e.col[lane + 64 * q] = col[q];
     }
-#endif
     if (lane == 0) { e.alpha = al; e.rpp = rp; e.piv = piv; }
 #ifdef SP_TSTAMPS
     { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) g_sp_stamps[sp] = t_; }
@@ -873,9 +827,7 @@ __device__ __forceinline__ void sp_produce_step(double (&phi)[SP_BC][4], SpState
     if (piv < 0) { stop = true; return; }                     // Q6: the loop ends here (:241-242)
     sp_mu_step<NQ>(st, col, al, piv, lane);
     SP_SEG(3, "+v", st.mu[0]);                                // weights
-#ifndef SP_X_NOELIM
     sp_elim<JJ + 1, NQ>(phi, col, piv, rp);
-#endif
 }
 
 // NQ: 64-row slots in use (N <= 64 NQ): a 20-point step does not run the ratio test of a 200-point one
@@ -1161,7 +1113,7 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
     static std::atomic<unsigned> epoch_ctr{0};
     const unsigned epoch = (epoch_ctr.fetch_add(1) + 1u) & 0x1FFFFFFu;
     void* comm = (void*)(Phi + (size_t)sober::CAR_NS * sober::CAR_PC + 512);
-    static const int per_xcd = getenv("SOBER_CARF_PER_XCD") ? atoi(getenv("SOBER_CARF_PER_XCD")) : 40;    // (tuning aid)
+    constexpr int per_xcd = 40;
     const unsigned spin_limit = sober_car_giveup_forced() ? 0u : sober::CARF_SPIN_LIMIT;
     CAR_BY_SIZE(m, N, hipLaunchKernelGGL((sober::k_car_bidiag_fused<MS_, CQ_>), dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X, ldx,
                                          N, m, vws, taup, Phi, comm, (unsigned)sober::carf_bytes(m), epoch, spin_limit));

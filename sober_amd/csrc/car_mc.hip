@@ -245,9 +245,7 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], double (&r)[C
     MC_STAMP_DECL
     for (int i = 64 * SL; i < i_end; ++i) {
         MC_STAMP(0);
-#ifndef MC_X_NOWAIT
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): my entries of reflector i - 1 are in memory (stored a step ago: free)
-#endif
         const int li = i & 63;
         const unsigned tag = (unsigned)i + 1u;
         const unsigned par = (unsigned)i & 1u;
@@ -287,9 +285,7 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], double (&r)[C
         }
         MC_LDS_BARRIER();
         MC_STAMP(2);
-#ifndef MC_X_NOPROG
         if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32((unsigned)i, rs, OFF_PROG + 4u * (unsigned)cu, 0, 0);   // (all four waves are past their wait)
-#endif
         // ---- 3. the exchange: thread t > i owns row t (publishes this CU's partial q_t, gathers the nine partials
         //         and column i's entry), thread i carries the partial norms in the slot of the (finished) row i and
         //         the diagonal entry A[i][i]; measured forms: scripts/xcd_exchange_probe.hip
@@ -496,11 +492,7 @@ __device__ __forceinline__ void phi_rows(const double* __restrict__ vws, int N, 
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int col = lane + 64 * q - m;
-#ifndef MC_X_NOSTORE
                 if (col >= 0 && col < K) PhiT[(size_t)col * NS + r] = (r < N) ? p[w][q] : 0.0;
-#else
-                if (col >= 0 && col < K && p[w][q] == 123.456) PhiT[(size_t)col * NS + r] = 0.0;
-#endif
             }
         }
         // this group of rows is in memory (a spin that gave up has set the error word): the pivot kernel refuses to run
@@ -526,9 +518,7 @@ __global__ __launch_bounds__(256) void k_mc_bidiag(const double* __restrict__ X,
     const int cu = __builtin_amdgcn_readfirstlane(L.ldead);
     if (cu < 0) return;
     if (cu >= GMAX) {                                               // (fused launch) a consumer: rows of Phi
-#ifndef MC_X_NOCONSUMERS
         phi_rows(vws, N, m, PhiT, comm, rs, L);
-#endif
         return;
     }
     __syncthreads();

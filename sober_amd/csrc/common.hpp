@@ -4,6 +4,16 @@
 #include <stdint.h>
 #include "../../include/sober_hip.h"
 
+// Diagnostic builds: the in-kernel time stamps (*_STAMPS switches: same results, slower kernels, debug exports) exist
+// only behind SOBER_DIAG_BUILD, which `make all` never defines.  Such a library says so (sober_diag_build() = 1) and
+// sober_amd._native.load() refuses it unless SOBER_ALLOW_DIAG_LIB=1 (the stamp scripts under scripts/ set it).  There
+// are no switches that change RESULTS: the timing-only experiments of rounds 2-3 are out of the source (their numbers:
+// profiles/r03_bidiag_where.txt).
+#if (defined(CAR_BSTAMPS) || defined(SP_TSTAMPS) || defined(MC_STAMPS) || defined(MC_TSTAMPS) || defined(CM_STAMPS) || \
+     defined(CH_STAMPS) || defined(LW_STAMPS)) && !defined(SOBER_DIAG_BUILD)
+#error "in-kernel stamps are diagnostic builds: make stamps, or EXTRA='-DSOBER_DIAG_BUILD -D..._STAMPS' with a BUILD/OUT of its own"
+#endif
+
 #define SOBER_MAX_DT 32          // largest padded dimension with a register-tiled instantiation
 #define SOBER_WAVE 64
 

@@ -175,15 +175,8 @@ __global__ __launch_bounds__(256) void k_kmeans_assign_mfma(const double* __rest
         for (int bl = 0; bl < PB; ++bl) {
             d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-#ifdef KM_X_NOMFMA       // timing-only builds (wrong results): what each part of the tile costs
-            for (int ks = 0; ks < KT; ++ks) { acc[0] += a[ks]; acc[1] += b[bl][ks]; acc[2] -= a[ks]; acc[3] -= b[bl][ks]; }
-#else
             for (int ks = 0; ks < KT; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[bl][ks], acc, 0, 0, 0);
-#endif
             // lane (lj, lg): centroid rows lg + 4 r of the tile against point lj: the two smallest so far
-#ifdef KM_X_NOSEL
-            b1[bl] += (acc[0] + acc[1]) + (acc[2] + acc[3]);
-#else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double v = acc[r];
@@ -192,7 +185,6 @@ __global__ __launch_bounds__(256) void k_kmeans_assign_mfma(const double* __rest
                 b1[bl] = km_min(b1[bl], v);
                 i1[bl] = lt ? (4 * t + r) : i1[bl];
             }
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -522,8 +514,7 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
     LAUNCH_CHECK();
     const bool sorted = ws != nullptr && N < 0x7fffffffLL && K <= KM_MAX_K_SORT && ws_bytes >= (int64_t)km_total(N, K);
     const int kt = (d + 4) / 4;                              // augmented rows [x, 1]: d + 1 entries, 4 per MFMA step
-    static const bool valu_e = getenv("SOBER_KMEANS_VALU") != nullptr;     // (same-box A/B of the E step)
-    const bool mfma_e = sorted && !valu_e && kt <= 8;
+    const bool mfma_e = sorted && kt <= 8;
     double* Caug = mfma_e ? (double*)((char*)ws + km_off_caug(N, K)) : nullptr;
     const int Kp = km_kp(K);
     if (mfma_e) {

@@ -146,7 +146,6 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
         Rub[L + 1] = (Rub[L] / S) * b + (Rlo[L] == Rub[L] ? Rub[L] % S : S - 1);
         ++L;
     }
-    if (const char* qm = getenv("SOBER_QUEUE_MAX")) { const int v = atoi(qm); if (v < L) L = v; }   // debugging aid
     if (L < 2) return 0;                                                // nothing to gain: the synchronised loop
     if (!sober_car_supported(S, b)) return SOBER_E_DIM;
     hipStream_t st = (hipStream_t)stream;
@@ -221,11 +220,6 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
     while (d < L && j->h_dR[d + 1] >= 0) { level_R[d] = j->h_dR[d]; ++d; }
     *done = d;
     *R_out = j->h_dR[d];
-    if (getenv("SOBER_QUEUE_DEBUG")) {
-        fprintf(stderr, "queued levels %d, completed %d:", L, d);
-        for (int l = 0; l <= L; ++l) fprintf(stderr, " %lld[%lld..%lld]", (long long)j->h_dR[l], (long long)Rlo[l], (long long)Rub[l]);
-        fprintf(stderr, "\n");
-    }
     return 0;
 }
 

@@ -51,11 +51,7 @@ __device__ __forceinline__ double tani_fast(double dot, double nx, double ny) {
     return fma(fma(-q, den, num), r, q);
 }
 
-#ifdef TANI_X_NOEXPAND      /* timing experiments only (scripts/tani_where.sh): results are wrong */
-#define LT_EXPAND(x) ((int4_t){(int)(x), (int)(x), (int)(x), (int)(x)})
-#else
 #define LT_EXPAND(x) expand16(x)
-#endif
 template <int DT>      // 64-bit words per fingerprint
 __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     const unsigned long long* __restrict__ rows, const double* __restrict__ rows_norm, int n_rows,
@@ -218,22 +214,14 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
             for (int j = 0; j < LT_BD && j < DT; ++j) bq[j] = *(const int4_t*)(bp + j * 64);
 #pragma unroll
             for (int ks = 0; ks < DT; ++ks) {
-#ifdef TANI_X_NODSREAD          /* timing experiments only (scripts/tani_where.sh): results are wrong */
-                const int4_t bfr = afr[0][(ks + 1) % DT];
-#else
                 const int4_t bfr = bq[ks % LT_BD];
                 if (ks + LT_BD < DT) bq[ks % LT_BD] = *(const int4_t*)(bp + (ks + LT_BD) * 64);
-#endif
 #pragma unroll
                 for (int t = 0; t < LT_RT; ++t)
-#ifdef TANI_X_NOMFMA
-                    cc[t] += bfr;
-#else
                 {
                     if (ks & 1) cd[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[t][ks], bfr, cd[t], 0, 0, 0);
                     else cc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[t][ks], bfr, cc[t], 0, 0, 0);
                 }
-#endif
             }
             // (the scheduler would pull every read back to just in front of its MFMA: pin the order -- LT_BD reads, then
             //  one MFMA per further read)
@@ -252,11 +240,7 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
             for (int t = 0; t < LT_RT; ++t)
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
-#ifdef TANI_X_NOQUOT
-                    acc[t][v] = fma((double)cc[t][v] + ny, w, acc[t][v]);
-#else
                     acc[t][v] = fma(tani_fast((double)cc[t][v], nxr[t][v], ny), w, acc[t][v]);
-#endif
         }
         LT_STAGE_WRITE(buf ^ 1)
         __syncthreads();

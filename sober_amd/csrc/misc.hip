@@ -388,6 +388,14 @@ using namespace sober;
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 extern "C" int sober_abi_version(void) { return SOBER_ABI_VERSION; }
+// 1 = this library carries in-kernel stamps (a diagnostic build: never the one the product or the tests load)
+extern "C" int sober_diag_build(void) {
+#ifdef SOBER_DIAG_BUILD
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 namespace sober {
 LaunchEvents& launch_events() {

@@ -14,8 +14,13 @@
 //      sums slot e & 1 of ranks 0, 1, .., W-1 -- its own region included, in that order -- into its share of the message.
 // Two slots are enough: a rank can only finish call e + 1 once every peer has raised e + 1, i.e. has left call e, so
 // nobody still reads slot e & 1 when call e + 2 overwrites it.  A rank that never shows up ends the wait after
-// spin_limit polls: the error word is set (sober_peer_status after the next synchronisation), the message is
-// restored from the rank's own slot by the caller's fallback -- never a hang.
+// spin_limit polls (~ 30 s: an uneven shard, a collector pause or a page-in on a peer are waited for like RCCL would):
+// the error word takes the number of the failing call and sober_peer_status reports SOBER_E_EXCHANGE after the next
+// synchronisation -- never a hang.  That error is FATAL for the sharded run on this rank (level_exec.cpp returns it,
+// _native.level_loop_sharded raises): a time-out is decided per rank, so there is no group-wide state left to continue
+// from; what can be continued is decided before the first call, by the self-check at set-up (PeerComm.self_check), after
+// which the group takes the RCCL route together.  sober_peer_status can hand back the rank's own message of the failing
+// call (its slot is still intact) for callers that want to report or re-send it.
 #include "common.hpp"
 #include <cstring>
 
@@ -34,7 +39,7 @@ struct PeerComm {
     unsigned char** d_peers = nullptr;                // the table above, on the device
     unsigned epoch = 0;                               // calls made so far
     unsigned arrivals = 0;                            // workgroups launched so far (mod 2^32)
-    unsigned spin_limit = 1u << 23;                   // polls of one flag before giving up (~ 2 s)
+    unsigned spin_limit = 1u << 27;                   // polls of one flag before giving up (~ 30 s; the set-up's self-check uses short waits)
     unsigned* h_err = nullptr;                        // the error word: pinned host memory the kernel writes (no copy to read it)
     bool connected = false;
 };
@@ -67,7 +72,9 @@ __global__ __launch_bounds__(256) void k_peer_allreduce(unsigned char* __restric
         }
         if (!ok) {
             __hip_atomic_store((unsigned*)(mine + PEER_OFF_ERR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (the FIRST failing call's number: later calls queued behind it must not move the slot sober_peer_status restores from)
+            unsigned expect = 0u;
+            __hip_atomic_compare_exchange_strong(err_host, &expect, epoch | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         s_ok = ok;
     }
@@ -186,10 +193,11 @@ extern "C" int64_t sober_peer_allreduce_ptr(void) { return (int64_t)(intptr_t)&s
 extern "C" int sober_peer_status(void* comm, double* restore, int64_t n, void* stream) {
     PeerComm* c = (PeerComm*)comm;
     if (!c) return SOBER_E_ARG;
-    if (*(volatile unsigned*)c->h_err == 0u) return 0;
+    const unsigned ew = *(volatile unsigned*)c->h_err;
+    if (ew == 0u) return 0;
     *(volatile unsigned*)c->h_err = 0u;                                // (reported once; the flags themselves stay consistent)
     if (restore && n > 0 && n <= c->n_max) {
-        const double* slot = (const double*)(c->mine + sober::PEER_HDR) + (size_t)(c->epoch & 1u) * (size_t)c->n_max;
+        const double* slot = (const double*)(c->mine + sober::PEER_HDR) + (size_t)(ew & 1u) * (size_t)c->n_max;   // (the failing call's slot)
         HIP_TRY(hipMemcpyAsync(restore, slot, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return SOBER_E_EXCHANGE;

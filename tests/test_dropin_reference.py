@@ -165,7 +165,7 @@ def test_should_reset_prior_equals_the_reference(ref):
 
     # a reset that is due and no hook: an error that says so, not a silently recycled prior
     s = object.__new__(sober_amd.Sober)
-    s.label, s.n_init, s.n_batches_until_reset, s.prior_initialiser = "continuous", 2, 3, None
+    s.label, s.n_init, s.n_batches_until_reset, s.prior_initialiser, s.candidate_funnel = "continuous", 2, 3, None, None
     s.pi = types.SimpleNamespace(model=types.SimpleNamespace(train_targets=torch.tensor([5.0, 1, 0, 0, 0, 0, 0, 0])))
     assert s.should_reset_prior(2, True)
     with pytest.raises(NotImplementedError, match="prior_initialiser"):
@@ -177,7 +177,7 @@ def test_should_reset_prior_equals_the_reference(ref):
 
     def _stop(*a, **k):                                                  # (stop right behind the reset)
         raise _Stop()
-    s.sampling_candidates = _stop
+    s.candidate_funnel = _stop
     with pytest.raises(_Stop):
         s.next_batch(100, 10, 2)
     assert called == [s]

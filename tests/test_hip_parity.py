@@ -473,7 +473,9 @@ def test_sober_next_batch_vs_reference(dev):
                     assert a.dtype == torch.int64 and np.array_equal(a.cpu().numpy(), z[tag + "_first"]), tag
                 assert np.array_equal(Xb.cpu().numpy(), z[tag + "_X"]), tag
         c = MG.SOBER_CASES["continuous"]
+        from examples.sampled_prior import sampling_candidates            # (candidate generation: outside the package)
         sober = sober_amd.Sober(MG.UniformPrior(c["d"], device=dev), model_for(c), kernel_type=c["kernel_type"],
+                                candidate_funnel=sampling_candidates,
                                 prior_updater=lambda s, X, w: None)     # the fixture's stand-in keeps the prior too
         torch.manual_seed(c["seed_call"])
         Xb = sober.next_batch(c["n_rec"], c["n_nys"], c["batch"])
@@ -1723,7 +1725,7 @@ def _peer_worker(rank, world, port, name, cuts, outq):
                                              sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu,
                                              group=dist.group.WORLD, row_offset=lo)
         from sober_amd._engine import DistComm
-        used = any(pc is not False and pc is not None for pc in DistComm._PEER.values())
+        used = any(ent[1] is not False and ent[1] is not None for ent in DistComm._PEER.values())
         outq.put((rank, idx.cpu().numpy(), w.cpu().numpy(), used))
     finally:
         dist.destroy_process_group()

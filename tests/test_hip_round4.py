@@ -1,0 +1,212 @@
+"""GPU tests added in round 4 (run with -m gpu on an MI355X), all through the C ABI:
+  * a fixed-seed slice of the randomised device-vs-oracle sweep (tests/tools/fuzz_parity.py) with its one-ulp classifier, so
+    that the driver repeats what used to be evidence under profiles/ only;
+  * the far side of the two size limits of the device kernels (N_nys > 536: host Nystrom route; batch > 224: host
+    Caratheodory route) against the oracle, asserting WHICH route ran and that it says so once;
+  * the two advisor findings of round 3 (a converted pool copy is never served from the packed-pool cache; a non-square
+    covar_cache root takes the Python route of the row table);
+  * `bench.py --gpus 2` end to end on the one GPU (gloo between the ranks; the direct-peer all-reduce forced in a second
+    run): the N > 1 branch of the bench must not meet its first run on an 8-GPU node."""
+import json
+import os
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import sober_amd
+from oracle import sober_oracle as O
+from tests.golden.synth import SEED_CALL, build_spec, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the -m gpu tests need the MI355X"
+    from sober_amd import _native
+    _native.load()
+    return torch.device("cuda:0")
+
+
+def kspec(spec):
+    return sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs, spec.S_cache,
+                                spec.noise, spec.mean_const, spec.alpha)
+
+
+# --------------------------------------------------------------------------- #
+# the randomised sweep, a fixed slice of it
+# --------------------------------------------------------------------------- #
+def test_fuzz_slice_vs_oracle(dev):
+    """30 random continuous-kernel recombinations (batch 5-120: every size instantiation of the one-CU Caratheodory kernels
+    and the multi-CU ones, leftovers of every kind, three modes, calc_obj in a quarter) and 10 fingerprint ones, device
+    against oracle on the same seeded inputs.  Bar per case: identical indices and weights within 1e-6, or the case is
+    ill-posed IN THE REFERENCE (its own indices change / its own weights move by > 1e-5 when its inputs move by one ulp --
+    the oracle is held to the reference on 64 random cases by tests/test_oracle_vs_reference_fuzz.py).  At most a fifth
+    of the slice may be ill-posed: the classifier is not a way out."""
+    from tests.tools import fuzz_parity as F
+    bad, ill, lines = [], 0, []
+    for tani, n, seed in ((False, 30, 2026), (True, 10, 2027)):
+        rng = np.random.default_rng(seed)
+        for i in range(n):
+            c = F.make_case(rng, tani, batches=[5, 8, 9, 16, 17, 24, 32, 33, 40, 56, 57, 64, 65, 80, 100, 112, 120], n_factor=25)
+            ok, verdict, same, relw = F.check_case(c, dev)
+            lines.append("%s: %s idx_equal=%s max rel w %.1e" % (F.describe(i, c), verdict, same, relw))
+            ill += verdict.startswith("ill-posed")
+            if not ok:
+                bad.append(lines[-1])
+    print("\n".join(lines))
+    assert not bad, bad
+    assert ill <= 8, (ill, [ln for ln in lines if "ill-posed" in ln])
+
+
+# --------------------------------------------------------------------------- #
+# beyond the compiled size set: the host routes, named
+# --------------------------------------------------------------------------- #
+def _vs_oracle(case, dev, timers, rtol):
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    mu_ref = _t(inp["mu0"].copy())
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx_ref, w_ref = O.recombination(_t(inp["X_cand"]), _t(inp["X_nys"]), case["b"], O.Kernel(spec, case["mode"]), init_weights=mu_ref)
+    mu = _t(inp["mu0"].copy()).to(dev)
+    from sober_amd._ops_hip import HipOps
+    ops = HipOps(dev)                                        # (a fresh backend: the size warning is given once per backend)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        torch.manual_seed(SEED_CALL)
+        idx, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                         sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu, _timers=timers, _ops=ops)
+        torch.manual_seed(SEED_CALL)                         # a second step on the same backend: no second warning
+        mu2 = _t(inp["mu0"].copy()).to(dev)
+        sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu2, _ops=ops)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref.numpy())
+    np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=rtol)
+    np.testing.assert_allclose(mu.cpu().numpy(), mu_ref.numpy(), rtol=rtol, atol=0)
+    return [str(r.message) for r in rec if issubclass(r.category, RuntimeWarning) and "sober_amd:" in str(r.message)]
+
+
+def test_nystrom_beyond_the_device_route_goes_to_the_host_and_says_so(dev):
+    """N_nys = 600 > 536 (csrc/chol.hip: CH_MAXN): make_cov_psd + svd_lowrank on host LAPACK (SOBER/_rchq.py:34-39 takes any
+    N_nys), everything else on the device; ONE warning naming the limit."""
+    timers = {}
+    msgs = _vs_oracle(dict(kind=O.RBF, mode="predictive_covariance", N=8000, M=600, d=5, b=40, n_obs=60, seed=41, ard=True),
+                      dev, timers, 1e-7)
+    assert "nystrom_host" in timers and "car_host" not in timers, timers
+    assert len(msgs) == 1 and "N_nys = 600" in msgs[0] and "536" in msgs[0], msgs
+
+
+def test_batch_beyond_the_device_kernels_goes_to_host_lapack_and_says_so(dev):
+    """batch = 250: a 500-point Caratheodory step is beyond csrc/car_mc.hip (N <= 448): host LAPACK + the C++ pivots for
+    every level (SOBER/_rchq.py:224-270 takes any batch), the literal Nystrom route with them; ONE warning per phase."""
+    timers = {}
+    msgs = _vs_oracle(dict(kind=O.RBF, mode="predictive_covariance", N=2600, M=400, d=6, b=250, n_obs=50, seed=42, ard=False),
+                      dev, timers, 1e-6)
+    assert "car_host" in timers and "nystrom_host" in timers, timers
+    assert sum("batch = 250" in m and "224" in m for m in msgs) == 1, msgs
+
+
+# --------------------------------------------------------------------------- #
+# advisor findings of round 3
+# --------------------------------------------------------------------------- #
+def test_converted_pool_copy_is_never_served_from_the_cache(dev):
+    """A fingerprint pool that is NOT float64-on-the-device (here: float32 on the host) reaches the backend as a converted
+    copy whose memory is freed after the call; the allocator hands the same block to the next call's copy, so pointer,
+    layout and a fresh version counter all match -- the packed-pool / pool-mean caches must not answer for it.  The pool
+    is modified IN PLACE between two calls; the second result must be the oracle's on the modified pool."""
+    case = dict(kind=O.TANIMOTO, mode="weighted_predictive_covariance", N=3000, M=64, d=256, b=10, n_obs=25, seed=77,
+                mean_const=0.3, bit_p=0.1)
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    from sober_amd._ops_hip import HipOps
+    ops = HipOps(dev)
+    X32 = _t(inp["X_cand"]).to(torch.float32)                # the caller's pool: float32, host memory
+    Xn = _t(inp["X_nys"]).to(dev)
+
+    def both(X32_now):
+        mu_ref = _t(inp["mu0"].copy())
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            i_ref, w_ref = O.recombination(X32_now.to(torch.float64), _t(inp["X_nys"]), case["b"], O.Kernel(spec, case["mode"]),
+                                           init_weights=mu_ref)
+            mu = _t(inp["mu0"].copy()).to(dev)
+            torch.manual_seed(SEED_CALL)
+            i, w = sober_amd.recombination(X32_now, Xn, case["b"], sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu, _ops=ops)
+        return i_ref.numpy(), w_ref.numpy(), i.cpu().numpy(), w.cpu().numpy()
+
+    a = both(X32)
+    assert np.array_equal(a[0], a[2]) and np.allclose(a[1], a[3], rtol=1e-7)
+    rng = np.random.default_rng(3)
+    flip = rng.random(X32.shape) < 0.2
+    X32[_t(flip)] = 1.0 - X32[_t(flip)]                      # in place: same object, same memory
+    b_ = both(X32)
+    assert not np.array_equal(a[0], b_[0])                   # (the modification matters: the reference selects other points)
+    assert np.array_equal(b_[0], b_[2]) and np.allclose(b_[1], b_[3], rtol=1e-7)
+
+
+def test_non_square_covar_cache_root_takes_the_python_route(dev):
+    """gpytorch's covar_cache is n_obs x k (a Lanczos root) once n_obs exceeds max_cholesky_size; W = S S^T (SOBER/_gp.py:277)
+    is still n_obs x n_obs.  sober_plan_rows assumes a square root: such a spec must build its row table through the
+    Python route (woodbury) -- same result as the oracle with the same root."""
+    case = dict(kind=O.RBF, mode="predictive_covariance", N=2500, M=64, d=3, b=10, n_obs=40, seed=91)
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    k = 24
+    S_k = spec.S_cache[:, :k].contiguous()                   # a rank-k root: W_k = S_k S_k^T
+    import dataclasses
+    spec_k = dataclasses.replace(spec, S_cache=S_k)
+    mu_ref = _t(inp["mu0"].copy())
+    torch.manual_seed(SEED_CALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        i_ref, w_ref = O.recombination(_t(inp["X_cand"]), _t(inp["X_nys"]), case["b"], O.Kernel(spec_k, case["mode"]), init_weights=mu_ref)
+        mu = _t(inp["mu0"].copy()).to(dev)
+        torch.manual_seed(SEED_CALL)
+        i, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                       sober_amd.Kernel(kspec(spec_k), case["mode"]), init_weights=mu)
+    assert np.array_equal(i.cpu().numpy(), i_ref.numpy())
+    np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=1e-7)
+
+
+# --------------------------------------------------------------------------- #
+# bench.py with two ranks on the one GPU
+# --------------------------------------------------------------------------- #
+def _bench_two_ranks(extra_env, port):
+    env = dict(os.environ, SOBER_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--check-unsharded"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("peer", [False, True], ids=["group_allreduce", "direct_peer_forced"])
+def test_bench_two_ranks_one_gpu(peer, dev):
+    """`bench.py --gpus 2 --config 2` as the driver launches it (torch.distributed.run), two ranks sharing the one GPU over
+    gloo: the JSON line of rank 0 says two GPUs-worth of ranks, the sharded route, twice the pool -- and the sharded result
+    IS the unsharded one (rank 0 repeats the step on the gathered pool: identical indices on every rank, weights 1e-9).
+    Second run: the direct-peer all-reduce forced over the non-nccl group (IPC-mapped regions on the one GPU)."""
+    d = _bench_two_ranks({"SOBER_PEER_ALLREDUCE": "force"} if peer else {"SOBER_PEER_ALLREDUCE": "0"}, 29671 + int(peer))
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert "row-sharded x2" in d["config"]["parallelism"]
+    if peer:
+        assert "direct-peer" in d["config"]["parallelism"], d["config"]["parallelism"]
+    assert "200000 in all" in d["config"]["workload"]
+    chk = d["parity_sharded_vs_unsharded"]
+    assert chk["idx_equal_unsharded"] and chk["ranks_agree"], chk
+    assert chk["max_rel_w_vs_unsharded"] < 1e-9, chk
+    assert d["n_selected"] <= 100 and d["value"] > 0 and d["roofline"] is not None

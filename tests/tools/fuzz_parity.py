@@ -1,34 +1,38 @@
 """Random small recombinations on the device against the oracle (same seeded inputs): batch sizes across the size
-instantiations of the Caratheodory kernels, leftovers of every kind, both continuous kernels, with and without the
-posterior correction.  python tests/tools/fuzz_parity.py [n_cases=60] [seed=0]"""
-import os, sys, warnings, time
+instantiations of the Caratheodory kernels, leftovers of every kind, the continuous kernels and fingerprints, the three
+modes, with and without `calc_obj`.  The functions are what tests/test_hip_round4.py::test_fuzz_slice_vs_oracle runs on a
+fixed 40-case slice; as a script:  python tests/tools/fuzz_parity.py [n_cases=60] [seed=0]   (FUZZ_KIND=tanimoto: fingerprint
+pools; FUZZ_ONLY=3,17: replay these cases with the diagnostics).
+
+Verdicts: "ok" = identical indices and weights within 1e-6 (the contract: 1e-4), or within 20x of what the REFERENCE's own
+weights move when its inputs move by one ulp; "ill-posed" = the reference's own indices change, or its own weights move by
+more than 1e-5, under that one-ulp move (the oracle is the reference: tests/test_oracle_vs_reference_fuzz.py holds it to
+the reference on 64 random cases) -- a second implementation cannot be held to such a case; "BAD" = anything else."""
+import os, sys, warnings
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import sober_amd
 from oracle import sober_oracle as O
-warnings.simplefilter("ignore")
-dev = torch.device("cuda:0")
+
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-only = set(int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v)     # replay these cases only (+ diagnostics)
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-bad = 0
-for case in range(n_cases):
-    b = int(rng.choice([5, 8, 9, 16, 17, 24, 32, 33, 40, 56, 57, 64, 65, 80, 100, 112, 120, 150]))
+BATCHES = [5, 8, 9, 16, 17, 24, 32, 33, 40, 56, 57, 64, 65, 80, 100, 112, 120, 150]
+
+
+def make_case(rng, tani=False, batches=BATCHES, n_factor=40):
+    """One random case (all the random draws happen here, in a fixed order: a seed names a sweep)."""
+    b = int(rng.choice(batches))
     d = int(rng.integers(2, 13))
     M = int(rng.integers(b + 8, max(b + 9, 4 * b)))
-    N = int(rng.integers(max(2 * b + 1, M + 1), 40 * b + 50))
+    N = int(rng.integers(max(2 * b + 1, M + 1), n_factor * b + 50))
     n_obs = int(rng.integers(8, 60))
-    kind = [O.RBF, O.MATERN52][int(rng.integers(0, 2))] if hasattr(O, "MATERN52") else O.RBF
-    tani = os.environ.get("FUZZ_KIND") == "tanimoto"
+    kind = [O.RBF, O.MATERN52][int(rng.integers(0, 2))]
     if tani:                                                 # fingerprints: 0/1 rows of 64..2048 bits
         kind, d = O.TANIMOTO, int(rng.choice([64, 100, 512, 1000, 2048]))
         b = min(b, 64)                                       # (a pool of random fingerprints has no more structure than that)
-        M = int(rng.integers(b + 8, max(b + 9, 4 * b))); N = int(rng.integers(max(2 * b + 1, M + 1), 40 * b + 50))
+        M = int(rng.integers(b + 8, max(b + 9, 4 * b))); N = int(rng.integers(max(2 * b + 1, M + 1), n_factor * b + 50))
     mode = ["predictive_covariance", "kernel", "weighted_predictive_covariance"][int(rng.integers(0, 3))]
     use_obj = bool(rng.random() < 0.25) and b <= 100
-    obj = (lambda Z: (Z ** 2).sum(1)) if use_obj else None
     X = rng.random((N, d)); Xo = rng.random((n_obs, d)); mu0 = rng.random(N); mu0 /= mu0.sum()
     if tani:
         pbit = float(rng.choice([0.03, 0.1, 0.3]))
@@ -36,42 +40,50 @@ for case in range(n_cases):
     Xn = X[rng.permutation(N)[:M]].copy()
     spec = O.make_spec(kind, t(Xo), t((0.25 + 0.5 * rng.random(d)) * np.sqrt(d)), outputscale=float(0.5 + 2 * rng.random()),
                        noise=1e-2, y_obs=t(rng.standard_normal(n_obs)))
+    seed = int(rng.integers(0, 1 << 30))
+    return dict(b=b, d=d, M=M, N=N, n_obs=n_obs, kind=kind, mode=mode, use_obj=use_obj, X=X, Xn=Xn, mu0=mu0, spec=spec, seed=seed)
+
+
+def _obj(c):
+    return (lambda Z: (Z ** 2).sum(1)) if c["use_obj"] else None
+
+
+def well_posed(c, verbose=True):
+    """How much the REFERENCE's result moves when candidates and Nystrom points move by one ulp (None: its indices change)."""
+    spec, b, mode, obj = c["spec"], c["b"], c["mode"], _obj(c)
+    torch.manual_seed(c["seed"])
+    i0, w0 = O.recombination(t(c["X"]), t(c["Xn"]), b, O.Kernel(spec, mode), init_weights=t(c["mu0"].copy()), calc_obj=obj)
+    torch.manual_seed(c["seed"])
+    i1, w1 = O.recombination(t(np.nextafter(c["X"], 2.0)), t(np.nextafter(c["Xn"], 2.0)), b, O.Kernel(spec, mode),
+                             init_weights=t(c["mu0"].copy()), calc_obj=obj)
+    eq = np.array_equal(i0.numpy(), i1.numpy())
+    move = float((w0 - w1).abs().max() / w0.abs().max()) if eq else None
+    if verbose:
+        G = O.Kernel(spec, mode)(t(c["Xn"]), t(c["Xn"]))
+        ev = torch.linalg.eigvalsh(0.5 * (G + G.T)).flip(0)
+        print("  the oracle against itself with candidates and Nystrom points one ulp up: idx equal %s, max rel w %s; Gram eigenvalues: "
+              "largest %.2e, number b-1 = %.2e, smallest %.2e" % (eq, "%.1e" % move if eq else "-", float(ev[0]), float(ev[b - 2]), float(ev[-1])))
+    return move
+
+
+def check_case(c, dev, verbose=False, always_diagnose=False):
+    """-> (ok, verdict, idx_equal, max rel weight error)."""
+    spec, b, mode, obj = c["spec"], c["b"], c["mode"], _obj(c)
     ks = sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs, spec.S_cache, spec.noise,
                               spec.mean_const, spec.alpha)
-    seed = int(rng.integers(0, 1 << 30))
-    mu_ref = t(mu0.copy())
-    if only and case not in only:
-        continue
-
-    def well_posed():
-        """How much the REFERENCE's result moves when candidates and Nystrom points move by one ulp (None: its indices
-        change), and the spectrum of the Gram matrix the Nystrom functions come from."""
-        torch.manual_seed(seed)
-        i0, w0 = O.recombination(t(X), t(Xn), b, O.Kernel(spec, mode), init_weights=t(mu0.copy()), calc_obj=obj)
-        torch.manual_seed(seed)
-        i1, w1 = O.recombination(t(np.nextafter(X, 2.0)), t(np.nextafter(Xn, 2.0)), b, O.Kernel(spec, mode), init_weights=t(mu0.copy()),
-                                 calc_obj=obj)
-        eq = np.array_equal(i0.numpy(), i1.numpy())
-        G = O.Kernel(spec, mode)(t(Xn), t(Xn))
-        ev = torch.linalg.eigvalsh(0.5 * (G + G.T)).flip(0)
-        move = float((w0 - w1).abs().max() / w0.abs().max()) if eq else None
-        print("  the oracle against itself with candidates and Nystrom points one ulp up: idx equal %s, max rel w %s; Gram eigenvalues: largest %.2e, "
-              "number b-1 = %.2e, smallest %.2e" % (eq, "%.1e" % move if eq else "-", float(ev[0]), float(ev[b - 2]), float(ev[-1])))
-        return move
-
-    try:
-        torch.manual_seed(seed)
-        idx_ref, w_ref = O.recombination(t(X), t(Xn), b, O.Kernel(spec, mode), init_weights=mu_ref, calc_obj=obj)
-        mu = t(mu0.copy()).to(dev)
-        torch.manual_seed(seed)
-        idx, w = sober_amd.recombination(t(X).to(dev), t(Xn).to(dev), b, sober_amd.Kernel(ks, mode), init_weights=mu, calc_obj=obj)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(c["seed"])
+        idx_ref, w_ref = O.recombination(t(c["X"]), t(c["Xn"]), b, O.Kernel(spec, mode), init_weights=t(c["mu0"].copy()), calc_obj=obj)
+        mu = t(c["mu0"].copy()).to(dev)
+        torch.manual_seed(c["seed"])
+        idx, w = sober_amd.recombination(t(c["X"]).to(dev), t(c["Xn"]).to(dev), b, sober_amd.Kernel(ks, mode), init_weights=mu, calc_obj=obj)
         same = np.array_equal(idx.cpu().numpy(), idx_ref.numpy())
         relw = float((w.cpu() - w_ref).abs().max() / w_ref.abs().max()) if same else float("nan")
-        ok = same and relw < 1e-6
-        verdict = "ok "
-        if not ok or only:
-            # beyond the sweep's own bar (1e-6; the contract's is 1e-4): is the case well-posed in the reference at all?
-            move = well_posed()
+        ok, verdict = same and relw < 1e-6, "ok"
+        if not ok or always_diagnose:
+            # beyond the sweep's own bar: is the case well-posed in the reference at all?
+            move = well_posed(c, verbose)
             if move is None:
                 ok, verdict = True, "ill-posed (the reference's own indices change under a one-ulp move of its inputs)"
             elif move > 1e-5:
@@ -79,11 +91,32 @@ for case in range(n_cases):
             elif same and relw <= max(1e-6, 20 * move):
                 ok, verdict = True, "ok (the reference's own weights move by %.1e under a one-ulp move)" % move
             else:
-                verdict = "BAD"
-    except Exception as e:                                   # noqa: BLE001
-        ok, same, relw, verdict = False, False, float("nan"), "BAD"
-        print("  exception:", type(e).__name__, str(e)[:200])
-    bad += 0 if ok else 1
-    print("case %2d b=%3d N=%5d M=%3d d=%2d n_obs=%2d %s %s%s: %s idx_equal=%s max rel w %.1e" %
-          (case, b, N, M, d, n_obs, spec.kind, mode, " +obj" if use_obj else "", verdict, same, relw), flush=True)
-print("bad cases:", bad, "of", n_cases)
+                ok, verdict = False, "BAD"
+    return ok, verdict, same, relw
+
+
+def describe(i, c):
+    return "case %2d b=%3d N=%5d M=%3d d=%4d n_obs=%2d %s %s%s" % (i, c["b"], c["N"], c["M"], c["d"], c["n_obs"], c["spec"].kind, c["mode"],
+                                                                " +obj" if c["use_obj"] else "")
+
+
+if __name__ == "__main__":
+    warnings.simplefilter("ignore")
+    dev = torch.device("cuda:0")
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    only = set(int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v)
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    tani = os.environ.get("FUZZ_KIND") == "tanimoto"
+    bad = 0
+    for i in range(n_cases):
+        c = make_case(rng, tani)
+        if only and i not in only:
+            continue
+        try:
+            ok, verdict, same, relw = check_case(c, dev, verbose=True, always_diagnose=bool(only))
+        except Exception as e:                               # noqa: BLE001
+            ok, verdict, same, relw = False, "BAD", False, float("nan")
+            print("  exception:", type(e).__name__, str(e)[:200])
+        bad += 0 if ok else 1
+        print("%s: %s idx_equal=%s max rel w %.1e" % (describe(i, c), verdict, same, relw), flush=True)
+    print("bad cases:", bad, "of", n_cases)
