@@ -59,7 +59,7 @@ CONFIGS = {
 }
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector = FP64 matrix (vendor)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
-INT8_PEAK_TOPS = 5000.0          # dense INT8 MFMA = 2 x the bf16 rate (MI355X_MICROARCH.md, matrix cores)
+FP4_PEAK_TOPS = 10000.0          # dense FP4 / FP6 MFMA (block-scaled f8f6f4 form) = 4 x the bf16 rate (MI355X_MICROARCH.md, matrix cores)
 CK = {"rbf": 28, "matern52": 40}
 # What the FP64 units of an MI355X sustain chip-wide (scripts/dp_rate_probe.hip, wall clock, all 256 CUs; committed
 # output: profiles/r03_dp_rate.txt): the clock under FP64 load is ~1.9 GHz, not the 2.4 GHz of the vendor figure.
@@ -375,18 +375,21 @@ def main():
               "traffic": traffic, "traffic_unit": "HBM bytes per launch, mean over the kernel's launches of a step",
               "traffic_source": traffic_src, "V_per_step": V, "entries_per_step": entries / ev_steps}
     if cfg["kind"] == "tanimoto":
-        # popcount(x & y) as an INT8 GEMM on the matrix cores (csrc/level_reduce_tani.hip): 2 * bits integer operations
-        # per (row, candidate) pair, against the dense INT8 MFMA peak (2 x the bf16 rate, MI355X_MICROARCH.md)
+        # popcount(x & y) as an FP4 (E2M1: 0.0 / 1.0) GEMM on the matrix cores (csrc/level_reduce_tani.hip): 2 * bits operations
+        # per (row, candidate) pair, against the dense FP4 MFMA peak (4 x the bf16 rate, MI355X_MICROARCH.md).  (Rounds 2-3
+        # ran it as an INT8 GEMM against the 5 P INT8 peak: this round's numbers are NOT comparable as fractions -- compare
+        # roofline.achieved / kernel_ms_per_step.)
         bits = 64 * ((cfg["d"] + 63) // 64)
         ops_step = entries / ev_steps * 2 * bits
         tops = entries * 2 * bits / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         alg_bytes = V * (bits / 8 + 16) + n_levels * (n_rows * S2 + S2) * 8
-        roofline = dict(common, bound="mfma", achieved=tops, peak=INT8_PEAK_TOPS, unit="TFLOP/s", frac=tops / INT8_PEAK_TOPS,
-                        step_frac=ops_step / (ms_per_step * 1e-3) / 1e12 / INT8_PEAK_TOPS, kernel="k_level_reduce_tani",
-                        note="bit-packed fingerprints, bits expanded to bytes in LDS, v_mfma_i32_16x16x64_i8 (integer "
-                             "operations counted in the TFLOP/s unit); the matrix pipe, the LDS (fragment reads + the "
-                             "expanded tile's writes) and the vector unit (bit expansion, Tanimoto quotient, FP64 "
-                             "accumulation) are each ~1/3 busy -- none of them is the single bound")
+        roofline = dict(common, bound="mfma", achieved=tops, peak=FP4_PEAK_TOPS, unit="TFLOP/s", frac=tops / FP4_PEAK_TOPS,
+                        step_frac=ops_step / (ms_per_step * 1e-3) / 1e12 / FP4_PEAK_TOPS, kernel="k_level_reduce_tani",
+                        peak_int8=5000.0, frac_of_int8_peak=tops / 5000.0,
+                        note="bit-packed fingerprints, every bit expanded to an E2M1 nibble (1.0 / 0.0) in LDS, "
+                             "v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales: exact popcounts in FP32 (bit-pair operations "
+                             "counted in the TFLOP/s unit, 2 per multiply-add); 256 rows per workgroup, so the 700-row table "
+                             "is three row blocks (the INT8 form of rounds 2-3: six, at half the matrix rate)")
     else:
         flop_per_entry = 2 * cfg["d"] + 2 + CK[cfg["kind"]]
         achieved = entries * flop_per_entry / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0

@@ -1,39 +1,57 @@
-// K1-K3 for bit-packed fingerprints (Tanimoto kernel, SOBER/_drug_modelling.py:15-25,37) on the INT8 matrix cores.
+// K1-K3 for bit-packed fingerprints (Tanimoto kernel, SOBER/_drug_modelling.py:15-25,37) on the FP4 matrix cores.
 //
 //   k(x, y) = (<x, y> + eps) / (|x| + |y| - <x, y> + eps),   <x, y> = popcount(x & y) = sum_k x_k y_k,  x_k, y_k in {0, 1}
 //
-// The dot product of 0/1 vectors is an integer GEMM: with the bits expanded to bytes, v_mfma_i32_16x16x64_i8 does
-// 16 x 16 x 64 multiply-adds in 16 cycles per SIMD -- one 64-bit word of 16 rows against the same word of 16
-// candidates per instruction, exact in int32.  The VALU form (level_reduce.hip: AND + v_bcnt per 32 bits, operands
-// broadcast from LDS) needs ~130 integer instructions per (row, candidate) pair at 2048 bits; here a pair costs 1/8 of
-// an MFMA pass and the vector unit is left with the Tanimoto quotient and the weighted FP64 accumulation.
+// The dot product of 0/1 vectors is a GEMM whose operands need ONE bit of precision: with every bit expanded to an E2M1
+// nibble (1.0 = 0x2, 0.0 = 0x0) and unit block scales, v_mfma_scale_f32_16x16x128_f8f6f4 does 16 x 16 x 128 multiply-adds
+// in 16 cycles per SIMD -- two 64-bit words of 16 rows against the same words of 16 candidates per instruction, exact in
+// FP32 (sums <= 2048 << 2^24).  Round 2-3 ran this on the INT8 cores (a bit per BYTE, v_mfma_i32_16x16x64_i8): half the
+// rate (scripts/fp4_popcount_probe.hip: 8.6 against 4.5 P bit-pair operations per second chip-wide), twice the bytes in
+// LDS and in the A fragments -- and the A fragments are what decides how many ROWS a workgroup covers (rows x 2048 bits x
+// bytes per bit must fit eight waves' registers): 128 rows at a byte per bit, i.e. six row blocks for the 700-row table,
+// each of which fetched, expanded and staged every candidate again (round 3's review: 437 MB fetched against 68 MB of
+// candidates at level 0); 256 rows at a nibble per bit: three.  The VALU form (level_reduce.hip: AND + v_bcnt per 32
+// bits) serves rows shorter than 512 bits.
 //
-// Layout.  Workgroup = 4 waves x 32 rows (two 16-row MFMA tiles per wave) x 16 consecutive sets x one element chunk.
-// The rows' bits are expanded ONCE into registers (A fragments: 2 tiles x DT words x 16 bytes per lane = 256 VGPRs at
-// 2048 bits -- one wave per SIMD, the whole register file).  The 16 candidates of an element arrive bit-packed from
-// HBM (256 B each instead of 16 KB as the reference's FP64 0/1 matrix), are expanded to bytes by all 256 threads
-// (16 bits -> one ds_write_b128) into a double-buffered LDS tile with padded rows, and every wave reads its B
-// fragments with ds_read_b128.  A and B use the same bit -> byte position map, which is all a dot product needs.
+// Layout.  Workgroup = 8 waves x 32 rows (two 16-row MFMA tiles per wave) x 16 consecutive sets x one element chunk.
+// The rows' bits are expanded ONCE into registers (A fragments: 2 tiles x DT/2 k-steps x 16 bytes per lane = 128 VGPRs at
+// 2048 bits).  The 32 candidates of a tile arrive bit-packed from HBM (256 B each instead of 16 KB as the reference's
+// FP64 0/1 matrix), are expanded to nibbles by all 512 threads (32 bits -> one ds_write_b128) into a double-buffered LDS
+// tile with padded rows, and every wave reads its B fragments with ds_read_b128 -- one read feeds both row tiles.  A and B
+// use the same bit -> nibble position map, which is all a dot product needs.
 // C/D map (dtype independent on gfx950): col = lane & 15 (one candidate = one set), row = 4 (lane >> 4) + reg:
-// every lane owns 8 FP64 accumulators (2 tiles x 4 rows) of its set -- no atomics, fixed summation order.
+// every lane owns 8 FP64 accumulators (2 tiles x 4 rows) of its set -- no atomics, fixed summation order; the sums are
+// the same bits as the INT8 kernel's (exact dot products, the same quotient, the same order over the elements).
 #include "common.hpp"
 
 namespace sober {
 
 typedef int int4_t __attribute__((ext_vector_type(4)));
+typedef int int8_t_ __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
 
 constexpr int LT_RW = 8;     // waves per workgroup (two per SIMD)
-constexpr int LT_RT = 1;     // 16-row MFMA tiles per wave: 128 VGPRs of A fragments at 2048 bits, nothing in AGPRs
+constexpr int LT_RT = 2;     // 16-row MFMA tiles per wave: 128 VGPRs of A fragments at 2048 bits (a nibble per bit), nothing in AGPRs
 constexpr int LT_SB = 16;    // sets per workgroup = MFMA N
 constexpr int LT_TE = 2;     // elements (of 16 candidates) staged per tile
-constexpr int LT_ROWS = LT_RW * LT_RT * 16;   // 128 rows per workgroup
+constexpr int LT_ROWS = LT_RW * LT_RT * 16;   // 256 rows per workgroup
 
-// 16 bits -> 16 bytes of 0 / 1 (dword q holds bits 4q .. 4q+3, one per byte)
-__device__ __forceinline__ int4_t expand16(unsigned bits) {
+// 32 bits -> 32 E2M1 nibbles of 1.0 (0x2) / 0.0 (dword q holds bits 8q .. 8q+7: bit k of the low four -> nibble 2k, of the
+// high four -> nibble 2k + 1; the multiplier puts four bits at byte distance, already shifted to the 0x2 position)
+__device__ __forceinline__ int4_t expand32(unsigned bits) {
     int4_t r;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = (int)((((bits >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u);
+    for (int q = 0; q < 4; ++q) {
+        const unsigned b8 = (bits >> (8 * q)) & 0xFFu;
+        const unsigned lo = ((b8 & 0xFu) * 0x00408102u) & 0x02020202u, hi = ((b8 >> 4) * 0x00408102u) & 0x02020202u;
+        r[q] = (int)(lo | (hi << 4));
+    }
     return r;
+}
+// 16 x 16 x 128 multiply-adds of E2M1 operands with unit scales (E8M0 127 in every byte of the scale registers)
+__device__ __forceinline__ float4_t mfma_f4(const int4_t a, const int4_t b, const float4_t c) {
+    const int8_t_ a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0}, b8 = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
 // (dot + eps) / (|x| + |y| - dot + eps): reciprocal seed + ONE Newton step (relative error ~2^-50), quotient, and one
@@ -51,7 +69,6 @@ __device__ __forceinline__ double tani_fast(double dot, double nx, double ny) {
     return fma(fma(-q, den, num), r, q);
 }
 
-#define LT_EXPAND(x) expand16(x)
 template <int DT>      // 64-bit words per fingerprint
 __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     const unsigned long long* __restrict__ rows, const double* __restrict__ rows_norm, int n_rows,
@@ -86,14 +103,16 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
         if ((int)blockIdx.y >= n_chunks) return;
         e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
     }
-    constexpr int ROWB = DT * 64 + 32;                 // bytes per candidate in LDS: row stride = 8 dwords mod 64 banks -> the four lane groups of a ds_read_b128 are conflict-free (a 16-byte pad leaves a 2-way conflict in each)
+    static_assert(DT % 2 == 0, "a k-step is two 64-bit words");
+    constexpr int KS = DT / 2;                         // k-steps (128 bits each) per fingerprint
+    constexpr int ROWB = DT * 32 + 32;                 // bytes per candidate in LDS: row stride = 8 dwords mod 64 banks -> the four lane groups of a ds_read_b128 are conflict-free (a 16-byte pad leaves a 2-way conflict in each)
     constexpr int TE = LT_TE;
     constexpr int NC = TE * SB;                        // candidates per tile
-    constexpr int UNITS = NC * DT * 4;                 // 16-bit units per tile
+    constexpr int UNITS = NC * DT * 2;                 // 32-bit units per tile
     constexpr int NTH = LT_RW * 64;                    // threads
     constexpr int UPT = (UNITS + NTH - 1) / NTH;       // units per thread
-    // dynamic LDS (66 KB at 2048 bits: beyond the static limit): [2][SB * ROWB] candidate bytes, then [2][SB] weights
-    // and [2][SB] popcounts
+    // dynamic LDS (66 KB at 2048 bits: beyond the static limit): [2][NC * ROWB] candidate nibbles, then [2][NC] weights
+    // and [2][NC] popcounts
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     unsigned char (*s_b)[NC * ROWB] = (unsigned char (*)[NC * ROWB])s_dyn;
     double (*s_w)[NC] = (double (*)[NC])(s_dyn + 2 * NC * ROWB);
@@ -109,15 +128,15 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     const int e0 = chunk * e_per_chunk;
     const int e1 = min(e0 + e_per_chunk, e_total);
 
-    // A fragments: lane holds bits [16 lk, 16 lk + 16) of every word of row (row0 + 16 t + lj), as bytes
-    int4_t afr[LT_RT][DT];
+    // A fragments: lane holds bits [32 lk, 32 lk + 32) of every k-step (two words) of row (row0 + 16 t + lj), as nibbles
+    int4_t afr[LT_RT][KS];
 #pragma unroll
     for (int t = 0; t < LT_RT; ++t) {
         const int r = row0 + 16 * t + lj;
 #pragma unroll
-        for (int ks = 0; ks < DT; ++ks) {
-            const unsigned long long wv = (r < n_rows) ? rows[(size_t)r * DT + ks] : 0ull;
-            afr[t][ks] = expand16((unsigned)(wv >> (16 * lk)) & 0xFFFFu);
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned long long wv = (r < n_rows) ? rows[(size_t)r * DT + 2 * ks + (lk >> 1)] : 0ull;
+            afr[t][ks] = expand32((unsigned)(wv >> (32 * (lk & 1))));
         }
     }
     double nxr[LT_RT][4];
@@ -135,17 +154,17 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
         for (int v = 0; v < 4; ++v) acc[t][v] = 0.0;
 
     // staging of one tile (TE elements of 16 consecutive list positions each).  TPC = 16 threads share a candidate:
-    // ONE list position, one validity flag and one base address per thread and tile, then UPT 16-bit units of that
-    // candidate at fixed strides (unit j * TPC + cp: word 4 j + cp / 4, quarter cp % 4) -- loads and LDS writes with
-    // immediate offsets.  (A first form spread a thread's units over UPT different candidates: their positions, flags
+    // ONE list position, one validity flag and one base address per thread and tile, then UPT 32-bit units of that
+    // candidate at fixed strides (unit j * TPC + cp: the cp-th 32 bits of the j-th run of 512) -- loads and LDS writes
+    // with immediate offsets.  (A first form spread a thread's units over UPT different candidates: their positions, flags
     // and addresses were more than half of the kernel's instruction stream.)  The address chain idx -> candidate words is
     // two global round trips, so the index is fetched TWO tiles ahead and the words ONE ahead; every load is
     // unconditional (clamped position, masked afterwards) so that the compiler counts outstanding loads instead of
     // draining them; expansion and LDS writes follow the current tile's MFMAs.  Positions are 32-bit offsets into this
     // launch's index list (count < 2^31).
     constexpr int TPC = NTH / NC;                      // threads per candidate
-    static_assert(NTH % NC == 0 && TPC % 4 == 0 && (DT * 4) % TPC == 0 && UPT == DT * 4 / TPC, "unit map");
-    unsigned long long stw[UPT];
+    static_assert(NTH % NC == 0 && (DT * 2) % TPC == 0 && UPT == DT * 2 / TPC, "unit map");
+    unsigned stw[UPT];
     int cpre = 0;
     bool ok_w = false, ok_t = false;
     double tot_acc = 0.0, m_raw = 0.0, wm_raw = 0.0, ny_raw = 0.0;
@@ -155,9 +174,8 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     const int tl32 = (int)min(tot_limit - pos0, (int64_t)0x7fffffff);
     const int cq = tid / TPC, cp = tid % TPC;                           // my candidate of the tile, my share of it
     const int qe = cq / SB, qs = cq % SB;
-    const int wsel = cp / 4, part = cp % 4;
     const bool qs_ok = s0 + qs < S;
-    unsigned char* const wr_base = &s_b[0][0] + cq * ROWB + wsel * 64 + part * 16;
+    unsigned char* const wr_base = &s_b[0][0] + cq * ROWB + cp * 16;
 #define LT_REL(e_, R, OK)                                                                  \
     const int R = rel0 + ((e_) + qe) * S + qs;                                             \
     const bool OK = qs_ok & ((e_) + qe < e1) & (R >= 0) & (R < cnt32);
@@ -170,8 +188,8 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     {                                                                                      \
         LT_REL(e_, r_, okl_)                                                               \
         const int c_ = okl_ ? cpre : 0;                                                    \
-        const unsigned long long* src_ = cand + (size_t)c_ * DT + wsel;                    \
-        _Pragma("unroll") for (int u = 0; u < UPT; ++u) stw[u] = src_[u * (TPC / 4)];      \
+        const unsigned* src_ = (const unsigned*)(cand + (size_t)c_ * DT) + cp;             \
+        _Pragma("unroll") for (int u = 0; u < UPT; ++u) stw[u] = src_[u * TPC];            \
         m_raw = mu[c_]; wm_raw = wm_ptr[c_]; ny_raw = cand_norm[c_];                       \
         ok_w = okl_; ok_t = okl_ & (r_ < tl32);                                            \
     }
@@ -179,8 +197,7 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     {                                                                                      \
         unsigned char* dst_ = wr_base + (buf_) * (NC * ROWB);                              \
         _Pragma("unroll") for (int u = 0; u < UPT; ++u)                                    \
-            *(int4_t*)(dst_ + u * (TPC / 4) * 64) =                                        \
-                LT_EXPAND(ok_w ? (unsigned)(stw[u] >> (16 * part)) & 0xFFFFu : 0u);        \
+            *(int4_t*)(dst_ + u * TPC * 16) = expand32(ok_w ? stw[u] : 0u);                \
         if (cp == 0) {                                                                     \
             s_w[buf_][cq] = ok_w ? (wmul ? m_raw * wm_raw : m_raw) * os : 0.0;             \
             s_ny[buf_][cq] = ok_w ? ny_raw : 0.0;                                          \
@@ -201,40 +218,34 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
         LT_PREFETCH_IDX(e + 2 * TE)
         const int te_cnt = rows_live ? min(TE, e1 - e) : 0;
         for (int te = 0; te < te_cnt; ++te) {
-            // B fragments LT_BD k-steps ahead of their MFMAs and two accumulators per tile: with a single accumulator and
-            // the compiler's own order (two reads, wait, two dependent MFMAs) an element was a chain of 16 LDS round trips
-            int4_t cc[LT_RT], cd[LT_RT];
+            // B fragments LT_BD k-steps ahead of their MFMAs; the two row tiles are the two independent accumulator chains
+            // (left to itself the compiler reads a fragment, waits, and issues its MFMAs: an LDS round trip per k-step)
+            float4_t cc[LT_RT];
 #pragma unroll
-            for (int t = 0; t < LT_RT; ++t) { cc[t] = (int4_t){0, 0, 0, 0}; cd[t] = cc[t]; }
+            for (int t = 0; t < LT_RT; ++t) cc[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
             __builtin_amdgcn_sched_barrier(0);
             const unsigned char* bp = &s_b[buf][(te * SB + lj) * ROWB + lk * 16];
-            constexpr int LT_BD = 8;
+            constexpr int LT_BD = KS < 8 ? KS : 8;
             int4_t bq[LT_BD];
 #pragma unroll
-            for (int j = 0; j < LT_BD && j < DT; ++j) bq[j] = *(const int4_t*)(bp + j * 64);
+            for (int j = 0; j < LT_BD; ++j) bq[j] = *(const int4_t*)(bp + j * 64);
 #pragma unroll
-            for (int ks = 0; ks < DT; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const int4_t bfr = bq[ks % LT_BD];
-                if (ks + LT_BD < DT) bq[ks % LT_BD] = *(const int4_t*)(bp + (ks + LT_BD) * 64);
+                if (ks + LT_BD < KS) bq[ks % LT_BD] = *(const int4_t*)(bp + (ks + LT_BD) * 64);
 #pragma unroll
-                for (int t = 0; t < LT_RT; ++t)
-                {
-                    if (ks & 1) cd[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[t][ks], bfr, cd[t], 0, 0, 0);
-                    else cc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[t][ks], bfr, cc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < LT_RT; ++t) cc[t] = mfma_f4(afr[t][ks], bfr, cc[t]);
             }
-            // (the scheduler would pull every read back to just in front of its MFMA: pin the order -- LT_BD reads, then
-            //  one MFMA per further read)
+            // (the scheduler would pull every read back to just in front of its MFMAs: pin the order -- LT_BD reads, then
+            //  LT_RT MFMAs per further read)
             __builtin_amdgcn_sched_group_barrier(0x100, LT_BD, 0);
 #pragma unroll
-            for (int ks = 0; ks < DT - LT_BD; ++ks) {
+            for (int ks = 0; ks < KS - LT_BD; ++ks) {
                 __builtin_amdgcn_sched_group_barrier(0x008, LT_RT, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, LT_RT * LT_BD, 0);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < LT_RT; ++t) cc[t] += cd[t];
             const double w = s_w[buf][te * SB + lj], ny = s_ny[buf][te * SB + lj];
 #pragma unroll
             for (int t = 0; t < LT_RT; ++t)
@@ -287,7 +298,7 @@ static int launch_lt(const void* rows, const double* rows_norm, int n_rows, cons
         grid.x += (unsigned)((S_x + LT_SB - 1) / LT_SB);
         if ((unsigned)n_xchunks > grid.y) grid.y = (unsigned)n_xchunks;
     }
-    const size_t lds = (size_t)2 * LT_TE * LT_SB * (DT * 64 + 32) + 4 * LT_TE * LT_SB * sizeof(double);
+    const size_t lds = (size_t)2 * LT_TE * LT_SB * (DT * 32 + 32) + 4 * LT_TE * LT_SB * sizeof(double);
     HIP_TRY(hipFuncSetAttribute((const void*)k_level_reduce_tani<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SOBER_LAUNCH_TIMED((k_level_reduce_tani<DT>), grid, dim3(LT_RW * 64), lds, st, (const unsigned long long*)rows,
                        rows_norm, n_rows, (const unsigned long long*)cand, cand_norm, idx, pos0, count, S, mu, wmul, os,
