@@ -30,20 +30,12 @@
 
 namespace sober {
 
-// Row groups of the bidiagonalisation's thread grid (16 lanes = one matrix row's 16-column slice; CAR_RG such rows): 32 = 512
-// threads, two waves per SIMD, 4 x 13 matrix slots per thread (round 4) -- 16 = 256 threads, one wave per SIMD, 7 x 13 slots
-// (rounds 2-3; -DCAR_RG=16 builds it for a same-box A/B)
-#ifndef CAR_RG
-#define CAR_RG 32
-#endif
-constexpr int CAR_MMAX = 112;       // m <= 112
-constexpr int CAR_MS = (CAR_MMAX + CAR_RG - 1) / CAR_RG;   // matrix row slots per thread in the bidiagonalisation
+constexpr int CAR_MS = 7;           // matrix row slots per thread in the bidiagonalisation: m <= 16 * 7
 constexpr int CAR_CQ = 13;          // 16-lane slots along N: N <= 16 * 13
 constexpr int CAR_NS = 16 * CAR_CQ; // stride of a reflector / of the LDS columns
 constexpr int CAR_PC = 128;         // columns of Phi in the global scratch (N - m <= 128), kept COLUMN by column: Phi[col * CAR_NS + row]
 //                                    (a pivot wave reads its seven columns as contiguous runs of rows)
-constexpr int CAR_BT = 16 * CAR_RG; // threads of k_car_bidiag
-constexpr int CAR_NW = CAR_BT / 64; // its waves
+constexpr int CAR_BT = 256;         // threads of k_car_bidiag
 
 // ---- DPP cross-lane helpers (row = 16 lanes).  ds_bpermute-based __shfl costs an LDS round trip
 // per step; these are plain VALU moves.
@@ -131,9 +123,6 @@ typedef __amdgpu_buffer_rsrc_t car_rsrc_t;
 constexpr unsigned CARF_ERR = 0, CARF_XCD = 16, CARF_TICKET = 32, CARF_PROGRESS = 48, CARF_DONE = 56;   // byte offsets in the comm block
 __host__ __device__ constexpr int64_t carf_bytes(int) { return 64; }
 constexpr unsigned CARF_SPIN_LIMIT = 1u << 22;
-constexpr int CARF_RW = 2;                                            // rows of P per consumer wave of the fused launch
-constexpr int CARF_GROUPS = CAR_NS / ((16 * CAR_RG / 64) * CARF_RW);  // groups of rows (one per consumer workgroup); CARF_DONE counts them
-static_assert(CARF_GROUPS * (16 * CAR_RG / 64) * CARF_RW == CAR_NS, "whole groups");
 __device__ __forceinline__ void carf_put(car_rsrc_t rs, unsigned off, double v, unsigned tag) {
     car_u32x4 g;
     g.x = (unsigned)__double2loint(v); g.y = tag; g.z = (unsigned)__double2hiint(v); g.w = tag;
@@ -149,7 +138,7 @@ struct CarPub { car_rsrc_t rs; unsigned tag0; };
 // stores have long been acknowledged (the wait below is then free) -- nothing is added to the chain of the step itself
 __device__ __forceinline__ void car_publish_progress(const CarPub& pub, int k) {
     const int tid = threadIdx.x;
-    if (k > 0 && (tid >> 6) == (((k - 1) & (CAR_RG - 1)) >> 2)) {      // (wave-uniform: the wave of row group (k-1) mod CAR_RG)
+    if (k > 0 && (tid >> 6) == (((k - 1) & 15) >> 2)) {                // (wave-uniform: the wave of DPP row (k-1) & 15)
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0) only
         if ((tid & 63) == 0) __builtin_amdgcn_raw_buffer_store_b32(pub.tag0 + (unsigned)k, pub.rs, CARF_PROGRESS, 0, 0);
     }
@@ -205,12 +194,11 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
     const int tid = threadIdx.x;
     const int R = tid >> 4, C = tid & 15;
     const int i_end = min(16 * S + 16, m - 1);
-    constexpr int KS = (16 * S) / CAR_RG;                // the lowest live row slot in this block of 16 steps
-    constexpr int KS1 = (KS + 1 < MS) ? KS + 1 : KS;     // row slot of row i+1 when row i is the last of its slot
+    constexpr int S1 = (S + 1 < MS) ? S + 1 : S;         // row slot of row i+1 when i is the block's last step
     const car_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(vws, 0, (int)((size_t)m * CAR_NS * sizeof(double)), 0x00020000);
     CB_DECL
     for (int i = 16 * S; i < i_end; ++i) {
-        const int li = i & 15, lr = i & (CAR_RG - 1), p = i & 1, pp = p ^ 1;     // (column lane, row group of step i)
+        const int li = i & 15, p = i & 1, pp = p ^ 1;
         if constexpr (FUSED) car_publish_progress(pub, i);   // reflector i - 1 is complete in memory by now
         // ---- H(i-1): scalars from the finished sums, z, the rank-1 update (rows >= i, columns >= i)
         double z[CAR_CQ], x[CAR_CQ], f[CAR_MS], cur[CAR_MS];
@@ -220,7 +208,7 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         for (int q = S; q < CQ; ++q) { x[q] = L.rowg[pp * CAR_NS + C + 16 * q]; z[q] = L.zsum[C + 16 * q]; }
         const double rgi = L.rowg[pp * CAR_NS + i];
 #pragma unroll
-        for (int k = KS; k < MS; ++k) cur[k] = L.colg[pp * 128 + R + CAR_RG * k];
+        for (int k = S; k < MS; ++k) cur[k] = L.colg[pp * 128 + R + 16 * k];
 #pragma unroll
         for (int q = S; q < CQ; ++q) {
             z[q] = fma(sc2, z[q], x[q]);
@@ -229,16 +217,16 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         z[S] = (C >= li) ? z[S] : 0.0;
         x[S] = (C > li) ? x[S] : 0.0;
 #pragma unroll
-        for (int k = KS; k < MS; ++k) f[k] = tauq * (sc2 * colp[k]);
-        f[KS] = (R == lr) ? tauq : f[KS];
+        for (int k = S; k < MS; ++k) f[k] = tauq * (sc2 * colp[k]);
+        f[S] = (R == li) ? tauq : f[S];
         const double zi = rdlane(z[S], li);                 // z at column i (lane li of every wave holds C == li)
         const double alpha = fma(-tauq, zi, rgi);
 #pragma unroll
-        for (int k = KS; k < MS; ++k) cur[k] = fma(-f[k], zi, cur[k]);                           // column i, my rows
+        for (int k = S; k < MS; ++k) cur[k] = fma(-f[k], zi, cur[k]);                            // column i, my rows
 #pragma unroll
         for (int q = S; q < CQ; ++q)
 #pragma unroll
-            for (int k = KS; k < MS; ++k) a[k][q] = CB2_HUPD(fma(-f[k], z[q], a[k][q]), a[k][q]);
+            for (int k = S; k < MS; ++k) a[k][q] = CB2_HUPD(fma(-f[k], z[q], a[k][q]), a[k][q]);
         // ---- G(i) from row i
         double ss0 = 0.0, ss1 = 0.0;
 #pragma unroll
@@ -251,20 +239,20 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
         // w = A v = column i + sc * (A x) over my rows
         double tG[CAR_MS];
 #pragma unroll
-        for (int k = KS; k < MS; ++k) {
+        for (int k = S; k < MS; ++k) {
             double w0 = 0.0, w1 = 0.0;
 #pragma unroll
             for (int q = S; q < CQ; ++q) { if (q & 1) w1 = fma(a[k][q], x[q], w1); else w0 = fma(a[k][q], x[q], w0); }
             tG[k] = tau * fma(sc, CB2_RSUM(w0 + w1), cur[k]);
         }
-        tG[KS] = (R > lr) ? tG[KS] : 0.0;                    // rows <= i stay
-        CB2_STAMP(4, tG[KS]);
+        tG[S] = (R > li) ? tG[S] : 0.0;                      // rows <= i stay
+        CB2_STAMP(4, tG[S]);
 #pragma unroll
-        for (int k = KS; k < MS; ++k) colp[k] = cur[k] - tG[k];     // column i after G(i)  (v_i = 1)
-        colp[KS] = (R > lr) ? colp[KS] : 0.0;
+        for (int k = S; k < MS; ++k) colp[k] = cur[k] - tG[k];      // column i after G(i)  (v_i = 1)
+        colp[S] = (R > li) ? colp[S] : 0.0;
 #pragma unroll
         for (int q = S; q < CQ; ++q) x[q] *= sc;         // x becomes v
-        if (R == lr) {                                       // the reflector goes to the scratch (Phi follows it)
+        if (R == li) {                                       // the reflector goes to the scratch (Phi follows it)
             const unsigned so = (unsigned)i * (unsigned)(CAR_NS * 8);
 #pragma unroll
             for (int q = 0; q < CAR_CQ; ++q) {            // (whole reflectors: the consumers read every slot)
@@ -279,87 +267,72 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
             if (C == 0) taup[i] = tau;
         }
 #pragma unroll
-        for (int k = KS; k < MS; ++k)
+        for (int k = S; k < MS; ++k)
 #pragma unroll
             for (int q = S; q < CQ; ++q) a[k][q] = CB2_GUPD(fma(-tG[k], x[q], a[k][q]), a[k][q]);
         // ---- what the next step is built from: row i+1 and column i+1 of A', and col'[i+1]
-        const bool clast = li == 15, rlast = lr == CAR_RG - 1;         // column / row i is the last of its slot
-        const int nc = (li + 1) & 15, nr = (lr + 1) & (CAR_RG - 1);
-        if (R == nr) {
-            if (!rlast) {                                    // (uniform)
+        const bool last = li == 15;
+        const int n1 = (li + 1) & 15;
+        if (!last) {                                         // (uniform)
+            if (R == n1) {
 #pragma unroll
-                for (int q = S; q < CQ; ++q) L.rowg[p * CAR_NS + C + 16 * q] = a[KS][q];
-                if (C == 0) L.scal[p] = colp[KS];
-            } else {
+                for (int q = S; q < CQ; ++q) L.rowg[p * CAR_NS + C + 16 * q] = a[S][q];
+                if (C == 0) L.scal[p] = colp[S];
+            }
+            if (C == n1) {
 #pragma unroll
-                for (int q = S; q < CQ; ++q) L.rowg[p * CAR_NS + C + 16 * q] = a[KS1][q];
-                if (C == 0) L.scal[p] = colp[KS1];
+                for (int k = S; k < MS; ++k) L.colg[p * 128 + R + 16 * k] = a[k][S];
+            }
+        } else {
+            if (R == 0) {
+#pragma unroll
+                for (int q = S; q < CQ; ++q) L.rowg[p * CAR_NS + C + 16 * q] = a[S1][q];
+                if (C == 0) L.scal[p] = colp[S1];
+            }
+            if (C == 0) {
+#pragma unroll
+                for (int k = S; k < MS; ++k) L.colg[p * 128 + R + 16 * k] = a[k][S + 1];
             }
         }
-        if (C == nc) {
-            if (!clast) {                                    // (uniform)
-#pragma unroll
-                for (int k = KS; k < MS; ++k) L.colg[p * 128 + R + CAR_RG * k] = a[k][S];
-            } else {
-#pragma unroll
-                for (int k = KS; k < MS; ++k) L.colg[p * 128 + R + CAR_RG * k] = a[k][S + 1];
-            }
-        }
-        CB2_STAMP(5, a[KS][S]);
+        CB2_STAMP(5, a[S][S]);
         // ---- partial column sums of H(i): rows >= i + 2 of col' against A'
         double cm[CAR_MS];
 #pragma unroll
-        for (int k = KS; k < MS; ++k) cm[k] = colp[k];
-        cm[KS] = (R > lr + 1) ? cm[KS] : 0.0;
-        if constexpr (KS + 1 < MS) cm[KS + 1] = (rlast && R == 0) ? 0.0 : cm[KS + 1];
+        for (int k = S; k < MS; ++k) cm[k] = colp[k];
+        cm[S] = (R > li + 1) ? cm[S] : 0.0;
+        if constexpr (S + 1 < MS) cm[S + 1] = (last && R == 0) ? 0.0 : cm[S + 1];
         double yp[CAR_CQ], s2p = 0.0;
 #pragma unroll
-        for (int q = S; q < CQ; ++q) yp[q] = cm[KS] * a[KS][q];
+        for (int q = S; q < CQ; ++q) yp[q] = cm[S] * a[S][q];
 #pragma unroll
-        for (int k = KS + 1; k < MS; ++k)
+        for (int k = S + 1; k < MS; ++k)
 #pragma unroll
             for (int q = S; q < CQ; ++q) yp[q] = fma(cm[k], a[k][q], yp[q]);
 #pragma unroll
-        for (int k = KS; k < MS; ++k) s2p = fma(cm[k], cm[k], s2p);
+        for (int k = S; k < MS; ++k) s2p = fma(cm[k], cm[k], s2p);
 #pragma unroll
         for (int q = S; q < CQ; ++q) L.zpart[R * CAR_NS + C + 16 * q] = yp[q];
         if (C == 0) L.s2part[R] = s2p;
         CB_STAMP(6);
         CB2_BARRIER();
         CB_STAMP(7);
-        // the CAR_RG partial sums per live column, by the waves in front of the last one: with 16 row groups column
-        // 16 S + t belongs to thread t (192 threads cover the live columns from block 1 on; in block 0 the last wave takes
-        // columns 192 .. 207 as well); with 32 row groups two neighbouring threads share a column (16 partials each, the two
-        // halves added by a DPP swap: 416 threads for 208 columns).  The LAST WAVE sums the norm and runs H(i)'s scalar chain
-        // (dlarfg: ~35 dependent instructions) HERE, beside the column sums, instead of every thread running it at the top
-        // of the next iteration with nothing to overlap it
-        if (tid < CAR_BT - 64) {                             // (wave-uniform)
-            if constexpr (CAR_RG == 16) {
-                const int c = 16 * S + tid;
-                if (c < 16 * CQ) {
-                    double z0 = 0.0, z1 = 0.0;
+        // the 16 partial sums per live column: column 16 S + t belongs to thread t of waves 0 .. 2 (192 threads cover the
+        // live columns from block 1 on).  WAVE 3 has no column of its own then: it sums the norm and runs H(i)'s scalar
+        // chain (dlarfg: ~35 dependent instructions) HERE, beside the column sums, instead of every thread running it at
+        // the top of the next iteration with nothing to overlap it (block 0: wave 3 also takes columns 192 .. 207)
+        if (tid < 192) {                                     // (wave-uniform)
+            const int c = 16 * S + tid;
+            if (c < 16 * CQ) {
+                double z0 = 0.0, z1 = 0.0;
 #pragma unroll
-                    for (int w = 0; w < 16; w += 2) {
-                        z0 += L.zpart[w * CAR_NS + c];
-                        z1 += L.zpart[(w + 1) * CAR_NS + c];
-                    }
-                    L.zsum[c] = z0 + z1;
+                for (int w = 0; w < 16; w += 2) {
+                    z0 += L.zpart[w * CAR_NS + c];
+                    z1 += L.zpart[(w + 1) * CAR_NS + c];
                 }
-            } else {
-                const int c = 16 * S + (tid >> 1), h = tid & 1;
-                if (c < 16 * CQ) {                           // (pairs of lanes: a pair is either in or out)
-                    double z0 = 0.0, z1 = 0.0;
-#pragma unroll
-                    for (int w = 0; w < 16; w += 2) {
-                        z0 += L.zpart[(16 * h + w) * CAR_NS + c];
-                        z1 += L.zpart[(16 * h + w + 1) * CAR_NS + c];
-                    }
-                    const double zz = z0 + z1, zo = dpp<0xB1>(zz);     // quad_perm [1, 0, 3, 2]: my neighbour's half
-                    if (h == 0) L.zsum[c] = zz + zo;                   // (rows 0-15's sum + rows 16-31's)
-                }
+                L.zsum[c] = z0 + z1;
             }
         } else {
-            if constexpr (S == 0 && CAR_RG == 16) {
+            if constexpr (S == 0) {
                 if (tid < 16 * CQ) {
                     double z0 = 0.0, z1 = 0.0;
 #pragma unroll
@@ -370,11 +343,10 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
                     L.zsum[tid] = z0 + z1;
                 }
             }
-            // (every 16-lane row of the wave: the same sum, same order)
-            const double s2n = row16_sum(CAR_RG == 16 ? L.s2part[C] : L.s2part[C] + L.s2part[C + 16]);
+            const double s2n = row16_sum(L.s2part[C]);       // (every 16-lane row of the wave: the same sum, same order)
             double tq, s2c;
             larfg_vt(L.scal[p], s2n, tq, s2c);
-            if (tid == CAR_BT - 64) { L.hsc[0] = tq; L.hsc[1] = s2c; }
+            if (tid == 192) { L.hsc[0] = tq; L.hsc[1] = s2c; }
         }
         CB_STAMP(8);
         CB2_BARRIER();
@@ -389,7 +361,7 @@ __device__ __forceinline__ void car_bidiag2_last(int m, const CarLds2& L, double
                                                  const CarPub& pub) {
     const int tid = threadIdx.x;
     const int R = tid >> 4, C = tid & 15;
-    const int i = m - 1, li = i & 15, lr = i & (CAR_RG - 1), pp = (i & 1) ^ 1;
+    const int i = m - 1, li = i & 15, pp = (i & 1) ^ 1;
     if constexpr (FUSED) car_publish_progress(pub, i);
     double x[CAR_CQ], zS = 0.0;
     const double tauq = L.hsc[0], sc2 = L.hsc[1];
@@ -409,7 +381,7 @@ __device__ __forceinline__ void car_bidiag2_last(int m, const CarLds2& L, double
     const double ss = row16_sum(ss0 + ss1);
     double beta, tau, sc;
     larfg_vt(alpha, ss, tau, sc); (void)beta;
-    if (R == lr) {
+    if (R == li) {
 #pragma unroll
         for (int q = 0; q < CAR_CQ; ++q) {
             double v;
@@ -427,8 +399,8 @@ __device__ __forceinline__ void car_bidiag2_body(const double* __restrict__ X, i
                                                  double* __restrict__ vws, double* __restrict__ taup, const CarPub& pub) {
     __shared__ double rowg[2 * CAR_NS];
     __shared__ double colg[2 * 128];
-    __shared__ double zpart[CAR_RG * CAR_NS];
-    __shared__ double s2part[CAR_RG];
+    __shared__ double zpart[16 * CAR_NS];
+    __shared__ double s2part[16];
     __shared__ double zsum[CAR_NS + 8];
     __shared__ double scal[2];
     __shared__ double hsc[2];
@@ -440,7 +412,7 @@ __device__ __forceinline__ void car_bidiag2_body(const double* __restrict__ X, i
         colp[k] = 0.0;
 #pragma unroll
         for (int q = 0; q < CAR_CQ; ++q) {
-            const int r = R + CAR_RG * k, c = C + 16 * q;
+            const int r = R + 16 * k, c = C + 16 * q;
             a[k][q] = 0.0;                                   // (slots beyond MS / CQ: constants, never touched again)
             if (k < MS && q < CQ) a[k][q] = (c < N && r < m) ? ((r == 0) ? 1.0 : X[(size_t)c * ldx + (r - 1)]) : 0.0;
         }
@@ -452,16 +424,21 @@ __device__ __forceinline__ void car_bidiag2_body(const double* __restrict__ X, i
     if (tid < 2) { scal[tid] = 0.0; hsc[tid] = 0.0; }    // (tau = 0: "H(-1)" is the identity)
     __syncthreads();
     const CarLds2 L{rowg, colg, zpart, s2part, zsum, scal, hsc};
-    // (a block of 16 steps exists in an instantiation whose row slots reach it: m <= CAR_RG MS)
-#define CAR_BLOCK(S_) if constexpr (CAR_RG * MS > 16 * S_) if (m > 16 * S_ + 1) car_bidiag2_block<S_, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
     car_bidiag2_block<0, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
-    CAR_BLOCK(1) CAR_BLOCK(2) CAR_BLOCK(3) CAR_BLOCK(4) CAR_BLOCK(5) CAR_BLOCK(6)
-#undef CAR_BLOCK
+    if constexpr (MS > 1) if (m > 17) car_bidiag2_block<1, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 2) if (m > 33) car_bidiag2_block<2, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 3) if (m > 49) car_bidiag2_block<3, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 4) if (m > 65) car_bidiag2_block<4, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 5) if (m > 81) car_bidiag2_block<5, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
+    if constexpr (MS > 6) if (m > 97) car_bidiag2_block<6, FUSED, MS, CQ>(a, colp, m, L, vws, taup, pub);
     const int sl = (m - 1) >> 4;
-#define CAR_LAST(S_) if constexpr (CAR_RG * MS > 16 * S_) if (sl == S_) car_bidiag2_last<S_, FUSED, MS, CQ>(m, L, vws, taup, pub);
-    CAR_LAST(0) CAR_LAST(1) CAR_LAST(2) CAR_LAST(3) CAR_LAST(4) CAR_LAST(5) CAR_LAST(6)
-#undef CAR_LAST
-    static_assert(CAR_MMAX <= 16 * 7, "seven blocks of 16 steps");
+    if (sl == 0) car_bidiag2_last<0, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 1) if (sl == 1) car_bidiag2_last<1, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 2) if (sl == 2) car_bidiag2_last<2, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 3) if (sl == 3) car_bidiag2_last<3, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 4) if (sl == 4) car_bidiag2_last<4, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 5) if (sl == 5) car_bidiag2_last<5, FUSED, MS, CQ>(m, L, vws, taup, pub);
+    if constexpr (MS > 6) if (sl >= 6) car_bidiag2_last<6, FUSED, MS, CQ>(m, L, vws, taup, pub);
 }
 
 template <int MS, int CQ>
@@ -533,8 +510,9 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
     const int NC = N - m;
     // TWO rows per wave, eight per workgroup: the launch's register budget is the producer's (one workgroup per CU), and
     // the 26 row groups must all be resident on the ~31 free CUs of the producer's XCD while it runs
-    constexpr int RW = CARF_RW;
-    constexpr int n_groups = CARF_GROUPS;
+    constexpr int RW = 2;
+    constexpr int n_groups = CAR_NS / (4 * RW);
+    static_assert(n_groups == CAR_NS / 8, "the pivot kernels check CARF_DONE against CAR_NS / 8");
     for (;;) {
         __syncthreads();
         if (tid == 0)
@@ -542,7 +520,7 @@ __global__ __launch_bounds__(CAR_BT) void k_car_bidiag_fused(const double* __res
         __syncthreads();
         const int grp = s_group;
         if (grp >= n_groups) return;
-        const int r0 = (CAR_NW * grp + wave) * RW;                     // my rows of P: r0, r0 + 1 (wave-uniform)
+        const int r0 = (4 * grp + wave) * RW;                          // my rows of P: r0, r0 + 1 (wave-uniform)
         double p[RW][4];
 #pragma unroll
         for (int w = 0; w < RW; ++w)
@@ -874,7 +852,7 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
     if (tid < SP_RING) ring[tid].tag = 0;
     if (tid < SP_W) prog[tid] = 0;
     // the fused launch in front gave up on a reflector, or not every group of Phi's rows found a consumer
-    const bool broken = err != nullptr && (err[CARF_ERR / 4] != 0u || err[CARF_DONE / 4] != (unsigned)CARF_GROUPS);
+    const bool broken = err != nullptr && (err[CARF_ERR / 4] != 0u || err[CARF_DONE / 4] != (unsigned)(CAR_NS / 8));
     __syncthreads();                                                  // (the only workgroup barrier)
 #ifdef SP_TSTAMPS
     if (tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_sp_stamps[256] = t_; }
@@ -1048,7 +1026,7 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
 
 // one compute unit (batch <= 100)
 static int car_one_cu(int N, int m) {
-    return (m >= 2 && N > m && N <= sober::CAR_NS && m <= sober::CAR_MMAX && N - m <= sober::SP_W * sober::SP_BC) ? 1 : 0;
+    return (m >= 2 && N > m && N <= sober::CAR_NS && m <= 16 * sober::CAR_MS && N - m <= sober::SP_W * sober::SP_BC) ? 1 : 0;
 }
 
 extern "C" int sober_car_supported(int N, int m) {
@@ -1058,7 +1036,7 @@ extern "C" int sober_car_supported(int N, int m) {
 // scratch: reflectors (m x 208), tau (m, padded to 128), Phi (208 x 128)
 // (a workspace sized for (N, m) also serves every (N' <= N, m): the final direct level)
 extern "C" int64_t sober_car_ws_bytes(int N, int m) {
-    const int64_t one = ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC + 1024) * (int64_t)sizeof(double)   // (+1024: stamp block)
+    const int64_t one = ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC + 512) * (int64_t)sizeof(double)   // (+512: stamp block)
                         + sober::carf_bytes(m);                                       // + the fused launch's granules
     if (car_one_cu(N, m)) return one;
     const int64_t mc = sober_car_mc_ws_bytes(N, m);
@@ -1088,8 +1066,8 @@ extern "C" int sober_car_safe_supported(int N, int m) { return car_one_cu(N, m);
 #define CAR_BY_SIZE(m_, N_, LAUNCH)                                                                    \
     do {                                                                                               \
         if ((m_) <= 16 && (N_) <= 32) { constexpr int MS_ = 1, CQ_ = 2; LAUNCH; }                      \
-        else if ((m_) <= 32 && (N_) <= 64) { constexpr int MS_ = (32 + CAR_RG - 1) / CAR_RG, CQ_ = 4; LAUNCH; }   \
-        else if ((m_) <= 64 && (N_) <= 112) { constexpr int MS_ = (64 + CAR_RG - 1) / CAR_RG, CQ_ = 7; LAUNCH; }  \
+        else if ((m_) <= 32 && (N_) <= 64) { constexpr int MS_ = 2, CQ_ = 4; LAUNCH; }                 \
+        else if ((m_) <= 64 && (N_) <= 112) { constexpr int MS_ = 4, CQ_ = 7; LAUNCH; }                \
         else if ((N_) <= 112) { constexpr int MS_ = sober::CAR_MS, CQ_ = 7; LAUNCH; }                  \
         else { constexpr int MS_ = sober::CAR_MS, CQ_ = sober::CAR_CQ; LAUNCH; }                       \
     } while (0)
@@ -1134,7 +1112,7 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
     // (an eighth of the rest: 26 are needed, 40 are offered) accumulate the rows of Phi as the reflectors appear
     static std::atomic<unsigned> epoch_ctr{0};
     const unsigned epoch = (epoch_ctr.fetch_add(1) + 1u) & 0x1FFFFFFu;
-    void* comm = (void*)(Phi + (size_t)sober::CAR_NS * sober::CAR_PC + 1024);
+    void* comm = (void*)(Phi + (size_t)sober::CAR_NS * sober::CAR_PC + 512);
     constexpr int per_xcd = 40;
     const unsigned spin_limit = sober_car_giveup_forced() ? 0u : sober::CARF_SPIN_LIMIT;
     CAR_BY_SIZE(m, N, hipLaunchKernelGGL((sober::k_car_bidiag_fused<MS_, CQ_>), dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X, ldx,
