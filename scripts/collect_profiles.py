@@ -18,8 +18,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03f"
-name = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04f"
+name = sys.argv[2] if len(sys.argv) > 2 else "r04"
 src = ROOT / "gpurun_out" / tag
 dst = ROOT / "profiles"
 DOMINANT = ("k_level_reduce_wave", "k_level_reduce_tani", "k_level_reduce<", "k_level_gather")
@@ -41,11 +41,13 @@ for c in range(1, 6):
             if any(d in r["Name"] for d in DOMINANT):
                 tot_ns += float(r["TotalDurationNs"]) if "TotalDurationNs" in r else float(r["AverageNs"]) * int(r["Calls"])
                 calls += int(r["Calls"])
-        # the stats run: 1 initialisation + 3 warm-up + 10 timed steps = 14 steps of the same work
+        # the stats run: 1 initialisation + 3 warm-up + 10 timed steps = 14 steps of the same work (+ 6 steps with a fresh
+        # pool for fingerprint pools: ms_per_step_fresh_pool) -- the step count follows from the launches per step
         if line is not None and calls:
-            per_step = tot_ns / 14 / 1e6
+            n_steps = max(1, round(calls / line["roofline"]["launches_per_step"]))
+            per_step = tot_ns / n_steps / 1e6
             mine = line["roofline"]["kernel_ms_per_step"]
-            check.append(f"cfg {c}: rocprofv3 {calls} calls, {per_step:.4f} ms/step (14 steps); bench.py (its own run) "
+            check.append(f"cfg {c}: rocprofv3 {calls} calls, {per_step:.4f} ms/step ({n_steps} steps); bench.py (its own run) "
                          f"{mine:.4f} ms/step over {line['roofline']['launches_per_step']:.1f} launches/step; "
                          f"ratio {mine / per_step:.3f}")
     rows, acc = [], {}

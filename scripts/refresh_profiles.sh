@@ -2,10 +2,10 @@
 # Run on the GPU box (gpurun): for every BASELINE configuration a driver-shaped bench line, a rocprofv3 kernel-stats run of
 # the same command and the two HBM counter passes (FETCH_SIZE, WRITE_SIZE: each its own run, kernel trace only -- never
 # together with other trace domains); for configuration 2 also two SQ counter sets; the FP64 rate probe.
-# Output under gpurun_out/$1 (default r03f); scripts/collect_profiles.py copies the judged summaries into profiles/.
-#   bash scripts/refresh_profiles.sh r03f "1 2 3 4 5"
+# Output under gpurun_out/$1 (default r04f); scripts/collect_profiles.py copies the judged summaries into profiles/.
+#   bash scripts/refresh_profiles.sh r04f "1 2 3 4 5"
 set -u
-TAG=${1:-r03f}
+TAG=${1:-r04f}
 CFGS=${2:-"1 2 3 4 5"}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
