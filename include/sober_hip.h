@@ -364,6 +364,10 @@ int sober_level_reduce_tani_queued_pair(const void* rows, const double* rows_nor
                                         int n_chunks_ub, double* partG, int ldg, double* partTot, int n_xchunks_ub,
                                         double* extraG, double* extraTot, const int64_t* dR, void* stream);
 int sober_level_chunks_cap(int n_rows, int64_t e_total_ub, int S);
+/* the same two for the fingerprint matrix-core kernel (sober_level_reduce_tani*: one workgroup per compute unit, the chunk
+ * count chosen for one or two rounds of the 256 compute units -- csrc/common.hpp: level_chunks_tani_for) */
+int sober_level_chunks_tani(int n_rows, int64_t pos0, int64_t count, int S);
+int sober_level_chunks_tani_cap(int n_rows, int64_t e_total_ub, int S);
 /* K7 (SOBER/_rchq.py:198-221) with R = *dR_cur and n_keep = keep_rank[S] read on the device; *dR_next = the next
  * level's R, or -1 with mu and the list untouched when the host loop has to take over (R <= S, no progress,
  * n_keep outside 1..S, more than R_ub_next survivors).                                                       */

@@ -19,7 +19,7 @@ for (n, n_rows, S, dt, pos0) in [(5003, 137, 20, 8, 0), (20011, 700, 200, 16, 0)
     mu = torch.rand(n, generator=g, dtype=torch.float64).to(dev); mu[::7] = 0.0
     wm = torch.rand(n, generator=g, dtype=torch.float64).to(dev)
     count = n - pos0
-    P = nat.level_chunks(n_rows, pos0, count, S)
+    P = int(lib.sober_level_chunks_tani(n_rows, pos0, count, S)) if hasattr(lib, "sober_level_chunks_tani") else nat.level_chunks(n_rows, pos0, count, S)
     partG = torch.zeros(64 * n_rows * S, dtype=torch.float64, device=dev); partTot = torch.zeros(64 * S, dtype=torch.float64, device=dev)
     def run():
         rc = lib.sober_level_reduce_tani(rows.data_ptr(), rn.data_ptr(), n_rows, cand.data_ptr(), cn.data_ptr(), dt, idx.data_ptr(),

@@ -129,6 +129,8 @@ SIGNATURES = {
     "sober_level_reduce_tani_queued_pair": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _f64, _i32,
                                                    _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "sober_level_chunks_cap": (_i32, [_i32, _i64, _i32]),
+    "sober_level_chunks_tani": (_i32, [_i32, _i64, _i64, _i32]),
+    "sober_level_chunks_tani_cap": (_i32, [_i32, _i64, _i32]),
     "sober_level_update_queued": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_record_event_pair": (_i32, [_vp, _vp, _vp]),
     "sober_set_launch_events": (_i32, [_vp, _vp]),

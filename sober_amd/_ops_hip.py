@@ -472,7 +472,7 @@ class HipOps:
             job.rows, job.cand, job.dim, job.n_rows = p.rows_aug.data_ptr(), p.cand_aug.data_ptr(), p.da, p.Mtot
             job.outputscale = float(p.spec.outputscale)
         else:
-            # fingerprints of 512 .. 2048 bits: popcount(x & y) on the INT8 matrix cores (level_reduce_tani.hip)
+            # fingerprints of 512 .. 2048 bits: popcount(x & y) on the FP4 matrix cores (level_reduce_tani.hip)
             tani = p.kind == nat.KIND_TANIMOTO and self.use_mfma and bool(nat.load().sober_level_reduce_tani_supported(p.rows.dt))
             job.variant, job.kind = (nat.LEVEL_TANI if tani else nat.LEVEL_VALU), p.kind
             job.rows, job.rows_norm = p.rows.data.data_ptr(), nat._ptr(p.rows.norm)

@@ -83,6 +83,37 @@ __host__ __device__ inline int level_chunks_for(int n_rows, int64_t e_total, int
     return (int)((e_total + epc - 1) / epc);
 }
 
+// Element chunks of a launch of the FINGERPRINT level kernel (level_reduce_tani.hip): one workgroup per compute unit (512
+// threads, ~240 VGPRs), all of a launch's workgroups equally long -- a launch costs ROUNDS x one workgroup's time, and a
+// workgroup's time is a fixed part (the rows' bits expanded into registers, two dependent gathers to the first tile, 32 KB
+// of partial sums out: ~3 tile times) plus its tiles of two elements.  So the count aims at ONE round of the 256 compute
+// units, INCLUDING the set group of the leftover positions that rides in the same grid on the queued levels: a second
+// round never pays (2 x (fixed + tiles / 2) > fixed + tiles), and every workgroup that is dispatched costs the launch
+// ~0.25 us whether it works or leaves at once (scripts/tani_queued_time.py: a queued launch sized for 12 chunks of which
+// 6 exist took 275 us against 156 -- the chunk index is therefore the SLOWEST grid dimension, surplus chunks are
+// dispatched last).  Round 3 sized for 512 workgroups without the leftover group: 13 chunks x 42 workgroups = 546 = THREE
+// rounds on the queued levels (levels 1-9 of cfg-5 at 2/3 of their speed, profiles/r04_pmc_cfg5.csv) and 13 partial-sum
+// slots of the whole table whatever the level's size.  Host and device use the same formula; scripts/tani_chunk_sweep.py
+// has the sweep (6 chunks is the fastest at every level size of cfg-5).
+__host__ __device__ inline int level_chunks_tani_cap(int n_rows, int64_t e_total_ub, int S) {
+    if (e_total_ub < 1) return 0;
+    const int64_t per = (int64_t)((S + 15) / 16 + 1) * ((n_rows + 255) / 256);      // workgroups per chunk
+    int64_t n = 256 / per;
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    if (n > e_total_ub) n = e_total_ub;
+    // (the leftover positions' launch -- 16 pseudo-sets, <= 13 elements: k_sum_partials folds its chunks x 16 columns into
+    //  set S - 1 in ONE thread per row, 208 dependent loads = 19 us at 13 chunks; two chunks: 32)
+    if (S <= 16 && n > (e_total_ub + 5) / 6) n = (e_total_ub + 5) / 6;
+    return (int)n;
+}
+__host__ __device__ inline int level_chunks_tani_for(int n_rows, int64_t e_total, int S) {
+    if (e_total < 1) return 0;
+    const int64_t n = level_chunks_tani_cap(n_rows, e_total, S);
+    const int64_t epc = (e_total + n - 1) / n;
+    return (int)((e_total + epc - 1) / epc);
+}
+
 // Split of one level launch of the wave-autonomous matrix-core kernel (level_reduce_mfma.hip: k_level_reduce_wave).
 // A wave owns a 64-row x 16-set tile over a contiguous range of elements.  All waves of a launch form ONE line, tile
 // after tile (row tiles of a set group adjacent), `wpt` waves per tile; a workgroup is SOBER_LW_W consecutive waves

@@ -67,8 +67,10 @@ extern "C" int sober_level_moments(const sober_level_job* j, void* stream) {
     if (j->count <= 0 || j->pos0 < 0 || j->E < 0) return SOBER_E_ARG;
     const int64_t ES = j->E * S;
     const bool mfma = j->variant == SOBER_LEVEL_MFMA;
+    const bool tani_k = j->variant == SOBER_LEVEL_TANI;
     const int n_chunks = mfma ? sober_level_parts_mfma(j->n_rows, j->pos0, j->count, S)
-                              : sober_level_chunks(j->n_rows, j->pos0, j->count, S);
+                              : (tani_k ? sober_level_chunks_tani(j->n_rows, j->pos0, j->count, S)
+                                        : sober_level_chunks(j->n_rows, j->pos0, j->count, S));
     if (n_chunks <= 0 || n_chunks > SOBER_LEVEL_MAX_CHUNKS) return n_chunks <= 0 ? n_chunks : SOBER_E_WS;
     // first placement: every live position, set = p mod S (leftovers land in sets 0..r-1, quirk Q1); tot over p < ES
     LX_EVENTS_BEFORE(j->ev[0], j->ev[1])
@@ -82,7 +84,8 @@ extern "C" int sober_level_moments(const sober_level_job* j, void* stream) {
     if (n_left > 0) {
         if (!j->extraG || !j->extraTot) return SOBER_E_ARG;
         n_xchunks = mfma ? sober_level_parts_mfma(j->n_rows, 0, n_left, SOBER_LEVEL_XS)
-                         : sober_level_chunks(j->n_rows, 0, n_left, SOBER_LEVEL_XS);
+                         : (tani_k ? sober_level_chunks_tani(j->n_rows, 0, n_left, SOBER_LEVEL_XS)
+                                   : sober_level_chunks(j->n_rows, 0, n_left, SOBER_LEVEL_XS));
         if (n_xchunks <= 0 || n_xchunks > SOBER_LEVEL_MAX_CHUNKS) return n_xchunks <= 0 ? n_xchunks : SOBER_E_WS;
         LX_EVENTS_BEFORE(j->ev[2], j->ev[3])
         LX_TRY(lx_reduce(j, j->idx + (lo - j->pos0), 0, n_left, SOBER_LEVEL_XS, n_xchunks, j->extraG, j->extraTot,
@@ -158,8 +161,8 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
         if (!(l == 0 && first_sums_ready)) {
             const bool tani = j->variant == SOBER_LEVEL_TANI;
             const int64_t e_ub = (Rub[l] + S - 1) / S, ex_ub = (S - 1 + SOBER_LEVEL_XS - 1) / SOBER_LEVEL_XS;
-            const int nch = tani ? sober_level_chunks_cap(j->n_rows, e_ub, S) : lx_chunks(j->n_rows, e_ub, S);
-            const int nxch = tani ? sober_level_chunks_cap(j->n_rows, ex_ub, SOBER_LEVEL_XS) : lx_chunks(j->n_rows, ex_ub, SOBER_LEVEL_XS);
+            const int nch = tani ? sober_level_chunks_tani_cap(j->n_rows, e_ub, S) : lx_chunks(j->n_rows, e_ub, S);
+            const int nxch = tani ? sober_level_chunks_tani_cap(j->n_rows, ex_ub, SOBER_LEVEL_XS) : lx_chunks(j->n_rows, ex_ub, SOBER_LEVEL_XS);
             if (nch <= 0 || nch > SOBER_LEVEL_MAX_CHUNKS || nxch <= 0 || nxch > SOBER_LEVEL_MAX_CHUNKS) return SOBER_E_WS;
             LX_EVENTS_BEFORE(j->ev[0], j->ev[1])
             if (j->ev[0] && j->ev[1]) j->ev_used[0] |= 1ull << l;

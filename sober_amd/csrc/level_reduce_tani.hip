@@ -85,7 +85,7 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     if (dR != nullptr) {                        // queued level (level_exec.cpp): the launch was sized from an UPPER BOUND of
         // the live positions; the exact number R sits in device memory.  leftover = 0: positions [0, R), set masses over
         // [0, E S) (S = S_main); leftover = 1: the leftover positions [E S_main, R) over S pseudo-sets.  The chunk count
-        // follows from the exact size (the formula the host uses: level_chunks_for); surplus workgroups leave.
+        // follows from the exact size (the formula the host uses: level_chunks_tani_for); surplus workgroups leave.
         const int64_t R = __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (R <= S_main) return;
         const int64_t ES = (R / S_main) * S_main;
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
         if (count <= 0) return;
         pos0 = 0; e_first = 0;
         e_total = (int)((count + S - 1) / S);
-        const int n_chunks = level_chunks_for(n_rows, e_total, S);
-        if ((int)blockIdx.y >= n_chunks) return;
+        const int n_chunks = level_chunks_tani_for(n_rows, e_total, S);
+        if ((int)blockIdx.z >= n_chunks) return;
         e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
     }
     static_assert(DT % 2 == 0, "a k-step is two 64-bit words");
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
     // (an XCD-aware one-dimensional grid -- the row blocks of one (set group, chunk) on ONE XCD, as in the FP64 level
     //  kernel -- was measured 16 % SLOWER here: 809 vs 695 us at level 0 of configuration 5)
     const int s0 = bx * SB;
-    const int chunk = blockIdx.y;
-    const int row0 = blockIdx.z * LT_ROWS + wave * (LT_RT * 16);
+    const int chunk = blockIdx.z;                      // (the slowest dimension: a queued launch's surplus chunks come last)
+    const int row0 = blockIdx.y * LT_ROWS + wave * (LT_RT * 16);
     const int e0 = chunk * e_per_chunk;
     const int e1 = min(e0 + e_per_chunk, e_total);
 
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(LT_RW * 64) void k_level_reduce_tani(
                 if (row < n_rows) partG[((size_t)chunk * n_rows + row) * ldg + col0 + s0 + lj] = acc[t][v];
             }
     }
-    if (partTot != nullptr && blockIdx.z == 0) {
+    if (partTot != nullptr && blockIdx.y == 0) {
         __syncthreads();
         if (cp == 0) s_w[0][cq] = tot_acc;                              // (the weight buffers are free now)
         __syncthreads();
@@ -293,10 +293,10 @@ static int launch_lt(const void* rows, const double* rows_norm, int n_rows, cons
     const int64_t e_first = pos0 / S;
     const int e_total = (int)((pos0 + count + S - 1) / S - e_first);
     const int e_per_chunk = (e_total + n_chunks - 1) / n_chunks;
-    dim3 grid((S + LT_SB - 1) / LT_SB, n_chunks, (n_rows + LT_ROWS - 1) / LT_ROWS);
+    dim3 grid((S + LT_SB - 1) / LT_SB, (n_rows + LT_ROWS - 1) / LT_ROWS, n_chunks);
     if (leftover == 2) {                                               // + the leftover launch's set groups and chunks
         grid.x += (unsigned)((S_x + LT_SB - 1) / LT_SB);
-        if ((unsigned)n_xchunks > grid.y) grid.y = (unsigned)n_xchunks;
+        if ((unsigned)n_xchunks > grid.z) grid.z = (unsigned)n_xchunks;
     }
     const size_t lds = (size_t)2 * LT_TE * LT_SB * (DT * 32 + 32) + 4 * LT_TE * LT_SB * sizeof(double);
     HIP_TRY(hipFuncSetAttribute((const void*)k_level_reduce_tani<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -313,6 +313,17 @@ static int launch_lt(const void* rows, const double* rows_norm, int n_rows, cons
 using namespace sober;
 
 extern "C" int sober_level_reduce_tani_supported(int dt) { return (dt == 8 || dt == 16 || dt == 32) ? 1 : 0; }
+
+// the element chunks of a launch of this kernel (common.hpp: level_chunks_tani_for), and the largest count a launch
+// sized for up to e_total_ub elements per set can find on the device
+extern "C" int sober_level_chunks_tani(int n_rows, int64_t pos0, int64_t count, int S) {
+    if (n_rows <= 0 || pos0 < 0 || count <= 0 || S <= 0) return SOBER_E_ARG;
+    return level_chunks_tani_for(n_rows, (pos0 + count + S - 1) / S - pos0 / S, S);
+}
+extern "C" int sober_level_chunks_tani_cap(int n_rows, int64_t e_total_ub, int S) {
+    if (n_rows <= 0 || e_total_ub <= 0 || S <= 0) return SOBER_E_ARG;
+    return level_chunks_tani_cap(n_rows, e_total_ub, S);
+}
 
 extern "C" int sober_level_reduce_tani(const void* rows, const double* rows_norm, int n_rows, const void* cand,
                                        const double* cand_norm, int dt, const int32_t* idx, int64_t pos0,

@@ -107,8 +107,8 @@ __global__ void k_sum_partials(const double* __restrict__ partG, const double* _
         if (R <= S) return;
         const int64_t E = R / S, left = R - E * S;
         // (chunked: the element-chunk kernels -- Tanimoto --, else the matrix-core FP64 kernel's slots per tile)
-        n_chunks = chunked ? level_chunks_for(n_rows, (R + S - 1) / S, S) : level_parts_mfma_for(n_rows, (R + S - 1) / S, S);
-        n_xchunks = left <= 0 ? 0 : (chunked ? level_chunks_for(n_rows, (left + n_xcols - 1) / n_xcols, n_xcols)
+        n_chunks = chunked ? level_chunks_tani_for(n_rows, (R + S - 1) / S, S) : level_parts_mfma_for(n_rows, (R + S - 1) / S, S);
+        n_xchunks = left <= 0 ? 0 : (chunked ? level_chunks_tani_for(n_rows, (left + n_xcols - 1) / n_xcols, n_xcols)
                                              : level_parts_mfma_for(n_rows, (left + n_xcols - 1) / n_xcols, n_xcols));
         if (left <= 0) { extraG = nullptr; extraTot = nullptr; }
     }
