@@ -88,10 +88,12 @@ __host__ __device__ inline int level_chunks_for(int n_rows, int64_t e_total, int
 // workgroup's time is a fixed part (the rows' bits expanded into registers, two dependent gathers to the first tile, 32 KB
 // of partial sums out: ~3 tile times) plus its tiles of two elements.  So the count aims at ONE round of the 256 compute
 // units, INCLUDING the set group of the leftover positions that rides in the same grid on the queued levels: a second
-// round never pays (2 x (fixed + tiles / 2) > fixed + tiles), and every workgroup that is dispatched costs the launch
-// ~0.25 us whether it works or leaves at once (scripts/tani_queued_time.py: a queued launch sized for 12 chunks of which
-// 6 exist took 275 us against 156 -- the chunk index is therefore the SLOWEST grid dimension, surplus chunks are
-// dispatched last).  Round 3 sized for 512 workgroups without the leftover group: 13 chunks x 42 workgroups = 546 = THREE
+// round never pays (2 x (fixed + tiles / 2) > fixed + tiles).  And the chunk index is the SLOWEST grid dimension: a
+// queued launch is sized from an upper bound, its surplus workgroups leave at once -- but to be dispatched each of them
+// needs a whole compute unit's registers and LDS like a working one, in order: placed between working ones (chunk as the
+// middle dimension, a launch sized for 12 chunks of which 6 exist) they wait for a unit to come free and everything behind
+// them waits too -- 275 us against 156 (scripts/tani_queued_time.py; an empty grid of 2048 such workgroups costs nothing
+// by itself).  Round 3 sized for 512 workgroups without the leftover group: 13 chunks x 42 workgroups = 546 = THREE
 // rounds on the queued levels (levels 1-9 of cfg-5 at 2/3 of their speed, profiles/r04_pmc_cfg5.csv) and 13 partial-sum
 // slots of the whole table whatever the level's size.  Host and device use the same formula; scripts/tani_chunk_sweep.py
 // has the sweep (6 chunks is the fastest at every level size of cfg-5).
