@@ -377,8 +377,13 @@ int sober_level_update_queued(const int32_t* idx_cur, int64_t R_ub, int S, const
 
 /* KMeans of SOBER/_weights.py:100-126: Lloyd, centroids initialised to the first K rows, exactly
  * `iters` iterations, first-index argmin (a NaN distance wins like torch.argmin), empty cluster ->
- * NaN centroid.  X is (N, d) row-major raw points.  labels: N int32.  ws: sober_kmeans_ws_bytes.  */
+ * NaN centroid.  X is (N, d) row-major raw points.  labels: N int32.  ws: sober_kmeans_ws_bytes (a smaller one
+ * selects the slower forms that need less: the FP64-only E step, or without any the (x - c)^2 kernel).       */
 int64_t sober_kmeans_ws_bytes(int64_t N, int d, int K);
+/* Shapes whose E step is screened on the BF16 matrix cores (csrc/kmeans.hip): byte offset, inside a workspace of
+ * sober_kmeans_ws_bytes, of a uint32 = the number of points the exact pass had to decide, summed over the
+ * iterations of the last call; -1 for a shape that is not screened.                                            */
+int64_t sober_kmeans_stat_offset(int64_t N, int d, int K);
 int sober_kmeans_lloyd(const double* X, int64_t N, int d, int K, int iters,
                        double* centroids, int32_t* labels, void* ws, int64_t ws_bytes, void* stream);
 

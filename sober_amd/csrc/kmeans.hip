@@ -15,6 +15,20 @@
 //         torch.argmin.  Labels bit-equal to k_kmeans_assign's.  The augmented rows of the NEXT E step are written by
 //         the M step itself (one launch less per iteration).
 //         (k_kmeans_assign: lanes <-> points, centroid tiles broadcast from LDS -- the form without a workspace.)
+// E step, SCREENED (round 4; pools of >= KM_SCREEN_MIN_N points, d <= 31, the centroid image fits LDS): the FP64 form is
+//         0.6 of the FP64 matrix peak at 1M x 20 x 500 (0.50 ms of the 0.69 ms an iteration takes) -- the arithmetic
+//         itself is the bound.  But the label only needs the ORDER of the distances, and an exact evaluation only where two
+//         of them are close: a first pass evaluates |c'|^2 - 2 x'.c' (x' = x - mu, c' = c - mu: centred on the initial
+//         centroids' mean, which leaves every distance as it is and takes the common offset out of the magnitudes) on the
+//         BF16 matrix cores from two-piece splits x' = xh + xl, -2c' = ah + al -- products xh ah + xh al + xl ah side by side
+//         along K, |c'|^2 as three pieces against 1.0, FP32 accumulation: v_mfma_f32_16x16x32_bf16, 3 d + 3 <= 32 NK
+//         slots -- keeps the two smallest per point, and takes the smallest as the label when the gap exceeds
+//         2^-12 (|x'|^2 + max |c'|^2): ~3x the bound on what the split (<= 2^-16.4), the dropped xl al products (2^-18) and
+//         64 FP32 accumulations (<= 2^-15) can move either value by (tests measure the actual error).  Every other point --
+//         near-ties, non-finite data or centroids, scales outside 1e-20 .. 1e30 -- goes to a list, and the FP64 kernel
+//         above runs on the list (its own exact re-check included): labels bit-equal to k_kmeans_assign's by construction.
+//         The points' BF16 image is built once per call (X does not change over the iterations), the centroids' by the M
+//         step; the first pass counts its labels for the sort, the list pass corrects the counts it changes.
 // M step: the points are brought into cluster order by a STABLE counting sort of (label, index) -- ascending indices
 //         inside a cluster -- and one workgroup per cluster sums its contiguous segment in a fixed order (no
 //         floating-point atomics -> bit-reproducible; the reference's scatter_add_ is sequential too).  The sort is three
@@ -97,36 +111,54 @@ __global__ __launch_bounds__(256) void k_kmeans_prep(const double* __restrict__ 
 constexpr int KM_PB = KM_PB_;      // 16-point blocks per wave
 // v_min_f64 / v_max_f64 as the hardware has them (fmin / fmax put a canonicalising v_max_f64 v, v, v in front of every
 // operand that comes out of an MFMA: 24 of the 131 vector instructions per tile); a NaN operand is dropped, which the
-// caller wants (it leaves the two smallest equal and sends the point to the re-check)
-__device__ __forceinline__ double km_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ double km_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// caller wants (it leaves the two smallest equal and sends the point to the re-check).
+// `after`: the compare mask of the same MFMA result.  The hazard recogniser does not look inside inline asm: it pads the
+// compiler's own first read of an MFMA result (that compare) with the wait states the result needs, but an asm statement
+// that reads the result was free to be scheduled right behind the MFMA (round 3's listing had the v_max_f64 there, in
+// front of the s_nops: a stale operand for the SECOND smallest value -- the margin test's input).  Taking the mask as an
+// operand orders the asm behind the compare.
+__device__ __forceinline__ double km_min(double a, double b, unsigned long long after) {
+    double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b), "s"(after)); return r;
+}
+__device__ __forceinline__ double km_max(double a, double b, unsigned long long after) {
+    double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b), "s"(after)); return r;
+}
 
 __device__ __forceinline__ void km_round_groups(int label, int lane, int& rank, int& cnt, bool& leader);
 
 // ucount != NULL: the workgroup also COUNTS its 256 points per label (the counting sort's first pass, see below: unit =
 // workgroup; every wave counts its 64 points into its own K counters in dynamic LDS -- 4 K ints --, the four are added
 // at the end): the labels never travel to a counting kernel and back
-template <int KT>                  // DA = 4 KT >= d + 1
+// LIST: the second pass of the screened E step -- the points are flist[0 .. *n_list), the waves walk the list with a grid
+// stride, a label that differs from the first pass's moves one count of the sort (ucount: [K][n_units], unit = 256 points)
+// (the list is short -- a few points per thousand -- and a wave is alone with its share: 16 points per wave there, 64 in
+//  the full pass)
+template <int KT, bool LIST>       // DA = 4 KT >= d + 1
 __global__ __launch_bounds__(256) void k_kmeans_assign_mfma(const double* __restrict__ X, int64_t N, int d,
                                                             const double* __restrict__ cent,
                                                             const double* __restrict__ Caug, int K, int Kp,
                                                             int32_t* __restrict__ labels,
-                                                            int32_t* __restrict__ ucount, int64_t n_units) {
+                                                            int32_t* __restrict__ ucount, int64_t n_units,
+                                                            const int32_t* __restrict__ flist,
+                                                            const unsigned* __restrict__ n_list) {
     extern __shared__ int km_hist[];
     typedef double d4 __attribute__((ext_vector_type(4)));
-    constexpr int DA = 4 * KT, PB = KM_PB;
+    constexpr int DA = 4 * KT, PB = LIST ? 1 : KM_PB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lj = lane & 15, lg = lane >> 4;
-    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * PB);
-    if (p0 >= N && ucount == nullptr) return;               // (a counting workgroup keeps all its waves for the final sum)
+    const int64_t NP = LIST ? (int64_t)*n_list : N;           // points to label
+  for (int64_t wu = (int64_t)blockIdx.x * 4 + wave; !LIST || wu * (16 * PB) < NP; wu += (int64_t)gridDim.x * 4) {
+    const int64_t p0 = wu * (16 * PB);
+    if (p0 >= NP && (LIST || ucount == nullptr)) return;      // (a counting workgroup keeps all its waves for the final sum)
     int* const hist = km_hist + wave * K;
-    if (ucount != nullptr)
+    if (!LIST && ucount != nullptr)
         for (int k = lane; k < K; k += 64) hist[k] = 0;     // (my own counters: no barrier needed before I use them)
     // B fragments: point p0 + 16 bl + lj, contraction slices kk = lg KT + ks (the same permutation on both operands)
     double b[PB][KT], x2[PB];
 #pragma unroll
     for (int bl = 0; bl < PB; ++bl) {
-        const int64_t i = min(p0 + 16 * bl + lj, N - 1);
+        const int64_t ip = min(p0 + 16 * bl + lj, NP - 1);
+        const int64_t i = LIST ? (int64_t)flist[ip] : ip;
         double part = 0.0;
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) {
@@ -181,8 +213,9 @@ __global__ __launch_bounds__(256) void k_kmeans_assign_mfma(const double* __rest
             for (int r = 0; r < 4; ++r) {
                 const double v = acc[r];
                 const bool lt = v < b1[bl];
-                b2[bl] = km_min(b2[bl], km_max(b1[bl], v));
-                b1[bl] = km_min(b1[bl], v);
+                const unsigned long long ltm = __builtin_amdgcn_ballot_w64(lt);
+                b2[bl] = km_min(b2[bl], km_max(b1[bl], v, ltm), ltm);
+                b1[bl] = km_min(b1[bl], v, ltm);
                 i1[bl] = lt ? (4 * t + r) : i1[bl];
             }
         }
@@ -213,8 +246,9 @@ __global__ __launch_bounds__(256) void k_kmeans_assign_mfma(const double* __rest
             k1 = take ? ok : k1;
             m1 = fmin(m1, o1);
         }
-        const int64_t i = p0 + 16 * bl + lj;
-        if (lg == 0 && i < N) {
+        const int64_t ip = p0 + 16 * bl + lj;
+        if (lg == 0 && ip < NP) {
+            const int64_t i = LIST ? (int64_t)flist[ip] : ip;
             const double margin = 0x1p-40 * (x2[bl] + cmax2);
             const bool x_nan = x2[bl] != x2[bl];
             if (x_nan) {                                     // every distance is NaN: the first index
@@ -244,9 +278,19 @@ __global__ __launch_bounds__(256) void k_kmeans_assign_mfma(const double* __rest
                 }
                 lab[bl] = bi;
             }
-            labels[i] = lab[bl];
+            if constexpr (LIST) {
+                const int was = labels[i];                   // (the first pass's candidate: counted under that label)
+                if (was != lab[bl]) {
+                    atomicAdd(ucount + (size_t)was * n_units + i / 256, -1);
+                    atomicAdd(ucount + (size_t)lab[bl] * n_units + i / 256, 1);
+                    labels[i] = lab[bl];
+                }
+            } else {
+                labels[i] = lab[bl];
+            }
         }
     }
+    if constexpr (LIST) continue;
     if (ucount == nullptr) return;
     // point p0 + L's label into lane L (it sits in lane L & 15 of block L >> 4), then the lanes of one label are found
     // with ballots and their number goes to the wave's counter of that label
@@ -264,6 +308,249 @@ __global__ __launch_bounds__(256) void k_kmeans_assign_mfma(const double* __rest
     if (blockIdx.x < n_units)
         for (int k = threadIdx.x; k < K; k += 256)
             ucount[(size_t)k * n_units + blockIdx.x] = (km_hist[k] + km_hist[K + k]) + (km_hist[2 * K + k] + km_hist[3 * K + k]);
+    return;
+  }
+}
+
+// ---- the screened E step's first pass (see the header) -----------------------------------------------------------------
+// K slots: s = 3 j + {0, 1, 2} for coordinate j < d: points {xh, xh, xl}, centroids {ah, al, ah} (a = -2 (c - mu));
+// s = 3 d + {0, 1, 2}: points 1.0, centroids the three pieces of |c - mu|^2; the rest zero.  KS = 32 NK slots per row.
+struct KmStat {
+    unsigned long long cmax2_bits[2];   // max |c - mu|^2 over the finite centroids (the bits of a non-negative double order
+    unsigned bad[2];                    // like integers); bad: a centroid that is not finite.  [parity of the iteration]
+    unsigned n_list;                    // points the first pass sent to the list
+    unsigned listed;                    // ... summed over the iterations of the call (sober_kmeans_stat_offset)
+};
+constexpr int KM_SCREEN_MIN_N = 16384;
+constexpr int KM_SCREEN_T = 512;        // threads of the first pass: 8 waves x 64 points = two units of the counting sort
+constexpr int KM_SCREEN_LDS = 78 * 1024;    // two workgroups per compute unit
+
+__device__ __forceinline__ unsigned short km_bf16(double v) {           // round to nearest even (NaN stays NaN, Inf stays Inf)
+    unsigned u = __float_as_uint((float)v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ double km_bf16_val(unsigned short h) { return (double)__uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ void km_split2(double v, unsigned short& h, unsigned short& l) {
+    h = km_bf16(v);
+    l = km_bf16(v - km_bf16_val(h));
+}
+
+// mu = mean of the first K rows (the initial centroids): any vector would do -- it only has to sit inside the cloud
+__global__ __launch_bounds__(256) void k_km_mu(const double* __restrict__ X, int K, int d, double* __restrict__ mu,
+                                               KmStat* __restrict__ st) {
+    __shared__ double s_part[8][32];
+    const int tid = threadIdx.x, j = tid & 31, g = tid >> 5;     // eight row groups x 32 coordinates
+    if (tid == 0) { st->cmax2_bits[0] = 0ull; st->cmax2_bits[1] = 0ull; st->bad[0] = 0u; st->bad[1] = 0u; st->n_list = 0u; st->listed = 0u; }
+    double acc = 0.0;
+    if (j < d)
+        for (int k = g; k < K; k += 8) acc += X[(size_t)k * d + j];
+    s_part[g][j] = acc;
+    __syncthreads();
+    if (tid >= d) return;
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += s_part[q][tid];
+    const double m = t / (double)K;
+    mu[tid] = (m == m && fabs(m) < 1e300) ? m : 0.0;
+}
+
+// the centroid's row of the BF16 image, by the threads of one workgroup (>= KS of them); c: the centroid (LDS or global)
+__device__ __forceinline__ void km_centroid_row(const double* c, const double* __restrict__ mu, int d, int KS,
+                                                unsigned short* __restrict__ row, KmStat* __restrict__ st, int par, int tid) {
+    if (tid < d) {
+        unsigned short h, l;
+        km_split2(-2.0 * (c[tid] - mu[tid]), h, l);
+        row[3 * tid] = h; row[3 * tid + 1] = l; row[3 * tid + 2] = h;
+    } else if (tid == d) {
+        double n2 = 0.0;
+        for (int j = 0; j < d; ++j) { const double cp = c[j] - mu[j]; n2 = fma(cp, cp, n2); }
+        const unsigned short p0 = km_bf16(n2);
+        const double r1 = n2 - km_bf16_val(p0);
+        const unsigned short p1 = km_bf16(r1);
+        const unsigned short p2 = km_bf16(r1 - km_bf16_val(p1));
+        row[3 * d] = p0; row[3 * d + 1] = p1; row[3 * d + 2] = p2;
+        if (n2 < 1e300) atomicMax(&st->cmax2_bits[par], (unsigned long long)__double_as_longlong(n2));
+        else atomicOr(&st->bad[par], 1u);                    // (NaN or Inf: an empty cluster's 0 / 0, overflowing data)
+    } else if (tid >= 3 * d + 3 && tid < KS) {
+        row[tid] = 0;
+    }
+}
+
+// the image of the initial centroids (rows < K) and of the padding rows up to Kp (|c|^2 = 1e30: they never win)
+__global__ __launch_bounds__(128) void k_km_cprep(const double* __restrict__ cent, int K, int d, int KS,
+                                                  const double* __restrict__ mu, unsigned short* __restrict__ Cb,
+                                                  KmStat* __restrict__ st) {
+    const int k = blockIdx.x, tid = threadIdx.x;
+    unsigned short* row = Cb + (size_t)k * KS;
+    if (k < K) { km_centroid_row(cent + (size_t)k * d, mu, d, KS, row, st, 0, tid); return; }
+    if (tid < KS) row[tid] = (tid == 3 * d) ? km_bf16(1e30) : (unsigned short)0;
+}
+
+// the points' image, once per call: Xb[i][KS] and |x - mu|^2 (FP32: it only scales the margin).  One thread per 16-byte
+// piece (8 slots: the coordinates floor(8 q / 3) .. + 3), 4 NK threads per point: rows are read and written as whole lines
+template <int NK>
+__global__ __launch_bounds__(256) void k_km_xprep(const double* __restrict__ X, int64_t N, int d,
+                                                  const double* __restrict__ mu, uint4* __restrict__ Xb,
+                                                  float* __restrict__ xn2) {
+    constexpr int LP = 4 * NK, PPW = 256 / LP;
+    __shared__ double s_x2[PPW][LP];
+    const int p = threadIdx.x / LP, q = threadIdx.x - p * LP;
+    const int64_t i = (int64_t)blockIdx.x * PPW + p;
+    const bool active = p < PPW && i < N;
+    const int s0 = 8 * q, j0 = s0 / 3;
+    unsigned short h[4], l[4];
+    double x2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = j0 + t;
+        h[t] = 0; l[t] = 0;
+        if (active && j < d) {
+            const double xv = X[i * d + j] - mu[j];
+            km_split2(xv, h[t], l[t]);
+            if (3 * j >= s0 && 3 * j < s0 + 8) x2 = fma(xv, xv, x2);      // (the piece that holds the coordinate's first slot)
+        } else if (j == d) {
+            h[t] = 0x3f80; l[t] = 0x3f80;                    // 1.0 against the three pieces of |c'|^2
+        }
+    }
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int sl = s0 + e, jj = sl / 3 - j0, pz = sl - 3 * (sl / 3);
+        const unsigned short hh = jj == 0 ? h[0] : (jj == 1 ? h[1] : (jj == 2 ? h[2] : h[3]));
+        const unsigned short ll = jj == 0 ? l[0] : (jj == 1 ? l[1] : (jj == 2 ? l[2] : l[3]));
+        w[e >> 1] |= (unsigned)(pz == 2 ? ll : hh) << (16 * (e & 1));
+    }
+    if (active) Xb[i * LP + q] = make_uint4(w[0], w[1], w[2], w[3]);
+    if (p < PPW) s_x2[p][q] = x2;
+    __syncthreads();
+    if (active && q == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < LP; ++k) t += s_x2[p][k];
+        xn2[i] = (float)t;
+    }
+}
+
+typedef __bf16 km_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float km_f4 __attribute__((ext_vector_type(4)));
+
+// first pass: labels (a candidate where the point goes to the list), the list, the sort's counts per unit of 256 points.
+// Dynamic LDS: the centroid image, Kp rows of KS * 2 + 16 bytes (the pad spreads the 16-byte fragment reads over the
+// banks), then 2 K counters.  par: parity of the iteration (which KmStat slot the M step filled; the other one is cleared).
+template <int NK>
+__global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __restrict__ Xb, const float* __restrict__ xn2,
+                                                                 int64_t N, const uint4* __restrict__ Cb, int K, int Kp,
+                                                                 KmStat* __restrict__ st, int par,
+                                                                 int32_t* __restrict__ labels, int32_t* __restrict__ ucount,
+                                                                 int64_t n_units, int32_t* __restrict__ flist) {
+    extern __shared__ int km_hist[];
+    constexpr int KS = 32 * NK, ROWB = KS * 2 + 16, PB = 4;
+    char* const cimg = (char*)km_hist;
+    int* const hist = (int*)(cimg + (size_t)Kp * ROWB);      // [2][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lj = lane & 15, lg = lane >> 4;
+    for (int q = tid; q < Kp * NK * 4; q += KM_SCREEN_T) {
+        const int row = q / (NK * 4), part = q % (NK * 4);
+        *(uint4*)(cimg + (size_t)row * ROWB + part * 16) = Cb[q];
+    }
+    const float cmax2 = (float)__longlong_as_double((long long)st->cmax2_bits[par]);
+    const bool bad = st->bad[par] != 0u;
+    if (blockIdx.x == 0 && tid == 0) { st->cmax2_bits[par ^ 1] = 0ull; st->bad[par ^ 1] = 0u; }   // (the M step fills it next)
+    const int n_tiles = Kp >> 4;
+    const int64_t n_pairs = (N + 511) / 512;
+    for (int64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        __syncthreads();                                      // (the image is in place; the last trip's counters are out)
+        for (int k = tid; k < 2 * K; k += KM_SCREEN_T) hist[k] = 0;
+        __syncthreads();
+        const int64_t p0 = pair * 512 + wave * 64;
+        km_bf16x8 b[PB][NK];
+        float x2[PB], b1[PB], b2[PB];
+        int i1[PB];
+#pragma unroll
+        for (int bl = 0; bl < PB; ++bl) {
+            const int64_t i = min(p0 + 16 * bl + lj, N - 1);
+#pragma unroll
+            for (int c = 0; c < NK; ++c) b[bl][c] = __builtin_bit_cast(km_bf16x8, Xb[(i * NK + c) * 4 + lg]);
+            x2[bl] = xn2[i];
+            b1[bl] = __builtin_inff(); b2[bl] = __builtin_inff(); i1[bl] = 0;
+        }
+        km_bf16x8 a[NK], an[NK];
+#pragma unroll
+        for (int c = 0; c < NK; ++c) a[c] = __builtin_bit_cast(km_bf16x8, *(const uint4*)(cimg + (size_t)lj * ROWB + c * 64 + lg * 16));
+        for (int t = 0; t < n_tiles; ++t) {
+            const int tn = min(t + 1, n_tiles - 1);
+#pragma unroll
+            for (int c = 0; c < NK; ++c)
+                an[c] = __builtin_bit_cast(km_bf16x8, *(const uint4*)(cimg + (size_t)(16 * tn + lj) * ROWB + c * 64 + lg * 16));
+            __builtin_amdgcn_sched_barrier(0);                // (the next tile's fragments are requested first, used a trip later)
+#pragma unroll
+            for (int bl = 0; bl < PB; ++bl) {
+                km_f4 acc = (km_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NK; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c], b[bl][c], acc, 0, 0, 0);
+                // lane (lj, lg): centroid rows 4 lg + r of the tile against point lj: the two smallest so far
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[r];
+                    const bool lt = v < b1[bl];
+                    b2[bl] = __builtin_amdgcn_fmed3f(b1[bl], b2[bl], v);     // (b1 <= b2: the middle one is the new second)
+                    b1[bl] = lt ? v : b1[bl];                 // (a select on the compare that is there anyway: fminf puts a
+                    i1[bl] = lt ? (4 * t + r) : i1[bl];       //  canonicalising v_max in front, and an inline-asm v_min is not
+                                                              //  seen by the hazard recogniser -- it read the MFMA's result early)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NK; ++c) a[c] = an[c];
+        }
+        int lab[PB];
+#pragma unroll
+        for (int bl = 0; bl < PB; ++bl) {
+            lab[bl] = -1;
+            float m1 = b1[bl], m2 = b2[bl];
+            int k1 = 16 * (i1[bl] >> 2) + 4 * lg + (i1[bl] & 3);
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float o1 = __shfl_xor(m1, o, 64), o2 = __shfl_xor(m2, o, 64);
+                const int ok = __shfl_xor(k1, o, 64);
+                const bool take = o1 < m1;
+                m2 = fminf(fminf(m2, o2), fmaxf(m1, o1));
+                k1 = take ? ok : k1;
+                m1 = fminf(m1, o1);
+            }
+            const int64_t i = p0 + 16 * bl + lj;
+            const bool valid = lg == 0 && i < N;
+            const float scale = x2[bl] + cmax2;
+            const bool sure = !bad && scale > 1e-20f && scale < 1e30f && (m2 - m1) > 0x1p-12f * scale && k1 < K;
+            if (valid) { lab[bl] = min(k1, K - 1); labels[i] = lab[bl]; }
+            const unsigned long long fl = __ballot(valid && !sure);
+            if (fl != 0ull) {                                 // (uniform)
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&st->n_list, (unsigned)__popcll(fl));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (valid && !sure) flist[base + __popcll(fl & ((1ull << lane) - 1ull))] = (int32_t)i;
+            }
+        }
+        // the counting sort's first pass (as in k_kmeans_assign_mfma): point p0 + L's label into lane L, the lanes of one
+        // label found with ballots, one LDS add per label and wave
+        int l64 = -1;
+#pragma unroll
+        for (int bl = 0; bl < PB; ++bl) {
+            const int v = __shfl(lab[bl], lane & 15, 64);
+            l64 = ((lane >> 4) == bl) ? v : l64;
+        }
+        int rank, cnt;
+        bool leader;
+        km_round_groups(l64, lane, rank, cnt, leader);
+        if (leader) atomicAdd(hist + (wave >> 2) * K + l64, cnt);
+        __syncthreads();
+        for (int q = tid; q < 2 * K; q += KM_SCREEN_T) {
+            const int u = q / K, k = q - u * K;
+            const int64_t unit = pair * 2 + u;
+            if (unit < n_units) ucount[(size_t)k * n_units + unit] = hist[q];
+        }
+    }
 }
 
 template <int DT>
@@ -435,7 +722,9 @@ template <int DT>
 __global__ __launch_bounds__(256) void k_kmeans_update_sorted(const double* __restrict__ X, int d, int K,
                                                               const int32_t* __restrict__ tot,
                                                               const int32_t* __restrict__ order,
-                                                              double* __restrict__ cent, double* __restrict__ Caug, int DA) {
+                                                              double* __restrict__ cent, double* __restrict__ Caug, int DA,
+                                                              const double* __restrict__ mu, unsigned short* __restrict__ Cb,
+                                                              int KS, KmStat* __restrict__ st, int par_next) {
     __shared__ double s_sum[4][DT + 1];
     __shared__ double s_c[DT];
     const int k = blockIdx.x, tid = threadIdx.x;
@@ -489,6 +778,10 @@ __global__ __launch_bounds__(256) void k_kmeans_update_sorted(const double* __re
         Caug[(size_t)k * DA + d] = n2;
     }
     if (tid > d && tid < DA) Caug[(size_t)k * DA + tid] = 0.0;
+    if (Cb == nullptr) return;
+    // (screened E step) the BF16 image of this centroid for the next first pass; the list is consumed by now
+    km_centroid_row(s_c, mu, d, KS, Cb + (size_t)k * KS, st, par_next, tid);
+    if (k == 0 && tid == 255) { st->listed += st->n_list; st->n_list = 0u; }
 }
 
 __global__ void k_copy_rows(const double* __restrict__ X, int64_t cnt, double* __restrict__ out) {
@@ -505,6 +798,20 @@ static inline size_t km_off_order(int K) { return km_al((size_t)K * 4); }
 static inline size_t km_off_ucount(int64_t N, int K) { return km_off_order(K) + km_al((size_t)N * 4); }
 static inline size_t km_off_caug(int64_t N, int K) { return km_off_ucount(N, K) + km_al((size_t)K * km_units(N) * 4); }
 static inline size_t km_total(int64_t N, int K) { return km_off_caug(N, K) + (size_t)km_kp(K) * 32 * 8; }
+// screened E step: + [KmStat | mu 32 doubles | Cb Kp x KS bf16 | |x'|^2 N floats | list N int32 | Xb N x KS bf16]
+static inline int km_ks(int d) { return 3 * d + 3 <= 32 ? 32 : (3 * d + 3 <= 64 ? 64 : 96); }
+static inline size_t km_screen_lds(int K, int d) { return (size_t)km_kp(K) * (km_ks(d) * 2 + 16) + (size_t)2 * K * 4; }
+static inline bool km_screen_shape(int64_t N, int d, int K) {
+    return N >= KM_SCREEN_MIN_N && N < 0x7fffffffLL && K <= KM_MAX_K_SORT && (d + 4) / 4 <= 8 && 3 * d + 3 <= 96 &&
+           km_screen_lds(K, d) <= (size_t)KM_SCREEN_LDS;
+}
+static inline size_t km_off_stat(int64_t N, int K) { return km_al(km_total(N, K)); }
+static inline size_t km_off_mu(int64_t N, int K) { return km_off_stat(N, K) + 256; }
+static inline size_t km_off_cb(int64_t N, int K) { return km_off_mu(N, K) + 256; }
+static inline size_t km_off_xn2(int64_t N, int K, int d) { return km_off_cb(N, K) + km_al((size_t)km_kp(K) * km_ks(d) * 2); }
+static inline size_t km_off_list(int64_t N, int K, int d) { return km_off_xn2(N, K, d) + km_al((size_t)N * 4); }
+static inline size_t km_off_xb(int64_t N, int K, int d) { return km_off_list(N, K, d) + km_al((size_t)N * 4); }
+static inline size_t km_total_screen(int64_t N, int K, int d) { return km_off_xb(N, K, d) + km_al((size_t)N * km_ks(d) * 2); }
 
 template <int DT>
 static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, double* cent,
@@ -535,12 +842,59 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
             sober_attr_done(attr_set);
         }
     }
+    // the screened E step (header): needs the larger workspace sober_kmeans_ws_bytes asks for at this shape
+    const bool screen = mfma_e && fuse_count && km_screen_shape(N, d, K) && ws_bytes >= (int64_t)km_total_screen(N, K, d);
+    const int ks = km_ks(d), nk = ks / 32;
+    KmStat* stat = screen ? (KmStat*)((char*)ws + km_off_stat(N, K)) : nullptr;
+    double* mu = screen ? (double*)((char*)ws + km_off_mu(N, K)) : nullptr;
+    unsigned short* Cb = screen ? (unsigned short*)((char*)ws + km_off_cb(N, K)) : nullptr;
+    float* xn2 = screen ? (float*)((char*)ws + km_off_xn2(N, K, d)) : nullptr;
+    int32_t* flist = screen ? (int32_t*)((char*)ws + km_off_list(N, K, d)) : nullptr;
+    uint4* Xb = screen ? (uint4*)((char*)ws + km_off_xb(N, K, d)) : nullptr;
+    const size_t lds_screen = km_screen_lds(K, d);
+    if (screen) {
+        static std::atomic<unsigned long long> attr_screen{0};
+        if (sober_attr_needed(attr_screen)) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<1>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<2>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<3>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
+            sober_attr_done(attr_screen);
+        }
+        hipLaunchKernelGGL(k_km_mu, dim3(1), dim3(256), 0, st, X, K, d, mu, stat);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_km_cprep, dim3((unsigned)Kp), dim3(128), 0, st, cent, K, d, ks, mu, Cb, stat);
+        LAUNCH_CHECK();
+        const int ppw = 256 / (4 * nk);                      // points per workgroup of k_km_xprep
+        const dim3 xgrid((unsigned)((N + ppw - 1) / ppw));
+        switch (nk) {
+            case 1: hipLaunchKernelGGL((k_km_xprep<1>), xgrid, dim3(256), 0, st, X, N, d, mu, Xb, xn2); break;
+            case 2: hipLaunchKernelGGL((k_km_xprep<2>), xgrid, dim3(256), 0, st, X, N, d, mu, Xb, xn2); break;
+            default: hipLaunchKernelGGL((k_km_xprep<3>), xgrid, dim3(256), 0, st, X, N, d, mu, Xb, xn2); break;
+        }
+        LAUNCH_CHECK();
+    }
     for (int it = 0; it < iters; ++it) {
-        if (mfma_e) {
+        if (screen) {
+            const int64_t n_pairs = (N + 511) / 512;
+            const dim3 sgrid((unsigned)(n_pairs < 512 ? n_pairs : 512));
+            switch (nk) {
+#define KM_SCASE(NK_) case NK_: hipLaunchKernelGGL((k_kmeans_screen<NK_>), sgrid, dim3(KM_SCREEN_T), lds_screen, st, Xb, xn2, N, \
+                                                  (const uint4*)Cb, K, Kp, stat, it & 1, labels, ucount, n_units, flist); break;
+                KM_SCASE(1) KM_SCASE(2) default: KM_SCASE(3)
+#undef KM_SCASE
+            }
+            LAUNCH_CHECK();
+            // the list: the FP64 kernel with its exact re-check, on a grid that strides over however many there are
+#define KM_CASE(T) case T: hipLaunchKernelGGL((k_kmeans_assign_mfma<T, true>), dim3(256), dim3(256), 0, st, X, N, d, cent, Caug, K, Kp, \
+                                              labels, ucount, n_units, flist, &stat->n_list); break;
+            switch (kt) { KM_CASE(1) KM_CASE(2) KM_CASE(3) KM_CASE(4) KM_CASE(5) KM_CASE(6) KM_CASE(7) KM_CASE(8) default: break; }
+#undef KM_CASE
+        } else if (mfma_e) {
             const int64_t n_waves = (N + 16 * KM_PB - 1) / (16 * KM_PB);
             const dim3 grid((unsigned)((n_waves + 3) / 4));
-#define KM_CASE(T) case T: hipLaunchKernelGGL((k_kmeans_assign_mfma<T>), grid, dim3(256), fuse_count ? lds_count : 0, st, X, N, d, \
-                                              cent, Caug, K, Kp, labels, fuse_count ? ucount : (int32_t*)nullptr, n_units); break;
+#define KM_CASE(T) case T: hipLaunchKernelGGL((k_kmeans_assign_mfma<T, false>), grid, dim3(256), fuse_count ? lds_count : 0, st, X, N, d, \
+                                              cent, Caug, K, Kp, labels, fuse_count ? ucount : (int32_t*)nullptr, n_units, \
+                                              (const int32_t*)nullptr, (const unsigned*)nullptr); break;
             switch (kt) { KM_CASE(1) KM_CASE(2) KM_CASE(3) KM_CASE(4) KM_CASE(5) KM_CASE(6) KM_CASE(7) KM_CASE(8) default: break; }
 #undef KM_CASE
         } else {
@@ -558,7 +912,8 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
             LAUNCH_CHECK();
             hipLaunchKernelGGL(k_km_place, ugrid, dim3(256), lds_place, st, labels, N, K, n_units, ucount, tot, order);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL((k_kmeans_update_sorted<DT>), dim3(K), dim3(256), 0, st, X, d, K, tot, order, cent, Caug, 4 * kt);
+            hipLaunchKernelGGL((k_kmeans_update_sorted<DT>), dim3(K), dim3(256), 0, st, X, d, K, tot, order, cent, Caug, 4 * kt,
+                               (const double*)mu, Cb, ks, stat, (it + 1) & 1);
         } else {
             hipLaunchKernelGGL((k_kmeans_update<DT>), dim3(K), dim3(256), 0, st, X, N, d, labels, cent);
         }
@@ -570,9 +925,14 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
 }  // namespace sober
 
 extern "C" int64_t sober_kmeans_ws_bytes(int64_t N, int d, int K) {
-    (void)d;
-    if (N <= 0 || K <= 0 || N >= 0x7fffffffLL) return 8;
+    if (N <= 0 || K <= 0 || d <= 0 || N >= 0x7fffffffLL) return 8;
+    if (sober::km_screen_shape(N, d, K)) return (int64_t)sober::km_total_screen(N, K, d);
     return (int64_t)sober::km_total(N, K);
+}
+
+extern "C" int64_t sober_kmeans_stat_offset(int64_t N, int d, int K) {
+    if (N <= 0 || K <= 0 || d <= 0 || !sober::km_screen_shape(N, d, K)) return -1;
+    return (int64_t)sober::km_off_stat(N, K) + 28;
 }
 
 extern "C" int sober_kmeans_lloyd(const double* X, int64_t N, int d, int K, int iters,

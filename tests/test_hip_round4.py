@@ -210,3 +210,55 @@ def test_bench_two_ranks_one_gpu(peer, dev):
     assert chk["idx_equal_unsharded"] and chk["ranks_agree"], chk
     assert chk["max_rel_w_vs_unsharded"] < 1e-9, chk
     assert d["n_selected"] <= 100 and d["value"] > 0 and d["roofline"] is not None
+
+
+def _lloyd(lib, nat, Xd, K, dev, nbytes, iters=10):
+    N, d = Xd.shape
+    c = torch.empty(K, d, dtype=torch.float64, device=dev)
+    cl = torch.empty(N, dtype=torch.int32, device=dev)
+    ws = torch.zeros(max(nbytes, 8), dtype=torch.uint8, device=dev)
+    nat._check(lib.sober_kmeans_lloyd(Xd.data_ptr(), N, d, K, iters, c.data_ptr(), cl.data_ptr(),
+                                      ws.data_ptr() if nbytes else None, nbytes, nat._stream(Xd)), "kmeans")
+    off = int(lib.sober_kmeans_stat_offset(N, d, K)) if nbytes else -1
+    listed = int(ws[off:off + 4].view(torch.int32).item()) if off >= 0 and nbytes > off else None
+    return cl.cpu().numpy(), c.cpu().numpy(), listed
+
+
+@pytest.mark.parametrize("N,d,K", [(100000, 10, 500), (40000, 20, 500), (30011, 3, 77), (20000, 9, 512), (20000, 31, 64),
+                                   (16384, 1, 33), (50000, 20, 17)])
+def test_kmeans_screened_e_step_equals_the_exact_kernel(N, d, K, dev):
+    """The E step screened on the BF16 matrix cores (csrc/kmeans.hip: two-piece splits, FP32 accumulation, a margin, the
+    FP64 kernel on whatever the margin does not decide) against the (x - c)^2 kernel that runs without a workspace: labels
+    bit-equal after ten iterations -- uniform pools, a pool far from the origin (the centring), tiny and huge scales
+    (everything goes to the list), a lattice (exact ties everywhere), tight blobs (near-ties at the margin's scale),
+    duplicated initial centroids, an empty cluster (NaN centroid), NaN and Inf coordinates."""
+    from sober_amd import _native as nat
+    lib = nat.load()
+    assert int(lib.sober_kmeans_stat_offset(N, d, K)) >= 0, "this shape is meant to take the screened path"
+    rng = np.random.default_rng(7 * N + d)
+    X = rng.random((N, d))
+    variants = {"uniform": X, "offset 1e4": X + 1e4, "offset -3e7, scale 5": 5.0 * X - 3e7, "scale 1e-14": 1e-14 * X,
+                "scale 1e18": 1e18 * X, "scale 1e160": 1e160 * X}
+    Xd2 = X.copy(); Xd2[1] = Xd2[0]; Xd2[K + 5] = Xd2[7]      # two identical initial centroids: the second one's cluster
+    variants["duplicates"] = Xd2                               # is empty after one step (NaN centroid: everything listed)
+    variants["lattice"] = np.floor(4.0 * X)                   # integer coordinates 0 .. 3: ties between many centroids
+    blobs = rng.random((K, d))[rng.integers(0, K, N)] + 1e-4 * rng.standard_normal((N, d))
+    variants["blobs 1e-4"] = blobs
+    Xe = X.copy(); Xe[:K] = 2.0 + np.arange(K)[:, None] * 3.0; Xe[K:] = Xe[0] + 1e-3 * rng.random((N - K, d))
+    variants["empty clusters"] = Xe
+    Xn = X.copy(); Xn[N // 2, d // 2] = np.nan; Xn[N // 3, 0] = np.inf
+    variants["nan and inf"] = Xn
+    full = int(lib.sober_kmeans_ws_bytes(N, d, K))
+    fractions = {}
+    for name, Xv in variants.items():
+        Xd = _t(Xv).to(dev)
+        cl_s, c_s, listed = _lloyd(lib, nat, Xd, K, dev, full)
+        cl_e, c_e, _ = _lloyd(lib, nat, Xd, K, dev, 0)
+        assert listed is not None
+        fractions[name] = listed / (10.0 * N)
+        assert np.array_equal(cl_s, cl_e), "%s: %d labels differ" % (name, int((cl_s != cl_e).sum()))
+        np.testing.assert_allclose(c_s, c_e, rtol=1e-12, equal_nan=True)
+    # the screen decides nearly everything on ordinary pools (what makes it worth running), and nothing where it must not
+    if d > 1:                                                 # (d = 1: the gaps ARE small against |x|^2 + |c|^2 for many points)
+        assert fractions["uniform"] < 0.05 and fractions["offset 1e4"] < 0.05, fractions
+    assert fractions["scale 1e-14"] == 1.0 and fractions["scale 1e160"] == 1.0, fractions
