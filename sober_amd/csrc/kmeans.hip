@@ -532,18 +532,14 @@ __global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __re
                 if (valid && !sure) flist[base + __popcll(fl & ((1ull << lane) - 1ull))] = (int32_t)i;
             }
         }
-        // the counting sort's first pass (as in k_kmeans_assign_mfma): point p0 + L's label into lane L, the lanes of one
-        // label found with ballots, one LDS add per label and wave
+        // the counting sort's first pass: point p0 + L's label into lane L (the unit's counters are integer adds: any order)
         int l64 = -1;
 #pragma unroll
         for (int bl = 0; bl < PB; ++bl) {
             const int v = __shfl(lab[bl], lane & 15, 64);
             l64 = ((lane >> 4) == bl) ? v : l64;
         }
-        int rank, cnt;
-        bool leader;
-        km_round_groups(l64, lane, rank, cnt, leader);
-        if (leader) atomicAdd(hist + (wave >> 2) * K + l64, cnt);
+        if (l64 >= 0) atomicAdd(hist + (wave >> 2) * K + l64, 1);     // (counts only: one LDS add per point, no ranks needed)
         __syncthreads();
         for (int q = tid; q < 2 * K; q += KM_SCREEN_T) {
             const int u = q / K, k = q - u * K;
@@ -725,7 +721,6 @@ __global__ __launch_bounds__(256) void k_kmeans_update_sorted(const double* __re
                                                               double* __restrict__ cent, double* __restrict__ Caug, int DA,
                                                               const double* __restrict__ mu, unsigned short* __restrict__ Cb,
                                                               int KS, KmStat* __restrict__ st, int par_next) {
-    __shared__ double s_sum[4][DT + 1];
     __shared__ double s_c[DT];
     const int k = blockIdx.x, tid = threadIdx.x;
     // lo = sum of the sizes of the clusters in front of mine
@@ -738,34 +733,34 @@ __global__ __launch_bounds__(256) void k_kmeans_update_sorted(const double* __re
     __syncthreads();
     const int lo = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
     const int n_k = tot[k];
-    double acc[DT + 1];
+    // a row is read by DT / 4 neighbouring lanes, 32 bytes each (one thread per row walked it with 8-byte loads, 64 rows
+    // -- 128 cache lines -- per load instruction, every line touched again by the next 19: 119 us at 1M x 20, x 10
+    // iterations); lane (rs, c) sums chunk c of rows rs, rs + RP, ...; the RP partial sums of a coordinate are added in
+    // order at the end -- a fixed order, like the one before
+    constexpr int CH = DT / 4, RP = 256 / CH;
+    __shared__ double s_acc[RP][DT];
+    const int ch = tid % CH, rs = tid / CH;
+    double a4[4] = {0.0, 0.0, 0.0, 0.0};
+    if (rs < RP) {
+#pragma unroll 4
+        for (int p = rs; p < n_k; p += RP) {
+            const double* row = X + (size_t)order[lo + p] * d + 4 * ch;
 #pragma unroll
-    for (int j = 0; j <= DT; ++j) acc[j] = 0.0;
-    for (int p = tid; p < n_k; p += 256) {
-        const int64_t i = order[lo + p];
+            for (int e = 0; e < 4; ++e)
+                if (4 * ch + e < d) a4[e] += row[e];
+        }
 #pragma unroll
-        for (int j = 0; j < DT; ++j)
-            if (j < d) acc[j] += X[i * d + j];
-        acc[DT] += 1.0;
-    }
-#pragma unroll
-    for (int j = 0; j <= DT; ++j) {
-        double v = acc[j];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        acc[j] = v;
-    }
-    __syncthreads();
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int j = 0; j <= DT; ++j) s_sum[tid >> 6][j] = acc[j];
+        for (int e = 0; e < 4; ++e) s_acc[rs][4 * ch + e] = a4[e];
     }
     __syncthreads();
     if (tid < d) {
         const int j = tid;
-        const double sum = ((s_sum[0][j] + s_sum[1][j]) + s_sum[2][j]) + s_sum[3][j];
-        const double cnt = ((s_sum[0][DT] + s_sum[1][DT]) + s_sum[2][DT]) + s_sum[3][DT];
-        const double c = sum / cnt;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;       // four interleaved chains, then one fixed combination
+        int r = 0;
+        for (; r + 3 < RP; r += 4) { s0 += s_acc[r][j]; s1 += s_acc[r + 1][j]; s2 += s_acc[r + 2][j]; s3 += s_acc[r + 3][j]; }
+        for (; r < RP; ++r) s0 += s_acc[r][j];
+        const double sum = (s0 + s1) + (s2 + s3);
+        const double c = sum / (double)n_k;                  // (an empty cluster: 0 / 0 = NaN, as in the reference)
         cent[(size_t)k * d + j] = c;
         if (Caug != nullptr) { Caug[(size_t)k * DA + j] = -2.0 * c; s_c[j] = c; }
     }
