@@ -292,18 +292,14 @@ __global__ __launch_bounds__(256) void k_kmeans_assign_mfma(const double* __rest
     }
     if constexpr (LIST) continue;
     if (ucount == nullptr) return;
-    // point p0 + L's label into lane L (it sits in lane L & 15 of block L >> 4), then the lanes of one label are found
-    // with ballots and their number goes to the wave's counter of that label
+    // point p0 + L's label into lane L (it sits in lane L & 15 of block L >> 4), then one LDS add per point
     int l64 = -1;
 #pragma unroll
     for (int bl = 0; bl < PB; ++bl) {
         const int v = __shfl(lab[bl], lane & 15, 64);
         l64 = ((lane >> 4) == bl) ? v : l64;
     }
-    int rank, cnt;
-    bool leader;
-    km_round_groups(l64, lane, rank, cnt, leader);
-    if (leader) hist[l64] += cnt;
+    if (l64 >= 0) atomicAdd(hist + l64, 1);                   // (counts only: integer adds in any order)
     __syncthreads();
     if (blockIdx.x < n_units)
         for (int k = threadIdx.x; k < K; k += 256)
@@ -594,9 +590,8 @@ __global__ __launch_bounds__(256) void k_kmeans_update(const double* __restrict_
 constexpr int KM_UNIT = 256;
 // one round of 64 points: rank of every lane among the lanes of its label (lane order), the group's size, its leader --
 // ballots only, nothing touches memory inside the loop (one trip per distinct label of the round)
-__device__ __forceinline__ void km_round_groups(int label, int lane, int& rank, int& cnt, bool& leader) {
+__device__ __forceinline__ void km_round_groups(int label, int lane, int& rank, int& cnt, bool& leader, unsigned long long todo) {
     const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned long long todo = __ballot(label >= 0);
     rank = 0; cnt = 0; leader = false;
     while (todo != 0ull) {                                   // (uniform)
         const int src = __ffsll((long long)todo) - 1;
@@ -609,24 +604,43 @@ __device__ __forceinline__ void km_round_groups(int label, int lane, int& rank, 
         todo &= ~m;
     }
 }
+__device__ __forceinline__ void km_round_groups(int label, int lane, int& rank, int& cnt, bool& leader) {
+    km_round_groups(label, lane, rank, cnt, leader, __ballot(label >= 0));
+}
 // hist[k]: the wave's running position for label k (counting: starts at 0; placing: starts at the cluster's offset + the
-// wave's offset inside the cluster).  Per round ONE gather read and one scatter write by the group leaders.
+// wave's offset inside the cluster).  Counting is one LDS add per point (integer sums: any order).  Placing needs the
+// rank of a point among the round's points of its label: with K in the hundreds most of a round's 64 labels occur once
+// (rank 0) -- a scratch counter per label (tmp, zero between rounds) tells which, and only the labels that occur twice or
+// more go through the ballot loop (~4 trips per round at K = 500 instead of ~60: 46 -> 2x us at 1M points).
 template <bool PLACE>
-__device__ __forceinline__ void km_wave_pass(const int32_t* __restrict__ labels, int64_t N, int64_t unit, int* hist,
+__device__ __forceinline__ void km_wave_pass(const int32_t* __restrict__ labels, int64_t N, int64_t unit, int* hist, int* tmp,
                                              int32_t* __restrict__ order) {
     volatile int* hv = hist;                                 // (the leaders write what the whole wave reads next round)
+    volatile int* tv = tmp;
     const int lane = threadIdx.x & 63;
     for (int r = 0; r < KM_UNIT / 64; ++r) {
         const int64_t i = unit * KM_UNIT + r * 64 + lane;
         const int label = (i < N) ? labels[i] : -1;
-        int rank, cnt;
-        bool leader;
-        km_round_groups(label, lane, rank, cnt, leader);
-        const int before = (label >= 0) ? hv[label] : 0;
-        if (PLACE) {
-            if (label >= 0) order[before + rank] = (int32_t)i;
+        if (!PLACE) {
+            if (label >= 0) atomicAdd(hist + label, 1);
+            continue;
         }
-        if (leader) hv[label] = before + cnt;                // (after every read of the round: a wave's LDS operations are in order)
+        // (a wave's LDS operations are executed in order: the adds, then the reads, then the clears)
+        if (label >= 0) atomicAdd(tmp + label, 1);
+        const int occ = (label >= 0) ? tv[label] : 0;
+        if (label >= 0) tv[label] = 0;
+        int rank = 0, cnt = 1;
+        bool leader = label >= 0;
+        const unsigned long long dup = __ballot(occ > 1);
+        if (dup != 0ull) {                                   // (uniform)
+            int r2, c2;
+            bool l2;
+            km_round_groups(occ > 1 ? label : -1, lane, r2, c2, l2, dup);
+            if (occ > 1) { rank = r2; cnt = c2; leader = l2; }
+        }
+        const int before = (label >= 0) ? hv[label] : 0;
+        if (label >= 0) order[before + rank] = (int32_t)i;
+        if (leader) hv[label] = before + cnt;                // (after every read of the round)
     }
 }
 
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(256) void k_km_count(const int32_t* __restrict__ la
     for (int k = lane; k < K; k += 64) hist[k] = 0;
     const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
     if (unit >= n_units) return;
-    km_wave_pass<false>(labels, N, unit, hist, nullptr);
+    km_wave_pass<false>(labels, N, unit, hist, nullptr, nullptr);
     for (int k = lane; k < K; k += 64) ucount[(size_t)k * n_units + unit] = hist[k];
 }
 
@@ -685,7 +699,7 @@ __global__ __launch_bounds__(256) void k_km_scan(int32_t* __restrict__ ucount, i
 __global__ __launch_bounds__(256) void k_km_place(const int32_t* __restrict__ labels, int64_t N, int K, int64_t n_units,
                                                   const int32_t* __restrict__ uoff, const int32_t* __restrict__ tot,
                                                   int32_t* __restrict__ order) {
-    extern __shared__ int km_hist[];                         // [4][K] counters, then [K] cluster offsets
+    extern __shared__ int km_hist[];                         // [4][K] counters, [K] cluster offsets, [4][K] scratch
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int* coff = km_hist + 4 * K;
     int* hist = km_hist + wave * K;
@@ -709,8 +723,9 @@ __global__ __launch_bounds__(256) void k_km_place(const int32_t* __restrict__ la
     const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
     if (unit >= n_units) return;
     // where this wave's points of cluster k start: K independent loads up front, nothing global inside the pass
-    for (int k = lane; k < K; k += 64) hist[k] = coff[k] + uoff[(size_t)k * n_units + unit];
-    km_wave_pass<true>(labels, N, unit, hist, order);
+    int* tmp = km_hist + (5 + wave) * K;
+    for (int k = lane; k < K; k += 64) { hist[k] = coff[k] + uoff[(size_t)k * n_units + unit]; tmp[k] = 0; }
+    km_wave_pass<true>(labels, N, unit, hist, tmp, order);
 }
 
 // M step on cluster-sorted points: workgroup k sums rows X[order[lo .. lo + n_k)] (ascending point indices)
@@ -827,13 +842,13 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
     int32_t* order = sorted ? (int32_t*)((char*)ws + km_off_order(K)) : nullptr;
     int32_t* ucount = sorted ? (int32_t*)((char*)ws + km_off_ucount(N, K)) : nullptr;
     const int64_t n_units = km_units(N);
-    const size_t lds_count = (size_t)4 * K * sizeof(int), lds_place = (size_t)5 * K * sizeof(int);
+    const size_t lds_count = (size_t)4 * K * sizeof(int), lds_place = (size_t)9 * K * sizeof(int);
     const bool fuse_count = mfma_e && sorted && lds_count <= 48 * 1024;   // the E step counts its own labels
     if (sorted && lds_place > 48 * 1024) {
         static std::atomic<unsigned long long> attr_set{0};
         if (sober_attr_needed(attr_set)) {
             HIP_TRY(hipFuncSetAttribute((const void*)k_km_count, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * KM_MAX_K_SORT * 4));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_km_place, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * KM_MAX_K_SORT * 4));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_km_place, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * KM_MAX_K_SORT * 4));
             sober_attr_done(attr_set);
         }
     }
