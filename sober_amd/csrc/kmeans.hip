@@ -183,45 +183,60 @@ __global__ __launch_bounds__(256) void k_kmeans_assign_mfma(const double* __rest
     double cmax2 = 0.0;
     int first_nan = 0x7fffffff;
     bool any_inf = false;
-    // A fragments one tile ahead
-    double a[KT], an[KT];
+    // A fragments G tiles ahead (G = 1 in the full pass: four point blocks per tile and several waves per SIMD cover an L2
+    // round trip; the list pass has one block per tile and the wave is alone on its SIMD -- one tile ahead left ~0.4 us of
+    // every tile exposed, 15-19 us per launch: four tiles per request there)
+    constexpr int G = LIST ? 4 : 1;
+    double a[G][KT], an[G][KT];
 #pragma unroll
-    for (int ks = 0; ks < KT; ++ks) a[ks] = Caug[(size_t)lj * DA + lg * KT + ks];
-    for (int t = 0; t < n_tiles; ++t) {
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
-            if (ks == ksn && 16 * t + lj < K) {
-                const double n2 = a[ks];
-                first_nan = (n2 != n2) ? min(first_nan, 16 * t + lj) : first_nan;
-                any_inf |= n2 > 1e300;
-                cmax2 = (n2 <= 1e300) ? fmax(cmax2, n2) : cmax2;
-            }
-        }
-        // the next tile's A fragments are requested FIRST (pinned: the compiler otherwise sinks the loads to the end of
+        for (int ks = 0; ks < KT; ++ks) a[g][ks] = Caug[(size_t)(16 * min(g, n_tiles - 1) + lj) * DA + lg * KT + ks];
+    for (int t0 = 0; t0 < n_tiles; t0 += G) {
+        // the next tiles' A fragments are requested FIRST (pinned: the compiler otherwise sinks the loads to the end of
         // the body and waits for them there -- an exposed L2 round trip per tile); they are taken over after the body
-        const int tn = min(t + 1, n_tiles - 1);
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) an[ks] = Caug[(size_t)(16 * tn + lj) * DA + lg * KT + ks];
+        for (int g = 0; g < G; ++g) {
+            const int tn = min(t0 + G + g, n_tiles - 1);
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) an[g][ks] = Caug[(size_t)(16 * tn + lj) * DA + lg * KT + ks];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int bl = 0; bl < PB; ++bl) {
-            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int g = 0; g < G; ++g) {
+            const int t = t0 + g;
+            if (t >= n_tiles) break;                         // (uniform)
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[bl][ks], acc, 0, 0, 0);
-            // lane (lj, lg): centroid rows lg + 4 r of the tile against point lj: the two smallest so far
+            for (int ks = 0; ks < KT; ++ks) {
+                if (ks == ksn && 16 * t + lj < K) {
+                    const double n2 = a[g][ks];
+                    first_nan = (n2 != n2) ? min(first_nan, 16 * t + lj) : first_nan;
+                    any_inf |= n2 > 1e300;
+                    cmax2 = (n2 <= 1e300) ? fmax(cmax2, n2) : cmax2;
+                }
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double v = acc[r];
-                const bool lt = v < b1[bl];
-                const unsigned long long ltm = __builtin_amdgcn_ballot_w64(lt);
-                b2[bl] = km_min(b2[bl], km_max(b1[bl], v, ltm), ltm);
-                b1[bl] = km_min(b1[bl], v, ltm);
-                i1[bl] = lt ? (4 * t + r) : i1[bl];
+            for (int bl = 0; bl < PB; ++bl) {
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KT; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][ks], b[bl][ks], acc, 0, 0, 0);
+                // lane (lj, lg): centroid rows lg + 4 r of the tile against point lj: the two smallest so far
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = acc[r];
+                    const bool lt = v < b1[bl];
+                    const unsigned long long ltm = __builtin_amdgcn_ballot_w64(lt);
+                    b2[bl] = km_min(b2[bl], km_max(b1[bl], v, ltm), ltm);
+                    b1[bl] = km_min(b1[bl], v, ltm);
+                    i1[bl] = lt ? (4 * t + r) : i1[bl];
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) a[ks] = an[ks];
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) a[g][ks] = an[g][ks];
     }
     // wave-wide: the scale, the first NaN centroid, any infinite one
 #pragma unroll
@@ -434,16 +449,18 @@ typedef float km_f4 __attribute__((ext_vector_type(4)));
 // first pass: labels (a candidate where the point goes to the list), the list, the sort's counts per unit of 256 points.
 // Dynamic LDS: the centroid image, Kp rows of KS * 2 + 16 bytes (the pad spreads the 16-byte fragment reads over the
 // banks), then 2 K counters.  par: parity of the iteration (which KmStat slot the M step filled; the other one is cleared).
-template <int NK>
+// PB: 16-point blocks per wave -- 4: a trip of the workgroup covers 512 points (two units of the sort); 2: 256 points (one
+// unit), twice the waves per point for pools too small to fill the chip with the first form
+template <int NK, int PB>
 __global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __restrict__ Xb, const float* __restrict__ xn2,
                                                                  int64_t N, const uint4* __restrict__ Cb, int K, int Kp,
                                                                  KmStat* __restrict__ st, int par,
                                                                  int32_t* __restrict__ labels, int32_t* __restrict__ ucount,
                                                                  int64_t n_units, int32_t* __restrict__ flist) {
     extern __shared__ int km_hist[];
-    constexpr int KS = 32 * NK, ROWB = KS * 2 + 16, PB = 4;
+    constexpr int KS = 32 * NK, ROWB = KS * 2 + 16, PTS = 128 * PB, NU = PB / 2;     // points, units per trip
     char* const cimg = (char*)km_hist;
-    int* const hist = (int*)(cimg + (size_t)Kp * ROWB);      // [2][K]
+    int* const hist = (int*)(cimg + (size_t)Kp * ROWB);      // [NU][K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 15, lg = lane >> 4;
     for (int q = tid; q < Kp * NK * 4; q += KM_SCREEN_T) {
@@ -454,12 +471,12 @@ __global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __re
     const bool bad = st->bad[par] != 0u;
     if (blockIdx.x == 0 && tid == 0) { st->cmax2_bits[par ^ 1] = 0ull; st->bad[par ^ 1] = 0u; }   // (the M step fills it next)
     const int n_tiles = Kp >> 4;
-    const int64_t n_pairs = (N + 511) / 512;
+    const int64_t n_pairs = (N + PTS - 1) / PTS;
     for (int64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
         __syncthreads();                                      // (the image is in place; the last trip's counters are out)
-        for (int k = tid; k < 2 * K; k += KM_SCREEN_T) hist[k] = 0;
+        for (int k = tid; k < NU * K; k += KM_SCREEN_T) hist[k] = 0;
         __syncthreads();
-        const int64_t p0 = pair * 512 + wave * 64;
+        const int64_t p0 = pair * PTS + wave * (16 * PB);
         km_bf16x8 b[PB][NK];
         float x2[PB], b1[PB], b2[PB];
         int i1[PB];
@@ -535,11 +552,11 @@ __global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __re
             const int v = __shfl(lab[bl], lane & 15, 64);
             l64 = ((lane >> 4) == bl) ? v : l64;
         }
-        if (l64 >= 0) atomicAdd(hist + (wave >> 2) * K + l64, 1);     // (counts only: one LDS add per point, no ranks needed)
+        if (l64 >= 0) atomicAdd(hist + (wave * PB / 16) * K + l64, 1);     // (counts only: one LDS add per point, no ranks needed)
         __syncthreads();
-        for (int q = tid; q < 2 * K; q += KM_SCREEN_T) {
+        for (int q = tid; q < NU * K; q += KM_SCREEN_T) {
             const int u = q / K, k = q - u * K;
-            const int64_t unit = pair * 2 + u;
+            const int64_t unit = pair * NU + u;
             if (unit < n_units) ucount[(size_t)k * n_units + unit] = hist[q];
         }
     }
@@ -865,9 +882,12 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
     if (screen) {
         static std::atomic<unsigned long long> attr_screen{0};
         if (sober_attr_needed(attr_screen)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<1>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<2>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<3>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
             sober_attr_done(attr_screen);
         }
         hipLaunchKernelGGL(k_km_mu, dim3(1), dim3(256), 0, st, X, K, d, mu, stat);
@@ -885,14 +905,14 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
     }
     for (int it = 0; it < iters; ++it) {
         if (screen) {
-            const int64_t n_pairs = (N + 511) / 512;
+            const int pb = N >= 512 * 512 ? 4 : 2;              // (fewer points per workgroup for a pool that would not fill the chip)
+            const int64_t n_pairs = (N + 128 * pb - 1) / (128 * pb);
             const dim3 sgrid((unsigned)(n_pairs < 512 ? n_pairs : 512));
-            switch (nk) {
-#define KM_SCASE(NK_) case NK_: hipLaunchKernelGGL((k_kmeans_screen<NK_>), sgrid, dim3(KM_SCREEN_T), lds_screen, st, Xb, xn2, N, \
-                                                  (const uint4*)Cb, K, Kp, stat, it & 1, labels, ucount, n_units, flist); break;
-                KM_SCASE(1) KM_SCASE(2) default: KM_SCASE(3)
+#define KM_SCASE(NK_, PB_) hipLaunchKernelGGL((k_kmeans_screen<NK_, PB_>), sgrid, dim3(KM_SCREEN_T), lds_screen, st, Xb, xn2, N, \
+                                              (const uint4*)Cb, K, Kp, stat, it & 1, labels, ucount, n_units, flist)
+            if (pb == 4) { if (nk == 1) KM_SCASE(1, 4); else if (nk == 2) KM_SCASE(2, 4); else KM_SCASE(3, 4); }
+            else { if (nk == 1) KM_SCASE(1, 2); else if (nk == 2) KM_SCASE(2, 2); else KM_SCASE(3, 2); }
 #undef KM_SCASE
-            }
             LAUNCH_CHECK();
             // the list: the FP64 kernel with its exact re-check, on a grid that strides over however many there are
 #define KM_CASE(T) case T: hipLaunchKernelGGL((k_kmeans_assign_mfma<T, true>), dim3(256), dim3(256), 0, st, X, N, d, cent, Caug, K, Kp, \
