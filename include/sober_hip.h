@@ -265,6 +265,14 @@ int sober_mc_selftest(const double* in, double* out, void* stream);
  * SOBER/_utils.py:117-157 (the "Nystrom Cholesky"), and is the core of the CholeskyQR used for the
  * range finder of torch.svd_lowrank (SOBER/_rchq.py:37).                                           */
 int sober_chol_max_n(void);
+/* The ladder's probes of make_cov_psd for sober_chol_max_n() < n <= sober_nystrom_max_n() (1024): every rung panel by
+ * panel, two launches per 32 columns, the 32 x 32 diagonal blocks through the same code as sober_cholesky (same verdict
+ * and minimum pivot).  work: n_shifts slabs of n x n doubles; xinv_ws: n_shifts x 1024 doubles.  info / min_pivot as
+ * sober_cholesky_probe_piv.  sober_nystrom_basis takes this route by itself (job.probe_ws must be set).            */
+int sober_nystrom_max_n(void);
+int sober_cholesky_probe_batched(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
+                                 double* work, int32_t* info, double* min_pivot, void* xinv_ws, int64_t ws_bytes,
+                                 void* stream);
 int sober_cholesky(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, void* stream);
 /* Same, and xinv (ceil(n/32) blocks of 32 x 32 doubles, row-major) receives the inverses of the 32 x 32 diagonal
  * blocks of L (identity-padded in the last block) -- the operands of sober_trsm_blocks.                       */

@@ -76,6 +76,8 @@ SIGNATURES = {
     "sober_level_car_retry": (_i32, [_vp, _vp]),
     "sober_mc_selftest": (_i32, [_vp, _vp, _vp]),
     "sober_chol_max_n": (_i32, []),
+    "sober_nystrom_max_n": (_i32, []),
+    "sober_cholesky_probe_batched": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_cholesky": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp]),
     "sober_cholesky_inv": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
     "sober_cholesky_inv_ratio": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp]),
@@ -525,6 +527,11 @@ def mc_selftest(x: torch.Tensor) -> torch.Tensor:
 
 def chol_max_n() -> int:
     return load().sober_chol_max_n()
+
+
+def nystrom_max_n() -> int:
+    """Largest N_nys of the device Nystrom route (the ladder's probes go panel by panel beyond chol_max_n())."""
+    return load().sober_nystrom_max_n()
 
 
 def cholesky(A, shift, info, min_pivot=None):

@@ -268,10 +268,10 @@ class HipOps:
         (tests/test_car_algorithm.py::test_car_invariant_under_orthogonal_mixing).  So any orthonormal basis of
         range(Q) serves, Q^T itself does.  (The literal host route still computes U_B.)"""
         dev, M = self.device, p.M
-        if M > nat.chol_max_n() or s > 256 or s >= M:
+        if M > nat.nystrom_max_n() or s > 256 or s >= M:
             if s < M:                                             # (s >= M is the reference's own degenerate case, not a size limit)
                 self.size_cliff("nystrom", f"N_nys = {M}, batch = {s + 1}: beyond the device Nystrom route (N_nys <= "
-                                           f"{nat.chol_max_n()}, batch <= 257); make_cov_psd and svd_lowrank run on host LAPACK "
+                                           f"{nat.nystrom_max_n()}, batch <= 257); make_cov_psd and svd_lowrank run on host LAPACK "
                                            "instead -- about 5-10x the device route's time for this phase")
             self.gram(p)
             return None
@@ -310,9 +310,12 @@ class HipOps:
         j.G, j.chol_work = G.data_ptr(), work.data_ptr()
         # (eight workgroups per rung from a few panels on: 0.49 -> 0.16 ms at M = 500; a rung whose workgroups lost each
         #  other reports PROBE_NO_VERDICT and the step goes to the host route, this process then stays with one each)
-        j.probe_mc = 1 if (M >= self.PROBE_MC_MIN and n_r <= 16 and self._probe_mc) else 0
+        j.probe_mc = 1 if (M >= self.PROBE_MC_MIN and n_r <= 16 and self._probe_mc and M <= nat.chol_max_n()) else 0
         if j.probe_mc:
             pws = self._buf_u8(p, "chol_mc_ws", nat.cholesky_probe_mc_ws_bytes(M, n_r))
+            j.probe_ws, j.probe_ws_bytes = pws.data_ptr(), pws.numel()
+        elif M > nat.chol_max_n():                           # (the panel-by-panel probes: one inverted diagonal block per rung)
+            pws = self._buf_u8(p, "chol_cb_ws", n_r * 8192)
             j.probe_ws, j.probe_ws_bytes = pws.data_ptr(), pws.numel()
         # the projection rides in the same call when the plan is a real one (it is simply redone should the flags
         # send the step to the host route)

@@ -893,6 +893,154 @@ __global__ void k_probe_mc_init(uint32_t* __restrict__ ws, int64_t n_words, int3
 }
 }  // namespace sober
 
+namespace sober {
+// ---------------- the ladder's probes beyond one workgroup's LDS panel: CH_MAXN < n <= CB_MAXN (round 4) ----------------
+// k_chol and k_chol_mc keep the panel below the diagonal block in LDS, (n - 32) x 36 doubles: n <= 536.  A Nystrom set of
+// up to 1024 points is probed panel by panel with TWO launches each, every rung in the same launches:
+//   k_cb_diag    one wave per rung: the 32 x 32 diagonal block (+ the rung's shift on its diagonal, as it is met) is
+//                factorised and inverted in registers (ch_diag_block: k_chol's own pivots, verdict and minimum);
+//   k_cb_update  one workgroup per 64 x 64 tile of the trailing lower triangle and rung: its rows of the panel
+//                L21 = A21 X^T for both sides of the tile (formed on the matrix cores from the block column itself: nobody
+//                has to finish a panel first, and nobody needs L afterwards -- only the verdicts are used), then
+//                A22 -= L21 L21^T.  A block column is read by its own panel's launches only, after every update of it.
+// 2 x n / 32 launches back to back on the stream; a failed rung keeps computing on whatever it holds (its verdict stands).
+constexpr int CB_MAXN = 1024;
+constexpr int CB_TILE = 64;
+
+__global__ __launch_bounds__(256) void k_cb_init(double* __restrict__ work, int n, const double* __restrict__ src, int ld_src,
+                                                 int32_t* __restrict__ info, double* __restrict__ min_pivot, int n_rungs) {
+    const int i = blockIdx.x, rung = blockIdx.y;
+    double* A = work + (size_t)rung * n * n;
+    for (int c = threadIdx.x; c <= i; c += 256) A[(size_t)i * n + c] = src[(size_t)i * ld_src + c];
+    if (i == 0 && threadIdx.x == 0) { info[rung] = 0; if (min_pivot) min_pivot[rung] = __builtin_inf(); }
+}
+
+__global__ __launch_bounds__(64) void k_cb_diag(double* __restrict__ work, int n, int kb, const double* __restrict__ shifts,
+                                                double* __restrict__ xinv, int32_t* __restrict__ info,
+                                                double* __restrict__ min_pivot) {
+    constexpr int LDP = CH_NB + 1;
+    __shared__ double D[CH_NB * LDP], Xs[CH_NB * LDP], s_dinv[CH_NB];
+    __shared__ int s_fail;
+    __shared__ double s_minp;
+    const int rung = blockIdx.x, lane = threadIdx.x;
+    double* A = work + (size_t)rung * n * n;
+    const int nb = min(CH_NB, n - kb);
+    const double shift = shifts[rung];
+#pragma unroll
+    for (int t = lane; t < CH_NB * CH_NB; t += 64) {
+        const int i = t >> 5, j = t & 31;
+        double v = (i < nb && j <= i) ? A[(size_t)(kb + i) * n + kb + j] : 0.0;
+        if (i == j && i < nb) v += shift;
+        D[i * LDP + j] = v;
+    }
+    if (lane == 0) { s_fail = 0; s_minp = __builtin_inf(); }
+    __syncthreads();
+    ch_diag_block(D, Xs, s_dinv, &s_fail, &s_minp, nb, kb, lane, nullptr);
+    __syncthreads();
+    double* xo = xinv + (size_t)rung * CH_NB * CH_NB;
+#pragma unroll
+    for (int t = lane; t < CH_NB * CH_NB; t += 64) xo[t] = Xs[(t >> 5) * LDP + (t & 31)];
+    if (lane == 0 && info[rung] == 0) {                       // (a decided rung keeps its verdict and its minimum)
+        if (min_pivot) min_pivot[rung] = fmin(min_pivot[rung], s_minp);
+        if (s_fail != 0) info[rung] = s_fail;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cb_update(double* __restrict__ work, int n, int kb, const double* __restrict__ xinv) {
+    constexpr int LDP = CH_NB + 1, LDPP = CH_LDPP;
+    __shared__ double Xs[CH_NB * LDP], Pr[CB_TILE * LDPP], Pc[CB_TILE * LDPP];
+    const int rung = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    double* A = work + (size_t)rung * n * n;
+    const int base = kb + CH_NB;                              // first row / column of the trailing matrix
+    // linear tile index -> (bi >= bj) in the lower triangle of 64-blocks
+    int bi = 0, rest = blockIdx.x;
+    while (rest > bi) { rest -= bi + 1; ++bi; }
+    const int bj = rest;
+    const int R0 = base + CB_TILE * bi, C0 = base + CB_TILE * bj;
+    const double* xi = xinv + (size_t)rung * CH_NB * CH_NB;
+    for (int t = tid; t < CH_NB * CH_NB; t += 256) Xs[(t >> 5) * LDP + (t & 31)] = xi[t];
+    __syncthreads();
+    // my 16 rows of the panel on either side of the tile: L21 = A21 X^T (k_chol's (c))
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        if (side == 1 && bi == bj) break;                     // (uniform: the diagonal tile has one side)
+        const int r0 = (side == 0 ? R0 : C0) + 16 * wave;
+        const double* arow = A + (size_t)min(r0 + li, n - 1) * n + kb;
+        double af[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) af[u] = arow[4 * u + lk];
+        ch_double4 acc0 = (ch_double4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = 4 * u + lk;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], Xs[li * LDP + k], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], Xs[(16 + li) * LDP + k], acc1, 0, 0, 0);
+        }
+        double* P = side == 0 ? Pr : Pc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + lk + 4 * r;
+            P[row * LDPP + li] = acc0[r];
+            P[row * LDPP + 16 + li] = acc1[r];
+        }
+    }
+    __syncthreads();
+    const double* Pcol = (bi == bj) ? Pr : Pc;
+    // A22 -= L21 L21^T for my 16 rows x 64 columns (k_chol's (d): same split accumulators)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        if (bi == bj && ct > wave) break;                     // (uniform: tiles above the diagonal)
+        double cv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            cv[e] = A[(size_t)min(R0 + 16 * wave + lk + 4 * e, n - 1) * n + min(C0 + 16 * ct + li, n - 1)];
+        ch_double4 acc0 = (ch_double4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+        const int pa = 16 * wave + li, pb = 16 * ct + li;
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[pa * LDPP + 4 * u + lk], Pcol[pb * LDPP + 4 * u + lk], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[pa * LDPP + 4 * u + 4 + lk], Pcol[pb * LDPP + 4 * u + 4 + lk], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = R0 + 16 * wave + lk + 4 * e, col = C0 + 16 * ct + li;
+            if (row < n && col <= row) A[(size_t)row * n + col] = cv[e] - (acc0[e] + acc1[e]);
+        }
+    }
+}
+}  // namespace sober
+
+extern "C" int sober_nystrom_max_n(void) { return sober::CB_MAXN; }
+
+// every rung of the ladder for CH_MAXN < n <= CB_MAXN (see above); work: n_shifts slabs of n x n doubles, xinv_ws:
+// n_shifts x 32 x 32 doubles.  info / min_pivot as sober_cholesky_probe_piv.
+extern "C" int sober_cholesky_probe_batched(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
+                                            double* work, int32_t* info, double* min_pivot, void* xinv_ws,
+                                            int64_t ws_bytes, void* stream) {
+    if (!src || !shifts || !work || !info || !xinv_ws || n <= 0 || ld_src < n || n_shifts <= 0) return SOBER_E_ARG;
+    if (n > sober::CB_MAXN || n_shifts > 64) return SOBER_E_DIM;
+    if (ws_bytes < (int64_t)n_shifts * sober::CH_NB * sober::CH_NB * 8) return SOBER_E_WS;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sober::k_cb_init, dim3(n, n_shifts), dim3(256), 0, st, work, n, src, ld_src, info, min_pivot, n_shifts);
+    LAUNCH_CHECK();
+    for (int kb = 0; kb < n; kb += sober::CH_NB) {
+        hipLaunchKernelGGL(sober::k_cb_diag, dim3(n_shifts), dim3(64), 0, st, work, n, kb, shifts, (double*)xinv_ws, info,
+                           min_pivot);
+        LAUNCH_CHECK();
+        const int rest = n - kb - sober::CH_NB;
+        if (rest <= 0) break;
+        const int T = (rest + sober::CB_TILE - 1) / sober::CB_TILE;
+        hipLaunchKernelGGL(sober::k_cb_update, dim3(T * (T + 1) / 2, n_shifts), dim3(256), 0, st, work, n, kb,
+                           (const double*)xinv_ws);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+namespace sober {
+}  // namespace sober
+
 extern "C" int sober_chol_max_n(void) { return sober::CH_MAXN; }
 
 extern "C" int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,

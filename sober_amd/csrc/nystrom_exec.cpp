@@ -49,7 +49,7 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
         return SOBER_E_ARG;
     const int M = j->M, s = j->s, n_r = j->n_rungs, niter = j->niter;
     if (M <= 0 || s <= 0 || s >= M || s > 256 || n_r <= 0 || n_r > 64 || niter < 0 || niter > 8) return SOBER_E_ARG;
-    if (M > sober_chol_max_n()) return SOBER_E_DIM;
+    if (M > sober_nystrom_max_n()) return SOBER_E_DIM;
     if (j->flags_bytes < sober_nystrom_flags_bytes(n_r, niter)) return SOBER_E_WS;
     hipStream_t st = (hipStream_t)stream;
     const int n_orth2 = 2 * (1 + 2 * niter);
@@ -63,7 +63,11 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
         // ---- make_cov_psd: |cov| + symmetry flag + largest diagonal entry, every rung of the jitter ladder probed at once,
         //      the first positive definite rung (or the diagonal fallback) applied with the reference's own additions
         NX_TRY(sober_abs_sym_dmax(j->G, M, M, j->C, M, flags, pivots + n_r, stream));
-        if (j->probe_mc) {
+        if (M > sober_chol_max_n()) {               // beyond one workgroup's LDS panel: panel by panel, two launches each
+            if (!j->probe_ws) return SOBER_E_ARG;
+            NX_TRY(sober_cholesky_probe_batched(j->C, M, M, j->shifts, n_r, j->chol_work, flags + 2, pivots, j->probe_ws,
+                                                j->probe_ws_bytes, stream));
+        } else if (j->probe_mc) {
             if (!j->probe_ws) return SOBER_E_ARG;
             NX_TRY(sober_cholesky_probe_mc(j->C, M, M, j->shifts, n_r, j->chol_work, flags + 2, pivots, j->probe_ws,
                                            j->probe_ws_bytes, stream));

@@ -98,13 +98,65 @@ def _vs_oracle(case, dev, timers, rtol):
 
 
 def test_nystrom_beyond_the_device_route_goes_to_the_host_and_says_so(dev):
-    """N_nys = 600 > 536 (csrc/chol.hip: CH_MAXN): make_cov_psd + svd_lowrank on host LAPACK (SOBER/_rchq.py:34-39 takes any
+    """N_nys = 1100 > 1024 (csrc/chol.hip: CB_MAXN): make_cov_psd + svd_lowrank on host LAPACK (SOBER/_rchq.py:34-39 takes any
     N_nys), everything else on the device; ONE warning naming the limit."""
     timers = {}
-    msgs = _vs_oracle(dict(kind=O.RBF, mode="predictive_covariance", N=8000, M=600, d=5, b=40, n_obs=60, seed=41, ard=True),
+    msgs = _vs_oracle(dict(kind=O.RBF, mode="predictive_covariance", N=8000, M=1100, d=5, b=40, n_obs=60, seed=41, ard=True),
                       dev, timers, 1e-7)
     assert "nystrom_host" in timers and "car_host" not in timers, timers
-    assert len(msgs) == 1 and "N_nys = 600" in msgs[0] and "536" in msgs[0], msgs
+    assert len(msgs) == 1 and "N_nys = 1100" in msgs[0] and "1024" in msgs[0], msgs
+
+
+@pytest.mark.parametrize("M,b", [(600, 40), (1000, 100)])
+def test_nystrom_between_536_and_1024_stays_on_the_device(M, b, dev):
+    """536 < N_nys <= 1024: the jitter ladder's probes go panel by panel (two launches per 32 columns, every rung in the same
+    launches: csrc/chol.hip k_cb_diag / k_cb_update), the rest of the chain is the one N_nys <= 536 takes; against the
+    oracle (make_cov_psd + svd_lowrank of SOBER/_rchq.py:34-39 on host LAPACK): identical points, weights to 1e-7."""
+    timers = {}
+    msgs = _vs_oracle(dict(kind=O.RBF, mode="predictive_covariance", N=20000, M=M, d=6, b=b, n_obs=80, seed=43 + M, ard=True),
+                      dev, timers, 1e-7)
+    assert "nystrom_device" in timers and "nystrom_host" not in timers and "car_host" not in timers, timers
+    assert msgs == [], msgs
+
+
+@pytest.mark.parametrize("n", [537, 600, 777, 1000, 1024])
+def test_panelwise_ladder_probes_agree_with_lapack(n, dev):
+    """sober_cholesky_probe_batched on an 11-rung ladder whose lower rungs are NOT positive definite: info == 0 exactly on
+    the rungs numpy's Cholesky accepts, a failing rung's info = the order of the first leading minor that is not positive
+    definite (dpotrf's convention), min pivot^(1/2) of an accepted rung = min diag(L) of numpy's factor."""
+    from sober_amd import _native as nat
+    lib = nat.load()
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n // 3))
+    A = B @ B.T / n                                            # rank n / 3: singular, PD only from a shift on
+    A += 1e-3 * np.diag(rng.random(n))
+    lam = np.linalg.eigvalsh(A)
+    shifts = np.concatenate([[-(lam[0] + 2e-3), -(lam[0] + 5e-4), -lam[0] * 0.5], 1e-5 * (2.0 ** np.arange(8) - 1)])
+    n_r = len(shifts)
+    Ad, sh = _t(A).to(dev), _t(shifts).to(dev)
+    work = torch.empty(n_r * n * n, dtype=torch.float64, device=dev)
+    info = torch.full((n_r,), -99, dtype=torch.int32, device=dev)
+    piv = torch.zeros(n_r, dtype=torch.float64, device=dev)
+    ws = torch.empty(n_r * 8192, dtype=torch.uint8, device=dev)
+    nat._check(lib.sober_cholesky_probe_batched(Ad.data_ptr(), n, n, sh.data_ptr(), n_r, work.data_ptr(), info.data_ptr(),
+                                                piv.data_ptr(), ws.data_ptr(), ws.numel(), nat._stream(Ad)), "probe_batched")
+    info, piv = info.cpu().numpy(), piv.cpu().numpy()
+    for r, s_ in enumerate(shifts):
+        As = A + s_ * np.eye(n)
+        try:
+            L = np.linalg.cholesky(As)
+            ok = True
+        except np.linalg.LinAlgError:
+            ok = False
+        if ok:
+            assert info[r] == 0, (r, s_, info[r])
+            np.testing.assert_allclose(np.sqrt(piv[r]), np.diag(L).min(), rtol=1e-6)
+        else:
+            lead = next(k for k in range(1, n + 1) if np.linalg.eigvalsh(As[:k, :k])[0] <= 0)
+            # (the first non-positive pivot in floating point can come a little after the first minor that is singular
+            #  in exact arithmetic; never before it)
+            assert info[r] >= lead and info[r] <= min(n, lead + 40), (r, s_, info[r], lead)
+            assert piv[r] <= 0.0 or not np.isfinite(piv[r]), (r, piv[r])
 
 
 def test_batch_beyond_the_device_kernels_goes_to_host_lapack_and_says_so(dev):
