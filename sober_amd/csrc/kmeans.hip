@@ -333,6 +333,14 @@ struct KmStat {
     unsigned listed;                    // ... summed over the iterations of the call (sober_kmeans_stat_offset)
 };
 constexpr int KM_SCREEN_MIN_N = 16384;
+// the margin's exponent: 2^-12 in every build that ships.  A diagnostic build with a smaller margin measures how far the
+// BF16 values really are from the exact ones: the smallest margin that still leaves every label right
+// (scripts/kmeans_margin.sh -> profiles/r04_kmeans_margin.txt)
+#ifndef KM_MARGIN_LOG2
+#define KM_MARGIN_LOG2 12
+#elif !defined(SOBER_DIAG_BUILD)
+#error "KM_MARGIN_LOG2 is a diagnostic switch: build with -DSOBER_DIAG_BUILD"
+#endif
 constexpr int KM_SCREEN_T = 512;        // threads of the first pass: 8 waves x 64 points = two units of the counting sort
 constexpr int KM_SCREEN_LDS = 78 * 1024;    // two workgroups per compute unit
 
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __re
             const int64_t i = p0 + 16 * bl + lj;
             const bool valid = lg == 0 && i < N;
             const float scale = x2[bl] + cmax2;
-            const bool sure = !bad && scale > 1e-20f && scale < 1e30f && (m2 - m1) > 0x1p-12f * scale && k1 < K;
+            const bool sure = !bad && scale > 1e-20f && scale < 1e30f && (m2 - m1) > __builtin_ldexpf(1.0f, -KM_MARGIN_LOG2) * scale && k1 < K;
             if (valid) { lab[bl] = min(k1, K - 1); labels[i] = lab[bl]; }
             const unsigned long long fl = __ballot(valid && !sure);
             if (fl != 0ull) {                                 // (uniform)
