@@ -22,9 +22,11 @@
 //         centroids' mean, which leaves every distance as it is and takes the common offset out of the magnitudes) on the
 //         BF16 matrix cores from two-piece splits x' = xh + xl, -2c' = ah + al -- products xh ah + xh al + xl ah side by side
 //         along K, |c'|^2 as three pieces against 1.0, FP32 accumulation: v_mfma_f32_16x16x32_bf16, 3 d + 3 <= 32 NK
-//         slots -- keeps the two smallest per point, and takes the smallest as the label when the gap exceeds
-//         2^-12 (|x'|^2 + max |c'|^2): ~3x the bound on what the split (<= 2^-16.4), the dropped xl al products (2^-18) and
-//         64 FP32 accumulations (<= 2^-15) can move either value by (tests measure the actual error).  Every other point --
+//         slots -- keeps the two smallest per point (a value carries its index in its 7 low mantissa bits, 8 beyond
+//         K = 512), and takes the smallest as the label when the gap exceeds 2^-12 (|x'|^2 + max |c'|^2): the split
+//         (<= 2^-16.4 of that scale), the dropped xl al products (2^-18), 64 FP32 accumulations (<= 2^-15) and the index bits
+//         (<= 2^-16; 2^-15 with 8) move a value by at most 2^-14, both together by half the margin (0.62 of it with 8 bits);
+//         measured: no label differs down to a margin of 2^-16 in 78 M point-iterations (profiles/r04_kmeans_margin.txt).  Every other point --
 //         near-ties, non-finite data or centroids, scales outside 1e-20 .. 1e30 -- goes to a list, and the FP64 kernel
 //         above runs on the list (its own exact re-check included): labels bit-equal to k_kmeans_assign's by construction.
 //         The points' BF16 image is built once per call (X does not change over the iterations), the centroids' by the M
@@ -459,7 +461,8 @@ typedef float km_f4 __attribute__((ext_vector_type(4)));
 // banks), then 2 K counters.  par: parity of the iteration (which KmStat slot the M step filled; the other one is cleared).
 // PB: 16-point blocks per wave -- 4: a trip of the workgroup covers 512 points (two units of the sort); 2: 256 points (one
 // unit), twice the waves per point for pools too small to fill the chip with the first form
-template <int NK, int PB>
+// IB: bits of a value's place inside the lane's stream (4 n_tiles <= 2^IB: 7 up to Kp = 512, 8 beyond)
+template <int NK, int PB, int IB>
 __global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __restrict__ Xb, const float* __restrict__ xn2,
                                                                  int64_t N, const uint4* __restrict__ Cb, int K, int Kp,
                                                                  KmStat* __restrict__ st, int par,
@@ -486,15 +489,18 @@ __global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __re
         __syncthreads();
         const int64_t p0 = pair * PTS + wave * (16 * PB);
         km_bf16x8 b[PB][NK];
-        float x2[PB], b1[PB], b2[PB];
-        int i1[PB];
+        float x2[PB], bias[PB];
+        unsigned b1[PB], b2[PB];
+        unsigned keep = ~((1u << IB) - 1u);
+        asm volatile("" : "+v"(keep));                        // (a VGPR: v_and_or takes one scalar operand, the place)
 #pragma unroll
         for (int bl = 0; bl < PB; ++bl) {
             const int64_t i = min(p0 + 16 * bl + lj, N - 1);
 #pragma unroll
             for (int c = 0; c < NK; ++c) b[bl][c] = __builtin_bit_cast(km_bf16x8, Xb[(i * NK + c) * 4 + lg]);
             x2[bl] = xn2[i];
-            b1[bl] = __builtin_inff(); b2[bl] = __builtin_inff(); i1[bl] = 0;
+            b1[bl] = 0x7f800000u; b2[bl] = 0x7f800000u;        // +inf
+            bias[bl] = x2[bl] + 0x1p-10f * (x2[bl] + cmax2);  // |x' - c'|^2 + bias: positive whatever the rounding
         }
         km_bf16x8 a[NK], an[NK];
 #pragma unroll
@@ -507,18 +513,26 @@ __global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __re
             __builtin_amdgcn_sched_barrier(0);                // (the next tile's fragments are requested first, used a trip later)
 #pragma unroll
             for (int bl = 0; bl < PB; ++bl) {
-                km_f4 acc = (km_f4){0.f, 0.f, 0.f, 0.f};
+                km_f4 acc = (km_f4){bias[bl], bias[bl], bias[bl], bias[bl]};
 #pragma unroll
                 for (int c = 0; c < NK; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c], b[bl][c], acc, 0, 0, 0);
                 // lane (lj, lg): centroid rows 4 lg + r of the tile against point lj: the two smallest so far
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = acc[r];
-                    const bool lt = v < b1[bl];
-                    b2[bl] = __builtin_amdgcn_fmed3f(b1[bl], b2[bl], v);     // (b1 <= b2: the middle one is the new second)
-                    b1[bl] = lt ? v : b1[bl];                 // (a select on the compare that is there anyway: fminf puts a
-                    i1[bl] = lt ? (4 * t + r) : i1[bl];       //  canonicalising v_max in front, and an inline-asm v_min is not
-                                                              //  seen by the hazard recogniser -- it read the MFMA's result early)
+                    // Three INTEGER instructions per value.  The accumulator starts at |x'|^2 plus a small bias, so every
+                    // value is a positive float (a squared distance + bias - error > 0) and unsigned integer order IS float
+                    // order; the value carries its place (4 t + r) in its low IB mantissa bits (<= 2^-16 of the scale at 7
+                    // bits, 2^-15 at 8: inside the margin's budget, see the header): v_and_or, the new second smallest = the
+                    // middle of (b1, b2, v), the new smallest = min(b1, v).  (A float min puts a canonicalising v_max in
+                    // front of an MFMA result; an inline-asm v_min is not seen by the hazard recogniser -- it read the
+                    // MFMA's result early; a separate index takes a compare and two selects.)
+                    unsigned place = (unsigned)(4 * t + r);
+                    asm("" : "+s"(place));                    // (its own SGPR: v_and_or instead of v_and + v_or3 with r inline)
+                    const unsigned v = (__float_as_uint(acc[r]) & keep) | place;
+                    // (v_med3_u32 has no builtin; its operands are VALU results the compiler made -- the v_and_or above --,
+                    //  not the MFMA's registers: no hazard hides in this asm)
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(b2[bl]) : "v"(b1[bl]), "v"(b2[bl]), "v"(v));   // (b1 <= b2: the middle one)
+                    b1[bl] = min(b1[bl], v);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -529,8 +543,9 @@ __global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __re
 #pragma unroll
         for (int bl = 0; bl < PB; ++bl) {
             lab[bl] = -1;
-            float m1 = b1[bl], m2 = b2[bl];
-            int k1 = 16 * (i1[bl] >> 2) + 4 * lg + (i1[bl] & 3);
+            float m1 = __uint_as_float(b1[bl]), m2 = __uint_as_float(b2[bl]);
+            const int code = (int)(b1[bl] & ((1u << IB) - 1u));                  // (+inf, nothing seen: 0)
+            int k1 = 16 * (code >> 2) + 4 * lg + (code & 3);
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
                 const float o1 = __shfl_xor(m1, o, 64), o2 = __shfl_xor(m2, o, 64);
@@ -890,12 +905,10 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
     if (screen) {
         static std::atomic<unsigned long long> attr_screen{0};
         if (sober_attr_needed(attr_screen)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS));
+#define KM_SATTR(NK_, PB_, IB_) HIP_TRY(hipFuncSetAttribute((const void*)k_kmeans_screen<NK_, PB_, IB_>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_SCREEN_LDS))
+            KM_SATTR(1, 4, 7); KM_SATTR(2, 4, 7); KM_SATTR(3, 4, 7); KM_SATTR(1, 2, 7); KM_SATTR(2, 2, 7); KM_SATTR(3, 2, 7);
+            KM_SATTR(1, 4, 8); KM_SATTR(2, 4, 8); KM_SATTR(3, 4, 8); KM_SATTR(1, 2, 8); KM_SATTR(2, 2, 8); KM_SATTR(3, 2, 8);
+#undef KM_SATTR
             sober_attr_done(attr_screen);
         }
         hipLaunchKernelGGL(k_km_mu, dim3(1), dim3(256), 0, st, X, K, d, mu, stat);
@@ -916,8 +929,10 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
             const int pb = N >= 512 * 512 ? 4 : 2;              // (fewer points per workgroup for a pool that would not fill the chip)
             const int64_t n_pairs = (N + 128 * pb - 1) / (128 * pb);
             const dim3 sgrid((unsigned)(n_pairs < 512 ? n_pairs : 512));
-#define KM_SCASE(NK_, PB_) hipLaunchKernelGGL((k_kmeans_screen<NK_, PB_>), sgrid, dim3(KM_SCREEN_T), lds_screen, st, Xb, xn2, N, \
-                                              (const uint4*)Cb, K, Kp, stat, it & 1, labels, ucount, n_units, flist)
+#define KM_SCASE(NK_, PB_) do { if (Kp <= 512) hipLaunchKernelGGL((k_kmeans_screen<NK_, PB_, 7>), sgrid, dim3(KM_SCREEN_T), lds_screen, st, Xb, xn2, N, \
+                                              (const uint4*)Cb, K, Kp, stat, it & 1, labels, ucount, n_units, flist); \
+                                 else hipLaunchKernelGGL((k_kmeans_screen<NK_, PB_, 8>), sgrid, dim3(KM_SCREEN_T), lds_screen, st, Xb, xn2, N, \
+                                              (const uint4*)Cb, K, Kp, stat, it & 1, labels, ucount, n_units, flist); } while (0)
             if (pb == 4) { if (nk == 1) KM_SCASE(1, 4); else if (nk == 2) KM_SCASE(2, 4); else KM_SCASE(3, 4); }
             else { if (nk == 1) KM_SCASE(1, 2); else if (nk == 2) KM_SCASE(2, 2); else KM_SCASE(3, 2); }
 #undef KM_SCASE
