@@ -277,7 +277,7 @@ def _lloyd(lib, nat, Xd, K, dev, nbytes, iters=10):
 
 
 @pytest.mark.parametrize("N,d,K", [(100000, 10, 500), (40000, 20, 500), (30011, 3, 77), (20000, 9, 512), (20000, 31, 64),
-                                   (16384, 1, 33), (50000, 20, 17)])
+                                   (16384, 1, 33), (50000, 20, 17), (20000, 4, 1), (20000, 5, 2), (300000, 8, 880)])
 def test_kmeans_screened_e_step_equals_the_exact_kernel(N, d, K, dev):
     """The E step screened on the BF16 matrix cores (csrc/kmeans.hip: two-piece splits, FP32 accumulation, a margin, the
     FP64 kernel on whatever the margin does not decide) against the (x - c)^2 kernel that runs without a workspace: labels
