@@ -392,6 +392,9 @@ int64_t sober_kmeans_ws_bytes(int64_t N, int d, int K);
  * sober_kmeans_ws_bytes, of a uint32 = the number of points the exact pass had to decide, summed over the
  * iterations of the last call; -1 for a shape that is not screened.                                            */
 int64_t sober_kmeans_stat_offset(int64_t N, int d, int K);
+/* The workspace that selects the screened E step at every shape that allows it (stat_offset >= 0) -- sober_kmeans_ws_bytes
+ * asks for it only from the pool size on where it is the faster form (N x ceil((d + 1) / 4) >= 300000); 0 otherwise. */
+int64_t sober_kmeans_ws_bytes_screened(int64_t N, int d, int K);
 int sober_kmeans_lloyd(const double* X, int64_t N, int d, int K, int iters,
                        double* centroids, int32_t* labels, void* ws, int64_t ws_bytes, void* stream);
 

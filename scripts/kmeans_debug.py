@@ -13,6 +13,6 @@ for shape in os.environ.get("KM_SHAPES", "30011,3,77;30011,3,80;30011,3,512;3001
         ws = torch.zeros(max(nbytes, 8), dtype=torch.uint8, device=dev)
         nat._check(lib.sober_kmeans_lloyd(X.data_ptr(), N, d, K, iters, c.data_ptr(), cl.data_ptr(), ws.data_ptr() if nbytes else None, nbytes, nat._stream(X)), "km")
         return cl.cpu().numpy(), c.cpu().numpy()
-    full = int(lib.sober_kmeans_ws_bytes(N, d, K))
+    full = int(lib.sober_kmeans_ws_bytes_screened(N, d, K)) or int(lib.sober_kmeans_ws_bytes(N, d, K))
     a, ca = run(full, 1); b, cb = run(0, 1)
     print(shape, "screened" if int(lib.sober_kmeans_stat_offset(N, d, K)) >= 0 else "fp64", "mismatches", int((a != b).sum()))

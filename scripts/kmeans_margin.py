@@ -24,7 +24,7 @@ for shape in "1000000,20,500;400000,10,500;400000,3,200;300000,31,256;500000,6,6
             off = int(lib.sober_kmeans_stat_offset(N, d, K))
             listed = int(ws[off:off + 4].view(torch.int32).item()) if nbytes else 0
             return cl, listed
-        full = int(lib.sober_kmeans_ws_bytes(N, d, K))
+        full = int(lib.sober_kmeans_ws_bytes_screened(N, d, K)) or int(lib.sober_kmeans_ws_bytes(N, d, K))
         a, listed = run(full); b, _ = run(0)
         bad = int((a != b).sum().item())
         tot_pts += 10 * N; tot_bad += bad

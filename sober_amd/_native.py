@@ -92,6 +92,7 @@ SIGNATURES = {
     "sober_jitter_ladder_auto": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "sober_kmeans_ws_bytes": (_i64, [_i64, _i32, _i32]),
     "sober_kmeans_stat_offset": (_i64, [_i64, _i32, _i32]),
+    "sober_kmeans_ws_bytes_screened": (_i64, [_i64, _i32, _i32]),
     "sober_kmeans_lloyd": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "sober_predict_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f64, _vp, _f64, _f64, _vp, _f64, _vp, _i32, _vp]),
     "sober_reduce_ws_bytes": (_i64, [_i64]),

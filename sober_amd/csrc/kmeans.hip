@@ -334,7 +334,11 @@ struct KmStat {
     unsigned n_list;                    // points the first pass sent to the list
     unsigned listed;                    // ... summed over the iterations of the call (sober_kmeans_stat_offset)
 };
-constexpr int KM_SCREEN_MIN_N = 16384;
+constexpr int KM_SCREEN_MIN_N = 4096;          // (eligible from here on; RECOMMENDED from KM_SCREEN_MIN_WORK on)
+// pool size x FP64 contraction steps from which the screened E step is faster than the FP64 one (same box, K = 500:
+// 20k x 10 0.54 vs 0.49 ms, 50k x 6 0.53 vs 0.46, 50k x 20 0.65 vs 0.65, 100k x 10 0.70 vs 0.73, 200k x 10 0.86 vs 1.12,
+// 1M x 20 2.8 vs 5.8): below it sober_kmeans_ws_bytes asks for the FP64 form's workspace only
+constexpr long long KM_SCREEN_MIN_WORK = 300000;
 // the margin's exponent: 2^-12 in every build that ships.  A diagnostic build with a smaller margin measures how far the
 // BF16 values really are from the exact ones: the smallest margin that still leaves every label right
 // (scripts/kmeans_margin.sh -> profiles/r04_kmeans_margin.txt)
@@ -979,8 +983,16 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
 
 extern "C" int64_t sober_kmeans_ws_bytes(int64_t N, int d, int K) {
     if (N <= 0 || K <= 0 || d <= 0 || N >= 0x7fffffffLL) return 8;
-    if (sober::km_screen_shape(N, d, K)) return (int64_t)sober::km_total_screen(N, K, d);
+    if (sober::km_screen_shape(N, d, K) && N * ((d + 4) / 4) >= sober::KM_SCREEN_MIN_WORK)
+        return (int64_t)sober::km_total_screen(N, K, d);
     return (int64_t)sober::km_total(N, K);
+}
+
+// the workspace that selects the screened E step wherever the shape allows it (sober_kmeans_stat_offset >= 0), also
+// below the size from which it pays -- what sober_kmeans_ws_bytes returns there; 0: not a screened shape
+extern "C" int64_t sober_kmeans_ws_bytes_screened(int64_t N, int d, int K) {
+    if (N <= 0 || K <= 0 || d <= 0 || !sober::km_screen_shape(N, d, K)) return 0;
+    return (int64_t)sober::km_total_screen(N, K, d);
 }
 
 extern "C" int64_t sober_kmeans_stat_offset(int64_t N, int d, int K) {

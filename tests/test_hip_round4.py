@@ -300,7 +300,8 @@ def test_kmeans_screened_e_step_equals_the_exact_kernel(N, d, K, dev):
     variants["empty clusters"] = Xe
     Xn = X.copy(); Xn[N // 2, d // 2] = np.nan; Xn[N // 3, 0] = np.inf
     variants["nan and inf"] = Xn
-    full = int(lib.sober_kmeans_ws_bytes(N, d, K))
+    full = int(lib.sober_kmeans_ws_bytes_screened(N, d, K))   # (also below the pool size from which the screen pays)
+    assert full >= int(lib.sober_kmeans_ws_bytes(N, d, K))
     fractions = {}
     for name, Xv in variants.items():
         Xd = _t(Xv).to(dev)
