@@ -362,20 +362,20 @@ __device__ __forceinline__ void km_split2(double v, unsigned short& h, unsigned 
 }
 
 // mu = mean of the first K rows (the initial centroids): any vector would do -- it only has to sit inside the cloud
-__global__ __launch_bounds__(256) void k_km_mu(const double* __restrict__ X, int K, int d, double* __restrict__ mu,
-                                               KmStat* __restrict__ st) {
-    __shared__ double s_part[8][32];
-    const int tid = threadIdx.x, j = tid & 31, g = tid >> 5;     // eight row groups x 32 coordinates
+__global__ __launch_bounds__(1024) void k_km_mu(const double* __restrict__ X, int K, int d, double* __restrict__ mu,
+                                                KmStat* __restrict__ st) {
+    __shared__ double s_part[32][33];
+    const int tid = threadIdx.x, j = tid & 31, g = tid >> 5;     // 32 row groups x 32 coordinates (a chain of K / 32 loads each)
     if (tid == 0) { st->cmax2_bits[0] = 0ull; st->cmax2_bits[1] = 0ull; st->bad[0] = 0u; st->bad[1] = 0u; st->n_list = 0u; st->listed = 0u; }
     double acc = 0.0;
     if (j < d)
-        for (int k = g; k < K; k += 8) acc += X[(size_t)k * d + j];
+        for (int k = g; k < K; k += 32) acc += X[(size_t)k * d + j];
     s_part[g][j] = acc;
     __syncthreads();
     if (tid >= d) return;
     double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t += s_part[q][tid];
+    for (int q = 0; q < 32; ++q) t += s_part[q][tid];
     const double m = t / (double)K;
     mu[tid] = (m == m && fabs(m) < 1e300) ? m : 0.0;
 }
@@ -915,7 +915,7 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
 #undef KM_SATTR
             sober_attr_done(attr_screen);
         }
-        hipLaunchKernelGGL(k_km_mu, dim3(1), dim3(256), 0, st, X, K, d, mu, stat);
+        hipLaunchKernelGGL(k_km_mu, dim3(1), dim3(1024), 0, st, X, K, d, mu, stat);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_km_cprep, dim3((unsigned)Kp), dim3(128), 0, st, cent, K, d, ks, mu, Cb, stat);
         LAUNCH_CHECK();
