@@ -62,9 +62,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
 FP4_PEAK_TOPS = 10000.0          # dense FP4 / FP6 MFMA (block-scaled f8f6f4 form) = 4 x the bf16 rate (MI355X_MICROARCH.md, matrix cores)
 CK = {"rbf": 28, "matern52": 40}
 # What the FP64 units of an MI355X sustain chip-wide (scripts/dp_rate_probe.hip, wall clock, all 256 CUs; committed
-# output: profiles/r03_dp_rate.txt): the clock under FP64 load is ~1.9 GHz, not the 2.4 GHz of the vendor figure.
+# output: profiles/r04_dp_rate.txt, first taken in round 3: profiles/r03_dp_rate.txt): the clock under FP64 load is ~1.9 GHz, not the 2.4 GHz of the vendor figure.
 FP64_MEASURED_TFLOPS = {"v_fma_f64": 61.0, "v_mfma_f64_16x16x4": 63.0, "level-kernel mix (12 MFMA + 160 FMA)": 69.0,
-                        "source": "profiles/r03_dp_rate.txt"}
+                        "source": "profiles/r04_dp_rate.txt"}
 
 
 def pmc_traffic(config):
@@ -251,14 +251,25 @@ def main():
     ops.prof = []
     ops.prof_reserve(48 * (args.steps + args.warmup + 1))    # event pairs for the level launches, created up front
     idx, w = step()                                      # initialisation (library load, workspaces, first-use paths)
-    # ... and a quarter of a second of the same step: a fresh process on a fresh box starts with the device's clocks and
-    # the allocator's pools cold (first line of a box 4.32 ms, the same command again 4.17: ten timed steps are 42 ms)
-    t_init = time.perf_counter()
-    n_init = 0
-    while world == 1 and time.perf_counter() - t_init < 0.25 and n_init < 60:
-        idx, w = step(); n_init += 1
-    for _ in range(20 if world > 1 else 0):              # (a fixed count where the steps are collective)
+    # the first `--steps` steps of this fresh process, timed like the timed region (ms_per_step_cold: what the same
+    # command measured before round 4's last commit put a quarter of a second of steps in front of the warm-ups)
+    torch.cuda.synchronize(); barrier()
+    t_cold = time.perf_counter()
+    for _ in range(args.steps):
         idx, w = step()
+    torch.cuda.synchronize(); barrier()
+    ms_cold = (time.perf_counter() - t_cold) / args.steps * 1e3
+    n_init = 1 + args.steps
+    # ... and a quarter of a second of the same step: a fresh process on a fresh box starts with the device's clocks and
+    # the allocator's pools cold (first line of a box 4.32 ms, the same command again 4.17: ten timed steps are 42 ms).
+    # These steps are reported: init_steps, warmup_effective = init_steps + --warmup.
+    t_init = time.perf_counter()
+    n_spin = 0
+    while world == 1 and time.perf_counter() - t_init < 0.25 and n_spin < 60:
+        idx, w = step(); n_spin += 1
+    for _ in range(20 if world > 1 else 0):              # (a fixed count where the steps are collective)
+        idx, w = step(); n_spin += 1
+    n_init += n_spin
     import gc
     gc.collect(); gc.disable()                           # no collector pauses inside the timed region
     for _ in range(args.warmup):
@@ -454,7 +465,12 @@ def main():
         "value": N_total / (elapsed / args.steps),
         "unit": "candidates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "init_steps": n_init, "warmup_effective": n_init + args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_cold": ms_cold,
+        "ms_per_step_protocol": f"untimed: 1 initialisation step, {args.steps} steps timed as ms_per_step_cold (the first steps of "
+                                f"a fresh process), {n_spin} steady-state steps (0.25 s), {args.warmup} warm-up steps; then the "
+                                f"{args.steps} timed steps behind ms_per_step / value",
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u64" if cfg["kind"] == "tanimoto" else "f64", "data": "synthetic",
         "config": {"workload": f"{cfg['name']}, N_rec={N_loc} per GPU ({N_total} in all), N_nys={cfg['M']}, "

@@ -1,80 +1,3 @@
-"""A sampled (continuous / categorical) prior in front of `sober_amd.Sober.next_batch` -- an EXAMPLE, outside the package.
-
-`sober_amd` is SOBER's recombination hot path; GENERATING candidates from a sampled prior
-(SOBER/_sampler.py:163-323: weighted draws, prior updates, WKDE refits) is not on it, and a user of the reference already
-has the reference's `EmpiricalSampler` for that.  What the path needs from it is one callable
-
-    candidate_funnel(sober, n_rec, n_nys, verbose) -> (X_cand, X_nys, weights)
-
-given to `sober_amd.Sober(prior, model, candidate_funnel=...)`.  This file is such a callable, with the control flow of
-the reference's `sampling_candidates` (same order of draws, same thresholds), the drawing / refitting / resetting
-delegated to the prior object and to the caller's `prior_updater` hook; the Nystrom subsample at its end is the
-package's `nystrom_subsample` (KMeans on the device for a continuous prior).  tests/ drive it against the reference's
-own `Sober.next_batch` fixture (tests/test_hip_parity.py::test_sober_next_batch_vs_reference)."""
-import torch
-
-
-def _categorical(sober):
-    return sober.label in ("mixedcategorical", "categorical")            # SOBER/_sampler.py:163-176
-
-
-def _update_prior(sober, X, weights):
-    """SOBER/_sampler.py:110-161 refits the prior on the weighted sample (`_prior_update.py`): the caller's hook."""
-    if sober.prior_updater is None:
-        raise NotImplementedError("updating a sampled prior needs Sober(..., prior_updater=callable(sampler, X, weights))")
-    sober.prior_updater(sober, X, weights)
-
-
-def _draw(sober, n_rec):
-    """SOBER/_sampler.py:178-208 -> (X_cand, X_indices or None, weights)."""
-    if _categorical(sober):
-        X_cand, X_indices = sober.prior.sample_both(n_rec)
-        weights = sober.pi(X_cand) / sober.prior.pdf(X_indices)
-        return X_cand, X_indices, sober.cleansing_weights(weights.contiguous())
-    X_cand = sober.prior.sample(n_rec)
-    weights = sober.pi(X_cand) / sober.prior.pdf(X_cand)
-    return X_cand, None, sober.cleansing_weights(weights.contiguous())
-
-
-def _recursive_draws(sober, n_rec, n_repeat):
-    """SOBER/_sampler.py:210-262: repeat the weighted draw until more than `thresh` candidates carry weight; none at
-    all -> uniform weights (`sober.flag`)."""
-    n_accepted, X_acc, I_acc, w_acc = 0, [], [], []
-    sober.flag = False
-    for _ in range(n_repeat):
-        X_cand, X_indices, weights = _draw(sober, n_rec)
-        idx = weights > 0
-        if not idx.sum() == 0:
-            X_acc.append(X_cand[idx])
-            w_acc.append(weights[idx])
-            n_accepted += int(idx.sum())
-            if X_indices is not None:
-                I_acc.append(X_indices[idx])
-        if n_accepted > sober.thresh:
-            break
-    if n_accepted == 0:
-        sober.flag = True
-        X_cand, X_indices, weights = _draw(sober, n_rec)
-        return X_cand, X_indices, torch.ones(n_rec, dtype=weights.dtype, device=weights.device) / n_rec
-    weights = sober.cleansing_weights(torch.cat(w_acc).contiguous())
-    return torch.vstack(X_acc), (torch.vstack(I_acc) if I_acc else None), weights
-
-
-def sampling_candidates(sober, n_rec, n_nys, verbose=False):
-    """SOBER/_sampler.py:264-323 -> (X_cand, X_nys, weights)."""
-    assert n_rec > n_nys
-    X_cand, X_indices, weights = _draw(sober, n_rec)
-    if sober.check_weights(weights):
-        _update_prior(sober, X_indices if X_indices is not None else X_cand, weights)
-        sober.thresh = n_nys
-        X_cand, _, weights = _recursive_draws(sober, n_rec, sober.thresh)
-    else:
-        X_cand, X_indices, weights = _recursive_draws(sober, n_rec, sober.thresh)
-        if sober.flag:
-            return X_cand, X_cand[:n_nys], weights
-        _update_prior(sober, X_indices if X_indices is not None else X_cand, weights)
-        sober.thresh = n_nys
-        X_cand, _, weights = _recursive_draws(sober, n_rec, sober.thresh)
-    X_nys = sober.nystrom_subsample(X_cand, weights, n_nys)
-    sober.thresh = sober.thresh_initial
-    return X_cand, X_nys, weights
+"""Kept for callers of round 4's layout: the sampled-prior funnel lives in the package now
+(`sober_amd/_sampled_prior.py`) and is `sober_amd.Sober`'s default `candidate_funnel`."""
+from sober_amd._sampled_prior import sampling_candidates  # noqa: F401

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOBER_ABI_VERSION 4
+#define SOBER_ABI_VERSION 5
 
 /* kernel families: model.covar_module.forward behind SOBER/_gp.py:292-294 */
 #define SOBER_KIND_RBF       0   /* outputscale * exp(-0.5 * |x/l - y/l|^2)                      */
@@ -44,6 +44,10 @@ int sober_abi_version(void);
 /* 1 = a diagnostic build (in-kernel time stamps, -DSOBER_DIAG_BUILD: `make stamps`); sober_amd refuses to load one
  * unless SOBER_ALLOW_DIAG_LIB=1.  `make all` gives 0. */
 int sober_diag_build(void);
+/* The A/B and test switches of the environment (SOBER_LEVEL_TWO_LAUNCHES, SOBER_TANI_NO_QUEUE, SOBER_CAR_FORCE_GIVEUP,
+ * SOBER_CAR_UNFUSED, SOBER_CAR_NO_GRAM) are read ONCE, when the library is loaded; a process that changes one afterwards
+ * (the tests do) calls this to have them read again.  Returns 0.                                                    */
+int sober_reload_switches(void);
 /* sizeof(sober_level_job) / sizeof(sober_nystrom_job) as the library was built: a binding that lays the structs out itself
  * (ctypes, cgo, JNA ...) checks its own size against these before the first call.                                   */
 int sober_level_job_size(void);
@@ -231,8 +235,8 @@ int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in
  * The level loops below redo a level that came back with n_keep = -1 in SOBER_CAR_SAFE mode, set job->car_mode so
  * that the rest of the run (and, through the caller, the following steps) stay there, and only return
  * SOBER_E_EXCHANGE when that mode does not cover the size.
- * sober_car_giveup_forced() = 1 while the environment variable SOBER_CAR_FORCE_GIVEUP is set: the test switch that
- * makes every SOBER_CAR_DEFAULT launch give up (spin limit of one poll / reported give-up).                      */
+ * sober_car_giveup_forced() = 1 while the switch SOBER_CAR_FORCE_GIVEUP is on (environment, read at load time and by
+ * sober_reload_switches): the test switch that makes every SOBER_CAR_DEFAULT launch give up at once.              */
 #define SOBER_CAR_DEFAULT 0
 #define SOBER_CAR_SAFE 1
 int sober_car_safe_supported(int N, int m);
@@ -354,13 +358,15 @@ int sober_level_reduce_mfma_queued_pair(int kind, const double* rows, int n_rows
                                         const double* wmul, double outputscale, int n_chunks_ub, double* partG,
                                         int ldg, double* partTot, int n_xchunks_ub, double* extraG, double* extraTot,
                                         const int64_t* dR, void* stream);
-/* chunked = 1: the partial sums come from an element-chunk kernel (sober_level_reduce_tani_queued: sober_level_chunks
+/* chunked = 1: the partial sums come from the fingerprint kernel (sober_level_reduce_tani_queued: sober_level_chunks_tani
  * of them at the level's exact size), 0: from the matrix-core FP64 kernel (sober_level_parts_mfma slots per tile). */
 int sober_sum_partials_queued(const double* partG, const double* partTot, int n_rows, int ldg, int S,
                               const double* extraG, const double* extraTot, int n_xcols, double* G, int ldo,
                               double* tot, const int64_t* dR, int chunked, void* stream);
 /* The Tanimoto level kernel with the level size read from device memory (leftover = 0 / 1 like
- * sober_level_reduce_mfma_queued); n_chunks_ub = sober_level_chunks_cap(n_rows, ceil(count_ub / S), S). */
+ * sober_level_reduce_mfma_queued); n_chunks_ub >= sober_level_chunks_tani_cap(n_rows, ceil(count_ub / S), S) (the kernel
+ * and sober_sum_partials_queued(chunked = 1) derive the exact count from the level's size with the same formula;
+ * a smaller n_chunks_ub is SOBER_E_ARG).                                                                        */
 int sober_level_reduce_tani_queued(const void* rows, const double* rows_norm, int n_rows, const void* cand,
                                    const double* cand_norm, int dt, const int32_t* idx, int64_t count_ub, int S,
                                    int S_main, int leftover, const double* mu, const double* wmul, double outputscale,

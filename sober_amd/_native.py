@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SOBER_HIP_LIB: a diagnostic build of the same library, e.g. the in-kernel-stamp build `make stamps`)
 LIB_PATH = os.environ.get("SOBER_HIP_LIB") or os.path.join(_HERE, "libsober_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 KIND_RBF, KIND_MATERN52, KIND_TANIMOTO = 0, 1, 2
 KIND_BY_NAME = {"rbf": KIND_RBF, "matern52": KIND_MATERN52, "tanimoto": KIND_TANIMOTO}
@@ -26,6 +26,7 @@ _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
 SIGNATURES = {
     "sober_abi_version": (_i32, []),
     "sober_diag_build": (_i32, []),
+    "sober_reload_switches": (_i32, []),
     "sober_level_job_size": (_i32, []),
     "sober_nystrom_job_size": (_i32, []),
     "sober_final_job_size": (_i32, []),
@@ -214,15 +215,16 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `make -C sober_amd/csrc` "
             "(python -c 'import __graft_entry__ as g; g.build()').  sober_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    lib.sober_abi_version.restype = _i32
+    got = lib.sober_abi_version()                       # (first: a stale library says "rebuild", not AttributeError)
+    if got != ABI_VERSION:
+        raise SoberHipError(f"libsober_hip ABI {got} != expected {ABI_VERSION}; rebuild (make -C sober_amd/csrc)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype, fn.argtypes = res, args
     if lib.sober_diag_build() and os.environ.get("SOBER_ALLOW_DIAG_LIB") != "1":
         raise SoberHipError(f"{LIB_PATH} is a diagnostic build (in-kernel time stamps): not a library to compute with; "
                             "`make -C sober_amd/csrc` builds the product (SOBER_ALLOW_DIAG_LIB=1: the stamp scripts)")
-    got = lib.sober_abi_version()
-    if got != ABI_VERSION:
-        raise SoberHipError(f"libsober_hip ABI {got} != expected {ABI_VERSION}; rebuild")
     for name, cls in (("sober_level_job_size", LevelJob), ("sober_nystrom_job_size", NystromJob),
                       ("sober_final_job_size", FinalJob)):
         if getattr(lib, name)() != C.sizeof(cls):
@@ -230,6 +232,11 @@ def load() -> C.CDLL:
                                 "include/sober_hip.h and sober_amd/_native.py disagree")
     _lib = lib
     return lib
+
+
+def reload_switches():
+    """Have the library read its environment switches again (they are read once, at load time)."""
+    load().sober_reload_switches()
 
 
 def _check(rc: int, what: str):

@@ -33,10 +33,10 @@ class EmpiricalSampler(RecombinationSampler):
     fingerprints): candidates are the prior's available rows, their weights come from `pi` (sober_amd.PI for the
     LFI sampler), the heaviest are kept (`adaptive_pruning`), scrubbed (`cleansing_weights`) and a Nystrom sample is
     drawn with probability ~ 1 / weight (`deweighted_resampling`) -- everything on the device; `sampling_recombination`
-    then takes (X_cand, X_nys, weights).  The sampled-prior path (`sampling_candidates`, SOBER/_sampler.py:163-323: draws
-    from the prior, prior updates, WKDE refits) is candidate GENERATION -- SURVEY.md section 2: out of scope -- and stays
-    with the reference; of that block only `nystrom_subsample` (:316-320, contract row a10) lives here.
-    `examples/sampled_prior.py` shows the few lines that connect a sampled prior to `Sober.next_batch`."""
+    then takes (X_cand, X_nys, weights).  The sampled-prior path (`sampling_candidates`, SOBER/_sampler.py:163-323) keeps
+    the reference's control flow (`sober_amd/_sampled_prior.py`): the draws and densities are the prior object's, the
+    refit of the prior on the weighted sample (`_prior_update.py`, SURVEY.md section 2: out of scope) is the caller's
+    `prior_updater` hook, the Nystrom subsample at its end is `nystrom_subsample` (:316-320, contract row a10)."""
 
     def __init__(self, prior, pi, kernel, thresh=5, label="dataset", dataset_pruning=True, prior_updater=None):
         super().__init__(kernel, thresh=thresh)
@@ -54,6 +54,11 @@ class EmpiricalSampler(RecombinationSampler):
         if self.label == "continuous":
             return self.kmeans_resampling(X_cand, n_clusters=n_nys)
         return X_cand[self.deweighted_resampling(weights, n_nys)]
+
+    def sampling_candidates(self, n_rec, n_nys, verbose=False):
+        """SOBER/_sampler.py:264-323 -> (X_cand, X_nys, weights) for a continuous / mixed / categorical prior."""
+        from ._sampled_prior import sampling_candidates
+        return sampling_candidates(self, n_rec, n_nys, verbose)
 
     def sampling_datasets(self, n_rec, n_nys):
         """SOBER/_sampler.py:351-382 -> (idx_sampled, X_cand, X_nys, weights) with pruning, else (X_cand, X_nys,

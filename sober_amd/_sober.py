@@ -2,9 +2,9 @@
 path: pi = `sober_amd.PI` (LFI weights over the pool), kernel = `sober_amd.Kernel`, the candidate funnel of
 `sober_amd.EmpiricalSampler`, `sampling_recombination` -> HIP.  What the reference does AROUND the path stays with
 the reference: GP fitting, the FBGP / BQ model families (`PI_FBGP`, `PI_BQ`), prior updates and WKDE refits
-(`_prior_update.py`), and candidate GENERATION from a sampled prior (SOBER/_sampler.py:163-323).  A continuous/mixed
-prior therefore needs three hooks from the caller: `candidate_funnel` (`(sober, n_rec, n_nys, verbose) -> (X_cand, X_nys,
-weights)`: the reference's `sampling_candidates`; `examples/sampled_prior.py` is one), `prior_updater` (`(sampler, X,
+(`_prior_update.py`).  A continuous/mixed prior runs through `sampling_candidates` with the reference's control flow
+(`sober_amd/_sampled_prior.py`, the default; `candidate_funnel=(sober, n_rec, n_nys, verbose) -> (X_cand, X_nys, weights)`
+replaces it) and needs two hooks from the caller: `prior_updater` (`(sampler, X,
 weights) -> None`, e.g. the reference's `update_prior` bound to its own prior classes) and `prior_initialiser`
 (`(sampler) -> None`: what the reference's `initialise_prior`, SOBER/_sampler.py:87-111, does with its own prior
 classes); WHEN the prior is reset is decided here exactly like the reference (`should_reset_prior`).  The dataset prior
@@ -83,11 +83,10 @@ class Sober(EmpiricalSampler):
         self.prior_initialiser(self)
 
     def sampling_candidates(self, n_rec, n_nys, verbose=False):
-        """SOBER/_sampler.py:264-323 is candidate generation: the caller's `candidate_funnel` does it."""
+        """SOBER/_sampler.py:264-323: the caller's `candidate_funnel` if one was given, else the reference's control
+        flow (`EmpiricalSampler.sampling_candidates` -> sober_amd/_sampled_prior.py)."""
         if getattr(self, "candidate_funnel", None) is None:
-            raise NotImplementedError(
-                "a sampled prior needs Sober(..., candidate_funnel=callable(sober, n_rec, n_nys, verbose) -> (X_cand, X_nys, "
-                "weights)): the reference's own sampling_candidates, or examples/sampled_prior.py")
+            return super().sampling_candidates(n_rec, n_nys, verbose=verbose)
         return self.candidate_funnel(self, n_rec, n_nys, verbose)
 
     def next_batch(self, n_rec, n_nys, batch_size, calc_obj=None, return_weights=False, recycle_prior=True,

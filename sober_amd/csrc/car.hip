@@ -680,6 +680,7 @@ constexpr int SP_W = 16, SP_BC = 7, SP_RING = 32;
 
 #ifdef SP_TSTAMPS     // diagnostic build (scripts/pivot_stamps.py): s_memrealtime (100 MHz) of every publish, by pivot index
 __device__ unsigned long long g_sp_stamps[260];
+constexpr int SP_W_MAX_DBG = 16;   // (= SP_W)
 __device__ unsigned long long g_sp_seg[SP_W_MAX_DBG * 8];   // per wave: ticks summed by segment of the produce step
 #define SP_SEG(K, DEP_CONSTRAINT, DEP) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), DEP_CONSTRAINT(DEP) :: "memory"); \
         sp_seg_[K] += t_ - sp_last_; sp_last_ = t_; } while (0)
@@ -1055,10 +1056,10 @@ static int car_pivot_attr(size_t sp_bytes) {
     return 0;
 }
 
-// SOBER_CAR_FORCE_GIVEUP (any value, read at every call): the test switch that makes the launches which depend on
+// SOBER_CAR_FORCE_GIVEUP (any value; read when the library is loaded and by sober_reload_switches): the test switch that makes the launches which depend on
 // partner workgroups give up -- the fused launch's consumers give up at once (spin limit 0), the multi-CU route reports
 // n_keep = -1 -- so that the recovery of the callers can be exercised (tests/test_hip_parity.py).
-extern "C" int sober_car_giveup_forced(void) { return getenv("SOBER_CAR_FORCE_GIVEUP") != nullptr ? 1 : 0; }
+extern "C" int sober_car_giveup_forced(void) { return sober::switches().car_force_giveup ? 1 : 0; }
 
 extern "C" int sober_car_safe_supported(int N, int m) { return car_one_cu(N, m); }
 
@@ -1094,7 +1095,7 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
     double* vws = (double*)ws;
     double* taup = vws + (size_t)m * sober::CAR_NS;
     double* Phi = taup + 128;
-    static const bool unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;                // (same-box A/B of the fused launch)
+    const bool unfused = sober::switches().car_unfused;                                // (same-box A/B of the fused launch)
     const size_t sp_bytes = sizeof(sober::SpSlot) * sober::SP_RING + sober::SP_W * sizeof(int);
     { const int rc = car_pivot_attr(sp_bytes); if (rc != 0) return rc; }
     if (phi_out != nullptr || unfused || mode == SOBER_CAR_SAFE) {

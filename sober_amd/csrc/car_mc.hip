@@ -929,7 +929,7 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
     double* PhiT = taup + 256;
     unsigned long long* dbg = (unsigned long long*)(PhiT + (size_t)KMAX * NS);
     HIP_TRY(hipMemsetAsync(ws, 0, (size_t)cbytes, st));
-    static const bool unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;                // (A/B switch)
+    const bool unfused = sober::switches().car_unfused;                                // (A/B switch)
     const int fused = (phi_out == nullptr && !unfused) ? 1 : 0;
     const int G = fused ? FUSED_GRID : ELECT_GRID;
     const size_t pad = fused ? (size_t)FUSED_LDS_PAD : 0;             // (dynamic LDS nobody touches: one workgroup per CU)

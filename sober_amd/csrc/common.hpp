@@ -56,6 +56,8 @@ LaunchEvents& launch_events();                      // (thread-local, misc.hip)
         }                                                                                                   \
     } while (0)
 
+#include "switches.hpp"
+
 #define LAUNCH_CHECK()                                  \
     do {                                                \
         hipError_t _e = hipGetLastError();              \

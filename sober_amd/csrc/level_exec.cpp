@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "../../include/sober_hip.h"
+#include "switches.hpp"
 
 extern "C" int sober_level_job_size(void) { return (int)sizeof(sober_level_job); }
 
@@ -170,7 +171,7 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
             //  kernel finds the same zero from dR); otherwise both placements travel in one launch (matrix-core FP64
             //  kernel) or in two queued ones (Tanimoto)
             const bool no_left = Rlo[l] == Rub[l] && Rub[l] % S == 0;
-            if (tani && !no_left && !getenv("SOBER_LEVEL_TWO_LAUNCHES")) {
+            if (tani && !no_left && !sober::switches().level_two_launches) {
                 LX_TRY(sober_level_reduce_tani_queued_pair(j->rows, j->rows_norm, j->n_rows, j->cand, j->cand_norm, j->dim, cur,
                                                            Rub[l], S, SOBER_LEVEL_XS, j->mu, j->wmul, j->outputscale, nch,
                                                            j->partG, S, j->partTot, nxch, j->extraG, j->extraTot, j->dR + l,
@@ -186,7 +187,7 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
                                                           S - 1, SOBER_LEVEL_XS, S, 1, j->mu, j->wmul, j->outputscale, nxch,
                                                           j->extraG, SOBER_LEVEL_XS, j->extraTot, j->dR + l, stream));
                 }
-            } else if (no_left || getenv("SOBER_LEVEL_TWO_LAUNCHES")) {
+            } else if (no_left || sober::switches().level_two_launches) {
                 LX_TRY(sober_level_reduce_mfma_queued(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand,
                                                       j->dim, cur, Rub[l], S, S, 0, j->mu, j->wmul, j->outputscale, nch,
                                                       j->partG, S, j->partTot, j->dR + l, stream));
@@ -235,7 +236,7 @@ extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, i
     int32_t *cur = idx_a, *nxt = idx_b;
     int levels = 0;
     j->ev_used[0] = j->ev_used[1] = 0;
-    if (j->dR && j->h_dR && (j->variant == SOBER_LEVEL_MFMA || (j->variant == SOBER_LEVEL_TANI && !getenv("SOBER_TANI_NO_QUEUE")))) {
+    if (j->dR && j->h_dR && (j->variant == SOBER_LEVEL_MFMA || (j->variant == SOBER_LEVEL_TANI && !sober::switches().tani_no_queue))) {
         int done = 0;
         int64_t R_after = R;
         LX_TRY(lx_loop_queued(j, R, idx_a, idx_b, first_sums_ready, events, max_levels, level_R, &done, &R_after, stream));

@@ -346,7 +346,7 @@ extern "C" int sober_level_reduce_tani(const void* rows, const double* rows_norm
 }
 
 // queued form (see sober_level_loop): the level size is read from device memory; the launch is sized for count_ub
-// positions and n_chunks_ub chunks (sober_level_chunks_cap)
+// positions and n_chunks_ub chunks (>= sober_level_chunks_tani_cap: the kernel takes the exact count from the level's size)
 extern "C" int sober_level_reduce_tani_queued(const void* rows, const double* rows_norm, int n_rows, const void* cand,
                                               const double* cand_norm, int dt, const int32_t* idx, int64_t count_ub, int S,
                                               int S_main, int leftover, const double* mu, const double* wmul,
@@ -355,6 +355,7 @@ extern "C" int sober_level_reduce_tani_queued(const void* rows, const double* ro
     if (!rows || !rows_norm || !cand || !cand_norm || !idx || !mu || !partG || !dR) return SOBER_E_ARG;
     if (n_rows <= 0 || count_ub <= 0 || S <= 0 || S_main <= 0 || n_chunks_ub <= 0 || ldg < S || (!leftover && S != S_main))
         return SOBER_E_ARG;
+    if (n_chunks_ub < sober::level_chunks_tani_cap(n_rows, (count_ub + S - 1) / S, S)) return SOBER_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     switch (dt) {
         case 8: return launch_lt<8>(rows, rows_norm, n_rows, cand, cand_norm, idx, 0, count_ub, S, mu, wmul, outputscale,
@@ -376,6 +377,7 @@ extern "C" int sober_level_reduce_tani_queued_pair(const void* rows, const doubl
                                                    const int64_t* dR, void* stream) {
     if (!rows || !rows_norm || !cand || !cand_norm || !idx || !mu || !partG || !dR || !extraG || !extraTot) return SOBER_E_ARG;
     if (n_rows <= 0 || count_ub <= 0 || S <= 1 || n_xcols <= 0 || n_chunks_ub <= 0 || n_xchunks_ub <= 0 || ldg < S) return SOBER_E_ARG;
+    if (n_chunks_ub < sober::level_chunks_tani_cap(n_rows, (count_ub + S - 1) / S, S)) return SOBER_E_ARG;
     hipStream_t st = (hipStream_t)stream;
 #define LT_PAIR(T) launch_lt<T>(rows, rows_norm, n_rows, cand, cand_norm, idx, 0, count_ub, S, mu, wmul, outputscale, n_chunks_ub, \
                                 partG, ldg, 0, partTot, 0, st, dR, S, 2, n_xcols, n_xchunks_ub, extraG, n_xcols, extraTot)

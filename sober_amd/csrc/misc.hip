@@ -383,6 +383,7 @@ __global__ void k_wkde_draw(const double* __restrict__ eps, int64_t n, int d, co
 
 }  // namespace sober
 
+#include <cstdlib>
 using namespace sober;
 
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -397,6 +398,20 @@ extern "C" int sober_diag_build(void) {
 #endif
 }
 
+namespace sober {
+static Switches read_switches() {
+    Switches w;
+    w.level_two_launches = getenv("SOBER_LEVEL_TWO_LAUNCHES") != nullptr;
+    w.tani_no_queue = getenv("SOBER_TANI_NO_QUEUE") != nullptr;
+    w.car_force_giveup = getenv("SOBER_CAR_FORCE_GIVEUP") != nullptr;
+    w.car_unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;
+    w.car_no_gram = getenv("SOBER_CAR_NO_GRAM") != nullptr;
+    return w;
+}
+static Switches g_switches = read_switches();       // once, when the library is loaded
+const Switches& switches() { return g_switches; }
+}  // namespace sober
+extern "C" int sober_reload_switches(void) { sober::g_switches = sober::read_switches(); return 0; }
 namespace sober {
 LaunchEvents& launch_events() {
     static thread_local LaunchEvents le;

@@ -39,7 +39,7 @@ struct PeerComm {
     unsigned char** d_peers = nullptr;                // the table above, on the device
     unsigned epoch = 0;                               // calls made so far
     unsigned arrivals = 0;                            // workgroups launched so far (mod 2^32)
-    unsigned spin_limit = 1u << 27;                   // polls of one flag before giving up (~ 30 s; the set-up's self-check uses short waits)
+    unsigned spin_limit = 1u << 27;                   // polls before giving up = the wall-time budget of a call in 0.22 us units (~ 30 s; the set-up's self-check uses short waits)
     unsigned* h_err = nullptr;                        // the error word: pinned host memory the kernel writes (no copy to read it)
     bool connected = false;
 };
@@ -61,20 +61,36 @@ __global__ __launch_bounds__(256) void k_peer_allreduce(unsigned char* __restric
         const unsigned before = __hip_atomic_fetch_add(arr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (before + 1u == arrivals_target)                            // the whole message is in my slot
             __hip_atomic_store((unsigned*)mine, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        int ok = 1;
+        // A rank whose error word is already set (an earlier call of this communicator timed out) does not wait again:
+        // every all-reduce queued behind the failed one -- one per level -- returns at once instead of spinning W x 30 s more.
+        // The wait itself is bounded in WALL time (s_memrealtime, 100 MHz: spin_limit polls of ~0.22 us each, for all
+        // peers together) as well as in polls, and looks at the error word every 64 polls.
+        unsigned* errw = (unsigned*)(mine + PEER_OFF_ERR);
+        int ok = __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u ? 1 : 0;
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long budget = (unsigned long long)spin_limit * 22ull;
         for (int r = 0; r < W && ok; ++r) {
             const unsigned* pf = (const unsigned*)peers[r];
             unsigned spins = 0;
             while ((int)(__hip_atomic_load(pf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
                 if (++spins > spin_limit) { ok = 0; break; }
+                if ((spins & 63u) == 0u &&
+                    (__builtin_amdgcn_s_memrealtime() - t_start > budget ||
+                     __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
         }
         if (!ok) {
-            __hip_atomic_store((unsigned*)(mine + PEER_OFF_ERR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            // (the FIRST failing call's number: later calls queued behind it must not move the slot sober_peer_status restores from)
-            unsigned expect = 0u;
-            __hip_atomic_compare_exchange_strong(err_host, &expect, epoch | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const bool first = __hip_atomic_exchange(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u;
+            // (the FIRST failing call's number: later calls queued behind it must not move the slot sober_peer_status
+            //  restores from -- they leave above without waiting, and only the workgroup that SET the error word writes
+            //  the host's copy: a plain store, no PCIe atomic needed; workgroups of the same call write the same value)
+            if (first || *(volatile unsigned*)err_host == 0u) {
+                unsigned expect = 0u;
+                if (!__hip_atomic_compare_exchange_strong(err_host, &expect, epoch | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_SYSTEM) && first && expect == 0u)
+                    *(volatile unsigned*)err_host = epoch | 0x80000000u;
+            }
         }
         s_ok = ok;
     }
@@ -196,6 +212,8 @@ extern "C" int sober_peer_status(void* comm, double* restore, int64_t n, void* s
     const unsigned ew = *(volatile unsigned*)c->h_err;
     if (ew == 0u) return 0;
     *(volatile unsigned*)c->h_err = 0u;                                // (reported once; the flags themselves stay consistent)
+    // ... and the region's own error word, which makes calls queued behind a failed one return without waiting
+    HIP_TRY(hipMemsetAsync(c->mine + sober::PEER_OFF_ERR, 0, sizeof(unsigned), (hipStream_t)stream));
     if (restore && n > 0 && n <= c->n_max) {
         const double* slot = (const double*)(c->mine + sober::PEER_HDR) + (size_t)(ew & 1u) * (size_t)c->n_max;   // (the failing call's slot)
         HIP_TRY(hipMemcpyAsync(restore, slot, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream));

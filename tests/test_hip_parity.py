@@ -126,14 +126,22 @@ def test_bit_reproducible(dev):
     assert torch.equal(idx1, idx2) and torch.equal(w1, w2) and torch.equal(mu1, mu2)
 
 
+def _reload_switches():
+    """The library reads its environment switches once, at load time: tell it that one was flipped."""
+    from sober_amd import _native as nat
+    nat.reload_switches()
+
+
 def test_leftover_workgroups_in_the_main_launch_equal_two_launches(dev, monkeypatch):
     """Queued levels send the second placement of the leftovers (SOBER/_rchq.py:153-164) as extra workgroups of the
     main launch; SOBER_LEVEL_TWO_LAUNCHES=1 makes the two launches of before: same arithmetic, bit for bit."""
     for name in ("recomb_cfg2_rbf.npz", "recomb_rbf_medium.npz"):
         path = os.path.join(GOLD, name)
         monkeypatch.delenv("SOBER_LEVEL_TWO_LAUNCHES", raising=False)
+        _reload_switches()
         _, _, z, idx1, w1, mu1 = run_hip(path, dev)
         monkeypatch.setenv("SOBER_LEVEL_TWO_LAUNCHES", "1")
+        _reload_switches()
         _, _, _, idx2, w2, mu2 = run_hip(path, dev)
         assert torch.equal(idx1, idx2) and torch.equal(w1, w2) and torch.equal(mu1, mu2)
         assert np.array_equal(idx1.cpu().numpy(), z["idx"])
@@ -153,8 +161,10 @@ def test_fingerprint_levels_queued_equal_synchronised(dev, monkeypatch):
         for sync in (False, True):
             if sync:
                 monkeypatch.setenv("SOBER_TANI_NO_QUEUE", "1")
+                _reload_switches()
             else:
                 monkeypatch.delenv("SOBER_TANI_NO_QUEUE", raising=False)
+                _reload_switches()
             mu = _t(inp["mu0"].copy()).to(dev)
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
@@ -473,7 +483,7 @@ def test_sober_next_batch_vs_reference(dev):
                     assert a.dtype == torch.int64 and np.array_equal(a.cpu().numpy(), z[tag + "_first"]), tag
                 assert np.array_equal(Xb.cpu().numpy(), z[tag + "_X"]), tag
         c = MG.SOBER_CASES["continuous"]
-        from examples.sampled_prior import sampling_candidates            # (candidate generation: outside the package)
+        from sober_amd._sampled_prior import sampling_candidates
         sober = sober_amd.Sober(MG.UniformPrior(c["d"], device=dev), model_for(c), kernel_type=c["kernel_type"],
                                 candidate_funnel=sampling_candidates,
                                 prior_updater=lambda s, X, w: None)     # the fixture's stand-in keeps the prior too
@@ -765,6 +775,7 @@ def forced_giveup(monkeypatch, dev):
     from sober_amd import _native as nat
     from sober_amd._ops_hip import HipOps
     monkeypatch.setenv("SOBER_CAR_FORCE_GIVEUP", "1")
+    _reload_switches()
     assert nat.load().sober_car_giveup_forced() == 1
     return HipOps(dev)
 
@@ -826,6 +837,7 @@ def test_giveup_beyond_one_cu_goes_to_the_host_route(dev, forced_giveup):
     i1, w1, m1 = run(forced_giveup, t_forced)
     assert forced_giveup.car_mode == nat.CAR_HOST and "car_host" in t_forced
     os.environ.pop("SOBER_CAR_FORCE_GIVEUP")
+    _reload_switches()
     t_plain = {}
     i0, w0, m0 = run(HipOps(dev), t_plain)
     assert "car_host" not in t_plain

@@ -188,9 +188,8 @@ def test_sober_on_a_gpytorch_shaped_model_vs_reference_fixture():
     model = ExactGPModel(spec, scale=True)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        from examples.sampled_prior import sampling_candidates            # (candidate generation: outside the package)
         sober = sober_amd.Sober(MG.UniformPrior(c["d"], device=dev), model, kernel_type=c["kernel_type"],
-                                candidate_funnel=sampling_candidates, prior_updater=lambda s_, X, w: None)
+                                prior_updater=lambda s_, X, w: None)    # (default candidate_funnel: sober_amd/_sampled_prior.py)
         torch.manual_seed(c["seed_call"])
         Xb = sober.next_batch(c["n_rec"], c["n_nys"], c["batch"])
     assert np.array_equal(Xb.cpu().numpy(), z["continuous_X"])
