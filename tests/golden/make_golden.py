@@ -646,10 +646,31 @@ def gen_sober(ref):
     np.savez_compressed(os.path.join(HERE, "sober_next_batch.npz"), **out)
 
 
+def gen_kmeans_screened(ref):
+    """The reference's KMeans (SOBER/_weights.py:100-126) on shapes whose E step the device runs SCREENED by default
+    (BF16 matrix cores + exact FP64 re-check, csrc/kmeans.hip: N * ceil((d + 1) / 4) >= 300000): 120000 x 10 into 64
+    clusters -- the reference's (N, K, D) temporary is 614 MB --, once on the unit cube and once on the same pool moved
+    by 1e4 (the screen works on centred coordinates).  Only the seed, the labels (one byte each) and the centroids are
+    stored."""
+    KMeans = ref["_weights"].KMeans
+    out = {}
+    N, d, K, seed = 120000, 10, 64, 321
+    x = np.random.default_rng(seed).random((N, d))
+    for tag, off in (("unit", 0.0), ("offset", 1e4)):
+        xv = x + off
+        cl, c = KMeans(torch.from_numpy(xv.copy()), K=K)
+        out.update({f"{tag}_off": off, f"{tag}_cl": cl.numpy().astype(np.uint8), f"{tag}_c": c.numpy(),
+                    f"{tag}_cks_x": checksum(xv)})
+        print("kmeans_screened", tag, "cluster sizes", np.bincount(cl.numpy(), minlength=K).min(), "...",
+              np.bincount(cl.numpy(), minlength=K).max())
+    out.update(seed=seed, N=N, d=d, K=K)
+    np.savez_compressed(os.path.join(HERE, "kmeans_screened.npz"), **out)
+
+
 if __name__ == "__main__":
-    # python make_golden.py [recombination kmeans weights psd tanimoto kernel_calls pi wkde basq pruning sober]   (default: all)
+    # python make_golden.py [recombination kmeans kmeans_screened weights psd tanimoto kernel_calls pi wkde basq pruning sober]   (default: all)
     ref = load_reference()
-    gens = {"recombination": gen_recombination, "kmeans": gen_kmeans, "weights": gen_weights, "psd": gen_psd,
+    gens = {"recombination": gen_recombination, "kmeans": gen_kmeans, "kmeans_screened": gen_kmeans_screened, "weights": gen_weights, "psd": gen_psd,
             "tanimoto": lambda ref: gen_tanimoto(), "kernel_calls": gen_kernel_calls, "pi": gen_pi,
             "wkde": gen_wkde, "basq": gen_basq, "pruning": gen_pruning, "sober": gen_sober, "d1": gen_d1_sensitivity}
     for name in (sys.argv[1:] or list(gens)):

@@ -50,8 +50,8 @@ def test_fuzz_slice_vs_oracle(dev):
     and the multi-CU ones, leftovers of every kind, three modes, calc_obj in a quarter) and 10 fingerprint ones, device
     against oracle on the same seeded inputs.  Bar per case: identical indices and weights within 1e-6, or the case is
     ill-posed IN THE REFERENCE (its own indices change / its own weights move by > 1e-5 when its inputs move by one ulp --
-    the oracle is held to the reference on 64 random cases by tests/test_oracle_vs_reference_fuzz.py).  At most a fifth
-    of the slice may be ill-posed: the classifier is not a way out."""
+    the oracle is held to the reference on 64 random cases by tests/test_oracle_vs_reference_fuzz.py).  At most a tenth
+    of the slice may be ill-posed (observed over the 770-case sweep: 4 %): the classifier is not a way out."""
     from tests.tools import fuzz_parity as F
     bad, ill, lines = [], 0, []
     for tani, n, seed in ((False, 30, 2026), (True, 10, 2027)):
@@ -65,7 +65,7 @@ def test_fuzz_slice_vs_oracle(dev):
                 bad.append(lines[-1])
     print("\n".join(lines))
     assert not bad, bad
-    assert ill <= 8, (ill, [ln for ln in lines if "ill-posed" in ln])
+    assert ill <= 4, (ill, [ln for ln in lines if "ill-posed" in ln])
 
 
 # --------------------------------------------------------------------------- #

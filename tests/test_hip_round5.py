@@ -1,0 +1,44 @@
+"""GPU tests added in round 5 (run with -m gpu on an MI355X), all through the C ABI:
+  * the SHIPPED KMeans path (E step screened on the BF16 matrix cores, the default at cfg-2 / cfg-4 shapes) against labels
+    and centroids the REFERENCE's own KMeans produced on such a shape (tests/golden/kmeans_screened.npz), not only against
+    the device's exact kernel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sober_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the -m gpu tests need the MI355X"
+    from sober_amd import _native
+    _native.load()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("tag", ["unit", "offset"])
+def test_kmeans_screened_default_path_vs_reference(tag, dev):
+    """SOBER/_weights.py:100-126 at 120000 x 10 into 64 clusters (the reference's (N, K, D) temporary: 614 MB), unit cube
+    and the same pool moved by 1e4: `sober_amd.KMeans` takes the screened E step by default here
+    (sober_kmeans_ws_bytes asks for the screen's workspace from N * ceil((d + 1) / 4) >= 300000 on) -- labels bit-equal
+    to the reference's, centroids to 1e-11."""
+    from sober_amd import _native as nat
+    z = np.load(os.path.join(GOLD, "kmeans_screened.npz"))
+    N, d, K = int(z["N"]), int(z["d"]), int(z["K"])
+    lib = nat.load()
+    assert lib.sober_kmeans_ws_bytes(N, d, K) == lib.sober_kmeans_ws_bytes_screened(N, d, K) > 0     # the screen IS the default here
+    x = np.random.default_rng(int(z["seed"])).random((N, d)) + float(z[f"{tag}_off"])
+    cl, c = sober_amd.KMeans(_t(x).to(dev), K=K)
+    assert np.array_equal(cl.cpu().numpy().astype(np.uint8), z[f"{tag}_cl"])
+    np.testing.assert_allclose(c.cpu().numpy(), z[f"{tag}_c"], rtol=1e-11)

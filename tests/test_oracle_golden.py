@@ -145,6 +145,17 @@ def test_kmeans_matches_reference():
     assert np.array_equal(cl2.numpy(), z["a_cl"]) and np.array_equal(c2.numpy(), z["a_c"])
 
 
+def test_kmeans_screened_shape_matches_reference():
+    """The oracle's KMeans on the shape whose E step the device runs screened by default (tests/golden/kmeans_screened.npz:
+    the reference's own labels and centroids at 120000 x 10 x 64, unit cube and the same pool at offset 1e4)."""
+    z = np.load(os.path.join(GOLD, "kmeans_screened.npz"))
+    x = np.random.default_rng(int(z["seed"])).random((int(z["N"]), int(z["d"])))
+    for tag in ("unit", "offset"):
+        cl, c = O.kmeans_chunked(_t(x + float(z[f"{tag}_off"])), K=int(z["K"]), chunk=8192)
+        assert np.array_equal(cl.numpy().astype(np.uint8), z[f"{tag}_cl"])
+        np.testing.assert_allclose(c.numpy(), z[f"{tag}_c"], rtol=1e-13)
+
+
 def test_weights_match_reference():
     z = np.load(os.path.join(GOLD, "weights.npz"))
     assert float(z["eps"]) == O.EPS_WEIGHTS                # Q5: FP32 eps even in FP64
