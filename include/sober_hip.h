@@ -45,7 +45,7 @@ int sober_abi_version(void);
  * unless SOBER_ALLOW_DIAG_LIB=1.  `make all` gives 0. */
 int sober_diag_build(void);
 /* The A/B and test switches of the environment (SOBER_LEVEL_TWO_LAUNCHES, SOBER_TANI_NO_QUEUE, SOBER_CAR_FORCE_GIVEUP,
- * SOBER_CAR_UNFUSED, SOBER_CAR_NO_GRAM) are read ONCE, when the library is loaded; a process that changes one afterwards
+ * SOBER_CAR_UNFUSED, SOBER_CAR_GRAM) are read ONCE, when the library is loaded; a process that changes one afterwards
  * (the tests do) calls this to have them read again.  Returns 0.                                                    */
 int sober_reload_switches(void);
 /* sizeof(sober_level_job) / sizeof(sober_nystrom_job) as the library was built: a binding that lays the structs out itself

@@ -10,7 +10,7 @@
 // are no switches that change RESULTS: the timing-only experiments of rounds 2-3 are out of the source (their numbers:
 // profiles/r03_bidiag_where.txt).
 #if (defined(CAR_BSTAMPS) || defined(SP_TSTAMPS) || defined(MC_STAMPS) || defined(MC_TSTAMPS) || defined(CM_STAMPS) || \
-     defined(CH_STAMPS) || defined(LW_STAMPS)) && !defined(SOBER_DIAG_BUILD)
+     defined(CH_STAMPS) || defined(LW_STAMPS) || defined(CG_STAMPS)) && !defined(SOBER_DIAG_BUILD)
 #error "in-kernel stamps are diagnostic builds: make stamps, or EXTRA='-DSOBER_DIAG_BUILD -D..._STAMPS' with a BUILD/OUT of its own"
 #endif
 

@@ -405,7 +405,7 @@ static Switches read_switches() {
     w.tani_no_queue = getenv("SOBER_TANI_NO_QUEUE") != nullptr;
     w.car_force_giveup = getenv("SOBER_CAR_FORCE_GIVEUP") != nullptr;
     w.car_unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;
-    w.car_no_gram = getenv("SOBER_CAR_NO_GRAM") != nullptr;
+    w.car_gram = getenv("SOBER_CAR_GRAM") != nullptr;
     return w;
 }
 static Switches g_switches = read_switches();       // once, when the library is loaded

@@ -42,3 +42,45 @@ def test_kmeans_screened_default_path_vs_reference(tag, dev):
     cl, c = sober_amd.KMeans(_t(x).to(dev), K=K)
     assert np.array_equal(cl.cpu().numpy().astype(np.uint8), z[f"{tag}_cl"])
     np.testing.assert_allclose(c.cpu().numpy(), z[f"{tag}_c"], rtol=1e-11)
+
+
+def test_gram_route_of_the_caratheodory_step_on_reference_levels(dev, monkeypatch):
+    """SOBER_CAR_GRAM=1 (opt-in, csrc/car_gram.inc): the Caratheodory step's reflectors by way of G = A A^T -- Householder
+    tridiagonalisation, P1 = (B^-1 Q^T A)^T, Householder reconstruction by a sign-choosing LU -- instead of the
+    bidiagonalisation.  On the reference's own level inputs (every golden with stored levels, batch 8 .. 100): the same
+    kept sets as the default route and as the golden, weights to 1e-8 of the largest."""
+    import glob
+    from sober_amd import _native as nat
+    n_checked = 0
+    for p in sorted(glob.glob(os.path.join(GOLD, "recomb_*.npz"))):
+        z = np.load(p)
+        if "L0_X_tmp" not in z.files:
+            continue
+        for i in range(int(z["n_levels"])):
+            X, mu = _t(z[f"L{i}_X_tmp"]).to(dev), _t(z[f"L{i}_tot_weights"]).to(dev)
+            N, n = X.shape
+            if n + 1 >= N or not nat.car_safe_supported(N, n + 1):
+                continue
+            out = []
+            for gram in (False, True):
+                if gram:
+                    monkeypatch.setenv("SOBER_CAR_GRAM", "1")
+                else:
+                    monkeypatch.delenv("SOBER_CAR_GRAM", raising=False)
+                nat.reload_switches()
+                keep = torch.empty(N + 1, dtype=torch.int32, device=dev)
+                w = torch.zeros(N, dtype=torch.float64, device=dev)
+                mo = torch.empty(N, dtype=torch.float64, device=dev)
+                nat.car_device(X, mu, keep, w, keep[N:], mo)
+                nk = int(keep[N].item())
+                assert nk > 0, (p, i, gram)
+                out.append((np.flatnonzero(keep[:N].cpu().numpy() >= 0), w[:nk].cpu().numpy()))
+            (k0, w0), (k1, w1) = out
+            if "calc_obj" not in p:
+                assert np.array_equal(k0, z[f"L{i}_idx_star"]), (p, i)
+            assert np.array_equal(k0, k1), (p, i)
+            assert np.abs(w1 - w0).max() <= 1e-8 * np.abs(w0).max(), (p, i)
+            n_checked += 1
+    monkeypatch.delenv("SOBER_CAR_GRAM", raising=False)
+    nat.reload_switches()
+    assert n_checked >= 50
