@@ -13,6 +13,11 @@ configuration (default 2, the one the metric is quoted on):
   3  Hartmann-shaped d=6  Matern-5/2     N_rec=50k   N_nys=500  batch=200
   4  Rosenbrock      d=20 RBF            N_rec=1M    N_nys=500  batch=100   (the 8-GPU configuration)
   5  Malaria-shaped  2048-bit Tanimoto   N_rec=250k  N_nys=500  batch=100   (weighted posterior covariance)
+  6  big pool        d=20 RBF            N_rec=8M    N_nys=500  batch=100   (not a BASELINE.json configuration: the throughput
+                                                                              regime on one GPU; parity by invariants)
+`--funnel` (one GPU, configuration 2's shapes): the ACQUISITION step as a user of `Sober.next_batch` sees it -- pi weights over
+the pool, cleansing_weights, the KMeans Nystrom subsample, sampling_recombination (SOBER/_sober.py:125-195,
+_sampler.py:264-323) -- with per-phase ms and the oracle's same funnel on the host cores beside it.
 N > 1: one rank per GPU over RCCL, the pool row-sharded, one small all-reduce per level.  Configurations 1-3 and 5
 scale WEAKLY (every rank owns a full-size shard, one recombination over the N-fold pool); configuration 4 is the
 reference's 8-GPU case and scales STRONGLY (the 1M-row pool is split N ways: 125k rows per GPU at N = 8).
@@ -56,6 +61,11 @@ CONFIGS = {
     5: dict(kind="tanimoto", mode="weighted_predictive_covariance", N=250000, M=500, d=2048, b=100, n_obs=200,
             seed=10, bit_p=0.04, mean_const=0.3, name="Malaria-shaped 2048-bit Tanimoto weighted posterior covariance",
             cpu_sample_N=20000),
+    # beyond BASELINE.json: the throughput regime (one GPU, the level kernel is nearly all of the step) -- the pool is
+    # generated on the device, parity by the result's invariants (no CPU reference at this size in bench time)
+    6: dict(kind="rbf", mode="predictive_covariance", N=8000000, M=500, d=20, b=100, n_obs=200, seed=0,
+            name="big pool d=20 RBF posterior covariance (beyond BASELINE.json: the throughput regime)",
+            cpu_sample_N=100000, device_pool=True),
 }
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector = FP64 matrix (vendor)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
@@ -111,7 +121,7 @@ def t(a):
 
 def build_inputs(cfg, rank, world, dev):
     """-> (X_cand, X_nys, mu0 on the device, spec, host inputs or None, rows on this rank)."""
-    case = {k: v for k, v in cfg.items() if k not in ("name", "golden", "strong", "cpu_sample_N")}
+    case = {k: v for k, v in cfg.items() if k not in ("name", "golden", "strong", "cpu_sample_N", "device_pool")}
     N_loc = case["N"] // world if cfg.get("strong") else case["N"]
     if cfg["kind"] == "tanimoto":
         # 250k x 2048 FP64 0/1 = 4 GB: built on the device; the GP side (observations, caches) from the small stream
@@ -129,6 +139,18 @@ def build_inputs(cfg, rank, world, dev):
         mu0 = torch.rand(N_loc, device=dev, generator=g, dtype=torch.float64)
         mu0 /= mu0.sum() * world
         return X, Xn, mu0, spec, None, N_loc
+    if cfg.get("device_pool"):
+        small = dict(case, N=max(cfg.get("cpu_sample_N", 100000), case["M"] + 1000))
+        small.pop("device_pool", None)
+        base = synth(small)
+        spec = build_spec(small, base)
+        g = torch.Generator(device=dev)
+        g.manual_seed(case["seed"] + 1 + rank)
+        X = torch.rand(N_loc, case["d"], generator=g, dtype=torch.float64, device=dev)
+        X[:small["N"]] = t(base["X_cand"]).to(dev)                   # (the head of the pool: what the CPU sample runs on)
+        mu0 = torch.rand(N_loc, generator=g, dtype=torch.float64, device=dev)
+        mu0 /= mu0.sum() * world
+        return X, t(base["X_nys"]).to(dev), mu0, spec, None, N_loc
     shard = dict(case, N=N_loc, seed=case["seed"] + rank)            # every rank synthesises its own shard
     inp = synth(shard)
     base = synth(dict(case, N=N_loc)) if rank else inp               # X_nys / X_obs come from rank 0's stream
@@ -180,6 +202,183 @@ def cpu_baseline_for(cfg, spec, inp, dev_inputs, cpu_steps):
                         "8 threads and at half the host's hardware threads; fastest reported"}
 
 
+class _PoolPrior:
+    """A continuous prior whose draw IS the resident synthetic pool (density 1 on the unit cube): `Sober.next_batch` then
+    runs the reference's sampled-prior control flow (SOBER/_sampler.py:264-323) on device-resident candidates."""
+    type = "continuous"
+
+    def __init__(self, X):
+        self.X, self.n_dims = X, X.shape[1]
+
+    def sample(self, n):
+        return self.X[:n]
+
+    def pdf(self, X):
+        return torch.ones(len(X), dtype=X.dtype, device=X.device)
+
+
+class _Model:
+    """What `sober_amd.Sober` touches of an exact-GP model when the kernel specification is given directly."""
+
+    def __init__(self, kernel_spec, n_obs):
+        self.kernel_spec = kernel_spec
+        self.train_targets = torch.zeros(n_obs, dtype=torch.double)
+
+
+def funnel(args):
+    """`bench.py --funnel`: one acquisition step = `Sober.next_batch(n_rec, n_nys, batch)` on a continuous prior at
+    configuration 2's shapes, device-resident; phases timed with a synchronisation either side (a second, unbracketed run
+    gives ms_per_step); the oracle's same funnel on the host cores as cpu_baseline; parity: the fixture of the reference's
+    own `Sober.next_batch` (tests/golden/sober_next_batch.npz) and the batch against the oracle's funnel at this size."""
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1, "--funnel is a one-GPU line"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    cfg = CONFIGS[2]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    X_cand, X_nys0, mu0, spec, inp, N = build_inputs(cfg, 0, 1, dev)
+    ks = sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs, spec.S_cache,
+                              spec.noise, spec.mean_const, spec.alpha)
+    sober_amd.setting_parameters(device=dev, dtype=torch.double)
+    M, b = cfg["M"], cfg["b"]
+
+    def make():
+        return sober_amd.Sober(_PoolPrior(X_cand), _Model(ks, cfg["n_obs"]), kernel_type=cfg["mode"],
+                               prior_updater=lambda s_, X, w: None)
+
+    def next_batch(sob):
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return sob.next_batch(N, M, b, return_weights=True)
+
+    sob = make()
+    for _ in range(max(args.warmup, 3)):
+        w_b, X_b = next_batch(sob)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w_b, X_b = next_batch(sob)
+    torch.cuda.synchronize()
+    ms_per_step = (time.perf_counter() - t0) / args.steps * 1e3
+    # per phase: the four calls bracketed by synchronisations
+    phases = {"pi_weights": 0.0, "cleansing_weights": 0.0, "kmeans_resampling": 0.0, "sampling_recombination": 0.0}
+    calls = {k: 0 for k in phases}
+
+    class bracket:                                                   # (keeps the wrapped object's attributes: Sober reads pi.model)
+        def __init__(self, name, fn):
+            self._name, self._fn = name, fn
+
+        def __getattr__(self, attr):
+            return getattr(self._fn, attr)
+
+        def __call__(self, *a, **k):
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            out = self._fn(*a, **k)
+            torch.cuda.synchronize()
+            phases[self._name] += time.perf_counter() - c0
+            calls[self._name] += 1
+            return out
+    sob2 = make()
+    sob2.pi = bracket("pi_weights", sob2.pi)
+    sob2.cleansing_weights = bracket("cleansing_weights", sob2.cleansing_weights)
+    sob2.kmeans_resampling = bracket("kmeans_resampling", sob2.kmeans_resampling)
+    sob2.sampling_recombination = bracket("sampling_recombination", sob2.sampling_recombination)
+    next_batch(sob2)
+    for k in phases:
+        phases[k], calls[k] = 0.0, 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        next_batch(sob2)
+    torch.cuda.synchronize()
+    ms_bracketed = (time.perf_counter() - t0) / args.steps * 1e3
+    phases_ms = {k: v / args.steps * 1e3 for k, v in phases.items()}
+    phases_ms["other (draws, checks, gathers, host)"] = ms_bracketed - sum(phases_ms.values())
+    # the oracle's same funnel (SOBER/_sampler.py:264-323 with the updater a no-op): once, on the host cores
+    cpu = None
+    parity = {}
+    if not args.no_cpu_baseline:
+        from oracle import sober_oracle as O
+        Xh = t(inp["X_cand"])
+        cph = {}
+        old_threads = torch.get_num_threads()
+        torch.set_num_threads(8)
+
+        def timed(name, fn):
+            c0 = time.perf_counter()
+            out = fn()
+            cph[name] = cph.get(name, 0.0) + (time.perf_counter() - c0) * 1e3
+            return out
+        # the reference's control flow (sober_amd/_sampled_prior.py restates SOBER/_sampler.py:264-323) over the ORACLE's
+        # arithmetic: pi, cleansing_weights, check_weights, KMeans, recombination all from oracle/sober_oracle.py
+        from sober_amd._sampled_prior import sampling_candidates
+
+        class _OracleSober:
+            label, thresh, thresh_initial, flag, prior_updater = "continuous", 5, 5, False, staticmethod(lambda s_, X, w: None)
+
+            def __init__(self):
+                self.prior = _PoolPrior(Xh)
+                opi = O.PI(spec)
+                self.pi = lambda X: timed("pi_weights", lambda: opi(X))
+
+            def cleansing_weights(self, w):
+                return timed("cleansing_weights", lambda: O.cleansing_weights(w))
+
+            def check_weights(self, w):
+                return O.check_weights(w, self.thresh)
+
+            def nystrom_subsample(self, X, w, n):
+                return timed("kmeans_resampling", lambda: O.kmeans_chunked(X, K=n, Niter=10)[1])
+        c_all = time.perf_counter()
+        Xc_ref, Xn_ref, wts = sampling_candidates(_OracleSober(), N, M)
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx_ref, w_ref = timed("sampling_recombination", lambda: O.recombination(
+                Xc_ref, Xn_ref, b, O.Kernel(spec, cfg["mode"]), init_weights=wts, stream_elements=16))
+        cpu_ms = (time.perf_counter() - c_all) * 1e3
+        torch.set_num_threads(old_threads)
+        cpu = {"value": N / (cpu_ms * 1e-3), "unit": "candidates/s", "cores": 8, "kind": "port", "ms_per_step": cpu_ms,
+               "phases_ms_per_step": cph, "host": host_cpu(),
+               "sample": "one acquisition step on the full workload (100k candidates): pi weights + cleansing twice, chunked KMeans "
+                         "(10 Lloyd iterations, 500 clusters), streaming recombination; oracle = torch CPU FP64 port of the reference"}
+        Xb_ref = Xc_ref[idx_ref]
+        same = bool(X_b.shape == Xb_ref.shape and torch.equal(X_b.cpu(), Xb_ref))
+        parity["batch_equal_oracle_funnel"] = same
+        parity["max_rel_w_vs_oracle_funnel"] = float(((w_b.cpu() - w_ref).abs() / w_ref.abs()).max()) if same else None
+    # the reference's own Sober.next_batch (fixture): the sampled-prior return shape, bit for bit
+    try:
+        from tests.golden import make_golden as MG
+        z = np.load(os.path.join(ROOT, "tests", "golden", "sober_next_batch.npz"))
+        c = MG.SOBER_CASES["continuous"]
+        model, fspec = MG.sober_model(c)
+        model.kernel_spec = sober_amd.KernelSpec(fspec.kind, fspec.lengthscale, fspec.outputscale, fspec.X_obs, fspec.S_cache,
+                                                 fspec.noise, fspec.mean_const, fspec.alpha)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sf = sober_amd.Sober(MG.UniformPrior(c["d"], device=dev), model, kernel_type=c["kernel_type"],
+                                 prior_updater=lambda s_, X, w: None)
+            torch.manual_seed(c["seed_call"])
+            Xf = sf.next_batch(c["n_rec"], c["n_nys"], c["batch"])
+        parity["reference_fixture_sober_next_batch_equal"] = bool(np.array_equal(Xf.cpu().numpy(), z["continuous_X"]))
+    except Exception as e:                                              # noqa: BLE001
+        parity["reference_fixture_sober_next_batch_equal"] = f"not run: {type(e).__name__}: {e}"
+    out = {
+        "metric": f"acquisition-step candidates/sec (Sober.next_batch: N_rec={N}, N_nys={M}, d={cfg['d']}, batch={b})",
+        "value": N / (ms_per_step * 1e-3), "unit": "candidates/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": max(args.warmup, 3), "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Sober.next_batch on a continuous prior, {cfg['name']}, n_rec={N}, n_nys={M}, batch={b}, "
+                               f"n_obs={cfg['n_obs']} (BASELINE.json configs[1] shapes; SOBER/_sober.py:125-195)",
+                   "parallelism": "single GPU"},
+        "phases_ms_per_step": phases_ms, "phase_calls_per_step": {k: v / args.steps for k, v in calls.items()},
+        "ms_per_step_with_phase_brackets": ms_bracketed,
+        "cpu_baseline": cpu, "parity": parity, "n_selected": int(X_b.shape[0]),
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +391,9 @@ def main():
                     help="the level launches of every n-th timed step carry the HIP event pairs behind roofline.achieved "
                          "(an event-carrying dispatch costs the stream 10-20 us: on every step that is +0.1-0.2 ms at "
                          "configuration 2, profiles/r03_event_cost.txt); 1 = every step")
+    ap.add_argument("--funnel", action="store_true",
+                    help="one GPU: time `Sober.next_batch` (pi weights -> cleansing_weights -> KMeans Nystrom subsample -> "
+                         "sampling_recombination) at configuration 2's shapes instead of the recombination step alone")
     ap.add_argument("--no-sweep", action="store_true", help="skip the n_obs sweep of SURVEY.md 8(d) (configuration 2, one GPU)")
     ap.add_argument("--check-unsharded", action="store_true",
                     help="N > 1: rank 0 gathers every shard and repeats the step UNSHARDED on its one GPU (outside the timed "
@@ -199,6 +401,8 @@ def main():
                          "tests/test_hip_round4.py, not for pools that do not fit one GPU")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.funnel:
+        return funnel(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -376,6 +580,18 @@ def main():
         relw = float(np.max(np.abs(w.cpu().numpy() - z["w"]) / np.abs(z["w"]))) if same else None
         parity = {"idx_equal_reference": same, "max_rel_w_vs_reference": relw}
 
+    if world == 1 and parity is None:
+        # no full-size reference in bench time: the result's invariants and run-to-run bit equality
+        ii, ww = idx.cpu().numpy(), w.cpu().numpy()
+        mu_after = mu.clone()
+        idx2, w2 = step()
+        dense = torch.zeros_like(mu0)
+        dense[idx] = w
+        parity = {"by": "invariants", "n_selected_le_batch": bool(0 < len(ii) <= b), "weights_positive": bool((ww > 0).all()),
+                  "mass_error": float(abs(ww.sum() - float(mu0.sum()))), "indices_ascending_in_pool": bool(
+                      (np.diff(ii) > 0).all() and ii.min() >= 0 and ii.max() < N_loc),
+                  "init_weights_hold_the_result": bool(torch.equal(mu_after, dense)),
+                  "bit_equal_run_to_run": bool(torch.equal(idx2, idx) and torch.equal(w2, w))}
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline = cpu_baseline_for(cfg, spec, inp, (X_cand, X_nys, mu0), args.cpu_steps)

@@ -310,6 +310,7 @@ class HipOps:
         j.G, j.chol_work = G.data_ptr(), work.data_ptr()
         # (eight workgroups per rung from a few panels on: 0.49 -> 0.16 ms at M = 500; a rung whose workgroups lost each
         #  other reports PROBE_NO_VERDICT and the step goes to the host route, this process then stays with one each)
+        j.no_skip = 1 if os.environ.get("SOBER_NYSTROM_NO_SKIP") else 0     # (A/B: every intermediate CholeskyQR pass taken)
         j.probe_mc = 1 if (M >= self.PROBE_MC_MIN and n_r <= 16 and self._probe_mc and M <= nat.chol_max_n()) else 0
         if j.probe_mc:
             pws = self._buf_u8(p, "chol_mc_ws", nat.cholesky_probe_mc_ws_bytes(M, n_r))

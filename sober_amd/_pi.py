@@ -5,9 +5,13 @@
     var(x)  = k(x, x) - k(x, X_obs) W k(X_obs, x) + noise          (exact GP; LOVE is upstream-only)
     pi(x)   = Phi((mean(x) - eta) / sqrt(var(x))),   eta = max_i mean(X_obs_i)
 
-The pool is processed in column chunks: KX = k(X_obs, chunk) by `sober_pairwise`, V = W KX on the
-FP64 matrix cores (`sober_dgemm`), the column-wise quadratic form and Phi in `sober_predict_finish`.
+One launch per chunk of the pool (`sober_predict_fused`, csrc/predict.hip; n_obs <= 256): the K(X_obs, x) columns of 32
+candidates are evaluated once into LDS, W k runs on the FP64 matrix cores, mean / variance / pi leave the kernel --
+nothing of size n_obs x N is ever in memory.  Beyond 256 observations (or an input dimension outside the register-tiled
+set) the materialised route of round 4 stays: KX = k(X_obs, chunk) by `sober_pairwise`, V = W KX (`sober_dgemm`), the
+column-wise quadratic form and Phi in `sober_predict_finish`.
 """
+import os
 import math
 
 import torch
@@ -36,10 +40,17 @@ def _predict(spec, X, eta=None, log=False):
     mean = torch.empty(N, dtype=torch.float64, device=dev)
     var = torch.empty(N, dtype=torch.float64, device=dev)
     lfi = torch.empty(N, dtype=torch.float64, device=dev) if eta is not None else None
+    fused = (nat.predict_fused_supported(kind, n_obs, pobs.dt) and spec.alpha is not None
+             and nat.fused_dim_supported(kind, spec.X_obs.shape[1]) and not os.environ.get("SOBER_PREDICT_MATERIALISED"))
     for lo in range(0, N, CHUNK):
         hi = min(N, lo + CHUNK)
         pts = prepare_points(spec, X[lo:hi])
         n = hi - lo
+        if fused:
+            nat.predict_fused(kind, pobs.data, pobs.norm, pts.data, pts.norm, n, pts.dt, spec.outputscale, W, spec.alpha,
+                              spec.mean_const, _kxx_const(spec), spec.noise, mean[lo:hi], var[lo:hi],
+                              0.0 if eta is None else eta, None if lfi is None else lfi[lo:hi], log)
+            continue
         mean[lo:hi] = posterior_mean(spec, pts)
         KX = torch.empty(n_obs, n, dtype=torch.float64, device=dev)
         nat.pairwise(kind, pobs.data, pobs.norm, pts.data, pts.norm, None, n, pts.dt, spec.outputscale, KX)

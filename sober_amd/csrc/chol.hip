@@ -142,8 +142,17 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
                                               int32_t* __restrict__ info, double* __restrict__ min_pivot,
                                               const double* __restrict__ src, int lds_src,
                                               const double* __restrict__ shifts, double* __restrict__ xout,
-                                              double* __restrict__ ratio_out) {
+                                              double* __restrict__ ratio_out, const double* __restrict__ skip_if,
+                                              double skip_thr) {
     extern __shared__ double lds[];
+    if (skip_if != nullptr && *skip_if >= skip_thr) {       // guarded form (sober_cholesky_inv_ratio_if): this factorisation is
+        if (threadIdx.x == 0 && blockIdx.x == 0) {           // not needed -- leave the verdicts of a perfect one behind
+            info[0] = 0;
+            if (min_pivot) min_pivot[0] = 1.0;
+            if (ratio_out) ratio_out[0] = 1.0;
+        }
+        return;
+    }
     if (src != nullptr) {                     // batched: copy the lower triangle into my slab first
         A += (size_t)blockIdx.x * n * ld;
         info += blockIdx.x;
@@ -756,10 +765,17 @@ constexpr int TB_WAVES = 2;
 __global__ __launch_bounds__(TB_WAVES * 64) void k_trsm_blocks(const double* __restrict__ Y, int64_t m, int q, int ldy,
                                                               const double* __restrict__ L, int ldl,
                                                               const double* __restrict__ Xinv,
-                                                              double* __restrict__ Q, int ldq) {
+                                                              double* __restrict__ Q, int ldq,
+                                                              const double* __restrict__ skip_if, double skip_thr) {
     extern __shared__ double tb_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
+    if (skip_if != nullptr && *skip_if >= skip_thr) {       // guarded form (sober_trsm_blocks_if): the block stays what it is
+        const int64_t r0 = ((int64_t)blockIdx.x * TB_WAVES + wave) * 16;
+        for (int64_t r = r0; r < min(r0 + 16, m); ++r)
+            for (int c = lane; c < q; c += 64) Q[r * ldq + c] = Y[r * ldy + c];
+        return;
+    }
     const int qpad = ((q + 31) / 32) * 32, LS = qpad + 4;             // stash row stride: fragments on distinct bank pairs
     double* stash = tb_lds + (size_t)wave * (16 * LS + 16 * 36);      // 16 x LS: the Q blocks finished so far
     double* tbuf = stash + 16 * LS;                                   // 16 x 36: the block being multiplied by X^T
@@ -1050,8 +1066,17 @@ extern "C" int sober_cholesky_inv(double* A, int n, int ld, double shift, int32_
     return sober_cholesky_inv_ratio(A, n, ld, shift, info, min_pivot, xinv, nullptr, stream);
 }
 
+extern "C" int sober_cholesky_inv_ratio_if(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
+                                           double* xinv, double* ratio_out, const double* skip_if, double skip_thr,
+                                           void* stream);
 extern "C" int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
                                         double* xinv, double* ratio_out, void* stream) {
+    return sober_cholesky_inv_ratio_if(A, n, ld, shift, info, min_pivot, xinv, ratio_out, nullptr, 0.0, stream);
+}
+
+extern "C" int sober_cholesky_inv_ratio_if(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
+                                           double* xinv, double* ratio_out, const double* skip_if, double skip_thr,
+                                           void* stream) {
     if (!A || !info || n <= 0 || ld < n) return SOBER_E_ARG;
     if (n > sober::CH_MAXN) return SOBER_E_DIM;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
@@ -1067,10 +1092,10 @@ extern "C" int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, 
     if (n <= sober::CH_SMALLN) {
         bytes += (size_t)n * (n + 1) * sizeof(double);
         hipLaunchKernelGGL(sober::k_chol<true>, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift,
-                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv, ratio_out);
+                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv, ratio_out, skip_if, skip_thr);
     } else {
         hipLaunchKernelGGL(sober::k_chol<false>, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift,
-                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv, ratio_out);
+                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv, ratio_out, skip_if, skip_thr);
     }
     LAUNCH_CHECK();
     return 0;
@@ -1081,8 +1106,17 @@ extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* i
     return sober_cholesky_inv(A, n, ld, shift, info, min_pivot, nullptr, stream);
 }
 
+extern "C" int sober_trsm_blocks_if(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
+                                    const double* Xinv, double* Q, int ldq, const double* skip_if, double skip_thr,
+                                    void* stream);
 extern "C" int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
                                  const double* Xinv, double* Q, int ldq, void* stream) {
+    return sober_trsm_blocks_if(Y, m, q, ldy, L, ldl, Xinv, Q, ldq, nullptr, 0.0, stream);
+}
+
+extern "C" int sober_trsm_blocks_if(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
+                                    const double* Xinv, double* Q, int ldq, const double* skip_if, double skip_thr,
+                                    void* stream) {
     if (!Y || !L || !Xinv || !Q || m <= 0 || q <= 0 || q > 256 || ldy < q || ldl < q || ldq < q) return SOBER_E_ARG;
     const int qpad = ((q + 31) / 32) * 32;
     const size_t bytes = (size_t)sober::TB_WAVES * (16 * (qpad + 4) + 16 * 36) * sizeof(double);
@@ -1094,7 +1128,7 @@ extern "C" int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, con
     }
     const int64_t row_blocks = (m + 15) / 16;
     hipLaunchKernelGGL(sober::k_trsm_blocks, dim3((unsigned)((row_blocks + sober::TB_WAVES - 1) / sober::TB_WAVES)),
-                       dim3(sober::TB_WAVES * 64), bytes, (hipStream_t)stream, Y, m, q, ldy, L, ldl, Xinv, Q, ldq);
+                       dim3(sober::TB_WAVES * 64), bytes, (hipStream_t)stream, Y, m, q, ldy, L, ldl, Xinv, Q, ldq, skip_if, skip_thr);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1115,7 +1149,7 @@ extern "C" int sober_cholesky_probe_piv(const double* src, int n, int ld_src, co
     HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 512));
     hipLaunchKernelGGL(sober::k_chol<false>, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
-                       info, min_pivot, src, ld_src, shifts, (double*)nullptr, (double*)nullptr);
+                       info, min_pivot, src, ld_src, shifts, (double*)nullptr, (double*)nullptr, (const double*)nullptr, 0.0);
     LAUNCH_CHECK();
     return 0;
 }

@@ -20,104 +20,7 @@
 
 namespace sober {
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-
-// exp of four independent arguments, written stage by stage so that the four dependency chains
-// interleave (one chain alone leaves the FP64 pipe idle for most of its latency).
-//
-// The argument arrives PRE-SCALED: y = a * 256/ln2 (the scale is folded into the augmented rows, so the
-// GEMM delivers y for free).  Then  n = rint(y)  via the 2^52 magic-number add (its low dword IS n),
-// r' = y - n exactly (no Cody-Waite split needed), exp(a) = 2^(n>>8) T[n&255] (1 + p(r')) with a 256-entry table,
-// a degree-4 polynomial (|r| <= ln2/512: truncation 3.8e-17) whose coefficients are pre-multiplied by (ln2/256)^k,
-// and the scaling by 2^(n>>8) as ONE integer add on the table value's high dword: the table stores 2^(j/256) with
-// (j << 12) subtracted from the high dword, so that adding (n << 12) = ((n>>8) << 20) + (j << 12) leaves exactly the
-// exponent increment.  8 FP64 + 4 integer instructions per value (libm: ~30): on gfx950 every vector instruction
-// of the SIMD -- integer ones too -- queues behind a running v_mfma_f64 (scripts/dp_rate_probe.hip), so the count
-// of instructions is what this kernel's time is made of.
-constexpr int EXP_TAB = 256;
-__device__ const unsigned long long c_exp_tab[EXP_TAB] = {
-#include "exp_table.inc"
-};
-__device__ __forceinline__ double exp_tab_entry(int j) { return __longlong_as_double((long long)c_exp_tab[j]); }
-__device__ __forceinline__ void exp_tab4(const double (&y)[4], const double* __restrict__ T, double (&out)[4]) {
-    const double MAGIC = 6755399441055744.0;        // 1.5 * 2^52
-    const double K1 = 0.0027076061740622863;        // (ln2/256)^k / k!
-    const double K2 = 3.665565596910106e-06;
-    const double K3 = 3.308302680541371e-09;
-    const double K4 = 2.239395190875157e-12;
-    double yc[4], u[4], r[4], t[4], q[4];
-    int n[4];
-    // clamp at about -261000 (e^-706 ~ 1e-307 keeps 2^(n>>8) a normal number) as an UNSIGNED MIN ON THE HIGH DWORD:
-    // for negative doubles a larger bit pattern is a more negative value, non-negative ones compare below any
-    // negative pattern and pass unchanged (NaN too).
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        yc[i] = __hiloint2double((int)min((unsigned)__double2hiint(y[i]), 0xC10FDC40u), __double2loint(y[i]));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = yc[i] + MAGIC;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) n[i] = __double2loint(u[i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double tv = T[n[i] & (EXP_TAB - 1)];
-        int hi;                                                        // exponent field += n >> 8 (see above)
-        asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(hi) : "v"(n[i]), "v"(__double2hiint(tv)));
-        t[i] = __hiloint2double(hi, __double2loint(tv));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = yc[i] - (u[i] - MAGIC);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = fma(r[i], K4, K3);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = fma(r[i], q[i], K2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = fma(r[i], q[i], K1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = q[i] * r[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = fma(t[i], q[i], t[i]);
-}
-
-template <int KIND>
-__device__ __forceinline__ void kern_from_arg4(const double4_t& c, const double* __restrict__ T, double (&k)[4]) {
-    if constexpr (KIND == SOBER_KIND_RBF) {
-        const double y[4] = {c[0], c[1], c[2], c[3]};                 // already -sq/2 * 256/ln2
-        exp_tab4(y, T, k);
-    } else {
-        const double s5 = 2.23606797749978969641;
-        const double INV_L = 0.0027076061740622863;                    // ln2/256: undo the pre-scaling
-        const double L = 369.3299304675746;
-        double sq[4], rr[4], a[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sq[i] = fmax((-2.0 * INV_L) * c[i], 1e-30);   // clamp_min(1e-30) before sqrt
-        // sqrt without the IEEE sequence (range checks, scaling, fix-up): sq >= 1e-30 is a normal number by the clamp
-        // above, so v_rsq_f64 (~2^-23) + ONE coupled Newton step on 1/sqrt (-> ~2^-45) + one residual correction of the
-        // root itself (quadratic again: rounding-limited, <= 1 ulp) -- the four chains written stage by stage so that
-        // they interleave
-        double rs[4], hh[4], ee[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rs[i] = __builtin_amdgcn_rsq(sq[i]);
-#pragma unroll
-        for (int it = 0; it < 1; ++it) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hh[i] = 0.5 * rs[i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ee[i] = fma(-(sq[i] * rs[i]), hh[i], 0.5);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rs[i] = fma(rs[i], ee[i], rs[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rr[i] = sq[i] * rs[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rr[i] = fma(fma(-rr[i], rr[i], sq[i]), 0.5 * rs[i], rr[i]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = (-s5 * L) * rr[i];
-        exp_tab4(a, T, k);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) k[i] *= (s5 * rr[i] + 1.0) + (5.0 / 3.0) * sq[i];
-    }
-}
+#include "kern_exp.inc"
 
 // ---- wave-autonomous variant ----------------------------------------------------------------------------------
 // The same arithmetic without a workgroup in the inner loop.  A wave owns a 64-row x 16-set tile over a contiguous

@@ -84,3 +84,43 @@ def test_gram_route_of_the_caratheodory_step_on_reference_levels(dev, monkeypatc
     monkeypatch.delenv("SOBER_CAR_GRAM", raising=False)
     nat.reload_switches()
     assert n_checked >= 50
+
+
+@pytest.mark.parametrize("kind,d,n_obs,N", [("rbf", 10, 200, 10007), ("matern52", 6, 37, 4096), ("rbf", 3, 255, 777),
+                                             ("tanimoto", 2048, 64, 3000), ("tanimoto", 100, 200, 1031)])
+def test_fused_prediction_equals_the_materialised_route(kind, d, n_obs, N, dev, monkeypatch):
+    """csrc/predict.hip (one launch: K(X_obs, x) once into LDS, W k on the FP64 matrix cores) against the four-launch
+    route it replaces (SOBER_PREDICT_MATERIALISED=1: posterior mean, materialised K(X_obs, pool), V = W KX, the column-wise
+    quadratic form): mean, variance and pi(x) of SOBER/_gp.py:212-238 / _pi.py:20-38 -- the same numbers up to the order
+    of the n_obs-term sums."""
+    from oracle import sober_oracle as O
+    rng = np.random.default_rng(n_obs + N)
+    if kind == "tanimoto":
+        X = (rng.random((N, d)) < 0.1).astype(np.float64)
+        Xo = (rng.random((n_obs, d)) < 0.1).astype(np.float64)
+        ls = np.ones(1)
+    else:
+        X, Xo = rng.random((N, d)), rng.random((n_obs, d))
+        ls = (0.3 + 0.4 * rng.random(d)) * np.sqrt(d)
+    spec = O.make_spec(kind, _t(Xo), _t(ls), outputscale=1.7, noise=1e-2, mean_const=0.3, y_obs=_t(rng.standard_normal(n_obs)))
+    ks = sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs, spec.S_cache, spec.noise,
+                              spec.mean_const, spec.alpha)
+    Xd = _t(X).to(dev)
+    out = []
+    for mat in (True, False):
+        if mat:
+            monkeypatch.setenv("SOBER_PREDICT_MATERIALISED", "1")
+        else:
+            monkeypatch.delenv("SOBER_PREDICT_MATERIALISED", raising=False)
+        mean, var = sober_amd.predict(Xd, ks)
+        w = sober_amd.PI(ks)(Xd)
+        lw = sober_amd.PI(ks)(Xd, log=True)
+        out.append([v.cpu().numpy() for v in (mean, var, w, lw)])
+    # (256 observations in three dimensions: alpha ~ 1e3, the mean is a cancelling sum -- 1e-10 of its terms' scale)
+    for a, b, tol in zip(out[0], out[1], (1e-10, 1e-10, 1e-9, 1e-9)):
+        scale = np.abs(a).max()
+        assert np.abs(a - b).max() <= tol * max(scale, 1.0), (np.abs(a - b).max(), scale)
+    # ... and the oracle (the reference's arithmetic) on a slice
+    m_ref, v_ref = O.predict(_t(X[:500]), spec)
+    np.testing.assert_allclose(out[1][0][:500], m_ref.numpy(), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(out[1][1][:500], v_ref.numpy(), rtol=1e-8, atol=1e-12)
