@@ -292,6 +292,10 @@ int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, int32_t* in
  * points to (device memory, written by an earlier kernel on the stream) is >= skip_thr the launch does nothing --
  * sober_cholesky_inv_ratio_if then leaves info = 0, min_pivot = 1, ratio = 1 and sober_trsm_blocks_if copies Y to Q.
  * The range finder's optional CholeskyQR passes (sober_nystrom_basis) without a host decision.                          */
+/* *ok = 1.0 when *k_out == n_rungs (sober_jitter_ladder_auto took the diagonal fallback) and the diagonal of A satisfies
+ * 0 < max d <= kappa_max * min d, else 0.0 -- the guard of the range finder's skipped passes.                              */
+int sober_diag_spread(const double* A, int n, int ld, const int32_t* k_out, int n_rungs, double kappa_max, double* ok,
+                      void* stream);
 int sober_dgemm_if(int transa, int transb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
                    int ldb, double beta, double* C, int ldc, const double* skip_if, double skip_thr, void* stream);
 int sober_cholesky_inv_ratio_if(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, double* xinv,
@@ -419,14 +423,15 @@ int sober_kmeans_lloyd(const double* X, int64_t N, int d, int K, int iters,
  * (log_flag: log(pi + FP32 eps)) -- the K(X_obs, x) column evaluated once into LDS, W k on the FP64 matrix cores, nothing
  * of size n_obs x N ever in memory.  obs / cand: prepared point sets (sober_scale_points rows of dt doubles, or
  * sober_pack_bits words + popcounts for Tanimoto); W: n_obs x n_obs, SYMMETRIC (S S^T of SOBER/_gp.py:277), ld ldw;
- * kxx_const: k(x, x) of the continuous kernels (Tanimoto takes it from the popcounts); mean_out may be NULL.
+ * kxx_const: k(x, x) of the continuous kernels (Tanimoto takes it from the popcounts); mean_out may be NULL; eta_ptr != NULL:
+ * the threshold is read from device memory (a max another kernel left there) instead of the argument.
  * sober_predict_fused_supported: n_obs <= 255 and a register-tiled point dimension; otherwise SOBER_E_DIM and the
  * caller keeps the materialised route (sober_pairwise + sober_dgemm + sober_predict_finish).                          */
 int sober_predict_fused_supported(int kind, int n_obs, int dt);
 int sober_predict_fused(int kind, const void* obs, const double* obs_norm, int n_obs, const void* cand,
                         const double* cand_norm, int64_t N, int dt, double outputscale, const double* W, int ldw,
                         const double* alpha, double c0, double kxx_const, double noise, double* mean_out, double* var_out,
-                        double eta, double* lfi_out, int log_flag, void* stream);
+                        double eta, const double* eta_ptr, double* lfi_out, int log_flag, void* stream);
 /* Posterior variance (and optionally the LFI weight pi) over a pool, SOBER/_gp.py:212-238 and
  * SOBER/_pi.py:31-38: KX = k(X_obs, pool) (n_obs x N, sober_pairwise), V = W KX (sober_dgemm);
  * var[j] = k(x_j, x_j) - sum_i KX[i][j] V[i][j] + noise; pi[j] = Phi((mean[j] - eta)/sqrt(var[j])),
@@ -643,9 +648,10 @@ int sober_projection(const double* Ut, int s, int M, const double* mean, const d
 typedef struct sober_nystrom_job {
     int32_t M, s, n_rungs, niter, probe_mc;     /* Gram size, basis size, ladder rungs (max_iter + 1), power iterations,
                                                    != 0: eight workgroups per rung (sober_cholesky_probe_mc)          */
-    int32_t no_skip;                            /* != 0: every intermediate block of the range finder takes its CholeskyQR pass
-                                                   (0: an odd block goes on as it is when the block in front of it left a
-                                                   pivot ratio >= 1e-4 -- decided on the device, csrc/nystrom_exec.cpp)   */
+    int32_t skip_passes;                        /* != 0 (opt-in): the intermediate blocks of the range finder go on unorthonormalised
+                                                   when the repaired matrix is the diagonal fallback with max d <= 20 min d --
+                                                   decided on the device; -0.2 ms at cfg-2, a subspace error of ~4e-11 that
+                                                   hypersensitive pools turn into other indices (csrc/nystrom_exec.cpp)      */
     const double* G;                            /* M x M Gram, row-major ld M: kernel(pt, pt) of SOBER/_rchq.py:35      */
     const double* shifts;                       /* n_rungs jitter totals 1e-5 (2^k - 1), device                        */
     const double* R;                            /* M x s standard normals, device: the CPU generator's draw            */

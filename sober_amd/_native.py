@@ -83,6 +83,7 @@ SIGNATURES = {
     "sober_cholesky_inv": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
     "sober_cholesky_inv_ratio": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp]),
     "sober_trsm_blocks": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "sober_diag_spread": (_i32, [_vp, _i32, _i32, _vp, _i32, _f64, _vp, _vp]),
     "sober_dgemm_if": (_i32, [_i32, _i32, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _i32, _f64, _vp, _i32, _vp, _f64, _vp]),
     "sober_cholesky_inv_ratio_if": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
     "sober_trsm_blocks_if": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _f64, _vp]),
@@ -100,7 +101,7 @@ SIGNATURES = {
     "sober_kmeans_lloyd": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "sober_predict_fused_supported": (_i32, [_i32, _i32, _i32]),
     "sober_predict_fused": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f64, _vp, _i32, _vp, _f64, _f64, _f64, _vp, _vp,
-                                   _f64, _vp, _i32, _vp]),
+                                   _f64, _vp, _vp, _i32, _vp]),
     "sober_predict_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f64, _vp, _f64, _f64, _vp, _f64, _vp, _i32, _vp]),
     "sober_reduce_ws_bytes": (_i64, [_i64]),
     "sober_cleansing_weights": (_i32, [_vp, _i64, _f64, _vp, _i64, _vp]),
@@ -170,7 +171,7 @@ class FinalJob(C.Structure):
 class NystromJob(C.Structure):
     """struct sober_nystrom_job of include/sober_hip.h (field for field)."""
     _fields_ = [
-        ("M", _i32), ("s", _i32), ("n_rungs", _i32), ("niter", _i32), ("probe_mc", _i32), ("no_skip", _i32),
+        ("M", _i32), ("s", _i32), ("n_rungs", _i32), ("niter", _i32), ("probe_mc", _i32), ("skip_passes", _i32),
         ("G", _vp), ("shifts", _vp), ("R", _vp), ("C", _vp), ("chol_work", _vp),
         ("probe_ws", _vp), ("probe_ws_bytes", _i64),
         ("Y", _vp * 2), ("Gm", _vp), ("xinv", _vp),
@@ -615,12 +616,14 @@ def predict_fused_supported(kind: int, n_obs: int, dt: int) -> bool:
 
 
 def predict_fused(kind, obs, obs_norm, cand, cand_norm, n, dt, outputscale, W, alpha, c0, kxx_const, noise, mean_out,
-                  var_out, eta=0.0, lfi_out=None, log=False):
-    """csrc/predict.hip: mean / variance / pi over `n` prepared candidates in one launch (W symmetric)."""
+                  var_out, eta=0.0, lfi_out=None, log=False, eta_dev=None):
+    """csrc/predict.hip: mean / variance / pi over `n` prepared candidates in one launch (W symmetric); eta_dev: the
+    threshold as a one-element device tensor (read by the kernel: no host read-back)."""
     _check(load().sober_predict_fused(int(kind), obs.data_ptr(), _ptr(obs_norm), obs.shape[0], cand.data_ptr(),
                                       _ptr(cand_norm), int(n), int(dt), float(outputscale), W.data_ptr(), W.stride(0),
                                       _ptr(alpha), float(c0), float(kxx_const), float(noise), _ptr(mean_out),
-                                      var_out.data_ptr(), float(eta), _ptr(lfi_out), int(bool(log)), _stream(cand)),
+                                      var_out.data_ptr(), float(eta), _ptr(eta_dev), _ptr(lfi_out), int(bool(log)),
+                                      _stream(cand)),
            "sober_predict_fused")
 
 

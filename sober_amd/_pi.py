@@ -31,7 +31,7 @@ def _kxx_const(spec):
     return 0.0                                            # tanimoto: per point, from the popcounts
 
 
-def _predict(spec, X, eta=None, log=False):
+def _predict(spec, X, eta=None, log=False, eta_dev=None):
     dev = X.device
     kind = nat.KIND_BY_NAME[spec.kind]
     pobs = prepare_points(spec, spec.X_obs)
@@ -39,9 +39,13 @@ def _predict(spec, X, eta=None, log=False):
     n_obs, N = len(pobs), X.shape[0]
     mean = torch.empty(N, dtype=torch.float64, device=dev)
     var = torch.empty(N, dtype=torch.float64, device=dev)
-    lfi = torch.empty(N, dtype=torch.float64, device=dev) if eta is not None else None
     fused = (nat.predict_fused_supported(kind, n_obs, pobs.dt) and spec.alpha is not None
              and nat.fused_dim_supported(kind, spec.X_obs.shape[1]) and not os.environ.get("SOBER_PREDICT_MATERIALISED"))
+    if eta is None and eta_dev is not None:
+        # the threshold is still in device memory: the fused kernel reads it there, the materialised route needs the number
+        eta = 0.0 if fused else float(eta_dev.item())
+        eta_dev = eta_dev if fused else None
+    lfi = torch.empty(N, dtype=torch.float64, device=dev) if eta is not None else None
     for lo in range(0, N, CHUNK):
         hi = min(N, lo + CHUNK)
         pts = prepare_points(spec, X[lo:hi])
@@ -49,7 +53,8 @@ def _predict(spec, X, eta=None, log=False):
         if fused:
             nat.predict_fused(kind, pobs.data, pobs.norm, pts.data, pts.norm, n, pts.dt, spec.outputscale, W, spec.alpha,
                               spec.mean_const, _kxx_const(spec), spec.noise, mean[lo:hi], var[lo:hi],
-                              0.0 if eta is None else eta, None if lfi is None else lfi[lo:hi], log)
+                              0.0 if eta is None else eta, None if lfi is None else lfi[lo:hi], log,
+                              eta_dev=eta_dev if eta is not None else None)
             continue
         mean[lo:hi] = posterior_mean(spec, pts)
         KX = torch.empty(n_obs, n, dtype=torch.float64, device=dev)
@@ -82,7 +87,7 @@ class PI:
         self.label = label
         self.Xobs = spec_from_model(model).X_obs
         self._spec = None
-        self.eta = None
+        self._eta_dev = None                              # max posterior mean at the observations, ON the device
 
     def _prepare(self, device):
         """A live model is read again on every call (the reference evaluates `self.model` each time, :20-38); a
@@ -92,12 +97,17 @@ class PI:
         if live or self._spec is None or same_device(self._spec.X_obs.device) != dev:
             self._spec = spec_from_model(self.model).to(dev)
             m_obs, _, _ = _predict(self._spec, self._spec.X_obs)
-            self.eta = float(m_obs.max().item())          # current maximum (:17)
+            self._eta_dev = m_obs.max().reshape(1)        # current maximum (:17): stays on the device -- no read-back per call
         return self._spec
+
+    @property
+    def eta(self):
+        """The reference's `self.eta` (SOBER/_pi.py:17) as a number (reads the device value back)."""
+        return None if self._eta_dev is None else float(self._eta_dev.item())
 
     def lfi(self, X_cand, log=False):
         spec = self._prepare(X_cand.device)
-        _, _, out = _predict(spec, X_cand.to(torch.float64), eta=self.eta, log=log)
+        _, _, out = _predict(spec, X_cand.to(torch.float64), eta_dev=self._eta_dev, log=log)
         return out
 
     def __call__(self, X_cand, log=False):

@@ -899,6 +899,32 @@ __global__ void k_jitter_ladder_auto(double* __restrict__ A, int n, int ld, cons
     }
 }
 
+// After the ladder: is the repaired matrix the DIAGONAL fallback with a mild spread?  *ok = 1.0 when no rung was positive
+// definite (k == n_rungs: the matrix is diag(d) now) and max d <= kappa_max * min d (min d > 0), else 0.0.  For a diagonal
+// matrix the eigenvalues ARE d, so kappa bounds what every further multiplication by it does to a block of the range
+// finder -- the one case in which the intermediate orthonormalisations can be dropped on a proven bound
+// (csrc/nystrom_exec.cpp).  One workgroup.
+__global__ __launch_bounds__(256) void k_diag_spread(const double* __restrict__ A, int n, int ld, const int32_t* __restrict__ k_out,
+                                                     int n_rungs, double kappa_max, double* __restrict__ ok) {
+    __shared__ double s_min[256], s_max[256];
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double d = A[(size_t)i * ld + i];
+        mn = fmin(mn, d); mx = fmax(mx, d);
+        if (!(d == d)) mn = -__builtin_inf();                     // (a NaN: never "mild")
+    }
+    s_min[threadIdx.x] = mn; s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (threadIdx.x < h) {
+            s_min[threadIdx.x] = fmin(s_min[threadIdx.x], s_min[threadIdx.x + h]);
+            s_max[threadIdx.x] = fmax(s_max[threadIdx.x], s_max[threadIdx.x + h]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *ok = (*k_out == n_rungs && s_min[0] > 0.0 && s_max[0] <= kappa_max * s_min[0]) ? 1.0 : 0.0;
+}
+
 }  // namespace sober
 
 namespace sober {
@@ -1211,6 +1237,14 @@ extern "C" int sober_jitter_ladder(double* A, int n, int ld, int k, void* stream
     if (!A || n <= 0 || ld < n || k < 0) return SOBER_E_ARG;
     if (k == 0) return 0;
     hipLaunchKernelGGL(sober::k_jitter_ladder, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, n, ld, k);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_diag_spread(const double* A, int n, int ld, const int32_t* k_out, int n_rungs, double kappa_max,
+                                 double* ok, void* stream) {
+    if (!A || !k_out || !ok || n <= 0 || ld < n || n_rungs <= 0) return SOBER_E_ARG;
+    hipLaunchKernelGGL(sober::k_diag_spread, dim3(1), dim3(256), 0, (hipStream_t)stream, A, n, ld, k_out, n_rungs, kappa_max, ok);
     LAUNCH_CHECK();
     return 0;
 }

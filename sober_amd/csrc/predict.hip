@@ -43,8 +43,10 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
                                                        const double* __restrict__ alpha, double c0, double kxx_const,
                                                        double noise, double* __restrict__ mean_out,
                                                        double* __restrict__ var_out, double eta,
+                                                       const double* __restrict__ eta_ptr,
                                                        double* __restrict__ lfi_out, int log_flag) {
     extern __shared__ __attribute__((aligned(16))) double pf_lds[];
+    if (eta_ptr != nullptr) eta = *eta_ptr;                       // (the threshold still in device memory: no host read-back)
     const int n_pad = pf_obs_pad(n_obs), rs = pf_rs(n_obs);
     double* const kxt = pf_lds;                                  // [PF_NB][rs]: K(X_obs, x_c), candidate-major
     double* const ys = kxt + (size_t)PF_NB * rs;                 // [PF_NB][DT]: the candidates' prepared rows
@@ -228,7 +230,8 @@ extern "C" int sober_predict_fused_supported(int kind, int n_obs, int dt) {
 extern "C" int sober_predict_fused(int kind, const void* obs, const double* obs_norm, int n_obs, const void* cand,
                                    const double* cand_norm, int64_t N, int dt, double outputscale, const double* W, int ldw,
                                    const double* alpha, double c0, double kxx_const, double noise, double* mean_out,
-                                   double* var_out, double eta, double* lfi_out, int log_flag, void* stream) {
+                                   double* var_out, double eta, const double* eta_ptr, double* lfi_out, int log_flag,
+                                   void* stream) {
     if (!obs || !cand || !W || !var_out || N <= 0 || ldw < n_obs) return SOBER_E_ARG;
     if (!sober_predict_fused_supported(kind, n_obs, dt)) return SOBER_E_DIM;
     if (kind == SOBER_KIND_TANIMOTO && (!obs_norm || !cand_norm)) return SOBER_E_ARG;
@@ -242,7 +245,7 @@ extern "C" int sober_predict_fused(int kind, const void* obs, const double* obs_
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_predict_fused<K, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
         hipLaunchKernelGGL((sober::k_predict_fused<K, D>), grid, dim3(256), bytes, st, (const double*)obs, obs_norm, n_obs,     \
                            (const double*)cand, cand_norm, N, dt, outputscale, W, ldw, alpha, c0, kxx_const, noise, mean_out,  \
-                           var_out, eta, lfi_out, log_flag);                                                                   \
+                           var_out, eta, eta_ptr, lfi_out, log_flag);                                                                   \
         break;                                                                                                                 \
     }
 #define PF_DIMS(K) switch (dt) { PF_LAUNCH(K, 4) PF_LAUNCH(K, 8) PF_LAUNCH(K, 12) PF_LAUNCH(K, 16) PF_LAUNCH(K, 20) PF_LAUNCH(K, 24) \
