@@ -45,10 +45,11 @@ def _recursive_draws(sober, n_rec, n_repeat):
     for _ in range(n_repeat):
         X_cand, X_indices, weights = _draw(sober, n_rec)
         idx = weights > 0
-        if not idx.sum() == 0:
+        n_pos = int(idx.sum())                               # (one read-back decides both of the reference's tests)
+        if n_pos != 0:
             X_acc.append(X_cand[idx])
             w_acc.append(weights[idx])
-            n_accepted += int(idx.sum())
+            n_accepted += n_pos
             if X_indices is not None:
                 I_acc.append(X_indices[idx])
         if n_accepted > sober.thresh:

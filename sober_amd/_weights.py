@@ -33,9 +33,15 @@ class WeightsStabiliser:
         """SOBER/_weights.py:40-55."""
         if weights.sum() == 0:
             return False
-        elif len(weights.unique()) < self.thresh:
-            return False
-        return True
+        # `len(weights.unique()) < thresh` asks for fewer than `thresh` (5) DISTINCT values; a sort of the whole pool is
+        # the reference's way of asking.  A head of the vector that already holds `thresh` distinct values answers it;
+        # only when it does not is the full answer computed (same verdict either way).
+        head = weights[:4096]
+        if len(head.unique()) >= self.thresh:
+            return True
+        if len(weights) > len(head) and len(weights.unique()) >= self.thresh:
+            return True
+        return False
 
     def weighted_resampling(self, weights, n_nys):
         """SOBER/_weights.py:57-77 (torch.multinomial: RNG-defined, stays in torch)."""

@@ -1644,12 +1644,15 @@ def _shard_worker_synth(rank, world, port, case, outq):
         X = _t(inp["X_cand"][lo:hi].copy()).to(dev)
         mu = _t(inp["mu0"][lo:hi].copy()).to(dev)
         torch.manual_seed(SEED_CALL if rank == 0 else SEED_CALL + 17 * rank)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
+        timers = {}
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
             idx, w = sober_amd.recombination(X, _t(inp["X_nys"]).to(dev), case["b"],
                                              sober_amd.Kernel(kspec(spec), case["mode"]), init_weights=mu,
-                                             group=dist.group.WORLD, row_offset=lo)
-        outq.put((rank, idx.cpu().numpy(), w.cpu().numpy(), int(torch.count_nonzero(mu))))
+                                             group=dist.group.WORLD, row_offset=lo, _timers=timers)
+        # (which routes the rank took: part of the message when the comparison fails)
+        route = sorted(timers) + [str(r.message)[:80] for r in rec if "sober_amd" in str(r.message)]
+        outq.put((rank, idx.cpu().numpy(), w.cpu().numpy(), int(torch.count_nonzero(mu)), route))
     finally:
         dist.destroy_process_group()
 
@@ -1798,8 +1801,9 @@ def test_cfg4_shape_eight_ranks_one_gpu(dev):
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    for rank, idx, w, _ in outs:
-        assert np.array_equal(idx, idx1), rank
+    agree = [bool(np.array_equal(o[1], outs[0][1])) for o in outs]
+    for rank, idx, w, _, route in outs:
+        assert np.array_equal(idx, idx1), (rank, "ranks agree among themselves: %s" % agree, [o[4] for o in outs])
         np.testing.assert_allclose(w, w1, rtol=1e-9)
     assert sum(o[3] for o in outs) == len(idx1)                       # Q3 across the eight shards
 
