@@ -223,6 +223,10 @@ int64_t sober_car_ws_bytes(int N, int m);
 int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
                      int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
                      double* phi_out, void* ws, int64_t ws_bytes, void* stream);
+/* out[i] = v_rcp_f64(x[i]): the hardware reciprocal seed exactly as the pivot kernels' screened ratio test
+ * (SOBER/_rchq.py:240-247) uses it -- test hook that pins its relative error (< 2^-22 per band step, csrc/car.hip). */
+int sober_probe_rcp(const double* x, double* out, int64_t n, void* stream);
+
 /* The same step with the choice of launches in the caller's hand (SOBER/_rchq.py:224-270 never fails, so a give-up
  * must be recoverable):
  *   SOBER_CAR_DEFAULT  what sober_car_device runs: launches whose workgroups wait for partner workgroups (the fused

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sober_car_supported": (_i32, [_i32, _i32]),
     "sober_car_ws_bytes": (_i64, [_i32, _i32]),
     "sober_car_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sober_probe_rcp": (_i32, [_vp, _vp, _i64, _vp]),
     "sober_second_elimination": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sober_car_mc_supported": (_i32, [_i32, _i32]),
     "sober_car_mc_ws_bytes": (_i64, [_i32, _i32]),
@@ -500,6 +501,13 @@ def car_supported(N: int, m: int) -> bool:
 
 def car_safe_supported(N: int, m: int) -> bool:
     return bool(load().sober_car_safe_supported(N, m))
+
+
+def probe_rcp(x):
+    """v_rcp_f64 of a float64 device tensor (test hook: the screened ratio test's seed)."""
+    out = torch.empty_like(x)
+    _check(load().sober_probe_rcp(x.data_ptr(), out.data_ptr(), x.numel(), _stream(x)), "sober_probe_rcp")
+    return out
 
 
 def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None, multi_cu=False, mode=CAR_DEFAULT):

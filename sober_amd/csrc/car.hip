@@ -657,7 +657,9 @@ __global__ __launch_bounds__(256) void k_car_phi(const double* __restrict__ vws,
 // ---------------- phase 3: the pivots of SOBER/_rchq.py:237-266 ----------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned dpp_min_u32(unsigned v) {
-    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    // (`old` = the minimum's identity: lanes a row mask leaves out read it, which is what they should combine with --
+    //  and the DPP combiner may then fold the move into the v_min_u32 itself)
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xf, false);
     return o < v ? o : v;
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {        // total in lane 63
@@ -690,32 +692,83 @@ __device__ unsigned long long g_sp_seg[SP_W_MAX_DBG * 8];   // per wave: ticks s
 #define SP_SEG(K, DEP_CONSTRAINT, DEP) do { } while (0)
 #endif
 struct SpSlot { double col[256]; double alpha, rpp; int piv; int tag; };
-struct SpState { double mu[4]; bool dead[4], inr[4]; };
+// tags and progress words through LDS-typed pointers: a volatile access through a generic pointer becomes a FLAT
+// instruction followed by s_waitcnt vmcnt(0) -- the publishing wave waited for its own tag store on every pivot
+typedef __attribute__((address_space(3))) volatile int sp_lds_vint;
+typedef __attribute__((address_space(3))) int sp_lds_int;
+__device__ __forceinline__ sp_lds_vint* sp_lds_v(volatile int* p) { return (sp_lds_vint*)p; }
+// alive[q]: rows 64 q + lane that are inside the step and not cancelled yet -- a wave-uniform lane mask (a pair of
+// scalar registers used directly as the select's condition; per-lane booleans cost a compare, a byte and/or and a
+// move per slot and pivot on the chain)
+struct SpState { double mu[4]; unsigned long long alive[4]; };
+__device__ __forceinline__ bool sp_alive(const SpState& st, int q) { return __builtin_amdgcn_inverse_ballot_w64(st.alive[q]); }
+constexpr int SP_BAND = 4;          // screened ratio test: candidates = high words within SP_BAND of the minimum
 
 #ifdef SP_TSTAMPS
 #define SP_DBG_ARGS0 , unsigned long long (&sp_seg_)[8], unsigned long long& sp_last_
 #else
 #define SP_DBG_ARGS0
 #endif
+// The ratio test of :240-247.  Screened form (round 5): the quotients' HIGH WORDS from mu * v_rcp_f64(col) (relative
+// error e < 2^-22, tests/test_hip_round5.py pins it) decide the winner whenever exactly one lane lies within SP_BAND
+// high-word steps (>= 2^-21 each) of the minimum: every other lane's exact quotient is then larger than the winner's
+// by more than 2 e -- the same index as the exact argmin, and alpha and 1/pivot are computed exactly for that lane
+// only (two divisions per pivot instead of four IEEE divisions and four order-preserving 64-bit keys).  Anything else
+// -- two lanes inside the band, a quotient that is negative, infinite or NaN (keys below 0x80100000 after the shift
+// that wraps them), no candidate -- takes the exact test below, unchanged.
 template <int NQ>
-__device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpState& st, int& piv, double& al, double& rp SP_DBG_ARGS0) {
+__device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpState& st, bool exact_only, int& piv, double& al, double& rp SP_DBG_ARGS0) {
+    if (!exact_only) {                                                // (SOBER_CAR_EXACT_RATIO: the A/B of the tests)
+        unsigned sk[4];
+        unsigned smin = 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double r = st.mu[q] * __builtin_amdgcn_rcp(col[q]);
+            const unsigned k = (unsigned)__double2hiint(r) + 0x80100000u;   // [+0, DBL_MAX] -> [0x80100000, 0xffffffff]; the rest below
+            sk[q] = (col[q] > 0.0) ? k : 0xffffffffu;                        // (col is 0 on rows that are not alive)
+            smin = min(smin, sk[q]);
+        }
+        const unsigned H = wave_min_u32(smin);
+        if (H >= 0x80100000u && H < 0xffffffffu - (unsigned)SP_BAND) {
+            unsigned long long mb[4];
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { mb[q] = __ballot(sk[q] <= H + (unsigned)SP_BAND); cnt += __popcll(mb[q]); }
+            if (cnt == 1) {
+                double mp = 0.0, cp = 1.0;
+                bool found = false;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (!found && mb[q] != 0ull) {                    // uniform
+                        const int f = __ffsll((long long)mb[q]) - 1;
+                        piv = f + 64 * q;
+                        mp = rdlane(st.mu[q], f);
+                        cp = rdlane(col[q], f);
+                        found = true;
+                    }
+                }
+                al = mp / cp;
+                rp = 1.0 / cp;
+                SP_SEG(5, "+s", piv);
+                return;
+            }
+        }
+    }
     double rt[4], rc[4];
     unsigned kh[4], kl[4];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { rt[q] = st.mu[q] / col[q]; rc[q] = 1.0 / col[q]; }
-    SP_SEG(5, "+v", rt[3]);                                          // the eight divisions
     unsigned hmin = 0xffffffffu;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const unsigned long long k = ratio_key(rt[q]);
-        const bool ok = st.inr[q] & (col[q] > 0.0) & !st.dead[q];
+        const bool ok = col[q] > 0.0;
         kh[q] = ok ? (unsigned)(k >> 32) : 0xffffffffu;
         kl[q] = ok ? (unsigned)k : 0xffffffffu;
         hmin = min(hmin, kh[q]);
     }
-    SP_SEG(6, "+v", hmin);                                           // keys, the lane's minimum
     unsigned H = wave_min_u32(hmin);
-    SP_SEG(7, "+s", H);                                              // the wave's minimum
+    SP_SEG(7, "+s", H);                                              // the exact test (rare)
     piv = -1; al = 0.0; rp = 1.0;
     if (H == 0xffffffffu) return;                                     // uniform: no candidate (:241-242)
     unsigned long long mb[4];
@@ -745,53 +798,59 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
 // mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (two roundings like the tensor expression, :253-254)
 template <int NQ>
 __device__ __forceinline__ void sp_mu_step(SpState& st, const double (&col)[4], double alpha, int piv, int lane) {
+    const unsigned long long bit = 1ull << (piv & 63);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        st.dead[q] = st.dead[q] | (lane + 64 * q == piv);
-        st.mu[q] = st.dead[q] ? 0.0 : __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q]));
+        st.alive[q] &= ~((piv >> 6) == q ? bit : 0ull);               // scalar
+        st.mu[q] = sp_alive(st, q) ? __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q])) : 0.0;
     }
 }
 //   Phi[:, c] -= Phi[:, 0] * (Phi[idx, c] / Phi[idx, 0])   (:260-266), my columns J0 .. SP_BC-1
 // (the row slot of the pivot entry by a uniform switch: picking it with three selects per column makes the compiler
 //  index a copy of phi in scratch memory -- 2x slower --, picking it arithmetically with four 0/1 weights measured
 //  3.5 us per step slower than the switch)
-template <int KP, int J0, int NQ>
-__device__ __forceinline__ void sp_elim_kp(double (&phi)[SP_BC][4], const double (&col)[4], int lp, double rpp) {
+template <int KP, int J0>
+__device__ __forceinline__ void sp_pivot_row_kp(const double (&phi)[SP_BC][4], int lp, double (&prow)[SP_BC]) {
 #pragma unroll
-    for (int j = J0; j < SP_BC; ++j) {
-        const double qv = rdlane(phi[j][KP], lp) * rpp;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) phi[j][q] = fma(-qv, col[q], phi[j][q]);
-    }
+    for (int j = J0; j < SP_BC; ++j) prow[j] = rdlane(phi[j][KP], lp);
 }
+// (the switch only READS: with the updates inside its cases the compiler keeps a renamed copy of phi per case and moves
+//  it back behind the switch -- 24 to 52 v_mov_b64 per pivot on the producing wave's chain)
 template <int J0, int NQ>
 __device__ __forceinline__ void sp_elim(double (&phi)[SP_BC][4], const double (&col)[4], int piv, double rpp) {
     const int kp = piv >> 6, lp = piv & 63;
+    double prow[SP_BC];
     if constexpr (NQ == 1) {
-        sp_elim_kp<0, J0, NQ>(phi, col, lp, rpp);
+        sp_pivot_row_kp<0, J0>(phi, lp, prow);
     } else if constexpr (NQ == 2) {
-        if (kp == 0) sp_elim_kp<0, J0, NQ>(phi, col, lp, rpp);        // uniform
-        else sp_elim_kp<1, J0, NQ>(phi, col, lp, rpp);
+        if (kp == 0) sp_pivot_row_kp<0, J0>(phi, lp, prow);           // uniform
+        else sp_pivot_row_kp<1, J0>(phi, lp, prow);
     } else {
         switch (kp) {                                                 // uniform
-            case 0: sp_elim_kp<0, J0, NQ>(phi, col, lp, rpp); break;
-            case 1: sp_elim_kp<1, J0, NQ>(phi, col, lp, rpp); break;
-            case 2: sp_elim_kp<2, J0, NQ>(phi, col, lp, rpp); break;
-            default: sp_elim_kp<3, J0, NQ>(phi, col, lp, rpp); break;
+            case 0: sp_pivot_row_kp<0, J0>(phi, lp, prow); break;
+            case 1: sp_pivot_row_kp<1, J0>(phi, lp, prow); break;
+            case 2: sp_pivot_row_kp<2, J0>(phi, lp, prow); break;
+            default: sp_pivot_row_kp<3, J0>(phi, lp, prow); break;
         }
+    }
+#pragma unroll
+    for (int j = J0; j < SP_BC; ++j) {
+        const double qv = prow[j] * rpp;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) phi[j][q] = fma(-qv, col[q], phi[j][q]);
     }
 }
 // wait for pivot s in the ring; false = give up (bounded)
 template <int NQ>
 __device__ __forceinline__ bool sp_consume(SpSlot* ring, int s, int lane, double (&col)[4], double& alpha, double& rpp, int& piv) {
     SpSlot& e = ring[s % SP_RING];
-    volatile int* tg = &e.tag;
+    sp_lds_vint* tg = sp_lds_v(&e.tag);
     unsigned spins = 0;
-    while (*tg != s + 1) {
+    while (__builtin_amdgcn_readfirstlane(*tg) != s + 1) {           // (uniform exit: what the loop carries -- the lane masks -- stays scalar)
         if (++spins > (1u << 24)) return false;
         __builtin_amdgcn_s_sleep(1);
     }
-    alpha = e.alpha; rpp = e.rpp; piv = e.piv;
+    alpha = e.alpha; rpp = e.rpp; piv = __builtin_amdgcn_readfirstlane(e.piv);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) col[q] = e.col[lane + 64 * q];
     return true;
@@ -807,13 +866,13 @@ __device__ __forceinline__ bool sp_consume(SpSlot* ring, int s, int lane, double
 #endif
 template <int JJ, int NQ>
 __device__ __forceinline__ void sp_produce_step(double (&phi)[SP_BC][4], SpState& st, SpSlot* ring, int sp, int lane,
-                                                double (&col)[4], bool& stop SP_DBG_ARGS) {
+                                                double (&col)[4], bool& stop, bool exact_only SP_DBG_ARGS) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[JJ][q];
+    for (int q = 0; q < NQ; ++q) col[q] = sp_alive(st, q) ? phi[JJ][q] : 0.0;
     SP_SEG(0, "+v", col[0]);                                  // (since the previous stamp: the elimination behind the last pivot)
     int piv;
     double al, rp;
-    sp_ratio_test<NQ>(col, st, piv, al, rp SP_DBG_PASS);
+    sp_ratio_test<NQ>(col, st, exact_only, piv, al, rp SP_DBG_PASS);
     SP_SEG(1, "+s", piv);                                     // ratio test: ballots, the winner's lane, its quotient
     SpSlot& e = ring[sp % SP_RING];
     if (piv >= 0) {
@@ -825,7 +884,8 @@ __device__ __forceinline__ void sp_produce_step(double (&phi)[SP_BC][4], SpState
     { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) g_sp_stamps[sp] = t_; }
 #endif
     asm volatile("" ::: "memory");                            // (program order; a wave's LDS operations execute in order:
-    if (lane == 0) *(volatile int*)&e.tag = sp + 1;           //  the tag lands after the data it releases -- no wait)
+    if (lane == 0) *(sp_lds_int*)&e.tag = sp + 1;             //  the tag lands after the data it releases -- no wait)
+    asm volatile("" ::: "memory");
     SP_SEG(2, "+s", piv);                                     // publish
     if (piv < 0) { stop = true; return; }                     // Q6: the loop ends here (:241-242)
     sp_mu_step<NQ>(st, col, al, piv, lane);
@@ -841,10 +901,10 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
                                                                 double* __restrict__ w_star,
                                                                 int32_t* __restrict__ n_keep_out,
                                                                 double* __restrict__ mu_out,
-                                                                const unsigned* __restrict__ err) {
+                                                                const unsigned* __restrict__ err, int exact_ratio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
     SpSlot* ring = (SpSlot*)sp_lds;
-    volatile int* prog = (volatile int*)(sp_lds + sizeof(SpSlot) * SP_RING);    // [SP_W]: pivots consumed so far
+    sp_lds_vint* prog = sp_lds_v((volatile int*)(sp_lds + sizeof(SpSlot) * SP_RING));   // [SP_W]: pivots consumed so far
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = N - m;
@@ -867,9 +927,9 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int row = lane + 64 * q;
-        st.inr[q] = row < N;
-        st.dead[q] = false;
-        st.mu[q] = st.inr[q] ? mu_in[row] + 0.0 : 0.0;
+        const int nq = min(max(N - 64 * q, 0), 64);
+        st.alive[q] = nq >= 64 ? ~0ull : ((1ull << nq) - 1ull);
+        st.mu[q] = row < N ? mu_in[row] + 0.0 : 0.0;
 #pragma unroll
         for (int j = 0; j < SP_BC; ++j)
             phi[j][q] = (c0 + j < K && row < N) ? Phi[(size_t)(c0 + j) * CAR_NS + row] : 0.0;
@@ -913,7 +973,7 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
         unsigned long long sp_seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sp_last_;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sp_last_) :: "memory");
 #endif
-#define SP_STEP(JJ) if (sp < s_end && !stop) { sp_produce_step<JJ, NQ>(phi, st, ring, sp, lane, col, stop SP_DBG_PASS); ++sp; }
+#define SP_STEP(JJ) if (sp < s_end && !stop) { sp_produce_step<JJ, NQ>(phi, st, ring, sp, lane, col, stop, exact_ratio != 0 SP_DBG_PASS); ++sp; }
         SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6)
 #undef SP_STEP
         static_assert(SP_BC == 7, "one SP_STEP per column of a block");
@@ -1084,6 +1144,19 @@ extern "C" int sober_car_safe_supported(int N, int m) { return car_one_cu(N, m);
         else { constexpr int NQ_ = 4; LAUNCH; }                        \
     } while (0)
 
+// v_rcp_f64 as the screened ratio test uses it (the test pins its relative error below the band's 2^-22 per SP_BAND step)
+namespace sober {
+__global__ __launch_bounds__(256) void k_probe_rcp(const double* __restrict__ x, double* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = __builtin_amdgcn_rcp(x[i]);
+}
+}
+extern "C" int sober_probe_rcp(const double* x, double* out, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sober::k_probe_rcp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    return (int)hipGetLastError();
+}
+
 extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const double* mu_in,
                                    int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
                                    double* phi_out, void* ws, int64_t ws_bytes, int mode, void* stream) {
@@ -1108,7 +1181,7 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
         hipLaunchKernelGGL(sober::k_car_phi, dim3(sober::CAR_PC / 4), dim3(256), 0, st, vws, taup, N, m, Phi, phi_out);
         LAUNCH_CHECK();
         CAR_PIVOT_BY_SIZE(N, hipLaunchKernelGGL((sober::k_car_pivot_stream<NQ_>), dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m,
-                                                mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)nullptr));
+                                                mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)nullptr, (int)sober::switches().car_exact_ratio));
         LAUNCH_CHECK();
         return 0;
     }
@@ -1130,7 +1203,7 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
                                              ldx, N, m, vws, taup, Phi, gws, comm, (unsigned)sober::cg_comm_bytes(), epoch, spin_limit));
         LAUNCH_CHECK();
         CAR_PIVOT_BY_SIZE(N, hipLaunchKernelGGL((sober::k_car_pivot_stream<NQ_>), dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m,
-                                                mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm));
+                                                mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm, (int)sober::switches().car_exact_ratio));
         LAUNCH_CHECK();
         return 0;
     }
@@ -1138,7 +1211,7 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
                                          N, m, vws, taup, Phi, comm, (unsigned)sober::cg_comm_bytes(), epoch, spin_limit));
     LAUNCH_CHECK();
     CAR_PIVOT_BY_SIZE(N, hipLaunchKernelGGL((sober::k_car_pivot_stream<NQ_>), dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m,
-                                            mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm));
+                                            mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm, (int)sober::switches().car_exact_ratio));
     LAUNCH_CHECK();
     return 0;
 }

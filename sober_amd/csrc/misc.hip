@@ -406,6 +406,7 @@ static Switches read_switches() {
     w.car_force_giveup = getenv("SOBER_CAR_FORCE_GIVEUP") != nullptr;
     w.car_unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;
     w.car_gram = getenv("SOBER_CAR_GRAM") != nullptr;
+    w.car_exact_ratio = getenv("SOBER_CAR_EXACT_RATIO") != nullptr;
     return w;
 }
 static Switches g_switches = read_switches();       // once, when the library is loaded

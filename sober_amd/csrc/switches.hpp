@@ -7,6 +7,7 @@ struct Switches {
     bool tani_no_queue;         // SOBER_TANI_NO_QUEUE: fingerprint levels sized by the host after a synchronisation
     bool car_force_giveup;      // SOBER_CAR_FORCE_GIVEUP: launches that wait for partner workgroups give up at once
     bool car_unfused;           // SOBER_CAR_UNFUSED: bidiagonalisation and Phi as two launches
+    bool car_exact_ratio;       // SOBER_CAR_EXACT_RATIO: the pivots' ratio test without its screened fast path (what the tests compare it with)
     bool car_gram;              // SOBER_CAR_GRAM: the Caratheodory step's reflectors by way of the Gram matrix (car_gram.inc; experimental)
 };
 const Switches& switches();     // (misc.hip)

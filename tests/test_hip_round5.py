@@ -124,3 +124,84 @@ def test_fused_prediction_equals_the_materialised_route(kind, d, n_obs, N, dev, 
     m_ref, v_ref = O.predict(_t(X[:500]), spec)
     np.testing.assert_allclose(out[1][0][:500], m_ref.numpy(), rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(out[1][1][:500], v_ref.numpy(), rtol=1e-8, atol=1e-12)
+
+
+def test_rcp_seed_is_accurate_enough_for_the_screened_ratio_test(dev):
+    """The pivots' screened ratio test (csrc/car.hip, sp_ratio_test) ranks mu * v_rcp_f64(col) by its high word and
+    accepts a lone candidate within SP_BAND = 4 high-word steps (each >= 2^-21 relative): sound while the seed's
+    relative error stays below 4 * 2^-22 = 2^-20.  Pinned here with a factor 4 to spare, over the whole exponent range."""
+    from sober_amd import _native as nat
+    rng = np.random.default_rng(7)
+    x = rng.uniform(1.0, 2.0, 1 << 20) * np.exp2(rng.integers(-1000, 1000, 1 << 20)) * rng.choice([-1.0, 1.0], 1 << 20)
+    x[:4] = [1.0, 3.0, 1.0 - 2.0 ** -53, 2.0 - 2.0 ** -52]
+    r = nat.probe_rcp(_t(x).to(dev)).cpu().numpy()
+    rel = np.abs(r * x - 1.0)
+    print("v_rcp_f64 max relative error: 2^%.2f" % np.log2(rel.max()))
+    assert rel.max() < 2.0 ** -22
+
+
+def _car_once(nat, dev, X, mu):
+    N = X.shape[0]
+    keep = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    w = torch.zeros(N, dtype=torch.float64, device=dev)
+    mo = torch.empty(N, dtype=torch.float64, device=dev)
+    nat.car_device(_t(X).to(dev), _t(mu).to(dev), keep, w, keep[N:], mo)
+    nk = int(keep[N].item())
+    return keep[:N].cpu().numpy(), w.cpu().numpy(), nk, mo.cpu().numpy()
+
+
+def test_screened_ratio_test_is_the_exact_one_bit_for_bit(dev, monkeypatch):
+    """SOBER_CAR_EXACT_RATIO=1 switches the screened fast path of the pivots' ratio test off (four IEEE divisions and
+    64-bit keys per pivot, the round-2..4 form).  The screen only ever picks the lane the exact test would pick and
+    computes alpha and 1 / pivot for it with the same two divisions, so EVERY output must be bit-identical: kept ranks,
+    weights, the full weight vector -- on the reference's level inputs, on random steps of every one-CU size class, with
+    zero masses (alpha = 0 ties -> several candidates -> exact test), tiny negative masses (keys outside the screen's
+    range -> exact test) and duplicated points."""
+    import glob
+    from sober_amd import _native as nat
+    from tests.test_car_algorithm import nullspace_gebrd, pivots
+    cases = []
+    for p in sorted(glob.glob(os.path.join(GOLD, "recomb_*.npz"))):
+        z = np.load(p)
+        if "L0_X_tmp" not in z.files:
+            continue
+        for i in range(int(z["n_levels"])):
+            X, mu = z[f"L{i}_X_tmp"], z[f"L{i}_tot_weights"]
+            if X.shape[1] + 1 < X.shape[0] and nat.car_safe_supported(X.shape[0], X.shape[1] + 1):
+                cases.append((f"{os.path.basename(p)}:L{i}", X, mu, None))
+    rng = np.random.default_rng(2025)
+    for k, (N, m) in enumerate([(200, 100), (200, 100), (150, 60), (128, 64), (100, 37), (64, 20), (40, 12), (199, 99),
+                                (208, 100), (190, 80)] * 3):
+        X = rng.standard_normal((N, m - 1)) * np.exp(-0.03 * rng.random() * np.arange(m - 1))[None, :]
+        mu = rng.random(N) + 0.05
+        kind = k % 3
+        if kind == 1:
+            mu[:: 5 + k % 4] = 0.0                                         # alpha = 0 ties
+        elif kind == 2:
+            mu[3::17] = -1e-18                                             # what rounding leaves behind an exact cancellation
+            X[N // 2:N // 2 + 5] = X[:5]                                   # duplicated points
+        A = np.vstack([np.ones(N), X.T])
+        cases.append((f"random{k}:{N}x{m}:{kind}", X, mu, pivots(nullspace_gebrd(A), mu.copy()) if kind != 2 else None))
+    n_oracle = 0
+    for name, X, mu, ref in cases:
+        outs = []
+        for exact in (False, True):
+            if exact:
+                monkeypatch.setenv("SOBER_CAR_EXACT_RATIO", "1")
+            else:
+                monkeypatch.delenv("SOBER_CAR_EXACT_RATIO", raising=False)
+            nat.reload_switches()
+            outs.append(_car_once(nat, dev, X, mu))
+        (k0, w0, n0, m0), (k1, w1, n1, m1) = outs
+        assert n0 == n1 and n0 > 0, name
+        assert np.array_equal(k0, k1), name
+        assert np.array_equal(w0.view(np.int64), w1.view(np.int64)), name
+        assert np.array_equal(m0.view(np.int64), m1.view(np.int64)), name
+        if ref is not None:
+            w_np, idx_np = ref
+            assert np.array_equal(np.flatnonzero(k0 >= 0), idx_np), name
+            np.testing.assert_allclose(w0[:n0], w_np, rtol=1e-8)
+            n_oracle += 1
+    monkeypatch.delenv("SOBER_CAR_EXACT_RATIO", raising=False)
+    nat.reload_switches()
+    assert len(cases) >= 60 and n_oracle >= 20
