@@ -38,7 +38,7 @@ seg = (C.c_ulonglong * 128)()
 if hasattr(lib, "sober_debug_sp_segments") and lib.sober_debug_sp_segments(seg) == 0:
     sg = np.array(seg[:], dtype=np.float64).reshape(16, 8)[:14]           # the 14 full blocks
     per = sg.sum(0) / (14 * 7) / 100.0
-    print("inside the ratio test: divisions %.3f | keys + lane minimum %.3f | wave minimum %.3f | ballots + winner %.3f" % (per[5], per[6], per[7], per[1]))
+    print("inside the ratio test (screened form): rcp, keys, lane minimum %.3f | wave minimum %.3f | ballots, winner's lane, read-outs %.3f | the winner's two divisions %.3f" % (per[5], per[6], per[7], per[1]))
     print("produce step by segment, us per pivot (each includes one stamp's own cost): elimination behind the previous pivot + column select %.3f | "
           "ratio test %.3f | publish %.3f | weights %.3f | (block end) %.3f" % (per[0], per[1], per[2], per[3], per[4] * 7))
 rt = (C.c_ulonglong * 8)()

@@ -717,7 +717,7 @@ constexpr int SP_BAND = 4;          // screened ratio test: candidates = high wo
 // -- two lanes inside the band, a quotient that is negative, infinite or NaN (keys below 0x80100000 after the shift
 // that wraps them), no candidate -- takes the exact test below, unchanged.
 template <int NQ>
-__device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpState& st, bool exact_only, int& piv, double& al, double& rp SP_DBG_ARGS0) {
+__device__ __forceinline__ int sp_ratio_test(const double (&col)[4], const SpState& st, bool exact_only SP_DBG_ARGS0) {
     if (!exact_only) {                                                // (SOBER_CAR_EXACT_RATIO: the A/B of the tests)
         unsigned sk[4];
         unsigned smin = 0xffffffffu;
@@ -728,36 +728,26 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
             sk[q] = (col[q] > 0.0) ? k : 0xffffffffu;                        // (col is 0 on rows that are not alive)
             smin = min(smin, sk[q]);
         }
-        const unsigned H = wave_min_u32(smin);
-        if (H >= 0x80100000u && H < 0xffffffffu - (unsigned)SP_BAND) {
-            unsigned long long mb[4];
+        SP_SEG(5, "+v", smin);                                       // the screen's keys, the lane's minimum
+        unsigned H = wave_min_u32(smin);
+        SP_SEG(6, "+s", H);                                          // the wave's minimum
+        if (__builtin_expect(H >= 0x80100000u && H < 0xffffffffu - (unsigned)SP_BAND, 1)) {
+            unsigned long long mb[4] = {0ull, 0ull, 0ull, 0ull};
             int cnt = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) { mb[q] = __ballot(sk[q] <= H + (unsigned)SP_BAND); cnt += __popcll(mb[q]); }
-            if (cnt == 1) {
-                double mp = 0.0, cp = 1.0;
-                bool found = false;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if (!found && mb[q] != 0ull) {                    // uniform
-                        const int f = __ffsll((long long)mb[q]) - 1;
-                        piv = f + 64 * q;
-                        mp = rdlane(st.mu[q], f);
-                        cp = rdlane(col[q], f);
-                        found = true;
-                    }
-                }
-                al = mp / cp;
-                rp = 1.0 / cp;
-                SP_SEG(5, "+s", piv);
-                return;
+            if (__builtin_expect(cnt == 1, 1)) {                      // one bit in all: slot and lane without a branch
+                const int f = __ffsll((long long)(mb[0] | mb[1] | mb[2] | mb[3])) - 1;
+                const int kp = (mb[1] != 0ull ? 1 : 0) + (mb[2] != 0ull ? 2 : 0) + (mb[3] != 0ull ? 3 : 0);
+                return f + 64 * kp;
             }
         }
     }
-    double rt[4], rc[4];
+    // the exact test: IEEE quotients, order-preserving 64-bit keys, first index among equal ones
+    double rt[4];
     unsigned kh[4], kl[4];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { rt[q] = st.mu[q] / col[q]; rc[q] = 1.0 / col[q]; }
+    for (int q = 0; q < NQ; ++q) rt[q] = st.mu[q] / col[q];
     unsigned hmin = 0xffffffffu;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -768,9 +758,7 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
         hmin = min(hmin, kh[q]);
     }
     unsigned H = wave_min_u32(hmin);
-    SP_SEG(7, "+s", H);                                              // the exact test (rare)
-    piv = -1; al = 0.0; rp = 1.0;
-    if (H == 0xffffffffu) return;                                     // uniform: no candidate (:241-242)
+    if (H == 0xffffffffu) return -1;                                  // uniform: no candidate (:241-242)
     unsigned long long mb[4];
     int cnt = 0;
 #pragma unroll
@@ -783,17 +771,10 @@ __device__ __forceinline__ void sp_ratio_test(const double (&col)[4], const SpSt
 #pragma unroll
         for (int q = 0; q < NQ; ++q) mb[q] = __ballot((kh[q] == H) & (kl[q] == Lw));
     }
-    bool found = false;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (!found && mb[q] != 0ull) {                                // uniform
-            const int f = __ffsll((long long)mb[q]) - 1;
-            piv = f + 64 * q;
-            al = rdlane(rt[q], f);
-            rp = rdlane(rc[q], f);
-            found = true;
-        }
-    }
+    for (int q = 0; q < NQ; ++q)
+        if (mb[q] != 0ull) return __ffsll((long long)mb[q]) - 1 + 64 * q;     // uniform
+    return -1;
 }
 // mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (two roundings like the tensor expression, :253-254)
 template <int NQ>
@@ -805,34 +786,40 @@ __device__ __forceinline__ void sp_mu_step(SpState& st, const double (&col)[4], 
         st.mu[q] = sp_alive(st, q) ? __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q])) : 0.0;
     }
 }
-//   Phi[:, c] -= Phi[:, 0] * (Phi[idx, c] / Phi[idx, 0])   (:260-266), my columns J0 .. SP_BC-1
-// (the row slot of the pivot entry by a uniform switch: picking it with three selects per column makes the compiler
-//  index a copy of phi in scratch memory -- 2x slower --, picking it arithmetically with four 0/1 weights measured
-//  3.5 us per step slower than the switch)
-template <int KP, int J0>
-__device__ __forceinline__ void sp_pivot_row_kp(const double (&phi)[SP_BC][4], int lp, double (&prow)[SP_BC]) {
+// what the pivot needs from row `piv`: its entries in my columns J0 .. (and, for the wave that found it, the row's weight
+// and its entry of the pivot column) -- ONE uniform switch over the row's slot, reads only
+// (with the updates inside its cases the compiler keeps a renamed copy of phi per case and moves it back behind the
+//  switch -- 24 to 52 v_mov_b64 per pivot on the producing wave's chain; picking the slot with three selects per column
+//  makes it index a copy of phi in scratch memory -- 2x slower --, picking it arithmetically with four 0/1 weights
+//  measured 3.5 us per step slower than the switch)
+template <int KP, int J0, bool OWN>
+__device__ __forceinline__ void sp_pivot_row_kp(const double (&phi)[SP_BC][4], const SpState& st, const double (&col)[4], int lp,
+                                                double (&prow)[SP_BC], double& mp, double& cp) {
+    if constexpr (OWN) { mp = rdlane(st.mu[KP], lp); cp = rdlane(col[KP], lp); }
 #pragma unroll
     for (int j = J0; j < SP_BC; ++j) prow[j] = rdlane(phi[j][KP], lp);
 }
-// (the switch only READS: with the updates inside its cases the compiler keeps a renamed copy of phi per case and moves
-//  it back behind the switch -- 24 to 52 v_mov_b64 per pivot on the producing wave's chain)
-template <int J0, int NQ>
-__device__ __forceinline__ void sp_elim(double (&phi)[SP_BC][4], const double (&col)[4], int piv, double rpp) {
+template <int J0, int NQ, bool OWN>
+__device__ __forceinline__ void sp_pivot_row(const double (&phi)[SP_BC][4], const SpState& st, const double (&col)[4], int piv,
+                                             double (&prow)[SP_BC], double& mp, double& cp) {
     const int kp = piv >> 6, lp = piv & 63;
-    double prow[SP_BC];
     if constexpr (NQ == 1) {
-        sp_pivot_row_kp<0, J0>(phi, lp, prow);
+        sp_pivot_row_kp<0, J0, OWN>(phi, st, col, lp, prow, mp, cp);
     } else if constexpr (NQ == 2) {
-        if (kp == 0) sp_pivot_row_kp<0, J0>(phi, lp, prow);           // uniform
-        else sp_pivot_row_kp<1, J0>(phi, lp, prow);
+        if (kp == 0) sp_pivot_row_kp<0, J0, OWN>(phi, st, col, lp, prow, mp, cp);          // uniform
+        else sp_pivot_row_kp<1, J0, OWN>(phi, st, col, lp, prow, mp, cp);
     } else {
-        switch (kp) {                                                 // uniform
-            case 0: sp_pivot_row_kp<0, J0>(phi, lp, prow); break;
-            case 1: sp_pivot_row_kp<1, J0>(phi, lp, prow); break;
-            case 2: sp_pivot_row_kp<2, J0>(phi, lp, prow); break;
-            default: sp_pivot_row_kp<3, J0>(phi, lp, prow); break;
+        switch (kp) {                                                 // uniform (a two-level if tree measured 2 us slower)
+            case 0: sp_pivot_row_kp<0, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
+            case 1: sp_pivot_row_kp<1, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
+            case 2: sp_pivot_row_kp<2, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
+            default: sp_pivot_row_kp<3, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
         }
     }
+}
+//   Phi[:, c] -= Phi[:, 0] * (Phi[idx, c] / Phi[idx, 0])   (:260-266), my columns J0 .. SP_BC-1
+template <int J0, int NQ>
+__device__ __forceinline__ void sp_elim_rows(double (&phi)[SP_BC][4], const double (&col)[4], const double (&prow)[SP_BC], double rpp) {
 #pragma unroll
     for (int j = J0; j < SP_BC; ++j) {
         const double qv = prow[j] * rpp;
@@ -840,20 +827,47 @@ __device__ __forceinline__ void sp_elim(double (&phi)[SP_BC][4], const double (&
         for (int q = 0; q < NQ; ++q) phi[j][q] = fma(-qv, col[q], phi[j][q]);
     }
 }
-// wait for pivot s in the ring; false = give up (bounded)
-template <int NQ>
+template <int J0, int NQ>
+__device__ __forceinline__ void sp_elim(double (&phi)[SP_BC][4], const SpState& st, const double (&col)[4], int piv, double rpp) {
+    double prow[SP_BC], mp, cp;
+    sp_pivot_row<J0, NQ, false>(phi, st, col, piv, prow, mp, cp);
+    sp_elim_rows<J0, NQ>(phi, col, prow, rpp);
+}
+// wait for pivot s in the ring; false = give up (bounded).  {piv, tag} travel as ONE 8-byte word.
+// EAGER (the wave whose block is next: its wait IS the hand-over, on the critical chain): every poll reads the whole
+// record behind the tag word -- a wave's LDS reads return in order, so when the tag is there the data read behind it
+// is the pivot's -- instead of a second round trip after the tag has been seen; no sleep between polls.
+typedef __attribute__((address_space(3))) volatile unsigned long long sp_lds_vu64;
+typedef __attribute__((address_space(3))) unsigned long long sp_lds_u64;
+typedef __attribute__((address_space(3))) volatile double sp_lds_vf64;
+template <int NQ, bool EAGER>
 __device__ __forceinline__ bool sp_consume(SpSlot* ring, int s, int lane, double (&col)[4], double& alpha, double& rpp, int& piv) {
     SpSlot& e = ring[s % SP_RING];
-    sp_lds_vint* tg = sp_lds_v(&e.tag);
+    sp_lds_vu64* pt = (sp_lds_vu64*)&e.piv;
     unsigned spins = 0;
-    while (__builtin_amdgcn_readfirstlane(*tg) != s + 1) {           // (uniform exit: what the loop carries -- the lane masks -- stays scalar)
-        if (++spins > (1u << 24)) return false;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    alpha = e.alpha; rpp = e.rpp; piv = __builtin_amdgcn_readfirstlane(e.piv);
+    if constexpr (EAGER) {
+        sp_lds_vf64* ar = (sp_lds_vf64*)&e.alpha;
+        sp_lds_vf64* ec = (sp_lds_vf64*)&e.col[lane];
+        for (;;) {
+            const unsigned long long v = *pt;
+            alpha = ar[0]; rpp = ar[1];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) col[q] = e.col[lane + 64 * q];
-    return true;
+            for (int q = 0; q < NQ; ++q) col[q] = ec[64 * q];
+            if (__builtin_amdgcn_readfirstlane((int)(v >> 32)) == s + 1) { piv = __builtin_amdgcn_readfirstlane((int)(unsigned)v); return true; }
+            if (++spins > (1u << 24)) return false;
+        }
+    } else {
+        unsigned long long v;
+        while (v = *pt, __builtin_amdgcn_readfirstlane((int)(v >> 32)) != s + 1) {   // (uniform exit: what the loop carries -- the lane masks -- stays scalar)
+            if (++spins > (1u << 24)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        piv = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+        alpha = e.alpha; rpp = e.rpp;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) col[q] = e.col[lane + 64 * q];
+        return true;
+    }
 }
 
 // pivot `sp` from column JJ of my block: ratio test, publish, update of my weights and of my columns behind JJ
@@ -870,27 +884,35 @@ __device__ __forceinline__ void sp_produce_step(double (&phi)[SP_BC][4], SpState
 #pragma unroll
     for (int q = 0; q < NQ; ++q) col[q] = sp_alive(st, q) ? phi[JJ][q] : 0.0;
     SP_SEG(0, "+v", col[0]);                                  // (since the previous stamp: the elimination behind the last pivot)
-    int piv;
-    double al, rp;
-    sp_ratio_test<NQ>(col, st, exact_only, piv, al, rp SP_DBG_PASS);
-    SP_SEG(1, "+s", piv);                                     // ratio test: ballots, the winner's lane, its quotient
+    int piv = sp_ratio_test<NQ>(col, st, exact_only SP_DBG_PASS);
     SpSlot& e = ring[sp % SP_RING];
-    if (piv >= 0) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) e.col[lane + 64 * q] = col[q];
+    if (__builtin_expect(piv < 0, 0)) {                       // Q6: no candidate, the loop ends here (:241-242)
+        if (lane == 0) *(sp_lds_u64*)&e.piv = 0xffffffffull | ((unsigned long long)(unsigned)(sp + 1) << 32);
+        stop = true;
+        return;
     }
-    if (lane == 0) { e.alpha = al; e.rpp = rp; e.piv = piv; }
+    // the winner's row, once: its weight and pivot entry (alpha and 1 / pivot by the same two IEEE divisions whichever
+    // test found it) and its entries of my remaining columns
+    double prow[SP_BC], mp = 0.0, cp = 1.0;
+    sp_pivot_row<JJ + 1, NQ, true>(phi, st, col, piv, prow, mp, cp);
+    SP_SEG(7, "+v", cp);                                      // ballots, the winner's lane, the read-outs
+    double al = mp / cp, rp = 1.0 / cp;
+    SP_SEG(1, "+v", al);                                      // the two divisions
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) e.col[lane + 64 * q] = col[q];
 #ifdef SP_TSTAMPS
     { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) g_sp_stamps[sp] = t_; }
 #endif
     asm volatile("" ::: "memory");                            // (program order; a wave's LDS operations execute in order:
-    if (lane == 0) *(sp_lds_int*)&e.tag = sp + 1;             //  the tag lands after the data it releases -- no wait)
+    if (lane == 0) {                                          //  the tag word lands after the data it releases -- no wait)
+        e.alpha = al; e.rpp = rp;
+        *(sp_lds_u64*)&e.piv = (unsigned long long)(unsigned)piv | ((unsigned long long)(unsigned)(sp + 1) << 32);
+    }
     asm volatile("" ::: "memory");
     SP_SEG(2, "+s", piv);                                     // publish
-    if (piv < 0) { stop = true; return; }                     // Q6: the loop ends here (:241-242)
     sp_mu_step<NQ>(st, col, al, piv, lane);
     SP_SEG(3, "+v", st.mu[0]);                                // weights
-    sp_elim<JJ + 1, NQ>(phi, col, piv, rp);
+    sp_elim_rows<JJ + 1, NQ>(phi, col, prow, rp);
 }
 
 // NQ: 64-row slots in use (N <= 64 NQ): a 20-point step does not run the ratio test of a 200-point one
@@ -942,11 +964,14 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
         double al, rp;
         int piv;
         if (s == s_mine - SP_BC) __builtin_amdgcn_s_setprio(2);      // on deck: the hand-over is on the critical chain
-        if (!sp_consume<NQ>(ring, s, lane, col, al, rp, piv)) { fail = true; break; }
+        // (two copies of the wait, picked by a uniform test: the eager one only for the last SP_BC pivots before my block)
+        const bool got = (s >= s_mine - SP_BC) ? sp_consume<NQ, true>(ring, s, lane, col, al, rp, piv)
+                                               : sp_consume<NQ, false>(ring, s, lane, col, al, rp, piv);
+        if (!got) { fail = true; break; }
         if (lane == 0) prog[w] = s + 1;
         if (piv < 0) { stop = true; break; }
         sp_mu_step<NQ>(st, col, al, piv, lane);
-        sp_elim<0, NQ>(phi, col, piv, rp);
+        sp_elim<0, NQ>(phi, st, col, piv, rp);
     }
     // my block
     if (!fail && !stop && c0 < K) {
@@ -988,7 +1013,7 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
     for (int s = c0 + SP_BC; s < K && !fail && !stop; ++s) {
         double al, rp;
         int piv;
-        if (!sp_consume<NQ>(ring, s, lane, col, al, rp, piv)) { fail = true; break; }
+        if (!sp_consume<NQ, false>(ring, s, lane, col, al, rp, piv)) { fail = true; break; }
         if (lane == 0) prog[0] = s + 1;
         if (piv < 0) { stop = true; break; }
         sp_mu_step<NQ>(st, col, al, piv, lane);
