@@ -611,7 +611,7 @@ __device__ __forceinline__ unsigned long long ratio_key(double x) {
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned dpp_min_u32(unsigned v) {
-    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xf, false);   // (`old` = the identity: folds into v_min_u32_dpp)
     return o < v ? o : v;
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {        // uniform result
@@ -624,33 +624,59 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {        // uniform
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// alive[q]: rows 64 q + lane inside the step and not cancelled (Phi[idx, :] = 0 of :266: readers go through the mask) --
+// wave-uniform lane masks in scalar registers, used directly as the selects' conditions (csrc/car.hip, SpState)
 struct PivState {
     double mu[NQ];
-    bool dead[NQ];      // Phi[idx, :] = 0 of :266: the row is marked, readers go through the mask
-    bool inr[NQ];
+    unsigned long long alive[NQ];
 };
+__device__ __forceinline__ bool alive_lane(const PivState& st, int q) { return __builtin_amdgcn_inverse_ballot_w64(st.alive[q]); }
+constexpr int PV_BAND = 4;          // screened ratio test: candidates = high words within PV_BAND of the minimum
 
-// ratio test of :239-247 on column `col`: first argmin of mu / col over col > 0 (a NaN quotient wins); piv = -1: none
-__device__ __forceinline__ void ratio_test(const double (&col)[NQ], const PivState& st, int& piv, double& al, double& rp) {
-    double rt[NQ], rc[NQ];
+// ratio test of :239-247 on column `col`: the row of the first argmin of mu / col over col > 0 (a NaN quotient wins);
+// -1: none.  Screened form first (csrc/car.hip, sp_ratio_test: the same argument and the same test of the seed's
+// accuracy): high words of mu * v_rcp_f64(col); a lone candidate within PV_BAND steps of the minimum IS the exact
+// argmin; anything else -- two candidates, a negative / infinite / NaN quotient, none -- takes the exact test.
+__device__ __forceinline__ int ratio_test(const double (&col)[NQ], const PivState& st, bool exact_only) {
+    if (!exact_only) {
+        unsigned sk[NQ];
+        unsigned smin = 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double r = st.mu[q] * __builtin_amdgcn_rcp(col[q]);
+            const unsigned k = (unsigned)__double2hiint(r) + 0x80100000u;
+            sk[q] = (col[q] > 0.0) ? k : 0xffffffffu;                 // (col is 0 on rows that are not alive)
+            smin = min(smin, sk[q]);
+        }
+        const unsigned H = wave_min_u32(smin);
+        if (__builtin_expect(H >= 0x80100000u && H < 0xffffffffu - (unsigned)PV_BAND, 1)) {
+            unsigned long long any = 0ull;
+            int cnt = 0, kp = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const unsigned long long mb = __ballot(sk[q] <= H + (unsigned)PV_BAND);
+                cnt += __popcll(mb);
+                any |= mb;
+                kp += (mb != 0ull) ? q : 0;
+            }
+            if (__builtin_expect(cnt == 1, 1)) return __ffsll((long long)any) - 1 + 64 * kp;   // one bit in all: no branch
+        }
+    }
+    double rt[NQ];
     unsigned kh[NQ], kl[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        rt[q] = st.mu[q] / col[q];
-        rc[q] = 1.0 / col[q];
-    }
+    for (int q = 0; q < NQ; ++q) rt[q] = st.mu[q] / col[q];
     unsigned hmin = 0xffffffffu;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const unsigned long long k = ratio_key(rt[q]);
-        const bool ok = st.inr[q] & (col[q] > 0.0) & !st.dead[q];
+        const bool ok = col[q] > 0.0;
         kh[q] = ok ? (unsigned)(k >> 32) : 0xffffffffu;
         kl[q] = ok ? (unsigned)k : 0xffffffffu;
         hmin = min(hmin, kh[q]);
     }
     const unsigned H = wave_min_u32(hmin);
-    piv = -1; al = 0.0; rp = 1.0;
-    if (H == 0xffffffffu) return;                                     // uniform: no candidate (:241-242)
+    if (H == 0xffffffffu) return -1;                                  // uniform: no candidate (:241-242)
     unsigned long long mb[NQ];
     int cnt = 0;
 #pragma unroll
@@ -663,51 +689,62 @@ __device__ __forceinline__ void ratio_test(const double (&col)[NQ], const PivSta
 #pragma unroll
         for (int q = 0; q < NQ; ++q) mb[q] = __ballot((kh[q] == H) & (kl[q] == Lw));
     }
-    bool found = false;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (!found && mb[q] != 0ull) {                                // uniform
-            const int f = __ffsll((long long)mb[q]) - 1;
-            piv = f + 64 * q;
-            al = rdlane(rt[q], f);
-            rp = rdlane(rc[q], f);
-            found = true;
-        }
-    }
+    for (int q = 0; q < NQ; ++q)
+        if (mb[q] != 0ull) return __ffsll((long long)mb[q]) - 1 + 64 * q;     // uniform
+    return -1;
 }
 
-// mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (two roundings like the tensor expression, :253-254)
+// mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (:253-254)
 __device__ __forceinline__ void mu_step(PivState& st, const double (&col)[NQ], double alpha, int piv, int lane) {
+    const unsigned long long bit = 1ull << (piv & 63);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        st.dead[q] = st.dead[q] | (lane + 64 * q == piv);
-        st.mu[q] = st.dead[q] ? 0.0 : __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q]));
+        st.alive[q] &= ~((piv >> 6) == q ? bit : 0ull);               // scalar
+        st.mu[q] = alive_lane(st, q) ? __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q])) : 0.0;
     }
 }
 
+// what a pivot needs from row `piv`: its entries of my columns J0 .. BC-1 (and, for the wave that found it, the row's
+// weight and its entry of the pivot column) -- ONE uniform switch over the row's slot that only READS; the updates
+// follow behind it (inside the cases the compiler keeps a renamed copy of phi per case and moves it back)
+template <int KP, int J0, bool OWN>
+__device__ __forceinline__ void pivot_row_kp(const double (&phi)[BC][NQ], const PivState& st, const double (&col)[NQ], int lp,
+                                             double (&prow)[BC], double& mp, double& cp) {
+    if constexpr (OWN) { mp = rdlane(st.mu[KP], lp); cp = rdlane(col[KP], lp); }
+#pragma unroll
+    for (int j = J0; j < BC; ++j) prow[j] = rdlane(phi[j][KP], lp);
+}
+template <int J0, bool OWN>
+__device__ __forceinline__ void pivot_row(const double (&phi)[BC][NQ], const PivState& st, const double (&col)[NQ], int piv,
+                                          double (&prow)[BC], double& mp, double& cp) {
+    const int kp = piv >> 6, lp = piv & 63;
+    switch (kp) {                                                     // uniform
+        case 0: pivot_row_kp<0, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
+        case 1: pivot_row_kp<1, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
+        case 2: pivot_row_kp<2, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
+        case 3: pivot_row_kp<3, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
+        case 4: pivot_row_kp<4, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
+        case 5: pivot_row_kp<5, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
+        default: pivot_row_kp<6, J0, OWN>(phi, st, col, lp, prow, mp, cp); break;
+    }
+}
 // rank-1 elimination of my columns J0 .. BC-1 with the pivot (col, piv, rpp):
 //   Phi[:, c] -= Phi[:, 0] * (Phi[idx, c] / Phi[idx, 0])   (:260-266)
-template <int KP, int J0>
-__device__ __forceinline__ void elim_kp(double (&phi)[BC][NQ], const double (&col)[NQ], int lp, double rpp) {
+template <int J0>
+__device__ __forceinline__ void elim_rows(double (&phi)[BC][NQ], const double (&col)[NQ], const double (&prow)[BC], double rpp) {
 #pragma unroll
     for (int j = J0; j < BC; ++j) {
-        const double qv = rdlane(phi[j][KP], lp) * rpp;
+        const double qv = prow[j] * rpp;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) phi[j][q] = fma(-qv, col[q], phi[j][q]);
     }
 }
 template <int J0>
-__device__ __forceinline__ void elim(double (&phi)[BC][NQ], const double (&col)[NQ], int piv, double rpp) {
-    const int kp = piv >> 6, lp = piv & 63;
-    switch (kp) {                                                     // uniform
-        case 0: elim_kp<0, J0>(phi, col, lp, rpp); break;
-        case 1: elim_kp<1, J0>(phi, col, lp, rpp); break;
-        case 2: elim_kp<2, J0>(phi, col, lp, rpp); break;
-        case 3: elim_kp<3, J0>(phi, col, lp, rpp); break;
-        case 4: elim_kp<4, J0>(phi, col, lp, rpp); break;
-        case 5: elim_kp<5, J0>(phi, col, lp, rpp); break;
-        default: elim_kp<6, J0>(phi, col, lp, rpp); break;
-    }
+__device__ __forceinline__ void elim(double (&phi)[BC][NQ], const PivState& st, const double (&col)[NQ], int piv, double rpp) {
+    double prow[BC], mp, cp;
+    pivot_row<J0, false>(phi, st, col, piv, prow, mp, cp);
+    elim_rows<J0>(phi, col, prow, rpp);
 }
 
 // wait for pivot s: header (alpha, 1/pivot, index) and this lane's rows of the pivot column; false = give up
@@ -730,11 +767,11 @@ __device__ __forceinline__ bool consume(rsrc_t rs, int s, int lane, double (&col
         for (int q = 0; q < NQ; ++q) gc[q] = load_granule(rs, coff + (unsigned)q * 1024u);
         const bool okh = granule_ok(h0, tag) && granule_ok(h1, tag) && granule_ok(h2, tag);
         alpha = granule_val(h0); rpp = granule_val(h1);
-        piv = okh ? (int)granule_val(h2) : 0;
+        piv = okh ? (int)granule_val(h2) : 0;                          // (the same in every lane; made scalar below)
         bool ok = okh;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { ok &= granule_ok(gc[q], tag) | (piv < 0); col[q] = granule_val(gc[q]); }
-        if (__all(ok)) return true;
+        if (__all(ok)) { piv = __builtin_amdgcn_readfirstlane(piv); return true; }
         if (spin_fail(rs, spins, 0x500u + (unsigned)s)) return false;
         asm volatile("" ::: "memory");
     }
@@ -756,9 +793,9 @@ __device__ __forceinline__ void publish(rsrc_t rs, int s, int lane, const double
     }
 }
 
-// my next column (register slot 0) is the pivot column: ratio test, publish, update the weights and my later
-// columns, then the slots move down by one.  A LOOP body on purpose: written out per column the kernel is 16 copies
-// of the ratio test, every one executed once and fetched cold.
+// column JJ of my block is the pivot column: ratio test, the winner's row read once, publish, update of the weights and
+// of my later columns.  One instance per column (the columns keep their registers): the loop form of rounds 2-4 moved
+// the seven later columns down by one slot behind every pivot -- 49 v_mov_b64 on the producing wave's chain.
 #ifdef MC_STAMPS
 #define MC_PSTAMP_ARGS , unsigned long long (&acc_)[12], unsigned long long& tl_
 #define MC_PSTAMP_PASS , acc_, tl_
@@ -769,16 +806,16 @@ __device__ __forceinline__ void publish(rsrc_t rs, int s, int lane, const double
 #ifdef MC_TSTAMPS      // diagnostic build (scripts/pivot_stamps.py mc): s_memrealtime (100 MHz) of every publish, by pivot index
 __device__ unsigned long long g_mc_stamps[260];
 #endif
-__device__ __forceinline__ bool produce(double (&phi)[BC][NQ], PivState& st, rsrc_t rs, int s, int lane MC_PSTAMP_ARGS) {
+template <int JJ>
+__device__ __forceinline__ bool produce(double (&phi)[BC][NQ], PivState& st, rsrc_t rs, int s, int lane, bool exact_only MC_PSTAMP_ARGS) {
     double col[NQ];
     MC_STAMP(0);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) col[q] = (st.dead[q] | !st.inr[q]) ? 0.0 : phi[0][q];
-    int piv;
-    double al, rp;
-    // (a reciprocal-based pre-selection with exact division for the winner only was measured slower: 302 vs 257 us
-    //  at 200 pivots -- the seven IEEE divisions pipeline well, the extra selection logic does not)
-    ratio_test(col, st, piv, al, rp);
+    for (int q = 0; q < NQ; ++q) col[q] = alive_lane(st, q) ? phi[JJ][q] : 0.0;
+    const int piv = ratio_test(col, st, exact_only);
+    double prow[BC], mp = 0.0, cp = 1.0;
+    if (piv >= 0) pivot_row<JJ + 1, true>(phi, st, col, piv, prow, mp, cp);
+    const double al = mp / cp, rp = 1.0 / cp;                         // (alpha and 1 / pivot: the same two divisions whichever test found the row)
     MC_STAMP(1);
     publish(rs, s, lane, col, al, rp, piv);
 #ifdef MC_TSTAMPS
@@ -787,13 +824,7 @@ __device__ __forceinline__ bool produce(double (&phi)[BC][NQ], PivState& st, rsr
     MC_STAMP(2);
     if (piv < 0) return false;                                        // Q6: the loop ends here (:241-242)
     mu_step(st, col, al, piv, lane);
-    elim<1>(phi, col, piv, rp);                                       // (consumed slots hold zeros and stay zero)
-#pragma unroll
-    for (int j = 0; j + 1 < BC; ++j)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) phi[j][q] = phi[j + 1][q];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) phi[BC - 1][q] = 0.0;
+    elim_rows<JJ + 1>(phi, col, prow, rp);
     MC_STAMP(3);
     return true;
 }
@@ -802,7 +833,7 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
                                                   const double* __restrict__ mu_in, int32_t* __restrict__ keep_rank,
                                                   double* __restrict__ w_star, int32_t* __restrict__ n_keep_out,
                                                   double* __restrict__ mu_out, void* comm, unsigned cbytes,
-                                                  unsigned long long* dbg, int phi_groups) {
+                                                  unsigned long long* dbg, int phi_groups, int exact_ratio) {
     __shared__ int lcu;
     const int lane = threadIdx.x & 63;
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(comm, 0, (int)cbytes, 0x00020000);
@@ -822,9 +853,9 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int row = lane + 64 * q;
-        st.inr[q] = row < N;
-        st.dead[q] = false;
-        st.mu[q] = st.inr[q] ? mu_in[row] + 0.0 : 0.0;
+        const int nq = min(max(N - 64 * q, 0), 64);
+        st.alive[q] = nq >= 64 ? ~0ull : ((1ull << nq) - 1ull);
+        st.mu[q] = row < N ? mu_in[row] + 0.0 : 0.0;
 #pragma unroll
         for (int j = 0; j < BC; ++j) phi[j][q] = (c0 + j < K && row < N) ? PhiT[(size_t)(c0 + j) * NS + row] : 0.0;
     }
@@ -845,14 +876,18 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
         if (s + 1 == min(c0, K)) MC_STAMP(6); else MC_STAMP(5);       // 6: the wait for the hand-over
         if (piv < 0) { stop = true; break; }
         mu_step(st, col, al, piv, lane);
-        elim<0>(phi, col, piv, rp);
+        elim<0>(phi, st, col, piv, rp);
         MC_STAMP(7);
     }
     // my block
     if (!fail && !stop && c0 < K) {
         bool go = true;
         const int s_end = min(c0 + BC, K);
-        for (int sp = c0; sp < s_end && go; ++sp) go = produce(phi, st, rs, sp, lane MC_PSTAMP_PASS);
+        int sp = c0;
+#define MC_STEP(JJ) if (sp < s_end && go) { go = produce<JJ>(phi, st, rs, sp, lane, exact_ratio != 0 MC_PSTAMP_PASS); ++sp; }
+        MC_STEP(0) MC_STEP(1) MC_STEP(2) MC_STEP(3) MC_STEP(4) MC_STEP(5) MC_STEP(6) MC_STEP(7)
+#undef MC_STEP
+        static_assert(BC == 8, "one MC_STEP per column of a block");
         stop = !go;
     }
     MC_STAMP_FLUSH(dbg, 256 + gw);
@@ -959,7 +994,7 @@ extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_mc_pivot, dim3(ELECT_GRID), dim3(256), 0, st, PhiT, N, m, mu_in, keep_rank, w_star, n_keep,
-                       mu_out, ws, cbytes, dbg, fused ? (NS + 4 * PHI_RW - 1) / (4 * PHI_RW) : 0);
+                       mu_out, ws, cbytes, dbg, fused ? (NS + 4 * PHI_RW - 1) / (4 * PHI_RW) : 0, (int)sober::switches().car_exact_ratio);
     LAUNCH_CHECK();
     if (sober_car_giveup_forced()) {                        // (test switch: what a give-up of the exchange reports)
         hipLaunchKernelGGL(k_mc_report_giveup, dim3(1), dim3(64), 0, st, n_keep);

@@ -154,7 +154,8 @@ def test_screened_ratio_test_is_the_exact_one_bit_for_bit(dev, monkeypatch):
     """SOBER_CAR_EXACT_RATIO=1 switches the screened fast path of the pivots' ratio test off (four IEEE divisions and
     64-bit keys per pivot, the round-2..4 form).  The screen only ever picks the lane the exact test would pick and
     computes alpha and 1 / pivot for it with the same two divisions, so EVERY output must be bit-identical: kept ranks,
-    weights, the full weight vector -- on the reference's level inputs, on random steps of every one-CU size class, with
+    weights, the full weight vector -- on the reference's level inputs, on random steps of every one-CU size class and of
+    the multi-CU kernels' sizes (csrc/car_mc.hip: the same screen), with
     zero masses (alpha = 0 ties -> several candidates -> exact test), tiny negative masses (keys outside the screen's
     range -> exact test) and duplicated points."""
     import glob
@@ -171,7 +172,7 @@ def test_screened_ratio_test_is_the_exact_one_bit_for_bit(dev, monkeypatch):
                 cases.append((f"{os.path.basename(p)}:L{i}", X, mu, None))
     rng = np.random.default_rng(2025)
     for k, (N, m) in enumerate([(200, 100), (200, 100), (150, 60), (128, 64), (100, 37), (64, 20), (40, 12), (199, 99),
-                                (208, 100), (190, 80)] * 3):
+                                (208, 100), (190, 80), (400, 200), (300, 180), (448, 230), (260, 40)] * 3):
         X = rng.standard_normal((N, m - 1)) * np.exp(-0.03 * rng.random() * np.arange(m - 1))[None, :]
         mu = rng.random(N) + 0.05
         kind = k % 3
@@ -204,4 +205,4 @@ def test_screened_ratio_test_is_the_exact_one_bit_for_bit(dev, monkeypatch):
             n_oracle += 1
     monkeypatch.delenv("SOBER_CAR_EXACT_RATIO", raising=False)
     nat.reload_switches()
-    assert len(cases) >= 60 and n_oracle >= 20
+    assert len(cases) >= 70 and n_oracle >= 24
