@@ -93,7 +93,7 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
             NX_TRY(sober_cholesky_probe_piv(j->C, M, M, j->shifts, n_r, j->chol_work, flags + 2, pivots, stream));
         }
         NX_TRY(sober_jitter_ladder_auto(j->C, M, M, flags + 2, n_r, flags + 1, stream));
-        NX_TRY(sober_diag_spread(j->C, M, M, flags + 1, n_r, NX_DIAG_KAPPA, skip_ok, stream));
+        if (j->skip_passes != 0) NX_TRY(sober_diag_spread(j->C, M, M, flags + 1, n_r, NX_DIAG_KAPPA, skip_ok, stream));   // (opt-in: one dispatch of the chain)
     }
     if (phase == 1) return 0;       // (the caller's host work -- stepping the generator for R -- overlaps with the probes)
     // ---- the range finder of torch.svd_lowrank (Halko et al. Alg. 4.4, torch/_lowrank.py:64-79): only range(Q) of the
