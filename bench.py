@@ -72,9 +72,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
 FP4_PEAK_TOPS = 10000.0          # dense FP4 / FP6 MFMA (block-scaled f8f6f4 form) = 4 x the bf16 rate (MI355X_MICROARCH.md, matrix cores)
 CK = {"rbf": 28, "matern52": 40}
 # What the FP64 units of an MI355X sustain chip-wide (scripts/dp_rate_probe.hip, wall clock, all 256 CUs; committed
-# output: profiles/r04_dp_rate.txt, first taken in round 3: profiles/r03_dp_rate.txt): the clock under FP64 load is ~1.9 GHz, not the 2.4 GHz of the vendor figure.
+# output: profiles/r05_dp_rate.txt, first taken in round 3: profiles/r03_dp_rate.txt): the clock under FP64 load is ~1.9 GHz, not the 2.4 GHz of the vendor figure.
 FP64_MEASURED_TFLOPS = {"v_fma_f64": 61.0, "v_mfma_f64_16x16x4": 63.0, "level-kernel mix (12 MFMA + 160 FMA)": 69.0,
-                        "source": "profiles/r04_dp_rate.txt"}
+                        "source": "profiles/r05_dp_rate.txt"}
 
 
 def pmc_traffic(config):
