@@ -160,38 +160,12 @@ __host__ __device__ inline int level_parts_mfma_cap(int n_rows, int64_t e_total,
 // Branch-free (a taken branch costs a single resident wave 50-80 cycles of instruction fetch): operands far outside the
 // normal range are rescaled by 2^(+-300) with selects, ss = 0 gives the identity (tau = 0).
 // -- one refined rsq, one fma, one refined rcp of a number in [1, 2]: 15 dependent operations instead of 23
-// Round 5: the rescaling (a compare, two selects, two products and an fma in front of the rsq -- six dependent
-// operations at ~20 cycles each on the critical path of EVERY reflector) runs only where it is needed: a wave whose
-// lanes all hold a norm^2 in [1e-200, 1e200] -- every reflector of every run so far -- starts the rsq on the unscaled
-// value (issued BEFORE the wave-uniform test, whose latency it hides) and computes exactly what the scaled sequence
-// computes with f = 1: bit-identical.  (-DSOBER_LARFG_ALWAYS_SCALED: the form of rounds 2-4, for A/Bs.)
+// (Round 5: the rescaling kept off the common path -- the rsq started on the unscaled norm^2 in front of a wave-uniform
+//  test, the scaled sequence only for tiny / huge / NaN operands; bit-identical by construction and on 103 steps -- measured
+//  184.7 against 183.1 us for the 200 x 100 bidiagonalisation: the five dependent operations it removes are not what the
+//  step waits for, the branch costs more.  Dropped; scripts/car_ab3.sh has the A/B.)
 __device__ __forceinline__ void larfg_vt(double alpha, double ss, double& tau, double& scal) {
     const double n2r = fma(alpha, alpha, ss);
-#ifndef SOBER_LARFG_ALWAYS_SCALED
-    {
-        double r = __builtin_amdgcn_rsq(n2r);
-        asm volatile("" : "+v"(r));                                  // (pinned in front of the test: the compiler sinks it behind the branch otherwise)
-        const bool odd = !((n2r >= 1e-200) & (n2r <= 1e200));        // tiny, huge, NaN
-        if (__builtin_expect(__ballot(odd) == 0ull, 1)) {
-            double h = 0.5 * r;
-            double e = fma(-(n2r * r), h, 0.5);
-            r = fma(r, e, r);
-            h = 0.5 * r;
-            e = fma(-(n2r * r), h, 0.5);
-            r = fma(r, e, r);
-            const double t = fma(fabs(alpha), r, 1.0);
-            double y = __builtin_amdgcn_rcp(t);
-            e = fma(-t, y, 1.0);
-            y = fma(y, e, y);
-            e = fma(-t, y, 1.0);
-            y = fma(y, e, y);
-            const bool none = ss == 0.0;
-            tau = none ? 0.0 : t;
-            scal = none ? 0.0 : copysign(r * y, alpha);
-            return;
-        }
-    }
-#endif
     const bool tiny = n2r < 1e-200, huge = n2r > 1e200;
     const double f = tiny ? 0x1p300 : (huge ? 0x1p-300 : 1.0);
     const double al = alpha * f;
