@@ -776,7 +776,8 @@ __device__ __forceinline__ int sp_ratio_test(const double (&col)[4], const SpSta
         if (mb[q] != 0ull) return __ffsll((long long)mb[q]) - 1 + 64 * q;     // uniform
     return -1;
 }
-// mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (two roundings like the tensor expression, :253-254)
+// mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (:253-254; the product and the subtraction contract to ONE fma under
+// -ffp-contract=fast -- half an ulp from the tensor expression's two roundings, inside what the parity tests bound)
 template <int NQ>
 __device__ __forceinline__ void sp_mu_step(SpState& st, const double (&col)[4], double alpha, int piv, int lane) {
     const unsigned long long bit = 1ull << (piv & 63);
@@ -1082,7 +1083,7 @@ __global__ __launch_bounds__(512) void k_second_elim(const double* __restrict__ 
     __shared__ double s_al;
     if (t == piv) s_al = al;
     __syncthreads();
-    // w_star = w_star - alpha[idx_sp] * w_null; w_star[idx_sp] = 0   (two roundings, :99-100)
+    // w_star = w_star - alpha[idx_sp] * w_null; w_star[idx_sp] = 0   (:99-100; one fma under -ffp-contract=fast)
     double w2 = w;
     if (any && t < n1) w2 = (t == piv) ? 0.0 : __dsub_rn(w, __dmul_rn(s_al, wn));
     const bool keep = t < n1 && w2 > 0.0;

@@ -695,7 +695,7 @@ __device__ __forceinline__ int ratio_test(const double (&col)[NQ], const PivStat
     return -1;
 }
 
-// mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (:253-254)
+// mu[:] = mu - alpha * Phi[:, 0]; mu[idx] = 0  (:253-254; one fma under -ffp-contract=fast, like csrc/car.hip)
 __device__ __forceinline__ void mu_step(PivState& st, const double (&col)[NQ], double alpha, int piv, int lane) {
     const unsigned long long bit = 1ull << (piv & 63);
 #pragma unroll
