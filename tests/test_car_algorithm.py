@@ -249,3 +249,43 @@ def test_gram_route_gives_the_dgebd2_basis(path):
         assert np.abs(w1 - w0).max() <= 1e-8 * np.abs(w0).max(), (i, np.abs(w1 - w0).max() / np.abs(w0).max())
         n_checked += 1
     assert n_checked >= 1
+
+
+def test_screened_ratio_test_accepts_only_the_exact_argmin():
+    """The argument behind the pivot kernels' screened ratio test (csrc/car.hip sp_ratio_test, csrc/car_mc.hip ratio_test),
+    restated in numpy: keys are the HIGH WORDS of approximate quotients q~ = mu * r~ with |r~ col - 1| <= e (the v_rcp_f64
+    seed: e = 2^-24.4 measured on the device, the band is laid out for 2^-22), a lone candidate within BAND = 4 key steps of
+    the minimum is accepted.  Property: whatever the errors do inside that bound, an accepted candidate IS the exact
+    argmin of mu / col over col > 0 -- on random columns and on adversarial ones whose two smallest quotients lie
+    2^-26 .. 2^-17 apart (where the screen must either pick the right one or decline)."""
+    rng = np.random.default_rng(5)
+    BAND, E = 4, 2.0 ** -22
+    accepted = declined = 0
+    for trial in range(4000):
+        n = int(rng.integers(4, 257))
+        col = rng.standard_normal(n) * np.exp(rng.uniform(-6, 6, n))
+        mu = rng.random(n) * np.exp(rng.uniform(-8, 2, n))
+        pos = np.flatnonzero(col > 0)
+        if len(pos) < 2:
+            continue
+        if trial % 2:                                                  # plant a near tie at the minimum
+            q = mu[pos] / col[pos]
+            i, j = pos[np.argsort(q)[:2]]
+            mu[j] = (mu[i] / col[i]) * col[j] * (1.0 + 2.0 ** -rng.uniform(17, 26))
+        exact = np.where(col > 0, mu / np.where(col > 0, col, 1.0), np.inf)
+        want = int(np.argmin(exact))
+        rt = (1.0 / np.where(col > 0, col, 1.0)) * (1.0 + rng.uniform(-E, E, n))      # the seed, anywhere inside its bound
+        qa = mu * rt
+        hi = (qa.view(np.uint64) >> np.uint64(32)).astype(np.uint64)
+        key = np.where(col > 0, (hi + np.uint64(0x80100000)) & np.uint64(0xFFFFFFFF), np.uint64(0xFFFFFFFF))
+        H = key.min()
+        if not (0x80100000 <= H < 0xFFFFFFFF - BAND):
+            declined += 1
+            continue
+        cand = np.flatnonzero(key <= H + BAND)
+        if len(cand) != 1:
+            declined += 1
+            continue
+        accepted += 1
+        assert int(cand[0]) == want, (trial, cand, want)
+    assert accepted > 1500 and declined > 200, (accepted, declined)
