@@ -404,10 +404,16 @@ __device__ __forceinline__ bool bidiag_steps(double (&a)[CPW][RS], double (&r)[C
         __builtin_amdgcn_wave_barrier();
         MC_STAMP(7);
         // ---- 7. both rank-1 updates fused: A <- A - tau w [1; v]^T - tauq u z'^T,  z' = z - tau (u^T w) [1; v]
-        const double tuw = tau * uw;
+        const double tuw = tau * uw, ntuw = -tuw;
 #define MC_UPDATE(J)                                                                       \
         {                                                                                  \
-            const double zj_ = fma(-tuw, r[J], rdlane(acc, J));                            \
+            /* z_J straight from the scalar pair the read-out leaves (the compiler moves it into a vector register */ \
+            /* first to use the two-operand fmac: two v_mov per column) */                 \
+            double zj_;                                                                    \
+            {                                                                              \
+                const double aj_ = rdlane(acc, J);                                         \
+                asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zj_) : "v"(ntuw), "v"(r[J]), "s"(aj_)); \
+            }                                                                              \
             _Pragma("unroll") for (int s = SL; s < RS; ++s) a[J][s] = fma(-tu[s], zj_, fma(-tw[s], r[J], a[J][s])); \
         }
         MC_FOR_LIVE(nlive, MC_UPDATE);
