@@ -784,7 +784,10 @@ __device__ __forceinline__ void sp_mu_step(SpState& st, const double (&col)[4], 
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         st.alive[q] &= ~((piv >> 6) == q ? bit : 0ull);               // scalar
-        st.mu[q] = sp_alive(st, q) ? __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q])) : 0.0;
+        // (no select: col is 0 on cancelled rows, so their weights stay what they are; the row cancelled NOW keeps a
+        //  rounding residue instead of the 0 of :254 -- nobody reads it again, its col is 0 from here on, and the
+        //  output applies the mask)
+        st.mu[q] = __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q]));
     }
 }
 // what the pivot needs from row `piv`: its entries in my columns J0 .. (and, for the wave that found it, the row's weight
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int row = lane + 64 * q;
-        const double v = (row < N) ? st.mu[q] + 0.0 : 0.0;           // -0.0 -> +0.0
+        const double v = sp_alive(st, q) ? st.mu[q] + 0.0 : 0.0;     // mu[idx] = 0 of :254 for every cancelled row; -0.0 -> +0.0
         const bool keep = (row < N) && (v > 0.0);
         const unsigned long long bal = __ballot(keep);
         const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));

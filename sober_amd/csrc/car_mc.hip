@@ -226,10 +226,12 @@ struct BidiagLds {
 
 // BODY(j) for the live register slots j = 0 .. nlive-1, written out (an early exit inside `#pragma unroll` keeps the
 // loop rolled and the arrays in scratch): not-taken compares while live, ONE taken branch at the first dead slot
+// (slots 0 .. 4 are ALWAYS live: nlive = CPW - ((i - gw) / NW + 1) >= 13 - (255 / 36 + 1) = 5 for every step i < m <= 64 RS_MAX
+//  = 256 -- sober_car_mc_supported -- so their five compare + branch pairs per use, 25 pairs per step, are not emitted)
+static_assert(CPW - ((64 * RS_MAX - 1) / NW + 1) >= 5, "MC_FOR_LIVE runs slots 0 .. 4 unconditionally");
 #define MC_FOR_LIVE(NL, BODY)                                                                      \
     do {                                                                                           \
-        if ((NL) <= 0) break; BODY(0)  if ((NL) <= 1) break; BODY(1)  if ((NL) <= 2) break; BODY(2)   \
-        if ((NL) <= 3) break; BODY(3)  if ((NL) <= 4) break; BODY(4)  if ((NL) <= 5) break; BODY(5)   \
+        BODY(0) BODY(1) BODY(2) BODY(3) BODY(4)  if ((NL) <= 5) break; BODY(5)                       \
         if ((NL) <= 6) break; BODY(6)  if ((NL) <= 7) break; BODY(7)  if ((NL) <= 8) break; BODY(8)   \
         if ((NL) <= 9) break; BODY(9)  if ((NL) <= 10) break; BODY(10) if ((NL) <= 11) break; BODY(11) \
         if ((NL) <= 12) break; BODY(12)                                                            \
@@ -707,7 +709,7 @@ __device__ __forceinline__ void mu_step(PivState& st, const double (&col)[NQ], d
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         st.alive[q] &= ~((piv >> 6) == q ? bit : 0ull);               // scalar
-        st.mu[q] = alive_lane(st, q) ? __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q])) : 0.0;
+        st.mu[q] = __dsub_rn(st.mu[q], __dmul_rn(alpha, col[q]));   // (no select: csrc/car.hip sp_mu_step; the output applies the mask)
     }
 }
 
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(256) void k_mc_pivot(const double* __restrict__ Phi
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int row = lane + 64 * q;
-        const double v = (row < N) ? st.mu[q] + 0.0 : 0.0;
+        const double v = alive_lane(st, q) ? st.mu[q] + 0.0 : 0.0;    // mu[idx] = 0 of :254 for every cancelled row
         const bool keep = (row < N) && (v > 0.0);
         const unsigned long long bal = __ballot(keep);
         const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
