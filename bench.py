@@ -439,7 +439,9 @@ def main():
 
     def step(tm=None):
         mu.copy_(mu0)
-        torch.manual_seed(SEED_CALL)
+        # (the path draws from the CPU generator only -- svd_lowrank's randn, like the reference; torch.manual_seed would also
+        #  walk the device generators: 19 us of bench bookkeeping per step against 1 us, scripts/bench_overheads.py)
+        torch.default_generator.manual_seed(SEED_CALL)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             return sober_amd.recombination(X_cand, X_nys, b, kernel, dev, torch.double, init_weights=mu,
