@@ -1,7 +1,11 @@
 """GPU tests added in round 5 (run with -m gpu on an MI355X), all through the C ABI:
   * the SHIPPED KMeans path (E step screened on the BF16 matrix cores, the default at cfg-2 / cfg-4 shapes) against labels
     and centroids the REFERENCE's own KMeans produced on such a shape (tests/golden/kmeans_screened.npz), not only against
-    the device's exact kernel."""
+    the device's exact kernel;
+  * the opt-in Gram route of the Caratheodory step against the default one on the reference's level inputs;
+  * the fused GP prediction kernel (csrc/predict.hip) against the materialised route and the oracle;
+  * the pivots' screened ratio test: the accuracy of the v_rcp_f64 seed it rests on, and bit equality of every output with the
+    exact test (kernel level: 75+ steps incl. ties, negative masses, multi-CU sizes; whole sampling steps)."""
 import os
 
 import numpy as np
@@ -206,3 +210,30 @@ def test_screened_ratio_test_is_the_exact_one_bit_for_bit(dev, monkeypatch):
     monkeypatch.delenv("SOBER_CAR_EXACT_RATIO", raising=False)
     nat.reload_switches()
     assert len(cases) >= 70 and n_oracle >= 24
+
+
+def test_whole_steps_with_and_without_the_screen_are_bit_equal(dev, monkeypatch):
+    """The same A/B one level up: sampling steps through the queued level loop and the final level (cfg-2's golden, a Matern
+    one with batch 100, a batch-200 step on the multi-CU kernels, a calc_obj one) with SOBER_CAR_EXACT_RATIO on and off --
+    identical indices, weights and mutated init_weights, bit for bit."""
+    import glob
+    from sober_amd import _native as nat
+    from tests.test_hip_parity import run_hip
+    names = ["recomb_cfg2_rbf.npz", "recomb_matern_medium.npz", "recomb_rbf_medium.npz"]
+    names += [os.path.basename(p) for p in sorted(glob.glob(os.path.join(GOLD, "recomb_*calc_obj*.npz")))[:1]]
+    for name in names:
+        path = os.path.join(GOLD, name)
+        if not os.path.exists(path):
+            continue
+        out = []
+        for exact in (False, True):
+            if exact:
+                monkeypatch.setenv("SOBER_CAR_EXACT_RATIO", "1")
+            else:
+                monkeypatch.delenv("SOBER_CAR_EXACT_RATIO", raising=False)
+            nat.reload_switches()
+            _, _, _, idx, w, mu = run_hip(path, dev)
+            out.append((idx, w, mu))
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2]), name
+    monkeypatch.delenv("SOBER_CAR_EXACT_RATIO", raising=False)
+    nat.reload_switches()
