@@ -26,7 +26,7 @@ def child(d, n, n_rows, S, P):
     E = n // S
     if P == 0: P = nat.level_parts_mfma(n_rows, 0, n, S)
     def run():
-        nat.level_reduce_mfma(0, rows, cand, da, idx, 0, 0, n, S, mu, None, 1.3, P, partG, S, 0, partTot, E * S)
+        nat.level_reduce_mfma(int(os.environ.get("LK_KIND", "0")), rows, cand, da, idx, 0, 0, n, S, mu, None, 1.3, P, partG, S, 0, partTot, E * S)   # LK_KIND=1: Matern-5/2
     for _ in range(3): run()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
