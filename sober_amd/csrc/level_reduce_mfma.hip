@@ -179,6 +179,12 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
             const double4_t c_ = ccv[Q][t];                                                \
             kern_from_arg4<KIND, (KT <= 2)>(c_, s_T, k_);                                             \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[t][r] = fma(k_[r], wcv[Q], acc[t][r]); \
+            /* the vector work of a row tile stays inside its tile (four chains are enough to keep the pipe fed), the matrix */ \
+            /* instructions may still cross: with all 16 values of an element in flight three instantiations spilled -- RBF */ \
+            /* KT = 4 / 5, Matern KT = 3: 12 / 148 / 56 bytes of scratch, reloaded in the hot loop; d = 15..18 ran 6 % SLOWER */ \
+            /* than d = 20 -- and the others sat at 244-256 registers.  Round 5: -11..-14 % on the spilling ones, -0.4..-4 % */ \
+            /* on the rest (scripts/level_kernel_sweep.py), same arithmetic */                 \
+            __builtin_amdgcn_sched_barrier(0x0008);                                        \
         }                                                                                  \
         LW_INTERLEAVE                                                                      \
     }
