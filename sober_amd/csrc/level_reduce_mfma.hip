@@ -177,7 +177,7 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                    \
             double k_[4];                                                                  \
             const double4_t c_ = ccv[Q][t];                                                \
-            kern_from_arg4<KIND, (KT <= 2)>(c_, s_T, k_);                                             \
+            kern_from_arg4<KIND>(c_, s_T, k_);                                             \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[t][r] = fma(k_[r], wcv[Q], acc[t][r]); \
             /* the vector work of a row tile stays inside its tile (four chains are enough to keep the pipe fed), the matrix */ \
             /* instructions may still cross: with all 16 values of an element in flight three instantiations spilled -- RBF */ \
