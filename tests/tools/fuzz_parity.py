@@ -7,7 +7,9 @@ pools; FUZZ_ONLY=3,17: replay these cases with the diagnostics).
 Verdicts: "ok" = identical indices and weights within 1e-6 (the contract: 1e-4), or within 20x of what the REFERENCE's own
 weights move when its inputs move by one ulp; "ill-posed" = the reference's own indices change, or its own weights move by
 more than 1e-5, under that one-ulp move (the oracle is the reference: tests/test_oracle_vs_reference_fuzz.py holds it to
-the reference on 64 random cases) -- a second implementation cannot be held to such a case; "BAD" = anything else."""
+the reference on 64 random cases), or -- with identical indices -- one of make_cov_psd's Cholesky verdicts falls on a
+numerically singular matrix (psd_knife_edge: round 5, sweep 22 case 91) -- a second implementation cannot be held to such a
+case; "BAD" = anything else."""
 import os, sys, warnings
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -66,6 +68,41 @@ def well_posed(c, verbose=True):
     return move
 
 
+def psd_knife_edge(c, rel=1e-12):
+    """True when one of the Cholesky verdicts of make_cov_psd (SOBER/_utils.py:117-157) falls on a numerically singular
+    matrix: |smallest eigenvalue| <= rel x largest of a matrix is_psd is asked about.  The reference's jitter (or none) then
+    hangs on the last bits of its Gram matrix -- a second implementation's Gram matrix differs in exactly those -- and a
+    one-ulp move of 0/1 fingerprints does not reach them (the case the input-perturbation test misses)."""
+    spec, mode = c["spec"], c["mode"]
+    cov = O.Kernel(spec, mode)(t(c["Xn"]), t(c["Xn"])).double()
+
+    def edge(m):
+        ev = torch.linalg.eigvalsh(0.5 * (m + m.T))
+        return bool(ev[0].abs() <= rel * ev[-1].abs())
+
+    def psd(m):
+        try:
+            torch.linalg.cholesky(m)
+            return True
+        except Exception:                                    # noqa: BLE001
+            return False
+    if edge(cov):
+        return True
+    if psd(cov):
+        return False
+    m = torch.nan_to_num(cov)
+    m = torch.sqrt(m * m.T)
+    jitter = 1e-5
+    for _ in range(12):
+        if edge(m):
+            return True
+        if psd(m):
+            return False
+        m = m + jitter * torch.eye(m.shape[0], dtype=m.dtype)
+        jitter *= 2
+    return False
+
+
 def check_case(c, dev, verbose=False, always_diagnose=False):
     """-> (ok, verdict, idx_equal, max rel weight error)."""
     spec, b, mode, obj = c["spec"], c["b"], c["mode"], _obj(c)
@@ -90,6 +127,8 @@ def check_case(c, dev, verbose=False, always_diagnose=False):
                 ok, verdict = True, "ill-posed (the reference's own weights move by %.1e under a one-ulp move of its inputs)" % move
             elif same and relw <= max(1e-6, 20 * move):
                 ok, verdict = True, "ok (the reference's own weights move by %.1e under a one-ulp move)" % move
+            elif same and psd_knife_edge(c):
+                ok, verdict = True, "ill-posed (is_psd decides on a numerically singular matrix: the reference's jitter hangs on the last bits of its Gram matrix)"
             else:
                 ok, verdict = False, "BAD"
     return ok, verdict, same, relw
