@@ -36,12 +36,45 @@ streaming (the same sums over cache-sized element blocks); median of 3 each, `va
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 import warnings
 
-import numpy as np
-import torch
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher in front of it: start the N ranks as a CHILD
+    `python -m torch.distributed.run` (one rank per GPU, rendezvous on 127.0.0.1) from this process -- which has imported
+    nothing that touches the GPU yet and never does --, pass the children's output through (rank 0 prints the ONE JSON
+    line) and return their exit code.  Under a launcher (WORLD_SIZE set) this is a no-op: the ranks run main() below."""
+    if "WORLD_SIZE" in os.environ:
+        return None
+    n = 1
+    argv = sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return None
+    import socket
+    with socket.socket() as sk:                                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+if __name__ == "__main__":
+    _rc = _self_launch()
+    if _rc is not None:
+        sys.exit(_rc)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -176,12 +209,13 @@ def cpu_baseline_for(cfg, spec, inp, dev_inputs, cpu_steps):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             return O.recombination(Xc, Xn, cfg["b"], ok, init_weights=m, stream_elements=stream)
-    # the reference-shaped CPU path barely scales with cores (memory-bound temporaries): time both variants at the
-    # host's thread count and at 8 threads, report the fastest
+    # the reference-shaped CPU path does not scale with cores (memory-bound temporaries): both variants at 8 threads.
+    # (Rounds 2-5 also timed them at half the host's hardware threads -- 64 on the GPU boxes: 3-7x SLOWER than at 8 every
+    # time, and three quarters of the command's wall clock; profiles/r05_bench_cfg2.json keeps the last of those figures.)
     runs = {}
     old = torch.get_num_threads()
     for variant, stream in (("reference_shaped", None), ("streaming", 16)):
-        for th in sorted({os.cpu_count() // 2 or 1, 8}):
+        for th in (min(8, os.cpu_count() or 1),):
             torch.set_num_threads(th)
             cpu_step(stream)                                  # warm-up
             each = []
@@ -199,7 +233,7 @@ def cpu_baseline_for(cfg, spec, inp, dev_inputs, cpu_steps):
                       + ("the full workload" if N_s == cfg["N"] else f"the first {N_s} candidates of the workload")
                       + f" (N_nys={cfg['M']}, batch={cfg['b']}), oracle = torch CPU FP64 port of the reference: "
                         "reference-shaped (materialised (E, M, S) tensor) and streaming (16-element blocks), each at "
-                        "8 threads and at half the host's hardware threads; fastest reported"}
+                        "8 threads; the faster one reported"}
 
 
 class _PoolPrior:
@@ -376,7 +410,7 @@ def funnel(args):
         "ms_per_step_with_phase_brackets": ms_bracketed,
         "cpu_baseline": cpu, "parity": parity, "n_selected": int(X_b.shape[0]),
     }
-    print(json.dumps(out))
+    return out
 
 
 def main():
@@ -399,15 +433,20 @@ def main():
                     help="N > 1: rank 0 gathers every shard and repeats the step UNSHARDED on its one GPU (outside the timed "
                          "region); the JSON then carries the comparison (identical indices, weights) -- the test hook of "
                          "tests/test_hip_round4.py, not for pools that do not fit one GPU")
+    ap.add_argument("--no-others", action="store_true",
+                    help="default line (one GPU, configuration 2): skip the `other_configs` (BASELINE.json configurations 1, 3, 4, 5, "
+                         "--other-steps steps each, no CPU leg) and `acquisition_step` (Sober.next_batch) sub-records")
+    ap.add_argument("--other-steps", type=int, default=10)
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
     if args.funnel:
-        return funnel(args)
+        print(json.dumps(funnel(args)))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert world == args.gpus, (f"--gpus {args.gpus} but WORLD_SIZE={world}: a launcher set another world size (without a "
+                                "launcher bench.py starts its own torch.distributed.run child: _self_launch)")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     # one rank per GPU over RCCL.  (Test hook: SOBER_BENCH_BACKEND=gloo lets several ranks share the GPUs that
     # exist -- the N > 1 code path on a one-GPU box; never used for a measurement.)
@@ -424,6 +463,53 @@ def main():
             dist.init_process_group(backend)
         group = dist.group.WORLD
 
+    out = measure(args, args.config, rank, world, dev, group, backend)
+    if rank != 0:
+        return
+    # The other BASELINE.json configurations and the acquisition step, timed by the SAME command (one GPU, default
+    # configuration; outside the headline's timed region, no CPU leg): what used to exist only as builder-run files
+    # under profiles/.  Every sub-record carries ms_per_step, the dominant kernel's roofline fraction and a parity verdict.
+    if world == 1 and args.config == 2 and not args.no_others:
+        light = argparse.Namespace(**dict(vars(args), steps=args.other_steps, warmup=2, no_cpu_baseline=True, no_sweep=True,
+                                          light=True))
+        others = {}
+        for c in (1, 3, 4, 5):
+            t_c = time.perf_counter()
+            try:
+                torch.cuda.empty_cache()
+                r = measure(light, c, 0, 1, dev, None, backend)
+                others[str(c)] = {
+                    "workload": r["config"]["workload"], "steps": r["steps"], "warmup_effective": r["warmup_effective"],
+                    "ms_per_step": r["ms_per_step"], "ms_per_step_median": r["ms_per_step_median"], "value": r["value"],
+                    "unit": r["unit"], "dtype": r["dtype"],
+                    "roofline": {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                                   "step_frac", "kernel_ms_per_step", "launches_per_step",
+                                                                   "traffic", "F_alg_per_step", "F_executed_per_step")},
+                    "parity": r["parity"], "ms_per_step_fresh_pool": r["ms_per_step_fresh_pool"],
+                    "phases_ms_per_step": r["phases_ms_per_step"], "n_selected": r["n_selected"],
+                    "wall_s": round(time.perf_counter() - t_c, 2)}
+            except Exception as e:                                      # noqa: BLE001  (a sub-record never takes the headline down)
+                others[str(c)] = {"error": f"{type(e).__name__}: {e}", "wall_s": round(time.perf_counter() - t_c, 2)}
+        out["other_configs"] = others
+        t_c = time.perf_counter()
+        try:
+            torch.cuda.empty_cache()
+            f = funnel(argparse.Namespace(**dict(vars(args), steps=5, warmup=3, no_cpu_baseline=True)))
+            out["acquisition_step"] = {k: f[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step",
+                                                         "phases_ms_per_step", "phase_calls_per_step", "parity", "n_selected")}
+            out["acquisition_step"]["workload"] = f["config"]["workload"]
+            out["acquisition_step"]["wall_s"] = round(time.perf_counter() - t_c, 2)
+        except Exception as e:                                          # noqa: BLE001
+            out["acquisition_step"] = {"error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(out))
+
+
+def measure(args, config, rank, world, dev, group, backend):
+    """One configuration, timed as the contract says (warm-up, barrier + synchronise either side of exactly --steps steps,
+    max over ranks) -> the JSON record on rank 0, None elsewhere.  `args.light` (the sub-records of the default line): no
+    cold-start protocol, no KMeans line, no CPU leg."""
+    cfg = CONFIGS[config]
+    light = bool(getattr(args, "light", False))
     X_cand, X_nys, mu0, spec, inp, N_loc = build_inputs(cfg, rank, world, dev)
     ks = sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs, spec.S_cache,
                               spec.noise, spec.mean_const, spec.alpha)
@@ -461,17 +547,18 @@ def main():
     # command measured before round 4's last commit put a quarter of a second of steps in front of the warm-ups)
     torch.cuda.synchronize(); barrier()
     t_cold = time.perf_counter()
-    for _ in range(args.steps):
+    n_cold = 2 if light else args.steps
+    for _ in range(n_cold):
         idx, w = step()
     torch.cuda.synchronize(); barrier()
-    ms_cold = (time.perf_counter() - t_cold) / args.steps * 1e3
-    n_init = 1 + args.steps
+    ms_cold = (time.perf_counter() - t_cold) / n_cold * 1e3
+    n_init = 1 + n_cold
     # ... and a quarter of a second of the same step: a fresh process on a fresh box starts with the device's clocks and
     # the allocator's pools cold (first line of a box 4.32 ms, the same command again 4.17: ten timed steps are 42 ms).
     # These steps are reported: init_steps, warmup_effective = init_steps + --warmup.
     t_init = time.perf_counter()
     n_spin = 0
-    while world == 1 and time.perf_counter() - t_init < 0.25 and n_spin < 60:
+    while world == 1 and time.perf_counter() - t_init < (0.1 if light else 0.25) and n_spin < 60:
         idx, w = step(); n_spin += 1
     for _ in range(20 if world > 1 else 0):              # (a fixed count where the steps are collective)
         idx, w = step(); n_spin += 1
@@ -516,7 +603,7 @@ def main():
     # the step together with the Nystrom subsample that precedes it in the reference's funnel for a continuous
     # prior (kmeans_resampling, SOBER/_weights.py:95-126, SOBER/_sampler.py:316-320); outside the timed region
     kmeans_ms = None
-    if world == 1 and cfg["kind"] != "tanimoto":
+    if world == 1 and cfg["kind"] != "tanimoto" and not light:
         sober_amd.KMeans(X_cand, cfg["M"])
         torch.cuda.synchronize()
         k0 = time.perf_counter()
@@ -571,7 +658,7 @@ def main():
             del X_all, mu_all
 
     if rank != 0:
-        return
+        return None
 
     # parity of the timed configuration against the reference golden (N=1, configurations with a full-size golden)
     parity = None
@@ -599,7 +686,7 @@ def main():
         cpu_baseline = cpu_baseline_for(cfg, spec, inp, (X_cand, X_nys, mu0), args.cpu_steps)
 
     ms_per_step = elapsed / args.steps * 1e3
-    traffic, traffic_src = pmc_traffic(args.config) if world == 1 else (None, None)
+    traffic, traffic_src = pmc_traffic(config) if world == 1 else (None, None)
     n_rows = cfg["M"] + (cfg["n_obs"] if cfg["mode"] != "kernel" else 0)
     V = entries / n_rows / ev_steps                      # visited list positions per step (sum of the levels' sizes)
     n_levels = sum(1 for _, _, e, _ in prof if e > 0 and e >= 2 * b * n_rows) / ev_steps   # main launches per step
@@ -655,7 +742,7 @@ def main():
 
     # n_obs sweep at the headline configuration (one GPU; outside the timed region)
     sweep = None
-    if world == 1 and args.config == 2 and not args.no_sweep:
+    if world == 1 and config == 2 and not args.no_sweep:
         sweep = {}
         for n_obs in (100, 200, 800, 1600):
             c2 = dict(cfg, n_obs=n_obs)
@@ -686,13 +773,13 @@ def main():
         "init_steps": n_init, "warmup_effective": n_init + args.warmup,
         "ms_per_step": ms_per_step,
         "ms_per_step_cold": ms_cold,
-        "ms_per_step_protocol": f"untimed: 1 initialisation step, {args.steps} steps timed as ms_per_step_cold (the first steps of "
+        "ms_per_step_protocol": f"untimed: 1 initialisation step, {n_cold} steps timed as ms_per_step_cold (the first steps of "
                                 f"a fresh process), {n_spin} steady-state steps (0.25 s), {args.warmup} warm-up steps; then the "
                                 f"{args.steps} timed steps behind ms_per_step / value",
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u64" if cfg["kind"] == "tanimoto" else "f64", "data": "synthetic",
         "config": {"workload": f"{cfg['name']}, N_rec={N_loc} per GPU ({N_total} in all), N_nys={cfg['M']}, "
-                               f"batch={cfg['b']}, n_obs={cfg['n_obs']} (BASELINE.json configs[{args.config - 1}])",
+                               f"batch={cfg['b']}, n_obs={cfg['n_obs']} (BASELINE.json configs[{config - 1}])",
                    "parallelism": f"pool row-sharded x{world}, one all-reduce of (n*S+S) f64 per level ({allreduce_route()})"
                                   if world > 1 else "single GPU"},
         "roofline": roofline,
@@ -713,7 +800,8 @@ def main():
         "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2] * 1e3, 3),    # (the steps without event pairs or host hiccups)
         "n_selected": int(idx.numel()),
     }
-    print(json.dumps(out))
+    gc.enable()
+    return out
 
 
 if __name__ == "__main__":

@@ -32,3 +32,39 @@ def test_mt19937_uniforms_and_state_follow_torch_randn():
             out[numel - 16:] = bm(un[numel:numel + 16])
         np.testing.assert_allclose(out, want.numpy(), rtol=0, atol=4e-15)
     assert _rng._self_check()
+
+
+def test_bench_self_launch_builds_a_child_torchrun(monkeypatch):
+    """bench.py --gpus N (N > 1) without a launcher: the ranks are started as a CHILD `python -m torch.distributed.run` on the
+    loopback interface (never an exec: the parent may not replace itself once anything touched the GPU, and it has touched
+    nothing); with WORLD_SIZE set, or N = 1, nothing is started."""
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class _R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return _R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench._self_launch() == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in __import__("os").environ
+    seen.clear()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus=2"])
+    assert bench._self_launch() == 7 and "--nproc-per-node=2" in seen["cmd"]
+    seen.clear()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1"])
+    assert bench._self_launch() is None and not seen
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert bench._self_launch() is None and not seen
