@@ -253,7 +253,15 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
 #pragma unroll
         for (int q = S; q < CQ; ++q) x[q] *= sc;         // x becomes v
         if (R == li) {                                       // the reflector goes to the scratch (Phi follows it)
-            const unsigned so = (unsigned)i * (unsigned)(CAR_NS * 8);
+            // (round 6, from the ISA -- profiles/r06_bidiag_isa.txt: in block 0 li == i, so inside this branch the compiler
+            //  knows i == R and rewrote the scalar offset below in terms of the LANE's R: thirteen waterfall loops
+            //  (readfirstlane / compare / saveexec / store / branch) per step.  The step index is laundered as what it is, a
+            //  wave-uniform value; and the lane's byte offset is made opaque to the known-bits analysis so that 128 q stays an
+            //  ADD and folds into the store's immediate offset: one address register instead of thirteen kept alive
+            //  through the whole kernel.)
+            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(i) * (unsigned)(CAR_NS * 8);
+            unsigned c8 = (unsigned)C * 8u;
+            asm volatile("" : "+v"(c8));
 #pragma unroll
             for (int q = 0; q < CAR_CQ; ++q) {            // (whole reflectors: the consumers read every slot)
                 double v;
@@ -262,7 +270,7 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
                 else v = x[q];
                 car_u32x2 g;
                 g.x = (unsigned)__double2loint(v); g.y = (unsigned)__double2hiint(v);
-                CB2_VSTORE(__builtin_amdgcn_raw_buffer_store_b64(g, vrs, (unsigned)(C * 8 + 128 * q), so, 0));
+                CB2_VSTORE(__builtin_amdgcn_raw_buffer_store_b64(g, vrs, c8 + (unsigned)(128 * q), so, 0));
             }
             if (C == 0) taup[i] = tau;
         }
