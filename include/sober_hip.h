@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOBER_ABI_VERSION 5
+#define SOBER_ABI_VERSION 6
 
 /* kernel families: model.covar_module.forward behind SOBER/_gp.py:292-294 */
 #define SOBER_KIND_RBF       0   /* outputscale * exp(-0.5 * |x/l - y/l|^2)                      */
@@ -45,7 +45,7 @@ int sober_abi_version(void);
  * unless SOBER_ALLOW_DIAG_LIB=1.  `make all` gives 0. */
 int sober_diag_build(void);
 /* The A/B and test switches of the environment (SOBER_LEVEL_TWO_LAUNCHES, SOBER_TANI_NO_QUEUE, SOBER_CAR_FORCE_GIVEUP,
- * SOBER_CAR_UNFUSED, SOBER_CAR_GRAM) are read ONCE, when the library is loaded; a process that changes one afterwards
+ * SOBER_CAR_UNFUSED, SOBER_CAR_GRAM, SOBER_CAR_EXACT_RATIO, SOBER_LEVEL_NO_CLASSES) are read ONCE, when the library is loaded; a process that changes one afterwards
  * (the tests do) calls this to have them read again.  Returns 0.                                                    */
 int sober_reload_switches(void);
 /* sizeof(sober_level_job) / sizeof(sober_nystrom_job) as the library was built: a binding that lays the structs out itself
@@ -407,6 +407,39 @@ int sober_level_update_queued(const int32_t* idx_cur, int64_t R_ub, int S, const
                               const double* w_star, const double* tot, double* mu, int32_t* idx_new,
                               const int64_t* dR_cur, int64_t* dR_next, int64_t R_ub_next, void* stream);
 
+/* ---- levels whose set sums are already held (round 6, csrc/level_class.hip) -----------------------------------------
+ * Survivors are compacted element-major (SOBER/_rchq.py:198-221): with n_keep = b kept sets, S = 2b and no leftovers the
+ * survivor of element e in the kept set of rank k moves to element e div 2, set (e mod 2) b + k, weight mu w*_k / tot_k
+ * (:204-205).  The next level's set sums (:116-126) are therefore level l's sums over the elements of one parity, times
+ * w*_k / tot_k: no kernel evaluation.  Class sums over c = e mod 2^D ARE set sums with 2^D S sets, so level 0 runs the level
+ * kernel over S' = 2^D S sets (sober_level_reduce_mfma_wpt, waves per tile from sober_level_class_wpt, partial slots
+ * sober_level_class_slots(wpt)); sober_class_sum turns its partial slots into class sums Gc (n_rows x CL S), class masses
+ * totc (CL S) and the level's own G (n_rows x S) / tot (S); sober_class_derive_queued forms level l + 1 (CL / 2 classes:
+ * Gn, totn -- untouched when CL = 2 -- and G / tot) from level l's (CL classes) with scale[k] = w*_k / tot_k and sof[k] =
+ * the set of rank k, both written by sober_level_update_queued_cls -- which also stops the queued chain (*dR_next = -1)
+ * unless exactly need_keep sets survived and the level had no leftovers.  *dR <= S: the derive launch leaves at once.   */
+int sober_level_class_wpt(int n_rows, int64_t e_total, int S);
+int sober_level_class_slots(int wpt);
+int sober_level_reduce_mfma_wpt(int kind, const double* rows, int n_rows, const double* cand, int da,
+                                const int32_t* idx, int64_t count, int S, const double* mu, const double* wmul,
+                                double outputscale, int wpt, int n_chunks, double* partG, int ldg, double* partTot,
+                                void* stream);
+int sober_class_sum(const double* partG, const double* partTot, int n_chunks, int n_rows, int S, int CL,
+                    double* Gc, double* totc, double* G, double* tot, void* stream);
+int sober_class_derive_queued(const double* Gc, const double* totc, int n_rows, int S, int CL, const double* scale,
+                              const int32_t* sof, double* Gn, double* totn, double* G, double* tot, const int64_t* dR,
+                              void* stream);
+int sober_level_update_queued_cls(const int32_t* idx_cur, int64_t R_ub, int S, const int32_t* keep_rank,
+                                  const double* w_star, const double* tot, double* mu, int32_t* idx_new,
+                                  const int64_t* dR_cur, int64_t* dR_next, int64_t R_ub_next, int need_keep,
+                                  double* cls_scale, int32_t* cls_sof, void* stream);
+/* The depth D (0 .. SOBER_CLASS_MAX_DEPTH) sober_level_moments / sober_level_loop use for a pool of R live positions in
+ * sets of S (variant: SOBER_LEVEL_MFMA or SOBER_LEVEL_TANI, 0 for the others): the largest D with R % (2^D S) == 0, at least
+ * two elements per set left at level D, 2^D x the class launch's partial slots within SOBER_LEVEL_MAX_CHUNKS -- and, for the
+ * fingerprint kernel (one workgroup per compute unit), a class launch that still fills the chip.                       */
+#define SOBER_CLASS_MAX_DEPTH 4
+int sober_level_class_depth(int variant, int n_rows, int64_t R, int S);
+
 /* KMeans of SOBER/_weights.py:100-126: Lloyd, centroids initialised to the first K rows, exactly
  * `iters` iterations, first-index argmin (a NaN distance wins like torch.argmin), empty cluster ->
  * NaN centroid.  X is (N, d) row-major raw points.  labels: N int32.  ws: sober_kmeans_ws_bytes (a smaller one
@@ -527,6 +560,13 @@ typedef struct sober_level_job {
                                                    raise it to SOBER_CAR_SAFE after a give-up (in/out)                   */
     uint64_t ev_used[2];                        /* out (sober_level_loop with events): bit l of [0] / [1] = the event pair of
                                                    level l's main / leftover launch was attached to a launch          */
+    /* levels derived from class sums (optional, MFMA / TANI variants with queued levels; see sober_class_derive_queued):
+       class_depth = D > 0 asks sober_level_moments(phase 1) for level 0's sums by 2^D element classes -- and tells
+       sober_level_loop (first_sums_ready) that they are there: levels 1 .. D are then gathered and scaled, not evaluated.
+       Gc[2] / totc[2]: ping-pong class sums, n_rows x 2^D S and 2^D S doubles each; cls_scale (S doubles), cls_sof (S int32) */
+    int32_t class_depth;
+    double* Gc[2]; double* totc[2];
+    double* cls_scale; int32_t* cls_sof;
 } sober_level_job;
 #define SOBER_LEVEL_QUEUE 24
 int sober_level_moments(const sober_level_job* job, void* stream);

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SOBER_HIP_LIB: a diagnostic build of the same library, e.g. the in-kernel-stamp build `make stamps`)
 LIB_PATH = os.environ.get("SOBER_HIP_LIB") or os.path.join(_HERE, "libsober_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 KIND_RBF, KIND_MATERN52, KIND_TANIMOTO = 0, 1, 2
 KIND_BY_NAME = {"rbf": KIND_RBF, "matern52": KIND_MATERN52, "tanimoto": KIND_TANIMOTO}
@@ -145,6 +145,14 @@ SIGNATURES = {
     "sober_level_chunks_tani": (_i32, [_i32, _i64, _i64, _i32]),
     "sober_level_chunks_tani_cap": (_i32, [_i32, _i64, _i32]),
     "sober_level_update_queued": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sober_level_update_queued_cls": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "sober_level_class_wpt": (_i32, [_i32, _i64, _i32]),
+    "sober_level_class_slots": (_i32, [_i32]),
+    "sober_level_class_depth": (_i32, [_i32, _i32, _i64, _i32]),
+    "sober_level_reduce_mfma_wpt": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _f64, _i32, _i32, _vp, _i32,
+                                           _vp, _vp]),
+    "sober_class_sum": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sober_class_derive_queued": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sober_record_event_pair": (_i32, [_vp, _vp, _vp]),
     "sober_set_launch_events": (_i32, [_vp, _vp]),
     "sober_projection": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
@@ -200,10 +208,12 @@ class LevelJob(C.Structure):
         ("dR", _vp), ("h_dR", _vp),
         ("car_mode", _i32),
         ("ev_used", C.c_uint64 * 2),
+        ("class_depth", _i32), ("Gc", _vp * 2), ("totc", _vp * 2), ("cls_scale", _vp), ("cls_sof", _vp),
     ]
 
 E_DIM = -2
 E_EXCHANGE = -5
+CLASS_MAX_DEPTH = 4                             # SOBER_CLASS_MAX_DEPTH
 CAR_DEFAULT, CAR_SAFE, CAR_HOST = 0, 1, 2     # (CAR_HOST: the host side's own third rung, never passed to the library)
 
 _lib: Optional[C.CDLL] = None

@@ -35,6 +35,10 @@ class HipOps(_PlanOps, _NystromOps, _LevelOps):
         self.use_mfma = True    # False: VALU-only level kernel (direct differences), kept for A/B runs
         # False (or SOBER_NO_QUEUE in the environment): every level sized by the host after a synchronisation
         self.queue_levels = os.environ.get("SOBER_NO_QUEUE") is None
+        # False: every level's set sums evaluated; True: levels 1 .. D of a pool without leftovers gathered and scaled from
+        # level 0's element-class sums (csrc/level_class.hip; the library's SOBER_LEVEL_NO_CLASSES switch gives depth 0 too)
+        self.level_classes = True
+        self.last_levels = None  # {"R": live positions per level, "derived": D} of the last level_loop call
         # the jitter ladder's probes on eight workgroups per rung (False: one workgroup each -- where the process stays
         # after a rung's workgroups lost each other)
         self._probe_mc = torch.cuda.get_device_properties(self.device).multi_processor_count >= 256   # (8 XCDs x 32 CUs: unpartitioned)

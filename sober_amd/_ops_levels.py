@@ -66,6 +66,15 @@ class _LevelOps:
             w["dR"] = torch.zeros(nat.LEVEL_QUEUE + 1, dtype=torch.int64, device=dev)
             w["h_dR"] = torch.zeros(nat.LEVEL_QUEUE + 1, dtype=torch.int64, pin_memory=True)
             job.dR, job.h_dR = w["dR"].data_ptr(), w["h_dR"].data_ptr()
+            if S % 2 == 0:
+                # levels derived from level 0's class sums (csrc/level_class.hip): ping-pong class sums, 2^D S columns at most
+                cl = 1 << nat.CLASS_MAX_DEPTH
+                w["Gc"] = [torch.empty(nr * S * (cl >> k), dtype=f64, device=dev) for k in (0, 1)]
+                w["totc"] = [torch.empty(S * (cl >> k), dtype=f64, device=dev) for k in (0, 1)]
+                w["cls_scale"], w["cls_sof"] = torch.empty(S, dtype=f64, device=dev), torch.empty(S, dtype=torch.int32, device=dev)
+                for k in (0, 1):
+                    job.Gc[k], job.totc[k] = w["Gc"][k].data_ptr(), w["totc"][k].data_ptr()
+                job.cls_scale, job.cls_sof = w["cls_scale"].data_ptr(), w["cls_sof"].data_ptr()
         for k in ("partG", "partTot", "extraG", "extraTot", "G", "Xtr", "tot", "X_tmp", "keep_rank", "w_star", "mu_out",
                   "h_flags"):
             setattr(job, k, w[k].data_ptr())
@@ -106,6 +115,11 @@ class _LevelOps:
             return p.ws["Xtr"], p.ws["tot"]
         nat._req(idx, torch.int32, "idx"); nat._req(mu, torch.float64, "mu")
         job.idx, job.pos0, job.count, job.E, job.mu = idx.data_ptr(), pos0, count, E, mu.data_ptr()
+        # the first level's sums of an unsharded pool without leftovers: by 2^D element classes, from which the queued
+        # loop forms levels 1 .. D without evaluating the kernel again (csrc/level_class.hip; D = 0: as ever)
+        job.class_depth = 0
+        if phase == 1 and pos0 == 0 and count == E * S and job.Gc[0] and job.dR and self.level_classes:
+            job.class_depth = int(nat.load().sober_level_class_depth(job.variant, job.n_rows, count, S))
         pair = None
         if self.prof is not None:
             n_left = max(pos0 + count - max(pos0, E * S), 0)
@@ -129,6 +143,8 @@ class _LevelOps:
         job = self._job(p, S)
         nat._req(mu, torch.float64, "mu"); nat._req(idx_cur, torch.int32, "idx"); nat._req(idx_new, torch.int32, "idx")
         job.mu = mu.data_ptr()
+        if not sums_ready:
+            job.class_depth = 0                                 # (class sums come from the phase-1 call only)
         events = pairs = None
         if self.prof is not None:
             n_max = min(nat.MAX_LEVELS, int(math.log2(max(R / S, 1.0))) + 3)
@@ -143,6 +159,7 @@ class _LevelOps:
         if not p.weighted and getattr(p, "Kmat", None) is None and self.car_mode != nat.CAR_HOST and job.car_ws:
             fin = self._final_job(p, S, mu, row_offset)
         level_R, R_final, in_b, gave_up = nat.level_loop(job, R, idx_cur, idx_new, sums_ready, events, nat._stream(mu), fin)
+        self.last_levels = {"R": [int(v) for v in level_R], "derived": int(job.class_depth) if sums_ready else 0}
         if fin is not None and fin.done:
             n_keep = int(p.ws["h_flags_np"][S])
             if n_keep >= 0:
@@ -173,6 +190,7 @@ class _LevelOps:
         job = self._job(p, S)
         nat._req(mu, torch.float64, "mu"); nat._req(idx_cur, torch.int32, "idx"); nat._req(idx_new, torch.int32, "idx")
         job.mu = mu.data_ptr()
+        job.class_depth = 0
         fn_ptr, comm_ptr, keep = comm.native_allreduce(p.ws["XT"], self.device)
         _, new_bounds, in_b = nat.level_loop_sharded(job, comm.rank, comm.world, bounds, idx_cur, idx_new, sums_ready,
                                                      fn_ptr, comm_ptr, R_stop, nat._stream(mu))

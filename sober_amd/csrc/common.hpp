@@ -144,6 +144,24 @@ __host__ __device__ inline int level_wave_wpt(int n_rows, int64_t e_total, int S
 // partial-sum slots per tile = the most workgroups `wpt` consecutive waves can touch
 __host__ __device__ inline int level_wave_slots(int wpt) { return wpt <= 0 ? 0 : (wpt + SOBER_LW_W - 2) / SOBER_LW_W + 1; }
 
+// Waves per tile of the CLASS launch (round 6: level 0 over 2^D x S sets, whose element-class sums give the next D levels
+// without a kernel evaluation -- level_exec.cpp).  Its tiles are 2^D times the level's: a one-round line (level_wave_wpt)
+// would leave the chip half empty (1100 tiles at 8 classes of cfg-4: one wave each) or spill into a short second round.
+// The line may be several rounds long instead; wpt minimises  rounds x (elements per wave x t_e + t_0)  with the per-wave
+// figures of profiles/r03_level_stamps.txt (1.7 us per element and wave at two waves per SIMD, 6 us fixed).  Host-known
+// sizes only (no queued launch uses it), so it need not be monotone.
+__host__ __device__ inline int level_class_wpt(int n_rows, int64_t e_total, int S) {
+    const int64_t tiles = level_wave_tiles(n_rows, S);
+    int best = 1;
+    double best_t = 1e300;
+    for (int w = 1; w <= 16 && w <= e_total; ++w) {
+        const int64_t rounds = (tiles * w + SOBER_WAVE_TARGET - 1) / SOBER_WAVE_TARGET;
+        const double t = (double)rounds * ((double)((e_total + w - 1) / w) * 1.7 + 6.0);
+        if (t < best_t * 0.97) { best_t = t; best = w; }            // (a longer line has to pay for its partial sums)
+    }
+    return best;
+}
+
 // partial sums per tile of the matrix-core level kernel (monotone in e_total: a launch sized from an upper bound covers
 // the exact one)
 __host__ __device__ inline int level_parts_mfma_for(int n_rows, int64_t e_total, int S) {

@@ -55,6 +55,61 @@ static int lx_reduce(const sober_level_job* j, const int32_t* idx, int64_t pos0,
     }
 }
 
+// ---- levels derived from class sums (csrc/level_class.hip) ------------------------------------------------------------
+// D for a pool of R live positions: no leftovers at levels 0 .. D (R % (2^D S) == 0), at least two elements per set left
+// at level D (so that level D is one of the queued ones), 2^D x the class launch's slots within the partial-sum buffers.
+extern "C" int sober_level_class_depth(int variant, int n_rows, int64_t R, int S) {
+    if (n_rows <= 0 || R <= 0 || S <= 0 || (S & 1) || sober::switches().level_no_classes) return 0;
+    if (variant != SOBER_LEVEL_MFMA && variant != SOBER_LEVEL_TANI) return 0;
+    int D = 0;
+    while (D < SOBER_CLASS_MAX_DEPTH) {
+        const int64_t SC = (int64_t)S << (D + 1);
+        if (R % SC != 0 || R / SC < 2) break;
+        int slots;
+        if (variant == SOBER_LEVEL_MFMA) {
+            const int wpt = sober_level_class_wpt(n_rows, R / SC, (int)SC);
+            slots = wpt > 0 ? sober_level_class_slots(wpt) : 0;
+        } else {
+            // the fingerprint kernel runs one workgroup per compute unit in (ideally) one round: a class launch with clearly
+            // fewer workgroups than the level's own launch costs level 0 more than the derived level saves
+            slots = sober_level_chunks_tani(n_rows, 0, R, (int)SC);
+            const int64_t rb = (n_rows + 255) / 256;
+            const int64_t wg_c = (int64_t)slots * ((SC + 15) / 16 + 1) * rb;
+            const int64_t wg_0 = (int64_t)sober_level_chunks_tani(n_rows, 0, R, S) * ((S + 15) / 16 + 1) * rb;
+            if (slots > 0 && wg_c * 100 < wg_0 * 85) break;
+        }
+        if (slots <= 0 || slots * (1 << (D + 1)) > SOBER_LEVEL_MAX_CHUNKS) break;
+        ++D;
+    }
+    return D;
+}
+
+// level 0 of such a pool: the level kernel over 2^D S sets, then class sums + their fold (G, tot: what every level has)
+static int lx_class_first(const sober_level_job* j, void* stream) {
+    const int S = j->S, D = j->class_depth, CL = 1 << D, SC = S * CL;
+    if ((j->variant != SOBER_LEVEL_MFMA && j->variant != SOBER_LEVEL_TANI) || D < 1 || D > SOBER_CLASS_MAX_DEPTH ||
+        j->pos0 != 0 || j->count % SC != 0 || j->count / SC < 2 || !j->Gc[0] || !j->totc[0])
+        return SOBER_E_ARG;
+    int nch;
+    if (j->variant == SOBER_LEVEL_MFMA) {
+        const int wpt = sober_level_class_wpt(j->n_rows, j->count / SC, SC);
+        if (wpt <= 0) return wpt < 0 ? wpt : SOBER_E_ARG;
+        nch = sober_level_class_slots(wpt);
+        if (nch <= 0 || nch * CL > SOBER_LEVEL_MAX_CHUNKS) return SOBER_E_WS;
+        LX_EVENTS_BEFORE(j->ev[0], j->ev[1])
+        LX_TRY(sober_level_reduce_mfma_wpt(j->kind, (const double*)j->rows, j->n_rows, (const double*)j->cand, j->dim, j->idx,
+                                           j->count, SC, j->mu, j->wmul, j->outputscale, wpt, nch, j->partG, SC, j->partTot,
+                                           stream));
+    } else {
+        nch = sober_level_chunks_tani(j->n_rows, 0, j->count, SC);
+        if (nch <= 0 || nch * CL > SOBER_LEVEL_MAX_CHUNKS) return nch <= 0 ? nch : SOBER_E_WS;
+        LX_EVENTS_BEFORE(j->ev[0], j->ev[1])
+        LX_TRY(sober_level_reduce_tani(j->rows, j->rows_norm, j->n_rows, j->cand, j->cand_norm, j->dim, j->idx, 0, j->count, SC,
+                                       j->mu, j->wmul, j->outputscale, nch, j->partG, SC, 0, j->partTot, j->count, stream));
+    }
+    return sober_class_sum(j->partG, j->partTot, nch, j->n_rows, S, CL, j->Gc[0], j->totc[0], j->G, j->tot, stream);
+}
+
 extern "C" int sober_level_moments(const sober_level_job* j, void* stream) {
     if (!j || !j->G || !j->tot || j->n_rows <= 0 || j->S <= 0 || j->n <= 0 || j->phase < 0 || j->phase > 2)
         return SOBER_E_ARG;
@@ -66,6 +121,7 @@ extern "C" int sober_level_moments(const sober_level_job* j, void* stream) {
     if (!j->cand || !j->idx || !j->mu || !j->partG || !j->partTot || (j->phase == 0 && (!j->P || !j->Xtr)))
         return SOBER_E_ARG;
     if (j->count <= 0 || j->pos0 < 0 || j->E < 0) return SOBER_E_ARG;
+    if (j->phase == 1 && j->class_depth > 0) return lx_class_first(j, stream);
     const int64_t ES = j->E * S;
     const bool mfma = j->variant == SOBER_LEVEL_MFMA;
     const bool tani_k = j->variant == SOBER_LEVEL_TANI;
@@ -152,6 +208,15 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
     }
     if (L < 2) return 0;                                                // nothing to gain: the synchronised loop
     if (!sober_car_supported(S, b)) return SOBER_E_DIM;
+    // levels 1 .. D gathered and scaled from level 0's class sums (the caller's phase-1 call left them: first_sums_ready)
+    int D = 0;
+    if (first_sums_ready && j->class_depth > 0) {
+        D = j->class_depth;
+        if ((j->variant != SOBER_LEVEL_MFMA && j->variant != SOBER_LEVEL_TANI) || D > SOBER_CLASS_MAX_DEPTH || D >= L ||
+            R0 % ((int64_t)S << D) != 0 ||
+            !j->Gc[0] || !j->Gc[1] || !j->totc[0] || !j->totc[1] || !j->cls_scale || !j->cls_sof)
+            return SOBER_E_ARG;
+    }
     hipStream_t st = (hipStream_t)stream;
     LX_TRY(sober_set_i64(j->dR, R0, stream));
     hipError_t e = hipSuccess;
@@ -159,7 +224,12 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
         int32_t* cur = (l & 1) ? idx_b : idx_a;
         int32_t* nxt = (l & 1) ? idx_a : idx_b;
         for (int k = 0; k < 4; ++k) j->ev[k] = events ? events[4 * l + k] : nullptr;
-        if (!(l == 0 && first_sums_ready)) {
+        if (l >= 1 && l <= D) {
+            // (level l holds 2^(D - l) classes; its predecessor's update left scale / sof and stopped the chain unless b sets survived)
+            LX_TRY(sober_class_derive_queued(j->Gc[(l - 1) & 1], j->totc[(l - 1) & 1], j->n_rows, S, 1 << (D - l + 1),
+                                             j->cls_scale, j->cls_sof, j->Gc[l & 1], j->totc[l & 1], j->G, j->tot, j->dR + l,
+                                             stream));
+        } else if (!(l == 0 && first_sums_ready)) {
             const bool tani = j->variant == SOBER_LEVEL_TANI;
             const int64_t e_ub = (Rub[l] + S - 1) / S, ex_ub = (S - 1 + SOBER_LEVEL_XS - 1) / SOBER_LEVEL_XS;
             const int nch = tani ? sober_level_chunks_tani_cap(j->n_rows, e_ub, S) : lx_chunks(j->n_rows, e_ub, S);
@@ -212,8 +282,12 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
         LX_TRY(sober_dgemm_coldiv_t(n, S, j->n_rows, j->P, j->n_rows, j->G, S, j->tot, j->X_tmp, n, stream));
         LX_TRY(sober_car_device_ex(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
                                    nullptr, j->car_ws, j->car_ws_bytes, j->car_mode, stream));
-        LX_TRY(sober_level_update_queued(cur, Rub[l], S, j->keep_rank, j->w_star, j->tot, j->mu, nxt, j->dR + l,
-                                         j->dR + l + 1, Rub[l + 1], stream));
+        if (l < D)
+            LX_TRY(sober_level_update_queued_cls(cur, Rub[l], S, j->keep_rank, j->w_star, j->tot, j->mu, nxt, j->dR + l,
+                                                 j->dR + l + 1, Rub[l + 1], b, j->cls_scale, j->cls_sof, stream));
+        else
+            LX_TRY(sober_level_update_queued(cur, Rub[l], S, j->keep_rank, j->w_star, j->tot, j->mu, nxt, j->dR + l,
+                                             j->dR + l + 1, Rub[l + 1], stream));
     }
     for (int k = 0; k < 4; ++k) j->ev[k] = nullptr;
     e = hipMemcpyAsync(j->h_dR, j->dR, sizeof(int64_t) * (size_t)(L + 1), hipMemcpyDeviceToHost, st);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
     double* __restrict__ partG, int ldg, int col0,
     double* __restrict__ partTot, int64_t tot_limit,
     const int64_t* __restrict__ dR, int S_main, int leftover,
-    int S_x, double* __restrict__ partG_x, int ldg_x, double* __restrict__ partTot_x, int grid_main) {
+    int S_x, double* __restrict__ partG_x, int ldg_x, double* __restrict__ partTot_x, int grid_main, int wpt_ov) {
     constexpr int DA = 4 * KT;
     constexpr int W = SOBER_LW_W;
 #ifdef LW_STAMPS      // diagnostic build (scripts/level_stamps.py): s_memrealtime (100 MHz, one origin for the whole chip) of every wave at eight points -> partG, slot 6 on
@@ -97,7 +97,9 @@ __global__ __launch_bounds__(SOBER_LW_W * 64, 8 / SOBER_LW_W) void k_level_reduc
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (scalar: the element loop is uniform)
     const int lj = lane & 15, lk = lane >> 4;
     const int G = (S + 15) >> 4, RT = (n_rows + 63) >> 6;
-    const int wpt = level_wave_wpt(n_rows, e_total, S);
+    // (wpt_ov > 0: the class launch of level_exec.cpp -- S is then 2^D x the level's sets and the line of waves may be
+    //  several rounds long, level_class_wpt)
+    const int wpt = wpt_ov > 0 ? wpt_ov : level_wave_wpt(n_rows, e_total, S);
     const int n_slots = level_wave_slots(wpt);
     const int n_waves = G * RT * wpt;
     const int per_xcd = gdim >> 3;                                      // (the grid is a multiple of 8)
@@ -321,10 +323,11 @@ static int launch_lm(const double* rows, int n_rows, const double* cand, const i
                      int64_t count, int S, const double* mu, const double* wmul, double os, int n_chunks,
                      double* partG, int ldg, int col0, double* partTot, int64_t tot_limit, hipStream_t st,
                      const int64_t* dR = nullptr, int S_main = 0, int leftover = 0, int S_x = 0, int n_xchunks = 0,
-                     double* partG_x = nullptr, int ldg_x = 0, double* partTot_x = nullptr) {
+                     double* partG_x = nullptr, int ldg_x = 0, double* partTot_x = nullptr, int wpt_ov = 0) {
     const int64_t e_first = pos0 / S;
     const int e_total = (int)((pos0 + count + S - 1) / S - e_first);
-    const int wpt = level_wave_wpt(n_rows, e_total, S);
+    if (wpt_ov < 0 || wpt_ov > e_total || (wpt_ov > 0 && (dR != nullptr || leftover))) return SOBER_E_ARG;
+    const int wpt = wpt_ov > 0 ? wpt_ov : level_wave_wpt(n_rows, e_total, S);
     if (n_chunks != level_wave_slots(wpt)) return SOBER_E_ARG;         // (sober_level_parts_mfma: the slots per tile)
     if (count + 2 * (int64_t)S > 0x7fffffffLL) return SOBER_E_ARG;     // (positions inside a launch are 32-bit, like the list's entries)
     const int64_t n_waves = level_wave_tiles(n_rows, S) * wpt;
@@ -340,7 +343,7 @@ static int launch_lm(const double* rows, int n_rows, const double* cand, const i
     }
     SOBER_LAUNCH_TIMED((k_level_reduce_wave<KIND, KT>), dim3((unsigned)(grid_main + grid_x)), dim3(SOBER_LW_W * 64), 0,
                        st, rows, n_rows, cand, idx, pos0, count, S, mu, wmul, os, e_first, e_total, partG, ldg, col0,
-                       partTot, tot_limit, dR, S_main, leftover, S_x, partG_x, ldg_x, partTot_x, grid_main);
+                       partTot, tot_limit, dR, S_main, leftover, S_x, partG_x, ldg_x, partTot_x, grid_main, wpt_ov);
     LAUNCH_CHECK();
     return 0;
 }
@@ -382,7 +385,7 @@ static int level_reduce_mfma_impl(int kind, const double* rows, int n_rows, cons
                                   const double* wmul, double outputscale, int n_chunks, double* partG,
                                   int ldg, int col0, double* partTot, int64_t tot_limit, void* stream,
                                   const int64_t* dR, int S_main, int leftover, int S_x = 0, int n_xchunks = 0,
-                                  double* partG_x = nullptr, int ldg_x = 0, double* partTot_x = nullptr);
+                                  double* partG_x = nullptr, int ldg_x = 0, double* partTot_x = nullptr, int wpt_ov = 0);
 
 extern "C" int sober_level_reduce_mfma(int kind, const double* rows, int n_rows, const double* cand, int da,
                                        const int32_t* idx, int64_t pos0, int64_t count, int S, const double* mu,
@@ -400,6 +403,23 @@ extern "C" int sober_level_reduce_mfma_queued(int kind, const double* rows, int 
     if (!dR || S_main <= 0 || (!leftover && S != S_main)) return SOBER_E_ARG;
     return level_reduce_mfma_impl(kind, rows, n_rows, cand, da, idx, 0, count_ub, S, mu, wmul, outputscale,
                                   n_chunks_ub, partG, ldg, 0, partTot, 0, stream, dR, S_main, leftover);
+}
+
+// The class launch (round 6, level_exec.cpp: lx_class_first): the same kernel over S = 2^D x (the level's sets) with an
+// explicit number of waves per tile -- sober_level_class_wpt -- whose line may be several rounds of the chip long.
+// n_chunks = sober_level_class_slots(wpt).  Positions [0, count) of the list, no leftovers (count % S == 0).
+extern "C" int sober_level_class_wpt(int n_rows, int64_t e_total, int S) {
+    if (n_rows <= 0 || e_total <= 0 || S <= 0) return SOBER_E_ARG;
+    return level_class_wpt(n_rows, e_total, S);
+}
+extern "C" int sober_level_class_slots(int wpt) { return wpt > 0 ? level_wave_slots(wpt) : SOBER_E_ARG; }
+extern "C" int sober_level_reduce_mfma_wpt(int kind, const double* rows, int n_rows, const double* cand, int da,
+                                           const int32_t* idx, int64_t count, int S, const double* mu,
+                                           const double* wmul, double outputscale, int wpt, int n_chunks, double* partG,
+                                           int ldg, double* partTot, void* stream) {
+    if (wpt <= 0 || count <= 0 || S <= 0 || count % S != 0) return SOBER_E_ARG;
+    return level_reduce_mfma_impl(kind, rows, n_rows, cand, da, idx, 0, count, S, mu, wmul, outputscale, n_chunks, partG,
+                                  ldg, 0, partTot, count, stream, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, wpt);
 }
 
 // both placements of a queued level in ONE launch: the leftover launch's workgroups ride behind the main ones
@@ -420,7 +440,7 @@ static int level_reduce_mfma_impl(int kind, const double* rows, int n_rows, cons
                                   const double* wmul, double outputscale, int n_chunks, double* partG,
                                   int ldg, int col0, double* partTot, int64_t tot_limit, void* stream,
                                   const int64_t* dR, int S_main, int leftover, int S_x, int n_xchunks,
-                                  double* partG_x, int ldg_x, double* partTot_x) {
+                                  double* partG_x, int ldg_x, double* partTot_x, int wpt_ov) {
     if (!rows || !cand || !idx || !mu || !partG) return SOBER_E_ARG;
     if (n_rows <= 0 || pos0 < 0 || count <= 0 || S <= 0 || n_chunks <= 0 || ldg < col0 + S) return SOBER_E_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -428,7 +448,7 @@ static int level_reduce_mfma_impl(int kind, const double* rows, int n_rows, cons
     case 4 * T:                                                                                                \
         return launch_lm<K, T>(rows, n_rows, cand, idx, pos0, count, S, mu, wmul, outputscale, n_chunks, partG, \
                                ldg, col0, partTot, tot_limit, st, dR, S_main, leftover, S_x, n_xchunks, partG_x,   \
-                               ldg_x, partTot_x);
+                               ldg_x, partTot_x, wpt_ov);
     switch (kind) {
         case SOBER_KIND_RBF:
             switch (da) { LM_CASE(SOBER_KIND_RBF, 1) LM_CASE(SOBER_KIND_RBF, 2) LM_CASE(SOBER_KIND_RBF, 3)

@@ -184,16 +184,26 @@ __global__ void k_level_update_queued(const int32_t* __restrict__ idx_cur, int S
                                       const double* __restrict__ w_star, const double* __restrict__ tot,
                                       double* __restrict__ mu, int32_t* __restrict__ idx_new,
                                       const int64_t* __restrict__ dR_cur, int64_t* __restrict__ dR_next,
-                                      int64_t R_ub_next) {
+                                      int64_t R_ub_next, int need_keep, double* __restrict__ cls_scale,
+                                      int32_t* __restrict__ cls_sof) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t R = __hip_atomic_load(dR_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int64_t E = R > 0 ? R / S : 0, ES = E * S, r = R - ES;
     const int n_keep = keep_rank[S];
     const bool last_kept = keep_rank[S - 1] >= 0;
     const int64_t R_new = E * (int64_t)n_keep + (last_kept ? r : 0);
-    const bool stop = R <= S || n_keep <= 0 || n_keep > S || R_new >= R || R_new > R_ub_next;
+    // need_keep > 0: the next level's set sums are DERIVED from this level's class sums (level_class.hip), which holds for
+    // exactly need_keep = S / 2 kept sets and no leftovers -- anything else stops the chain here, the synchronised loop
+    // redoes this level and goes on with evaluated sums
+    const bool stop = R <= S || n_keep <= 0 || n_keep > S || R_new >= R || R_new > R_ub_next ||
+                      (need_keep > 0 && (n_keep != need_keep || r != 0));
     if (t == 0) *dR_next = stop ? -1 : R_new;
-    if (stop || t >= R) return;
+    if (stop) return;
+    if (cls_scale != nullptr && t < S) {                        // rank k -> its set and the factor of its survivors' weights
+        const int k = keep_rank[t];
+        if (k >= 0) { cls_sof[k] = (int32_t)t; cls_scale[k] = w_star[k] / tot[t]; }
+    }
+    if (t >= R) return;
     const int c = idx_cur[t];
     int s;
     int64_t dst;
@@ -406,6 +416,7 @@ static Switches read_switches() {
     w.car_force_giveup = getenv("SOBER_CAR_FORCE_GIVEUP") != nullptr;
     w.car_unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;
     w.car_gram = getenv("SOBER_CAR_GRAM") != nullptr;
+    w.level_no_classes = getenv("SOBER_LEVEL_NO_CLASSES") != nullptr;
     w.car_exact_ratio = getenv("SOBER_CAR_EXACT_RATIO") != nullptr;
     return w;
 }
@@ -571,7 +582,22 @@ extern "C" int sober_level_update_queued(const int32_t* idx_cur, int64_t R_ub, i
     if (!idx_cur || !keep_rank || !w_star || !tot || !mu || !idx_new || !dR_cur || !dR_next || R_ub <= 0 || S <= 0)
         return SOBER_E_ARG;
     hipLaunchKernelGGL(k_level_update_queued, dim3(nblk(R_ub, 256)), dim3(256), 0, (hipStream_t)stream, idx_cur, S,
-                       keep_rank, w_star, tot, mu, idx_new, dR_cur, dR_next, R_ub_next);
+                       keep_rank, w_star, tot, mu, idx_new, dR_cur, dR_next, R_ub_next, 0, (double*)nullptr, (int32_t*)nullptr);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ... of a level whose successor's set sums are derived from class sums (level_class.hip): the chain stops unless exactly
+// need_keep sets survived and the level had no leftovers; cls_sof[k] / cls_scale[k] = the set of rank k and w*_k / tot_k
+extern "C" int sober_level_update_queued_cls(const int32_t* idx_cur, int64_t R_ub, int S, const int32_t* keep_rank,
+                                             const double* w_star, const double* tot, double* mu, int32_t* idx_new,
+                                             const int64_t* dR_cur, int64_t* dR_next, int64_t R_ub_next, int need_keep,
+                                             double* cls_scale, int32_t* cls_sof, void* stream) {
+    if (!idx_cur || !keep_rank || !w_star || !tot || !mu || !idx_new || !dR_cur || !dR_next || R_ub < S || S <= 0 ||
+        need_keep <= 0 || need_keep > S || !cls_scale || !cls_sof)
+        return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_level_update_queued, dim3(nblk(R_ub, 256)), dim3(256), 0, (hipStream_t)stream, idx_cur, S,
+                       keep_rank, w_star, tot, mu, idx_new, dR_cur, dR_next, R_ub_next, need_keep, cls_scale, cls_sof);
     LAUNCH_CHECK();
     return 0;
 }

@@ -72,3 +72,112 @@ def test_bench_default_line_carries_the_other_configs_and_the_acquisition_step(d
     a = d["acquisition_step"]
     assert "error" not in a, a
     assert a["ms_per_step"] > 0 and a["parity"]["reference_fixture_sober_next_batch_equal"] is True, a
+
+
+# --------------------------------------------------------------------------- #
+# levels derived from level 0's class sums (csrc/level_class.hip)
+# --------------------------------------------------------------------------- #
+def _kspec(spec):
+    return sober_amd.KernelSpec(spec.kind, spec.lengthscale, spec.outputscale, spec.X_obs, spec.S_cache, spec.noise,
+                                spec.mean_const, spec.alpha)
+
+
+def _both_ways(case, dev):
+    """The same step with the levels derived from class sums (default) and with every level's sums evaluated."""
+    import warnings
+    from sober_amd._ops_hip import HipOps
+    from tests.golden.synth import SEED_CALL, build_spec, synth
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    out = []
+    for classes in (True, False):
+        ops = HipOps(dev)
+        ops.level_classes = classes
+        mu = _t(inp["mu0"].copy()).to(dev)
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            i, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                           sober_amd.Kernel(_kspec(spec), case["mode"]), init_weights=mu, _ops=ops)
+        out.append((i.cpu().numpy(), w.cpu().numpy(), mu.cpu().numpy(), dict(ops.last_levels)))
+    return inp, spec, out
+
+
+@pytest.mark.parametrize("case,depth", [
+    (dict(kind="rbf", mode="predictive_covariance", N=100000, M=500, d=10, b=100, n_obs=200, seed=0), 2),      # BASELINE configs[1]
+    (dict(kind="rbf", mode="predictive_covariance", N=2000, M=100, d=2, b=10, n_obs=30, seed=0, ard=True), 2),  # configs[0]
+    (dict(kind="matern52", mode="predictive_covariance", N=40 * 8 * 30, M=96, d=6, b=20, n_obs=40, seed=3), 4),
+    (dict(kind="rbf", mode="weighted_predictive_covariance", N=64 * 8 * 7, M=120, d=20, b=32, n_obs=50, seed=4, mean_const=0.1), 3),
+    (dict(kind="rbf", mode="predictive_covariance", N=200 * 1024, M=300, d=5, b=100, n_obs=60, seed=6, zero_frac=0.0), 4),
+    (dict(kind="tanimoto", mode="weighted_predictive_covariance", N=100 * 2 * 21, M=300, d=512, b=50, n_obs=100, seed=12, bit_p=0.06, mean_const=0.3), 1),
+    (dict(kind="tanimoto", mode="predictive_covariance", N=200 * 2 * 125, M=500, d=1024, b=100, n_obs=200, seed=13, bit_p=0.04), 1),
+    (dict(kind="rbf", mode="predictive_covariance", N=60 * 2 * 9, M=80, d=3, b=30, n_obs=20, seed=9), 1),
+    (dict(kind="rbf", mode="predictive_covariance", N=60 * 2 * 9 + 7, M=80, d=3, b=30, n_obs=20, seed=9), 0),   # leftovers: evaluated
+    (dict(kind="rbf", mode="predictive_covariance", N=60 * 9, M=80, d=3, b=30, n_obs=20, seed=9), 0),           # odd element count
+], ids=["cfg2", "cfg1", "matern_d4", "weighted_d3", "rbf_205k_d4", "tanimoto_small", "tanimoto_50k", "depth1", "leftovers", "odd"])
+def test_levels_derived_from_class_sums_equal_the_evaluated_ones(case, depth, dev):
+    """SOBER/_rchq.py:116-126 on levels 1 .. D is a gather-and-scale of level 0's sums by element class e mod 2^D (:198-221:
+    element-major compaction) -- the default path -- against the same step with every level's kernel evaluated
+    (`HipOps.level_classes = False`): identical indices, weights and the mutated init_weights to 1e-9; the executor reports the
+    depth it used; and both against the oracle."""
+    import warnings
+    from oracle import sober_oracle as O
+    from tests.golden.synth import SEED_CALL
+    inp, spec, ((i1, w1, m1, lv1), (i0, w0, m0, lv0)) = _both_ways(case, dev)
+    # (depth: what the pool's size allows -- R % (2^D S) == 0 with two elements left -- capped by the executor where the class
+    #  launch's partial slots x classes would not fit its buffers: sober_level_class_depth)
+    assert (lv1["derived"] == depth or (depth > 2 and 2 <= lv1["derived"] < depth)) and lv0["derived"] == 0, (lv1, lv0)
+    assert lv1["R"] == lv0["R"]
+    assert np.array_equal(i1, i0)
+    np.testing.assert_allclose(w1, w0, rtol=1e-9)
+    np.testing.assert_allclose(m1, m0, rtol=1e-9, atol=0)
+    if case["N"] <= 30000:
+        mu_ref = _t(inp["mu0"].copy())
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            i_ref, w_ref = O.recombination(_t(inp["X_cand"]), _t(inp["X_nys"]), case["b"], O.Kernel(spec, case["mode"]),
+                                           init_weights=mu_ref)
+        assert np.array_equal(i1, i_ref.numpy())
+        np.testing.assert_allclose(w1, w_ref.numpy(), rtol=1e-7)
+
+
+def test_class_chain_stops_unless_exactly_b_sets_survive(dev):
+    """sober_level_update_queued_cls: the successor's sums can only be derived when exactly b of the 2b sets survived and the
+    level had no leftovers -- otherwise *dR_next = -1 with the weights and the list untouched (the synchronised loop redoes
+    the level); with b survivors it writes the rank -> set table and the factors w*_k / tot_k the derive kernel reads."""
+    from sober_amd import _native as nat
+    lib = nat.load()
+    S, b, E = 8, 4, 6
+    R = S * E
+    i32, f64 = torch.int32, torch.float64
+    idx = torch.arange(R, dtype=i32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(keep, r_extra=0):
+        kr = torch.full((S + 1,), -1, dtype=i32, device=dev)
+        kept = [s for s in range(S) if keep[s]]
+        for k, s in enumerate(kept):
+            kr[s] = k
+        kr[S] = len(kept)
+        w_star = torch.arange(1, S + 1, dtype=f64, device=dev) * 0.125
+        tot = torch.arange(2, S + 2, dtype=f64, device=dev)
+        mu = torch.ones(R + r_extra, dtype=f64, device=dev)
+        idx_ = torch.arange(R + r_extra, dtype=i32, device=dev)
+        new = torch.full((R + r_extra,), -7, dtype=i32, device=dev)
+        dR = torch.tensor([R + r_extra, 123], dtype=torch.int64, device=dev)
+        scale, sof = torch.full((S,), -1.0, dtype=f64, device=dev), torch.full((S,), -1, dtype=i32, device=dev)
+        nat._check(lib.sober_level_update_queued_cls(idx_.data_ptr(), R + r_extra, S, kr.data_ptr(), w_star.data_ptr(), tot.data_ptr(),
+                                                     mu.data_ptr(), new.data_ptr(), dR.data_ptr(), dR[1:].data_ptr(), R, b,
+                                                     scale.data_ptr(), sof.data_ptr(), st), "update_cls")
+        torch.cuda.synchronize()
+        return int(dR[1].item()), mu.cpu().numpy(), new.cpu().numpy(), scale.cpu().numpy(), sof.cpu().numpy(), kept
+
+    nxt, mu, new, scale, sof, kept = run([1, 0, 1, 0, 0, 1, 1, 0])
+    assert nxt == E * b and sof[:b].tolist() == kept
+    np.testing.assert_array_equal(scale[:b], [(k + 1) * 0.125 / (s + 2) for k, s in enumerate(kept)])
+    assert sorted(new[:E * b].tolist()) == sorted(e * S + s for e in range(E) for s in kept)
+    nxt, mu, new, *_ = run([1, 0, 1, 0, 0, 1, 0, 0])                  # three survivors
+    assert nxt == -1 and (mu == 1.0).all() and (new == -7).all()
+    nxt, mu, new, *_ = run([1, 0, 1, 0, 0, 1, 1, 0], r_extra=3)       # leftovers
+    assert nxt == -1 and (mu == 1.0).all() and (new == -7).all()
