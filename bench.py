@@ -688,8 +688,13 @@ def measure(args, config, rank, world, dev, group, backend):
     ms_per_step = elapsed / args.steps * 1e3
     traffic, traffic_src = pmc_traffic(config) if world == 1 else (None, None)
     n_rows = cfg["M"] + (cfg["n_obs"] if cfg["mode"] != "kernel" else 0)
-    V = entries / n_rows / ev_steps                      # visited list positions per step (sum of the levels' sizes)
-    n_levels = sum(1 for _, _, e, _ in prof if e > 0 and e >= 2 * b * n_rows) / ev_steps   # main launches per step
+    V = entries / n_rows / ev_steps                      # list positions the level kernel EVALUATED per step
+    # the levels of the step (live positions each) and how many of them took their set sums from level 0's class sums
+    # instead of a kernel launch (csrc/level_class.hip): the algorithmic figures of SURVEY.md 8(d) count every level
+    lv = getattr(ops, "last_levels", None) or {"R": [], "derived": 0}
+    V_alg = float(sum(lv["R"])) if lv["R"] and world == 1 else V
+    n_levels = float(len(lv["R"])) if lv["R"] and world == 1 else \
+        sum(1 for _, _, e, _ in prof if e > 0 and e >= 2 * b * n_rows) / ev_steps
     S2, n1 = 2 * b, b - 1
     common = {"launches": n_launches, "launches_per_step": n_launches / ev_steps, "steps_with_events": ev_steps,
               "kernel_ms_per_step": kern_ms / ev_steps,
@@ -697,7 +702,8 @@ def measure(args, config, rank, world, dev, group, backend):
                         f"the kernel in every {ev_every}-th step of the timed region ({ev_steps} of {args.steps} steps), "
                         "nothing subtracted",
               "traffic": traffic, "traffic_unit": "HBM bytes per launch, mean over the kernel's launches of a step",
-              "traffic_source": traffic_src, "V_per_step": V, "entries_per_step": entries / ev_steps}
+              "traffic_source": traffic_src, "V_per_step": V, "V_alg_per_step": V_alg, "entries_per_step": entries / ev_steps,
+              "levels_per_step": n_levels, "levels_derived_from_class_sums": int(lv["derived"]) if world == 1 else None}
     if cfg["kind"] == "tanimoto":
         # popcount(x & y) as an FP4 (E2M1: 0.0 / 1.0) GEMM on the matrix cores (csrc/level_reduce_tani.hip): 2 * bits operations
         # per (row, candidate) pair, against the dense FP4 MFMA peak (4 x the bf16 rate, MI355X_MICROARCH.md).  (Rounds 2-3
@@ -706,9 +712,10 @@ def measure(args, config, rank, world, dev, group, backend):
         bits = 64 * ((cfg["d"] + 63) // 64)
         ops_step = entries / ev_steps * 2 * bits
         tops = entries * 2 * bits / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-        alg_bytes = V * (bits / 8 + 16) + n_levels * (n_rows * S2 + S2) * 8
+        alg_bytes = V_alg * (bits / 8 + 16) + n_levels * (n_rows * S2 + S2) * 8
         roofline = dict(common, bound="mfma", achieved=tops, peak=FP4_PEAK_TOPS, unit="TFLOP/s", frac=tops / FP4_PEAK_TOPS,
                         step_frac=ops_step / (ms_per_step * 1e-3) / 1e12 / FP4_PEAK_TOPS, kernel="k_level_reduce_tani",
+                        F_executed_per_step=ops_step, F_alg_per_step=V_alg * n_rows * 2 * bits,
                         peak_int8=5000.0, frac_of_int8_peak=tops / 5000.0,
                         note="bit-packed fingerprints, every bit expanded to an E2M1 nibble (1.0 / 0.0) in LDS, "
                              "v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales: exact popcounts in FP32 (bit-pair operations "
@@ -718,19 +725,25 @@ def measure(args, config, rank, world, dev, group, backend):
         flop_per_entry = 2 * cfg["d"] + 2 + CK[cfg["kind"]]
         achieved = entries * flop_per_entry / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         # F_alg = entries (2d + 2 + C_k) + L (2 M n_obs S + 2 n M S)
-        f_alg = entries / ev_steps * flop_per_entry + n_levels * (2.0 * cfg["M"] * cfg["n_obs"] * S2 + 2.0 * n1 * cfg["M"] * S2)
-        alg_bytes = V * (8 * cfg["d"] + 16) + n_levels * (n_rows * S2 + S2) * 8
+        f_gemm = n_levels * (2.0 * cfg["M"] * cfg["n_obs"] * S2 + 2.0 * n1 * cfg["M"] * S2)
+        f_alg = V_alg * n_rows * flop_per_entry + f_gemm            # every level's kernel entries, as the reference evaluates them
+        f_exe = entries / ev_steps * flop_per_entry + f_gemm        # what this step evaluated (derived levels: a gather and a scale)
+        alg_bytes = V_alg * (8 * cfg["d"] + 16) + n_levels * (n_rows * S2 + S2) * 8
         roofline = dict(common, bound="mfma", achieved=achieved, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=achieved / FP64_PEAK_TFLOPS, peak_measured=FP64_MEASURED_TFLOPS,
                         frac_of_measured_mix=achieved / FP64_MEASURED_TFLOPS["level-kernel mix (12 MFMA + 160 FMA)"],
-                        F_alg_per_step=f_alg, step_frac=f_alg / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                        F_alg_per_step=f_alg, F_executed_per_step=f_exe,
+                        step_frac=f_exe / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                        step_frac_alg=f_alg / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                         kernel="k_level_reduce_wave",
                         note="FP64 compute-bound: -|x-y|^2/2 on v_mfma_f64_16x16x4 (augmented GEMM), "
                              "table-driven FP64 exp on the VALU; MI355X FP64 vector and matrix peaks are "
                              "both 78.6 TFLOP/s at 2.4 GHz and share the vector ALU: on gfx950 no vector "
                              "instruction of a SIMD overlaps with a running v_mfma_f64, and the clock under "
                              "FP64 load is ~1.9 GHz (peak_measured) -- the kernel is bound by its instruction count; "
-                             f"algorithmic flop = entries * (2d+2+C_k) = entries * {flop_per_entry}; all launches of "
+                             f"achieved / frac: EXECUTED entries * (2d+2+C_k) = entries * {flop_per_entry} over the kernel's own time "
+                             "(levels whose set sums are gathered and scaled from level 0's element-class sums are not counted: "
+                             "F_executed_per_step; F_alg_per_step counts every level like SURVEY.md 8d); all launches of "
                              "the kernel are counted (level 0 alone runs ~1.35x the average; the deep levels are "
                              "launch-bound); step_frac: the step is a chain of ~200 dependent Caratheodory "
                              "reflector/pivot steps per level, not a throughput problem")

@@ -255,6 +255,20 @@ int sober_car_device_ex(const double* X, int ldx, int N, int m, const double* mu
  * Out: keep_rank[0:Nsets] (new ranks, -1 = cancelled), w_star[0:n_keep], *n_keep.                               */
 int sober_second_elimination(const double* phi, const double* objp, const double* w1, const int32_t* rank1, int n1,
                              int Nsets, int32_t* keep_rank, double* w_star, int32_t* n_keep, void* stream);
+/* Round 6: that null vector in ONE launch (csrc/null_vector.hip): Gauss-Jordan elimination with partial pivoting on
+ * A2 = [features of the n1 survivors; 1] (nfun + 1 rows, n1 = nfun + 2 points) read straight from the level's X (Nsets x ldx,
+ * the first nfun columns: the objective column is not part of A2) through rank1 -- instead of a second run of the Caratheodory
+ * kernels on the survivors.  null_row[0:Nsets]: the vector by SET, zero on cancelled sets; *status: 0, -1 / -2 when the first
+ * step gave up / did not leave exactly n1 sets (*n_keep1 read on the device), -3 when A2 has a zero pivot row (null space not
+ * a line: the reference's answer is then whatever its SVD returns -- the caller's host route).  nfun <= 111 (one workgroup).
+ * sober_second_elimination_rows: the elimination with null vector and objective BY SET and the first step's verdict read on
+ * the device: *n_keep = -2 (nothing written) unless *n_keep1 == n1, -1 when the first step gave up.                  */
+int sober_null_vector_supported(int nfun);
+int sober_null_vector(const double* X, int ldx, int Nsets, int nfun, const int32_t* rank1, const int32_t* n_keep1, int n1,
+                      double* null_row, int32_t* status, void* stream);
+int sober_second_elimination_rows(const double* null_row, const double* obj_row, const double* w1, const int32_t* rank1,
+                                  const int32_t* n_keep1, int n1, int Nsets, int32_t* keep_rank, double* w_star,
+                                  int32_t* n_keep, void* stream);
 
 /* The multi-CU implementation by itself (any size it covers, also the small ones: test and timing hook). */
 int sober_car_mc_supported(int N, int m);

@@ -72,6 +72,9 @@ SIGNATURES = {
     "sober_car_mc_ws_bytes": (_i64, [_i32, _i32]),
     "sober_car_mc_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_car_device_ex": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "sober_null_vector_supported": (_i32, [_i32]),
+    "sober_null_vector": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "sober_second_elimination_rows": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sober_car_safe_supported": (_i32, [_i32, _i32]),
     "sober_car_giveup_forced": (_i32, []),
     "sober_final_commit": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
@@ -544,6 +547,19 @@ def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None, multi_
     _check(fn(X.data_ptr(), X.stride(0), N, n + 1, mu_in.data_ptr(), keep_rank.data_ptr(),
               w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
               ws.data_ptr(), nbytes, _stream(X)), name)
+
+
+def null_vector(X, nfun, rank1, n_keep1, n1, null_row, status):
+    """sober_null_vector: the null vector of [X[survivors, :nfun]^T; 1] by set (csrc/null_vector.hip)."""
+    _check(load().sober_null_vector(X.data_ptr(), X.stride(0), X.shape[0], int(nfun), rank1.data_ptr(), n_keep1.data_ptr(),
+                                    int(n1), null_row.data_ptr(), status.data_ptr(), _stream(X)), "sober_null_vector")
+
+
+def second_elimination_rows(null_row, obj_row, w1, rank1, n_keep1, n1, keep_rank, w_star, n_keep):
+    _check(load().sober_second_elimination_rows(null_row.data_ptr(), obj_row.data_ptr(), w1.data_ptr(), rank1.data_ptr(),
+                                                n_keep1.data_ptr(), int(n1), rank1.numel(), keep_rank.data_ptr(),
+                                                w_star.data_ptr(), n_keep.data_ptr(), _stream(null_row)),
+           "sober_second_elimination_rows")
 
 
 def second_elimination(phi, objp, w1, rank1, n1, keep_rank, w_star, n_keep):

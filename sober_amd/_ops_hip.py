@@ -38,6 +38,9 @@ class HipOps(_PlanOps, _NystromOps, _LevelOps):
         # False: every level's set sums evaluated; True: levels 1 .. D of a pool without leftovers gathered and scaled from
         # level 0's element-class sums (csrc/level_class.hip; the library's SOBER_LEVEL_NO_CLASSES switch gives depth 0 too)
         self.level_classes = True
+        # acquisition-guided branch: the second elimination's direction from csrc/null_vector.hip (False: from a second
+        # Caratheodory step on the b + 1 survivors, rounds 2-5 -- which stays for the sizes that kernel does not cover)
+        self.obj_null_kernel = True
         self.last_levels = None  # {"R": live positions per level, "derived": D} of the last level_loop call
         # the jitter ladder's probes on eight workgroups per rung (False: one workgroup each -- where the process stays
         # after a rung's workgroups lost each other)

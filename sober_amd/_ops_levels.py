@@ -345,6 +345,31 @@ class _LevelOps:
         N, n1f = X.shape                                     # n1f = n + 1 functions incl. the objective
         dev = self.device
         n1 = n1f + 1                                         # what the first step leaves when the branch is regular
+        # Round 6: the second elimination's direction by ONE launch on the survivors' own matrix (csrc/null_vector.hip: Gauss-
+        # Jordan with partial pivoting) instead of a second run of the Caratheodory kernels; the first step's verdict is read
+        # on the device, so nothing is read back between the launches.  Sizes beyond that kernel keep the second step below.
+        if self.obj_null_kernel and bool(nat.load().sober_null_vector_supported(n1f - 1)) and self.car_supported(N, n1f + 1):
+            for _ in range(2):
+                kr1, w1, nk1_d, _mu = self.car_device(X, mu_in)
+                null_row = torch.empty(N, dtype=torch.float64, device=dev)
+                status = torch.empty(1, dtype=torch.int32, device=dev)
+                nat.null_vector(X, n1f - 1, kr1, nk1_d, n1, null_row, status)
+                ocol = (X[:, n1f - 1] if obj_head is None else obj_head[:N]).contiguous()
+                keep_rank = torch.empty(N, dtype=torch.int32, device=dev)
+                w_star = torch.empty(N, dtype=torch.float64, device=dev)
+                n_keep = torch.empty(1, dtype=torch.int32, device=dev)
+                nat.second_elimination_rows(null_row, ocol, w1, kr1, nk1_d, n1, keep_rank, w_star, n_keep)
+                (kr1_h, nk1_h, keep_h, nk_h, st_h) = self.to_host(kr1, nk1_d, keep_rank, n_keep, status)
+                nk1 = int(nk1_h[0])
+                if nk1 == n1 and int(st_h[0]) == 0:
+                    return keep_rank, w_star, keep_h, int(nk_h[0]), (kr1_h, w1, n1)
+                if nk1 >= 0:
+                    return None                              # irregular first step or a rank-deficient A2: the host route
+                self._car_downgrade(nat.CAR_SAFE if nat.car_safe_supported(N, n1f + 1) and self.car_mode == nat.CAR_DEFAULT
+                                    else nat.CAR_HOST, "Caratheodory step")
+                if not self.car_supported(N, n1f + 1):
+                    return None
+            return None
         for _ in range(2):
             if not self.car_supported(N, n1f + 1) or not self.car_supported(n1, n1f):
                 return None

@@ -1059,16 +1059,34 @@ __global__ __launch_bounds__(SP_W * 64) void k_car_pivot_stream(const double* __
 // sign by the objective, :92-93, so ANY null vector gives its result).  One workgroup; n1 <= 512.
 //   in : phi[n1], objp[n1], w1[n1] (ranks of the first step), rank1[Nsets] (set -> rank or -1)
 //   out: keep_rank[Nsets] (new ranks), w_star[n_keep], *n_keep_out
+// BY_ROW: phi and objp are indexed by SET (sober_null_vector's output; the level's objective column) and brought to rank
+// order here; the first step must have left exactly n1 sets (*n_keep1 == n1), else *n_keep_out = -2 and nothing is written
+// (the caller's host route takes the level: the reference then reads a singular vector of a full-rank matrix); -1: it gave up.
+template <bool BY_ROW>
 __global__ __launch_bounds__(512) void k_second_elim(const double* __restrict__ phi, const double* __restrict__ objp,
                                                      const double* __restrict__ w1, const int32_t* __restrict__ rank1,
                                                      int n1, int Nsets, int32_t* __restrict__ keep_rank,
-                                                     double* __restrict__ w_star, int32_t* __restrict__ n_keep_out) {
+                                                     double* __restrict__ w_star, int32_t* __restrict__ n_keep_out,
+                                                     const int32_t* __restrict__ n_keep1) {
     __shared__ double red[512];
     __shared__ unsigned long long kmin[512];
     __shared__ int kidx[512];
     __shared__ int cnt[512];
     const int t = threadIdx.x;
-    const double ph = t < n1 ? phi[t] : 0.0, ob = t < n1 ? objp[t] : 0.0, w = t < n1 ? w1[t] : 0.0;
+    double ph, ob;
+    if constexpr (BY_ROW) {
+        if (*n_keep1 != n1) { if (t == 0) *n_keep_out = (*n_keep1 < 0) ? -1 : -2; return; }      // (uniform)
+        __shared__ double s_ph[512], s_ob[512];
+        for (int sidx = t; sidx < Nsets; sidx += 512) {
+            const int r1 = rank1[sidx];
+            if (r1 >= 0 && r1 < n1) { s_ph[r1] = phi[sidx]; s_ob[r1] = objp[sidx]; }
+        }
+        __syncthreads();
+        ph = t < n1 ? s_ph[t] : 0.0; ob = t < n1 ? s_ob[t] : 0.0;
+    } else {
+        ph = t < n1 ? phi[t] : 0.0; ob = t < n1 ? objp[t] : 0.0;
+    }
+    const double w = t < n1 ? w1[t] : 0.0;
     red[t] = ob * ph;                                                   // torch.dot(obj_p, w_null): only its sign is used
     __syncthreads();
     for (int h = 256; h > 0; h >>= 1) {
@@ -1265,8 +1283,22 @@ extern "C" int sober_second_elimination(const double* phi, const double* objp, c
                                         void* stream) {
     if (!phi || !objp || !w1 || !rank1 || !keep_rank || !w_star || !n_keep || n1 <= 0 || Nsets <= 0) return SOBER_E_ARG;
     if (n1 > 512) return SOBER_E_DIM;
-    hipLaunchKernelGGL(sober::k_second_elim, dim3(1), dim3(512), 0, (hipStream_t)stream, phi, objp, w1, rank1, n1, Nsets,
-                       keep_rank, w_star, n_keep);
+    hipLaunchKernelGGL(sober::k_second_elim<false>, dim3(1), dim3(512), 0, (hipStream_t)stream, phi, objp, w1, rank1, n1, Nsets,
+                       keep_rank, w_star, n_keep, (const int32_t*)nullptr);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ... with the null vector and the objective BY SET (sober_null_vector's output; the level's objective column) and the
+// first step's verdict read on the device: *n_keep = -2 when it did not leave exactly n1 sets (-1: it gave up)
+extern "C" int sober_second_elimination_rows(const double* null_row, const double* obj_row, const double* w1,
+                                             const int32_t* rank1, const int32_t* n_keep1, int n1, int Nsets,
+                                             int32_t* keep_rank, double* w_star, int32_t* n_keep, void* stream) {
+    if (!null_row || !obj_row || !w1 || !rank1 || !n_keep1 || !keep_rank || !w_star || !n_keep || n1 <= 0 || Nsets <= 0)
+        return SOBER_E_ARG;
+    if (n1 > 512) return SOBER_E_DIM;
+    hipLaunchKernelGGL(sober::k_second_elim<true>, dim3(1), dim3(512), 0, (hipStream_t)stream, null_row, obj_row, w1, rank1, n1,
+                       Nsets, keep_rank, w_star, n_keep, n_keep1);
     LAUNCH_CHECK();
     return 0;
 }

@@ -181,3 +181,87 @@ def test_class_chain_stops_unless_exactly_b_sets_survive(dev):
     assert nxt == -1 and (mu == 1.0).all() and (new == -7).all()
     nxt, mu, new, *_ = run([1, 0, 1, 0, 0, 1, 1, 0], r_extra=3)       # leftovers
     assert nxt == -1 and (mu == 1.0).all() and (new == -7).all()
+
+
+# --------------------------------------------------------------------------- #
+# acquisition-guided branch: the second elimination's direction in one launch (csrc/null_vector.hip)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("N,nfun", [(200, 99), (200, 100), (60, 29), (40, 12), (24, 11), (208, 103), (130, 64), (224, 110), (16, 7),
+                                   (30, 1)])
+def test_null_vector_kernel_on_the_survivors_matrix(N, nfun, dev):
+    """sober_null_vector on the survivors of a Caratheodory step with the objective as one more function (X = [features |
+    objective], N x (nfun + 1)): the vector it returns by set annihilates A2 = [features of the survivors; 1]
+    (SOBER/_rchq.py:88-91: the reference takes that vector from an SVD of this very matrix) -- residual at rounding level,
+    the angle to numpy's SVD null vector below 1e-12 --, is zero on cancelled sets; and the status word says when the first
+    step did not leave nfun + 2 sets."""
+    from sober_amd import _native as nat
+    rng = np.random.default_rng(100 * N + nfun)
+    X = rng.standard_normal((N, nfun + 1)) * np.exp(-0.02 * np.arange(nfun + 1))[None, :]
+    mu = rng.random(N) + 0.05
+    Xd, mud = _t(X).to(dev), _t(mu).to(dev)
+    i32, f64 = torch.int32, torch.float64
+    kr, w1, nk, mo = (torch.empty(N, dtype=i32, device=dev), torch.empty(N, dtype=f64, device=dev),
+                      torch.empty(1, dtype=i32, device=dev), torch.empty(N, dtype=f64, device=dev))
+    nat.car_device(Xd, mud, kr, w1, nk, mo)
+    n1 = nfun + 2
+    null_row = torch.full((N,), 7.0, dtype=f64, device=dev)
+    status = torch.full((1,), 99, dtype=i32, device=dev)
+    nat.null_vector(Xd, nfun, kr, nk, n1, null_row, status)
+    torch.cuda.synchronize()
+    assert int(nk.item()) == n1 and int(status.item()) == 0
+    krh, v = kr.cpu().numpy(), null_row.cpu().numpy()
+    kept = krh >= 0
+    assert (v[~kept] == 0.0).all() and np.abs(v[kept]).max() >= 1.0
+    A2 = np.concatenate([X[kept, :nfun].T, np.ones((1, n1))], 0)        # (nfun + 1) x (nfun + 2)
+    res = np.abs(A2 @ v[kept]).max() / (np.abs(A2).max() * np.abs(v[kept]).max())
+    assert res < 1e-12, res
+    ref = np.linalg.svd(A2)[2][-1]
+    assert 1.0 - abs(ref @ v[kept]) / np.linalg.norm(v[kept]) < 1e-12
+    # the first step's verdict is checked on the device
+    nk_bad = torch.tensor([n1 - 1], dtype=i32, device=dev)
+    nat.null_vector(Xd, nfun, kr, nk_bad, n1, null_row, status)
+    assert int(status.item()) == -2
+    nk_bad.fill_(-1)
+    nat.null_vector(Xd, nfun, kr, nk_bad, n1, null_row, status)
+    assert int(status.item()) == -1
+
+
+def test_null_vector_kernel_reports_a_rank_deficient_matrix(dev):
+    """Two identical feature columns among the survivors: A2 has a zero pivot row, its null space is a plane, and the
+    reference's vector is whatever its SVD returns -- status -3, the caller's host route takes the level."""
+    from sober_amd import _native as nat
+    N, nfun = 12, 9
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((N, nfun + 1))
+    X[:, 4] = X[:, 2]
+    i32, f64 = torch.int32, torch.float64
+    kr = torch.full((N,), -1, dtype=i32, device=dev)
+    kr[:nfun + 2] = torch.arange(nfun + 2, dtype=i32, device=dev)
+    nk = torch.tensor([nfun + 2], dtype=i32, device=dev)
+    null_row, status = torch.empty(N, dtype=f64, device=dev), torch.full((1,), 99, dtype=i32, device=dev)
+    nat.null_vector(_t(X).to(dev), nfun, kr, nk, nfun + 2, null_row, status)
+    assert int(status.item()) == -3
+
+
+def test_calc_obj_step_with_the_null_vector_kernel_equals_the_second_step_route(dev):
+    """The acquisition-guided recombination (SOBER/_rchq.py:67-69, :87-106, :177-196) with the second elimination's direction
+    from csrc/null_vector.hip (default) against the route of rounds 2-5 (a second Caratheodory step on the b + 1 survivors,
+    `HipOps.obj_null_kernel = False`) and against the reference golden: same points, weights 1e-6 (the golden's bar)."""
+    import warnings
+    from sober_amd._ops_hip import HipOps
+    from tests.golden.synth import SEED_CALL, calc_obj_fn, load_case
+    case, inp, spec, z = load_case(os.path.join(GOLD, "recomb_rbf_calc_obj.npz"))
+    res = []
+    for flag in (True, False):
+        ops = HipOps(dev)
+        ops.obj_null_kernel = flag
+        mu = _t(inp["mu0"].copy()).to(dev)
+        torch.manual_seed(SEED_CALL)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            i, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), case["b"],
+                                           sober_amd.Kernel(_kspec(spec), case["mode"]), init_weights=mu, calc_obj=calc_obj_fn, _ops=ops)
+        res.append((i.cpu().numpy(), w.cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][0], z["idx"])
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-8)
+    np.testing.assert_allclose(res[0][1], z["w"], rtol=1e-6)
