@@ -44,9 +44,11 @@ int sober_abi_version(void);
 /* 1 = a diagnostic build (in-kernel time stamps, -DSOBER_DIAG_BUILD: `make stamps`); sober_amd refuses to load one
  * unless SOBER_ALLOW_DIAG_LIB=1.  `make all` gives 0. */
 int sober_diag_build(void);
-/* The A/B and test switches of the environment (SOBER_LEVEL_TWO_LAUNCHES, SOBER_TANI_NO_QUEUE, SOBER_CAR_FORCE_GIVEUP,
- * SOBER_CAR_UNFUSED, SOBER_CAR_GRAM, SOBER_CAR_EXACT_RATIO, SOBER_LEVEL_NO_CLASSES) are read ONCE, when the library is loaded; a process that changes one afterwards
- * (the tests do) calls this to have them read again.  Returns 0.                                                    */
+/* The A/B and test switches of the environment that the LIBRARY reads (SOBER_LEVEL_TWO_LAUNCHES, SOBER_TANI_NO_QUEUE,
+ * SOBER_CAR_FORCE_GIVEUP, SOBER_CAR_UNFUSED, SOBER_CAR_EXACT_RATIO, SOBER_LEVEL_NO_CLASSES) are read ONCE, when it is loaded; a
+ * process that changes one afterwards (the tests do) calls this to have them read again.  Returns 0.  (The Python host side has
+ * switches of its own, read where they act: SOBER_NO_QUEUE at HipOps construction, SOBER_PREDICT_MATERIALISED and
+ * SOBER_NYSTROM_DEBUG per call, SOBER_HIP_LIB / SOBER_ALLOW_DIAG_LIB at load -- INTEGRATION.md lists them.)           */
 int sober_reload_switches(void);
 /* sizeof(sober_level_job) / sizeof(sober_nystrom_job) as the library was built: a binding that lays the structs out itself
  * (ctypes, cgo, JNA ...) checks its own size against these before the first call.                                   */
@@ -306,20 +308,6 @@ int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, int32_t* in
                              double* ratio_out, void* stream);
 /* Q[r, 0:q] = Y[r, 0:q] L^-T (L lower triangular q x q, q <= 256: the Q factor of Y when L L^T = Y^T Y), blocked
  * on the matrix cores with the inverted diagonal blocks of sober_cholesky_inv: block-to-block dependency only.                                                          */
-/* Guarded forms of sober_dgemm / sober_cholesky_inv_ratio / sober_trsm_blocks: when skip_if != NULL and the double it
- * points to (device memory, written by an earlier kernel on the stream) is >= skip_thr the launch does nothing --
- * sober_cholesky_inv_ratio_if then leaves info = 0, min_pivot = 1, ratio = 1 and sober_trsm_blocks_if copies Y to Q.
- * The range finder's optional CholeskyQR passes (sober_nystrom_basis) without a host decision.                          */
-/* *ok = 1.0 when *k_out == n_rungs (sober_jitter_ladder_auto took the diagonal fallback) and the diagonal of A satisfies
- * 0 < max d <= kappa_max * min d, else 0.0 -- the guard of the range finder's skipped passes.                              */
-int sober_diag_spread(const double* A, int n, int ld, const int32_t* k_out, int n_rungs, double kappa_max, double* ok,
-                      void* stream);
-int sober_dgemm_if(int transa, int transb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
-                   int ldb, double beta, double* C, int ldc, const double* skip_if, double skip_thr, void* stream);
-int sober_cholesky_inv_ratio_if(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, double* xinv,
-                                double* ratio_out, const double* skip_if, double skip_thr, void* stream);
-int sober_trsm_blocks_if(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl, const double* Xinv,
-                         double* Q, int ldq, const double* skip_if, double skip_thr, void* stream);
 int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl, const double* Xinv,
                       double* Q, int ldq, void* stream);
 /* All rungs of the jitter ladder in one launch: workgroup b factorises (src + shifts[b] I) in slab b of
@@ -706,10 +694,7 @@ int sober_projection(const double* Ut, int s, int M, const double* mean, const d
 typedef struct sober_nystrom_job {
     int32_t M, s, n_rungs, niter, probe_mc;     /* Gram size, basis size, ladder rungs (max_iter + 1), power iterations,
                                                    != 0: eight workgroups per rung (sober_cholesky_probe_mc)          */
-    int32_t skip_passes;                        /* != 0 (opt-in): the intermediate blocks of the range finder go on unorthonormalised
-                                                   when the repaired matrix is the diagonal fallback with max d <= 20 min d --
-                                                   decided on the device; -0.2 ms at cfg-2, a subspace error of ~4e-11 that
-                                                   hypersensitive pools turn into other indices (csrc/nystrom_exec.cpp)      */
+    int32_t reserved0;                          /* (0)                                                                  */
     const double* G;                            /* M x M Gram, row-major ld M: kernel(pt, pt) of SOBER/_rchq.py:35      */
     const double* shifts;                       /* n_rungs jitter totals 1e-5 (2^k - 1), device                        */
     const double* R;                            /* M x s standard normals, device: the CPU generator's draw            */

@@ -87,10 +87,6 @@ SIGNATURES = {
     "sober_cholesky_inv": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
     "sober_cholesky_inv_ratio": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp]),
     "sober_trsm_blocks": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
-    "sober_diag_spread": (_i32, [_vp, _i32, _i32, _vp, _i32, _f64, _vp, _vp]),
-    "sober_dgemm_if": (_i32, [_i32, _i32, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _i32, _f64, _vp, _i32, _vp, _f64, _vp]),
-    "sober_cholesky_inv_ratio_if": (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
-    "sober_trsm_blocks_if": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _f64, _vp]),
     "sober_cholesky_probe": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_cholesky_probe_piv": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "sober_cholesky_probe_mc_ws_bytes": (_i64, [_i32, _i32]),
@@ -183,7 +179,7 @@ class FinalJob(C.Structure):
 class NystromJob(C.Structure):
     """struct sober_nystrom_job of include/sober_hip.h (field for field)."""
     _fields_ = [
-        ("M", _i32), ("s", _i32), ("n_rungs", _i32), ("niter", _i32), ("probe_mc", _i32), ("skip_passes", _i32),
+        ("M", _i32), ("s", _i32), ("n_rungs", _i32), ("niter", _i32), ("probe_mc", _i32), ("_pad0", _i32),
         ("G", _vp), ("shifts", _vp), ("R", _vp), ("C", _vp), ("chol_work", _vp),
         ("probe_ws", _vp), ("probe_ws_bytes", _i64),
         ("Y", _vp * 2), ("Gm", _vp), ("xinv", _vp),
@@ -653,6 +649,16 @@ def predict_fused(kind, obs, obs_norm, cand, cand_norm, n, dt, outputscale, W, a
                   var_out, eta=0.0, lfi_out=None, log=False, eta_dev=None):
     """csrc/predict.hip: mean / variance / pi over `n` prepared candidates in one launch (W symmetric); eta_dev: the
     threshold as a one-element device tensor (read by the kernel: no host read-back)."""
+    # (the kernel takes raw pointers: only W's row stride travels -- everything else must be what it assumes)
+    if W.dtype != torch.float64 or W.dim() != 2 or W.stride(1) != 1:
+        raise SoberHipError(f"predict_fused: W must be float64 with unit inner stride, got {W.dtype} strides {tuple(W.stride())}")
+    if cand.dtype == torch.float64 and (cand.dim() != 2 or cand.stride(1) != 1 or cand.stride(0) != dt):
+        raise SoberHipError(f"predict_fused: candidates must be rows of {dt} contiguous float64, got strides {tuple(cand.stride())}")
+    for t_, nm in ((alpha, "alpha"), (mean_out, "mean_out"), (var_out, "var_out"), (lfi_out, "lfi_out"), (eta_dev, "eta_dev")):
+        if t_ is not None:
+            _req(t_, torch.float64, "predict_fused: " + nm)
+    if alpha is not None and alpha.numel() != obs.shape[0]:
+        raise SoberHipError(f"predict_fused: alpha has {alpha.numel()} entries for {obs.shape[0]} observations")
     _check(load().sober_predict_fused(int(kind), obs.data_ptr(), _ptr(obs_norm), obs.shape[0], cand.data_ptr(),
                                       _ptr(cand_norm), int(n), int(dt), float(outputscale), W.data_ptr(), W.stride(0),
                                       _ptr(alpha), float(c0), float(kxx_const), float(noise), _ptr(mean_out),
@@ -845,8 +851,13 @@ class PeerComm:
     def allreduce(self, buf, stream: int):
         _check(load().sober_peer_allreduce_f64(self.handle, buf.data_ptr(), buf.numel(), stream), "sober_peer_allreduce_f64")
 
-    def status(self) -> int:
-        return int(load().sober_peer_status(self.handle, None, 0, None))
+    def status(self, stream: int = None) -> int:
+        """sober_peer_status on `stream` (default: the device's current stream -- the one the all-reduces were queued on, so
+        that the clearing of the error word is ordered against them)."""
+        if stream is None:
+            import torch as _t
+            stream = _t.cuda.current_stream(self.device).cuda_stream
+        return int(load().sober_peer_status(self.handle, None, 0, stream))
 
     def self_check(self, dist, group) -> bool:
         """Four calls with rank- and round-dependent data; every rank must see the exact sums.  The ranks enter together

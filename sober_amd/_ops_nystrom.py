@@ -81,9 +81,6 @@ class _NystromOps:
         j.G, j.chol_work = G.data_ptr(), work.data_ptr()
         # (eight workgroups per rung from a few panels on: 0.49 -> 0.16 ms at M = 500; a rung whose workgroups lost each
         #  other reports PROBE_NO_VERDICT and the step goes to the host route, this process then stays with one each)
-        # (opt-in, SOBER_NYSTROM_SKIP=1: the range finder's intermediate CholeskyQR passes dropped behind the diagonal fallback
-        #  with a mild spread -- faster, a subspace error of ~4e-11 instead of ~1e-15: csrc/nystrom_exec.cpp has the trade)
-        j.skip_passes = 1 if os.environ.get("SOBER_NYSTROM_SKIP") else 0
         j.probe_mc = 1 if (M >= self.PROBE_MC_MIN and n_r <= 16 and self._probe_mc and M <= nat.chol_max_n()) else 0
         if j.probe_mc:
             pws = self._buf_u8(p, "chol_mc_ws", nat.cholesky_probe_mc_ws_bytes(M, n_r))
@@ -120,9 +117,9 @@ class _NystromOps:
             overlap()                                       # (device work independent of U, behind the chain)
         ev.synchronize()
         hb = st["h_flags"]
-        n8 = 8 * (n_r + 1 + n_orth2 + 1)
+        n8 = 8 * (n_r + 1 + n_orth2)
         f64s, i32s = hb[:n8].view(torch.float64), hb[n8:].view(torch.int32)
-        piv_h, pivs_rf = f64s[:n_r + 1], f64s[n_r + 1:n_r + 1 + n_orth2]      # (then one double: passes skipped, 1.0 / 0.0)
+        piv_h, pivs_rf = f64s[:n_r + 1], f64s[n_r + 1:n_r + 1 + n_orth2]
         flags_h, infos_rf = i32s[:2 + n_r], i32s[2 + n_r:]
         if any(int(v) == nat.PROBE_NO_VERDICT for v in flags_h[2:]):
             self._probe_mc = False
@@ -134,8 +131,7 @@ class _NystromOps:
         # while min pivot / max diagonal of its Gram matrix (~ cond^-2) stays above ORTH1_MIN_RATIO
         last = 2 * niter
         if os.environ.get("SOBER_NYSTROM_DEBUG"):
-            print("nystrom: pivot ratios of the range finder's blocks", [float(pivs_rf[k + 1]) for k in range(0, n_orth2, 2)],
-                  "intermediate passes skipped:", float(f64s[n_r + 1 + n_orth2]))
+            print("nystrom: pivot ratios of the range finder's blocks", [float(pivs_rf[k + 1]) for k in range(0, n_orth2, 2)])
         single = [k for k in range(0, n_orth2, 2) if k // 2 != last]
         rank_lost = bool((infos_rf != 0).any()) or float(pivs_rf[2 * last + 1]) < 0.5 \
             or any(not (float(pivs_rf[k + 1]) >= self.ORTH1_MIN_RATIO) for k in single)

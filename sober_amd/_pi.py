@@ -36,7 +36,11 @@ def _predict(spec, X, eta=None, log=False, eta_dev=None):
     kind = nat.KIND_BY_NAME[spec.kind]
     pobs = prepare_points(spec, spec.X_obs)
     W = woodbury(spec)
+    if W.dtype != torch.float64 or W.stride(-1) != 1:      # (the fused kernel reads raw rows: csrc/predict.hip takes W's row stride only)
+        W = W.to(torch.float64).contiguous()
     n_obs, N = len(pobs), X.shape[0]
+    alpha = spec.alpha if spec.alpha is None or (spec.alpha.dtype == torch.float64 and spec.alpha.is_contiguous()) \
+        else spec.alpha.to(torch.float64).contiguous()
     mean = torch.empty(N, dtype=torch.float64, device=dev)
     var = torch.empty(N, dtype=torch.float64, device=dev)
     fused = (nat.predict_fused_supported(kind, n_obs, pobs.dt) and spec.alpha is not None
@@ -51,7 +55,7 @@ def _predict(spec, X, eta=None, log=False, eta_dev=None):
         pts = prepare_points(spec, X[lo:hi])
         n = hi - lo
         if fused:
-            nat.predict_fused(kind, pobs.data, pobs.norm, pts.data, pts.norm, n, pts.dt, spec.outputscale, W, spec.alpha,
+            nat.predict_fused(kind, pobs.data, pobs.norm, pts.data, pts.norm, n, pts.dt, spec.outputscale, W, alpha,
                               spec.mean_const, _kxx_const(spec), spec.noise, mean[lo:hi], var[lo:hi],
                               0.0 if eta is None else eta, None if lfi is None else lfi[lo:hi], log,
                               eta_dev=eta_dev if eta is not None else None)
@@ -104,6 +108,16 @@ class PI:
     def eta(self):
         """The reference's `self.eta` (SOBER/_pi.py:17) as a number (reads the device value back)."""
         return None if self._eta_dev is None else float(self._eta_dev.item())
+
+    @eta.setter
+    def eta(self, value):
+        """The reference's eta is a plain attribute a caller may assign (SOBER/_pi.py:17): the value goes to the device word the
+        kernel reads; a live model's next call re-derives it from the model, like the reference's own `lfi`."""
+        dev = self._eta_dev.device if self._eta_dev is not None else (self._spec.X_obs.device if self._spec is not None else None)
+        if dev is None:
+            from . import _settings
+            dev = _settings._device
+        self._eta_dev = torch.tensor([float(value)], dtype=torch.float64, device=dev)
 
     def lfi(self, X_cand, log=False):
         spec = self._prepare(X_cand.device)

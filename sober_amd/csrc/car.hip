@@ -660,7 +660,6 @@ __global__ __launch_bounds__(256) void k_car_phi(const double* __restrict__ vws,
     }
 }
 
-#include "car_gram.inc"
 
 // ---------------- phase 3: the pivots of SOBER/_rchq.py:237-266 ----------------
 template <int CTRL, int ROW_MASK>
@@ -1155,8 +1154,7 @@ extern "C" int sober_car_supported(int N, int m) {
 // (a workspace sized for (N, m) also serves every (N' <= N, m): the final direct level)
 extern "C" int64_t sober_car_ws_bytes(int N, int m) {
     const int64_t one = ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC + 512) * (int64_t)sizeof(double)   // (+512: stamp block)
-                        + sober::cg_comm_bytes()                                      // + the fused launches' words
-                        + sober::cg_ws_doubles() * (int64_t)sizeof(double);           // + the Gram route's scratch (car_gram.inc)
+                        + sober::carf_bytes(0);                                       // + the fused launch's words
     if (car_one_cu(N, m)) return one;
     const int64_t mc = sober_car_mc_ws_bytes(N, m);
     return mc > one ? mc : one;
@@ -1207,9 +1205,11 @@ __global__ __launch_bounds__(256) void k_probe_rcp(const double* __restrict__ x,
 }
 }
 extern "C" int sober_probe_rcp(const double* x, double* out, int64_t n, void* stream) {
-    if (n <= 0) return 0;
+    if (n < 0 || (n > 0 && (!x || !out))) return SOBER_E_ARG;
+    if (n == 0) return 0;
     hipLaunchKernelGGL(sober::k_probe_rcp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, n);
-    return (int)hipGetLastError();
+    LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const double* mu_in,
@@ -1245,25 +1245,10 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
     static std::atomic<unsigned> epoch_ctr{0};
     const unsigned epoch = (epoch_ctr.fetch_add(1) + 1u) & 0x1FFFFFFu;
     void* comm = (void*)(Phi + (size_t)sober::CAR_NS * sober::CAR_PC + 512);
-    double* gws = (double*)((char*)comm + sober::cg_comm_bytes());
     constexpr int per_xcd = 40;
     const unsigned spin_limit = sober_car_giveup_forced() ? 0u : sober::CARF_SPIN_LIMIT;
-    if (sober::switches().car_gram) {
-        // the reflectors by way of the Gram matrix (car_gram.inc): G = A A^T, then ONE launch -- tridiagonalisation + LU in
-        // workgroup 0 (the bidiagonalisation instead when G is too ill-conditioned), Q^T A / P1 and Phi in the others
-        const int mt = (m + 15) / 16;
-        hipLaunchKernelGGL(sober::k_car_gram, dim3(mt, mt), dim3(256), 0, st, X, ldx, N, m, sober::cg_ws(gws).G);
-        LAUNCH_CHECK();
-        CAR_BY_SIZE(m, N, hipLaunchKernelGGL((sober::k_car_gram_fused<MS_, CQ_>), dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X,
-                                             ldx, N, m, vws, taup, Phi, gws, comm, (unsigned)sober::cg_comm_bytes(), epoch, spin_limit));
-        LAUNCH_CHECK();
-        CAR_PIVOT_BY_SIZE(N, hipLaunchKernelGGL((sober::k_car_pivot_stream<NQ_>), dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m,
-                                                mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm, (int)sober::switches().car_exact_ratio));
-        LAUNCH_CHECK();
-        return 0;
-    }
     CAR_BY_SIZE(m, N, hipLaunchKernelGGL((sober::k_car_bidiag_fused<MS_, CQ_>), dim3(1 + 8 * per_xcd), dim3(sober::CAR_BT), 0, st, X, ldx,
-                                         N, m, vws, taup, Phi, comm, (unsigned)sober::cg_comm_bytes(), epoch, spin_limit));
+                                         N, m, vws, taup, Phi, comm, (unsigned)sober::carf_bytes(0), epoch, spin_limit));
     LAUNCH_CHECK();
     CAR_PIVOT_BY_SIZE(N, hipLaunchKernelGGL((sober::k_car_pivot_stream<NQ_>), dim3(1), dim3(sober::SP_W * 64), sp_bytes, st, Phi, N, m,
                                             mu_in, keep_rank, w_star, n_keep, mu_out, (const unsigned*)comm, (int)sober::switches().car_exact_ratio));

@@ -142,17 +142,8 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
                                               int32_t* __restrict__ info, double* __restrict__ min_pivot,
                                               const double* __restrict__ src, int lds_src,
                                               const double* __restrict__ shifts, double* __restrict__ xout,
-                                              double* __restrict__ ratio_out, const double* __restrict__ skip_if,
-                                              double skip_thr) {
+                                              double* __restrict__ ratio_out) {
     extern __shared__ double lds[];
-    if (skip_if != nullptr && *skip_if >= skip_thr) {       // guarded form (sober_cholesky_inv_ratio_if): this factorisation is
-        if (threadIdx.x == 0 && blockIdx.x == 0) {           // not needed -- leave the verdicts of a perfect one behind
-            info[0] = 0;
-            if (min_pivot) min_pivot[0] = 1.0;
-            if (ratio_out) ratio_out[0] = 1.0;
-        }
-        return;
-    }
     if (src != nullptr) {                     // batched: copy the lower triangle into my slab first
         A += (size_t)blockIdx.x * n * ld;
         info += blockIdx.x;
@@ -765,17 +756,10 @@ constexpr int TB_WAVES = 2;
 __global__ __launch_bounds__(TB_WAVES * 64) void k_trsm_blocks(const double* __restrict__ Y, int64_t m, int q, int ldy,
                                                               const double* __restrict__ L, int ldl,
                                                               const double* __restrict__ Xinv,
-                                                              double* __restrict__ Q, int ldq,
-                                                              const double* __restrict__ skip_if, double skip_thr) {
+                                                              double* __restrict__ Q, int ldq) {
     extern __shared__ double tb_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    if (skip_if != nullptr && *skip_if >= skip_thr) {       // guarded form (sober_trsm_blocks_if): the block stays what it is
-        const int64_t r0 = ((int64_t)blockIdx.x * TB_WAVES + wave) * 16;
-        for (int64_t r = r0; r < min(r0 + 16, m); ++r)
-            for (int c = lane; c < q; c += 64) Q[r * ldq + c] = Y[r * ldy + c];
-        return;
-    }
     const int qpad = ((q + 31) / 32) * 32, LS = qpad + 4;             // stash row stride: fragments on distinct bank pairs
     double* stash = tb_lds + (size_t)wave * (16 * LS + 16 * 36);      // 16 x LS: the Q blocks finished so far
     double* tbuf = stash + 16 * LS;                                   // 16 x 36: the block being multiplied by X^T
@@ -897,32 +881,6 @@ __global__ void k_jitter_ladder_auto(double* __restrict__ A, int n, int ld, cons
     } else if (k == n_rungs) {
         A[(size_t)i * ld + j] = 0.0;
     }
-}
-
-// After the ladder: is the repaired matrix the DIAGONAL fallback with a mild spread?  *ok = 1.0 when no rung was positive
-// definite (k == n_rungs: the matrix is diag(d) now) and max d <= kappa_max * min d (min d > 0), else 0.0.  For a diagonal
-// matrix the eigenvalues ARE d, so kappa bounds what every further multiplication by it does to a block of the range
-// finder -- the one case in which the intermediate orthonormalisations can be dropped on a proven bound
-// (csrc/nystrom_exec.cpp).  One workgroup.
-__global__ __launch_bounds__(256) void k_diag_spread(const double* __restrict__ A, int n, int ld, const int32_t* __restrict__ k_out,
-                                                     int n_rungs, double kappa_max, double* __restrict__ ok) {
-    __shared__ double s_min[256], s_max[256];
-    double mn = __builtin_inf(), mx = -__builtin_inf();
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const double d = A[(size_t)i * ld + i];
-        mn = fmin(mn, d); mx = fmax(mx, d);
-        if (!(d == d)) mn = -__builtin_inf();                     // (a NaN: never "mild")
-    }
-    s_min[threadIdx.x] = mn; s_max[threadIdx.x] = mx;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-        if (threadIdx.x < h) {
-            s_min[threadIdx.x] = fmin(s_min[threadIdx.x], s_min[threadIdx.x + h]);
-            s_max[threadIdx.x] = fmax(s_max[threadIdx.x], s_max[threadIdx.x + h]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *ok = (*k_out == n_rungs && s_min[0] > 0.0 && s_max[0] <= kappa_max * s_min[0]) ? 1.0 : 0.0;
 }
 
 }  // namespace sober
@@ -1092,17 +1050,8 @@ extern "C" int sober_cholesky_inv(double* A, int n, int ld, double shift, int32_
     return sober_cholesky_inv_ratio(A, n, ld, shift, info, min_pivot, xinv, nullptr, stream);
 }
 
-extern "C" int sober_cholesky_inv_ratio_if(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
-                                           double* xinv, double* ratio_out, const double* skip_if, double skip_thr,
-                                           void* stream);
 extern "C" int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
                                         double* xinv, double* ratio_out, void* stream) {
-    return sober_cholesky_inv_ratio_if(A, n, ld, shift, info, min_pivot, xinv, ratio_out, nullptr, 0.0, stream);
-}
-
-extern "C" int sober_cholesky_inv_ratio_if(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot,
-                                           double* xinv, double* ratio_out, const double* skip_if, double skip_thr,
-                                           void* stream) {
     if (!A || !info || n <= 0 || ld < n) return SOBER_E_ARG;
     if (n > sober::CH_MAXN) return SOBER_E_DIM;
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
@@ -1118,10 +1067,10 @@ extern "C" int sober_cholesky_inv_ratio_if(double* A, int n, int ld, double shif
     if (n <= sober::CH_SMALLN) {
         bytes += (size_t)n * (n + 1) * sizeof(double);
         hipLaunchKernelGGL(sober::k_chol<true>, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift,
-                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv, ratio_out, skip_if, skip_thr);
+                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv, ratio_out);
     } else {
         hipLaunchKernelGGL(sober::k_chol<false>, dim3(1), dim3(sober::CH_T), bytes, (hipStream_t)stream, A, n, ld, shift,
-                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv, ratio_out, skip_if, skip_thr);
+                           info, min_pivot, (const double*)nullptr, 0, (const double*)nullptr, xinv, ratio_out);
     }
     LAUNCH_CHECK();
     return 0;
@@ -1132,17 +1081,8 @@ extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* i
     return sober_cholesky_inv(A, n, ld, shift, info, min_pivot, nullptr, stream);
 }
 
-extern "C" int sober_trsm_blocks_if(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
-                                    const double* Xinv, double* Q, int ldq, const double* skip_if, double skip_thr,
-                                    void* stream);
 extern "C" int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
                                  const double* Xinv, double* Q, int ldq, void* stream) {
-    return sober_trsm_blocks_if(Y, m, q, ldy, L, ldl, Xinv, Q, ldq, nullptr, 0.0, stream);
-}
-
-extern "C" int sober_trsm_blocks_if(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
-                                    const double* Xinv, double* Q, int ldq, const double* skip_if, double skip_thr,
-                                    void* stream) {
     if (!Y || !L || !Xinv || !Q || m <= 0 || q <= 0 || q > 256 || ldy < q || ldl < q || ldq < q) return SOBER_E_ARG;
     const int qpad = ((q + 31) / 32) * 32;
     const size_t bytes = (size_t)sober::TB_WAVES * (16 * (qpad + 4) + 16 * 36) * sizeof(double);
@@ -1154,7 +1094,7 @@ extern "C" int sober_trsm_blocks_if(const double* Y, int64_t m, int q, int ldy, 
     }
     const int64_t row_blocks = (m + 15) / 16;
     hipLaunchKernelGGL(sober::k_trsm_blocks, dim3((unsigned)((row_blocks + sober::TB_WAVES - 1) / sober::TB_WAVES)),
-                       dim3(sober::TB_WAVES * 64), bytes, (hipStream_t)stream, Y, m, q, ldy, L, ldl, Xinv, Q, ldq, skip_if, skip_thr);
+                       dim3(sober::TB_WAVES * 64), bytes, (hipStream_t)stream, Y, m, q, ldy, L, ldl, Xinv, Q, ldq);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1175,7 +1115,7 @@ extern "C" int sober_cholesky_probe_piv(const double* src, int n, int ld_src, co
     HIP_TRY(hipFuncSetAttribute((const void*)sober::k_chol<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 512));
     hipLaunchKernelGGL(sober::k_chol<false>, dim3(n_shifts), dim3(sober::CH_T), bytes, (hipStream_t)stream, work, n, n, 0.0,
-                       info, min_pivot, src, ld_src, shifts, (double*)nullptr, (double*)nullptr, (const double*)nullptr, 0.0);
+                       info, min_pivot, src, ld_src, shifts, (double*)nullptr, (double*)nullptr);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1237,14 +1177,6 @@ extern "C" int sober_jitter_ladder(double* A, int n, int ld, int k, void* stream
     if (!A || n <= 0 || ld < n || k < 0) return SOBER_E_ARG;
     if (k == 0) return 0;
     hipLaunchKernelGGL(sober::k_jitter_ladder, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, n, ld, k);
-    LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int sober_diag_spread(const double* A, int n, int ld, const int32_t* k_out, int n_rungs, double kappa_max,
-                                 double* ok, void* stream) {
-    if (!A || !k_out || !ok || n <= 0 || ld < n || n_rungs <= 0) return SOBER_E_ARG;
-    hipLaunchKernelGGL(sober::k_diag_spread, dim3(1), dim3(256), 0, (hipStream_t)stream, A, n, ld, k_out, n_rungs, kappa_max, ok);
     LAUNCH_CHECK();
     return 0;
 }

@@ -31,11 +31,7 @@ __global__ __launch_bounds__(256) void k_dgemm(int transa, int transb, int m, in
                                                double alpha, const double* __restrict__ A, int lda,
                                                const double* __restrict__ B, int ldb, double beta,
                                                double* __restrict__ C, int ldc,
-                                               const double* __restrict__ coldiv, double* __restrict__ Ct, int ldct,
-                                               const double* __restrict__ skip_if, double skip_thr) {
-    // (guarded form, sober_dgemm_if: nothing to do when a number another kernel left in device memory says so -- the
-    //  CholeskyQR pass of the range finder that a well-conditioned previous block makes unnecessary, nystrom_exec.cpp)
-    if (skip_if != nullptr && *skip_if >= skip_thr) return;
+                                               const double* __restrict__ coldiv, double* __restrict__ Ct, int ldct) {
     __shared__ double red[SPLIT == 4 ? 3 * 256 : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int i0, j0, kbeg, kend;
@@ -99,29 +95,23 @@ __global__ __launch_bounds__(256) void k_dgemm(int transa, int transb, int m, in
 
 }  // namespace sober
 
-extern "C" int sober_dgemm_if(int transa, int transb, int m, int n, int k, double alpha, const double* A,
-                              int lda, const double* B, int ldb, double beta, double* C, int ldc,
-                              const double* skip_if, double skip_thr, void* stream) {
+extern "C" int sober_dgemm(int transa, int transb, int m, int n, int k, double alpha, const double* A,
+                           int lda, const double* B, int ldb, double beta, double* C, int ldc,
+                           void* stream) {
     if (!A || !B || !C || m <= 0 || n <= 0 || k <= 0) return SOBER_E_ARG;
     if (lda < (transa ? m : k) || ldb < (transb ? k : n) || ldc < n) return SOBER_E_ARG;
     const long tiles = (long)((n + 15) / 16) * ((m + 15) / 16);
     if (tiles <= 2048 && k >= 64) {                  // few tiles: cut the K chain in four
         dim3 grid((n + 15) / 16, (m + 15) / 16);
         hipLaunchKernelGGL(sober::k_dgemm<4>, grid, dim3(256), 0, (hipStream_t)stream, transa, transb, m, n, k,
-                           alpha, A, lda, B, ldb, beta, C, ldc, (const double*)nullptr, (double*)nullptr, 0, skip_if, skip_thr);
+                           alpha, A, lda, B, ldb, beta, C, ldc, (const double*)nullptr, (double*)nullptr, 0);
     } else {
         dim3 grid((n + 31) / 32, (m + 31) / 32);
         hipLaunchKernelGGL(sober::k_dgemm<1>, grid, dim3(256), 0, (hipStream_t)stream, transa, transb, m, n, k,
-                           alpha, A, lda, B, ldb, beta, C, ldc, (const double*)nullptr, (double*)nullptr, 0, skip_if, skip_thr);
+                           alpha, A, lda, B, ldb, beta, C, ldc, (const double*)nullptr, (double*)nullptr, 0);
     }
     LAUNCH_CHECK();
     return 0;
-}
-
-extern "C" int sober_dgemm(int transa, int transb, int m, int n, int k, double alpha, const double* A,
-                           int lda, const double* B, int ldb, double beta, double* C, int ldc,
-                           void* stream) {
-    return sober_dgemm_if(transa, transb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 0.0, stream);
 }
 
 // Ct[j][i] = (A B)[i][j] / coldiv[j]  (A: m x k, B: k x n, both row-major; coldiv may be null): the projection P G and the
@@ -134,11 +124,11 @@ extern "C" int sober_dgemm_coldiv_t(int m, int n, int k, const double* A, int ld
     if (tiles <= 2048 && k >= 64) {
         dim3 grid((n + 15) / 16, (m + 15) / 16);
         hipLaunchKernelGGL(sober::k_dgemm<4>, grid, dim3(256), 0, (hipStream_t)stream, 0, 0, m, n, k, 1.0, A, lda, B, ldb,
-                           0.0, (double*)nullptr, 0, coldiv, Ct, ldct, (const double*)nullptr, 0.0);
+                           0.0, (double*)nullptr, 0, coldiv, Ct, ldct);
     } else {
         dim3 grid((n + 31) / 32, (m + 31) / 32);
         hipLaunchKernelGGL(sober::k_dgemm<1>, grid, dim3(256), 0, (hipStream_t)stream, 0, 0, m, n, k, 1.0, A, lda, B, ldb,
-                           0.0, (double*)nullptr, 0, coldiv, Ct, ldct, (const double*)nullptr, 0.0);
+                           0.0, (double*)nullptr, 0, coldiv, Ct, ldct);
     }
     LAUNCH_CHECK();
     return 0;

@@ -415,7 +415,6 @@ static Switches read_switches() {
     w.tani_no_queue = getenv("SOBER_TANI_NO_QUEUE") != nullptr;
     w.car_force_giveup = getenv("SOBER_CAR_FORCE_GIVEUP") != nullptr;
     w.car_unfused = getenv("SOBER_CAR_UNFUSED") != nullptr;
-    w.car_gram = getenv("SOBER_CAR_GRAM") != nullptr;
     w.level_no_classes = getenv("SOBER_LEVEL_NO_CLASSES") != nullptr;
     w.car_exact_ratio = getenv("SOBER_CAR_EXACT_RATIO") != nullptr;
     return w;

@@ -23,37 +23,23 @@ extern "C" int sober_nystrom_job_size(void) { return (int)sizeof(sober_nystrom_j
 
 extern "C" int64_t sober_nystrom_flags_bytes(int n_rungs, int niter) {
     const int64_t n_orth2 = 2 * (1 + 2 * (int64_t)niter);
-    return 8 * (n_rungs + 1 + n_orth2 + 1) + 4 * (2 + n_rungs + n_orth2);
+    return 8 * (n_rungs + 1 + n_orth2) + 4 * (2 + n_rungs + n_orth2);
 }
 
 // CholeskyQR of the M x s block in *Y, in place over the two buffers (`passes` = 2: CholeskyQR2; 1: the intermediate
 // blocks of the power iteration, with min pivot / max diagonal of the Gram matrix in pivs[slot + 1]).  On return *Y
 // holds Q and *other is free.
-// skip_if (device pointer or NULL; intermediate blocks only): a double another kernel left -- at or above skip_thr this
-// block goes on unorthonormalised (the three launches leave at once, the block is copied).  OPT-IN (job->skip_passes;
-// SOBER_NYSTROM_SKIP=1 through sober_amd), and here is why it is not the default.  torch's intermediate QRs exist for
-// conditioning only: range(Q) of the last block is range(A^5 R) with or without them.  What they buy is the ACCURACY of that
-// range in floating point: the last block's CholeskyQR2 returns it to ~eps x cond(block), and with the passes cond(block) is
-// one multiplication by A deep, without them five.  Round 5 measured both rules that suggest themselves:
-//   * "the block in front left a pivot ratio >= 1e-4" (the round-4 review's proposal): the ratios are no bound on what a
-//     multiplication by A does -- a d = 3 pool whose Gram eigenvalue number b - 1 is 3e-9 of the largest showed ratios of
-//     0.014 and lost its subspace (tests/test_hip_round4.py::test_fuzz_slice_vs_oracle, case 0: other indices);
-//   * a PROVEN bound -- the diagonal fallback of make_cov_psd (SOBER/_utils.py:153-156: the eigenvalues of diag(d) ARE d)
-//     with max d <= NX_DIAG_KAPPA min d (sober_diag_spread): cond <= 20^4 x cond(R) ~ 4e5, a subspace error of ~4e-11.
-//     That is invisible at BASELINE configurations 1-4 (identical indices, weights 1e-12 .. 4e-11: scripts/nystrom_skip_check.py)
-//     and -0.2 ms of a cfg-2 step (4.17 -> 3.96 ms, profiles/r05_ab_nystrom_skip.txt) -- and it still fails the same fuzz
-//     case, whose Caratheodory steps amplify a relative 1e-16 to 2e-6 (the reference's own weights move that much under a
-//     one-ulp move of its inputs): 4e-11 becomes other indices, the device's 8.9e-6 with every pass taken does not.
-// The parity bar is the suite's, so the passes stay; the second rule is what the switch enables.
-#define NX_DIAG_KAPPA 20.0
+// (Round 5 built and measured dropping the intermediate passes behind a device-side guard -- -0.2 ms at cfg-2, a subspace
+//  error of 4e-11 that one hypersensitive pool of the fuzz slice turns into other indices: profiles/r05_ab_nystrom_skip.txt.
+//  Round 6 took that opt-in path and its guarded launches out of the library; the passes stay.)
 static int nx_orth(const sober_nystrom_job* j, double** Y, double** other, int32_t* infos, double* pivs, int slot,
-                   int passes, const double* skip_if, double skip_thr, void* stream) {
+                   int passes, void* stream) {
     const int M = j->M, s = j->s;
     for (int it = 0; it < passes; ++it) {
-        NX_TRY(sober_dgemm_if(1, 0, s, s, M, 1.0, *Y, s, *Y, s, 0.0, j->Gm, s, skip_if, skip_thr, stream));   // Y^T Y
-        NX_TRY(sober_cholesky_inv_ratio_if(j->Gm, s, s, 0.0, infos + slot + it, pivs + slot + it, j->xinv,
-                                           passes == 1 ? pivs + slot + 1 : nullptr, skip_if, skip_thr, stream));
-        NX_TRY(sober_trsm_blocks_if(*Y, M, s, s, j->Gm, s, j->xinv, *other, s, skip_if, skip_thr, stream));   // Q = Y R^-1
+        NX_TRY(sober_dgemm(1, 0, s, s, M, 1.0, *Y, s, *Y, s, 0.0, j->Gm, s, stream));                         // Y^T Y
+        NX_TRY(sober_cholesky_inv_ratio(j->Gm, s, s, 0.0, infos + slot + it, pivs + slot + it, j->xinv,
+                                        passes == 1 ? pivs + slot + 1 : nullptr, stream));
+        NX_TRY(sober_trsm_blocks(*Y, M, s, s, j->Gm, s, j->xinv, *other, s, stream));                         // Q = Y R^-1
         double* t = *Y; *Y = *other; *other = t;
     }
     return 0;
@@ -70,11 +56,10 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
     if (j->flags_bytes < sober_nystrom_flags_bytes(n_r, niter)) return SOBER_E_WS;
     hipStream_t st = (hipStream_t)stream;
     const int n_orth2 = 2 * (1 + 2 * niter);
-    // the flag block: pivots[n_r + 1] f64 | pivs_rf[n_orth2] f64 | skip_ok f64 | flags[2 + n_r] i32 | infos_rf[n_orth2] i32
+    // the flag block: pivots[n_r + 1] f64 | pivs_rf[n_orth2] f64 | flags[2 + n_r] i32 | infos_rf[n_orth2] i32
     double* pivots = (double*)j->flags_block;
     double* pivs_rf = pivots + n_r + 1;
-    double* skip_ok = pivs_rf + n_orth2;                  // 1.0: the intermediate blocks may go on unorthonormalised
-    int32_t* flags = (int32_t*)(skip_ok + 1);
+    int32_t* flags = (int32_t*)(pivs_rf + n_orth2);
     int32_t* infos_rf = flags + 2 + n_r;
     if (phase != 2) {
         NX_HIP(hipMemsetAsync(j->flags_block, 0, (size_t)j->flags_bytes, st));
@@ -93,7 +78,6 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
             NX_TRY(sober_cholesky_probe_piv(j->C, M, M, j->shifts, n_r, j->chol_work, flags + 2, pivots, stream));
         }
         NX_TRY(sober_jitter_ladder_auto(j->C, M, M, flags + 2, n_r, flags + 1, stream));
-        if (j->skip_passes != 0) NX_TRY(sober_diag_spread(j->C, M, M, flags + 1, n_r, NX_DIAG_KAPPA, skip_ok, stream));   // (opt-in: one dispatch of the chain)
     }
     if (phase == 1) return 0;       // (the caller's host work -- stepping the generator for R -- overlaps with the probes)
     // ---- the range finder of torch.svd_lowrank (Halko et al. Alg. 4.4, torch/_lowrank.py:64-79): only range(Q) of the
@@ -101,17 +85,14 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
     const int last = 2 * niter;
     double *Q = j->Y[0], *free_buf = j->Y[1];
     NX_TRY(sober_dgemm(0, 0, M, s, M, 1.0, j->C, M, j->R, s, 0.0, Q, s, stream));                         // A R
-    NX_TRY(nx_orth(j, &Q, &free_buf, infos_rf, pivs_rf, 0, last > 0 ? 1 : 2, nullptr, 0.0, stream));
+    NX_TRY(nx_orth(j, &Q, &free_buf, infos_rf, pivs_rf, 0, last > 0 ? 1 : 2, stream));
     int slot = 2, k = 0;
-    const bool may_skip = j->skip_passes != 0;
     for (int it = 0; it < niter; ++it) {
         for (int half = 0; half < 2; ++half) {
             ++k;
             NX_TRY(sober_dgemm(half == 0 ? 1 : 0, 0, M, s, M, 1.0, j->C, M, Q, s, 0.0, free_buf, s, stream));   // A^H Q, then A Q
             double* t = Q; Q = free_buf; free_buf = t;                                                 // (Q is consumed)
-            const double* skip_if = (may_skip && k != last) ? skip_ok : nullptr;
-            const double thr = 0.5;
-            NX_TRY(nx_orth(j, &Q, &free_buf, infos_rf, pivs_rf, slot, (half == 1 && k == last) ? 2 : 1, skip_if, thr, stream));
+            NX_TRY(nx_orth(j, &Q, &free_buf, infos_rf, pivs_rf, slot, (half == 1 && k == last) ? 2 : 1, stream));
             slot += 2;
         }
     }

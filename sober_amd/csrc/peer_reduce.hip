@@ -52,6 +52,11 @@ __global__ __launch_bounds__(256) void k_peer_allreduce(unsigned char* __restric
     const size_t slot_off = PEER_HDR + (size_t)(epoch & 1u) * (size_t)n_max * sizeof(double);
     double* my_slot = (double*)(mine + slot_off);
     const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    // A communicator whose error word is set (an earlier call timed out) neither writes nor posts any more: the wait was what
+    // kept the two-slot double buffer safe (a peer had to post epoch e + 1 before slot e & 1 was reused), so a failed rank
+    // that went on copying could overwrite call e's slot with call e + 2's data under a slower, healthy peer still summing
+    // call e.  That peer now meets a missing epoch instead and fails on its own bounded wait -- loudly, not with wrong sums.
+    if (__hip_atomic_load((unsigned*)(mine + PEER_OFF_ERR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
     for (int64_t i = t0; i < n; i += stride) my_slot[i] = buf[i];
     __threadfence_system();                                            // my share is out before I count myself in
     __syncthreads();

@@ -9,7 +9,6 @@ struct Switches {
     bool car_unfused;           // SOBER_CAR_UNFUSED: bidiagonalisation and Phi as two launches
     bool car_exact_ratio;       // SOBER_CAR_EXACT_RATIO: the pivots' ratio test without its screened fast path (what the tests compare it with)
     bool level_no_classes;      // SOBER_LEVEL_NO_CLASSES: every level's set sums evaluated (no levels derived from class sums, level_class.hip)
-    bool car_gram;              // SOBER_CAR_GRAM: the Caratheodory step's reflectors by way of the Gram matrix (car_gram.inc; experimental)
 };
 const Switches& switches();     // (misc.hip)
 }

@@ -2,7 +2,6 @@
   * the SHIPPED KMeans path (E step screened on the BF16 matrix cores, the default at cfg-2 / cfg-4 shapes) against labels
     and centroids the REFERENCE's own KMeans produced on such a shape (tests/golden/kmeans_screened.npz), not only against
     the device's exact kernel;
-  * the opt-in Gram route of the Caratheodory step against the default one on the reference's level inputs;
   * the fused GP prediction kernel (csrc/predict.hip) against the materialised route and the oracle;
   * the pivots' screened ratio test: the accuracy of the v_rcp_f64 seed it rests on, and bit equality of every output with the
     exact test (kernel level: 75+ steps incl. ties, negative masses, multi-CU sizes; whole sampling steps)."""
@@ -48,50 +47,6 @@ def test_kmeans_screened_default_path_vs_reference(tag, dev):
     np.testing.assert_allclose(c.cpu().numpy(), z[f"{tag}_c"], rtol=1e-11)
 
 
-def test_gram_route_of_the_caratheodory_step_on_reference_levels(dev, monkeypatch):
-    """SOBER_CAR_GRAM=1 (opt-in, csrc/car_gram.inc): the Caratheodory step's reflectors by way of G = A A^T -- Householder
-    tridiagonalisation, P1 = (B^-1 Q^T A)^T, Householder reconstruction by a sign-choosing LU -- instead of the
-    bidiagonalisation.  On the reference's own level inputs (every golden with stored levels, batch 8 .. 100): the same
-    kept sets as the default route and as the golden, weights to 1e-8 of the largest."""
-    import glob
-    from sober_amd import _native as nat
-    n_checked = 0
-    for p in sorted(glob.glob(os.path.join(GOLD, "recomb_*.npz"))):
-        z = np.load(p)
-        if "L0_X_tmp" not in z.files:
-            continue
-        for i in range(int(z["n_levels"])):
-            X, mu = _t(z[f"L{i}_X_tmp"]).to(dev), _t(z[f"L{i}_tot_weights"]).to(dev)
-            N, n = X.shape
-            if n + 1 >= N or not nat.car_safe_supported(N, n + 1):
-                continue
-            out = []
-            for gram in (False, True):
-                if gram:
-                    monkeypatch.setenv("SOBER_CAR_GRAM", "1")
-                else:
-                    monkeypatch.delenv("SOBER_CAR_GRAM", raising=False)
-                nat.reload_switches()
-                keep = torch.empty(N + 1, dtype=torch.int32, device=dev)
-                w = torch.zeros(N, dtype=torch.float64, device=dev)
-                mo = torch.empty(N, dtype=torch.float64, device=dev)
-                nat.car_device(X, mu, keep, w, keep[N:], mo)
-                nk = int(keep[N].item())
-                assert nk > 0, (p, i, gram)
-                out.append((np.flatnonzero(keep[:N].cpu().numpy() >= 0), w[:nk].cpu().numpy()))
-            (k0, w0), (k1, w1) = out
-            if "calc_obj" not in p:
-                assert np.array_equal(k0, z[f"L{i}_idx_star"]), (p, i)
-            assert np.array_equal(k0, k1), (p, i)
-            assert np.abs(w1 - w0).max() <= 1e-8 * np.abs(w0).max(), (p, i)
-            n_checked += 1
-    monkeypatch.delenv("SOBER_CAR_GRAM", raising=False)
-    nat.reload_switches()
-    assert n_checked >= 50
-
-
-@pytest.mark.parametrize("kind,d,n_obs,N", [("rbf", 10, 200, 10007), ("matern52", 6, 37, 4096), ("rbf", 3, 255, 777),
-                                             ("tanimoto", 2048, 64, 3000), ("tanimoto", 100, 200, 1031)])
 def test_fused_prediction_equals_the_materialised_route(kind, d, n_obs, N, dev, monkeypatch):
     """csrc/predict.hip (one launch: K(X_obs, x) once into LDS, W k on the FP64 matrix cores) against the four-launch
     route it replaces (SOBER_PREDICT_MATERIALISED=1: posterior mean, materialised K(X_obs, pool), V = W KX, the column-wise

@@ -265,3 +265,37 @@ def test_calc_obj_step_with_the_null_vector_kernel_equals_the_second_step_route(
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][0], z["idx"])
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-8)
     np.testing.assert_allclose(res[0][1], z["w"], rtol=1e-6)
+
+
+def test_kmeans_with_an_empty_cluster_is_bounded_not_a_cliff(dev):
+    """An empty cluster leaves a NaN centroid (SOBER/_weights.py:117-124 divides by a zero count) and the screened E step
+    (csrc/kmeans.hip) then sends EVERY point to its exact FP64 pass -- the advisor's "silent cliff".  Its price, measured
+    here so that it cannot grow unseen: the same 1M x 20 pool with and without a duplicated initial centroid, ten Lloyd
+    iterations each -- the degenerate run within 8 x the clean one (it is the round-3 E step, before the screen existed),
+    labels identical to the kernel that runs without the screen's workspace."""
+    import time
+    from sober_amd import _native as nat
+    lib = nat.load()
+    N, d, K = 1000000, 20, 500
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    X = torch.rand(N, d, generator=g, dtype=torch.float64, device=dev)
+    Xb = X.clone(); Xb[1] = Xb[0]                                      # two identical initial centroids: one cluster goes empty
+
+    def run(Xd, nbytes):
+        c = torch.empty(K, d, dtype=torch.float64, device=dev)
+        cl = torch.empty(N, dtype=torch.int32, device=dev)
+        ws = torch.zeros(max(nbytes, 8), dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            nat._check(lib.sober_kmeans_lloyd(Xd.data_ptr(), N, d, K, 10, c.data_ptr(), cl.data_ptr(), ws.data_ptr() if nbytes else None,
+                                              nbytes, nat._stream(Xd)), "kmeans")
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        return dt, cl.cpu().numpy(), c.cpu().numpy()
+    nb = int(lib.sober_kmeans_ws_bytes(N, d, K))
+    assert nb == int(lib.sober_kmeans_ws_bytes_screened(N, d, K)) > 0
+    t_clean, _, _ = run(X, nb)
+    t_bad, cl_bad, c_bad = run(Xb, nb)
+    assert np.isnan(c_bad).any(), "the duplicated centroid was meant to empty a cluster"
+    _, cl_ref, _ = run(Xb, 0)                                           # (no workspace: the (x - c)^2 kernel, no screen)
+    assert np.array_equal(cl_bad, cl_ref)
+    assert t_bad < 8.0 * t_clean, (t_bad, t_clean)
