@@ -79,6 +79,10 @@ int sober_scale_points(const double* X, int64_t n, int d, int64_t ldx,
  * per-row popcount (|x|^2) as double.  *bad_flag (device int32, zero it first) is set to 1 when an
  * input is neither 0.0 nor 1.0.  Replaces the FP64 storage consumed by
  * SOBER/_drug_modelling.py:20-22.                                                                */
+/* the same for the rows idx[0:n] of X only: out[i, 0:dt] = X[idx[i], 0:d] / lengthscale; gather_src != NULL: also
+ * gather_out[i] = gather_src[idx[i]] (the live positions' weights, SOBER/_rchq.py:84, without a launch of their own)   */
+int sober_scale_points_idx(const double* X, const int32_t* idx, int64_t n, int d, int64_t ldx, const double* lengthscale,
+                           int ls_len, double* out, int dt, const double* gather_src, double* gather_out, void* stream);
 int sober_pack_bits(const double* X, int64_t n, int d, int64_t ldx,
                     uint64_t* words, int nwords, double* norms, int32_t* bad_flag, void* stream);
 
@@ -123,6 +127,12 @@ int sober_level_reduce(int kind, const void* rows, const double* rows_norm, int 
  * exponential (table-driven FP64 exp) and accumulates.  Same outputs and chunking as
  * sober_level_reduce.                                                                            */
 int sober_aug_dim(int d);
+/* The plan's two augmented tables in two launches (round 6): center[0:d] = the column means of X_nys (fixed summation order),
+ * then rows_aug ((M + n_obs) x da, side 0: [X_nys; X_obs], read where they lie -- no concatenated copy) and cand_aug (N x da,
+ * side 1) like sober_augment_points.  n_obs = 0 / X_obs = NULL: mode "kernel".  d <= 30.                              */
+int sober_augment_plan(const double* X_nys, int64_t M, int64_t ld_nys, const double* X_obs, int64_t n_obs, int64_t ld_obs,
+                       const double* X_cand, int64_t N, int64_t ld_cand, int d, const double* lengthscale, int ls_len,
+                       double* center, double* rows_aug, double* cand_aug, int da, void* stream);
 int sober_augment_points(const double* X, int64_t n, int d, int64_t ldx, const double* lengthscale,
                          int ls_len, const double* center, int side, double* out, int da, void* stream);
 int sober_level_reduce_mfma(int kind, const double* rows, int n_rows, const double* cand, int da,
@@ -431,6 +441,12 @@ int sober_class_sum(const double* partG, const double* partTot, int n_chunks, in
 int sober_class_derive_queued(const double* Gc, const double* totc, int n_rows, int S, int CL, const double* scale,
                               const int32_t* sof, double* Gn, double* totn, double* G, double* tot, const int64_t* dR,
                               void* stream);
+/* the general form of the two: need_keep = 0 -- no class tables --, R_known >= 0: the level's size by value (the chain's first
+ * level, known to the host) instead of *dR_cur                                                                        */
+int sober_level_update_queued_ex(const int32_t* idx_cur, int64_t R_ub, int S, const int32_t* keep_rank,
+                                 const double* w_star, const double* tot, double* mu, int32_t* idx_new,
+                                 const int64_t* dR_cur, int64_t* dR_next, int64_t R_ub_next, int need_keep,
+                                 double* cls_scale, int32_t* cls_sof, int64_t R_known, void* stream);
 int sober_level_update_queued_cls(const int32_t* idx_cur, int64_t R_ub, int S, const int32_t* keep_rank,
                                   const double* w_star, const double* tot, double* mu, int32_t* idx_new,
                                   const int64_t* dR_cur, int64_t* dR_next, int64_t R_ub_next, int need_keep,
@@ -670,7 +686,13 @@ typedef struct sober_final_job {
     int64_t N, row_offset;
     double *K, *mu_live;
     int64_t* out_idx; double* out_w;
+    /* cand_sc == NULL (continuous kernels, round 6): the pool is not kept in scaled form -- the final level scales the rows it
+       touches itself (sober_scale_points_idx) from the RAW pool: cand_raw (N x ld_raw doubles, d_raw coordinates), the
+       lengthscale (ls_len 1 or d_raw, device) and sc_buf, 2 b x dt doubles of scratch                                      */
+    const double* cand_raw; int64_t ld_raw; int32_t d_raw, ls_len; const double* ls; double* sc_buf;
 } sober_final_job;
+/* sober_level_final with its arguments in the struct (what sober_level_loop_final runs; the raw-pool form exists only here) */
+int sober_level_final_job(const sober_level_job* job, const sober_final_job* final, const int32_t* idx, int R, void* stream);
 int sober_final_job_size(void);
 int sober_level_loop_final(sober_level_job* job, sober_final_job* final, int64_t R, int32_t* idx_a, int32_t* idx_b,
                            int first_sums_ready, void** events, int max_levels, int64_t* level_R, int32_t* n_levels,

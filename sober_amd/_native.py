@@ -38,6 +38,8 @@ SIGNATURES = {
     "sober_padded_dim": (_i32, [_i32]),
     "sober_bit_words": (_i32, [_i32]),
     "sober_scale_points": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "sober_augment_plan": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "sober_scale_points_idx": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sober_pack_bits": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
     "sober_mt19937_uniform53": (_i32, [_vp, _i64, _i64, _vp]),
     "sober_box_muller": (_i32, [_vp, _i64, _vp, _vp]),
@@ -144,6 +146,7 @@ SIGNATURES = {
     "sober_level_chunks_tani": (_i32, [_i32, _i64, _i64, _i32]),
     "sober_level_chunks_tani_cap": (_i32, [_i32, _i64, _i32]),
     "sober_level_update_queued": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sober_level_update_queued_ex": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp]),
     "sober_level_update_queued_cls": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "sober_level_class_wpt": (_i32, [_i32, _i64, _i32]),
     "sober_level_class_slots": (_i32, [_i32]),
@@ -160,6 +163,7 @@ SIGNATURES = {
     "sober_gather_f64": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "sober_final_scatter": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "sober_level_final": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "sober_level_final_job": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "sober_level_loop": (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 
@@ -173,6 +177,7 @@ class FinalJob(C.Structure):
         ("rows_sc", _vp), ("rows_norm", _vp), ("cand_sc", _vp), ("cand_norm", _vp),
         ("dt", _i32), ("done", _i32), ("N", _i64), ("row_offset", _i64),
         ("K", _vp), ("mu_live", _vp), ("out_idx", _vp), ("out_w", _vp),
+        ("cand_raw", _vp), ("ld_raw", _i64), ("d_raw", _i32), ("ls_len", _i32), ("ls", _vp), ("sc_buf", _vp),
     ]
 
 
@@ -319,6 +324,16 @@ def fused_dim_supported(kind: int, d: int) -> bool:
     return r > 0
 
 
+def scale_points_idx(X, idx, n, lengthscale, out):
+    """out[i] = X[idx[i]] / lengthscale for i < n (zero padded to out's row length)."""
+    _req(lengthscale, torch.float64, "lengthscale"); _req(out, torch.float64, "out"); _req(idx, torch.int32, "idx")
+    if X.dtype != torch.float64 or X.stride(-1) != 1:
+        raise SoberHipError("scale_points_idx: X must be float64 with unit inner stride")
+    _check(load().sober_scale_points_idx(X.data_ptr(), idx.data_ptr(), int(n), X.shape[1], X.stride(0), lengthscale.data_ptr(),
+                                         lengthscale.numel(), out.data_ptr(), out.shape[1], None, None, _stream(X)),
+           "sober_scale_points_idx")
+
+
 def scale_points(X, lengthscale, out):
     n, d = X.shape
     _req(X, torch.float64, "X"); _req(lengthscale, torch.float64, "lengthscale"); _req(out, torch.float64, "out")
@@ -423,6 +438,20 @@ def aug_dim(d: int) -> int:
     """DA for the matrix-core level kernel, or -1 when d + 2 exceeds the compiled tile set."""
     r = load().sober_aug_dim(d)
     return r if r > 0 else -1
+
+
+def augment_plan(X_nys, X_obs, X_cand, lengthscale, center, rows_aug, cand_aug):
+    """sober_augment_plan: center <- column means of X_nys; rows_aug <- [X_nys; X_obs] (side 0), cand_aug <- X_cand (side 1)."""
+    for t_, nm in ((X_nys, "X_nys"), (X_cand, "X_cand"), (X_obs, "X_obs")):
+        if t_ is not None and (t_.dtype != torch.float64 or t_.stride(-1) != 1):
+            raise SoberHipError(f"augment_plan: {nm} must be float64 with unit inner stride")
+    _req(rows_aug, torch.float64, "rows_aug"); _req(cand_aug, torch.float64, "cand_aug"); _req(center, torch.float64, "center")
+    n_obs = 0 if X_obs is None else X_obs.shape[0]
+    _check(load().sober_augment_plan(X_nys.data_ptr(), X_nys.shape[0], X_nys.stride(0), _ptr(X_obs), n_obs,
+                                     X_obs.stride(0) if n_obs else 0, X_cand.data_ptr(), X_cand.shape[0], X_cand.stride(0),
+                                     X_nys.shape[1], lengthscale.data_ptr(), lengthscale.numel(), center.data_ptr(),
+                                     rows_aug.data_ptr(), cand_aug.data_ptr(), rows_aug.shape[1], _stream(X_cand)),
+           "sober_augment_plan")
 
 
 def augment_points(X, lengthscale, center, side, out):
@@ -900,6 +929,10 @@ def level_final(job: LevelJob, rows, rows_norm, cand, cand_norm, dt, idx, R, N, 
                                     _ptr(cand_norm), dt, idx.data_ptr(), int(R), int(N), int(row_offset),
                                     K.data_ptr(), mu_live.data_ptr(), out_idx.data_ptr(), out_w.data_ptr(), stream),
            "sober_level_final")
+
+
+def level_final_job(job: LevelJob, fin: "FinalJob", idx, R: int, stream: int):
+    _check(load().sober_level_final_job(C.addressof(job), C.addressof(fin), idx.data_ptr(), int(R), stream), "sober_level_final_job")
 
 
 def nystrom_flags_bytes(n_rungs: int, niter: int) -> int:

@@ -204,7 +204,14 @@ class _LevelOps:
         dev = self.device
         f = nat.FinalJob()
         f.rows_sc, f.rows_norm = p.rows.data.data_ptr(), nat._ptr(p.rows.norm)
-        f.cand_sc, f.cand_norm = p.cand.data.data_ptr(), nat._ptr(p.cand.norm)
+        if p.cand is not None:
+            f.cand_sc, f.cand_norm = p.cand.data.data_ptr(), nat._ptr(p.cand.norm)
+        else:                                                # (the raw pool: the final level scales the rows it touches)
+            Xr, ls = p.cand_raw, p.spec.lengthscale
+            f.cand_sc, f.cand_norm = None, None
+            f.cand_raw, f.ld_raw, f.d_raw = Xr.data_ptr(), Xr.stride(0), Xr.shape[1]
+            f.ls, f.ls_len = ls.data_ptr(), ls.numel()
+            f.sc_buf = self._buf(p, "sc_final", S * p.rows.dt).data_ptr()
         f.dt, f.done, f.N, f.row_offset = p.rows.dt, 0, mu.numel(), row_offset
         p._fin_out = (torch.empty(S, dtype=torch.int64, device=dev), torch.empty(S, dtype=torch.float64, device=dev))
         f.K, f.mu_live = self._buf(p, "K_final", p.Mtot * S).data_ptr(), self._buf(p, "mu_live", S).data_ptr()
@@ -226,15 +233,12 @@ class _LevelOps:
         job = self._job(p, S)
         if not job.car_ws:
             return None
-        dev, f64 = self.device, torch.float64
+        dev = self.device
         job.mu = mu.data_ptr()
-        K = self._buf(p, "K_final", job.n_rows * S)
-        mu_live = self._buf(p, "mu_live", S)
-        out_idx = torch.empty(S, dtype=torch.int64, device=dev)
-        out_w = torch.empty(S, dtype=f64, device=dev)
+        fin = self._final_job(p, S, mu, row_offset)
+        out_idx, out_w = p._fin_out
         st = torch.cuda.current_stream(dev)
-        nat.level_final(job, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, p.rows.dt, idx_cur, R, mu.numel(),
-                        row_offset, K, mu_live, out_idx, out_w, st.cuda_stream)
+        nat.level_final_job(job, fin, idx_cur, R, st.cuda_stream)
         st.synchronize()
         n_keep = int(p.ws["h_flags_np"][S])
         if n_keep < 0:
@@ -282,8 +286,13 @@ class _LevelOps:
         (SOBER/_rchq.py:78)."""
         dev = self.device
         K = torch.empty(p.Mtot, count, dtype=torch.float64, device=dev)
-        nat.pairwise(p.kind, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, idx, count, p.rows.dt,
-                     p.spec.outputscale, K)
+        if p.cand is not None:
+            nat.pairwise(p.kind, p.rows.data, p.rows.norm, p.cand.data, p.cand.norm, idx, count, p.rows.dt,
+                         p.spec.outputscale, K)
+        else:                                                # (the raw pool: these rows scaled here)
+            sc = torch.empty(count, p.rows.dt, dtype=torch.float64, device=dev)
+            nat.scale_points_idx(p.cand_raw, idx, count, p.spec.lengthscale, sc)
+            nat.pairwise(p.kind, p.rows.data, p.rows.norm, sc, None, None, count, p.rows.dt, p.spec.outputscale, K)
         if p.weighted:
             K = K * p.wmul[idx[:count].long()].unsqueeze(0)
         Xtr = torch.empty(p.n, count, dtype=torch.float64, device=dev)

@@ -14,7 +14,7 @@ class Plan:
     """Per-step device state shared by all levels.  The POOL's side of it (scaled / augmented candidates, the pool's
     posterior mean) is prepared at first use: the Nystrom chain needs the row table only, so the host enqueues that
     chain first and prepares the pool while the GPU is busy with it (build_plan: `_pool_prep`)."""
-    _POOL_FIELDS = ("cand", "cand_aug", "rows_aug", "wmul")
+    _POOL_FIELDS = ("cand", "cand_raw", "cand_aug", "rows_aug", "wmul")
 
     def __getattr__(self, name):                                  # (only reached when the attribute is not set yet)
         if name in Plan._POOL_FIELDS:
@@ -94,18 +94,32 @@ class _PlanOps:
         def pool_prep():
             # everything that reads the candidate pool -- first touched by the first level's set sums, which the engine
             # enqueues behind the Nystrom chain: this host work then runs beside that chain, not in front of it
-            p.cand = self._packed_pool(spec, X_cand, pool_owner)
+            # The pool in SCALED form (x / lengthscale, padded) is what the VALU level kernel, the pool's posterior mean and
+            # the final direct level read.  On the matrix-core path (augmented pool below) without the weighted mode only the
+            # final level is left -- at most 2 b rows -- so the copy is not made (65 us and 192 MB of writes at 1M x 20, half
+            # a millisecond at 8M): that level scales its own rows from the raw pool (sober_scale_points_idx, same quotients).
+            Xc64 = X_cand if (X_cand.dtype == torch.float64 and X_cand.stride(-1) == 1) else X_cand.to(torch.float64).contiguous()
+            if p.da > 0 and not p.weighted and p.kind != nat.KIND_TANIMOTO and self.lazy_scaled_pool:
+                p.cand, p.cand_raw = None, Xc64
+            else:
+                p.cand = self._packed_pool(spec, X_cand, pool_owner)
+                p.cand_raw = None
             p.wmul = self._pool_mean(spec, p.cand, X_cand, pool_owner) if p.weighted else None   # mu_y of SOBER/_kernel.py:41
             # matrix-core level kernel: augmented copies of the row table and the pool
             if p.da > 0:
-                st = stacked if stacked is not None else (torch.cat([Xn64, spec.X_obs], 0) if corrected else Xn64)
-                center = Xn64.mean(0).contiguous()                # any shift works; this one keeps |x~| small
                 p.rows_aug = torch.empty(p.Mtot, p.da, dtype=torch.float64, device=dev)
                 p.cand_aug = torch.empty(X_cand.shape[0], p.da, dtype=torch.float64, device=dev)
-                nat.augment_points(st.to(torch.float64).contiguous(), spec.lengthscale, center, 0, p.rows_aug)
-                Xc = X_cand if (X_cand.dtype == torch.float64 and X_cand.stride(-1) == 1) else \
-                    X_cand.to(torch.float64).contiguous()
-                nat.augment_points(Xc, spec.lengthscale, center, 1, p.cand_aug)
+                Xo = spec.X_obs if corrected else None
+                if Xn64.shape[1] <= 30 and (Xo is None or (Xo.dtype == torch.float64 and Xo.stride(-1) == 1)):
+                    # centre (the Nystrom points' mean: any shift works, this one keeps |x~| small) + both tables: two launches
+                    center = torch.empty(Xn64.shape[1], dtype=torch.float64, device=dev)
+                    nat.augment_plan(Xn64 if Xn64.stride(-1) == 1 else Xn64.contiguous(), Xo, Xc64, spec.lengthscale, center,
+                                     p.rows_aug, p.cand_aug)
+                else:
+                    st = stacked if stacked is not None else (torch.cat([Xn64, spec.X_obs], 0) if corrected else Xn64)
+                    center = Xn64.mean(0).contiguous()
+                    nat.augment_points(st.to(torch.float64).contiguous(), spec.lengthscale, center, 0, p.rows_aug)
+                    nat.augment_points(Xc64, spec.lengthscale, center, 1, p.cand_aug)
             else:
                 p.rows_aug = p.cand_aug = None
         p._pool_prep = pool_prep

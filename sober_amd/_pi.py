@@ -31,16 +31,24 @@ def _kxx_const(spec):
     return 0.0                                            # tanimoto: per point, from the popcounts
 
 
-def _predict(spec, X, eta=None, log=False, eta_dev=None):
-    dev = X.device
-    kind = nat.KIND_BY_NAME[spec.kind]
+def _model_side(spec):
+    """What a prediction needs of the MODEL alone: the prepared observations, W = S S^T (SOBER/_gp.py:277) and alpha -- two
+    launches and a handful of host calls that `PI` makes once per model snapshot instead of once per call (the reference's
+    gpytorch model caches its prediction strategy in the same way)."""
     pobs = prepare_points(spec, spec.X_obs)
     W = woodbury(spec)
     if W.dtype != torch.float64 or W.stride(-1) != 1:      # (the fused kernel reads raw rows: csrc/predict.hip takes W's row stride only)
         W = W.to(torch.float64).contiguous()
-    n_obs, N = len(pobs), X.shape[0]
     alpha = spec.alpha if spec.alpha is None or (spec.alpha.dtype == torch.float64 and spec.alpha.is_contiguous()) \
         else spec.alpha.to(torch.float64).contiguous()
+    return pobs, W, alpha
+
+
+def _predict(spec, X, eta=None, log=False, eta_dev=None, model_side=None):
+    dev = X.device
+    kind = nat.KIND_BY_NAME[spec.kind]
+    pobs, W, alpha = model_side if model_side is not None else _model_side(spec)
+    n_obs, N = len(pobs), X.shape[0]
     mean = torch.empty(N, dtype=torch.float64, device=dev)
     var = torch.empty(N, dtype=torch.float64, device=dev)
     fused = (nat.predict_fused_supported(kind, n_obs, pobs.dt) and spec.alpha is not None
@@ -92,6 +100,7 @@ class PI:
         self.Xobs = spec_from_model(model).X_obs
         self._spec = None
         self._eta_dev = None                              # max posterior mean at the observations, ON the device
+        self._model_side = None                           # prepared observations, W, alpha of the snapshot in self._spec
 
     def _prepare(self, device):
         """A live model is read again on every call (the reference evaluates `self.model` each time, :20-38); a
@@ -100,7 +109,8 @@ class PI:
         live = not isinstance(self.model, KernelSpec)
         if live or self._spec is None or same_device(self._spec.X_obs.device) != dev:
             self._spec = spec_from_model(self.model).to(dev)
-            m_obs, _, _ = _predict(self._spec, self._spec.X_obs)
+            self._model_side = _model_side(self._spec)
+            m_obs, _, _ = _predict(self._spec, self._spec.X_obs, model_side=self._model_side)
             self._eta_dev = m_obs.max().reshape(1)        # current maximum (:17): stays on the device -- no read-back per call
         return self._spec
 
@@ -121,7 +131,7 @@ class PI:
 
     def lfi(self, X_cand, log=False):
         spec = self._prepare(X_cand.device)
-        _, _, out = _predict(spec, X_cand.to(torch.float64), eta_dev=self._eta_dev, log=log)
+        _, _, out = _predict(spec, X_cand.to(torch.float64), eta_dev=self._eta_dev, log=log, model_side=self._model_side)
         return out
 
     def __call__(self, X_cand, log=False):

@@ -44,22 +44,27 @@ def _recursive_draws(sober, n_rec, n_repeat):
     sober.flag = False
     for _ in range(n_repeat):
         X_cand, X_indices, weights = _draw(sober, n_rec)
-        idx = weights > 0
-        n_pos = int(idx.sum())                               # (one read-back decides both of the reference's tests)
+        # (the reference's `idx = weights > 0; X_cand[idx]; weights[idx]; X_indices[idx]` is a mask count and three masked
+        #  gathers, each with its own synchronisation on a device: ONE list of the positive positions serves them all, and a
+        #  draw whose weights are all positive is taken as it is)
+        pos = torch.nonzero(weights > 0).squeeze(1)
+        n_pos = int(pos.numel())
         if n_pos != 0:
-            X_acc.append(X_cand[idx])
-            w_acc.append(weights[idx])
+            whole = n_pos == weights.numel()
+            X_acc.append(X_cand if whole else X_cand.index_select(0, pos))
+            w_acc.append(weights if whole else weights.index_select(0, pos))
             n_accepted += n_pos
             if X_indices is not None:
-                I_acc.append(X_indices[idx])
+                I_acc.append(X_indices if whole else X_indices.index_select(0, pos))
         if n_accepted > sober.thresh:
             break
     if n_accepted == 0:
         sober.flag = True
         X_cand, X_indices, weights = _draw(sober, n_rec)
         return X_cand, X_indices, torch.ones(n_rec, dtype=weights.dtype, device=weights.device) / n_rec
-    weights = sober.cleansing_weights(torch.cat(w_acc).contiguous())
-    return torch.vstack(X_acc), (torch.vstack(I_acc) if I_acc else None), weights
+    one = len(w_acc) == 1                                     # (a single accepted draw: nothing to concatenate)
+    weights = sober.cleansing_weights((w_acc[0].clone() if one else torch.cat(w_acc)).contiguous())
+    return (X_acc[0] if one else torch.vstack(X_acc)), ((I_acc[0] if one else torch.vstack(I_acc)) if I_acc else None), weights
 
 
 def sampling_candidates(sober, n_rec, n_nys, verbose=False):

@@ -30,18 +30,27 @@ class WeightsStabiliser:
         return weights.detach()
 
     def check_weights(self, weights):
-        """SOBER/_weights.py:40-55."""
+        """SOBER/_weights.py:40-55: False for an all-zero vector or one with fewer than `thresh` (5) DISTINCT values."""
+        # `len(weights.unique()) < thresh` sorts the whole pool to ask for five distinct values.  A head of the vector that
+        # already holds `thresh` of them answers it -- and travels to the host together with the sum in ONE copy (the
+        # reference's three device questions, `sum() == 0` and two `unique()`, were three synchronisations and two sorts per
+        # call); only a head that does not is followed by the full answer (same verdict either way).
+        if weights.is_cuda:
+            head = weights[:4096]
+            both = torch.cat([weights.sum().reshape(1).to(head.dtype), head]).cpu()
+            if float(both[0]) == 0:
+                return False
+            seen = set()
+            for v in both[1:].tolist():                   # (NaNs are each "distinct" for torch.unique too)
+                seen.add(v if v == v else object())
+                if len(seen) >= self.thresh:
+                    return True
+            if len(weights) > len(head) and len(weights.unique()) >= self.thresh:
+                return True
+            return False
         if weights.sum() == 0:
             return False
-        # `len(weights.unique()) < thresh` asks for fewer than `thresh` (5) DISTINCT values; a sort of the whole pool is
-        # the reference's way of asking.  A head of the vector that already holds `thresh` distinct values answers it;
-        # only when it does not is the full answer computed (same verdict either way).
-        head = weights[:4096]
-        if len(head.unique()) >= self.thresh:
-            return True
-        if len(weights) > len(head) and len(weights.unique()) >= self.thresh:
-            return True
-        return False
+        return len(weights.unique()) >= self.thresh
 
     def weighted_resampling(self, weights, n_nys):
         """SOBER/_weights.py:57-77 (torch.multinomial: RNG-defined, stays in torch)."""

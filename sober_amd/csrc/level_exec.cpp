@@ -218,7 +218,9 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
             return SOBER_E_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
-    LX_TRY(sober_set_i64(j->dR, R0, stream));
+    // (dR[0]: only the first level's own set sums read it -- when the caller has them already, every kernel of level 0 takes
+    //  R0 by value and the launch that would put it there is not made)
+    if (!first_sums_ready) LX_TRY(sober_set_i64(j->dR, R0, stream));
     hipError_t e = hipSuccess;
     for (int l = 0; l < L; ++l) {
         int32_t* cur = (l & 1) ? idx_b : idx_a;
@@ -282,18 +284,16 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
         LX_TRY(sober_dgemm_coldiv_t(n, S, j->n_rows, j->P, j->n_rows, j->G, S, j->tot, j->X_tmp, n, stream));
         LX_TRY(sober_car_device_ex(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
                                    nullptr, j->car_ws, j->car_ws_bytes, j->car_mode, stream));
-        if (l < D)
-            LX_TRY(sober_level_update_queued_cls(cur, Rub[l], S, j->keep_rank, j->w_star, j->tot, j->mu, nxt, j->dR + l,
-                                                 j->dR + l + 1, Rub[l + 1], b, j->cls_scale, j->cls_sof, stream));
-        else
-            LX_TRY(sober_level_update_queued(cur, Rub[l], S, j->keep_rank, j->w_star, j->tot, j->mu, nxt, j->dR + l,
-                                             j->dR + l + 1, Rub[l + 1], stream));
+        LX_TRY(sober_level_update_queued_ex(cur, Rub[l], S, j->keep_rank, j->w_star, j->tot, j->mu, nxt, j->dR + l,
+                                            j->dR + l + 1, Rub[l + 1], l < D ? b : 0, j->cls_scale, j->cls_sof,
+                                            (l == 0 && first_sums_ready) ? R0 : (int64_t)-1, stream));
     }
     for (int k = 0; k < 4; ++k) j->ev[k] = nullptr;
     e = hipMemcpyAsync(j->h_dR, j->dR, sizeof(int64_t) * (size_t)(L + 1), hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return (int)e;
     e = hipStreamSynchronize(st);                                       // the one synchronisation of the chain
     if (e != hipSuccess) return (int)e;
+    j->h_dR[0] = R0;
     int d = 0;
     while (d < L && j->h_dR[d + 1] >= 0) { level_R[d] = j->h_dR[d]; ++d; }
     *done = d;
@@ -361,27 +361,44 @@ extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, i
     return 0;
 }
 
+extern "C" int sober_level_final_job(const sober_level_job* j, const sober_final_job* f, const int32_t* idx, int R,
+                                     void* stream) {
+    if (!j || !f || !f->rows_sc || (!f->cand_sc && (!f->cand_raw || !f->ls || !f->sc_buf)) || !idx || !f->K || !f->mu_live ||
+        !f->out_idx || !f->out_w || !j->P || !j->Xtr || !j->X_tmp || !j->keep_rank || !j->w_star || !j->mu_out || !j->car_ws ||
+        !j->h_flags || !j->mu)
+        return SOBER_E_ARG;
+    const int S = j->S, n = j->n;
+    if (R <= n + 1 || R > S || f->N <= 0) return SOBER_E_ARG;
+    if (!sober_car_supported(R, n + 1)) return SOBER_E_DIM;
+    if (f->cand_sc) {
+        LX_TRY(sober_pairwise(j->kind, f->rows_sc, f->rows_norm, j->n_rows, f->cand_sc, f->cand_norm, idx, R, f->dt,
+                              j->outputscale, f->K, R, stream));                          // kernel(pt_nys, samp[idx])  (:78)
+    } else {                                                                              // (the R rows scaled here: same quotients)
+        LX_TRY(sober_scale_points_idx(f->cand_raw, idx, R, f->d_raw, f->ld_raw, f->ls, f->ls_len, f->sc_buf, f->dt, j->mu,
+                                      f->mu_live, stream));                               // (+ mu[idx], :84)
+        LX_TRY(sober_pairwise(j->kind, f->rows_sc, f->rows_norm, j->n_rows, f->sc_buf, nullptr, nullptr, R, f->dt,
+                              j->outputscale, f->K, R, stream));
+    }
+    LX_TRY(sober_dgemm_coldiv_t(n, R, j->n_rows, j->P, j->n_rows, f->K, R, nullptr, j->X_tmp, n, stream));   // (U K)^T, no division
+    if (f->cand_sc) LX_TRY(sober_gather_f64(j->mu, idx, R, f->mu_live, stream));       // :84
+    LX_TRY(sober_car_device_ex(j->X_tmp, n, R, n + 1, f->mu_live, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
+                               nullptr, j->car_ws, j->car_ws_bytes, j->car_mode, stream));   // :85
+    // mu[:] = 0 (:109) and the write-back -- both skipped on the device when the step reported no result
+    LX_TRY(sober_final_commit(idx, R, j->keep_rank, j->w_star, j->keep_rank + S, f->row_offset, j->mu, f->N, f->out_idx,
+                              f->out_w, stream));
+    hipError_t e = hipMemcpyAsync(j->h_flags + S, j->keep_rank + S, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 extern "C" int sober_level_final(const sober_level_job* j, const void* rows_sc, const double* rows_norm,
                                  const void* cand_sc, const double* cand_norm, int dt, const int32_t* idx, int R,
                                  int64_t N, int64_t row_offset, double* K, double* mu_live, int64_t* out_idx,
                                  double* out_w, void* stream) {
-    if (!j || !rows_sc || !cand_sc || !idx || !K || !mu_live || !out_idx || !out_w || !j->P || !j->Xtr || !j->X_tmp ||
-        !j->keep_rank || !j->w_star || !j->mu_out || !j->car_ws || !j->h_flags || !j->mu)
-        return SOBER_E_ARG;
-    const int S = j->S, n = j->n;
-    if (R <= n + 1 || R > S || N <= 0) return SOBER_E_ARG;
-    if (!sober_car_supported(R, n + 1)) return SOBER_E_DIM;
-    LX_TRY(sober_pairwise(j->kind, rows_sc, rows_norm, j->n_rows, cand_sc, cand_norm, idx, R, dt, j->outputscale, K, R,
-                          stream));                                                  // kernel(pt_nys, samp[idx])  (:78)
-    LX_TRY(sober_dgemm_coldiv_t(n, R, j->n_rows, j->P, j->n_rows, K, R, nullptr, j->X_tmp, n, stream));   // (U K)^T, no division
-    LX_TRY(sober_gather_f64(j->mu, idx, R, mu_live, stream));                       // :84
-    LX_TRY(sober_car_device_ex(j->X_tmp, n, R, n + 1, mu_live, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
-                               nullptr, j->car_ws, j->car_ws_bytes, j->car_mode, stream));   // :85
-    // mu[:] = 0 (:109) and the write-back -- both skipped on the device when the step reported no result
-    LX_TRY(sober_final_commit(idx, R, j->keep_rank, j->w_star, j->keep_rank + S, row_offset, j->mu, N, out_idx, out_w,
-                              stream));
-    hipError_t e = hipMemcpyAsync(j->h_flags + S, j->keep_rank + S, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
-    return e == hipSuccess ? 0 : (int)e;
+    if (!cand_sc) return SOBER_E_ARG;
+    sober_final_job f = {};
+    f.rows_sc = rows_sc; f.rows_norm = rows_norm; f.cand_sc = cand_sc; f.cand_norm = cand_norm; f.dt = dt;
+    f.N = N; f.row_offset = row_offset; f.K = K; f.mu_live = mu_live; f.out_idx = out_idx; f.out_w = out_w;
+    return sober_level_final_job(j, &f, idx, R, stream);
 }
 
 extern "C" int sober_final_job_size(void) { return (int)sizeof(sober_final_job); }
@@ -401,9 +418,7 @@ extern "C" int sober_level_loop_final(sober_level_job* j, sober_final_job* f, in
     if (j->car_mode != SOBER_CAR_DEFAULT && j->car_mode != SOBER_CAR_SAFE) return 0;
     if (!sober_car_supported((int)Rf, n + 1)) return 0;
     if (j->car_mode == SOBER_CAR_SAFE && !sober_car_safe_supported((int)Rf, n + 1)) return 0;
-    if (!f->rows_sc || !f->cand_sc || !f->K || !f->mu_live || !f->out_idx || !f->out_w) return SOBER_E_ARG;
-    LX_TRY(sober_level_final(j, f->rows_sc, f->rows_norm, f->cand_sc, f->cand_norm, f->dt, *in_b ? idx_b : idx_a, (int)Rf,
-                             f->N, f->row_offset, f->K, f->mu_live, f->out_idx, f->out_w, stream));
+    LX_TRY(sober_level_final_job(j, f, *in_b ? idx_b : idx_a, (int)Rf, stream));
     const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     f->done = 1;

@@ -318,6 +318,65 @@ __global__ __launch_bounds__(256) void k_augment_points(const double* __restrict
     }
 }
 
+// The plan's augmented tables in TWO launches (round 6; they were a concatenation, a mean, and one k_augment_points per
+// table): k_center_mean -- the column means of the Nystrom points, summed in a fixed order: "any shift works; this one keeps
+// |x~| small" -- and k_augment_all, one grid over the row table [X_nys; X_obs] (side 0) followed by the pool (side 1), each
+// read from where it lies.
+__global__ __launch_bounds__(256) void k_center_mean(const double* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                     double* __restrict__ center) {
+    __shared__ double s_p[8][32];
+    const int j = threadIdx.x & 31, g = threadIdx.x >> 5;         // coordinate, row group (8 groups)
+    double acc = 0.0;
+    if (j < d)
+        for (int64_t i = g; i < n; i += 8) acc += X[i * ldx + j];
+    s_p[g][j] = acc;
+    __syncthreads();
+    if (g == 0 && j < d) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += s_p[q][j];
+        center[j] = t / (double)n;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_augment_all(const double* __restrict__ Xa, int64_t na, int64_t lda,
+                                                     const double* __restrict__ Xb, int64_t nb, int64_t ldb,
+                                                     const double* __restrict__ Xc, int64_t nc, int64_t ldc, int d,
+                                                     const double* __restrict__ ls, int ls_len,
+                                                     const double* __restrict__ center, double* __restrict__ rows_out,
+                                                     double* __restrict__ cand_out, int da) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l16 = threadIdx.x & 15;
+    const int64_t n_rows = na + nb, n_all = n_rows + nc;
+    const bool live = i < n_all;
+    const int64_t ir = live ? i : n_all - 1;
+    const int side = ir < n_rows ? 0 : 1;
+    const double* src = ir < na ? Xa + ir * lda : (ir < n_rows ? Xb + (ir - na) * ldb : Xc + (ir - n_rows) * ldc);
+    double* dst = side == 0 ? rows_out + ir * da : cand_out + (ir - n_rows) * da;
+    const double sc = (side == 0) ? 369.3299304675746 : 1.0;       // 256/ln2: exp_tab4's pre-scaling
+    double v[2], nrm = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = l16 + 16 * h, jc = min(j, d - 1);
+        const double x = (src[jc] - center[jc]) / ls[ls_len == 1 ? 0 : jc];
+        v[h] = (j < d) ? x : 0.0;
+        nrm = fma(v[h], v[h], nrm);
+    }
+    nrm += aug_dpp<0x128>(nrm);
+    nrm += aug_dpp<0x124>(nrm);
+    nrm += aug_dpp<0x122>(nrm);
+    nrm += aug_dpp<0x121>(nrm);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = l16 + 16 * h;
+        double o = v[h] * sc;
+        if (j == d + side) o = -0.5 * nrm * sc;
+        else if (j == d + 1 - side) o = sc;
+        else if (j >= d) o = 0.0;
+        if (live && j < da) dst[j] = o;
+    }
+}
+
 template <int KIND, int KT>
 static int launch_lm(const double* rows, int n_rows, const double* cand, const int32_t* idx, int64_t pos0,
                      int64_t count, int S, const double* mu, const double* wmul, double os, int n_chunks,
@@ -376,6 +435,24 @@ extern "C" int sober_augment_points(const double* X, int64_t n, int d, int64_t l
     if (da > 32) return SOBER_E_DIM;
     hipLaunchKernelGGL(k_augment_points, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, X, n,
                        d, ldx, lengthscale, ls_len, center, side, out, da);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_augment_plan(const double* X_nys, int64_t M, int64_t ld_nys, const double* X_obs, int64_t n_obs,
+                                  int64_t ld_obs, const double* X_cand, int64_t N, int64_t ld_cand, int d,
+                                  const double* lengthscale, int ls_len, double* center, double* rows_aug, double* cand_aug,
+                                  int da, void* stream) {
+    if (!X_nys || !X_cand || !lengthscale || !center || !rows_aug || !cand_aug || M <= 0 || N <= 0 || n_obs < 0 || d <= 0 ||
+        (n_obs > 0 && !X_obs) || ld_nys < d || ld_cand < d || (n_obs > 0 && ld_obs < d) || da < d + 2)
+        return SOBER_E_ARG;
+    if ((ls_len != 1 && ls_len != d) || d > 30) return SOBER_E_ARG;
+    if (da > 32) return SOBER_E_DIM;
+    hipLaunchKernelGGL(k_center_mean, dim3(1), dim3(256), 0, (hipStream_t)stream, X_nys, M, d, ld_nys, center);
+    LAUNCH_CHECK();
+    const int64_t n_all = M + n_obs + N;
+    hipLaunchKernelGGL(k_augment_all, dim3((unsigned)((n_all + 15) / 16)), dim3(256), 0, (hipStream_t)stream, X_nys, M, ld_nys,
+                       X_obs, n_obs, ld_obs, X_cand, N, ld_cand, d, lengthscale, ls_len, center, rows_aug, cand_aug, da);
     LAUNCH_CHECK();
     return 0;
 }

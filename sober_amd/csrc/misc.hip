@@ -17,6 +17,23 @@ __global__ void k_scale_points(const double* __restrict__ X, int64_t n, int d, i
     out[t] = v;
 }
 
+// ... of the rows idx[0:n] only (the final direct level's <= 2 b points: the pool itself is never copied in scaled form
+// on the matrix-core path -- 192 MB written and read back at 1M x 20 for the sake of 200 rows)
+// (gsrc != NULL: gout[i] = gsrc[idx[i]] rides along -- the live positions' weights of SOBER/_rchq.py:84, one launch less)
+__global__ void k_scale_points_idx(const double* __restrict__ X, const int32_t* __restrict__ idx, int64_t n, int d, int64_t ldx,
+                                   const double* __restrict__ ls, int ls_len, double* __restrict__ out, int dt,
+                                   const double* __restrict__ gsrc, double* __restrict__ gout) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * dt) return;
+    const int64_t i = t / dt;
+    const int j = (int)(t % dt);
+    const int64_t c = idx[i];
+    double v = 0.0;
+    if (j < d) v = X[c * ldx + j] / ls[ls_len == 1 ? 0 : j];
+    out[t] = v;
+    if (gsrc != nullptr && j == 0) gout[i] = gsrc[c];
+}
+
 // one wave per row: ballot packs 64 bits at a time
 __global__ void k_pack_bits(const double* __restrict__ X, int64_t n, int d, int64_t ldx,
                             uint64_t* __restrict__ words, int nwords, double* __restrict__ norms,
@@ -185,9 +202,10 @@ __global__ void k_level_update_queued(const int32_t* __restrict__ idx_cur, int S
                                       double* __restrict__ mu, int32_t* __restrict__ idx_new,
                                       const int64_t* __restrict__ dR_cur, int64_t* __restrict__ dR_next,
                                       int64_t R_ub_next, int need_keep, double* __restrict__ cls_scale,
-                                      int32_t* __restrict__ cls_sof) {
+                                      int32_t* __restrict__ cls_sof, int64_t R_known) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t R = __hip_atomic_load(dR_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (R_known >= 0: the chain's first level, whose size the host knows -- no launch just to put it into dR[0])
+    const int64_t R = R_known >= 0 ? R_known : __hip_atomic_load(dR_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int64_t E = R > 0 ? R / S : 0, ES = E * S, r = R - ES;
     const int n_keep = keep_rank[S];
     const bool last_kept = keep_rank[S - 1] >= 0;
@@ -277,6 +295,44 @@ __global__ void k_final_scatter_guarded(const int32_t* __restrict__ idx, int n, 
     mu[c] = w;
     out_idx[k] = (int64_t)c + row_offset;
     out_w[k] = w;
+}
+
+// mu[:] = 0 and the write-back in ONE launch (round 6): every workgroup keeps the <= 512 kept (candidate, weight) pairs in
+// LDS, in rank order -- ascending candidates, because the live list is (a list that is not falls back to a scan) -- and each
+// element of mu looks itself up: a binary search of <= 9 steps instead of a second launch behind the zero fill.
+__global__ __launch_bounds__(256) void k_final_commit(const int32_t* __restrict__ idx, int n, const int32_t* __restrict__ keep_rank,
+                                                      const double* __restrict__ w_star, const int32_t* __restrict__ n_keep,
+                                                      int64_t row_offset, double* __restrict__ mu, int64_t N,
+                                                      int64_t* __restrict__ out_idx, double* __restrict__ out_w) {
+    const int nk = *n_keep;
+    if (nk < 0) return;                                      // (the step reported no result: the weights stay what they were)
+    __shared__ int s_c[512];
+    __shared__ double s_w[512];
+    __shared__ int s_unsorted;
+    if (threadIdx.x == 0) s_unsorted = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int k = keep_rank[t];
+        if (k >= 0 && k < 512) { s_c[k] = idx[t]; s_w[k] = w_star[k]; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x + 1; k < nk; k += blockDim.x)
+        if (s_c[k] <= s_c[k - 1]) s_unsorted = 1;
+    __syncthreads();
+    const bool sorted = s_unsorted == 0;
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < nk; k += blockDim.x) { out_idx[k] = (int64_t)s_c[k] + row_offset; out_w[k] = s_w[k]; }
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N; t += (int64_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (sorted) {
+            int lo = 0, hi = nk;                              // first k with s_c[k] >= t
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)s_c[mid] < t) lo = mid + 1; else hi = mid; }
+            if (lo < nk && (int64_t)s_c[lo] == t) v = s_w[lo];
+        } else {
+            for (int k = 0; k < nk; ++k) if ((int64_t)s_c[k] == t) v = s_w[k];     // (the last rank writing a candidate wins, like the scatter)
+        }
+        mu[t] = v;
+    }
 }
 
 // left block of the projection: P[r][c] = Ut[r][c] * mean[c]  (c < M; ldp = M + n_obs)
@@ -499,6 +555,17 @@ extern "C" int sober_scale_points(const double* X, int64_t n, int d, int64_t ldx
     return 0;
 }
 
+extern "C" int sober_scale_points_idx(const double* X, const int32_t* idx, int64_t n, int d, int64_t ldx,
+                                      const double* lengthscale, int ls_len, double* out, int dt, const double* gather_src,
+                                      double* gather_out, void* stream) {
+    if (!X || !idx || !lengthscale || !out || n <= 0 || d <= 0 || dt < d || ldx < d) return SOBER_E_ARG;
+    if ((ls_len != 1 && ls_len != d) || (gather_src && !gather_out)) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_scale_points_idx, dim3(nblk(n * dt, 256)), dim3(256), 0, (hipStream_t)stream, X, idx, n, d, ldx,
+                       lengthscale, ls_len, out, dt, gather_src, gather_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sober_pack_bits(const double* X, int64_t n, int d, int64_t ldx, uint64_t* words,
                                int nwords, double* norms, int32_t* bad_flag, void* stream) {
     if (!X || !words || !norms || !bad_flag || n <= 0 || d <= 0 || nwords * 64 < d || ldx < d)
@@ -581,7 +648,23 @@ extern "C" int sober_level_update_queued(const int32_t* idx_cur, int64_t R_ub, i
     if (!idx_cur || !keep_rank || !w_star || !tot || !mu || !idx_new || !dR_cur || !dR_next || R_ub <= 0 || S <= 0)
         return SOBER_E_ARG;
     hipLaunchKernelGGL(k_level_update_queued, dim3(nblk(R_ub, 256)), dim3(256), 0, (hipStream_t)stream, idx_cur, S,
-                       keep_rank, w_star, tot, mu, idx_new, dR_cur, dR_next, R_ub_next, 0, (double*)nullptr, (int32_t*)nullptr);
+                       keep_rank, w_star, tot, mu, idx_new, dR_cur, dR_next, R_ub_next, 0, (double*)nullptr, (int32_t*)nullptr, (int64_t)-1);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// the general form: need_keep = 0 / cls_* = NULL for a level whose successor is evaluated; R_known >= 0: this level's size by
+// value (the chain's first level) instead of *dR_cur
+extern "C" int sober_level_update_queued_ex(const int32_t* idx_cur, int64_t R_ub, int S, const int32_t* keep_rank,
+                                            const double* w_star, const double* tot, double* mu, int32_t* idx_new,
+                                            const int64_t* dR_cur, int64_t* dR_next, int64_t R_ub_next, int need_keep,
+                                            double* cls_scale, int32_t* cls_sof, int64_t R_known, void* stream) {
+    if (!idx_cur || !keep_rank || !w_star || !tot || !mu || !idx_new || (!dR_cur && R_known < 0) || !dR_next || R_ub <= 0 ||
+        S <= 0 || need_keep < 0 || need_keep > S || (need_keep > 0 && (!cls_scale || !cls_sof)))
+        return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_level_update_queued, dim3(nblk(R_ub, 256)), dim3(256), 0, (hipStream_t)stream, idx_cur, S,
+                       keep_rank, w_star, tot, mu, idx_new, dR_cur, dR_next, R_ub_next, need_keep,
+                       need_keep > 0 ? cls_scale : nullptr, need_keep > 0 ? cls_sof : nullptr, R_known);
     LAUNCH_CHECK();
     return 0;
 }
@@ -596,7 +679,7 @@ extern "C" int sober_level_update_queued_cls(const int32_t* idx_cur, int64_t R_u
         need_keep <= 0 || need_keep > S || !cls_scale || !cls_sof)
         return SOBER_E_ARG;
     hipLaunchKernelGGL(k_level_update_queued, dim3(nblk(R_ub, 256)), dim3(256), 0, (hipStream_t)stream, idx_cur, S,
-                       keep_rank, w_star, tot, mu, idx_new, dR_cur, dR_next, R_ub_next, need_keep, cls_scale, cls_sof);
+                       keep_rank, w_star, tot, mu, idx_new, dR_cur, dR_next, R_ub_next, need_keep, cls_scale, cls_sof, (int64_t)-1);
     LAUNCH_CHECK();
     return 0;
 }
@@ -715,6 +798,12 @@ extern "C" int sober_final_commit(const int32_t* idx, int n, const int32_t* keep
     if (!idx || !keep_rank || !w_star || !n_keep || !mu || !out_idx || !out_w || n <= 0 || N <= 0) return SOBER_E_ARG;
     int64_t nb = nblk(N, 256);
     if (nb > 4096) nb = 4096;
+    if (n <= 512) {
+        hipLaunchKernelGGL(k_final_commit, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, idx, n, keep_rank, w_star, n_keep,
+                           row_offset, mu, N, out_idx, out_w);
+        LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_zero_unless_failed, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, mu, N, n_keep);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_final_scatter_guarded, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, idx, n, keep_rank,

@@ -47,6 +47,8 @@ def test_kmeans_screened_default_path_vs_reference(tag, dev):
     np.testing.assert_allclose(c.cpu().numpy(), z[f"{tag}_c"], rtol=1e-11)
 
 
+@pytest.mark.parametrize("kind,d,n_obs,N", [("rbf", 10, 200, 10007), ("matern52", 6, 37, 4096), ("rbf", 3, 255, 777),
+                                             ("tanimoto", 2048, 64, 3000), ("tanimoto", 100, 200, 1031)])
 def test_fused_prediction_equals_the_materialised_route(kind, d, n_obs, N, dev, monkeypatch):
     """csrc/predict.hip (one launch: K(X_obs, x) once into LDS, W k on the FP64 matrix cores) against the four-launch
     route it replaces (SOBER_PREDICT_MATERIALISED=1: posterior mean, materialised K(X_obs, pool), V = W KX, the column-wise
