@@ -142,13 +142,49 @@ __global__ __launch_bounds__(256) void k_kmeans_assign_mfma(const double* __rest
                                                             int32_t* __restrict__ labels,
                                                             int32_t* __restrict__ ucount, int64_t n_units,
                                                             const int32_t* __restrict__ flist,
-                                                            const unsigned* __restrict__ n_list) {
+                                                            const unsigned* __restrict__ n_list,
+                                                            const int* __restrict__ nan_first_p) {
     extern __shared__ int km_hist[];
     typedef double d4 __attribute__((ext_vector_type(4)));
     constexpr int DA = 4 * KT, PB = LIST ? 1 : KM_PB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lj = lane & 15, lg = lane >> 4;
     const int64_t NP = LIST ? (int64_t)*n_list : N;           // points to label
+    if constexpr (LIST) {
+        // A NaN centroid (an empty cluster's 0 / 0) sends EVERY point to this list, and every finite point's answer is known
+        // without a single tile: its first NaN distance is that centroid (the reference's argmin returns the first NaN).
+        // Walking the 32 centroid tiles for a million points sixteen at a time took this launch from 15 us to 10 ms per
+        // iteration (the advisor's "silent cliff", tests/test_hip_round6.py times it); now one thread per listed point:
+        // finite -> that centroid, a NaN coordinate -> 0 (all its distances are NaN), an infinite one -> the exact loop.
+        const int nf = nan_first_p != nullptr ? *nan_first_p : 0x7fffffff;
+        if (nf != 0x7fffffff) {                               // (uniform)
+            for (int64_t ip = (int64_t)blockIdx.x * 256 + threadIdx.x; ip < NP; ip += (int64_t)gridDim.x * 256) {
+                const int64_t i = flist[ip];
+                bool x_nan = false, x_inf = false;
+                for (int j = 0; j < d; ++j) { const double v = X[i * d + j]; x_nan |= v != v; x_inf |= fabs(v) > 1e150; }
+                int lab = x_nan ? 0 : nf;
+                if (x_inf && !x_nan) {
+                    double best = __builtin_inf();
+                    int bi = 0;
+                    bool best_nan = false;
+                    for (int k = 0; k < K; ++k) {
+                        double dist = 0.0;
+                        for (int j = 0; j < d; ++j) { const double df = X[i * d + j] - cent[(size_t)k * d + j]; dist = fma(df, df, dist); }
+                        const bool isn = dist != dist;
+                        if (!best_nan && (isn || dist < best)) { best = dist; bi = k; best_nan = isn; }
+                    }
+                    lab = bi;
+                }
+                const int was = labels[i];
+                if (was != lab) {
+                    atomicAdd(ucount + (size_t)was * n_units + i / 256, -1);
+                    atomicAdd(ucount + (size_t)lab * n_units + i / 256, 1);
+                    labels[i] = lab;
+                }
+            }
+            return;
+        }
+    }
   for (int64_t wu = (int64_t)blockIdx.x * 4 + wave; !LIST || wu * (16 * PB) < NP; wu += (int64_t)gridDim.x * 4) {
     const int64_t p0 = wu * (16 * PB);
     if (p0 >= NP && (LIST || ucount == nullptr)) return;      // (a counting workgroup keeps all its waves for the final sum)
@@ -333,7 +369,11 @@ struct KmStat {
     unsigned bad[2];                    // like integers); bad: a centroid that is not finite.  [parity of the iteration]
     unsigned n_list;                    // points the first pass sent to the list
     unsigned listed;                    // ... summed over the iterations of the call (sober_kmeans_stat_offset)
-};
+    int nan_first[2];                   // the first centroid with a NaN coordinate (0x7fffffff: none).  [parity of the iteration]
+    unsigned big_ticket;                // the M step of a cluster that holds more than half the pool: arrivals of its KM_BIG_SPLIT
+};                                      // workgroups (k_kmeans_update_sorted; their partial sums borrow the E step's list)
+static_assert(sizeof(KmStat) <= 256, "the workspace keeps 256 bytes for it (km_off_mu)");
+constexpr int KM_BIG_SPLIT = 64;
 constexpr int KM_SCREEN_MIN_N = 4096;          // (eligible from here on; RECOMMENDED from KM_SCREEN_MIN_WORK on)
 // pool size x FP64 contraction steps from which the screened E step is faster than the FP64 one (same box, K = 500:
 // 20k x 10 0.54 vs 0.49 ms, 50k x 6 0.53 vs 0.46, 50k x 20 0.65 vs 0.65, 100k x 10 0.70 vs 0.73, 200k x 10 0.86 vs 1.12,
@@ -366,7 +406,8 @@ __global__ __launch_bounds__(1024) void k_km_mu(const double* __restrict__ X, in
                                                 KmStat* __restrict__ st) {
     __shared__ double s_part[32][33];
     const int tid = threadIdx.x, j = tid & 31, g = tid >> 5;     // 32 row groups x 32 coordinates (a chain of K / 32 loads each)
-    if (tid == 0) { st->cmax2_bits[0] = 0ull; st->cmax2_bits[1] = 0ull; st->bad[0] = 0u; st->bad[1] = 0u; st->n_list = 0u; st->listed = 0u; }
+    if (tid == 0) { st->cmax2_bits[0] = 0ull; st->cmax2_bits[1] = 0ull; st->bad[0] = 0u; st->bad[1] = 0u; st->n_list = 0u; st->listed = 0u;
+                    st->nan_first[0] = 0x7fffffff; st->nan_first[1] = 0x7fffffff; st->big_ticket = 0u; }
     double acc = 0.0;
     if (j < d)
         for (int k = g; k < K; k += 32) acc += X[(size_t)k * d + j];
@@ -382,7 +423,8 @@ __global__ __launch_bounds__(1024) void k_km_mu(const double* __restrict__ X, in
 
 // the centroid's row of the BF16 image, by the threads of one workgroup (>= KS of them); c: the centroid (LDS or global)
 __device__ __forceinline__ void km_centroid_row(const double* c, const double* __restrict__ mu, int d, int KS,
-                                                unsigned short* __restrict__ row, KmStat* __restrict__ st, int par, int tid) {
+                                                unsigned short* __restrict__ row, KmStat* __restrict__ st, int par, int tid,
+                                                int k) {
     if (tid < d) {
         unsigned short h, l;
         km_split2(-2.0 * (c[tid] - mu[tid]), h, l);
@@ -397,6 +439,7 @@ __device__ __forceinline__ void km_centroid_row(const double* c, const double* _
         row[3 * d] = p0; row[3 * d + 1] = p1; row[3 * d + 2] = p2;
         if (n2 < 1e300) atomicMax(&st->cmax2_bits[par], (unsigned long long)__double_as_longlong(n2));
         else atomicOr(&st->bad[par], 1u);                    // (NaN or Inf: an empty cluster's 0 / 0, overflowing data)
+        if (n2 != n2) atomicMin(&st->nan_first[par], k);     // (a NaN centroid: every finite point's first NaN distance)
     } else if (tid >= 3 * d + 3 && tid < KS) {
         row[tid] = 0;
     }
@@ -408,7 +451,7 @@ __global__ __launch_bounds__(128) void k_km_cprep(const double* __restrict__ cen
                                                   KmStat* __restrict__ st) {
     const int k = blockIdx.x, tid = threadIdx.x;
     unsigned short* row = Cb + (size_t)k * KS;
-    if (k < K) { km_centroid_row(cent + (size_t)k * d, mu, d, KS, row, st, 0, tid); return; }
+    if (k < K) { km_centroid_row(cent + (size_t)k * d, mu, d, KS, row, st, 0, tid, k); return; }
     if (tid < KS) row[tid] = (tid == 3 * d) ? km_bf16(1e30) : (unsigned short)0;
 }
 
@@ -484,7 +527,7 @@ __global__ __launch_bounds__(KM_SCREEN_T) void k_kmeans_screen(const uint4* __re
     }
     const float cmax2 = (float)__longlong_as_double((long long)st->cmax2_bits[par]);
     const bool bad = st->bad[par] != 0u;
-    if (blockIdx.x == 0 && tid == 0) { st->cmax2_bits[par ^ 1] = 0ull; st->bad[par ^ 1] = 0u; }   // (the M step fills it next)
+    if (blockIdx.x == 0 && tid == 0) { st->cmax2_bits[par ^ 1] = 0ull; st->bad[par ^ 1] = 0u; st->nan_first[par ^ 1] = 0x7fffffff; }   // (the M step fills it next)
     const int n_tiles = Kp >> 4;
     const int64_t n_pairs = (N + PTS - 1) / PTS;
     for (int64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
@@ -782,9 +825,29 @@ __global__ __launch_bounds__(KM_UPD_T) void k_kmeans_update_sorted(const double*
                                                               const int32_t* __restrict__ order,
                                                               double* __restrict__ cent, double* __restrict__ Caug, int DA,
                                                               const double* __restrict__ mu, unsigned short* __restrict__ Cb,
-                                                              int KS, KmStat* __restrict__ st, int par_next) {
+                                                              int KS, KmStat* __restrict__ st, int par_next, int64_t N_pool,
+                                                              double* __restrict__ big_part) {
     __shared__ double s_c[DT];
-    const int k = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int k = blockIdx.x, split = -1;
+    // A cluster that holds more than half the pool (the degenerate clustering behind an empty cluster: the reference's argmin
+    // sends EVERY point to the first NaN centroid) is not summed by one workgroup -- 9.6 ms per iteration at 1M x 20, the
+    // second half of the advisor's "cliff" -- but by the KM_BIG_SPLIT workgroups launched behind the K regular ones: each sums
+    // a contiguous share in this kernel's own order, the last to arrive adds the shares in share order (fixed: run-to-run
+    // bit-equal).  Every other cluster is summed exactly as before; without the screen's statistics block (N_pool = 0) so is this one.
+    if (k >= K) {                                            // one of the extra workgroups: is there such a cluster?
+        __shared__ int s_g;
+        if (tid == 0) s_g = -1;
+        __syncthreads();
+        for (int j = tid; j < K; j += KM_UPD_T)
+            if (2 * (int64_t)tot[j] > N_pool) s_g = j;       // (at most one)
+        __syncthreads();
+        if (s_g < 0) return;
+        split = k - K;
+        k = s_g;
+    } else if (N_pool > 0 && 2 * (int64_t)tot[k] > N_pool) {
+        return;                                              // (the extra workgroups' cluster)
+    }
     // lo = sum of the sizes of the clusters in front of mine
     __shared__ int s_lo[KM_UPD_T / 64];
     int part = 0;
@@ -797,6 +860,8 @@ __global__ __launch_bounds__(KM_UPD_T) void k_kmeans_update_sorted(const double*
 #pragma unroll
     for (int q = 0; q < KM_UPD_T / 64; ++q) lo += s_lo[q];
     const int n_k = tot[k];
+    const int share = (n_k + KM_BIG_SPLIT - 1) / KM_BIG_SPLIT;
+    const int p_lo = split < 0 ? 0 : min(n_k, split * share), p_hi = split < 0 ? n_k : min(n_k, p_lo + share);
     // a row is read by DT / 4 neighbouring lanes, 32 bytes each (one thread per row walked it with 8-byte loads, 64 rows
     // -- 128 cache lines -- per load instruction, every line touched again by the next 19: 119 us at 1M x 20, x 10
     // iterations); lane (rs, c) sums chunk c of rows rs, rs + RP, ...; the RP partial sums of a coordinate are added in
@@ -807,7 +872,7 @@ __global__ __launch_bounds__(KM_UPD_T) void k_kmeans_update_sorted(const double*
     double a4[4] = {0.0, 0.0, 0.0, 0.0};
     if (rs < RP) {
 #pragma unroll 4
-        for (int p = rs; p < n_k; p += RP) {
+        for (int p = p_lo + rs; p < p_hi; p += RP) {
             const double* row = X + (size_t)order[lo + p] * d + 4 * ch;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -817,13 +882,36 @@ __global__ __launch_bounds__(KM_UPD_T) void k_kmeans_update_sorted(const double*
         for (int e = 0; e < 4; ++e) s_acc[rs][4 * ch + e] = a4[e];
     }
     __syncthreads();
+    double sum = 0.0;
     if (tid < d) {
         const int j = tid;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;       // four interleaved chains, then one fixed combination
         int r = 0;
         for (; r + 3 < RP; r += 4) { s0 += s_acc[r][j]; s1 += s_acc[r + 1][j]; s2 += s_acc[r + 2][j]; s3 += s_acc[r + 3][j]; }
         for (; r < RP; ++r) s0 += s_acc[r][j];
-        const double sum = (s0 + s1) + (s2 + s3);
+        sum = (s0 + s1) + (s2 + s3);
+    }
+    if (split >= 0) {                                        // my share is out; the last share to arrive adds them all
+        if (tid < d) big_part[split * 32 + tid] = sum;
+        __threadfence();
+        __syncthreads();
+        __shared__ int s_last;
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(&st->big_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (t == (unsigned)KM_BIG_SPLIT - 1u) ? 1 : 0;
+            if (s_last) __hip_atomic_store(&st->big_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return;                                 // (uniform)
+        __threadfence();
+        if (tid < d) {
+            sum = 0.0;
+            for (int e = 0; e < KM_BIG_SPLIT; ++e)
+                sum += __hip_atomic_load(big_part + e * 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid < d) {
+        const int j = tid;
         const double c = sum / (double)n_k;                  // (an empty cluster: 0 / 0 = NaN, as in the reference)
         cent[(size_t)k * d + j] = c;
         if (Caug != nullptr) { Caug[(size_t)k * DA + j] = -2.0 * c; s_c[j] = c; }
@@ -839,7 +927,7 @@ __global__ __launch_bounds__(KM_UPD_T) void k_kmeans_update_sorted(const double*
     if (tid > d && tid < DA) Caug[(size_t)k * DA + tid] = 0.0;
     if (Cb == nullptr) return;
     // (screened E step) the BF16 image of this centroid for the next first pass; the list is consumed by now
-    km_centroid_row(s_c, mu, d, KS, Cb + (size_t)k * KS, st, par_next, tid);
+    km_centroid_row(s_c, mu, d, KS, Cb + (size_t)k * KS, st, par_next, tid, k);
     if (k == 0 && tid == KM_UPD_T - 1) { st->listed += st->n_list; st->n_list = 0u; }
 }
 
@@ -948,7 +1036,7 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
             LAUNCH_CHECK();
             // the list: the FP64 kernel with its exact re-check, on a grid that strides over however many there are
 #define KM_CASE(T) case T: hipLaunchKernelGGL((k_kmeans_assign_mfma<T, true>), dim3(256), dim3(256), 0, st, X, N, d, cent, Caug, K, Kp, \
-                                              labels, ucount, n_units, flist, &stat->n_list); break;
+                                              labels, ucount, n_units, flist, &stat->n_list, &stat->nan_first[it & 1]); break;
             switch (kt) { KM_CASE(1) KM_CASE(2) KM_CASE(3) KM_CASE(4) KM_CASE(5) KM_CASE(6) KM_CASE(7) KM_CASE(8) default: break; }
 #undef KM_CASE
         } else if (mfma_e) {
@@ -956,7 +1044,7 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
             const dim3 grid((unsigned)((n_waves + 3) / 4));
 #define KM_CASE(T) case T: hipLaunchKernelGGL((k_kmeans_assign_mfma<T, false>), grid, dim3(256), fuse_count ? lds_count : 0, st, X, N, d, \
                                               cent, Caug, K, Kp, labels, fuse_count ? ucount : (int32_t*)nullptr, n_units, \
-                                              (const int32_t*)nullptr, (const unsigned*)nullptr); break;
+                                              (const int32_t*)nullptr, (const unsigned*)nullptr, (const int*)nullptr); break;
             switch (kt) { KM_CASE(1) KM_CASE(2) KM_CASE(3) KM_CASE(4) KM_CASE(5) KM_CASE(6) KM_CASE(7) KM_CASE(8) default: break; }
 #undef KM_CASE
         } else {
@@ -974,8 +1062,10 @@ static int run_kmeans(const double* X, int64_t N, int d, int K, int iters, doubl
             LAUNCH_CHECK();
             hipLaunchKernelGGL(k_km_place, ugrid, dim3(256), lds_place, st, labels, N, K, n_units, ucount, tot, order);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL((k_kmeans_update_sorted<DT>), dim3(K), dim3(KM_UPD_T), 0, st, X, d, K, tot, order, cent, Caug, 4 * kt,
-                               (const double*)mu, Cb, ks, stat, (it + 1) & 1);
+            // (+ KM_BIG_SPLIT workgroups for a cluster that holds more than half the pool; they leave at once otherwise)
+            hipLaunchKernelGGL((k_kmeans_update_sorted<DT>), dim3(K + (stat ? KM_BIG_SPLIT : 0)), dim3(KM_UPD_T), 0, st, X, d, K, tot,
+                               order, cent, Caug, 4 * kt, (const double*)mu, Cb, ks, stat, (it + 1) & 1, stat ? N : (int64_t)0,
+                               (double*)flist);      // (the list is consumed by now: KM_BIG_SPLIT x 32 doubles of it)
         } else {
             hipLaunchKernelGGL((k_kmeans_update<DT>), dim3(K), dim3(256), 0, st, X, N, d, labels, cent);
         }

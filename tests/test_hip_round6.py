@@ -268,11 +268,12 @@ def test_calc_obj_step_with_the_null_vector_kernel_equals_the_second_step_route(
 
 
 def test_kmeans_with_an_empty_cluster_is_bounded_not_a_cliff(dev):
-    """An empty cluster leaves a NaN centroid (SOBER/_weights.py:117-124 divides by a zero count) and the screened E step
-    (csrc/kmeans.hip) then sends EVERY point to its exact FP64 pass -- the advisor's "silent cliff".  Its price, measured
-    here so that it cannot grow unseen: the same 1M x 20 pool with and without a duplicated initial centroid, ten Lloyd
-    iterations each -- the degenerate run within 8 x the clean one (it is the round-3 E step, before the screen existed),
-    labels identical to the kernel that runs without the screen's workspace."""
+    """An empty cluster leaves a NaN centroid (SOBER/_weights.py:117-124 divides by a zero count); the reference's argmin then
+    sends EVERY point to it.  Up to round 5 that cost the screened path (csrc/kmeans.hip) 10 ms per iteration twice over at
+    1M x 20 -- every point through the list pass's tile walk sixteen at a time, then one workgroup summing a cluster that holds
+    the whole pool: 105 ms for ten iterations against 2.4 (the advisor's "silent cliff", measured by this very test).  Now
+    the list pass answers a NaN centroid without a tile and such a cluster's sum is shared by 64 workgroups: the degenerate
+    run within 8 x the clean one, labels identical to the kernel that runs without the screen's workspace."""
     import time
     from sober_amd import _native as nat
     lib = nat.load()
