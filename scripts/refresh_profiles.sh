@@ -19,19 +19,19 @@ for c in $CFGS; do
 done
 for c in $CFGS; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_cfg$c" -o run -- \
-    python3 bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline --no-sweep > "$OUT/prof_cfg$c.log" 2>&1
+    python3 bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline --no-sweep --no-others > "$OUT/prof_cfg$c.log" 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_cfg$c" -o run -- \
-    python3 bench.py --config $c --steps 3 --warmup 2 --no-cpu-baseline --no-sweep > "$OUT/pmc_fetch_cfg$c.log" 2>&1
+    python3 bench.py --config $c --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-others > "$OUT/pmc_fetch_cfg$c.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_cfg$c" -o run -- \
-    python3 bench.py --config $c --steps 3 --warmup 2 --no-cpu-baseline --no-sweep > "$OUT/pmc_write_cfg$c.log" 2>&1
+    python3 bench.py --config $c --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-others > "$OUT/pmc_write_cfg$c.log" 2>&1
 done
 if echo " $CFGS " | grep -q " 2 "; then
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o run -- \
-    python3 bench.py --config 2 --steps 3 --warmup 2 --no-cpu-baseline --no-sweep > "$OUT/pmc_sq.log" 2>&1
+    python3 bench.py --config 2 --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-others > "$OUT/pmc_sq.log" 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F64 \
     --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -o run -- \
-    python3 bench.py --config 2 --steps 3 --warmup 2 --no-cpu-baseline --no-sweep > "$OUT/pmc_sq2.log" 2>&1
+    python3 bench.py --config 2 --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-others > "$OUT/pmc_sq2.log" 2>&1
 fi
 # keep what travels back small: the per-dispatch traces of the stats runs are not needed (the stats are)
 find "$OUT" -name "run_kernel_trace.csv" -path "*prof_cfg*" -delete
