@@ -264,9 +264,6 @@ __device__ __forceinline__ void car_bidiag2_block(double (&a)[CAR_MS][CAR_CQ], d
             asm volatile("" : "+v"(c8));
 #pragma unroll
             for (int q = 0; q < CAR_CQ; ++q) {            // (whole reflectors: the consumers read every slot)
-#ifdef CB2_X_FEWSTORES                                    // timing-only (diagnostic build, wrong results): what 9 of the 13 stores cost
-                if ((q & 3) != 0) continue;
-#endif
                 double v;
                 if (q < S || q >= CQ) v = 0.0;
                 else if (q == S) v = (C < li) ? 0.0 : ((C == li) ? 1.0 : x[S]);
