@@ -265,6 +265,10 @@ int sober_car_device_ex(const double* X, int ldx, int N, int m, const double* mu
  * set to its rank or -1) move along the null vector phi of [X_p; 1] -- the one-column phi_out of sober_car_device on
  * the n1 survivors -- oriented so that sum w * objp does not decrease, until one more reaches zero.
  * Out: keep_rank[0:Nsets] (new ranks, -1 = cancelled), w_star[0:n_keep], *n_keep.                               */
+/* The objective's row of the level's set sums (SOBER/_rchq.py:138-146, :157-163): out[s] = sum of obj[c] mu[c] over the list
+ * positions p in [pos0, pos0 + count) with p mod S = s (c = idx[p - pos0]), the leftovers p >= E S also into set S - 1 (Q1).   */
+int sober_obj_set_sums(const double* obj, const double* mu, const int32_t* idx, int64_t pos0, int64_t count, int S, int64_t E,
+                       double* out, void* stream);
 int sober_second_elimination(const double* phi, const double* objp, const double* w1, const int32_t* rank1, int n1,
                              int Nsets, int32_t* keep_rank, double* w_star, int32_t* n_keep, void* stream);
 /* Round 6: that null vector in ONE launch (csrc/null_vector.hip): Gauss-Jordan elimination with partial pivoting on

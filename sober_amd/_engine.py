@@ -483,6 +483,9 @@ class RecombinationEngine:
         dev = mu.device
         if count == 0:
             return torch.zeros(S, dtype=torch.float64, device=dev)
+        native = getattr(self.ops, "obj_set_sums", None)
+        if native is not None and obj.dtype == torch.float64 and obj.is_contiguous():
+            return native(obj, mu, idx_cur, pos0, count, S, E)       # one launch (csrc/misc.hip: k_obj_set_sums)
         c = idx_cur[:count].long()
         v = obj[c] * mu[c]
         e_first = pos0 // S

@@ -74,6 +74,7 @@ SIGNATURES = {
     "sober_car_mc_ws_bytes": (_i64, [_i32, _i32]),
     "sober_car_mc_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_car_device_ex": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "sober_obj_set_sums": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp]),
     "sober_null_vector_supported": (_i32, [_i32]),
     "sober_null_vector": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sober_second_elimination_rows": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
@@ -572,6 +573,12 @@ def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None, multi_
     _check(fn(X.data_ptr(), X.stride(0), N, n + 1, mu_in.data_ptr(), keep_rank.data_ptr(),
               w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
               ws.data_ptr(), nbytes, _stream(X)), name)
+
+
+def obj_set_sums(obj, mu, idx, pos0, count, S, E, out):
+    _req(obj, torch.float64, "obj"); _req(mu, torch.float64, "mu"); _req(idx, torch.int32, "idx"); _req(out, torch.float64, "out")
+    _check(load().sober_obj_set_sums(obj.data_ptr(), mu.data_ptr(), idx.data_ptr(), int(pos0), int(count), int(S), int(E),
+                                     out.data_ptr(), _stream(mu)), "sober_obj_set_sums")
 
 
 def null_vector(X, nfun, rank1, n_keep1, n1, null_row, status):

@@ -411,6 +411,12 @@ class _LevelOps:
             return keep_rank, w_star, keep_h, int(nk_h[0]), (kr1_h, w1, n1)
         return None
 
+    def obj_set_sums(self, obj, mu, idx_cur, pos0, count, S, E):
+        """The objective's row of a level's set sums (SOBER/_rchq.py:138-146, :157-163) in one launch."""
+        out = torch.empty(S, dtype=torch.float64, device=self.device)
+        nat.obj_set_sums(obj, mu, idx_cur, pos0, count, S, E, out)
+        return out
+
     def level_update(self, idx_cur, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0):
         nat.level_update(idx_cur, 0, pos0, count, S, E, keep_rank, w_star, tot, n_keep, mu, idx_new, new_pos0)
 

@@ -335,6 +335,32 @@ __global__ __launch_bounds__(256) void k_final_commit(const int32_t* __restrict_
     }
 }
 
+// X_for_obj of SOBER/_rchq.py:138-146 plus the leftover addition to the last set (:157-163) for the list positions
+// [pos0, pos0 + count): out[s] = sum over the positions p = s (mod S) of obj[c] mu[c]  (c = idx[p - pos0]; leftovers p >= E S
+// are counted in set p mod S AND in set S - 1: quirk Q1, like the kernel rows).  One workgroup per set, a thread's elements
+// in element order, the 256 partial sums by a fixed tree: no atomics, run-to-run bit-equal.  (It was nine torch launches
+// per level of the acquisition-guided branch.)
+__global__ __launch_bounds__(256) void k_obj_set_sums(const double* __restrict__ obj, const double* __restrict__ mu,
+                                                      const int32_t* __restrict__ idx, int64_t pos0, int64_t count, int S,
+                                                      int64_t E, double* __restrict__ out) {
+    __shared__ double s_p[256];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int64_t ES = E * (int64_t)S, end = pos0 + count;
+    double acc = 0.0;
+    // first position >= pos0 that is congruent to s
+    int64_t p = pos0 + ((s - pos0 % S) % S + S) % S;
+    for (p += (int64_t)tid * S; p < end; p += (int64_t)256 * S) { const int c = idx[p - pos0]; acc += obj[c] * mu[c]; }
+    if (s == S - 1)                                          // the leftovers' second placement
+        for (int64_t q = max(pos0, ES) + tid; q < end; q += 256) { const int c = idx[q - pos0]; acc += obj[c] * mu[c]; }
+    s_p[tid] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) s_p[tid] += s_p[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) out[s] = s_p[0];
+}
+
 // left block of the projection: P[r][c] = Ut[r][c] * mean[c]  (c < M; ldp = M + n_obs)
 __global__ void k_projection_left(const double* __restrict__ Ut, int s, int M, const double* __restrict__ mean,
                                   double* __restrict__ P, int ldp) {
@@ -808,6 +834,14 @@ extern "C" int sober_final_commit(const int32_t* idx, int n, const int32_t* keep
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_final_scatter_guarded, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, idx, n, keep_rank,
                        w_star, n_keep, row_offset, mu, out_idx, out_w);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_obj_set_sums(const double* obj, const double* mu, const int32_t* idx, int64_t pos0, int64_t count, int S,
+                                  int64_t E, double* out, void* stream) {
+    if (!obj || !mu || !idx || !out || pos0 < 0 || count <= 0 || S <= 0 || E < 0) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_obj_set_sums, dim3((unsigned)S), dim3(256), 0, (hipStream_t)stream, obj, mu, idx, pos0, count, S, E, out);
     LAUNCH_CHECK();
     return 0;
 }

@@ -21,8 +21,11 @@ t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 BATCHES = [5, 8, 9, 16, 17, 24, 32, 33, 40, 56, 57, 64, 65, 80, 100, 112, 120, 150]
 
 
-def make_case(rng, tani=False, batches=BATCHES, n_factor=40):
-    """One random case (all the random draws happen here, in a fixed order: a seed names a sweep)."""
+def make_case(rng, tani=False, batches=BATCHES, n_factor=40, even_elements=0):
+    """One random case (all the random draws happen here, in a fixed order: a seed names a sweep).
+    even_elements = D > 0 (round 6, FUZZ_EVEN=D): the pool's size is rounded up to a multiple of 2^D x 2 b with at least two
+    elements per set left at level D -- a pool without leftovers whose levels 1 .. D are DERIVED from level 0's class sums
+    (csrc/level_class.hip) instead of evaluated; the random draws are the same as without the switch."""
     b = int(rng.choice(batches))
     d = int(rng.integers(2, 13))
     M = int(rng.integers(b + 8, max(b + 9, 4 * b)))
@@ -35,6 +38,9 @@ def make_case(rng, tani=False, batches=BATCHES, n_factor=40):
         M = int(rng.integers(b + 8, max(b + 9, 4 * b))); N = int(rng.integers(max(2 * b + 1, M + 1), n_factor * b + 50))
     mode = ["predictive_covariance", "kernel", "weighted_predictive_covariance"][int(rng.integers(0, 3))]
     use_obj = bool(rng.random() < 0.25) and b <= 100
+    if even_elements > 0:
+        q = (1 << even_elements) * 2 * b
+        N = max(2 * q, ((N + q - 1) // q) * q)
     X = rng.random((N, d)); Xo = rng.random((n_obs, d)); mu0 = rng.random(N); mu0 /= mu0.sum()
     if tani:
         pbit = float(rng.choice([0.03, 0.1, 0.3]))
@@ -146,9 +152,10 @@ if __name__ == "__main__":
     only = set(int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v)
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     tani = os.environ.get("FUZZ_KIND") == "tanimoto"
+    even = int(os.environ.get("FUZZ_EVEN", "0"))
     bad = 0
     for i in range(n_cases):
-        c = make_case(rng, tani)
+        c = make_case(rng, tani, even_elements=even)
         if only and i not in only:
             continue
         try:
