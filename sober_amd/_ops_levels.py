@@ -359,19 +359,22 @@ class _LevelOps:
         # on the device, so nothing is read back between the launches.  Sizes beyond that kernel keep the second step below.
         if self.obj_null_kernel and bool(nat.load().sober_null_vector_supported(n1f - 1)) and self.car_supported(N, n1f + 1):
             for _ in range(2):
-                kr1, w1, nk1_d, _mu = self.car_device(X, mu_in)
+                # every verdict of the level in ONE int32 block -- [keep_rank N | n_keep | first step's n_keep | status | first
+                # step's ranks N] -- so that one copy brings them to the host (they were five copies and their five launches)
+                flags = torch.empty(2 * N + 3, dtype=torch.int32, device=dev)
+                keep_rank, n_keep, nk1_d, status, kr1 = flags[:N], flags[N:N + 1], flags[N + 1:N + 2], flags[N + 2:N + 3], flags[N + 3:]
+                w1 = torch.empty(N, dtype=torch.float64, device=dev)
+                mu1 = torch.empty(N, dtype=torch.float64, device=dev)
+                nat.car_device(X, mu_in, kr1, w1, nk1_d, mu1, mode=min(self.car_mode, nat.CAR_SAFE))
                 null_row = torch.empty(N, dtype=torch.float64, device=dev)
-                status = torch.empty(1, dtype=torch.int32, device=dev)
                 nat.null_vector(X, n1f - 1, kr1, nk1_d, n1, null_row, status)
                 ocol = (X[:, n1f - 1] if obj_head is None else obj_head[:N]).contiguous()
-                keep_rank = torch.empty(N, dtype=torch.int32, device=dev)
                 w_star = torch.empty(N, dtype=torch.float64, device=dev)
-                n_keep = torch.empty(1, dtype=torch.int32, device=dev)
                 nat.second_elimination_rows(null_row, ocol, w1, kr1, nk1_d, n1, keep_rank, w_star, n_keep)
-                (kr1_h, nk1_h, keep_h, nk_h, st_h) = self.to_host(kr1, nk1_d, keep_rank, n_keep, status)
-                nk1 = int(nk1_h[0])
-                if nk1 == n1 and int(st_h[0]) == 0:
-                    return keep_rank, w_star, keep_h, int(nk_h[0]), (kr1_h, w1, n1)
+                (fl_h,) = self.to_host(flags)
+                keep_h, nk_h, nk1, st_h, kr1_h = fl_h[:N], int(fl_h[N]), int(fl_h[N + 1]), int(fl_h[N + 2]), fl_h[N + 3:]
+                if nk1 == n1 and st_h == 0:
+                    return keep_rank, w_star, keep_h, nk_h, (kr1_h, w1, n1)
                 if nk1 >= 0:
                     return None                              # irregular first step or a rank-deficient A2: the host route
                 self._car_downgrade(nat.CAR_SAFE if nat.car_safe_supported(N, n1f + 1) and self.car_mode == nat.CAR_DEFAULT
