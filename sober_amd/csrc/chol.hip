@@ -161,12 +161,12 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
     double* P = lds + 2 * CH_NB * LDP;       // (n - kb - nb) x LDPP panel
     double* const A_glob = A;
     const int ld_glob = ld;
-    if constexpr (SMALL) {                   // lower triangle -> LDS (odd row stride), and work there from here on
-        double* As = P + (size_t)(n > CH_NB ? n - CH_NB : 0) * LDPP;
-        for (int i = threadIdx.x >> 6; i < n; i += CH_T / 64)
-            for (int j = threadIdx.x & 63; j <= i; j += 64) As[i * (n + 1) + j] = A_glob[(size_t)i * ld_glob + j];
-        A = As;
-        ld = n + 1;
+    // SMALL: the lower triangle goes to LDS (odd row stride) and the work happens there.  Round 6: the first diagonal block is
+    // read straight from the caller's matrix and wave 0 factorises it WHILE waves 1-7 stage the triangle (the staging -- a
+    // dozen dependent global loads per wave, ~6 us -- used to stand in front of the first block's chain)
+    double* As = nullptr;
+    if constexpr (SMALL) {
+        As = P + (size_t)(n > CH_NB ? n - CH_NB : 0) * LDPP;
     }
     __shared__ int s_fail;
     __shared__ double s_minp;
@@ -184,6 +184,28 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
         if (lane == 0) s_dm[wave] = dl;
     }
     __syncthreads();
+    bool ahead0 = false;
+    if constexpr (SMALL) {
+        const int nb0 = min(CH_NB, n);
+#pragma unroll
+        for (int t = tid; t < CH_NB * CH_NB; t += CH_T) {
+            const int i = t >> 5, j = t & 31;
+            double v = (i < nb0 && j <= i) ? A_glob[(size_t)i * ld_glob + j] : 0.0;
+            if (i == j && i < nb0) v += shift;
+            D[i * LDP + j] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            ch_diag_block(D, Xs, s_dinv, &s_fail, &s_minp, nb0, 0, lane, xout);
+        } else {
+            for (int i = wave - 1; i < n; i += CH_T / 64 - 1)
+                for (int j = lane; j <= i; j += 64) As[i * (n + 1) + j] = A_glob[(size_t)i * ld_glob + j];
+        }
+        A = As;
+        ld = n + 1;
+        __syncthreads();
+        ahead0 = true;
+    }
 #ifdef CH_STAMPS
     long long st_t[5] = {0, 0, 0, 0, 0}, st_last = wall_clock64();
 #define CH_STAMP(K) { const long long now_ = wall_clock64(); st_t[K] += now_ - st_last; st_last = now_; }
@@ -191,7 +213,7 @@ __global__ __launch_bounds__(CH_T) void k_chol(double* __restrict__ A, int n, in
 #define CH_STAMP(K)
 #endif
 
-    bool ahead = false;                                   // this panel's diagonal block was factorised by the previous (d)
+    bool ahead = ahead0;                                  // this panel's diagonal block was factorised by the previous (d)
     for (int kb = 0; kb < n; kb += CH_NB) {
         const int nb = min(CH_NB, n - kb);
         const int nr = n - kb - nb;                       // rows below the diagonal block
