@@ -8,7 +8,7 @@ python3 - <<PY
 import csv, json
 rows = list(csv.DictReader(open('/tmp/ck/run_kernel_stats.csv')))
 # steps of the whole run (initialisation, cold, warm-up, timed, parity): one k_car_pivot_stream / k_mc_pivot per level, counted through the final-level kernel
-fin = [r for r in rows if 'k_final_scatter' in r['Name']]
+fin = [r for r in rows if 'k_abs_sym' in r['Name']]
 steps = float(fin[0]['Calls']) if fin else 14.0
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print("kernel time per step (all %d steps of the run averaged): %.3f ms" % (steps, tot / steps / 1e6))

@@ -322,19 +322,21 @@ __global__ __launch_bounds__(256) void k_augment_points(const double* __restrict
 // table): k_center_mean -- the column means of the Nystrom points, summed in a fixed order: "any shift works; this one keeps
 // |x~| small" -- and k_augment_all, one grid over the row table [X_nys; X_obs] (side 0) followed by the pool (side 1), each
 // read from where it lies.
-__global__ __launch_bounds__(256) void k_center_mean(const double* __restrict__ X, int64_t n, int d, int64_t ldx,
-                                                     double* __restrict__ center) {
-    __shared__ double s_p[8][32];
-    const int j = threadIdx.x & 31, g = threadIdx.x >> 5;         // coordinate, row group (8 groups)
+__global__ __launch_bounds__(1024) void k_center_mean(const double* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                      double* __restrict__ center) {
+    __shared__ double s_p[32][33];
+    const int j = threadIdx.x & 31, g = threadIdx.x >> 5;         // coordinate, row group (32 groups: a chain of n / 32 loads each)
     double acc = 0.0;
-    if (j < d)
-        for (int64_t i = g; i < n; i += 8) acc += X[i * ldx + j];
+    if (j < d) {
+#pragma unroll 4
+        for (int64_t i = g; i < n; i += 32) acc += X[i * ldx + j];
+    }
     s_p[g][j] = acc;
     __syncthreads();
     if (g == 0 && j < d) {
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t += s_p[q][j];
+        for (int q = 0; q < 32; ++q) t += s_p[q][j];
         center[j] = t / (double)n;
     }
 }
@@ -448,7 +450,7 @@ extern "C" int sober_augment_plan(const double* X_nys, int64_t M, int64_t ld_nys
         return SOBER_E_ARG;
     if ((ls_len != 1 && ls_len != d) || d > 30) return SOBER_E_ARG;
     if (da > 32) return SOBER_E_DIM;
-    hipLaunchKernelGGL(k_center_mean, dim3(1), dim3(256), 0, (hipStream_t)stream, X_nys, M, d, ld_nys, center);
+    hipLaunchKernelGGL(k_center_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, X_nys, M, d, ld_nys, center);
     LAUNCH_CHECK();
     const int64_t n_all = M + n_obs + N;
     hipLaunchKernelGGL(k_augment_all, dim3((unsigned)((n_all + 15) / 16)), dim3(256), 0, (hipStream_t)stream, X_nys, M, ld_nys,
