@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOBER_ABI_VERSION 6
+#define SOBER_ABI_VERSION 7
 
 /* kernel families: model.covar_module.forward behind SOBER/_gp.py:292-294 */
 #define SOBER_KIND_RBF       0   /* outputscale * exp(-0.5 * |x/l - y/l|^2)                      */
@@ -144,7 +144,8 @@ int sober_level_reduce_mfma(int kind, const double* rows, int n_rows, const doub
 /* chunk count the library would pick for a level of `count` positions in S sets.                 */
 /* The live list idx_story = arange(N)[mu != 0] (SOBER/_rchq.py:63-65) as an ordered stream compaction whose count
  * stays on the device (*count_out, int64): no synchronisation to size the output, unlike torch.nonzero.  idx_out holds
- * N entries; ws from sober_nonzero_ws_bytes(N).                                                                      */
+ * N entries; ws from sober_nonzero_ws_bytes(N), ZERO before its first use -- the call (one launch: ticket-ordered tiles with a
+ * decoupled look-back) leaves it zero again; one call at a time per workspace (ABI 7: the workspace used to be arbitrary).   */
 int64_t sober_nonzero_ws_bytes(int64_t N);
 int sober_nonzero_i32(const double* mu, int64_t N, int32_t* idx_out, int64_t* count_out, void* ws, int64_t ws_bytes,
                       void* stream);

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SOBER_HIP_LIB: a diagnostic build of the same library, e.g. the in-kernel-stamp build `make stamps`)
 LIB_PATH = os.environ.get("SOBER_HIP_LIB") or os.path.join(_HERE, "libsober_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 KIND_RBF, KIND_MATERN52, KIND_TANIMOTO = 0, 1, 2
 KIND_BY_NAME = {"rbf": KIND_RBF, "matern52": KIND_MATERN52, "tanimoto": KIND_TANIMOTO}

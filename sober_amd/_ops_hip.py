@@ -105,7 +105,7 @@ class HipOps(_PlanOps, _NystromOps, _LevelOps):
         key = ("nz", N)
         bufs = self._pin.get(key)
         if bufs is None:
-            ws = torch.empty(nat.nonzero_ws_bytes(N), dtype=torch.uint8, device=self.device)
+            ws = torch.zeros(nat.nonzero_ws_bytes(N), dtype=torch.uint8, device=self.device)   # (zero once: every call leaves it zero)
             bufs = self._pin[key] = (ws, torch.zeros(1, dtype=torch.int64, device=self.device),
                                      torch.zeros(1, dtype=torch.int64).pin_memory())
         ws, cnt, pin = bufs

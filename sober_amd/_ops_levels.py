@@ -63,7 +63,7 @@ class _LevelOps:
         w["h_flags_np"] = w["h_flags"].numpy()
         if job.variant in (nat.LEVEL_MFMA, nat.LEVEL_TANI) and self.queue_levels:
             # queued levels (csrc/level_exec.cpp): live positions per level, on the device and in pinned memory
-            w["dR"] = torch.zeros(nat.LEVEL_QUEUE + 1, dtype=torch.int64, device=dev)
+            w["dR"] = torch.empty(nat.LEVEL_QUEUE + 1, dtype=torch.int64, device=dev)   # (every entry a chain reads, the chain wrote)
             w["h_dR"] = torch.zeros(nat.LEVEL_QUEUE + 1, dtype=torch.int64, pin_memory=True)
             job.dR, job.h_dR = w["dR"].data_ptr(), w["h_dR"].data_ptr()
             if S % 2 == 0:

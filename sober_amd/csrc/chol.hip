@@ -10,6 +10,7 @@
 //    (applied twice for orthogonality to rounding); Q differs from LAPACK's only by column signs,
 //    which cancel in U = Q U_B.
 #include "common.hpp"
+#include "internal.hpp"
 
 namespace sober {
 
@@ -908,9 +909,17 @@ __global__ void k_jitter_ladder_auto(double* __restrict__ A, int n, int ld, cons
 }  // namespace sober
 
 namespace sober {
-__global__ void k_probe_mc_init(uint32_t* __restrict__ ws, int64_t n_words, int32_t* __restrict__ info, int n_info, int32_t value) {
+// (pre != NULL: a second area zeroed in the same launch, BEFORE info is written -- info may lie inside it: the Nystrom job's
+//  flag block)
+__global__ void k_probe_mc_init(uint32_t* __restrict__ ws, int64_t n_words, int32_t* __restrict__ info, int n_info, int32_t value,
+                                uint32_t* __restrict__ pre, int64_t n_pre) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_words) ws[t] = 0u;
+    if (pre != nullptr) {
+        // the words info[] occupies are written by the thread that sets them (no ordering between threads is needed)
+        const int64_t i0 = (uint32_t*)info - pre;
+        if (t < n_pre && !(t >= i0 && t < i0 + n_info)) pre[t] = 0u;
+    }
     if (t < n_info) info[t] = value;
 }
 }  // namespace sober
@@ -1152,14 +1161,29 @@ extern "C" int64_t sober_cholesky_probe_mc_ws_bytes(int n, int n_shifts) {
 // sober_cholesky_probe_piv with CM_G workgroups per rung (n_shifts <= 16).  info[r] = -7: the rung's workgroups lost each
 // other (bounded spins; e.g. a dispatcher that does not spread 256 workgroups evenly over the XCDs) -- no verdict
 // for that rung, the caller falls back to sober_cholesky_probe_piv or the host.
-extern "C" int sober_cholesky_probe_mc(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
-                                       double* work, int32_t* info, double* min_pivot, void* ws, int64_t ws_bytes,
-                                       void* stream) {
+int64_t sober::probe_mc_flag_bytes(int n_shifts) {
+    return ((int64_t)sober::CM_HDR + (int64_t)n_shifts * sober::CM_RUNG_BYTES + 255) / 256 * 256;
+}
+
+int sober::nystrom_flags_init(void* flags_block, int64_t flags_bytes, void* probe_ws, int64_t ws_flag_bytes, int32_t* info,
+                              int n_info, void* stream) {
+    if (!flags_block || !probe_ws || !info || flags_bytes <= 0 || (flags_bytes & 3) || ws_flag_bytes <= 0 || n_info <= 0)
+        return SOBER_E_ARG;
+    const int64_t n_pre = flags_bytes / 4, n_ws = ws_flag_bytes / 4;
+    const int64_t n = n_pre > n_ws ? n_pre : n_ws;
+    hipLaunchKernelGGL(sober::k_probe_mc_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (uint32_t*)probe_ws, n_ws, info, n_info, (int32_t)sober::CM_INFO_EXCHANGE, (uint32_t*)flags_block, n_pre);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int sober::cholesky_probe_mc(const double* src, int n, int ld_src, const double* shifts, int n_shifts, double* work,
+                             int32_t* info, double* min_pivot, void* ws, int64_t ws_bytes, bool init, void* stream) {
     if (!src || !shifts || !work || !info || !ws || n <= 0 || ld_src < n || n_shifts <= 0) return SOBER_E_ARG;
     if (n > sober::CH_MAXN || n_shifts > 16) return SOBER_E_DIM;
     const int64_t need = sober_cholesky_probe_mc_ws_bytes(n, n_shifts);
     if (ws_bytes < need || need > 0x7fffffff) return SOBER_E_WS;
-    const int64_t flags = ((int64_t)sober::CM_HDR + (int64_t)n_shifts * sober::CM_RUNG_BYTES + 255) / 256 * 256;
+    const int64_t flags = sober::probe_mc_flag_bytes(n_shifts);
     const int nr = n > sober::CH_NB ? n - sober::CH_NB : 0;
     const size_t bytes = ((size_t)2 * sober::CH_NB * (sober::CH_NB + 1) + (size_t)nr * sober::CH_LDPP) * sizeof(double);
     static std::atomic<unsigned long long> attr_set{0};             // (one bit per device)
@@ -1171,15 +1195,24 @@ extern "C" int sober_cholesky_probe_mc(const double* src, int n, int ld_src, con
     // the flag area zeroed, and every rung starts as "no verdict": a rung that finds no workgroups at all (a device
     // whose XCC ids do not run over 0..7, e.g. a partitioned one) must not read as info = 0 -- ONE launch (the two
     // memsets this replaces were four fill kernels and 35 us of a host-paced stream in front of the probe)
-    hipLaunchKernelGGL(sober::k_probe_mc_init, dim3((unsigned)((flags / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (uint32_t*)ws, (int64_t)(flags / 4), info, n_shifts, (int32_t)sober::CM_INFO_EXCHANGE);
-    LAUNCH_CHECK();
+    if (init) {
+        hipLaunchKernelGGL(sober::k_probe_mc_init, dim3((unsigned)((flags / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (uint32_t*)ws, (int64_t)(flags / 4), info, n_shifts, (int32_t)sober::CM_INFO_EXCHANGE,
+                           (uint32_t*)nullptr, (int64_t)0);
+        LAUNCH_CHECK();
+    }
     // one workgroup per CU (the LDS request sees to that), 32 per XCD: 16 of them find a seat (two rungs x CM_G)
     const size_t lds_bytes = bytes > (size_t)84 * 1024 ? bytes : (size_t)84 * 1024;
     hipLaunchKernelGGL(sober::k_chol_mc, dim3(256), dim3(sober::CH_T), lds_bytes, (hipStream_t)stream, work, n, n, info,
                        min_pivot, src, ld_src, shifts, n_shifts, (unsigned char*)ws, (unsigned)need, (unsigned)flags);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sober_cholesky_probe_mc(const double* src, int n, int ld_src, const double* shifts, int n_shifts,
+                                       double* work, int32_t* info, double* min_pivot, void* ws, int64_t ws_bytes,
+                                       void* stream) {
+    return sober::cholesky_probe_mc(src, n, ld_src, shifts, n_shifts, work, info, min_pivot, ws, ws_bytes, true, stream);
 }
 
 extern "C" int sober_abs_sym_dmax(const double* C, int n, int ld, double* out, int ldo, int32_t* flag, double* dmax,

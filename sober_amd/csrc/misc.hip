@@ -1,6 +1,7 @@
 // Small kernels around the hot path: point preparation, materialised kernel matrices, posterior
 // mean over a pool, partial-sum reduction, barycentres, the K7 weight/list update, weight scrubbing.
 #include "common.hpp"
+#include "internal.hpp"
 
 namespace sober {
 
@@ -14,6 +15,18 @@ __global__ void k_scale_points(const double* __restrict__ X, int64_t n, int d, i
     const int j = (int)(t % dt);
     double v = 0.0;
     if (j < d) v = X[i * ldx + j] / ls[ls_len == 1 ? 0 : j];
+    out[t] = v;
+}
+
+// ... of two point sets into one table (rows = [Xa; Xb] / lengthscale: the Nystrom points and the observations of a plan)
+__global__ void k_scale_points2(const double* __restrict__ Xa, int64_t na, int64_t lda, const double* __restrict__ Xb, int64_t nb,
+                                int64_t ldb, int d, const double* __restrict__ ls, int ls_len, double* __restrict__ out, int dt) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (na + nb) * dt) return;
+    const int64_t i = t / dt;
+    const int j = (int)(t % dt);
+    double v = 0.0;
+    if (j < d) v = (i < na ? Xa[i * lda + j] : Xb[(i - na) * ldb + j]) / ls[ls_len == 1 ? 0 : j];
     out[t] = v;
 }
 
@@ -370,6 +383,17 @@ __global__ void k_projection_left(const double* __restrict__ Ut, int s, int M, c
     P[(size_t)r * ldp + c] = mean ? Ut[t] * mean[c] : Ut[t];
 }
 
+// Ut = Q^T and the left block of P from Q itself (one launch for k_barycentres(tot = NULL) + k_projection_left)
+__global__ void k_transpose_projection(const double* __restrict__ Q, int s, int M, const double* __restrict__ mean,
+                                       double* __restrict__ Ut, double* __restrict__ P, int ldp) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= s * M) return;
+    const int r = t / M, c = t - r * M;
+    const double v = Q[(size_t)c * s + r];
+    Ut[t] = v;
+    if (P != nullptr) P[(size_t)r * ldp + c] = mean ? v * mean[c] : v;
+}
+
 __global__ void k_i64_to_i32(const int64_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) out[t] = (int32_t)in[t];
@@ -577,6 +601,24 @@ extern "C" int sober_scale_points(const double* X, int64_t n, int d, int64_t ldx
     if (ls_len != 1 && ls_len != d) return SOBER_E_ARG;
     hipLaunchKernelGGL(k_scale_points, dim3(nblk(n * dt, 256)), dim3(256), 0, (hipStream_t)stream, X,
                        n, d, ldx, lengthscale, ls_len, out, dt);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int sober::scale_points2(const double* Xa, int64_t na, int64_t lda, const double* Xb, int64_t nb, int64_t ldb, int d,
+                         const double* lengthscale, int ls_len, double* out, int dt, void* stream) {
+    if (!Xa || !Xb || !lengthscale || !out || na <= 0 || nb <= 0 || d <= 0 || dt < d || lda < d || ldb < d) return SOBER_E_ARG;
+    if (ls_len != 1 && ls_len != d) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_scale_points2, dim3(nblk((na + nb) * dt, 256)), dim3(256), 0, (hipStream_t)stream, Xa, na, lda, Xb, nb,
+                       ldb, d, lengthscale, ls_len, out, dt);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int sober::transpose_projection(const double* Q, int s, int M, const double* mean, double* Ut, double* P, int ldp, void* stream) {
+    if (!Q || !Ut || s <= 0 || M <= 0 || (P && ldp < M)) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_transpose_projection, dim3(nblk((int64_t)s * M, 256)), dim3(256), 0, (hipStream_t)stream, Q, s, M, mean,
+                       Ut, P, ldp);
     LAUNCH_CHECK();
     return 0;
 }

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/sober_hip.h"
+#include "internal.hpp"
 
 extern "C" int sober_nystrom_job_size(void) { return (int)sizeof(sober_nystrom_job); }
 
@@ -62,7 +63,12 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
     int32_t* flags = (int32_t*)(pivs_rf + n_orth2);
     int32_t* infos_rf = flags + 2 + n_r;
     if (phase != 2) {
-        NX_HIP(hipMemsetAsync(j->flags_block, 0, (size_t)j->flags_bytes, st));
+        // (the multi-workgroup probe's own set-up rides in the launch that zeroes the flag block)
+        const bool mc = M <= sober_chol_max_n() && j->probe_mc && j->probe_ws && (j->flags_bytes & 3) == 0 &&
+                        j->probe_ws_bytes >= sober_cholesky_probe_mc_ws_bytes(M, n_r);
+        if (mc) NX_TRY(sober::nystrom_flags_init(j->flags_block, j->flags_bytes, j->probe_ws, sober::probe_mc_flag_bytes(n_r),
+                                                 flags + 2, n_r, stream));
+        else NX_HIP(hipMemsetAsync(j->flags_block, 0, (size_t)j->flags_bytes, st));
         // ---- make_cov_psd: |cov| + symmetry flag + largest diagonal entry, every rung of the jitter ladder probed at once,
         //      the first positive definite rung (or the diagonal fallback) applied with the reference's own additions
         NX_TRY(sober_abs_sym_dmax(j->G, M, M, j->C, M, flags, pivots + n_r, stream));
@@ -72,8 +78,8 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
                                                 j->probe_ws_bytes, stream));
         } else if (j->probe_mc) {
             if (!j->probe_ws) return SOBER_E_ARG;
-            NX_TRY(sober_cholesky_probe_mc(j->C, M, M, j->shifts, n_r, j->chol_work, flags + 2, pivots, j->probe_ws,
-                                           j->probe_ws_bytes, stream));
+            NX_TRY(sober::cholesky_probe_mc(j->C, M, M, j->shifts, n_r, j->chol_work, flags + 2, pivots, j->probe_ws,
+                                            j->probe_ws_bytes, !mc, stream));
         } else {
             NX_TRY(sober_cholesky_probe_piv(j->C, M, M, j->shifts, n_r, j->chol_work, flags + 2, pivots, stream));
         }
@@ -96,16 +102,19 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
             slot += 2;
         }
     }
-    NX_TRY(sober_barycentres(Q, s, M, s, nullptr, j->Ut, stream));                                      // U = Q^T (s x M)
-    // ---- P = [U diag(mean), -(U diag(mean)) T]: the Nystrom test functions with the posterior correction folded in
-    if (j->P) NX_TRY(sober_projection(j->Ut, s, M, j->mean_nys, j->T, j->n_obs, j->P, stream));
+    // ---- U = Q^T (s x M) and P = [U diag(mean), -(U diag(mean)) T]: the Nystrom test functions with the posterior
+    //      correction folded in (the transposition and P's left block in one launch)
+    if (j->P && (j->T ? j->n_obs <= 0 : false)) return SOBER_E_ARG;
+    const int ldp = M + (j->T ? j->n_obs : 0);
+    NX_TRY(sober::transpose_projection(Q, s, M, j->mean_nys, j->Ut, j->P, ldp, stream));
+    if (j->P && j->T) NX_TRY(sober_dgemm(0, 0, s, j->n_obs, M, -1.0, j->P, ldp, j->T, j->n_obs, 0.0, j->P + M, ldp, stream));
     NX_HIP(hipMemcpyAsync(j->h_flags_block, j->flags_block, (size_t)sober_nystrom_flags_bytes(n_r, niter),
                           hipMemcpyDeviceToHost, st));
     return 0;
 }
 
 // ---- the ROW TABLE's side of a step's plan behind one call (continuous kernels) -----------------------------------------
-// rows = [X_nys; X_obs] / lengthscale (two launches into one table: no concatenated copy), Kall = k(rows, X_nys)
+// rows = [X_nys; X_obs] / lengthscale (one launch into one table: no concatenated copy), Kall = k(rows, X_nys)
 // ((M + n_obs) x M), W = S S^T (SOBER/_gp.py:277), T = K(X_nys, X_obs) W (M x n_obs; SOBER/_gp.py:293,295) and the Gram
 // matrix of SOBER/_rchq.py:35, G = K(X_nys, X_nys) - T K(X_obs, X_nys), in the reference's association order.  With
 // n_obs = 0 (mode "kernel"): rows and G = k(X_nys, X_nys) only.  The same launches the host language used to issue one
@@ -116,10 +125,12 @@ extern "C" int sober_plan_rows(int kind, const double* X_nys, int M, int64_t ld_
                                double* G, void* stream) {
     if (!X_nys || !lengthscale || !rows || !G || M <= 0 || d <= 0 || n_obs < 0 || dt < d) return SOBER_E_ARG;
     if (kind != SOBER_KIND_RBF && kind != SOBER_KIND_MATERN52) return SOBER_E_ARG;
-    NX_TRY(sober_scale_points(X_nys, M, d, ld_nys, lengthscale, ls_len, rows, dt, stream));
-    if (n_obs == 0) return sober_pairwise(kind, rows, nullptr, M, rows, nullptr, nullptr, M, dt, outputscale, G, M, stream);
+    if (n_obs == 0) {
+        NX_TRY(sober_scale_points(X_nys, M, d, ld_nys, lengthscale, ls_len, rows, dt, stream));
+        return sober_pairwise(kind, rows, nullptr, M, rows, nullptr, nullptr, M, dt, outputscale, G, M, stream);
+    }
     if (!X_obs || !S_cache || !Kall || !W || !T || ld_s < n_obs) return SOBER_E_ARG;
-    NX_TRY(sober_scale_points(X_obs, n_obs, d, ld_obs, lengthscale, ls_len, rows + (size_t)M * dt, dt, stream));
+    NX_TRY(sober::scale_points2(X_nys, M, ld_nys, X_obs, n_obs, ld_obs, d, lengthscale, ls_len, rows, dt, stream));
     NX_TRY(sober_pairwise(kind, rows, nullptr, (int64_t)M + n_obs, rows, nullptr, nullptr, M, dt, outputscale, Kall, M, stream));
     NX_TRY(sober_dgemm(0, 1, n_obs, n_obs, n_obs, 1.0, S_cache, ld_s, S_cache, ld_s, 0.0, W, n_obs, stream));
     const double* KXn = Kall + (size_t)M * M;                              // k(X_obs, X_nys), n_obs x M

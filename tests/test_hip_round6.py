@@ -300,3 +300,32 @@ def test_kmeans_with_an_empty_cluster_is_bounded_not_a_cliff(dev):
     _, cl_ref, _ = run(Xb, 0)                                           # (no workspace: the (x - c)^2 kernel, no screen)
     assert np.array_equal(cl_bad, cl_ref)
     assert t_bad < 8.0 * t_clean, (t_bad, t_clean)
+
+
+# --------------------------------------------------------------------------------------------- the live list in one launch
+@pytest.mark.parametrize("N,density", [(1, 1.0), (63, 0.5), (2048, 1.0), (2049, 0.0), (20000, 1.0), (20000, 0.37), (100003, 0.5),
+                                       (1 << 20, 0.9), (3_000_001, 0.01), (10_000_000, 1.0)])
+def test_live_list_kernel_is_torch_nonzero(N, density, dev):
+    """idx_story = arange(N)[mu != 0] (SOBER/_rchq.py:63-65) by csrc/compact.hip's single launch (ticket-ordered tiles,
+    decoupled look-back): the positions torch.nonzero returns, in its order, NaN counted as live; the workspace is left zero,
+    so the same one serves call after call (three calls here, the weights changed in between)."""
+    from sober_amd import _native as nat
+    g = torch.Generator().manual_seed(N)
+    mu = torch.rand(N, generator=g, dtype=torch.float64)
+    mu[torch.rand(N, generator=g) >= density] = 0.0
+    if N > 70:
+        mu[7], mu[N - 1], mu[64] = float("nan"), -0.0, -1e-300
+    mu = mu.to(dev)
+    ws = torch.zeros(nat.nonzero_ws_bytes(N), dtype=torch.uint8, device=dev)
+    cnt = torch.full((1,), -5, dtype=torch.int64, device=dev)
+    for rep in range(3):
+        out = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        nat.nonzero_i32(mu, out, cnt, ws)
+        ref = torch.nonzero(mu != 0).flatten()
+        assert int(cnt.item()) == ref.numel()
+        assert torch.equal(out[:ref.numel()].long(), ref)
+        assert bool((out[ref.numel():] == -1).all())
+        assert not bool(ws.any())
+        mu = torch.roll(mu, 977)
+        if N > 10:
+            mu[rep] = 0.0
