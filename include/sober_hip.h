@@ -225,12 +225,13 @@ int sober_car_pivot_host_fast(double* h_Phi, int N, int m, double* h_mu);
  * followed by the N-m pivots of :237-266.  Outputs: keep_rank[N] (rank of each surviving row in
  * idx_star, -1 if cancelled), w_star[0:n_keep], *n_keep, mu_out[N]; phi_out (N x (N-m), may be NULL)
  * receives the null-space basis before the pivots (test hook).
- * Two implementations behind the same entry point: one compute unit (csrc/car.hip: N <= 208, m <= 112,
+ * Three implementations behind the same entry point (the third, csrc/car_big.hip, for everything beyond the second: below):
+ * one compute unit (csrc/car.hip: N <= 208, m <= 112,
  * batch <= 100) and, beyond that, a multi-CU version (csrc/car_mc.hip: N <= 448, m <= 256, batch <= 224:
  * the matrix spread over ceil(N/52) workgroups with ONE cross-workgroup exchange per bidiagonalisation
  * step, the pivots as a streaming pipeline of 32 waves).  n_keep = -1 reports a give-up of the multi-CU
  * exchange (bounded spins).
- * sober_car_supported(N, m) = 1 iff one of the two covers the size.                               */
+ * sober_car_supported(N, m) = 1 iff one of the three covers the size (N <= 2048).                 */
 int sober_car_supported(int N, int m);
 int64_t sober_car_ws_bytes(int N, int m);
 int sober_car_device(const double* X, int ldx, int N, int m, const double* mu_in,
@@ -248,7 +249,8 @@ int sober_probe_rcp(const double* x, double* out, int64_t n, void* stream);
  *                      *n_keep = -1 and leaves keep_rank / w_star unwritten.
  *   SOBER_CAR_SAFE     only launches in which no workgroup depends on another one (stand-alone bidiagonalisation,
  *                      one wave per column of Phi, the one-workgroup pivot stream): cannot give up; exists for the
- *                      one-CU sizes (sober_car_safe_supported), SOBER_E_DIM beyond -- the host route is next.
+ *                      one-CU sizes and, through csrc/car_big.hip (a launch per dependency), for every size up to
+ *                      N = 2048 (sober_car_safe_supported); SOBER_E_DIM beyond -- the host route is next.
  * The level loops below redo a level that came back with n_keep = -1 in SOBER_CAR_SAFE mode, set job->car_mode so
  * that the rest of the run (and, through the caller, the following steps) stay there, and only return
  * SOBER_E_EXCHANGE when that mode does not cover the size.
@@ -293,6 +295,16 @@ int64_t sober_car_mc_ws_bytes(int N, int m);
 int sober_car_mc_device(const double* X, int ldx, int N, int m, const double* mu_in,
                         int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
                         double* phi_out, void* ws, int64_t ws_bytes, void* stream);
+/* The memory-resident implementation (csrc/car_big.hip, round 6): any N <= 2048 points with m < N test functions (batch <= 1023),
+ * the matrix in L2 / HBM, one launch per dependency -- k_big_right / k_big_left per bidiagonalisation step, one wave per null
+ * vector for Phi, the pivots in panels of eight (a launch per panel) -- so no workgroup ever waits for another one: it is what
+ * sober_car_device runs beyond batch 224 (host LAPACK + C++ pivots before) and the SOBER_CAR_SAFE rung of the multi-CU sizes.
+ * Same outputs as sober_car_device; never reports n_keep = -1.                                                        */
+int sober_car_big_supported(int N, int m);
+int64_t sober_car_big_ws_bytes(int N, int m);
+int sober_car_big_device(const double* X, int ldx, int N, int m, const double* mu_in,
+                         int32_t* keep_rank, double* w_star, int32_t* n_keep, double* mu_out,
+                         double* phi_out, void* ws, int64_t ws_bytes, void* stream);
 /* Self test of the gfx950 lane-swap reductions the multi-CU kernels rely on: in (64) ->
  * out[0:64] = sum over the wave, out[64:128] = sum over lanes l, l^16, l^32, l^48.                  */
 int sober_mc_selftest(const double* in, double* out, void* stream);
@@ -321,7 +333,7 @@ int sober_cholesky_inv(double* A, int n, int ld, double shift, int32_t* info, do
  * what decides whether one CholeskyQR pass is enough) -- on the device, no reduction kernels around the call. */
 int sober_cholesky_inv_ratio(double* A, int n, int ld, double shift, int32_t* info, double* min_pivot, double* xinv,
                              double* ratio_out, void* stream);
-/* Q[r, 0:q] = Y[r, 0:q] L^-T (L lower triangular q x q, q <= 256: the Q factor of Y when L L^T = Y^T Y), blocked
+/* Q[r, 0:q] = Y[r, 0:q] L^-T (L lower triangular q x q, q <= sober_chol_max_n(): the Q factor of Y when L L^T = Y^T Y), blocked
  * on the matrix cores with the inverted diagonal blocks of sober_cholesky_inv: block-to-block dependency only.                                                          */
 int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl, const double* Xinv,
                       double* Q, int ldq, void* stream);

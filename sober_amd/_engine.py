@@ -377,8 +377,8 @@ class RecombinationEngine:
         if car_on_host and not self.force_host_car and getattr(ops, "size_cliff", None) is not None \
                 and getattr(ops, "car_supported", None) is not None and not ops.car_supported(S, n_fun):
             ops.size_cliff("car", f"batch = {n + 1}: a Caratheodory step on 2 x batch = {S} points with {n_fun} test functions is beyond "
-                                  "the device kernels (one compute unit: batch <= 100, several: batch <= 224); every level's "
-                                  "step runs on host LAPACK + the C++ pivots instead -- several ms per level")
+                                  "the device kernels (registers of one compute unit: batch <= 100, of nine: batch <= 224, memory-resident: "
+                                  "2 x batch <= 2048); every level's step runs on host LAPACK + the C++ pivots instead -- seconds per level")
         if comm.world > 1:                                  # (no hook on that route)
             start_list()
         U = self.nystrom_basis(plan, n, overlap=head_once if comm.world == 1 else None, literal=car_on_host,

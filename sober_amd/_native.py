@@ -73,6 +73,9 @@ SIGNATURES = {
     "sober_car_mc_supported": (_i32, [_i32, _i32]),
     "sober_car_mc_ws_bytes": (_i64, [_i32, _i32]),
     "sober_car_mc_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sober_car_big_supported": (_i32, [_i32, _i32]),
+    "sober_car_big_ws_bytes": (_i64, [_i32, _i32]),
+    "sober_car_big_device": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sober_car_device_ex": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "sober_obj_set_sums": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp]),
     "sober_null_vector_supported": (_i32, [_i32]),
@@ -549,13 +552,14 @@ def probe_rcp(x):
     return out
 
 
-def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None, multi_cu=False, mode=CAR_DEFAULT):
+def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None, multi_cu=False, mode=CAR_DEFAULT, big=False):
     """X (N, m-1) float64 device (unit inner stride), mu_in (N).  multi_cu=True: the multi-CU kernels of
-    csrc/car_mc.hip whatever the size (test and timing hook; sober_car_device picks by size).  mode: CAR_DEFAULT or
-    CAR_SAFE (sober_car_device_ex: only launches that cannot give up; one-CU sizes)."""
+    csrc/car_mc.hip whatever the size; big=True: the memory-resident kernels of csrc/car_big.hip whatever the size (test and
+    timing hooks; sober_car_device picks by size).  mode: CAR_DEFAULT or CAR_SAFE (sober_car_device_ex: only launches that
+    cannot give up)."""
     N, n = X.shape
     lib = load()
-    if mode != CAR_DEFAULT and not multi_cu:
+    if mode != CAR_DEFAULT and not multi_cu and not big:
         nbytes = lib.sober_car_ws_bytes(N, n + 1)
         ws = _CAR_WS.get(X.device)
         if ws is None or ws.numel() * 8 < nbytes:
@@ -564,12 +568,14 @@ def car_device(X, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out=None, multi_
                                        w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
                                        ws.data_ptr(), nbytes, int(mode), _stream(X)), "sober_car_device_ex")
         return
-    nbytes = max(lib.sober_car_ws_bytes(N, n + 1), lib.sober_car_mc_ws_bytes(N, n + 1) if multi_cu else 0)
+    nbytes = max(lib.sober_car_ws_bytes(N, n + 1), lib.sober_car_mc_ws_bytes(N, n + 1) if multi_cu else 0,
+                 lib.sober_car_big_ws_bytes(N, n + 1) if big else 0)
     ws = _CAR_WS.get(X.device)
     if ws is None or ws.numel() * 8 < nbytes:
         ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=X.device)
         _CAR_WS[X.device] = ws
-    fn, name = (lib.sober_car_mc_device, "sober_car_mc_device") if multi_cu else (lib.sober_car_device, "sober_car_device")
+    fn, name = (lib.sober_car_big_device, "sober_car_big_device") if big else \
+        (lib.sober_car_mc_device, "sober_car_mc_device") if multi_cu else (lib.sober_car_device, "sober_car_device")
     _check(fn(X.data_ptr(), X.stride(0), N, n + 1, mu_in.data_ptr(), keep_rank.data_ptr(),
               w_star.data_ptr(), n_keep.data_ptr(), mu_out.data_ptr(), _ptr(phi_out),
               ws.data_ptr(), nbytes, _stream(X)), name)

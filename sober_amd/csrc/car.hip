@@ -22,8 +22,8 @@
 //                 through an LDS ring.
 //
 // Limits of these one-CU kernels: N <= 208, m <= 112, N - m <= 112 (batch <= 100).  sober_car_device hands larger
-// steps (N <= 448, m <= 256: batch <= 224) to the multi-CU kernels of car_mc.hip; beyond those the engine takes the
-// host LAPACK route (sober_car_pivot_host).
+// steps (N <= 448, m <= 256: batch <= 224) to the multi-CU kernels of car_mc.hip, steps beyond those (N <= 2048) to the
+// memory-resident kernels of car_big.hip; only then the engine takes the host LAPACK route (sober_car_pivot_host).
 #include "common.hpp"
 #include <atomic>
 #include <cstdlib>
@@ -1140,6 +1140,11 @@ extern "C" int64_t sober_car_mc_ws_bytes(int N, int m);
 extern "C" int sober_car_mc_device(const double* X, int ldx, int N, int m, const double* mu_in, int32_t* keep_rank,
                                    double* w_star, int32_t* n_keep, double* mu_out, double* phi_out, void* ws,
                                    int64_t ws_bytes, void* stream);
+extern "C" int sober_car_big_supported(int N, int m);
+extern "C" int64_t sober_car_big_ws_bytes(int N, int m);
+extern "C" int sober_car_big_device(const double* X, int ldx, int N, int m, const double* mu_in, int32_t* keep_rank,
+                                    double* w_star, int32_t* n_keep, double* mu_out, double* phi_out, void* ws,
+                                    int64_t ws_bytes, void* stream);
 
 // one compute unit (batch <= 100)
 static int car_one_cu(int N, int m) {
@@ -1147,7 +1152,7 @@ static int car_one_cu(int N, int m) {
 }
 
 extern "C" int sober_car_supported(int N, int m) {
-    return (car_one_cu(N, m) || sober_car_mc_supported(N, m)) ? 1 : 0;
+    return (car_one_cu(N, m) || sober_car_mc_supported(N, m) || sober_car_big_supported(N, m)) ? 1 : 0;
 }
 
 // scratch: reflectors (m x 208), tau (m, padded to 128), Phi (208 x 128)
@@ -1156,8 +1161,12 @@ extern "C" int64_t sober_car_ws_bytes(int N, int m) {
     const int64_t one = ((int64_t)m * sober::CAR_NS + 128 + (int64_t)sober::CAR_NS * sober::CAR_PC + 512) * (int64_t)sizeof(double)   // (+512: stamp block)
                         + sober::carf_bytes(0);                                       // + the fused launch's words
     if (car_one_cu(N, m)) return one;
-    const int64_t mc = sober_car_mc_ws_bytes(N, m);
-    return mc > one ? mc : one;
+    // (beyond one compute unit the memory-resident route of car_big.hip is the SOBER_CAR_SAFE rung of the multi-CU sizes too)
+    int64_t need = sober_car_big_supported(N, m) ? sober_car_big_ws_bytes(N, m) : 0;
+    if (need < one) need = one;
+    // (some N' <= N may be a multi-CU size although N is not: the final direct level of a batch-250 run has 251 .. 448 points)
+    if (sober_car_mc_supported(N < m + 1 ? N : m + 1, m)) { const int64_t mc = sober_car_mc_ws_bytes(N, m); if (mc > need) need = mc; }
+    return need;
 }
 
 // the per-device function attribute of the streaming pivot kernel (dynamic LDS beyond 64 KB)
@@ -1177,7 +1186,7 @@ static int car_pivot_attr(size_t sp_bytes) {
 // n_keep = -1 -- so that the recovery of the callers can be exercised (tests/test_hip_parity.py).
 extern "C" int sober_car_giveup_forced(void) { return sober::switches().car_force_giveup ? 1 : 0; }
 
-extern "C" int sober_car_safe_supported(int N, int m) { return car_one_cu(N, m); }
+extern "C" int sober_car_safe_supported(int N, int m) { return (car_one_cu(N, m) || sober_car_big_supported(N, m)) ? 1 : 0; }
 
 // the bidiagonalisation's instantiation by size: row / column slots in use (m <= 16 MS_, N <= 16 CQ_)
 #define CAR_BY_SIZE(m_, N_, LAUNCH)                                                                    \
@@ -1217,9 +1226,13 @@ extern "C" int sober_car_device_ex(const double* X, int ldx, int N, int m, const
                                    double* phi_out, void* ws, int64_t ws_bytes, int mode, void* stream) {
     if (!X || !mu_in || !keep_rank || !w_star || !n_keep || !mu_out || !ws || ldx < m - 1) return SOBER_E_ARG;
     if (mode != SOBER_CAR_DEFAULT && mode != SOBER_CAR_SAFE) return SOBER_E_ARG;
-    if (!car_one_cu(N, m)) {                                // beyond one compute unit: car_mc.hip
-        if (mode == SOBER_CAR_SAFE) return SOBER_E_DIM;     // (every launch there depends on partner workgroups)
-        return sober_car_mc_device(X, ldx, N, m, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out, ws, ws_bytes, stream);
+    if (!car_one_cu(N, m)) {
+        // beyond one compute unit: car_mc.hip (matrix in the registers of nine compute units, batch <= 224; every launch there
+        // depends on partner workgroups), else -- and in SOBER_CAR_SAFE mode -- car_big.hip (matrix in memory, a launch per
+        // dependency: nothing to give up)
+        if (mode == SOBER_CAR_DEFAULT && sober_car_mc_supported(N, m))
+            return sober_car_mc_device(X, ldx, N, m, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out, ws, ws_bytes, stream);
+        return sober_car_big_device(X, ldx, N, m, mu_in, keep_rank, w_star, n_keep, mu_out, phi_out, ws, ws_bytes, stream);
     }
     if (ws_bytes < sober_car_ws_bytes(N, m)) return SOBER_E_WS;
     hipStream_t st = (hipStream_t)stream;

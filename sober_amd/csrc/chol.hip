@@ -1114,13 +1114,13 @@ extern "C" int sober_cholesky(double* A, int n, int ld, double shift, int32_t* i
 
 extern "C" int sober_trsm_blocks(const double* Y, int64_t m, int q, int ldy, const double* L, int ldl,
                                  const double* Xinv, double* Q, int ldq, void* stream) {
-    if (!Y || !L || !Xinv || !Q || m <= 0 || q <= 0 || q > 256 || ldy < q || ldl < q || ldq < q) return SOBER_E_ARG;
+    if (!Y || !L || !Xinv || !Q || m <= 0 || q <= 0 || q > sober::CH_MAXN || ldy < q || ldl < q || ldq < q) return SOBER_E_ARG;
     const int qpad = ((q + 31) / 32) * 32;
     const size_t bytes = (size_t)sober::TB_WAVES * (16 * (qpad + 4) + 16 * 36) * sizeof(double);
     static std::atomic<unsigned long long> attr_set{0};             // (one bit per device)
     if (sober_attr_needed(attr_set)) {
         HIP_TRY(hipFuncSetAttribute((const void*)sober::k_trsm_blocks, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    120 * 1024));
+                                    160 * 1024 - 512));          // (q = 536: 2 x 74.7 KB)
         sober_attr_done(attr_set);
     }
     const int64_t row_blocks = (m + 15) / 16;

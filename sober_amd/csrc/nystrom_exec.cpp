@@ -52,7 +52,7 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
         !j->xinv || !j->flags_block || !j->h_flags_block || !j->Ut)
         return SOBER_E_ARG;
     const int M = j->M, s = j->s, n_r = j->n_rungs, niter = j->niter;
-    if (M <= 0 || s <= 0 || s >= M || s > 256 || n_r <= 0 || n_r > 64 || niter < 0 || niter > 8) return SOBER_E_ARG;
+    if (M <= 0 || s <= 0 || s >= M || s > sober_chol_max_n() || n_r <= 0 || n_r > 64 || niter < 0 || niter > 8) return SOBER_E_ARG;
     if (M > sober_nystrom_max_n()) return SOBER_E_DIM;
     if (j->flags_bytes < sober_nystrom_flags_bytes(n_r, niter)) return SOBER_E_WS;
     hipStream_t st = (hipStream_t)stream;

@@ -329,3 +329,73 @@ def test_live_list_kernel_is_torch_nonzero(N, density, dev):
         mu = torch.roll(mu, 977)
         if N > 10:
             mu[rep] = 0.0
+
+
+# ------------------------------------------------------------------ the memory-resident Caratheodory route (csrc/car_big.hip)
+def _car_big_case(N, m, seed, dev, decay=0.0, zero_every=0):
+    from sober_amd import _native as nat
+    from tests.test_car_algorithm import nullspace_gebrd
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, m - 1)) * np.exp(-decay * np.arange(m - 1))[None, :]
+    mu = rng.random(N) + 0.05
+    if zero_every:
+        mu[::zero_every] = 0.0
+    mu /= mu.sum()
+    Xd, mud = _t(X).to(dev), _t(mu).to(dev)
+    kr = torch.empty(N, dtype=torch.int32, device=dev)
+    ws = torch.zeros(N, dtype=torch.float64, device=dev)
+    nk = torch.empty(1, dtype=torch.int32, device=dev)
+    mo = torch.empty(N, dtype=torch.float64, device=dev)
+    phi = torch.empty(N, N - m, dtype=torch.float64, device=dev)
+    nat.car_device(Xd, mud, kr, ws, nk, mo, phi_out=phi, big=True)
+    torch.cuda.synchronize()
+    A = np.vstack([np.ones(N), X.T])
+    return X, mu, kr.cpu().numpy(), ws.cpu().numpy(), int(nk.item()), mo.cpu().numpy(), phi.cpu().numpy(), nullspace_gebrd(A), A
+
+
+@pytest.mark.parametrize("N,m,decay,zero_every", [(64, 20, 0.0, 0), (13, 12, 0.0, 0), (200, 101, 0.03, 0), (400, 201, 0.0, 7), (500, 251, 0.01, 0),
+                                                  (600, 301, 0.0, 0), (1024, 513, 0.005, 0), (1100, 540, 0.0, 5), (700, 120, 0.0, 0),
+                                                  (2048, 1025, 0.002, 0)])
+def test_car_big_vs_gebrd_restatement(N, m, decay, zero_every, dev):
+    """The memory-resident Caratheodory kernels (csrc/car_big.hip: a launch per dependency, any N <= 2048): null-space basis = the
+    dgebd2 reflectors' (numpy restatement, itself pinned to LAPACK's SVD on the reference's inputs in tests/test_car_algorithm.py)
+    and = torch.linalg.svd's Vh[m:] (SOBER/_rchq.py:231-234); the pivots of :237-266 select the restatement's sets with the same
+    weights (zero masses: alpha = 0 pivots and first-index ties included); the result is a recombination."""
+    from tests.test_car_algorithm import pivots
+    X, mu, kr, ws, nk, mo, phi, Phi_np, A = _car_big_case(N, m, 3000 + N + m, dev, decay, zero_every)
+    np.testing.assert_allclose(phi, Phi_np, rtol=0, atol=5e-12)
+    if N <= 1100:
+        Vh = torch.linalg.svd(torch.from_numpy(A))[2].numpy()
+        np.testing.assert_allclose(phi, Vh[m:].T, rtol=0, atol=1e-9)
+    w_np, idx_np = pivots(Phi_np, mu)
+    idx = np.flatnonzero(kr >= 0)
+    assert np.array_equal(idx, idx_np)
+    assert np.array_equal(kr[idx], np.arange(nk))
+    np.testing.assert_allclose(ws[:nk], w_np, rtol=1e-8)
+    assert np.array_equal(np.flatnonzero(mo > 0), idx)
+    assert (ws[:nk] > 0).all() and nk <= m
+    np.testing.assert_allclose(ws[:nk].sum(), mu.sum(), rtol=1e-12)
+    np.testing.assert_allclose(ws[:nk] @ X[idx], mu @ X, rtol=0, atol=1e-11)
+
+
+def test_car_big_equals_the_register_resident_routes_on_reference_levels(dev):
+    """The same step through all three device implementations on the reference's own level inputs (batch 100): same sets,
+    weights to rounding -- and bit-equal from run to run (fixed reduction trees, no atomics)."""
+    from sober_amd import _native as nat
+    z = np.load(os.path.join(GOLD, "recomb_matern_medium.npz"))
+    for i in range(int(z["n_levels"])):
+        X, mu = _t(z[f"L{i}_X_tmp"]).to(dev), _t(z[f"L{i}_tot_weights"]).to(dev)
+        N = X.shape[0]
+        outs = []
+        for kw in (dict(), dict(multi_cu=True), dict(big=True), dict(big=True)):
+            kr = torch.empty(N, dtype=torch.int32, device=dev)
+            ws = torch.zeros(N, dtype=torch.float64, device=dev)
+            nk = torch.empty(1, dtype=torch.int32, device=dev)
+            mo = torch.empty(N, dtype=torch.float64, device=dev)
+            nat.car_device(X, mu, kr, ws, nk, mo, **kw)
+            outs.append((kr.cpu().numpy(), ws.cpu().numpy(), int(nk.item())))
+        (k1, w1, n1), (k2, w2, n2), (k3, w3, n3), (k4, w4, n4) = outs
+        assert n1 == n3 and np.array_equal(k1, k3) and np.array_equal(k2, k3), i
+        np.testing.assert_allclose(w3[:n3], w1[:n1], rtol=1e-10)
+        assert np.array_equal(k3, k4) and np.array_equal(w3, w4), i
+        assert np.array_equal(np.flatnonzero(k3 >= 0), z[f"L{i}_idx_star"])
