@@ -49,8 +49,9 @@ class HipOps(_PlanOps, _NystromOps, _LevelOps):
         # after a rung's workgroups lost each other)
         self._probe_mc = torch.cuda.get_device_properties(self.device).multi_processor_count >= 256   # (8 XCDs x 32 CUs: unpartitioned)
         # the rung of the Caratheodory step on this device: CAR_DEFAULT (launches whose workgroups wait for partner
-        # workgroups: fused / multi-CU), CAR_SAFE after one of them gave up (single-workgroup kernels, batch <= 100),
-        # CAR_HOST beyond those (host LAPACK + C++ pivots) -- SOBER/_rchq.py:224-270 never fails, so neither may this
+        # workgroups: fused / multi-CU), CAR_SAFE after one of them gave up (launches without such waits: the single-workgroup
+        # kernels up to batch 100, csrc/car_big.hip's launch per dependency beyond), CAR_HOST beyond the device kernels
+        # (host LAPACK + C++ pivots) -- SOBER/_rchq.py:224-270 never fails, so neither may this
         self.car_mode = nat.CAR_DEFAULT
 
     def size_cliff(self, which: str, message: str):

@@ -93,7 +93,8 @@ class _LevelOps:
             self.car_mode = mode
             warnings.warn("sober_amd: a multi-workgroup Caratheodory launch gave up waiting for its partner workgroups "
                           f"({why}); this and the following steps use "
-                          + ("the single-workgroup kernels" if mode == nat.CAR_SAFE else "the host LAPACK route")
+                          + ("the kernels without such waits (one workgroup, or a launch per dependency beyond batch 100)" if mode == nat.CAR_SAFE
+                             else "the host LAPACK route")
                           + " for that step -- same result, slower")
 
     def level_moments(self, p: Plan, idx, pos0, count, S, E, mu, phase: int = 0, n: int = None):

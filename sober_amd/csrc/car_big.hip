@@ -17,7 +17,7 @@
 //                 A -= tau u z^T for its own columns.  The two launches of a step are its two global dependencies
 //                 (row i must be complete before G(i), column i before H(i)): 2 m - 2 launches in all.
 //   k_big_phi     Phi = P [0; I]: a wave per null vector, the vector in registers, the m reflectors applied backwards.
-//   k_big_pivot   the pivots in PANELS of eight null vectors, a workgroup (1024 threads, thread <-> point) per eight columns of
+//   k_big_pivot   the pivots in PANELS of eight null vectors, a workgroup (256 threads, a thread <-> up to eight points) per eight columns of
 //                 Phi: every workgroup applies the previous panel's eight eliminations to its columns (the pivot rows'
 //                 entries go round the workgroup through LDS, one barrier per pivot); workgroup 0, whose columns ARE the next
 //                 panel, then runs that panel's eight ratio tests and in-panel eliminations and files columns, pivot indices
@@ -34,7 +34,9 @@ namespace big {
 
 constexpr int MAXN = 2048;
 constexpr int PB = 8;                 // null vectors per pivot panel
-constexpr int PT = 1024;              // threads of a pivot workgroup
+constexpr int PT = 256;               // threads of a pivot workgroup: ONE wave per SIMD (sixteen waves spent 3.4 us per pivot
+                                      // on instruction issue alone: every wave runs the reductions and the barriers' code)
+constexpr int FT = 1024;              // threads of the finishing workgroup
 
 struct PanelRec {                     // what a panel leaves for the next launch
     int piv[PB];
@@ -284,6 +286,8 @@ __global__ __launch_bounds__(PT) void k_big_pivot(double* __restrict__ PhiT, int
     __shared__ double s_ba[PT / 64];
     __shared__ int s_br[PT / 64];
     __shared__ double s_pp, s_mu;
+    __shared__ int s_opiv[PB];
+    __shared__ double s_orpp[PB];
     if (flags->stop) return;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int jb = j0 + blockIdx.x * PB;                     // this workgroup's columns jb .. jb + nc - 1
@@ -295,28 +299,43 @@ __global__ __launch_bounds__(PT) void k_big_pivot(double* __restrict__ PhiT, int
 #pragma unroll
         for (int c = 0; c < PB; ++c) phi[q][c] = (r < N && c < nc) ? PhiT[(size_t)(jb + c) * ld + r] : 0.0;
     }
-    // ---- the previous panel's eliminations on these columns
+    // ---- the previous panel's eliminations on these columns (its record and its columns asked for at once: a memory round
+    //      trip per pivot inside the loop cost 1.5 us each)
     if (j0 > 0) {
-        const int nv = prev->nvalid;
-        for (int s = 0; s < nv; ++s) {
-            const int piv = prev->piv[s];
-            const double rpp = prev->rpp[s];
-            const double* colp = PhiT + (size_t)(j0 - PB + s) * ld;
+        __shared__ int s_piv[PB];
+        __shared__ double s_rpp[PB];
+        __shared__ int s_nv;
+        if (t < PB) { s_piv[t] = prev->piv[t]; s_rpp[t] = prev->rpp[t]; }
+        if (t == 0) s_nv = prev->nvalid;
+        double cs[RPT][PB];
 #pragma unroll
-            for (int q = 0; q < RPT; ++q)
-                if (t + PT * q == piv) {
+        for (int q = 0; q < RPT; ++q) {
+            const int r = t + PT * q;
 #pragma unroll
-                    for (int c = 0; c < PB; ++c) s_pr[s][c] = phi[q][c];
-                }
-            __syncthreads();
+            for (int sx = 0; sx < PB; ++sx) cs[q][sx] = r < N ? PhiT[(size_t)(j0 - PB + sx) * ld + r] : 0.0;
+        }
+        __syncthreads();
+        const int nv = s_nv;
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int r = t + PT * q;
-                const double cs = r < N ? colp[r] : 0.0;
+        for (int sx = 0; sx < PB; ++sx) {
+            if (sx < nv) {
+                const int piv = s_piv[sx];
+                const double rpp = s_rpp[sx];
 #pragma unroll
-                for (int c = 0; c < PB; ++c) {
-                    const double f = s_pr[s][c] * rpp;
-                    phi[q][c] = (r == piv) ? 0.0 : fma(-cs, f, phi[q][c]);
+                for (int q = 0; q < RPT; ++q)
+                    if (t + PT * q == piv) {
+#pragma unroll
+                        for (int c = 0; c < PB; ++c) s_pr[sx][c] = phi[q][c];
+                    }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const int r = t + PT * q;
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) {
+                        const double f = s_pr[sx][c] * rpp;
+                        phi[q][c] = (r == piv) ? 0.0 : fma(-cs[q][sx], f, phi[q][c]);
+                    }
                 }
             }
         }
@@ -386,7 +405,6 @@ __global__ __launch_bounds__(PT) void k_big_pivot(double* __restrict__ PhiT, int
                 const double pp = s_pp;
                 const double alpha = s_mu / pp;              // = alpha[idx] (:246), a NaN included
                 const double rpp = 1.0 / pp;
-                double* colg = PhiT + (size_t)(jb + s) * ld;
 #pragma unroll
                 for (int q = 0; q < RPT; ++q) {
                     const int r = t + PT * q;
@@ -395,28 +413,37 @@ __global__ __launch_bounds__(PT) void k_big_pivot(double* __restrict__ PhiT, int
 #pragma unroll
                     for (int c = 0; c < PB; ++c)
                         if (c > s) phi[q][c] = (r == piv) ? 0.0 : fma(-cs, s_pr[s][c] * rpp, phi[q][c]);      // :260-266
-                    if (r < N) colg[r] = cs;                 // the pivot column as the other workgroups will apply it
                 }
-                if (t == 0) { cur->piv[s] = piv; cur->rpp[s] = rpp; }
+                if (t == 0) { s_opiv[s] = piv; s_orpp[s] = rpp; }
                 nvalid = s + 1;
             }
         }
     }
+    // (memory is written once, here: a store in front of a barrier makes the barrier wait for its acknowledgement, 1.5 us per
+    //  pivot when the pivot columns were filed as they were found)
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
         const int r = t + PT * q;
-        if (r < N) mu[r] = mr[q];
+        if (r < N) {
+            mu[r] = mr[q];
+            // the pivot columns as the other workgroups will apply them: column s has not changed since its own step
+#pragma unroll
+            for (int c = 0; c < PB; ++c)
+                if (c < nvalid) PhiT[(size_t)(jb + c) * ld + r] = phi[q][c];
+        }
     }
+    if (t < PB && t < nvalid) { cur->piv[t] = s_opiv[t]; cur->rpp[t] = s_orpp[t]; }
     if (t == 0) cur->nvalid = nvalid;
 }
 
 // w_star = mu[mu > 0], idx_star = arange(N)[mu > 0] (:268-269) as ranks
-__global__ __launch_bounds__(PT) void k_big_finish(const double* __restrict__ mu, int N, int32_t* __restrict__ keep_rank,
+__global__ __launch_bounds__(FT) void k_big_finish(const double* __restrict__ mu, int N, int32_t* __restrict__ keep_rank,
                                                    double* __restrict__ w_star, int32_t* __restrict__ n_keep, double* __restrict__ mu_out) {
-    __shared__ int s_cnt[PT / 64];
+    __shared__ int s_cnt[FT / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     int base = 0;
-    for (int r0 = 0; r0 < N; r0 += PT) {
+    for (int r0 = 0; r0 < N; r0 += FT) {
         const int r = r0 + t;
         const double v = r < N ? mu[r] : 0.0;
         const bool keep = r < N && v > 0.0;
@@ -426,7 +453,7 @@ __global__ __launch_bounds__(PT) void k_big_finish(const double* __restrict__ mu
         __syncthreads();
         int before = 0, total = 0;
 #pragma unroll
-        for (int k = 0; k < PT / 64; ++k) {
+        for (int k = 0; k < FT / 64; ++k) {
             if (k < w) before += s_cnt[k];
             total += s_cnt[k];
         }
@@ -503,13 +530,13 @@ extern "C" int sober_car_big_device(const double* X, int ldx, int N, int m, cons
     int p = 0;
     for (int j0 = 0; j0 < K; j0 += PB, ++p) {
         const int groups = (K - j0 + PB - 1) / PB;
-        if (N <= PT)
-            hipLaunchKernelGGL(k_big_pivot<1>, dim3(groups), dim3(PT), 0, st, PhiT, ld, N, K, j0, rec + ((p + 1) & 1), rec + (p & 1), mu_in, mu, flags);
-        else
-            hipLaunchKernelGGL(k_big_pivot<2>, dim3(groups), dim3(PT), 0, st, PhiT, ld, N, K, j0, rec + ((p + 1) & 1), rec + (p & 1), mu_in, mu, flags);
+        PanelRec *pr = rec + ((p + 1) & 1), *cr = rec + (p & 1);
+        if (N <= 2 * PT) hipLaunchKernelGGL(k_big_pivot<2>, dim3(groups), dim3(PT), 0, st, PhiT, ld, N, K, j0, pr, cr, mu_in, mu, flags);
+        else if (N <= 4 * PT) hipLaunchKernelGGL(k_big_pivot<4>, dim3(groups), dim3(PT), 0, st, PhiT, ld, N, K, j0, pr, cr, mu_in, mu, flags);
+        else hipLaunchKernelGGL(k_big_pivot<8>, dim3(groups), dim3(PT), 0, st, PhiT, ld, N, K, j0, pr, cr, mu_in, mu, flags);
     }
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_finish, dim3(1), dim3(PT), 0, st, mu, N, keep_rank, w_star, n_keep, mu_out);
+    hipLaunchKernelGGL(k_big_finish, dim3(1), dim3(FT), 0, st, mu, N, keep_rank, w_star, n_keep, mu_out);
     LAUNCH_CHECK();
     return 0;
 }

@@ -813,9 +813,10 @@ def test_giveup_is_recovered_on_the_single_workgroup_kernels(name, dev, forced_g
     assert not any("gave up" in str(r.message) for r in rec)
 
 
-def test_giveup_beyond_one_cu_goes_to_the_host_route(dev, forced_giveup):
+def test_giveup_beyond_one_cu_goes_to_the_memory_resident_kernels(dev, forced_giveup):
     """batch 120 (S = 240: the multi-CU kernels, every one of which depends on partner workgroups): the levels and the
-    final level go to host LAPACK + the C++ pivots; same indices as the undisturbed run, weights to 1e-8."""
+    final level are redone by csrc/car_big.hip (a launch per dependency: the SOBER_CAR_SAFE rung beyond one compute unit since
+    round 6; host LAPACK + the C++ pivots before); same indices as the undisturbed run, weights to 1e-8."""
     from sober_amd import _native as nat
     from sober_amd._ops_hip import HipOps
     from tests.golden.synth import synth, build_spec
@@ -835,7 +836,7 @@ def test_giveup_beyond_one_cu_goes_to_the_host_route(dev, forced_giveup):
         return idx.cpu().numpy(), w.cpu().numpy(), mu.cpu().numpy()
     t_forced = {}
     i1, w1, m1 = run(forced_giveup, t_forced)
-    assert forced_giveup.car_mode == nat.CAR_HOST and "car_host" in t_forced
+    assert forced_giveup.car_mode == nat.CAR_SAFE and "car_host" not in t_forced
     os.environ.pop("SOBER_CAR_FORCE_GIVEUP")
     _reload_switches()
     t_plain = {}
@@ -848,7 +849,8 @@ def test_giveup_beyond_one_cu_goes_to_the_host_route(dev, forced_giveup):
 
 def test_car_safe_mode_equals_default_mode(dev):
     """sober_car_device_ex: SOBER_CAR_SAFE (stand-alone launches) against SOBER_CAR_DEFAULT (fused launch) on a
-    reference level input -- same sets, weights to 1e-12; SOBER_E_DIM beyond the one-CU sizes."""
+    reference level input -- same sets, weights to 1e-12; beyond the one-CU sizes the safe rung is csrc/car_big.hip (round 6:
+    SOBER_E_DIM before), SOBER_E_DIM only beyond N = 2048."""
     from sober_amd import _native as nat
     z = np.load(os.path.join(GOLD, "recomb_matern_medium.npz"))
     X, mu = _t(z["L0_X_tmp"]).to(dev), _t(z["L0_tot_weights"]).to(dev)
@@ -861,12 +863,23 @@ def test_car_safe_mode_equals_default_mode(dev):
         out.append((kr.cpu().numpy(), ws.cpu().numpy(), int(nk.item())))
     assert out[0][2] == out[1][2] > 0 and np.array_equal(out[0][0], out[1][0])
     np.testing.assert_allclose(out[1][1][:out[1][2]], out[0][1][:out[0][2]], rtol=1e-12)
-    assert not nat.car_safe_supported(400, 200) and nat.car_supported(400, 200)
-    Xb = torch.randn(400, 199, dtype=torch.float64, device=dev)
+    assert nat.car_safe_supported(400, 200) and nat.car_supported(400, 200) and not nat.car_safe_supported(2049, 200)
+    g = torch.Generator().manual_seed(3)
+    Xb = torch.randn(400, 199, dtype=torch.float64, generator=g).to(dev)
+    mub = (torch.rand(400, dtype=torch.float64, generator=g) + 0.05).to(dev)
+    outb = []
+    for mode in (nat.CAR_DEFAULT, nat.CAR_SAFE):             # (the multi-CU kernels, then the memory-resident ones)
+        kr = torch.empty(400, dtype=torch.int32, device=dev); ws = torch.empty(400, dtype=torch.float64, device=dev)
+        nk = torch.empty(1, dtype=torch.int32, device=dev); mo = torch.empty(400, dtype=torch.float64, device=dev)
+        nat.car_device(Xb, mub, kr, ws, nk, mo, mode=mode)
+        outb.append((kr.cpu().numpy(), ws.cpu().numpy(), int(nk.item())))
+    assert outb[0][2] == outb[1][2] > 0 and np.array_equal(outb[0][0], outb[1][0])
+    np.testing.assert_allclose(outb[1][1][:outb[1][2]], outb[0][1][:outb[0][2]], rtol=1e-9)
+    Xc = torch.randn(2049, 199, dtype=torch.float64, device=dev)
     with pytest.raises(nat.SoberHipError, match="dimension"):
-        nat.car_device(Xb, torch.rand(400, dtype=torch.float64, device=dev), torch.empty(400, dtype=torch.int32, device=dev),
-                       torch.empty(400, dtype=torch.float64, device=dev), torch.empty(1, dtype=torch.int32, device=dev),
-                       torch.empty(400, dtype=torch.float64, device=dev), mode=nat.CAR_SAFE)
+        nat.car_device(Xc, torch.rand(2049, dtype=torch.float64, device=dev), torch.empty(2049, dtype=torch.int32, device=dev),
+                       torch.empty(2049, dtype=torch.float64, device=dev), torch.empty(1, dtype=torch.int32, device=dev),
+                       torch.empty(2049, dtype=torch.float64, device=dev), mode=nat.CAR_SAFE)
 
 
 def test_cfg3_matern_full_size_vs_oracle(dev):
@@ -1029,7 +1042,9 @@ def test_tile_set_error_codes(dev):
     assert nat.padded_dim(33, generic=True) == 36 and nat.bit_words(2049, generic=True) == 33
     lib = nat.load()
     assert lib.sober_aug_dim(30) == 32 and lib.sober_aug_dim(31) == nat.E_DIM
-    assert lib.sober_car_supported(449, 200) == 0 and lib.sober_car_supported(448, 257) == 0
+    assert lib.sober_car_mc_supported(449, 200) == 0 and lib.sober_car_mc_supported(448, 257) == 0
+    assert lib.sober_car_supported(449, 200) == 1 and lib.sober_car_supported(2048, 1025) == 1      # (csrc/car_big.hip)
+    assert lib.sober_car_supported(2049, 200) == 0 and lib.sober_car_supported(200, 200) == 0
     assert lib.sober_car_supported(400, 200) == 1 and lib.sober_car_supported(200, 100) == 1
 
 
