@@ -751,11 +751,13 @@ def _vs_oracle(kind, mode, N, M, d, b, n_obs, seed, dev, bit_p=0.04, ard=True, c
     assert abs(float(w.sum()) - 1.0) < 1e-12 and len(w) <= b
 
 
-@pytest.mark.parametrize("N,M,d,b", [(2000, 64, 3, 10), (6000, 150, 4, 50), (20000, 300, 6, 100), (9000, 300, 5, 120)])
+@pytest.mark.parametrize("N,M,d,b", [(2000, 64, 3, 10), (6000, 150, 4, 50), (20000, 300, 6, 100), (9000, 300, 5, 120), (6000, 500, 6, 250)])
 def test_calc_obj_levels_on_the_device(N, M, d, b, dev):
     """The acquisition-guided branch (SOBER/_rchq.py:67-69, :79-106, :138-150, :168-196) with every Caratheodory
     step (one more function: the objective) and every extra elimination on the device -- one-CU kernels up to batch
-    100, the multi-CU kernels beyond -- against the oracle's LAPACK route; no host Caratheodory step is taken."""
+    100, the multi-CU kernels beyond, the memory-resident ones at batch 250 (where the second elimination's direction comes from
+    a second step on the survivors: csrc/null_vector.hip ends at 111 functions) -- against the oracle's LAPACK route; no host
+    Caratheodory step is taken."""
     timers = {}
     # (two eliminations per level: the weights carry a few more rounding errors than the plain branch -- 1e-6 here,
     #  the contract is 1e-4)
