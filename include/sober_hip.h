@@ -286,8 +286,13 @@ int sober_null_vector_supported(int nfun);
 int sober_null_vector(const double* X, int ldx, int Nsets, int nfun, const int32_t* rank1, const int32_t* n_keep1, int n1,
                       double* null_row, int32_t* status, void* stream);
 int sober_second_elimination_rows(const double* null_row, const double* obj_row, const double* w1, const int32_t* rank1,
-                                  const int32_t* n_keep1, int n1, int Nsets, int32_t* keep_rank, double* w_star,
-                                  int32_t* n_keep, void* stream);
+                                  const int32_t* n_keep1, const int32_t* status, int n1, int Nsets, int32_t* keep_rank,
+                                  double* w_star, int32_t* n_keep, void* stream);
+/* (status: sober_null_vector's verdict word read on the device -- != 0 gives *n_keep = -2 --, or NULL.)
+ * The objective's set sums of a QUEUED level (sober_level_loop_obj below): the level's size from *dR (R_known >= 0: by value),
+ * the barycentre column out[s] / tot[s] written to xcol[s * ldx] and ocol[s]; nothing is written once the chain has stopped. */
+int sober_obj_set_sums_queued(const double* obj, const double* mu, const int32_t* idx, int S, const int64_t* dR, int64_t R_known,
+                              const double* tot, double* xcol, int ldx, double* ocol, void* stream);
 
 /* The multi-CU implementation by itself (any size it covers, also the small ones: test and timing hook). */
 int sober_car_mc_supported(int N, int m);
@@ -629,6 +634,26 @@ int sober_level_car_retry(sober_level_job* job, void* stream);
 int sober_level_loop(sober_level_job* job, int64_t R, int32_t* idx_a, int32_t* idx_b, int first_sums_ready,
                      void** events, int max_levels, int64_t* level_R, int32_t* n_levels, int64_t* R_final,
                      int32_t* in_b, void* stream);
+/* The same queued chain for the ACQUISITION-GUIDED branch (calc_obj: SOBER/_rchq.py:67-69, :138-150, :173-196; round 6): per level
+ * the set sums, the objective's set sums and barycentre column (sober_obj_set_sums_queued), the Caratheodory step with n + 2
+ * functions, the second elimination's direction (sober_null_vector) and the elimination (sober_second_elimination_rows), the
+ * update -- every verdict read on the device, one synchronisation for the chain.  A level whose outcome is not the regular one
+ * (the first step left other than n + 2 sets, a rank-deficient survivors' matrix, a give-up, no progress) stops the chain with
+ * weights and list untouched; *n_levels complete levels and *R_final live positions come back, the rest (that level, the
+ * leftover-dependent last levels, the final direct level) is the caller's synchronised route.  job: as for sober_level_loop
+ * with car_ws sized by sober_car_ws_bytes(S, n + 2); class sums are not used.  SOBER_E_DIM: n beyond sober_null_vector.     */
+typedef struct sober_obj_job {
+    const double* obj;          /* calc_obj by candidate (already negated: :69)                                        */
+    double* X_tmp;              /* S x (n + 1): the barycentres with the objective's column                            */
+    double* ocol;               /* S: that column, contiguous                                                          */
+    int32_t* kr1; double* w1; int32_t* nk1;     /* the first step's ranks (S), weights (S), survivor count             */
+    double* null_row;           /* S                                                                                   */
+    int32_t* status;            /* sober_null_vector's verdict                                                         */
+} sober_obj_job;
+int sober_obj_job_size(void);
+int sober_level_loop_obj(sober_level_job* job, const sober_obj_job* obj_job, int64_t R, int32_t* idx_a, int32_t* idx_b,
+                         int first_sums_ready, int max_levels, int64_t* level_R, int32_t* n_levels, int64_t* R_final,
+                         int32_t* in_b, void* stream);
 /* The level loop of a ROW-SHARDED pool, native: rank `rank` of `world` owns the list positions
  * [bounds[rank], bounds[rank+1]) (bounds: world + 1 int64, updated in place after every level from the replicated
  * verdict: closed-form compaction, no candidate row moves).  Per level: local set sums -> ONE all-reduce of the flat

@@ -404,6 +404,16 @@ class RecombinationEngine:
             idx_cur, idx_new, R = ops.level_loop(plan, idx_cur, idx_new, R, S, mu, sums_ready, self.row_offset)
             pos0, count, bounds, sums_ready = 0, R, [0, R], False
             self._tick("levels_device", t0)
+        elif not sharded and obj is not None and levels is None and not self.force_host_car and R > S \
+                and getattr(ops, "level_loop_obj", None) is not None:
+            # acquisition-guided branch: the levels that certainly exist as one queued chain of the level executor (every
+            # verdict read on the device); an irregular level, the last levels and the final one stay with the loop below
+            t0 = time.perf_counter()
+            res = ops.level_loop_obj(plan, idx_cur, idx_new, R, S, mu, obj, sums_ready)
+            if res is not None and res[3] > 0:
+                idx_cur, idx_new, R = res[:3]
+                pos0, count, bounds, sums_ready = 0, R, [0, R], False
+            self._tick("levels_device", t0)
         elif sharded and obj is None and levels is None and not self.force_host_car and R > S \
                 and getattr(ops, "level_loop_sharded", None) is not None and ops.car_supported(S, n + 1) \
                 and getattr(comm, "native_allreduce", None) is not None:

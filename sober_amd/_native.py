@@ -80,7 +80,10 @@ SIGNATURES = {
     "sober_obj_set_sums": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp]),
     "sober_null_vector_supported": (_i32, [_i32]),
     "sober_null_vector": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
-    "sober_second_elimination_rows": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "sober_second_elimination_rows": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "sober_obj_set_sums_queued": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
+    "sober_obj_job_size": (_i32, []),
+    "sober_level_loop_obj": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sober_car_safe_supported": (_i32, [_i32, _i32]),
     "sober_car_giveup_forced": (_i32, []),
     "sober_final_commit": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
@@ -185,6 +188,12 @@ class FinalJob(C.Structure):
     ]
 
 
+class ObjJob(C.Structure):
+    """struct sober_obj_job of include/sober_hip.h (field for field)."""
+    _fields_ = [("obj", _vp), ("X_tmp", _vp), ("ocol", _vp), ("kr1", _vp), ("w1", _vp), ("nk1", _vp), ("null_row", _vp),
+                ("status", _vp)]
+
+
 class NystromJob(C.Structure):
     """struct sober_nystrom_job of include/sober_hip.h (field for field)."""
     _fields_ = [
@@ -252,7 +261,7 @@ def load() -> C.CDLL:
         raise SoberHipError(f"{LIB_PATH} is a diagnostic build (in-kernel time stamps): not a library to compute with; "
                             "`make -C sober_amd/csrc` builds the product (SOBER_ALLOW_DIAG_LIB=1: the stamp scripts)")
     for name, cls in (("sober_level_job_size", LevelJob), ("sober_nystrom_job_size", NystromJob),
-                      ("sober_final_job_size", FinalJob)):
+                      ("sober_final_job_size", FinalJob), ("sober_obj_job_size", ObjJob)):
         if getattr(lib, name)() != C.sizeof(cls):
             raise SoberHipError(f"{cls.__name__}: {C.sizeof(cls)} bytes here, {getattr(lib, name)()} in libsober_hip; "
                                 "include/sober_hip.h and sober_amd/_native.py disagree")
@@ -593,11 +602,21 @@ def null_vector(X, nfun, rank1, n_keep1, n1, null_row, status):
                                     int(n1), null_row.data_ptr(), status.data_ptr(), _stream(X)), "sober_null_vector")
 
 
-def second_elimination_rows(null_row, obj_row, w1, rank1, n_keep1, n1, keep_rank, w_star, n_keep):
+def second_elimination_rows(null_row, obj_row, w1, rank1, n_keep1, n1, keep_rank, w_star, n_keep, status=None):
     _check(load().sober_second_elimination_rows(null_row.data_ptr(), obj_row.data_ptr(), w1.data_ptr(), rank1.data_ptr(),
-                                                n_keep1.data_ptr(), int(n1), rank1.numel(), keep_rank.data_ptr(),
+                                                n_keep1.data_ptr(), _ptr(status), int(n1), rank1.numel(), keep_rank.data_ptr(),
                                                 w_star.data_ptr(), n_keep.data_ptr(), _stream(null_row)),
            "sober_second_elimination_rows")
+
+
+def level_loop_obj(job, obj_job, R, idx_a, idx_b, first_sums_ready, stream):
+    """sober_level_loop_obj: the queued chain of the acquisition-guided branch -> (level_R list, R_final, list is idx_b?)."""
+    level_R = (_i64 * MAX_LEVELS)()
+    n_levels, in_b, R_final = _i32(0), _i32(0), _i64(0)
+    _check(load().sober_level_loop_obj(C.addressof(job), C.addressof(obj_job), R, idx_a.data_ptr(), idx_b.data_ptr(),
+                                       int(bool(first_sums_ready)), MAX_LEVELS, level_R, C.byref(n_levels), C.byref(R_final),
+                                       C.byref(in_b), stream), "sober_level_loop_obj")
+    return list(level_R[:n_levels.value]), int(R_final.value), bool(in_b.value)
 
 
 def second_elimination(phi, objp, w1, rank1, n1, keep_rank, w_star, n_keep):

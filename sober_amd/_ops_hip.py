@@ -41,6 +41,9 @@ class HipOps(_PlanOps, _NystromOps, _LevelOps):
         # acquisition-guided branch: the second elimination's direction from csrc/null_vector.hip (False: from a second
         # Caratheodory step on the b + 1 survivors, rounds 2-5 -- which stays for the sizes that kernel does not cover)
         self.obj_null_kernel = True
+        # ... and that branch's levels as one queued chain of the level executor (False: a visit to Python and a read-back per
+        # level, rounds 2-6a -- what still takes the levels the chain does not complete)
+        self.queue_obj_levels = True
         # matrix-core path, unweighted: no scaled copy of the pool (the final level scales its <= 2 b rows itself); False: the
         # copy of rounds 1-5 (A/B, and what the VALU level kernel and the weighted mode still use)
         self.lazy_scaled_pool = True

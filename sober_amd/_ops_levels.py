@@ -136,6 +136,46 @@ class _LevelOps:
                 job.ev[k] = None
         return p.ws["Xtr"], p.ws["tot"]
 
+    def level_loop_obj(self, p: Plan, idx_cur, idx_new, R: int, S: int, mu, obj, sums_ready: bool):
+        """The acquisition-guided branch's levels (SOBER/_rchq.py:116-221 with :138-150, :173-196) as ONE queued chain of the level
+        executor (csrc/level_exec.cpp: sober_level_loop_obj): set sums, the objective's column, the step with n + 2 functions, the
+        second elimination and the update of every level that certainly exists, one synchronisation -- instead of a visit to
+        Python (and a read-back) per level.  Returns (idx_cur, idx_new, R, levels done) for the engine's synchronised loop, which
+        takes whatever the chain did not complete (an irregular level, the last levels, the final one); None: not applicable."""
+        job = self._job(p, S)
+        n = job.n
+        if not self.queue_obj_levels or not self.queue_levels or not job.dR or job.variant not in (nat.LEVEL_MFMA, nat.LEVEL_TANI):
+            return None
+        if self.car_mode == nat.CAR_HOST or not self.obj_null_kernel or not self.car_supported(S, n + 2) \
+                or not bool(nat.load().sober_null_vector_supported(n)):
+            return None
+        nat._req(mu, torch.float64, "mu"); nat._req(idx_cur, torch.int32, "idx"); nat._req(idx_new, torch.int32, "idx")
+        nat._req(obj, torch.float64, "obj")
+        dev, f64, w = self.device, torch.float64, p.ws
+        if "obj_job" not in w:
+            oj = nat.ObjJob()
+            w["obj_X"] = torch.empty(S, n + 1, dtype=f64, device=dev)
+            w["obj_f"] = torch.empty(3, S, dtype=f64, device=dev)              # ocol | w1 | null_row
+            w["obj_i"] = torch.empty(S + 2, dtype=torch.int32, device=dev)     # kr1 | nk1 | status
+            nbytes = nat.car_ws_bytes(S, n + 2)
+            w["obj_car_ws"] = (torch.empty(max(nbytes // 8, 1), dtype=f64, device=dev), nbytes)
+            oj.X_tmp, oj.ocol, oj.w1, oj.null_row = (w["obj_X"].data_ptr(), w["obj_f"][0].data_ptr(), w["obj_f"][1].data_ptr(),
+                                                       w["obj_f"][2].data_ptr())
+            oj.kr1, oj.nk1, oj.status = w["obj_i"].data_ptr(), w["obj_i"][S:].data_ptr(), w["obj_i"][S + 1:].data_ptr()
+            w["obj_job"] = oj
+        oj = w["obj_job"]
+        oj.obj = obj.data_ptr()
+        job.mu = mu.data_ptr()
+        saved = (job.car_ws, job.car_ws_bytes, job.class_depth)
+        job.car_ws, job.car_ws_bytes, job.class_depth = w["obj_car_ws"][0].data_ptr(), w["obj_car_ws"][1], 0
+        try:
+            level_R, R_final, in_b = nat.level_loop_obj(job, oj, R, idx_cur, idx_new, sums_ready, nat._stream(mu))
+        finally:
+            job.car_ws, job.car_ws_bytes, job.class_depth = saved
+        if in_b:
+            idx_cur, idx_new = idx_new, idx_cur
+        return idx_cur, idx_new, R_final, len(level_R)
+
     def level_loop(self, p: Plan, idx_cur, idx_new, R: int, S: int, mu, sums_ready: bool, row_offset: int = 0):
         """The whole halving loop of an unsharded pool while R > S (SOBER/_rchq.py:116-221) in ONE call of the
         level executor (csrc/level_exec.cpp: sober_level_loop) -- no trip through Python between a level's
@@ -371,7 +411,7 @@ class _LevelOps:
                 nat.null_vector(X, n1f - 1, kr1, nk1_d, n1, null_row, status)
                 ocol = (X[:, n1f - 1] if obj_head is None else obj_head[:N]).contiguous()
                 w_star = torch.empty(N, dtype=torch.float64, device=dev)
-                nat.second_elimination_rows(null_row, ocol, w1, kr1, nk1_d, n1, keep_rank, w_star, n_keep)
+                nat.second_elimination_rows(null_row, ocol, w1, kr1, nk1_d, n1, keep_rank, w_star, n_keep, status=status)
                 (fl_h,) = self.to_host(flags)
                 keep_h, nk_h, nk1, st_h, kr1_h = fl_h[:N], int(fl_h[N]), int(fl_h[N + 1]), int(fl_h[N + 2]), fl_h[N + 3:]
                 if nk1 == n1 and st_h == 0:

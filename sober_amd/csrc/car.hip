@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(512) void k_second_elim(const double* __restrict__ 
                                                      const double* __restrict__ w1, const int32_t* __restrict__ rank1,
                                                      int n1, int Nsets, int32_t* __restrict__ keep_rank,
                                                      double* __restrict__ w_star, int32_t* __restrict__ n_keep_out,
-                                                     const int32_t* __restrict__ n_keep1) {
+                                                     const int32_t* __restrict__ n_keep1, const int32_t* __restrict__ status) {
     __shared__ double red[512];
     __shared__ unsigned long long kmin[512];
     __shared__ int kidx[512];
@@ -1075,6 +1075,8 @@ __global__ __launch_bounds__(512) void k_second_elim(const double* __restrict__ 
     double ph, ob;
     if constexpr (BY_ROW) {
         if (*n_keep1 != n1) { if (t == 0) *n_keep_out = (*n_keep1 < 0) ? -1 : -2; return; }      // (uniform)
+        // (the null-vector kernel's verdict: a rank-deficient A2 has no null LINE -- the caller's host route)
+        if (status != nullptr && *status != 0) { if (t == 0) *n_keep_out = -2; return; }
         __shared__ double s_ph[512], s_ob[512];
         for (int sidx = t; sidx < Nsets; sidx += 512) {
             const int r1 = rank1[sidx];
@@ -1282,21 +1284,22 @@ extern "C" int sober_second_elimination(const double* phi, const double* objp, c
     if (!phi || !objp || !w1 || !rank1 || !keep_rank || !w_star || !n_keep || n1 <= 0 || Nsets <= 0) return SOBER_E_ARG;
     if (n1 > 512) return SOBER_E_DIM;
     hipLaunchKernelGGL(sober::k_second_elim<false>, dim3(1), dim3(512), 0, (hipStream_t)stream, phi, objp, w1, rank1, n1, Nsets,
-                       keep_rank, w_star, n_keep, (const int32_t*)nullptr);
+                       keep_rank, w_star, n_keep, (const int32_t*)nullptr, (const int32_t*)nullptr);
     LAUNCH_CHECK();
     return 0;
 }
 
 // ... with the null vector and the objective BY SET (sober_null_vector's output; the level's objective column) and the
 // first step's verdict read on the device: *n_keep = -2 when it did not leave exactly n1 sets (-1: it gave up)
+// (status: sober_null_vector's verdict word, or NULL; != 0 there reads as "not regular": *n_keep = -2)
 extern "C" int sober_second_elimination_rows(const double* null_row, const double* obj_row, const double* w1,
-                                             const int32_t* rank1, const int32_t* n_keep1, int n1, int Nsets,
-                                             int32_t* keep_rank, double* w_star, int32_t* n_keep, void* stream) {
+                                             const int32_t* rank1, const int32_t* n_keep1, const int32_t* status, int n1,
+                                             int Nsets, int32_t* keep_rank, double* w_star, int32_t* n_keep, void* stream) {
     if (!null_row || !obj_row || !w1 || !rank1 || !n_keep1 || !keep_rank || !w_star || !n_keep || n1 <= 0 || Nsets <= 0)
         return SOBER_E_ARG;
     if (n1 > 512) return SOBER_E_DIM;
     hipLaunchKernelGGL(sober::k_second_elim<true>, dim3(1), dim3(512), 0, (hipStream_t)stream, null_row, obj_row, w1, rank1, n1,
-                       Nsets, keep_rank, w_star, n_keep, n_keep1);
+                       Nsets, keep_rank, w_star, n_keep, n_keep1, status);
     LAUNCH_CHECK();
     return 0;
 }

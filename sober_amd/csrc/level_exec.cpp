@@ -9,6 +9,7 @@
 #include "switches.hpp"
 
 extern "C" int sober_level_job_size(void) { return (int)sizeof(sober_level_job); }
+extern "C" int sober_obj_job_size(void) { return (int)sizeof(sober_obj_job); }
 
 #define LX_TRY(call)                 \
     do {                             \
@@ -192,8 +193,11 @@ static int lx_chunks(int n_rows, int64_t e_total, int S) { return sober_level_pa
 
 // Phase A of sober_level_loop: every level that certainly exists, enqueued back to back with device-resident sizes.
 // -> *done = levels completed, *R_out = live positions after them (their list: idx_a if *done is even).
-static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_t* idx_b, int first_sums_ready,
-                          void** events, int max_levels, int64_t* level_R, int* done, int64_t* R_out, void* stream) {
+// (oj != NULL: the acquisition-guided branch -- the objective as one more function of the step and the second elimination
+//  behind it, SOBER/_rchq.py:138-150, :173-196 -- with every verdict read on the device; the regular outcome leaves b sets too)
+static int lx_loop_queued(sober_level_job* j, const sober_obj_job* oj, int64_t R0, int32_t* idx_a, int32_t* idx_b,
+                          int first_sums_ready, void** events, int max_levels, int64_t* level_R, int* done, int64_t* R_out,
+                          void* stream) {
     const int S = j->S, n = j->n, b = n + 1;
     *done = 0;
     *R_out = R0;
@@ -207,10 +211,11 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
         ++L;
     }
     if (L < 2) return 0;                                                // nothing to gain: the synchronised loop
-    if (!sober_car_supported(S, b)) return SOBER_E_DIM;
+    if (!sober_car_supported(S, oj ? b + 1 : b)) return SOBER_E_DIM;
+    if (oj && (!sober_null_vector_supported(n) || b + 1 > 512)) return SOBER_E_DIM;
     // levels 1 .. D gathered and scaled from level 0's class sums (the caller's phase-1 call left them: first_sums_ready)
     int D = 0;
-    if (first_sums_ready && j->class_depth > 0) {
+    if (first_sums_ready && j->class_depth > 0 && !oj) {     // (the objective's row has no class sums: every level evaluated)
         D = j->class_depth;
         if ((j->variant != SOBER_LEVEL_MFMA && j->variant != SOBER_LEVEL_TANI) || D > SOBER_CLASS_MAX_DEPTH || D >= L ||
             R0 % ((int64_t)S << D) != 0 ||
@@ -281,9 +286,24 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
                                              SOBER_LEVEL_XS, j->G, S, j->tot, j->dR + l, tani ? 1 : 0, stream));
         }
         // projection and barycentres in one launch (X_tmp = (P G)^T / tot: bit-identical to the two steps)
-        LX_TRY(sober_dgemm_coldiv_t(n, S, j->n_rows, j->P, j->n_rows, j->G, S, j->tot, j->X_tmp, n, stream));
-        LX_TRY(sober_car_device_ex(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
-                                   nullptr, j->car_ws, j->car_ws_bytes, j->car_mode, stream));
+        if (oj) {
+            // ... into n + 1 columns, the last one the objective's barycentres (:138-150); the step with n + 2 functions (:173);
+            // the direction of the second elimination from the survivors' own matrix and the elimination (:177-196).  A first
+            // step that did not leave n + 2 sets, a rank-deficient survivors' matrix or a give-up end as n_keep <= 0 in
+            // keep_rank[S]: the update below then stops the chain and the caller's synchronised route takes that level
+            LX_TRY(sober_dgemm_coldiv_t(n, S, j->n_rows, j->P, j->n_rows, j->G, S, j->tot, oj->X_tmp, n + 1, stream));
+            LX_TRY(sober_obj_set_sums_queued(oj->obj, j->mu, cur, S, j->dR + l, (l == 0 && first_sums_ready) ? R0 : (int64_t)-1,
+                                             j->tot, oj->X_tmp + n, n + 1, oj->ocol, stream));
+            LX_TRY(sober_car_device_ex(oj->X_tmp, n + 1, S, n + 2, j->tot, oj->kr1, oj->w1, oj->nk1, j->mu_out, nullptr,
+                                       j->car_ws, j->car_ws_bytes, j->car_mode, stream));
+            LX_TRY(sober_null_vector(oj->X_tmp, n + 1, S, n, oj->kr1, oj->nk1, n + 2, oj->null_row, oj->status, stream));
+            LX_TRY(sober_second_elimination_rows(oj->null_row, oj->ocol, oj->w1, oj->kr1, oj->nk1, oj->status, n + 2, S,
+                                                 j->keep_rank, j->w_star, j->keep_rank + S, stream));
+        } else {
+            LX_TRY(sober_dgemm_coldiv_t(n, S, j->n_rows, j->P, j->n_rows, j->G, S, j->tot, j->X_tmp, n, stream));
+            LX_TRY(sober_car_device_ex(j->X_tmp, n, S, n + 1, j->tot, j->keep_rank, j->w_star, j->keep_rank + S, j->mu_out,
+                                       nullptr, j->car_ws, j->car_ws_bytes, j->car_mode, stream));
+        }
         LX_TRY(sober_level_update_queued_ex(cur, Rub[l], S, j->keep_rank, j->w_star, j->tot, j->mu, nxt, j->dR + l,
                                             j->dR + l + 1, Rub[l + 1], l < D ? b : 0, j->cls_scale, j->cls_sof,
                                             (l == 0 && first_sums_ready) ? R0 : (int64_t)-1, stream));
@@ -301,6 +321,27 @@ static int lx_loop_queued(sober_level_job* j, int64_t R0, int32_t* idx_a, int32_
     return 0;
 }
 
+// The queued chain of the acquisition-guided branch by itself: every level that certainly exists, enqueued back to back, ONE
+// synchronisation.  *n_levels levels are complete (level_R[l] = their sizes), *R_final positions are live (their list: idx_b when
+// *in_b); the level the chain stopped at -- if any: an irregular outcome, a give-up, the leftover-dependent last levels -- and the
+// final direct level are the caller's (its synchronised route knows the reference's answers for the irregular cases).
+extern "C" int sober_level_loop_obj(sober_level_job* j, const sober_obj_job* oj, int64_t R, int32_t* idx_a, int32_t* idx_b,
+                                    int first_sums_ready, int max_levels, int64_t* level_R, int32_t* n_levels, int64_t* R_final,
+                                    int32_t* in_b, void* stream) {
+    if (!j || !oj || !idx_a || !idx_b || !level_R || !n_levels || !R_final || !in_b || !j->mu || R <= 0 || !j->dR || !j->h_dR)
+        return SOBER_E_ARG;
+    if (!oj->obj || !oj->X_tmp || !oj->ocol || !oj->kr1 || !oj->w1 || !oj->nk1 || !oj->null_row || !oj->status) return SOBER_E_ARG;
+    if (j->variant != SOBER_LEVEL_MFMA && j->variant != SOBER_LEVEL_TANI) return SOBER_E_ARG;
+    int done = 0;
+    int64_t R_after = R;
+    j->ev_used[0] = j->ev_used[1] = 0;
+    LX_TRY(lx_loop_queued(j, oj, R, idx_a, idx_b, first_sums_ready, nullptr, max_levels, level_R, &done, &R_after, stream));
+    *n_levels = done;
+    *R_final = R_after;
+    *in_b = (done & 1) ? 1 : 0;
+    return 0;
+}
+
 extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, int32_t* idx_b, int first_sums_ready,
                                 void** events, int max_levels, int64_t* level_R, int32_t* n_levels, int64_t* R_final,
                                 int32_t* in_b, void* stream) {
@@ -313,7 +354,7 @@ extern "C" int sober_level_loop(sober_level_job* j, int64_t R, int32_t* idx_a, i
     if (j->dR && j->h_dR && (j->variant == SOBER_LEVEL_MFMA || (j->variant == SOBER_LEVEL_TANI && !sober::switches().tani_no_queue))) {
         int done = 0;
         int64_t R_after = R;
-        LX_TRY(lx_loop_queued(j, R, idx_a, idx_b, first_sums_ready, events, max_levels, level_R, &done, &R_after, stream));
+        LX_TRY(lx_loop_queued(j, nullptr, R, idx_a, idx_b, first_sums_ready, events, max_levels, level_R, &done, &R_after, stream));
         if (done > 0) {
             levels = done;
             R = R_after;

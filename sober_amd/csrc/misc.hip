@@ -374,6 +374,35 @@ __global__ __launch_bounds__(256) void k_obj_set_sums(const double* __restrict__
     if (tid == 0) out[s] = s_p[0];
 }
 
+// ... for a QUEUED level (level_exec.cpp: the acquisition-guided branch's chain): the level's size read on the device (*dR, or
+// R_known >= 0 for the chain's first level), and -- tot being complete by then -- the objective's barycentre column written where
+// the Caratheodory step and the second elimination read it: xcol[s * ldx] (the last column of X_tmp) and ocol[s], both out / tot.
+__global__ __launch_bounds__(256) void k_obj_set_sums_queued(const double* __restrict__ obj, const double* __restrict__ mu,
+                                                             const int32_t* __restrict__ idx, int S, const int64_t* __restrict__ dR,
+                                                             int64_t R_known, const double* __restrict__ tot,
+                                                             double* __restrict__ xcol, int ldx, double* __restrict__ ocol) {
+    __shared__ double s_p[256];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int64_t R = R_known >= 0 ? R_known : __hip_atomic_load(dR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (R <= S) return;                                      // (the chain has stopped, or nothing left to halve)
+    const int64_t ES = (R / S) * (int64_t)S;
+    double acc = 0.0;
+    for (int64_t p = s + (int64_t)tid * S; p < R; p += (int64_t)256 * S) { const int c = idx[p]; acc += obj[c] * mu[c]; }
+    if (s == S - 1)                                          // the leftovers' second placement (Q1)
+        for (int64_t q = ES + tid; q < R; q += 256) { const int c = idx[q]; acc += obj[c] * mu[c]; }
+    s_p[tid] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) s_p[tid] += s_p[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double v = s_p[0] / tot[s];
+        xcol[(size_t)s * ldx] = v;
+        ocol[s] = v;
+    }
+}
+
 // left block of the projection: P[r][c] = Ut[r][c] * mean[c]  (c < M; ldp = M + n_obs)
 __global__ void k_projection_left(const double* __restrict__ Ut, int s, int M, const double* __restrict__ mean,
                                   double* __restrict__ P, int ldp) {
@@ -884,6 +913,15 @@ extern "C" int sober_obj_set_sums(const double* obj, const double* mu, const int
                                   int64_t E, double* out, void* stream) {
     if (!obj || !mu || !idx || !out || pos0 < 0 || count <= 0 || S <= 0 || E < 0) return SOBER_E_ARG;
     hipLaunchKernelGGL(k_obj_set_sums, dim3((unsigned)S), dim3(256), 0, (hipStream_t)stream, obj, mu, idx, pos0, count, S, E, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sober_obj_set_sums_queued(const double* obj, const double* mu, const int32_t* idx, int S, const int64_t* dR,
+                                        int64_t R_known, const double* tot, double* xcol, int ldx, double* ocol, void* stream) {
+    if (!obj || !mu || !idx || !tot || !xcol || !ocol || S <= 0 || ldx <= 0 || (!dR && R_known < 0)) return SOBER_E_ARG;
+    hipLaunchKernelGGL(k_obj_set_sums_queued, dim3((unsigned)S), dim3(256), 0, (hipStream_t)stream, obj, mu, idx, S, dR, R_known,
+                       tot, xcol, ldx, ocol);
     LAUNCH_CHECK();
     return 0;
 }

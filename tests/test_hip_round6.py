@@ -399,3 +399,43 @@ def test_car_big_equals_the_register_resident_routes_on_reference_levels(dev):
         np.testing.assert_allclose(w3[:n3], w1[:n1], rtol=1e-10)
         assert np.array_equal(k3, k4) and np.array_equal(w3, w4), i
         assert np.array_equal(np.flatnonzero(k3 >= 0), z[f"L{i}_idx_star"])
+
+
+# ------------------------------------------------------------------ the acquisition-guided branch's levels as one queued chain
+@pytest.mark.parametrize("kind,mode,N,M,d,b,seed", [("rbf", "predictive_covariance", 100000, 500, 10, 100, 1), ("matern52", "kernel", 30000, 300, 5, 40, 2),
+                                                    ("rbf", "weighted_predictive_covariance", 20000, 200, 4, 30, 3), ("tanimoto", "kernel", 40000, 300, 1024, 60, 4),
+                                                    ("rbf", "predictive_covariance", 12345, 150, 3, 17, 5)])
+def test_calc_obj_levels_queued_equal_the_level_by_level_route(kind, mode, N, M, d, b, seed, dev):
+    """recombination(..., calc_obj=...) (SOBER/_rchq.py:67-69, :138-150, :173-196) with its levels as ONE queued chain of the level
+    executor (sober_level_loop_obj: every verdict read on the device, one synchronisation) against the level-by-level route of the
+    same package (`HipOps.queue_obj_levels = False`: a visit to Python and a read-back per level): the same kernels on the same
+    data in the same order -- bit-identical points and weights; the chain really ran (fewer read-backs is its point)."""
+    import warnings
+    from oracle import sober_oracle as O
+    from sober_amd._ops_hip import HipOps
+    from sober_amd import _native as nat
+    from tests.golden.synth import SEED_CALL, build_spec, calc_obj_fn, synth
+    case = dict(kind=kind, mode=mode, N=N, M=M, d=d, b=b, n_obs=0 if mode == "kernel" else 40, seed=seed, ard=False, bit_p=0.06)
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    res, done = [], []
+    for flag in (True, False):
+        ops = HipOps(dev)
+        ops.queue_obj_levels = flag
+        calls = []
+        orig = nat.level_loop_obj
+        nat.level_loop_obj = lambda *a, **k: (calls.append(orig(*a, **k)), calls[-1])[1]
+        try:
+            mu = _t(inp["mu0"].copy()).to(dev)
+            torch.manual_seed(SEED_CALL)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                i, w = sober_amd.recombination(_t(inp["X_cand"]).to(dev), _t(inp["X_nys"]).to(dev), b,
+                                               sober_amd.Kernel(_kspec(spec), mode), init_weights=mu, calc_obj=calc_obj_fn, _ops=ops)
+        finally:
+            nat.level_loop_obj = orig
+        res.append((i.cpu().numpy(), w.cpu().numpy(), mu.cpu().numpy()))
+        done.append(sum(len(c[0]) for c in calls))
+    assert done[1] == 0 and done[0] >= 2, done
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
