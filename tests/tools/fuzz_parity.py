@@ -2,7 +2,7 @@
 instantiations of the Caratheodory kernels, leftovers of every kind, the continuous kernels and fingerprints, the three
 modes, with and without `calc_obj`.  The functions are what tests/test_hip_round4.py::test_fuzz_slice_vs_oracle runs on a
 fixed 40-case slice; as a script:  python tests/tools/fuzz_parity.py [n_cases=60] [seed=0]   (FUZZ_KIND=tanimoto: fingerprint
-pools; FUZZ_ONLY=3,17: replay these cases with the diagnostics).
+pools; FUZZ_ONLY=3,17: replay these cases with the diagnostics; FUZZ_BATCHES=230,250,300 FUZZ_NFACTOR=12: other batches).
 
 Verdicts: "ok" = identical indices and weights within 1e-6 (the contract: 1e-4), or within 20x of what the REFERENCE's own
 weights move when its inputs move by one ulp; "ill-posed" = the reference's own indices change, or its own weights move by
@@ -21,7 +21,7 @@ t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 BATCHES = [5, 8, 9, 16, 17, 24, 32, 33, 40, 56, 57, 64, 65, 80, 100, 112, 120, 150]
 
 
-def make_case(rng, tani=False, batches=BATCHES, n_factor=40, even_elements=0):
+def make_case(rng, tani=False, batches=BATCHES, n_factor=40, even_elements=0, obj_max=100):
     """One random case (all the random draws happen here, in a fixed order: a seed names a sweep).
     even_elements = D > 0 (round 6, FUZZ_EVEN=D): the pool's size is rounded up to a multiple of 2^D x 2 b with at least two
     elements per set left at level D -- a pool without leftovers whose levels 1 .. D are DERIVED from level 0's class sums
@@ -37,7 +37,7 @@ def make_case(rng, tani=False, batches=BATCHES, n_factor=40, even_elements=0):
         b = min(b, 64)                                       # (a pool of random fingerprints has no more structure than that)
         M = int(rng.integers(b + 8, max(b + 9, 4 * b))); N = int(rng.integers(max(2 * b + 1, M + 1), n_factor * b + 50))
     mode = ["predictive_covariance", "kernel", "weighted_predictive_covariance"][int(rng.integers(0, 3))]
-    use_obj = bool(rng.random() < 0.25) and b <= 100
+    use_obj = bool(rng.random() < 0.25) and b <= obj_max
     if even_elements > 0:
         q = (1 << even_elements) * 2 * b
         N = max(2 * q, ((N + q - 1) // q) * q)
@@ -153,9 +153,13 @@ if __name__ == "__main__":
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     tani = os.environ.get("FUZZ_KIND") == "tanimoto"
     even = int(os.environ.get("FUZZ_EVEN", "0"))
+    # FUZZ_BATCHES=230,250,300 (round 6): batches beyond the register-resident Caratheodory kernels (csrc/car_big.hip), with
+    # calc_obj allowed up to batch 400 and pools of at most FUZZ_NFACTOR (default 40) x batch candidates
+    batches = [int(v) for v in os.environ.get("FUZZ_BATCHES", "").split(",") if v] or BATCHES
+    n_factor = int(os.environ.get("FUZZ_NFACTOR", "40"))
     bad = 0
     for i in range(n_cases):
-        c = make_case(rng, tani, even_elements=even)
+        c = make_case(rng, tani, batches=batches, n_factor=n_factor, even_elements=even, obj_max=400 if batches is not BATCHES else 100)
         if only and i not in only:
             continue
         try:
