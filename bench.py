@@ -99,6 +99,11 @@ CONFIGS = {
     6: dict(kind="rbf", mode="predictive_covariance", N=8000000, M=500, d=20, b=100, n_obs=200, seed=0,
             name="big pool d=20 RBF posterior covariance (beyond BASELINE.json: the throughput regime)",
             cpu_sample_N=100000, device_pool=True),
+    # beyond BASELINE.json: a batch beyond the register-resident Caratheodory kernels (csrc/car_big.hip: the matrix in memory, a
+    # launch per dependency; host LAPACK until round 5) -- cfg-2's pool with batch 250
+    7: dict(kind="rbf", mode="predictive_covariance", N=100000, M=600, d=10, b=250, n_obs=200, seed=0,
+            name="Ackley-shaped d=10 RBF posterior covariance at batch 250 (beyond BASELINE.json: beyond the register-resident "
+                 "Caratheodory kernels)", cpu_sample_N=20000),
 }
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector = FP64 matrix (vendor)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
@@ -491,6 +496,18 @@ def main():
             except Exception as e:                                      # noqa: BLE001  (a sub-record never takes the headline down)
                 others[str(c)] = {"error": f"{type(e).__name__}: {e}", "wall_s": round(time.perf_counter() - t_c, 2)}
         out["other_configs"] = others
+        # ... and one configuration beyond BASELINE.json's batches (config 7: batch 250, every Caratheodory step on the
+        # memory-resident kernels), same protocol, three steps
+        t_c = time.perf_counter()
+        try:
+            torch.cuda.empty_cache()
+            r = measure(argparse.Namespace(**dict(vars(light), steps=3)), 7, 0, 1, dev, None, backend)
+            out["beyond_baseline"] = {"7": {
+                "workload": r["config"]["workload"], "steps": r["steps"], "ms_per_step": r["ms_per_step"], "value": r["value"],
+                "unit": r["unit"], "dtype": r["dtype"], "parity": r["parity"], "phases_ms_per_step": r["phases_ms_per_step"],
+                "n_selected": r["n_selected"], "wall_s": round(time.perf_counter() - t_c, 2)}}
+        except Exception as e:                                          # noqa: BLE001
+            out["beyond_baseline"] = {"7": {"error": f"{type(e).__name__}: {e}", "wall_s": round(time.perf_counter() - t_c, 2)}}
         t_c = time.perf_counter()
         try:
             torch.cuda.empty_cache()

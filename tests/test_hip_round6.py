@@ -69,6 +69,10 @@ def test_bench_default_line_carries_the_other_configs_and_the_acquisition_step(d
         else:
             assert p["by"] == "invariants" and all(v for k, v in p.items() if isinstance(v, bool)), (c, p)
             assert p["mass_error"] < 1e-12, (c, p)
+    x = d["beyond_baseline"]["7"]                             # (batch 250: every Caratheodory step on csrc/car_big.hip)
+    assert "error" not in x, x
+    assert 0 < x["ms_per_step"] < 200 and x["n_selected"] == 250 and x["parity"]["by"] == "invariants", x
+    assert all(v for k, v in x["parity"].items() if isinstance(v, bool)) and x["parity"]["mass_error"] < 1e-12, x
     a = d["acquisition_step"]
     assert "error" not in a, a
     assert a["ms_per_step"] > 0 and a["parity"]["reference_fixture_sober_next_batch_equal"] is True, a
