@@ -321,7 +321,7 @@ int sober_mc_selftest(const double* in, double* out, void* stream);
  * SOBER/_utils.py:117-157 (the "Nystrom Cholesky"), and is the core of the CholeskyQR used for the
  * range finder of torch.svd_lowrank (SOBER/_rchq.py:37).                                           */
 int sober_chol_max_n(void);
-/* The ladder's probes of make_cov_psd for sober_chol_max_n() < n <= sober_nystrom_max_n() (1024): every rung panel by
+/* The ladder's probes of make_cov_psd for sober_chol_max_n() < n <= sober_nystrom_max_n() (2048): every rung panel by
  * panel, two launches per 32 columns, the 32 x 32 diagonal blocks through the same code as sober_cholesky (same verdict
  * and minimum pivot).  work: n_shifts slabs of n x n doubles; xinv_ws: n_shifts x 1024 doubles.  info / min_pivot as
  * sober_cholesky_probe_piv.  sober_nystrom_basis takes this route by itself (job.probe_ws must be set).            */

@@ -927,7 +927,7 @@ __global__ void k_probe_mc_init(uint32_t* __restrict__ ws, int64_t n_words, int3
 namespace sober {
 // ---------------- the ladder's probes beyond one workgroup's LDS panel: CH_MAXN < n <= CB_MAXN (round 4) ----------------
 // k_chol and k_chol_mc keep the panel below the diagonal block in LDS, (n - 32) x 36 doubles: n <= 536.  A Nystrom set of
-// up to 1024 points is probed panel by panel with TWO launches each, every rung in the same launches:
+// up to 2048 points is probed panel by panel with TWO launches each, every rung in the same launches:
 //   k_cb_diag    one wave per rung: the 32 x 32 diagonal block (+ the rung's shift on its diagonal, as it is met) is
 //                factorised and inverted in registers (ch_diag_block: k_chol's own pivots, verdict and minimum);
 //   k_cb_update  one workgroup per 64 x 64 tile of the trailing lower triangle and rung: its rows of the panel
@@ -935,7 +935,7 @@ namespace sober {
 //                has to finish a panel first, and nobody needs L afterwards -- only the verdicts are used), then
 //                A22 -= L21 L21^T.  A block column is read by its own panel's launches only, after every update of it.
 // 2 x n / 32 launches back to back on the stream; a failed rung keeps computing on whatever it holds (its verdict stands).
-constexpr int CB_MAXN = 1024;
+constexpr int CB_MAXN = 2048;             // (round 6: 1024 before; nothing in the panel kernels depends on it -- the work slabs are n x n per rung)
 constexpr int CB_TILE = 64;
 
 __global__ __launch_bounds__(256) void k_cb_init(double* __restrict__ work, int n, const double* __restrict__ src, int ld_src,
