@@ -9,7 +9,7 @@ from tests.golden.synth import SEED_CALL, build_spec, synth
 from tests.test_hip_round4 import kspec, _t
 
 dev = torch.device("cuda:0")
-for b, M, N in [(200, 500, 100000), (250, 600, 100000), (300, 700, 100000), (512, 1000, 100000), (1000, 1024, 100000)]:
+for b, M, N in [(200, 500, 100000), (250, 600, 100000), (300, 700, 100000), (512, 1000, 100000), (1000, 1500, 100000)]:
     case = dict(kind=O.RBF, mode="predictive_covariance", N=N, M=M, d=10, b=b, n_obs=100, seed=7, ard=True)
     inp = synth(case)
     spec = build_spec(case, inp)

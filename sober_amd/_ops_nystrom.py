@@ -39,10 +39,10 @@ class _NystromOps:
         (tests/test_car_algorithm.py::test_car_invariant_under_orthogonal_mixing).  So any orthonormal basis of
         range(Q) serves, Q^T itself does.  (The literal host route still computes U_B.)"""
         dev, M = self.device, p.M
-        if M > nat.nystrom_max_n() or s > nat.chol_max_n() or s >= M:
+        if M > nat.nystrom_max_n() or s > 2 * nat.chol_max_n() or s >= M:
             if s < M:                                             # (s >= M is the reference's own degenerate case, not a size limit)
                 self.size_cliff("nystrom", f"N_nys = {M}, batch = {s + 1}: beyond the device Nystrom route (N_nys <= "
-                                           f"{nat.nystrom_max_n()}, batch <= {nat.chol_max_n() + 1}); make_cov_psd and svd_lowrank run on host LAPACK "
+                                           f"{nat.nystrom_max_n()}, batch <= {2 * nat.chol_max_n() + 1}); make_cov_psd and svd_lowrank run on host LAPACK "
                                            "instead -- about 5-10x the device route's time for this phase")
             self.gram(p)
             return None

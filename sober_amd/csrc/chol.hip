@@ -1042,6 +1042,27 @@ __global__ __launch_bounds__(256) void k_cb_update(double* __restrict__ work, in
 }
 }  // namespace sober
 
+namespace sober {
+__global__ void k_orth_merge(int32_t* __restrict__ info, double* __restrict__ piv, double* __restrict__ ratio,
+                             const int32_t* __restrict__ info2, const double* __restrict__ piv2, const double* __restrict__ ratio2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (*info == 0) *info = *info2;
+    *piv = fmin(*piv, *piv2);                                 // (a NaN pivot of either half stays visible: fmin would hide it)
+    if (*piv2 != *piv2) *piv = *piv2;
+    if (ratio != nullptr) {
+        *ratio = fmin(*ratio, *ratio2);
+        if (*ratio2 != *ratio2) *ratio = *ratio2;
+    }
+}
+}  // namespace sober
+int sober::orth_merge(int32_t* info, double* piv, double* ratio, const int32_t* info2, const double* piv2, const double* ratio2,
+                      void* stream) {
+    if (!info || !piv || !info2 || !piv2 || (ratio && !ratio2)) return SOBER_E_ARG;
+    hipLaunchKernelGGL(sober::k_orth_merge, dim3(1), dim3(64), 0, (hipStream_t)stream, info, piv, ratio, info2, piv2, ratio2);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sober_nystrom_max_n(void) { return sober::CB_MAXN; }
 
 // every rung of the ladder for CH_MAXN < n <= CB_MAXN (see above); work: n_shifts slabs of n x n doubles, xinv_ws:

@@ -21,4 +21,7 @@ int nystrom_flags_init(void* flags_block, int64_t flags_bytes, void* probe_ws, i
 int cholesky_probe_mc(const double* src, int n, int ld_src, const double* shifts, int n_shifts, double* work, int32_t* info,
                       double* min_pivot, void* ws, int64_t ws_bytes, bool init, void* stream);
 
+// the verdicts of two Cholesky factorisations in one slot: info <- the first failure, piv <- min, ratio <- min (ratio may be NULL)
+int orth_merge(int32_t* info, double* piv, double* ratio, const int32_t* info2, const double* piv2, const double* ratio2, void* stream);
+
 }  // namespace sober

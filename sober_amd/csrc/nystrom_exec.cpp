@@ -33,14 +33,41 @@ extern "C" int64_t sober_nystrom_flags_bytes(int n_rungs, int niter) {
 // (Round 5 built and measured dropping the intermediate passes behind a device-side guard -- -0.2 ms at cfg-2, a subspace
 //  error of 4e-11 that one hypersensitive pool of the fuzz slice turns into other indices: profiles/r05_ab_nystrom_skip.txt.
 //  Round 6 took that opt-in path and its guarded launches out of the library; the passes stay.)
+// ... of a block whose rank s is beyond one workgroup's Cholesky panel (sober_chol_max_n() < s <= 2 x that; round 6): the
+// columns in two halves, block Gram-Schmidt with the same three kernels --
+//     Q1 = Y1 R11^-1,   W = Q1^T Y2,   Y2 -= Q1 W,   Q2 = Y2 R22^-1
+// -- which IS the QR factorisation of [Y1 | Y2] (unique: positive diagonals), so the same Q to rounding; the verdicts of the two
+// factorisations are merged into the pass's slot (first failure, smallest pivot, smallest pivot ratio).
+static int nx_orth_halves(const sober_nystrom_job* j, double* Y, double* O, int32_t* info, double* piv, double* ratio, void* stream) {
+    const int M = j->M, s = j->s, s1 = (s + 1) / 2, s2 = s - s1;
+    double* G1 = j->Gm;                                       // s1 x s1 (then s2 x s2), compact
+    double* W = j->Gm + (size_t)s1 * s1;                      // s1 x s2: s1 s1 + s1 s2 = s1 s <= s s doubles in all
+    double* tail = j->xinv + (size_t)((s + 31) / 32 - 1) * 1024;          // (a half uses fewer 32-blocks of xinv than that)
+    double *piv2 = tail, *ratio2 = tail + 1;
+    int32_t* info2 = (int32_t*)(tail + 2);
+    NX_TRY(sober_dgemm(1, 0, s1, s1, M, 1.0, Y, s, Y, s, 0.0, G1, s1, stream));
+    NX_TRY(sober_cholesky_inv_ratio(G1, s1, s1, 0.0, info, piv, j->xinv, ratio, stream));
+    NX_TRY(sober_trsm_blocks(Y, M, s1, s, G1, s1, j->xinv, O, s, stream));
+    NX_TRY(sober_dgemm(1, 0, s1, s2, M, 1.0, O, s, Y + s1, s, 0.0, W, s2, stream));
+    NX_TRY(sober_dgemm(0, 0, M, s2, s1, -1.0, O, s, W, s2, 1.0, Y + s1, s, stream));
+    NX_TRY(sober_dgemm(1, 0, s2, s2, M, 1.0, Y + s1, s, Y + s1, s, 0.0, G1, s2, stream));
+    NX_TRY(sober_cholesky_inv_ratio(G1, s2, s2, 0.0, info2, piv2, j->xinv, ratio ? ratio2 : nullptr, stream));
+    NX_TRY(sober_trsm_blocks(Y + s1, M, s2, s, G1, s2, j->xinv, O + s1, s, stream));
+    return sober::orth_merge(info, piv, ratio, info2, piv2, ratio ? ratio2 : nullptr, stream);
+}
+
 static int nx_orth(const sober_nystrom_job* j, double** Y, double** other, int32_t* infos, double* pivs, int slot,
                    int passes, void* stream) {
     const int M = j->M, s = j->s;
     for (int it = 0; it < passes; ++it) {
-        NX_TRY(sober_dgemm(1, 0, s, s, M, 1.0, *Y, s, *Y, s, 0.0, j->Gm, s, stream));                         // Y^T Y
-        NX_TRY(sober_cholesky_inv_ratio(j->Gm, s, s, 0.0, infos + slot + it, pivs + slot + it, j->xinv,
-                                        passes == 1 ? pivs + slot + 1 : nullptr, stream));
-        NX_TRY(sober_trsm_blocks(*Y, M, s, s, j->Gm, s, j->xinv, *other, s, stream));                         // Q = Y R^-1
+        if (s > sober_chol_max_n()) {
+            NX_TRY(nx_orth_halves(j, *Y, *other, infos + slot + it, pivs + slot + it, passes == 1 ? pivs + slot + 1 : nullptr, stream));
+        } else {
+            NX_TRY(sober_dgemm(1, 0, s, s, M, 1.0, *Y, s, *Y, s, 0.0, j->Gm, s, stream));                         // Y^T Y
+            NX_TRY(sober_cholesky_inv_ratio(j->Gm, s, s, 0.0, infos + slot + it, pivs + slot + it, j->xinv,
+                                            passes == 1 ? pivs + slot + 1 : nullptr, stream));
+            NX_TRY(sober_trsm_blocks(*Y, M, s, s, j->Gm, s, j->xinv, *other, s, stream));                         // Q = Y R^-1
+        }
         double* t = *Y; *Y = *other; *other = t;
     }
     return 0;
@@ -52,7 +79,7 @@ extern "C" int sober_nystrom_basis(const sober_nystrom_job* j, int phase, void* 
         !j->xinv || !j->flags_block || !j->h_flags_block || !j->Ut)
         return SOBER_E_ARG;
     const int M = j->M, s = j->s, n_r = j->n_rungs, niter = j->niter;
-    if (M <= 0 || s <= 0 || s >= M || s > sober_chol_max_n() || n_r <= 0 || n_r > 64 || niter < 0 || niter > 8) return SOBER_E_ARG;
+    if (M <= 0 || s <= 0 || s >= M || s > 2 * sober_chol_max_n() || n_r <= 0 || n_r > 64 || niter < 0 || niter > 8) return SOBER_E_ARG;
     if (M > sober_nystrom_max_n()) return SOBER_E_DIM;
     if (j->flags_bytes < sober_nystrom_flags_bytes(n_r, niter)) return SOBER_E_WS;
     hipStream_t st = (hipStream_t)stream;
