@@ -247,6 +247,38 @@ def test_null_vector_kernel_reports_a_rank_deficient_matrix(dev):
     assert int(status.item()) == -3
 
 
+def test_second_elimination_reads_the_null_vector_kernels_verdict(dev):
+    """sober_second_elimination_rows with the status word of sober_null_vector (what the queued chain of the acquisition-guided
+    branch relies on: nothing is read back between the launches): a regular level (status 0, the first step left n1 sets) is
+    eliminated as without the word; status != 0 (a rank-deficient survivors' matrix) or another survivor count reports
+    n_keep = -2, a first step that gave up -1 -- and writes nothing else."""
+    from sober_amd import _native as nat
+    i32, f64 = torch.int32, torch.float64
+    rng = np.random.default_rng(5)
+    Nsets, n1 = 30, 12
+    kr1 = torch.full((Nsets,), -1, dtype=i32)
+    kr1[torch.from_numpy(np.sort(rng.permutation(Nsets)[:n1]))] = torch.arange(n1, dtype=i32)
+    kr1 = kr1.to(dev)
+    null_row = _t(rng.standard_normal(Nsets)).to(dev)
+    obj_row = _t(rng.standard_normal(Nsets)).to(dev)
+    w1 = _t(rng.random(Nsets) + 0.1).to(dev)
+
+    def run(nk1_val, status_val):
+        nk1 = torch.tensor([nk1_val], dtype=i32, device=dev)
+        status = None if status_val is None else torch.tensor([status_val], dtype=i32, device=dev)
+        kr = torch.full((Nsets,), -7, dtype=i32, device=dev)
+        ws = torch.full((Nsets,), -7.0, dtype=f64, device=dev)
+        nk = torch.full((1,), -7, dtype=i32, device=dev)
+        nat.second_elimination_rows(null_row, obj_row, w1, kr1, nk1, n1, kr, ws, nk, status=status)
+        return kr.cpu().numpy(), ws.cpu().numpy(), int(nk.item())
+    k0, w0, n0 = run(n1, None)
+    k1, w1_, n1_ = run(n1, 0)
+    assert n0 == n1_ == n1 - 1 and np.array_equal(k0, k1) and np.array_equal(w0, w1_)
+    for nk1_val, st, want in ((n1, -3, -2), (n1 - 1, 0, -2), (n1 + 1, 0, -2), (-1, 0, -1)):
+        k, w, n = run(nk1_val, st)
+        assert n == want and (k == -7).all() and (w == -7.0).all(), (nk1_val, st, n)
+
+
 def test_calc_obj_step_with_the_null_vector_kernel_equals_the_second_step_route(dev):
     """The acquisition-guided recombination (SOBER/_rchq.py:67-69, :87-106, :177-196) with the second elimination's direction
     from csrc/null_vector.hip (default) against the route of rounds 2-5 (a second Caratheodory step on the b + 1 survivors,
