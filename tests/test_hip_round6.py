@@ -475,3 +475,46 @@ def test_calc_obj_levels_queued_equal_the_level_by_level_route(kind, mode, N, M,
     assert done[1] == 0 and done[0] >= 2, done
     assert np.array_equal(res[0][0], res[1][0])
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_calc_obj_chain_hands_an_irregular_level_to_the_level_by_level_route(dev):
+    """A pool of only eight distinct fingerprints: the barycentre matrix of a level has rank <= 8 < batch, the first step leaves
+    fewer than n + 2 sets, and the reference then reads a singular vector of a full-rank matrix (SOBER/_rchq.py:87-106) -- not a
+    case for the device kernels.  The queued chain must stop there with weights and list untouched (n_keep = -2 in the flags ->
+    the update stops the chain) and the level-by-level route take over: the same result as with the chain switched off, bit for
+    bit; and a valid one (positive weights, unit mass, at most batch points)."""
+    import warnings
+    from oracle import sober_oracle as O
+    from sober_amd._ops_hip import HipOps
+    from tests.golden.synth import SEED_CALL, build_spec, calc_obj_fn
+    rng = np.random.default_rng(8)
+    d, b, N, M = 512, 16, 6000, 40                           # (512 bits: the fingerprint level kernel whose levels are queued)
+    pats = (rng.random((8, d)) < 0.1).astype(np.float64)
+    X = pats[rng.integers(0, 8, N)]
+    Xn = X[rng.permutation(N)[:M]].copy()
+    mu0 = rng.random(N); mu0 /= mu0.sum()
+    spec = O.make_spec(O.TANIMOTO, _t(np.zeros((1, d))), _t(np.ones(1)), outputscale=1.0, noise=1e-2, mean_const=0.0, y_obs=_t(np.zeros(1)))
+    from sober_amd import _native as nat
+    res, chains = [], []
+    orig = nat.level_loop_obj
+    nat.level_loop_obj = lambda *a, **k: (chains.append(orig(*a, **k)), chains[-1])[1]
+    try:
+        for flag in (True, False):
+            ops = HipOps(dev)
+            ops.queue_obj_levels = flag
+            mu = _t(mu0.copy()).to(dev)
+            torch.manual_seed(SEED_CALL)
+            timers = {}
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                i, w = sober_amd.recombination(_t(X).to(dev), _t(Xn).to(dev), b, sober_amd.Kernel(_kspec(spec), "kernel"), init_weights=mu,
+                                               calc_obj=calc_obj_fn, _ops=ops, _timers=timers)
+            res.append((i.cpu().numpy(), w.cpu().numpy(), mu.cpu().numpy()))
+            assert "car_host" in timers, timers             # (the irregular levels are the host route's)
+    finally:
+        nat.level_loop_obj = orig
+    # the chain was enqueued once (first run) and completed fewer levels than the pool has: it stopped at the irregular one
+    assert len(chains) == 1 and len(chains[0][0]) < 4 and chains[0][1] > 2 * b, chains
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    i, w, _ = res[0]
+    assert 0 < len(i) <= b and (w > 0).all() and abs(w.sum() - 1.0) < 1e-9
