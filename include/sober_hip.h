@@ -509,6 +509,15 @@ int sober_predict_fused(int kind, const void* obs, const double* obs_norm, int n
                         const double* cand_norm, int64_t N, int dt, double outputscale, const double* W, int ldw,
                         const double* alpha, double c0, double kxx_const, double noise, double* mean_out, double* var_out,
                         double eta, const double* eta_ptr, double* lfi_out, int log_flag, void* stream);
+/* The same launch from the ROOT of W (round 6): St = S^T (n_obs x n_obs, row stride ldst) with W = S S^T -- W is never formed,
+ * var = kxx - |St k|^2 + noise.  *tri_flag != 0 (a device word; NULL = 0) promises that St is LOWER triangular -- gpytorch's
+ * covar_cache of an exact GP is the transposed inverse Cholesky factor, SOBER/_gp.py:272-277 --: the tile products above the
+ * diagonal are skipped (91 of 169 at n_obs = 200; the busiest wave carries 28 instead of 52).                          */
+int sober_predict_fused_root(int kind, const void* obs, const double* obs_norm, int n_obs, const void* cand,
+                             const double* cand_norm, int64_t N, int dt, double outputscale, const double* St, int ldst,
+                             const int32_t* tri_flag, const double* alpha, double c0, double kxx_const, double noise,
+                             double* mean_out, double* var_out, double eta, const double* eta_ptr, double* lfi_out, int log_flag,
+                             void* stream);
 /* Posterior variance (and optionally the LFI weight pi) over a pool, SOBER/_gp.py:212-238 and
  * SOBER/_pi.py:31-38: KX = k(X_obs, pool) (n_obs x N, sober_pairwise), V = W KX (sober_dgemm);
  * var[j] = k(x_j, x_j) - sum_i KX[i][j] V[i][j] + noise; pi[j] = Phi((mean[j] - eta)/sqrt(var[j])),

@@ -111,6 +111,8 @@ SIGNATURES = {
     "sober_predict_fused_supported": (_i32, [_i32, _i32, _i32]),
     "sober_predict_fused": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f64, _vp, _i32, _vp, _f64, _f64, _f64, _vp, _vp,
                                    _f64, _vp, _vp, _i32, _vp]),
+    "sober_predict_fused_root": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f64, _vp, _i32, _vp, _vp, _f64, _f64, _f64, _vp,
+                                        _vp, _f64, _vp, _vp, _i32, _vp]),
     "sober_predict_finish": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f64, _vp, _f64, _f64, _vp, _f64, _vp, _i32, _vp]),
     "sober_reduce_ws_bytes": (_i64, [_i64]),
     "sober_cleansing_weights": (_i32, [_vp, _i64, _f64, _vp, _i64, _vp]),
@@ -707,9 +709,11 @@ def predict_fused_supported(kind: int, n_obs: int, dt: int) -> bool:
 
 
 def predict_fused(kind, obs, obs_norm, cand, cand_norm, n, dt, outputscale, W, alpha, c0, kxx_const, noise, mean_out,
-                  var_out, eta=0.0, lfi_out=None, log=False, eta_dev=None):
+                  var_out, eta=0.0, lfi_out=None, log=False, eta_dev=None, root_tri=None):
     """csrc/predict.hip: mean / variance / pi over `n` prepared candidates in one launch (W symmetric); eta_dev: the
-    threshold as a one-element device tensor (read by the kernel: no host read-back)."""
+    threshold as a one-element device tensor (read by the kernel: no host read-back).  root_tri (a one-element int32 device
+    tensor): `W` is then S^T, the transposed root of W = S S^T, and the word says whether it is lower triangular
+    (sober_predict_fused_root)."""
     # (the kernel takes raw pointers: only W's row stride travels -- everything else must be what it assumes)
     if W.dtype != torch.float64 or W.dim() != 2 or W.stride(1) != 1:
         raise SoberHipError(f"predict_fused: W must be float64 with unit inner stride, got {W.dtype} strides {tuple(W.stride())}")
@@ -720,6 +724,16 @@ def predict_fused(kind, obs, obs_norm, cand, cand_norm, n, dt, outputscale, W, a
             _req(t_, torch.float64, "predict_fused: " + nm)
     if alpha is not None and alpha.numel() != obs.shape[0]:
         raise SoberHipError(f"predict_fused: alpha has {alpha.numel()} entries for {obs.shape[0]} observations")
+    if root_tri is not None:
+        _req(root_tri, torch.int32, "predict_fused: root_tri")
+        if W.shape[0] != W.shape[1] or W.shape[0] != obs.shape[0]:
+            raise SoberHipError(f"predict_fused: the root must be {obs.shape[0]} x {obs.shape[0]}, got {tuple(W.shape)}")
+        _check(load().sober_predict_fused_root(int(kind), obs.data_ptr(), _ptr(obs_norm), obs.shape[0], cand.data_ptr(),
+                                               _ptr(cand_norm), int(n), int(dt), float(outputscale), W.data_ptr(), W.stride(0),
+                                               root_tri.data_ptr(), _ptr(alpha), float(c0), float(kxx_const), float(noise),
+                                               _ptr(mean_out), var_out.data_ptr(), float(eta), _ptr(eta_dev), _ptr(lfi_out),
+                                               int(bool(log)), _stream(cand)), "sober_predict_fused_root")
+        return
     _check(load().sober_predict_fused(int(kind), obs.data_ptr(), _ptr(obs_norm), obs.shape[0], cand.data_ptr(),
                                       _ptr(cand_norm), int(n), int(dt), float(outputscale), W.data_ptr(), W.stride(0),
                                       _ptr(alpha), float(c0), float(kxx_const), float(noise), _ptr(mean_out),

@@ -7,7 +7,9 @@
 
 One launch per chunk of the pool (`sober_predict_fused`, csrc/predict.hip; n_obs <= 256): the K(X_obs, x) columns of 32
 candidates are evaluated once into LDS, W k runs on the FP64 matrix cores, mean / variance / pi leave the kernel --
-nothing of size n_obs x N is ever in memory.  Beyond 256 observations (or an input dimension outside the register-tiled
+nothing of size n_obs x N is ever in memory.  With a square root S of W = S S^T (SOBER/_gp.py:277) the kernel works from S^T
+itself -- var = k(x, x) - |S^T k|^2 + noise -- and skips the tile products above the diagonal when S^T is lower triangular (the
+inverse Cholesky factor gpytorch caches: round 6).  Beyond 256 observations (or an input dimension outside the register-tiled
 set) the materialised route of round 4 stays: KX = k(X_obs, chunk) by `sober_pairwise`, V = W KX (`sober_dgemm`), the
 column-wise quadratic form and Phi in `sober_predict_finish`.
 """
@@ -36,23 +38,33 @@ def _model_side(spec):
     launches and a handful of host calls that `PI` makes once per model snapshot instead of once per call (the reference's
     gpytorch model caches its prediction strategy in the same way)."""
     pobs = prepare_points(spec, spec.X_obs)
+    alpha = spec.alpha if spec.alpha is None or (spec.alpha.dtype == torch.float64 and spec.alpha.is_contiguous()) \
+        else spec.alpha.to(torch.float64).contiguous()
+    S = spec.S_cache
+    if S.dim() == 2 and S.shape[0] == S.shape[1] and not os.environ.get("SOBER_PREDICT_FROM_W"):
+        # a square root (gpytorch's covar_cache of an exact GP): the fused kernel works from S^T itself -- W = S S^T
+        # (SOBER/_gp.py:277) is not formed -- and is told ON THE DEVICE whether it is lower triangular (it is, for the inverse
+        # Cholesky factor: the tile products above the diagonal are then skipped); no read-back
+        St = S.to(torch.float64).t().contiguous()
+        tri = (torch.count_nonzero(torch.triu(St, 1)) == 0).to(torch.int32).reshape(1)
+        return pobs, St, alpha, tri
     W = woodbury(spec)
     if W.dtype != torch.float64 or W.stride(-1) != 1:      # (the fused kernel reads raw rows: csrc/predict.hip takes W's row stride only)
         W = W.to(torch.float64).contiguous()
-    alpha = spec.alpha if spec.alpha is None or (spec.alpha.dtype == torch.float64 and spec.alpha.is_contiguous()) \
-        else spec.alpha.to(torch.float64).contiguous()
-    return pobs, W, alpha
+    return pobs, W, alpha, None
 
 
 def _predict(spec, X, eta=None, log=False, eta_dev=None, model_side=None):
     dev = X.device
     kind = nat.KIND_BY_NAME[spec.kind]
-    pobs, W, alpha = model_side if model_side is not None else _model_side(spec)
+    pobs, W, alpha, root_tri = model_side if model_side is not None else _model_side(spec)
     n_obs, N = len(pobs), X.shape[0]
     mean = torch.empty(N, dtype=torch.float64, device=dev)
     var = torch.empty(N, dtype=torch.float64, device=dev)
     fused = (nat.predict_fused_supported(kind, n_obs, pobs.dt) and spec.alpha is not None
              and nat.fused_dim_supported(kind, spec.X_obs.shape[1]) and not os.environ.get("SOBER_PREDICT_MATERIALISED"))
+    if not fused and root_tri is not None:                # (the materialised route wants W itself)
+        W, root_tri = woodbury(spec).to(torch.float64).contiguous(), None
     if eta is None and eta_dev is not None:
         # the threshold is still in device memory: the fused kernel reads it there, the materialised route needs the number
         eta = 0.0 if fused else float(eta_dev.item())
@@ -66,7 +78,7 @@ def _predict(spec, X, eta=None, log=False, eta_dev=None, model_side=None):
             nat.predict_fused(kind, pobs.data, pobs.norm, pts.data, pts.norm, n, pts.dt, spec.outputscale, W, alpha,
                               spec.mean_const, _kxx_const(spec), spec.noise, mean[lo:hi], var[lo:hi],
                               0.0 if eta is None else eta, None if lfi is None else lfi[lo:hi], log,
-                              eta_dev=eta_dev if eta is not None else None)
+                              eta_dev=eta_dev if eta is not None else None, root_tri=root_tri)
             continue
         mean[lo:hi] = posterior_mean(spec, pts)
         KX = torch.empty(n_obs, n, dtype=torch.float64, device=dev)

@@ -35,7 +35,12 @@ __host__ __device__ inline size_t pf_lds_bytes(int n_obs, int dt) {
 
 // DT: the prepared rows' length (padded dimension of the continuous kernels, 64-bit words of a fingerprint) -- static, so
 // that the observation's coordinates stay in registers and the distance loops carry no bounds
-template <int KIND, int DT>
+// ROOT (round 6): W is not formed -- the table passed as `W` is S^T, the transposed root of W = S S^T (SOBER/_gp.py:277: gpytorch's
+// covar_cache, the inverse Cholesky factor's transpose: UPPER triangular, so S^T is lower triangular), the matrix cores form
+// V'' = S^T KX and the quadratic form is |V''|^2 by column.  *tri_flag != 0 says that S^T is lower triangular: row tile T then needs
+// the observations k <= 16 T + 15 only -- 91 of the 169 tile products at n_obs = 200, and the busiest wave carries 28 of them
+// instead of 52.  (The k index of a step's four slices is 8 p + 2 lk + {0, 1} there: consecutive steps walk along k.)
+template <int KIND, int DT, bool ROOT>
 __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict__ obs, const double* __restrict__ obs_norm,
                                                        int n_obs, const double* __restrict__ cand,
                                                        const double* __restrict__ cand_norm, int64_t N, int dt,
@@ -44,7 +49,8 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
                                                        double noise, double* __restrict__ mean_out,
                                                        double* __restrict__ var_out, double eta,
                                                        const double* __restrict__ eta_ptr,
-                                                       double* __restrict__ lfi_out, int log_flag) {
+                                                       double* __restrict__ lfi_out, int log_flag,
+                                                       const int32_t* __restrict__ tri_flag) {
     extern __shared__ __attribute__((aligned(16))) double pf_lds[];
     if (eta_ptr != nullptr) eta = *eta_ptr;                       // (the threshold still in device memory: no host read-back)
     const int n_pad = pf_obs_pad(n_obs), rs = pf_rs(n_obs);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
     // (unconditional loads at clamped addresses; what lies past the table becomes a zero)
 #define PF_LOADA(DST, KP)                                                                          \
     {                                                                                              \
-        const int k0_ = kbase + 2 * (KP);                     /* (even) */                         \
+        const int k0_ = ROOT ? 8 * (KP) + 2 * lk : kbase + 2 * (KP);    /* (even) */               \
         const int kc_ = max(min(k0_, n_obs - 2), 0);          /* the pair [kc, kc + 1] lies inside the row */ \
         const bool odd_ = k0_ == n_obs - 1;                   /* the row's last entry sits in the pair's second half */ \
         _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                         \
@@ -152,16 +158,30 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
 #define PF_STEP2(A_, KP)                                                                           \
     {                                                                                              \
         pf_d2 b_[2];                                                                               \
-        _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) b_[ct] = *(const pf_d2*)(kxt + (size_t)(16 * ct + li) * rs + kbase + 2 * (KP)); \
+        const int kb_ = ROOT ? 8 * (KP) + 2 * lk : kbase + 2 * (KP);                               \
+        _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) b_[ct] = *(const pf_d2*)(kxt + (size_t)(16 * ct + li) * rs + kb_); \
         _Pragma("unroll") for (int h = 0; h < 2; ++h)                                              \
             _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                     \
-                if (wlive[rt]) {                                                                   \
+                if (wlive[rt] && (!ROOT || (KP) < kp_end[rt])) {                                   \
                     _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                               \
                         acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[rt][h], b_[ct][h], acc[rt][ct], 0, 0, 0); \
                 }                                                                                  \
             }                                                                                      \
     }
-    const int n_kp = Kq >> 1;                                     // pairs of steps (even: Kq is a multiple of 4)
+    int n_kp = Kq >> 1;                                           // pairs of steps (even: Kq is a multiple of 4)
+    int kp_end[4] = {0, 0, 0, 0};
+    if constexpr (ROOT) {
+        const int tri = tri_flag != nullptr ? *tri_flag : 0;
+        const int n_kp_all = n_pad >> 3;                          // (n_pad is a multiple of 16)
+        n_kp = 0;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int T = wave + 4 * rt;
+            kp_end[rt] = wlive[rt] ? (tri ? min(n_kp_all, 2 * T + 2) : n_kp_all) : 0;     // k <= 16 T + 15 (the mean's row sits in the last tile)
+            n_kp = max(n_kp, kp_end[rt]);
+        }
+        n_kp = (n_kp + 1) & ~1;                                   // (the loop below takes two pair-steps at a time)
+    }
     double a0[4][2], a1[4][2];
     PF_LOADA(a0, 0)
     for (int kp = 0; kp < n_kp; kp += 2) {
@@ -182,8 +202,13 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
             const int r = 16 * (wave + 4 * rt) + lk + 4 * reg;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-                const double kv = (r < n_obs) ? kxt[(size_t)(16 * ct + li) * rs + min(r, n_pad - 1)] : 0.0;
-                qp[ct] = fma(kv, (r < n_obs) ? acc[rt][ct][reg] : 0.0, qp[ct]);
+                if constexpr (ROOT) {
+                    const double v = (r < n_obs) ? acc[rt][ct][reg] : 0.0;
+                    qp[ct] = fma(v, v, qp[ct]);
+                } else {
+                    const double kv = (r < n_obs) ? kxt[(size_t)(16 * ct + li) * rs + min(r, n_pad - 1)] : 0.0;
+                    qp[ct] = fma(kv, (r < n_obs) ? acc[rt][ct][reg] : 0.0, qp[ct]);
+                }
                 if (r == n_obs && wlive[rt]) s_mean[16 * ct + li] = acc[rt][ct][reg];
             }
         }
@@ -227,11 +252,11 @@ extern "C" int sober_predict_fused_supported(int kind, int n_obs, int dt) {
     return 0;
 }
 
-extern "C" int sober_predict_fused(int kind, const void* obs, const double* obs_norm, int n_obs, const void* cand,
-                                   const double* cand_norm, int64_t N, int dt, double outputscale, const double* W, int ldw,
-                                   const double* alpha, double c0, double kxx_const, double noise, double* mean_out,
-                                   double* var_out, double eta, const double* eta_ptr, double* lfi_out, int log_flag,
-                                   void* stream) {
+static int predict_fused_launch(int kind, const void* obs, const double* obs_norm, int n_obs, const void* cand,
+                                const double* cand_norm, int64_t N, int dt, double outputscale, const double* W, int ldw,
+                                const double* alpha, double c0, double kxx_const, double noise, double* mean_out,
+                                double* var_out, double eta, const double* eta_ptr, double* lfi_out, int log_flag,
+                                bool root, const int32_t* tri_flag, void* stream) {
     if (!obs || !cand || !W || !var_out || N <= 0 || ldw < n_obs) return SOBER_E_ARG;
     if (!sober_predict_fused_supported(kind, n_obs, dt)) return SOBER_E_DIM;
     if (kind == SOBER_KIND_TANIMOTO && (!obs_norm || !cand_norm)) return SOBER_E_ARG;
@@ -242,10 +267,17 @@ extern "C" int sober_predict_fused(int kind, const void* obs, const double* obs_
     // (the dynamic-LDS attribute per instantiation and device: set on every call -- a few hundred ns of host time)
 #define PF_LAUNCH(K, D)                                                                                                        \
     case D: {                                                                                                                  \
-        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_predict_fused<K, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
-        hipLaunchKernelGGL((sober::k_predict_fused<K, D>), grid, dim3(256), bytes, st, (const double*)obs, obs_norm, n_obs,     \
-                           (const double*)cand, cand_norm, N, dt, outputscale, W, ldw, alpha, c0, kxx_const, noise, mean_out,  \
-                           var_out, eta, eta_ptr, lfi_out, log_flag);                                                                   \
+        if (root) {                                                                                                            \
+            HIP_TRY(hipFuncSetAttribute((const void*)sober::k_predict_fused<K, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
+            hipLaunchKernelGGL((sober::k_predict_fused<K, D, true>), grid, dim3(256), bytes, st, (const double*)obs, obs_norm, n_obs, \
+                               (const double*)cand, cand_norm, N, dt, outputscale, W, ldw, alpha, c0, kxx_const, noise, mean_out, \
+                               var_out, eta, eta_ptr, lfi_out, log_flag, tri_flag);                                            \
+        } else {                                                                                                               \
+            HIP_TRY(hipFuncSetAttribute((const void*)sober::k_predict_fused<K, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
+            hipLaunchKernelGGL((sober::k_predict_fused<K, D, false>), grid, dim3(256), bytes, st, (const double*)obs, obs_norm, n_obs, \
+                               (const double*)cand, cand_norm, N, dt, outputscale, W, ldw, alpha, c0, kxx_const, noise, mean_out, \
+                               var_out, eta, eta_ptr, lfi_out, log_flag, (const int32_t*)nullptr);                             \
+        }                                                                                                                      \
         break;                                                                                                                 \
     }
 #define PF_DIMS(K) switch (dt) { PF_LAUNCH(K, 4) PF_LAUNCH(K, 8) PF_LAUNCH(K, 12) PF_LAUNCH(K, 16) PF_LAUNCH(K, 20) PF_LAUNCH(K, 24) \
@@ -263,4 +295,25 @@ extern "C" int sober_predict_fused(int kind, const void* obs, const double* obs_
 #undef PF_LAUNCH
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sober_predict_fused(int kind, const void* obs, const double* obs_norm, int n_obs, const void* cand,
+                                   const double* cand_norm, int64_t N, int dt, double outputscale, const double* W, int ldw,
+                                   const double* alpha, double c0, double kxx_const, double noise, double* mean_out,
+                                   double* var_out, double eta, const double* eta_ptr, double* lfi_out, int log_flag,
+                                   void* stream) {
+    return predict_fused_launch(kind, obs, obs_norm, n_obs, cand, cand_norm, N, dt, outputscale, W, ldw, alpha, c0, kxx_const, noise,
+                                mean_out, var_out, eta, eta_ptr, lfi_out, log_flag, false, nullptr, stream);
+}
+
+// ... with the ROOT of W instead of W: St = S^T (n_obs x n_obs, row stride ldst), W = S S^T; *tri_flag (device, may be NULL = 0)
+// != 0 promises that St is lower triangular (gpytorch's covar_cache of an exact GP): the tile products above the diagonal
+// are then skipped.  Same outputs; var = kxx - |St k|^2 + noise.
+extern "C" int sober_predict_fused_root(int kind, const void* obs, const double* obs_norm, int n_obs, const void* cand,
+                                        const double* cand_norm, int64_t N, int dt, double outputscale, const double* St, int ldst,
+                                        const int32_t* tri_flag, const double* alpha, double c0, double kxx_const, double noise,
+                                        double* mean_out, double* var_out, double eta, const double* eta_ptr, double* lfi_out,
+                                        int log_flag, void* stream) {
+    return predict_fused_launch(kind, obs, obs_norm, n_obs, cand, cand_norm, N, dt, outputscale, St, ldst, alpha, c0, kxx_const,
+                                noise, mean_out, var_out, eta, eta_ptr, lfi_out, log_flag, true, tri_flag, stream);
 }

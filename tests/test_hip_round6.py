@@ -518,3 +518,40 @@ def test_calc_obj_chain_hands_an_irregular_level_to_the_level_by_level_route(dev
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     i, w, _ = res[0]
     assert 0 < len(i) <= b and (w > 0).all() and abs(w.sum() - 1.0) < 1e-9
+
+
+# ------------------------------------------------------------------ GP prediction from the root of W
+@pytest.mark.parametrize("kind,d,n_obs,N", [("rbf", 10, 200, 40000), ("matern52", 6, 130, 5000), ("rbf", 3, 17, 3000), ("tanimoto", 512, 90, 6000),
+                                            ("rbf", 20, 255, 9000)])
+def test_prediction_from_the_root_equals_prediction_from_w(kind, d, n_obs, N, dev, monkeypatch):
+    """predict / PI (SOBER/_gp.py:212-238, SOBER/_pi.py:20-38) with the fused kernel working from S^T -- the triangular root
+    gpytorch caches: the tile products above the diagonal skipped -- against the same kernel working from W = S S^T
+    (SOBER_PREDICT_FROM_W=1, rounds 5-6a), and with a root that is NOT triangular (S Q, Q orthogonal: the same W; the device flag
+    then says so and nothing is skipped): mean / variance 1e-10, pi 1e-9."""
+    from oracle import sober_oracle as O
+    from sober_amd import _pi
+    from tests.golden.synth import build_spec, synth
+    case = dict(kind=kind, mode="predictive_covariance", N=N, M=20, d=d, n_obs=n_obs, b=5, seed=n_obs, ard=False, bit_p=0.08, mean_const=0.2)
+    inp = synth(case)
+    spec = build_spec(case, inp)
+    ks = _kspec(spec).to(dev)
+    X = _t(inp["X_cand"]).to(dev)
+
+    def run(ksp):
+        pi = sober_amd.PI(ksp)
+        m, v = _pi.predict(X, ksp)
+        return m.cpu().numpy(), v.cpu().numpy(), pi(X).cpu().numpy()
+    m1, v1, p1 = run(ks)
+    assert bool((torch.triu(ks.S_cache.t(), 1) == 0).all())     # (the oracle's spec carries the triangular root)
+    monkeypatch.setenv("SOBER_PREDICT_FROM_W", "1")
+    m0, v0, p0 = run(ks)
+    monkeypatch.delenv("SOBER_PREDICT_FROM_W")
+    g = torch.Generator().manual_seed(1)
+    Q, _ = torch.linalg.qr(torch.randn(n_obs, n_obs, dtype=torch.float64, generator=g))
+    ks2 = sober_amd.KernelSpec(ks.kind, ks.lengthscale, ks.outputscale, ks.X_obs, (ks.S_cache @ Q.to(dev)).contiguous(), ks.noise,
+                               ks.mean_const, ks.alpha)
+    m2, v2, p2 = run(ks2)
+    for m, v, p_ in ((m1, v1, p1), (m2, v2, p2)):
+        np.testing.assert_allclose(m, m0, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(v, v0, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(p_, p0, rtol=1e-9, atol=1e-13)
