@@ -135,9 +135,23 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
     typedef double pf_d2 __attribute__((ext_vector_type(2), aligned(8)));
     const double* arow[4];
     bool wlive[4], wzero[4];
+    // which row tile is (wave, rt)'s: wave + 4 rt -- or, with a triangular root (tile T costs T + 1 steps), the live tiles dealt
+    // out from the longest in a snake (wave 0 1 2 3 3 2 1 0 0 ...): 24 / 23 / 22 / 22 steps per wave at 13 tiles instead of
+    // 28 / 18 / 21 / 24
+    const int n_tiles = (n_wrows + 15) >> 4;
+    int tile[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-        const int T = wave + 4 * rt, wr = 16 * T + li;
+        if constexpr (ROOT) {
+            const int slot = 4 * rt + ((rt & 1) ? 3 - wave : wave);
+            tile[rt] = slot < n_tiles ? n_tiles - 1 - slot : 16 + slot;      // (a slot past the live tiles: a tile nobody has)
+        } else {
+            tile[rt] = wave + 4 * rt;
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int T = tile[rt], wr = 16 * T + li;
         wlive[rt] = 16 * T < n_wrows;                             // (wave-uniform)
         wzero[rt] = wr >= n_wrows;                                // rows past [W; alpha^T]: zeros
         arow[rt] = (wr < n_obs) ? W + (size_t)wr * ldw : ((wr == n_obs && alpha != nullptr) ? alpha : W);
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
         n_kp = 0;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            const int T = wave + 4 * rt;
+            const int T = tile[rt];
             kp_end[rt] = wlive[rt] ? (tri ? min(n_kp_all, 2 * T + 2) : n_kp_all) : 0;     // k <= 16 T + 15 (the mean's row sits in the last tile)
             n_kp = max(n_kp, kp_end[rt]);
         }
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int r = 16 * (wave + 4 * rt) + lk + 4 * reg;
+            const int r = 16 * tile[rt] + lk + 4 * reg;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 if constexpr (ROOT) {
