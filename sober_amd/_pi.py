@@ -113,6 +113,8 @@ class PI:
         self._spec = None
         self._eta_dev = None                              # max posterior mean at the observations, ON the device
         self._model_side = None                           # prepared observations, W, alpha of the snapshot in self._spec
+        self._side_key = None                             # what the model side was derived from (a live model: see _prepare)
+        self._eta_set_by_caller = False
 
     def _prepare(self, device):
         """A live model is read again on every call (the reference evaluates `self.model` each time, :20-38); a
@@ -120,10 +122,19 @@ class PI:
         dev = same_device(device)
         live = not isinstance(self.model, KernelSpec)
         if live or self._spec is None or same_device(self._spec.X_obs.device) != dev:
-            self._spec = spec_from_model(self.model).to(dev)
-            self._model_side = _model_side(self._spec)
-            m_obs, _, _ = _predict(self._spec, self._spec.X_obs, model_side=self._model_side)
-            self._eta_dev = m_obs.max().reshape(1)        # current maximum (:17): stays on the device -- no read-back per call
+            spec = spec_from_model(self.model).to(dev)
+            # a live model is READ on every call, but what follows from it -- the prepared observations, the root of W, alpha,
+            # the threshold: three launches, a prediction over the observations and their host side -- is redone only when
+            # what was read has changed: the tensors' identity and version counters (an optimiser step or a new prediction
+            # cache changes either) and the scalars
+            key = (spec.kind, float(spec.outputscale), float(spec.noise), float(spec.mean_const)) + tuple(
+                (t.data_ptr(), t._version, tuple(t.shape), t.dtype) if t is not None else None
+                for t in (spec.X_obs, spec.S_cache, spec.alpha, spec.lengthscale))
+            if self._spec is None or key != self._side_key or self._eta_set_by_caller:
+                self._spec, self._side_key, self._eta_set_by_caller = spec, key, False
+                self._model_side = _model_side(spec)
+                m_obs, _, _ = _predict(spec, spec.X_obs, model_side=self._model_side)
+                self._eta_dev = m_obs.max().reshape(1)    # current maximum (:17): stays on the device -- no read-back per call
         return self._spec
 
     @property
@@ -140,6 +151,7 @@ class PI:
             from . import _settings
             dev = _settings._device
         self._eta_dev = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        self._eta_set_by_caller = not isinstance(self.model, KernelSpec)   # (a live model's next call re-derives it)
 
     def lfi(self, X_cand, log=False):
         spec = self._prepare(X_cand.device)

@@ -555,3 +555,38 @@ def test_prediction_from_the_root_equals_prediction_from_w(kind, d, n_obs, N, de
         np.testing.assert_allclose(m, m0, rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(v, v0, rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(p_, p0, rtol=1e-9, atol=1e-13)
+
+
+def test_pi_on_a_live_model_follows_the_model_and_caches_what_did_not_change(dev):
+    """PI on a LIVE model (anything that is not a KernelSpec snapshot: the reference evaluates `self.model` on every call,
+    SOBER/_pi.py:20-38): the model is read on every call, but the prepared observations, the root of W and the threshold are
+    rebuilt only when what was read has changed (tensor identity / version counters / scalars).  Unchanged model: the same
+    object is reused; alpha changed IN PLACE: the next call follows it (pi equals a fresh PI's); eta assigned by the caller: the
+    next call of a live model re-derives it, as before."""
+    from oracle import sober_oracle as O
+    from tests.golden.synth import build_spec, synth
+    case = dict(kind="rbf", mode="predictive_covariance", N=5000, M=20, d=6, n_obs=60, b=5, seed=5, ard=False, mean_const=0.1)
+    inp = synth(case)
+    ks = _kspec(build_spec(case, inp)).to(dev)
+
+    class Live:                                              # (a duck model: spec_from_model reads .kernel_spec)
+        def __init__(self, spec):
+            self.spec = spec
+
+        def kernel_spec(self):
+            return self.spec
+    X = _t(inp["X_cand"]).to(dev)
+    live = Live(ks)
+    pi = sober_amd.PI(live)
+    p0 = pi(X).clone()
+    side0 = pi._model_side
+    p1 = pi(X)
+    assert pi._model_side is side0 and torch.equal(p0, p1)          # nothing changed: nothing rebuilt
+    ks.alpha.mul_(1.5)                                               # the model moves in place (version counter)
+    p2 = pi(X)
+    assert pi._model_side is not side0
+    assert torch.equal(p2, sober_amd.PI(Live(ks))(X)) and not torch.equal(p2, p0)
+    eta_model = pi.eta
+    pi.eta = eta_model + 1.0
+    p3 = pi(X)                                                       # a live model's call re-derives the threshold
+    assert abs(pi.eta - eta_model) < 1e-15 and torch.equal(p3, p2)
