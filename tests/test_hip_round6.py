@@ -391,7 +391,7 @@ def _car_big_case(N, m, seed, dev, decay=0.0, zero_every=0):
 
 @pytest.mark.parametrize("N,m,decay,zero_every", [(64, 20, 0.0, 0), (13, 12, 0.0, 0), (200, 101, 0.03, 0), (400, 201, 0.0, 7), (500, 251, 0.01, 0),
                                                   (600, 301, 0.0, 0), (1024, 513, 0.005, 0), (1100, 540, 0.0, 5), (700, 120, 0.0, 0),
-                                                  (2048, 1025, 0.002, 0)])
+                                                  (1536, 800, 0.002, 0)])
 def test_car_big_vs_gebrd_restatement(N, m, decay, zero_every, dev):
     """The memory-resident Caratheodory kernels (csrc/car_big.hip: a launch per dependency, any N <= 2048): null-space basis = the
     dgebd2 reflectors' (numpy restatement, itself pinned to LAPACK's SVD on the reference's inputs in tests/test_car_algorithm.py)
@@ -399,7 +399,7 @@ def test_car_big_vs_gebrd_restatement(N, m, decay, zero_every, dev):
     weights (zero masses: alpha = 0 pivots and first-index ties included); the result is a recombination."""
     from tests.test_car_algorithm import pivots
     X, mu, kr, ws, nk, mo, phi, Phi_np, A = _car_big_case(N, m, 3000 + N + m, dev, decay, zero_every)
-    np.testing.assert_allclose(phi, Phi_np, rtol=0, atol=5e-12)
+    np.testing.assert_allclose(phi, Phi_np, rtol=0, atol=5e-12)         # (held at 2048 x 1025 too: 49 s of numpy, not in the suite)
     if N <= 1100:
         Vh = torch.linalg.svd(torch.from_numpy(A))[2].numpy()
         np.testing.assert_allclose(phi, Vh[m:].T, rtol=0, atol=1e-9)
