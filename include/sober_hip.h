@@ -47,7 +47,7 @@ int sober_diag_build(void);
 /* The A/B and test switches of the environment that the LIBRARY reads (SOBER_LEVEL_TWO_LAUNCHES, SOBER_TANI_NO_QUEUE,
  * SOBER_CAR_FORCE_GIVEUP, SOBER_CAR_UNFUSED, SOBER_CAR_EXACT_RATIO, SOBER_LEVEL_NO_CLASSES) are read ONCE, when it is loaded; a
  * process that changes one afterwards (the tests do) calls this to have them read again.  Returns 0.  (The Python host side has
- * switches of its own, read where they act: SOBER_NO_QUEUE at HipOps construction, SOBER_PREDICT_MATERIALISED and
+ * switches of its own, read where they act: SOBER_NO_QUEUE at HipOps construction, SOBER_PREDICT_MATERIALISED, SOBER_PREDICT_FROM_W and
  * SOBER_NYSTROM_DEBUG per call, SOBER_HIP_LIB / SOBER_ALLOW_DIAG_LIB at load -- INTEGRATION.md lists them.)           */
 int sober_reload_switches(void);
 /* sizeof(sober_level_job) / sizeof(sober_nystrom_job) as the library was built: a binding that lays the structs out itself
