@@ -502,7 +502,7 @@ int sober_kmeans_lloyd(const double* X, int64_t N, int d, int K, int iters,
  * sober_pack_bits words + popcounts for Tanimoto); W: n_obs x n_obs, SYMMETRIC (S S^T of SOBER/_gp.py:277), ld ldw;
  * kxx_const: k(x, x) of the continuous kernels (Tanimoto takes it from the popcounts); mean_out may be NULL; eta_ptr != NULL:
  * the threshold is read from device memory (a max another kernel left there) instead of the argument.
- * sober_predict_fused_supported: n_obs <= 255 and a register-tiled point dimension; otherwise SOBER_E_DIM and the
+ * sober_predict_fused_supported: n_obs <= 511 (255 until round 6; eight row tiles per wave beyond) and a register-tiled point dimension; otherwise SOBER_E_DIM and the
  * caller keeps the materialised route (sober_pairwise + sober_dgemm + sober_predict_finish).                          */
 int sober_predict_fused_supported(int kind, int n_obs, int dt);
 int sober_predict_fused(int kind, const void* obs, const double* obs_norm, int n_obs, const void* cand,

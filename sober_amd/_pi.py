@@ -5,11 +5,11 @@
     var(x)  = k(x, x) - k(x, X_obs) W k(X_obs, x) + noise          (exact GP; LOVE is upstream-only)
     pi(x)   = Phi((mean(x) - eta) / sqrt(var(x))),   eta = max_i mean(X_obs_i)
 
-One launch per chunk of the pool (`sober_predict_fused`, csrc/predict.hip; n_obs <= 256): the K(X_obs, x) columns of 32
+One launch per chunk of the pool (`sober_predict_fused`, csrc/predict.hip; n_obs <= 511): the K(X_obs, x) columns of 32
 candidates are evaluated once into LDS, W k runs on the FP64 matrix cores, mean / variance / pi leave the kernel --
 nothing of size n_obs x N is ever in memory.  With a square root S of W = S S^T (SOBER/_gp.py:277) the kernel works from S^T
 itself -- var = k(x, x) - |S^T k|^2 + noise -- and skips the tile products above the diagonal when S^T is lower triangular (the
-inverse Cholesky factor gpytorch caches: round 6).  Beyond 256 observations (or an input dimension outside the register-tiled
+inverse Cholesky factor gpytorch caches: round 6).  Beyond 511 observations (or an input dimension outside the register-tiled
 set) the materialised route of round 4 stays: KX = k(X_obs, chunk) by `sober_pairwise`, V = W KX (`sober_dgemm`), the
 column-wise quadratic form and Phi in `sober_predict_finish`.
 """

@@ -22,7 +22,7 @@ namespace sober {
 #include "kern_exp.inc"
 
 constexpr int PF_NB = 32;                 // candidates per workgroup
-constexpr int PF_MAX_OBS = 255;           // n_obs + 1 rows of [W; alpha^T] in sixteen row tiles over four waves
+constexpr int PF_MAX_OBS = 511;           // n_obs + 1 rows of [W; alpha^T] in 4 NRT row tiles over four waves (NRT = 4: n_obs <= 255, 8: <= 511)
 typedef double pf_d4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline int pf_obs_pad(int n_obs) { return (n_obs + 15) / 16 * 16; }
@@ -40,7 +40,7 @@ __host__ __device__ inline size_t pf_lds_bytes(int n_obs, int dt) {
 // V'' = S^T KX and the quadratic form is |V''|^2 by column.  *tri_flag != 0 says that S^T is lower triangular: row tile T then needs
 // the observations k <= 16 T + 15 only -- 91 of the 169 tile products at n_obs = 200, and the busiest wave carries 28 of them
 // instead of 52.  (The k index of a step's four slices is 8 p + 2 lk + {0, 1} there: consecutive steps walk along k.)
-template <int KIND, int DT, bool ROOT>
+template <int KIND, int DT, bool ROOT, int NRT>
 __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict__ obs, const double* __restrict__ obs_norm,
                                                        int n_obs, const double* __restrict__ cand,
                                                        const double* __restrict__ cand_norm, int64_t N, int dt,
@@ -73,15 +73,14 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
     }
     if (tid < PF_NB) { s_yn[tid] = (KIND == SOBER_KIND_TANIMOTO) ? cand_norm[min(c_base + tid, N - 1)] : 0.0; s_mean[tid] = 0.0; }
     if (tid < EXP_TAB) s_T[tid] = exp_tab_entry(tid);
-    {
-        const int r = tid;
+    __syncthreads();
+    for (int r = tid; r < rs; r += 256) {                         // (one trip up to 255 observations, at most three at 511)
         const bool live = r < n_obs;
         double x[DT];
 #pragma unroll
         for (int q = 0; q < DT; ++q) x[q] = obs[(size_t)min(r, n_obs - 1) * DT + q];
         const double nx = (KIND == SOBER_KIND_TANIMOTO) ? obs_norm[min(r, n_obs - 1)] : 0.0;
-        __syncthreads();
-        if (r < rs) {
+        {
             for (int c4 = 0; c4 < PF_NB; c4 += 4) {
                 double k[4];
                 if constexpr (KIND == SOBER_KIND_TANIMOTO) {
@@ -121,9 +120,9 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
     //      tiles ct = 0, 1.  Row n_obs of the product is alpha^T KX = mean - c0.  The A fragments (W^T = W: lane (li, lk)
     //      takes W[k = 4 ks + lk][16 T + li], 128 contiguous bytes per 16 lanes) come straight from L2 -- W is 320 KB and
     //      every workgroup reads it -- three k-steps ahead of their matrix instructions; the B fragments from LDS.
-    pf_d4 acc[4][2];
+    pf_d4 acc[NRT][2];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (pf_d4){0.0, 0.0, 0.0, 0.0};
     // The k index of a matrix instruction's four slices is ANY four values (the sum is order-free as long as A and B agree):
@@ -133,24 +132,24 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
     const int Kq = n_pad >> 2;                                    // (a multiple of 4)
     const int n_wrows = n_obs + (alpha != nullptr ? 1 : 0);
     typedef double pf_d2 __attribute__((ext_vector_type(2), aligned(8)));
-    const double* arow[4];
-    bool wlive[4], wzero[4];
+    const double* arow[NRT];
+    bool wlive[NRT], wzero[NRT];
     // which row tile is (wave, rt)'s: wave + 4 rt -- or, with a triangular root (tile T costs T + 1 steps), the live tiles dealt
     // out from the longest in a snake (wave 0 1 2 3 3 2 1 0 0 ...): 24 / 23 / 22 / 22 steps per wave at 13 tiles instead of
     // 28 / 18 / 21 / 24
     const int n_tiles = (n_wrows + 15) >> 4;
-    int tile[4];
+    int tile[NRT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < NRT; ++rt) {
         if constexpr (ROOT) {
             const int slot = 4 * rt + ((rt & 1) ? 3 - wave : wave);
-            tile[rt] = slot < n_tiles ? n_tiles - 1 - slot : 16 + slot;      // (a slot past the live tiles: a tile nobody has)
+            tile[rt] = slot < n_tiles ? n_tiles - 1 - slot : 4 * NRT + slot; // (a slot past the live tiles: a tile nobody has)
         } else {
             tile[rt] = wave + 4 * rt;
         }
     }
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < NRT; ++rt) {
         const int T = tile[rt], wr = 16 * T + li;
         wlive[rt] = 16 * T < n_wrows;                             // (wave-uniform)
         wzero[rt] = wr >= n_wrows;                                // rows past [W; alpha^T]: zeros
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
         const int k0_ = ROOT ? 8 * (KP) + 2 * lk : kbase + 2 * (KP);    /* (even) */               \
         const int kc_ = max(min(k0_, n_obs - 2), 0);          /* the pair [kc, kc + 1] lies inside the row */ \
         const bool odd_ = k0_ == n_obs - 1;                   /* the row's last entry sits in the pair's second half */ \
-        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                         \
+        _Pragma("unroll") for (int rt = 0; rt < NRT; ++rt) {                                       \
             const pf_d2 v_ = *(const pf_d2*)(arow[rt] + kc_);                                      \
             DST[rt][0] = (wzero[rt] || k0_ >= n_obs) ? 0.0 : (odd_ ? v_[1] : v_[0]);               \
             DST[rt][1] = (wzero[rt] || k0_ + 1 >= n_obs) ? 0.0 : v_[1];                            \
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
         const int kb_ = ROOT ? 8 * (KP) + 2 * lk : kbase + 2 * (KP);                               \
         _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) b_[ct] = *(const pf_d2*)(kxt + (size_t)(16 * ct + li) * rs + kb_); \
         _Pragma("unroll") for (int h = 0; h < 2; ++h)                                              \
-            _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                     \
+            _Pragma("unroll") for (int rt = 0; rt < NRT; ++rt) {                                   \
                 if (wlive[rt] && (!ROOT || (KP) < kp_end[rt])) {                                   \
                     _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                               \
                         acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[rt][h], b_[ct][h], acc[rt][ct], 0, 0, 0); \
@@ -183,20 +182,22 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
             }                                                                                      \
     }
     int n_kp = Kq >> 1;                                           // pairs of steps (even: Kq is a multiple of 4)
-    int kp_end[4] = {0, 0, 0, 0};
+    int kp_end[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) kp_end[rt] = 0;
     if constexpr (ROOT) {
         const int tri = tri_flag != nullptr ? *tri_flag : 0;
         const int n_kp_all = n_pad >> 3;                          // (n_pad is a multiple of 16)
         n_kp = 0;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < NRT; ++rt) {
             const int T = tile[rt];
             kp_end[rt] = wlive[rt] ? (tri ? min(n_kp_all, 2 * T + 2) : n_kp_all) : 0;     // k <= 16 T + 15 (the mean's row sits in the last tile)
             n_kp = max(n_kp, kp_end[rt]);
         }
         n_kp = (n_kp + 1) & ~1;                                   // (the loop below takes two pair-steps at a time)
     }
-    double a0[4][2], a1[4][2];
+    double a0[NRT][2], a1[NRT][2];
     PF_LOADA(a0, 0)
     for (int kp = 0; kp < n_kp; kp += 2) {
         PF_LOADA(a1, min(kp + 1, n_kp - 1))
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void k_predict_fused(const double* __restrict_
     //      row n_obs is the mean's sum (KX is zero there: it drops out of q by itself)
     double qp[2] = {0.0, 0.0};
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int r = 16 * tile[rt] + lk + 4 * reg;
@@ -272,6 +273,7 @@ static int predict_fused_launch(int kind, const void* obs, const double* obs_nor
                                 double* var_out, double eta, const double* eta_ptr, double* lfi_out, int log_flag,
                                 bool root, const int32_t* tri_flag, void* stream) {
     if (!obs || !cand || !W || !var_out || N <= 0 || ldw < n_obs) return SOBER_E_ARG;
+    if (!root) tri_flag = nullptr;
     if (!sober_predict_fused_supported(kind, n_obs, dt)) return SOBER_E_DIM;
     if (kind == SOBER_KIND_TANIMOTO && (!obs_norm || !cand_norm)) return SOBER_E_ARG;
     const size_t bytes = sober::pf_lds_bytes(n_obs, dt);
@@ -279,18 +281,21 @@ static int predict_fused_launch(int kind, const void* obs, const double* obs_nor
     const dim3 grid((unsigned)((N + sober::PF_NB - 1) / sober::PF_NB));
     hipStream_t st = (hipStream_t)stream;
     // (the dynamic-LDS attribute per instantiation and device: set on every call -- a few hundred ns of host time)
+#define PF_ONE(K, D, R, NRT_)                                                                                                  \
+    {                                                                                                                          \
+        HIP_TRY(hipFuncSetAttribute((const void*)sober::k_predict_fused<K, D, R, NRT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
+        hipLaunchKernelGGL((sober::k_predict_fused<K, D, R, NRT_>), grid, dim3(256), bytes, st, (const double*)obs, obs_norm, n_obs, \
+                           (const double*)cand, cand_norm, N, dt, outputscale, W, ldw, alpha, c0, kxx_const, noise, mean_out,  \
+                           var_out, eta, eta_ptr, lfi_out, log_flag, tri_flag);                                                \
+    }
+    // (eight row tiles per wave beyond 255 observations, four up to there: the accumulators of the tiles a wave does not have
+    //  would cost it registers for nothing)
 #define PF_LAUNCH(K, D)                                                                                                        \
     case D: {                                                                                                                  \
         if (root) {                                                                                                            \
-            HIP_TRY(hipFuncSetAttribute((const void*)sober::k_predict_fused<K, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
-            hipLaunchKernelGGL((sober::k_predict_fused<K, D, true>), grid, dim3(256), bytes, st, (const double*)obs, obs_norm, n_obs, \
-                               (const double*)cand, cand_norm, N, dt, outputscale, W, ldw, alpha, c0, kxx_const, noise, mean_out, \
-                               var_out, eta, eta_ptr, lfi_out, log_flag, tri_flag);                                            \
+            if (n_obs <= 255) PF_ONE(K, D, true, 4) else PF_ONE(K, D, true, 8)                                                 \
         } else {                                                                                                               \
-            HIP_TRY(hipFuncSetAttribute((const void*)sober::k_predict_fused<K, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
-            hipLaunchKernelGGL((sober::k_predict_fused<K, D, false>), grid, dim3(256), bytes, st, (const double*)obs, obs_norm, n_obs, \
-                               (const double*)cand, cand_norm, N, dt, outputscale, W, ldw, alpha, c0, kxx_const, noise, mean_out, \
-                               var_out, eta, eta_ptr, lfi_out, log_flag, (const int32_t*)nullptr);                             \
+            if (n_obs <= 255) PF_ONE(K, D, false, 4) else PF_ONE(K, D, false, 8)                                               \
         }                                                                                                                      \
         break;                                                                                                                 \
     }
@@ -307,6 +312,7 @@ static int predict_fused_launch(int kind, const void* obs, const double* obs_nor
     }
 #undef PF_DIMS
 #undef PF_LAUNCH
+#undef PF_ONE
     LAUNCH_CHECK();
     return 0;
 }

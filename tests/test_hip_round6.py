@@ -522,12 +522,13 @@ def test_calc_obj_chain_hands_an_irregular_level_to_the_level_by_level_route(dev
 
 # ------------------------------------------------------------------ GP prediction from the root of W
 @pytest.mark.parametrize("kind,d,n_obs,N", [("rbf", 10, 200, 40000), ("matern52", 6, 130, 5000), ("rbf", 3, 17, 3000), ("tanimoto", 512, 90, 6000),
-                                            ("rbf", 20, 255, 9000)])
+                                            ("rbf", 20, 255, 9000), ("matern52", 8, 300, 7000), ("rbf", 10, 511, 6000), ("tanimoto", 1024, 400, 3000)])
 def test_prediction_from_the_root_equals_prediction_from_w(kind, d, n_obs, N, dev, monkeypatch):
     """predict / PI (SOBER/_gp.py:212-238, SOBER/_pi.py:20-38) with the fused kernel working from S^T -- the triangular root
     gpytorch caches: the tile products above the diagonal skipped -- against the same kernel working from W = S S^T
     (SOBER_PREDICT_FROM_W=1, rounds 5-6a), and with a root that is NOT triangular (S Q, Q orthogonal: the same W; the device flag
-    then says so and nothing is skipped): mean / variance 1e-10, pi 1e-9."""
+    then says so and nothing is skipped): mean / variance 1e-10, pi 1e-9.  Beyond 255 observations (up to 511: eight row tiles per
+    wave, round 6 -- the materialised route before) also against that materialised route (SOBER_PREDICT_MATERIALISED=1)."""
     from oracle import sober_oracle as O
     from sober_amd import _pi
     from tests.golden.synth import build_spec, synth
@@ -551,6 +552,13 @@ def test_prediction_from_the_root_equals_prediction_from_w(kind, d, n_obs, N, de
     ks2 = sober_amd.KernelSpec(ks.kind, ks.lengthscale, ks.outputscale, ks.X_obs, (ks.S_cache @ Q.to(dev)).contiguous(), ks.noise,
                                ks.mean_const, ks.alpha)
     m2, v2, p2 = run(ks2)
+    if n_obs > 255:
+        monkeypatch.setenv("SOBER_PREDICT_MATERIALISED", "1")
+        m3, v3, p3 = run(ks)
+        monkeypatch.delenv("SOBER_PREDICT_MATERIALISED")
+        np.testing.assert_allclose(m1, m3, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(v1, v3, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(p1, p3, rtol=1e-8, atol=1e-13)
     for m, v, p_ in ((m1, v1, p1), (m2, v2, p2)):
         np.testing.assert_allclose(m, m0, rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(v, v0, rtol=1e-10, atol=1e-12)
