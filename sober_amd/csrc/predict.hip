@@ -13,8 +13,9 @@
 //      three k-steps ahead, the KX fragments from LDS -- no barrier inside (a first form streamed W through LDS panels
 //      with a barrier each: 0.76 ms per call, the L2 round trip of every panel exposed behind 16 matrix instructions);
 //   3. var = kxx - sum_r KX[r][c] V[r][c] + noise straight from the accumulators, pi(x) with the reference's erfc form.
-// Bound: the FP64 matrix cores (2 n_obs^2 flop per candidate: 8 GFLOP at 200 x 100k).  n_obs <= 255 (sixteen row tiles over
-// four waves, the mean's row included: n_obs <= 255); beyond that the caller keeps the materialised route.
+// Bound: the FP64 matrix cores (2 n_obs^2 flop per candidate: 8 GFLOP at 200 x 100k; half of it from a triangular root, below).
+// n_obs <= 511 (the mean's row included: sixteen row tiles over four waves up to 255 observations, thirty-two -- NRT = 8 -- up
+// to 511; the KX tile then takes up to 132 KB of LDS); beyond that the caller keeps the materialised route.
 #include "common.hpp"
 
 namespace sober {
