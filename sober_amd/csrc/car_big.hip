@@ -54,6 +54,30 @@ __device__ __forceinline__ double wsum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// the same total in every lane without a trip through the LDS crossbar per stage (DPP row rotations, then the gfx950 lane
+// swaps: csrc/car_mc.hip's reduction) -- for the one place where the reduction IS the step: k_big_phi
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wsum_dpp(double v) {
+    v += dpp_mov<0x128>(v);                                   // row_ror 8, 4, 2, 1: every lane of a 16-lane row holds the row's sum
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x122>(v);
+    v += dpp_mov<0x121>(v);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(v);
+    hi = __double2hiint(v);
+    auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
 
 // dlarfg on (alpha, |x|^2): beta, tau and the scale of x (tau = 0, scale = 0: H = I)
 __device__ __forceinline__ void larfg(double alpha, double ss, double& tau, double& scale) {
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(256) void k_big_phi(const double* __restrict__ Vg, 
                     vv[k] = 0.0;
                     if (k >= k0 && 64 * k < ld) { vv[k] = v[64 * k]; acc = fma(vv[k], p[k], acc); }
                 }
-                const double ty = s_tau[buf][i - lo] * wsum(acc);
+                const double ty = s_tau[buf][i - lo] * wsum_dpp(acc);
 #pragma unroll
                 for (int k = 0; k < NQ; ++k)
                     if (k >= k0) p[k] = fma(-ty, vv[k], p[k]);
