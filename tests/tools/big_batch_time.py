@@ -1,8 +1,8 @@
 """Whole recombination steps at batches beyond the register-resident Caratheodory kernels (csrc/car_big.hip), device step vs the
-host route of rounds 1-5 (force_host_car):  python scripts/big_batch_time.py"""
+host route of rounds 1-5 (force_host_car):  python tests/tools/big_batch_time.py"""
 import os, sys, time, warnings
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sober_amd
 from oracle import sober_oracle as O
 from tests.golden.synth import SEED_CALL, build_spec, synth

@@ -1,7 +1,7 @@
-"""The Nystrom phase at N_nys beyond 1024 (device route up to 2048 since round 6) against the host route:  python scripts/big_nys_time.py"""
+"""The Nystrom phase at N_nys beyond 1024 (device route up to 2048 since round 6) against the host route:  python tests/tools/big_nys_time.py"""
 import os, sys, time, warnings
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sober_amd
 from oracle import sober_oracle as O
 from sober_amd._ops_hip import HipOps

@@ -1,8 +1,8 @@
 """recombination(..., calc_obj=...) at cfg-2's shapes: the queued chain of the level executor against the level-by-level route, and
-the plain step beside them, alternating in one process:  python scripts/calc_obj_ab.py"""
+the plain step beside them, alternating in one process:  python tests/tools/calc_obj_ab.py"""
 import os, sys, time, warnings, statistics
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sober_amd
 from oracle import sober_oracle as O
 from sober_amd._ops_hip import HipOps

@@ -1,8 +1,8 @@
 """GP prediction / pi over 100k candidates at several numbers of observations: the fused launch (from the triangular root of W) against
-the materialised route:  python scripts/predict_time.py"""
+the materialised route:  python tests/tools/predict_time.py"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sober_amd
 from oracle import sober_oracle as O
 from tests.golden.synth import build_spec, synth
