@@ -485,7 +485,9 @@ __global__ __launch_bounds__(CW_THREADS) void k_clean_partial(double* __restrict
     if (threadIdx.x == 0) part[blockIdx.x] = s[0];
 }
 
-__global__ __launch_bounds__(CW_BLOCKS) void k_clean_total(double* __restrict__ part) {
+// (every workgroup forms the total from the 256 partial sums itself, by the tree the single-workgroup launch of rounds 1-6 used -- the same bits --: the launch
+//  that did only that is gone)
+__global__ __launch_bounds__(CW_BLOCKS) void k_clean_scale(double* __restrict__ w, int64_t n, const double* __restrict__ part) {
     __shared__ double s[CW_BLOCKS];
     s[threadIdx.x] = part[threadIdx.x];
     __syncthreads();
@@ -493,13 +495,9 @@ __global__ __launch_bounds__(CW_BLOCKS) void k_clean_total(double* __restrict__ 
         if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) part[CW_BLOCKS] = s[0];
-}
-
-__global__ void k_clean_scale(double* __restrict__ w, int64_t n, const double* __restrict__ part) {
+    const double tot = s[0];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double tot = part[CW_BLOCKS];
     w[i] = (tot != 0.0) ? w[i] / tot : 1.0 / (double)n;     // :34-37
 }
 
@@ -966,9 +964,7 @@ extern "C" int sober_cleansing_weights(double* w, int64_t n, double eps, void* w
     double* part = (double*)ws;
     hipLaunchKernelGGL(k_clean_partial, dim3(CW_BLOCKS), dim3(CW_THREADS), 0, st, w, n, eps, part);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_clean_total, dim3(1), dim3(CW_BLOCKS), 0, st, part);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_clean_scale, dim3(nblk(n, 256)), dim3(256), 0, st, w, n, part);
+    hipLaunchKernelGGL(k_clean_scale, dim3(nblk(n, CW_BLOCKS)), dim3(CW_BLOCKS), 0, st, w, n, part);
     LAUNCH_CHECK();
     return 0;
 }
