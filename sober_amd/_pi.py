@@ -126,7 +126,10 @@ class PI:
             # a live model is READ on every call, but what follows from it -- the prepared observations, the root of W, alpha,
             # the threshold: three launches, a prediction over the observations and their host side -- is redone only when
             # what was read has changed: the tensors' identity and version counters (an optimiser step or a new prediction
-            # cache changes either) and the scalars
+            # cache changes either) and the scalars.  (Sound because self._spec keeps the tensors it was derived from ALIVE: no
+            # new tensor can come back at one of their addresses unless it shares their storage -- and then the version counter
+            # tells.  A model whose attributes are recomputed on every access, like gpytorch's constrained lengthscale, simply
+            # never hits the cache.)
             key = (spec.kind, float(spec.outputscale), float(spec.noise), float(spec.mean_const)) + tuple(
                 (t.data_ptr(), t._version, tuple(t.shape), t.dtype) if t is not None else None
                 for t in (spec.X_obs, spec.S_cache, spec.alpha, spec.lengthscale))
