@@ -171,7 +171,8 @@ extern "C" int sober_level_car(const sober_level_job* j, void* stream) {
 
 // A level whose Caratheodory step came back with n_keep = -1 (its launches gave up waiting for partner workgroups):
 // the barycentres and masses are still in place, so the step alone is redone with the launches that depend on nobody
-// (SOBER_CAR_SAFE, one-CU sizes) and the job stays in that mode.  -> 0 with a fresh verdict in h_flags, or
+// (SOBER_CAR_SAFE: the single-workgroup kernels at the one-CU sizes, csrc/car_big.hip's launch per dependency beyond) and the
+// job stays in that mode.  -> 0 with a fresh verdict in h_flags, or
 // SOBER_E_EXCHANGE when that mode does not cover the size (the caller's host route is next).
 extern "C" int sober_level_car_retry(sober_level_job* j, void* stream) {
     if (!j || !j->X_tmp || !j->tot || !j->keep_rank || !j->w_star || !j->mu_out || !j->car_ws || !j->h_flags) return SOBER_E_ARG;
